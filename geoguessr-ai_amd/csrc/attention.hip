@@ -1,0 +1,430 @@
+// Window attention (TinyViT Attention / CLIP MHSA) forward and backward on MFMA (gfx950).
+//
+// One 256-thread workgroup per (window, head).  A window has N <= 256 tokens (49 / 196 for TinyViT @224,
+// 50 for CLIP ViT-B/32), so a full score row lives in one wave's registers and softmax needs no online
+// rescaling.  Scores are computed "swapped" (S^T = K Q^T) with v_mfma_f32_16x16x32_bf16 so that a lane owns one
+// query column and its keys sit in registers: row max / sum are register reductions + two shuffles, and the
+// exponentiated tile is directly the B operand of the P.V product (no LDS round trip; the MFMA k index is
+// permuted identically on both operands).  Only operands that must be read "k-major" (V^T forward; K^T, Q^T,
+// dO^T backward) are staged transposed in LDS.
+//
+// Layout: qkv is a row-major [tokens, ld] bf16 matrix; head h has q at column q_off + h*head_stride, k at
+// k_off + h*head_stride, v at v_off + h*head_stride (TinyViT: per-head interleaved 3*D blocks -> offsets
+// 0/D/2D, stride 3D; CLIP: [q|k|v] blocks of width nh*D -> offsets 0/C/2C, stride D).
+#include "common.h"
+#include "../../include/gg.h"
+
+struct AttnParams {
+    const bf16* qkv; int64_t ld;
+    int q_off, k_off, v_off, head_stride;
+    bf16* out; int64_t ldo;           // forward output [tokens, ldo], head h at column h*D
+    const float* bias; int nbias;     // [nh][nbias] relative-position table or null; idx = |di|*ws + |dj|
+    int ws, nWx, nWy, H, W;           // ws > 0: windows of ws x ws tokens inside an H x W map; ws == 0: linear
+    int N;                            // tokens per window
+    int nh;
+    float scale;
+    // backward
+    const bf16* dout; int64_t lddo;   // [tokens, lddo]
+    bf16* dqkv;                       // same layout as qkv
+    float* dbias;                     // [nh][nbias] accumulated with atomics, or null
+};
+
+__device__ __forceinline__ int attn_token(const AttnParams& p, int w, int t) {
+    if (t >= p.N) return -1;
+    if (p.ws == 0) return w * p.N + t;
+    const int per_img = p.nWx * p.nWy;
+    const int b = w / per_img, r = w % per_img;
+    const int wy = r / p.nWx, wx = r % p.nWx;
+    const int i = t / p.ws, j = t % p.ws;
+    return (b * p.H + wy * p.ws + i) * p.W + wx * p.ws + j;
+}
+// 8 consecutive bf16 of row `tok` at column `col` (zeros for padded rows)
+__device__ __forceinline__ bf16x8 attn_row_frag(const bf16* base, int64_t ld, int tok, int col) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tok >= 0) v = *reinterpret_cast<const bf16x8*>(base + (int64_t)tok * ld + col);
+    return v;
+}
+// 4+4 bf16 of a transposed LDS image T[d][key]: keys k0..k0+3 and k0+16..k0+19
+__device__ __forceinline__ bf16x8 attn_tr_frag(const bf16* T, int stride, int d, int k0) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(T + d * stride + k0);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(T + d * stride + k0 + 16);
+    bf16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return v;
+}
+__device__ __forceinline__ bf16x8 attn_pack(const f32x4& a, const f32x4& b) {
+    bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+    return v;
+}
+// transposed staging of a [N, D] column block of `src` into T[D][stride] (zero for padded keys)
+template <int D>
+__device__ __forceinline__ void attn_stage_transposed(bf16* T, int stride, const bf16* src, int64_t ld, int col, const int* tok,
+                                                      int Np) {
+    constexpr int CH = D / 8;
+    for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {
+        const int key = idx / CH, dc = idx % CH;
+        const bf16x8 v = attn_row_frag(src, ld, tok[key], col + dc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T[(dc * 8 + j) * stride + key] = v[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------- forward
+template <int D, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    constexpr int Np = NKT * 16;
+    constexpr int VS = Np + 8;
+    constexpr int KS = D / 32;    // MFMA k-steps over the head dim
+    constexpr int DT = D / 16;    // output d tiles
+    __shared__ __attribute__((aligned(16))) bf16 Vt[D * VS];
+    __shared__ int tok[Np];
+    __shared__ float bias_s[256];
+    __shared__ unsigned char ci[Np], cj[Np];
+
+    const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    for (int t = threadIdx.x; t < Np; t += blockDim.x) {
+        tok[t] = attn_token(p, w, t);
+        const int tt = min(t, p.N - 1);
+        ci[t] = p.ws ? (unsigned char)(tt / p.ws) : 0;
+        cj[t] = p.ws ? (unsigned char)(tt % p.ws) : 0;
+    }
+    if (p.bias) for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) bias_s[t] = p.bias[h * p.nbias + t];
+    __syncthreads();
+    attn_stage_transposed<D>(Vt, VS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok, Np);
+    __syncthreads();
+
+    const int nqt = (p.N + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int qi = qt * 16 + lr;
+        const int qtok = tok[qi];
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
+        const int qci = ci[qi], qcj = cj[qi];
+
+        f32x4 s[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const int ktok = tok[kt * 16 + lr];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = attn_row_frag(p.qkv, p.ld, ktok, p.k_off + h * p.head_stride + ks * 32 + lg * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);   // D[i=key][j=query]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + lg * 4 + r;
+                float v = acc[r] * p.scale;
+                if (p.bias) v += bias_s[abs(qci - (int)ci[key]) * p.ws + abs(qcj - (int)cj[key])];
+                v = key < p.N ? v : -INFINITY;
+                acc[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            s[kt] = acc;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+
+        f32x4 o[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+            const bf16x8 pf = attn_pack(s[2 * kp], s[2 * kp + 1]);   // k = key 32kp + 16(jj>>2) + 4lg + (jj&3)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 vf = attn_tr_frag(Vt, VS, dt * 16 + lr, kp * 32 + lg * 4);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);   // D[i=d][j=query]
+            }
+        }
+        if (qtok >= 0) {
+            const float inv = 1.f / l;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+                *reinterpret_cast<bf16x4*>(p.out + (int64_t)qtok * p.ldo + h * D + dt * 16 + lg * 4) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward
+template <int D, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
+    constexpr int Np = NKT * 16;
+    constexpr int TS = Np + 8;
+    constexpr int KS = D / 32;
+    constexpr int DT = D / 16;
+    __shared__ __attribute__((aligned(16))) bf16 Qt[D * TS];
+    __shared__ __attribute__((aligned(16))) bf16 Kt[D * TS];
+    __shared__ __attribute__((aligned(16))) bf16 dOt[D * TS];
+    __shared__ __attribute__((aligned(16))) float row_m[Np], row_linv[Np], row_delta[Np];
+    __shared__ int tok[Np];
+    __shared__ float bias_s[256], dbias_s[256];
+    __shared__ unsigned char ci[Np], cj[Np];
+
+    const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int qcol = p.q_off + h * p.head_stride, kcol = p.k_off + h * p.head_stride, vcol = p.v_off + h * p.head_stride;
+    const int ocol = h * D;
+
+    for (int t = threadIdx.x; t < Np; t += blockDim.x) {
+        tok[t] = attn_token(p, w, t);
+        const int tt = min(t, p.N - 1);
+        ci[t] = p.ws ? (unsigned char)(tt / p.ws) : 0;
+        cj[t] = p.ws ? (unsigned char)(tt % p.ws) : 0;
+    }
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
+        bias_s[t] = (p.bias && t < p.nbias) ? p.bias[h * p.nbias + t] : 0.f;
+        dbias_s[t] = 0.f;
+    }
+    __syncthreads();
+    attn_stage_transposed<D>(Qt, TS, p.qkv, p.ld, qcol, tok, Np);
+    attn_stage_transposed<D>(Kt, TS, p.qkv, p.ld, kcol, tok, Np);
+    attn_stage_transposed<D>(dOt, TS, p.dout, p.lddo, ocol, tok, Np);
+    __syncthreads();
+
+    const int nt = (p.N + 15) / 16;
+    // ---- phase 1: a wave owns a query tile; row statistics, delta, dQ, dbias ----
+    for (int qt = wave; qt < nt; qt += 4) {
+        const int qi = qt * 16 + lr;
+        const int qtok = tok[qi];
+        bf16x8 qf[KS], dof[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, qcol + ks * 32 + lg * 8);
+            dof[ks] = attn_row_frag(p.dout, p.lddo, qtok, ocol + ks * 32 + lg * 8);
+        }
+        const int qci = ci[qi], qcj = cj[qi];
+        f32x4 s[NKT], dp[NKT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+            const int ktok = tok[kt * 16 + lr];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = attn_row_frag(p.qkv, p.ld, ktok, kcol + ks * 32 + lg * 8);
+                const bf16x8 vf = attn_row_frag(p.qkv, p.ld, ktok, vcol + ks * 32 + lg * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);      // S^T  [key][query]
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc2, 0, 0, 0);   // dP^T [key][query]
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + lg * 4 + r;
+                float v = acc[r] * p.scale;
+                if (p.bias) v += bias_s[abs(qci - (int)ci[key]) * p.ws + abs(qcj - (int)cj[key])];
+                v = key < p.N ? v : -INFINITY;
+                acc[r] = v;
+                mx = fmaxf(mx, v);
+            }
+            s[kt] = acc;
+            dp[kt] = acc2;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[kt][r] - mx);
+                s[kt][r] = e;
+                l += e;
+            }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float linv = 1.f / l;
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[kt][r] *= linv;                 // P
+                delta += s[kt][r] * dp[kt][r];
+            }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+        if (lg == 0) { row_m[qi] = mx; row_linv[qi] = linv; row_delta[qi] = delta; }
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ds = s[kt][r] * (dp[kt][r] - delta);
+                dp[kt][r] = ds;                   // dS^T
+                if (p.dbias && qtok >= 0) {
+                    const int key = kt * 16 + lg * 4 + r;
+                    if (key < p.N) atomicAdd(&dbias_s[abs(qci - (int)ci[key]) * p.ws + abs(qcj - (int)cj[key])], ds);
+                }
+            }
+        f32x4 dq[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kp = 0; kp < NKT / 2; ++kp) {
+            const bf16x8 df = attn_pack(dp[2 * kp], dp[2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 kf = attn_tr_frag(Kt, TS, dt * 16 + lr, kp * 32 + lg * 4);
+                dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, df, dq[dt], 0, 0, 0);   // dQ^T [d][query]
+            }
+        }
+        if (qtok >= 0) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 ov = {(bf16)(dq[dt][0] * p.scale), (bf16)(dq[dt][1] * p.scale), (bf16)(dq[dt][2] * p.scale),
+                             (bf16)(dq[dt][3] * p.scale)};
+                *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)qtok * p.ld + qcol + dt * 16 + lg * 4) = ov;
+            }
+        }
+    }
+    __syncthreads();
+    if (p.dbias)
+        for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) atomicAdd(&p.dbias[h * p.nbias + t], dbias_s[t]);
+
+    // ---- phase 2: a wave owns a key tile; dK, dV ----
+    for (int kt = wave; kt < nt; kt += 4) {
+        const int ki = kt * 16 + lr;
+        const int ktok = tok[ki];
+        bf16x8 kf[KS], vf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = attn_row_frag(p.qkv, p.ld, ktok, kcol + ks * 32 + lg * 8);
+            vf[ks] = attn_row_frag(p.qkv, p.ld, ktok, vcol + ks * 32 + lg * 8);
+        }
+        const int kci = ci[ki], kcj = cj[ki];
+        const bool kvalid = ki < p.N;
+        f32x4 dk[DT], dv[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int qp = 0; qp < NKT / 2; ++qp) {
+            f32x4 pt[2], dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qt = qp * 2 + u;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                const int qtok = tok[qt * 16 + lr];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qf = attn_row_frag(p.qkv, p.ld, qtok, qcol + ks * 32 + lg * 8);
+                    const bf16x8 dof = attn_row_frag(p.dout, p.lddo, qtok, ocol + ks * 32 + lg * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], acc, 0, 0, 0);     // S  [query][key]
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[ks], acc2, 0, 0, 0);  // dP [query][key]
+                }
+                const int q0 = qt * 16 + lg * 4;
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(&row_m[q0]);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_linv[q0]);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&row_delta[q0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = q0 + r;
+                    float v = acc[r] * p.scale;
+                    if (p.bias) v += bias_s[abs((int)ci[q] - kci) * p.ws + abs((int)cj[q] - kcj)];
+                    const bool ok = kvalid && q < p.N;    // rows >= N hold uninitialised statistics
+                    const float pr = ok ? __expf(v - m4[r]) * l4[r] : 0.f;
+                    acc[r] = pr;
+                    acc2[r] = ok ? pr * (acc2[r] - d4[r]) : 0.f;
+                }
+                pt[u] = acc;
+                dst[u] = acc2;
+            }
+            const bf16x8 pf = attn_pack(pt[0], pt[1]);      // k = query 32qp + 16(jj>>2) + 4lg + (jj&3)
+            const bf16x8 df = attn_pack(dst[0], dst[1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 qtf = attn_tr_frag(Qt, TS, dt * 16 + lr, qp * 32 + lg * 4);
+                const bf16x8 dotf = attn_tr_frag(dOt, TS, dt * 16 + lr, qp * 32 + lg * 4);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[dt], 0, 0, 0);    // dK^T [d][key]
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[dt], 0, 0, 0);   // dV^T [d][key]
+            }
+        }
+        if (ktok >= 0) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 a = {(bf16)(dk[dt][0] * p.scale), (bf16)(dk[dt][1] * p.scale), (bf16)(dk[dt][2] * p.scale), (bf16)(dk[dt][3] * p.scale)};
+                bf16x4 b = {(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)ktok * p.ld + kcol + dt * 16 + lg * 4) = a;
+                *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)ktok * p.ld + vcol + dt * 16 + lg * 4) = b;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- host
+static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
+    GG_CHECK(a && a->qkv, "%s: null qkv", who);
+    GG_CHECK(a->head_dim == 32 || a->head_dim == 64, "%s: head_dim must be 32 or 64 (got %d)", who, a->head_dim);
+    GG_CHECK(a->tokens_per_window > 0 && a->tokens_per_window <= 256,
+             "%s: %d tokens per window unsupported (max 256: full-row softmax in registers)", who, a->tokens_per_window);
+    GG_CHECK(a->num_windows > 0 && a->num_heads > 0, "%s: bad window/head count", who);
+    GG_CHECK((a->ld & 7) == 0 && (a->q_off & 7) == 0 && (a->k_off & 7) == 0 && (a->v_off & 7) == 0 && (a->head_stride & 7) == 0,
+             "%s: qkv offsets/strides must be multiples of 8 elements", who);
+    if (a->window_size > 0) {
+        GG_CHECK(a->window_size * a->window_size == a->tokens_per_window, "%s: window_size^2 != tokens_per_window", who);
+        GG_CHECK(a->map_h % a->window_size == 0 && a->map_w % a->window_size == 0, "%s: map not divisible by window", who);
+        GG_CHECK(a->num_windows % ((a->map_h / a->window_size) * (a->map_w / a->window_size)) == 0, "%s: window count", who);
+        GG_CHECK(a->window_size <= 16, "%s: window_size > 16 unsupported", who);
+    }
+    if (a->bias) GG_CHECK(a->window_size > 0 && a->tokens_per_window <= 256, "%s: bias needs a window geometry", who);
+    p.qkv = (const bf16*)a->qkv; p.ld = a->ld;
+    p.q_off = a->q_off; p.k_off = a->k_off; p.v_off = a->v_off; p.head_stride = a->head_stride;
+    p.out = (bf16*)a->out; p.ldo = a->ldo;
+    p.bias = a->bias; p.nbias = a->window_size * a->window_size;
+    p.ws = a->window_size;
+    p.H = a->map_h; p.W = a->map_w;
+    p.nWx = a->window_size ? a->map_w / a->window_size : 1;
+    p.nWy = a->window_size ? a->map_h / a->window_size : 1;
+    p.N = a->tokens_per_window; p.nh = a->num_heads; p.scale = a->scale;
+    p.dout = (const bf16*)a->dout; p.lddo = a->lddo; p.dqkv = (bf16*)a->dqkv; p.dbias = a->dbias;
+    return 0;
+}
+static int attn_nkt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 224 ? 14 : 16)); }
+
+extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
+    AttnParams p;
+    GG_TRY(attn_fill(p, a, "gg_attention_fwd"));
+    GG_CHECK(a->out && (a->ldo & 3) == 0, "gg_attention_fwd: bad out");
+    dim3 grid((unsigned)(a->num_windows * a->num_heads)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nkt = attn_nkt(p.N);
+#define GG_FWD(D_, K_) hipLaunchKernelGGL((attn_fwd_kernel<D_, K_>), grid, block, 0, s, p)
+    if (a->head_dim == 32) {
+        if (nkt == 4) GG_FWD(32, 4); else if (nkt == 10) GG_FWD(32, 10); else if (nkt == 14) GG_FWD(32, 14); else GG_FWD(32, 16);
+    } else {
+        if (nkt == 4) GG_FWD(64, 4); else if (nkt == 10) GG_FWD(64, 10); else if (nkt == 14) GG_FWD(64, 14); else GG_FWD(64, 16);
+    }
+#undef GG_FWD
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
+    AttnParams p;
+    GG_TRY(attn_fill(p, a, "gg_attention_bwd"));
+    GG_CHECK(a->dout && a->dqkv && (a->lddo & 7) == 0, "gg_attention_bwd: bad dout/dqkv");
+    GG_CHECK(a->head_dim == 32, "gg_attention_bwd: only head_dim 32 (TinyViT) is built");
+    dim3 grid((unsigned)(a->num_windows * a->num_heads)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const int nkt = attn_nkt(p.N);
+#define GG_BWD(K_) hipLaunchKernelGGL((attn_bwd_kernel<32, K_>), grid, block, 0, s, p)
+    if (nkt == 4) GG_BWD(4); else if (nkt == 10) GG_BWD(10); else if (nkt == 14) GG_BWD(14); else GG_BWD(16);
+#undef GG_BWD
+    GG_LAUNCH_CHECK();
+    return 0;
+}

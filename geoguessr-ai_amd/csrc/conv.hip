@@ -1,0 +1,339 @@
+// Spatial (3x3) kernels of PatchEmbed / MBConv / PatchMerging / local_conv on NHWC bf16 activations.
+// All of them are HBM-bound byte movers: 16-byte (8 x bf16) accesses along the channel axis, one
+// thread per (pixel, 8-channel group).  Dense 3x3 convs become im2col + the MFMA GEMM; depthwise
+// convs are computed here directly with fp32 taps.
+#include "common.h"
+#include "../../include/gg.h"
+
+// ---------------------------------------------------------------- im2col (dense 3x3, pad 1)
+// x f32 NCHW (B,3,H,W) -> col bf16 [B*Ho*Wo, 32]; k = (ky*3+kx)*3 + ci for k < 27, zeros above.
+__global__ __launch_bounds__(256) void im2col_nchw3_kernel(const float* __restrict__ x, bf16* __restrict__ col, int B, int H,
+                                                           int W, int Ho, int Wo, int stride) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(p % Wo);
+        const int oy = (int)((p / Wo) % Ho);
+        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const float* xb = x + (int64_t)b * 3 * H * W;
+        bf16 v[32];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+                    v[(ky * 3 + kx) * 3 + ci] = ok ? (bf16)xb[((int64_t)ci * H + iy) * W + ix] : (bf16)0.f;
+            }
+#pragma unroll
+        for (int k = 27; k < 32; ++k) v[k] = (bf16)0.f;
+        bf16x8* o = reinterpret_cast<bf16x8*>(col + p * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 t;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = v[i * 8 + j];
+            o[i] = t;
+        }
+    }
+}
+
+// x bf16 NHWC (B,H,W,C) -> col bf16 [B*Ho*Wo, 9*C]; k = (ky*3+kx)*C + c.
+__global__ __launch_bounds__(256) void im2col_nhwc_kernel(const bf16* __restrict__ x, bf16* __restrict__ col, int B, int H, int W,
+                                                          int C, int Ho, int Wo, int stride) {
+    const int cg = C >> 3;
+    const int per_pix = 9 * cg;
+    const int64_t total = (int64_t)B * Ho * Wo * per_pix;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % per_pix);
+        const int64_t p = i / per_pix;
+        const int tap = ch / cg, g = ch % cg;
+        const int ky = tap / 3, kx = tap % 3;
+        const int ox = (int)(p % Wo);
+        const int oy = (int)((p / Wo) % Ho);
+        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+            v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 8);
+        *reinterpret_cast<bf16x8*>(col + p * (9 * C) + tap * C + g * 8) = v;
+    }
+}
+
+// transpose of im2col_nhwc: dcol bf16 [B*Ho*Wo, 9*C] -> dx bf16 NHWC (gather form, no atomics)
+__global__ __launch_bounds__(256) void col2im_nhwc_kernel(const bf16* __restrict__ dcol, bf16* __restrict__ dx, int B, int H, int W,
+                                                          int C, int Ho, int Wo, int stride) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t p = i / cg;
+        const int ix = (int)(p % W);
+        const int iy = (int)((p / W) % H);
+        const int b = (int)(p / ((int64_t)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty % stride) != 0) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx % stride) != 0) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * (9 * C) +
+                                                                  (ky * 3 + kx) * C + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+        *reinterpret_cast<bf16x8*>(dx + p * C + g * 8) = o;
+    }
+}
+
+// ---------------------------------------------------------------- depthwise 3x3 (pad 1), NHWC
+// Thread = (pixel-lane pp, channel group g) with blockDim.x = CG * PP, g fixed per thread so that the
+// per-channel BatchNorm statistics (sum, sum of squares of the fp32 result) accumulate in registers.
+// wt: taps fp32 [9][C].  colstats: [gridDim.x][2][C] or null.
+__global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y, int B, int H,
+                                     int W, int C, int Ho, int Wo, int stride, int CG, int PP, int pix_per_block,
+                                     float* __restrict__ colstats) {
+    extern __shared__ float sred[];   // [PP][2][C]
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int64_t total = (int64_t)B * Ho * Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(total, p0 + pix_per_block);
+    float wreg[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wreg[t][j] = wt[t * C + g * 8 + j];
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (int64_t p = p0 + pp; p < p1; p += PP) {
+        const int ox = (int)(p % Wo);
+        const int oy = (int)((p / Wo) % Ho);
+        const int b = (int)(p / ((int64_t)Wo * Ho));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * wreg[ky * 3 + kx][j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            o[j] = (bf16)acc[j];
+            s[j] += acc[j];
+            q[j] += acc[j] * acc[j];
+        }
+        *reinterpret_cast<bf16x8*>(y + p * C + g * 8) = o;
+    }
+    if (colstats) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sred[(pp * 2 + 0) * C + g * 8 + j] = s[j];
+            sred[(pp * 2 + 1) * C + g * 8 + j] = q[j];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < PP; ++k) t += sred[k * 2 * C + i];
+            colstats[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+}
+
+// dx[b,iy,ix,c] = sum_{ky,kx} w[ky][kx][c] * dy[b,oy,ox,c],  oy*stride + ky - 1 == iy
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const bf16* __restrict__ dy, const float* __restrict__ wt,
+                                                                 bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
+                                                                 int stride) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t p = i / cg;
+        const int ix = (int)(p % W);
+        const int iy = (int)((p / W) % H);
+        const int b = (int)(p / ((int64_t)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty % stride) != 0) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx % stride) != 0) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + g * 8);
+                const float* wp = wt + (ky * 3 + kx) * C + g * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * wp[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+        *reinterpret_cast<bf16x8*>(dx + p * C + g * 8) = o;
+    }
+}
+
+// dw partials [gridDim.x][9][C]: sum over this block's output pixels of dy * x_tap
+__global__ void dwconv3x3_bwd_weight_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int B, int H, int W, int C,
+                                            int Ho, int Wo, int stride, int CG, int PP, int pix_per_block,
+                                            float* __restrict__ part) {
+    extern __shared__ float sred[];   // [PP][9][C]
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int64_t total = (int64_t)B * Ho * Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+    const int64_t p1 = min(total, p0 + pix_per_block);
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    for (int64_t p = p0 + pp; p < p1; p += PP) {
+        const int ox = (int)(p % Wo);
+        const int oy = (int)((p / Wo) % Ho);
+        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + p * C + g * 8);
+        float df[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) df[j] = (float)d[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += df[j] * (float)v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sred[(pp * 9 + t) * C + g * 8 + j] = acc[t][j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < PP; ++k) t += sred[k * 9 * C + i];
+        part[(int64_t)blockIdx.x * 9 * C + i] = t;
+    }
+}
+// part [nparts][9][C] -> grad of conv.weight (C,1,3,3): grad[c*9 + tap] (+)= sum
+__global__ void dwconv_wgrad_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ grad, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // index into [9][C]
+    if (i >= 9 * C) return;
+    double s = 0.0;
+    for (int k = 0; k < nparts; ++k) s += (double)part[(int64_t)k * 9 * C + i];
+    const int tap = i / C, c = i % C;
+    float* o = grad + c * 9 + tap;
+    *o = accumulate ? *o + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------- host
+static int grid_for(int64_t n, int cap = 16384) { return (int)std::min<int64_t>(gg_cdiv(n, 256), cap); }
+
+extern "C" int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int W, int stride, void* stream) {
+    GG_CHECK(x && col && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gg_im2col_nchw3_f32: bad args");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    hipLaunchKernelGGL(im2col_nchw3_kernel, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)col, B,
+                       H, W, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, int stride, void* stream) {
+    GG_CHECK(x && col && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_im2col_nhwc_bf16: bad args (C %% 8)");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 9 * (C / 8), 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)x, (bf16*)col, B, H, W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream) {
+    GG_CHECK(dcol && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_col2im_nhwc_bf16: bad args");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)dcol, (bf16*)dx, B, H, W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+struct DwGeom { int CG, PP, threads, pix_per_block, nblocks; };
+static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
+    DwGeom g;
+    g.CG = C / 8;
+    g.PP = std::max(1, std::min(256 / g.CG, 15360 / lds_floats_per_pp));   // <= 60 KB of dynamic LDS
+    g.threads = g.CG * g.PP;
+    int64_t target_blocks = 4096;
+    int64_t ppb = std::max<int64_t>(gg_cdiv(npix, target_blocks), (int64_t)g.PP * 4);
+    ppb = gg_align(ppb, g.PP);
+    g.pix_per_block = (int)ppb;
+    g.nblocks = (int)gg_cdiv(npix, ppb);
+    return g;
+}
+extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C) { return dw_geom((int64_t)B * Ho * Wo, C, 2 * C).nblocks; }
+
+extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats,
+                                void* stream) {
+    GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && C <= 2048 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    DwGeom g = dw_geom((int64_t)B * Ho * Wo, C, 2 * C);
+    GG_CHECK(g.threads <= 1024, "gg_dwconv3x3_fwd: C too large");
+    size_t lds = colstats ? (size_t)g.PP * 2 * C * sizeof(float) : 0;
+    hipLaunchKernelGGL(dwconv3x3_fwd_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
+                       B, H, W, C, Ho, Wo, stride, g.CG, g.PP, g.pix_per_block, colstats);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
+    GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)dy, wt, (bf16*)dx, B, H, W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    return (int64_t)dw_geom((int64_t)B * Ho * Wo, C, 9 * C).nblocks * 9 * C;
+}
+extern "C" int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch,
+                                       float* grad, int accumulate, void* stream) {
+    GG_CHECK(x && dy && scratch && grad && B > 0 && (C & 7) == 0, "gg_dwconv3x3_bwd_weight: bad args");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    DwGeom g = dw_geom((int64_t)B * Ho * Wo, C, 9 * C);
+    size_t lds = (size_t)g.PP * 9 * C * sizeof(float);
+    GG_CHECK(lds <= 64 * 1024, "gg_dwconv3x3_bwd_weight: LDS budget exceeded for C=%d", C);
+    hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)dy, B, H, W, C, Ho, Wo, stride, g.CG, g.PP, g.pix_per_block, scratch);
+    hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3((unsigned)gg_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, scratch,
+                       g.nblocks, C, grad, accumulate);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

@@ -57,8 +57,8 @@ __device__ __forceinline__ void store_tile_lds(bf16* __restrict__ S, const bf16x
 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BM * LDS_STRIDE];
-    bf16* As[2] = {smem, smem + BM * LDS_STRIDE};
-    bf16* Bs[2] = {smem + 2 * BM * LDS_STRIDE, smem + 3 * BM * LDS_STRIDE};
+#define AS_(b) (smem + (b) * (BM * LDS_STRIDE))
+#define BS_(b) (smem + (2 + (b)) * (BM * LDS_STRIDE))
 
     const int tiles = p.tilesM * p.tilesN;
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     if (nk > 0) {
         load_tile_regs(p.A, p.lda, p.M, p.K, m0, kbeg, kend, ra);
         load_tile_regs(p.B, p.ldb, p.N, p.K, n0, kbeg, kend, rb);
-        store_tile_lds(As[0], ra);
-        store_tile_lds(Bs[0], rb);
+        store_tile_lds(AS_(0), ra);
+        store_tile_lds(BS_(0), rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
         bf16x8 xf[4], wf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            xf[i] = *reinterpret_cast<const bf16x8*>(As[cur] + (wm * 64 + i * 16 + lr) * LDS_STRIDE + lg * 8);
-            wf[i] = *reinterpret_cast<const bf16x8*>(Bs[cur] + (wn * 64 + i * 16 + lr) * LDS_STRIDE + lg * 8);
+            xf[i] = *reinterpret_cast<const bf16x8*>(AS_(cur) + (wm * 64 + i * 16 + lr) * LDS_STRIDE + lg * 8);
+            wf[i] = *reinterpret_cast<const bf16x8*>(BS_(cur) + (wn * 64 + i * 16 + lr) * LDS_STRIDE + lg * 8);
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
             for (int mt = 0; mt < 4; ++mt)
                 acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         if (kt + 1 < nk) {
-            store_tile_lds(As[cur ^ 1], ra);
-            store_tile_lds(Bs[cur ^ 1], rb);
+            store_tile_lds(AS_(cur ^ 1), ra);
+            store_tile_lds(BS_(cur ^ 1), rb);
         }
         __syncthreads();
     }

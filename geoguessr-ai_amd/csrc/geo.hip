@@ -1,0 +1,319 @@
+// SuperGuessr head epilogue, haversine-smoothed loss, ProtoRefiner and scoring (gfx950).
+//
+// geo_head_kernel fuses, per sample row, everything models/super_guessr.py:355-383 and
+// main_coordinator_idun_s3.py:390-391 do on the (N, K=12647) logits: haversine to every centroid
+// (models/utils.py:39-57), row argmin (nearest-centroid label), smooth labels (models/utils.py:20-32),
+// log-softmax, soft / hard cross-entropy, d(loss)/d(logits), softmax arg-max, centroid gather and top-5.
+// One 256-thread workgroup per row keeps the whole row (logit + distance per element) in registers:
+// logits are read once, dlogits written once -> 2*N*K*4 algorithmic bytes.
+#include "common.h"
+#include "../../include/gg.h"
+
+#define GEO_NT 256
+
+__device__ __forceinline__ float haversine_km_f32(float lon1r, float lat1r, float coslat1, float lon2r, float lat2r, float coslat2) {
+    // models/utils.py:48-56 in fp32: a = sin^2(dlat/2) + cos(lat1) cos(lat2) sin^2(dlon/2)
+    const float sdlat = sinf((lat1r - lat2r) * 0.5f);
+    const float sdlon = sinf((lon1r - lon2r) * 0.5f);
+    float a = sdlat * sdlat + (coslat1 * coslat2) * (sdlon * sdlon);
+    a = fminf(a, 1.0f);   // exact antipodes can round above 1 (asin -> NaN); documented divergence
+    const float c = 2.0f * asinf(sqrtf(a));
+    return (6378137.0f * c) / 1000.0f;
+}
+
+struct ArgVal { float v; int i; };
+__device__ __forceinline__ ArgVal argmax_better(ArgVal a, ArgVal b) {   // larger value, then smaller index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ ArgVal block_argmax(ArgVal x, float* sv, int* si) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ArgVal y;
+        y.v = __shfl_xor(x.v, o, 64);
+        y.i = __shfl_xor(x.i, o, 64);
+        x = argmax_better(x, y);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = x.v; si[threadIdx.x >> 6] = x.i; }
+    __syncthreads();
+    ArgVal r = {sv[0], si[0]};
+#pragma unroll
+    for (int k = 1; k < GEO_NT / 64; ++k) r = argmax_better(r, (ArgVal){sv[k], si[k]});
+    return r;
+}
+
+struct GeoParams {
+    const float* logits; int64_t ldl;
+    int N, K;
+    const float* labels;       // (N,2) lon,lat deg or null
+    const float* centroids;    // (K,2) lon,lat deg
+    const int64_t* labels_clf; // (N,) or null
+    int mode;                  // 0 predictions only, 1 soft CE, 2 hard CE
+    float smoothing_km;
+    float grad_scale;          // dlogits = d(mean loss)/dlogits * grad_scale  (1/N folded in)
+    float* loss_rows;
+    bf16* dlogits; int64_t ldd;
+    int64_t* preds; float* llh; float* topk_vals; int64_t* topk_idx; int num_candidates;
+    int64_t* nearest;
+};
+
+template <int E>
+__global__ __launch_bounds__(GEO_NT) void geo_head_kernel(GeoParams p) {
+    __shared__ float red[GEO_NT / 64];
+    __shared__ float sv[GEO_NT / 64];
+    __shared__ int si[GEO_NT / 64];
+    const int n = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float* zrow = p.logits + (int64_t)n * p.ldl;
+
+    float z[E];
+    float zmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int k = e * GEO_NT + tid;
+        z[e] = k < p.K ? zrow[k] : -INFINITY;
+        zmax = fmaxf(zmax, z[e]);
+    }
+    zmax = gg_block_max<GEO_NT>(zmax, red);
+    float se = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) se += __expf(z[e] - zmax);
+    se = gg_block_sum<GEO_NT>(se, red);
+    const float lse = zmax + logf(se);
+
+    const bool have_labels = p.labels != nullptr;
+    if (have_labels && (p.mode == 1 || p.nearest)) {
+        const float d2r = 0.017453292519943295f;
+        const float lon1 = p.labels[2 * n] * d2r, lat1 = p.labels[2 * n + 1] * d2r;
+        const float cl1 = cosf(lat1);
+        float d[E];
+        ArgVal best = {-INFINITY, 0x7fffffff};   // argmax of -d == argmin of d
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = e * GEO_NT + tid;
+            if (k < p.K) {
+                const float lon2 = p.centroids[2 * k] * d2r, lat2 = p.centroids[2 * k + 1] * d2r;
+                d[e] = haversine_km_f32(lon1, lat1, cl1, lon2, lat2, cosf(lat2));
+                best = argmax_better(best, (ArgVal){-d[e], k});
+            } else d[e] = INFINITY;
+        }
+        best = block_argmax(best, sv, si);
+        const float dmin = -best.v;
+        if (p.nearest && tid == 0) p.nearest[n] = best.i;
+        if (p.mode == 1) {
+            float zs = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float sft = __expf(-(d[e] - dmin) / p.smoothing_km);
+                if (!(sft == sft) || isinf(sft)) sft = 0.f;       // nan_to_num(nan=0, posinf=0, neginf=0)
+                d[e] = sft;
+                zs += sft;
+            }
+            zs = gg_block_sum<GEO_NT>(zs, red);
+            const float inv = 1.0f / fmaxf(zs, 1e-12f);
+            const float tsum = zs * inv;
+            float lr = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int k = e * GEO_NT + tid;
+                if (k < p.K) {
+                    const float t = d[e] * inv;
+                    lr -= t * (z[e] - lse);
+                    if (p.dlogits) p.dlogits[(int64_t)n * p.ldd + k] = (bf16)((__expf(z[e] - lse) * tsum - t) * p.grad_scale);
+                }
+            }
+            lr = gg_block_sum<GEO_NT>(lr, red);
+            if (tid == 0 && p.loss_rows) p.loss_rows[n] = lr;
+        }
+    }
+    if (p.mode == 2) {
+        const int lab = (int)p.labels_clf[n];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = e * GEO_NT + tid;
+            if (k < p.K) {
+                if (k == lab && p.loss_rows) p.loss_rows[n] = -(z[e] - lse);
+                if (p.dlogits) p.dlogits[(int64_t)n * p.ldd + k] = (bf16)((__expf(z[e] - lse) - (k == lab ? 1.f : 0.f)) * p.grad_scale);
+            }
+        }
+    }
+    if (p.dlogits && p.mode != 0)
+        for (int k = p.K + tid; k < p.ldd; k += GEO_NT) p.dlogits[(int64_t)n * p.ldd + k] = (bf16)0.f;
+
+    // predictions: top-`num_candidates` of softmax == of logits (destroys z)
+    if (p.preds || p.topk_idx) {
+        for (int c = 0; c < p.num_candidates; ++c) {
+            ArgVal best = {-INFINITY, 0x7fffffff};
+#pragma unroll
+            for (int e = 0; e < E; ++e) best = argmax_better(best, (ArgVal){z[e], e * GEO_NT + tid});
+            best = block_argmax(best, sv, si);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if (e * GEO_NT + tid == best.i) z[e] = -INFINITY;
+            if (tid == 0) {
+                if (p.topk_idx) {
+                    p.topk_idx[(int64_t)n * p.num_candidates + c] = best.i;
+                    p.topk_vals[(int64_t)n * p.num_candidates + c] = __expf(best.v - lse);
+                }
+                if (c == 0) {
+                    if (p.preds) p.preds[n] = best.i;
+                    if (p.llh) { p.llh[2 * n] = p.centroids[2 * best.i]; p.llh[2 * n + 1] = p.centroids[2 * best.i + 1]; }
+                }
+            }
+        }
+    }
+}
+
+__global__ void mean_f32_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = gg_block_sum<256>(s, red);
+    if (threadIdx.x == 0) out[0] = s / (float)n;
+}
+
+// ---------------------------------------------------------------------------- haversine matrix (debug / parity)
+__global__ void haversine_matrix_kernel(const float* __restrict__ x, const float* __restrict__ cent, float* __restrict__ out, int N, int K) {
+    const float d2r = 0.017453292519943295f;
+    const int64_t total = (int64_t)N * K;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const int n = (int)(i / K);
+        const float lon1 = x[2 * n] * d2r, lat1 = x[2 * n + 1] * d2r, lon2 = cent[2 * k] * d2r, lat2 = cent[2 * k + 1] * d2r;
+        out[i] = haversine_km_f32(lon1, lat1, cosf(lat1), lon2, lat2, cosf(lat2));
+    }
+}
+
+// ---------------------------------------------------------------------------- ProtoRefiner (models/proto_refiner.py:129-237)
+// One wave per sample.  Prototype table in CSR form: prototypes of cell c are rows cell_ptr[c]..cell_ptr[c+1].
+__global__ __launch_bounds__(64) void proto_refine_kernel(const float* __restrict__ emb, int V, int D, const float* __restrict__ initial,
+                                                          const int64_t* __restrict__ cand, const float* __restrict__ cprob, int ncand,
+                                                          const int64_t* __restrict__ cell_ptr, int num_cells,
+                                                          const float* __restrict__ proto_emb, const float* __restrict__ proto_ll, int topk,
+                                                          float max_refinement, float temperature, float* __restrict__ out_llh,
+                                                          int64_t* __restrict__ out_cell, int64_t* __restrict__ out_idx) {
+    extern __shared__ float e[];   // D floats: the query embedding (mean over V views)
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int d = lane; d < D; d += 64) {
+        float s = 0.f;
+        for (int v = 0; v < V; ++v) s += emb[((int64_t)b * V + v) * D + d];
+        e[d] = s / (float)V;
+    }
+    __syncthreads();
+    float top_d[8], top_lon[8], top_lat[8];
+    for (int c = 0; c < topk; ++c) {
+        const int64_t cell = cand[(int64_t)b * ncand + c];
+        int64_t lo = 0, hi = 0;
+        if (cell >= 0 && cell < num_cells) { lo = cell_ptr[cell]; hi = cell_ptr[cell + 1]; }
+        float best = -INFINITY;
+        int64_t bestp = -1;
+        for (int64_t pi = lo; pi < hi; ++pi) {
+            float s = 0.f;
+            for (int d = lane; d < D; d += 64) {
+                const float df = proto_emb[pi * D + d] - e[d];
+                s += df * df;
+            }
+            s = gg_wave_sum(s);
+            const float logit = -sqrtf(s);
+            if (logit > best) { best = logit; bestp = pi; }   // first maximum, like torch.argmax
+        }
+        if (bestp < 0) { top_d[c] = -100000.0f; top_lon[c] = 0.f; top_lat[c] = 0.f; }
+        else { top_d[c] = best; top_lon[c] = proto_ll[2 * bestp]; top_lat[c] = proto_ll[2 * bestp + 1]; }
+    }
+    if (lane == 0) {
+        float ex[8], sum = 0.f;
+        for (int c = 0; c < topk; ++c) { ex[c] = expf(top_d[c] / temperature); sum += ex[c]; }
+        int refined = 0, initial_best = 0;
+        float bf = -INFINITY, bc = -INFINITY;
+        for (int c = 0; c < topk; ++c) {
+            const float cp = cprob ? cprob[(int64_t)b * ncand + c] : (c == 0 ? 1.f : 0.f);
+            const float f = cp * (ex[c] / sum);
+            if (f > bf) { bf = f; refined = c; }
+            if (cp > bc) { bc = cp; initial_best = c; }
+        }
+        // geo_utils.haversine: fp32 trig, fp64 radius
+        const float d2r = 0.017453292519943295f;
+        const float lon1 = initial[2 * b] * d2r, lat1 = initial[2 * b + 1] * d2r;
+        const float lon2 = top_lon[refined] * d2r, lat2 = top_lat[refined] * d2r;
+        const float sdlat = sinf((lat2 - lat1) * 0.5f), sdlon = sinf((lon2 - lon1) * 0.5f);
+        float a = sdlat * sdlat + cosf(lat1) * cosf(lat2) * sdlon * sdlon;
+        a = fminf(a, 1.f);
+        const double dist = 6378137.0 * (double)(2.0f * asinf(sqrtf(a))) / 1000.0;
+        const int k = dist > (double)max_refinement ? initial_best : refined;
+        out_idx[b] = k;
+        out_llh[2 * b] = top_lon[k];
+        out_llh[2 * b + 1] = top_lat[k];
+        out_cell[b] = cand[(int64_t)b * ncand + k];
+    }
+}
+
+// ---------------------------------------------------------------------------- scoring (run_benchmark.py:28-65), fp64
+__global__ void score_kernel(const float* __restrict__ pred, const float* __restrict__ truth, int N, float* __restrict__ dist_km,
+                             float* __restrict__ score) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double d2r = 0.017453292519943295769;
+    const double lon1 = pred[2 * i] * d2r, lat1 = pred[2 * i + 1] * d2r, lon2 = truth[2 * i] * d2r, lat2 = truth[2 * i + 1] * d2r;
+    const double sa = sin((lat2 - lat1) * 0.5), sb = sin((lon2 - lon1) * 0.5);
+    double a = sa * sa + cos(lat1) * cos(lat2) * sb * sb;
+    a = fmin(a, 1.0);
+    const double km = 6371000.0 * 2.0 * asin(sqrt(a)) / 1000.0;
+    dist_km[i] = (float)km;
+    score[i] = (float)(5000.0 * exp(-km / 1492.7));
+}
+
+// ------------------------------------------------------------------------------------------- host
+extern "C" int gg_geo_head(const GgGeoHeadArgs* a, void* stream) {
+    GG_CHECK(a && a->logits && a->centroids, "gg_geo_head: null logits/centroids");
+    GG_CHECK(a->N > 0 && a->K > 0 && a->K <= GEO_NT * 64, "gg_geo_head: K=%d unsupported (max %d)", a->K, GEO_NT * 64);
+    GG_CHECK(a->mode >= 0 && a->mode <= 2, "gg_geo_head: bad mode");
+    if (a->mode == 1) GG_CHECK(a->labels, "gg_geo_head: soft CE needs labels (lon,lat)");
+    if (a->mode == 2) GG_CHECK(a->labels_clf, "gg_geo_head: hard CE needs labels_clf");
+    if (a->dlogits) GG_CHECK(a->ldd >= a->K, "gg_geo_head: ldd < K");
+    if (a->topk_idx) GG_CHECK(a->topk_vals && a->num_candidates > 0 && a->num_candidates <= 16, "gg_geo_head: bad top-k args");
+    GeoParams p;
+    p.logits = a->logits; p.ldl = a->ldl; p.N = a->N; p.K = a->K;
+    p.labels = a->labels; p.centroids = a->centroids; p.labels_clf = a->labels_clf; p.mode = a->mode;
+    p.smoothing_km = a->smoothing_km > 0 ? a->smoothing_km : 65.0f;
+    p.grad_scale = a->grad_scale;
+    p.loss_rows = a->loss_rows; p.dlogits = (bf16*)a->dlogits; p.ldd = a->ldd;
+    p.preds = a->preds; p.llh = a->llh; p.topk_vals = a->topk_vals; p.topk_idx = a->topk_idx;
+    p.num_candidates = a->num_candidates > 0 ? a->num_candidates : 1;
+    p.nearest = a->nearest;
+    const int per = (int)gg_cdiv(a->K, GEO_NT);
+    dim3 grid(a->N), block(GEO_NT);
+    hipStream_t s = (hipStream_t)stream;
+    if (per <= 4) hipLaunchKernelGGL(geo_head_kernel<4>, grid, block, 0, s, p);
+    else if (per <= 16) hipLaunchKernelGGL(geo_head_kernel<16>, grid, block, 0, s, p);
+    else if (per <= 50) hipLaunchKernelGGL(geo_head_kernel<50>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(geo_head_kernel<64>, grid, block, 0, s, p);
+    if (a->loss && a->loss_rows && a->mode != 0) hipLaunchKernelGGL(mean_f32_kernel, dim3(1), dim3(256), 0, s, a->loss_rows, a->N, a->loss);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_haversine_matrix(const float* x, const float* centroids, float* out, int N, int K, void* stream) {
+    GG_CHECK(x && centroids && out && N > 0 && K > 0, "gg_haversine_matrix: bad args");
+    int blocks = (int)std::min<int64_t>(gg_cdiv((int64_t)N * K, 256), 16384);
+    hipLaunchKernelGGL(haversine_matrix_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, centroids, out, N, K);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_proto_refine(const GgProtoRefineArgs* a, void* stream) {
+    GG_CHECK(a && a->embedding && a->initial_preds && a->candidate_cells && a->cell_ptr && a->proto_emb && a->proto_lnglat,
+             "gg_proto_refine: null argument");
+    GG_CHECK(a->B > 0 && a->D > 0 && a->V > 0, "gg_proto_refine: bad shape");
+    GG_CHECK(a->topk > 0 && a->topk <= 8 && a->topk <= a->num_candidates,
+             "gg_proto_refine: \"topk\" must be <= number of candidates passed (and <= 8): topk=%d candidates=%d", a->topk, a->num_candidates);
+    GG_CHECK(a->out_llh && a->out_cell && a->out_idx, "gg_proto_refine: null output");
+    hipLaunchKernelGGL(proto_refine_kernel, dim3(a->B), dim3(64), (size_t)a->D * sizeof(float), (hipStream_t)stream, a->embedding, a->V,
+                       a->D, a->initial_preds, a->candidate_cells, a->candidate_probs, a->num_candidates, a->cell_ptr, a->num_cells,
+                       a->proto_emb, a->proto_lnglat, a->topk, a->max_refinement, a->temperature, a->out_llh, a->out_cell, a->out_idx);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, float* dist_km, float* score, void* stream) {
+    GG_CHECK(pred_llh && true_llh && dist_km && score && N > 0, "gg_geoguessr_score: bad args");
+    hipLaunchKernelGGL(score_kernel, dim3((unsigned)gg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred_llh, true_llh, N, dist_km, score);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

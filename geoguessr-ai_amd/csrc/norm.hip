@@ -1,0 +1,513 @@
+// BatchNorm (train-mode batch statistics), LayerNorm, pooling.  HBM-bound wavefront-reduction kernels.
+//
+// BatchNorm2d in train mode (timm ConvNorm; reference keeps every BN in train mode):
+//   producer kernel (GEMM / dwconv) emits per-block column partials of sum and sum-of-squares of the
+//   fp32 pre-BN result  ->  bn_finalize (fp64 reduction, running-stat update)  ->  bn_apply.
+// Backward:  bn_bwd_reduce (dz, per-channel sum g, sum g*xhat)  ->  bn_bwd_finalize  ->  bn_bwd_apply.
+#include "common.h"
+#include "../../include/gg.h"
+
+// ------------------------------------------------------------------------------ BN statistics
+// part [nparts][2][C] -> stat [2][C] = (mean, rstd); running stats updated with unbiased variance.
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, float eps, float momentum,
+                                   float* __restrict__ stat, float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        s += (double)part[(int64_t)i * 2 * C + c];
+        q += (double)part[(int64_t)i * 2 * C + C + c];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[c] = (float)mean;
+    stat[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+__global__ void bn_eval_stat_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int C, float eps, float* __restrict__ stat) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    stat[c] = rm[c];
+    stat[C + c] = rsqrtf(rv[c] + eps);
+}
+
+// out = act( [residual + rs *] (gamma * (y - mean) * rstd + beta) )
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ stat,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int64_t M, int C,
+                                                       int act, const bf16* __restrict__ residual, const float* __restrict__ rowscale,
+                                                       int rows_per_scale, bf16* __restrict__ out) {
+    const int cg = C >> 3;
+    const int64_t total = M * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t m = i / cg;
+        const int c0 = g * 8;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+        bf16x8 r;
+        float rs = 1.f;
+        if (residual) {
+            r = *reinterpret_cast<const bf16x8*>(residual + m * C + c0);
+            if (rowscale) rs = rowscale[m / rows_per_scale];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            float z = ((float)v[j] - stat[c]) * stat[C + c] * gamma[c] + beta[c];
+            if (residual) z = (float)r[j] + rs * z;
+            o[j] = (bf16)gg_act(z, act);
+        }
+        *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+    }
+}
+
+// Thread = (row-lane pp, channel group g), g fixed per thread (blockDim.x = CG*PP).
+//   z    = gamma*xhat + beta ; pre = residual ? residual + rs*z : z
+//   dpre = dout * act'(pre)            -> written to dz (it is also the skip-path gradient of an MBConv)
+//   g    = residual ? rs*dpre : dpre   -> partial sums  sum g, sum g*xhat   [gridDim.x][2][C]
+__global__ void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ y, const float* __restrict__ stat,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int64_t M, int C, int act,
+                                     const bf16* __restrict__ residual, const float* __restrict__ rowscale, int rows_per_scale,
+                                     bf16* __restrict__ dz, float* __restrict__ part, int CG, int PP, int rows_per_block) {
+    extern __shared__ float sred[];   // [PP][2][C]
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int c0 = g * 8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    float mu[8], rstd[8], ga[8], be[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = stat[c0 + j]; rstd[j] = stat[C + c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
+        s[j] = q[j] = 0.f;
+    }
+    for (int64_t m = r0 + pp; m < r1; m += PP) {
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + m * C + c0);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+        bf16x8 r;
+        float rs = 1.f;
+        if (residual) {
+            r = *reinterpret_cast<const bf16x8*>(residual + m * C + c0);
+            if (rowscale) rs = rowscale[m / rows_per_scale];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)v[j] - mu[j]) * rstd[j];
+            float pre = ga[j] * xh + be[j];
+            if (residual) pre = (float)r[j] + rs * pre;
+            const float dpre = (float)d[j] * gg_act_grad(pre, act);
+            o[j] = (bf16)dpre;
+            const float gg = residual ? rs * dpre : dpre;
+            s[j] += gg;
+            q[j] += gg * xh;
+        }
+        if (dz) *reinterpret_cast<bf16x8*>(dz + m * C + c0) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sred[(pp * 2 + 0) * C + c0 + j] = s[j];
+        sred[(pp * 2 + 1) * C + c0 + j] = q[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < PP; ++k) t += sred[k * 2 * C + i];
+        part[(int64_t)blockIdx.x * 2 * C + i] = t;
+    }
+}
+// part [nparts][2][C] -> sums [2][C] (sum g, sum g*xhat); optional dgamma (+)= sum g*xhat, dbeta (+)= sum g
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        s += (double)part[(int64_t)i * 2 * C + c];
+        q += (double)part[(int64_t)i * 2 * C + C + c];
+    }
+    sums[c] = (float)s;
+    sums[C + c] = (float)q;
+    if (dgamma) {
+        dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
+        dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
+    }
+}
+// dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  g = rs*dz
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y,
+                                                           const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, int64_t M, int C,
+                                                           const float* __restrict__ rowscale, int rows_per_scale,
+                                                           bf16* __restrict__ dy) {
+    const int cg = C >> 3;
+    const int64_t total = M * cg;
+    const float invM = 1.0f / (float)M;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t m = i / cg;
+        const int c0 = g * 8;
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + m * C + c0);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+        const float rs = rowscale ? rowscale[m / rows_per_scale] : 1.f;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const float rstd = stat[C + c];
+            const float xh = ((float)v[j] - stat[c]) * rstd;
+            const float gg = rs * (float)d[j];
+            o[j] = (bf16)(gamma[c] * rstd * (gg - sums[c] * invM - xh * sums[C + c] * invM));
+        }
+        *reinterpret_cast<bf16x8*>(dy + m * C + c0) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// One wave per row, 8-element chunks: lane takes chunks lane, lane+64 (C <= 1024).
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&f)[8]) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&f)[8]) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&f)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&f)[8]) {
+        *reinterpret_cast<f32x4*>(p) = (f32x4){f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+    }
+};
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int64_t M, int C, float eps,
+                                                            TO* __restrict__ out, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int nch = C >> 3;
+    for (int64_t m = wave; m < M; m += nwaves) {
+        float v[2][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nch) {
+                Vec8<TI>::load(x + m * C + ch * 8, v[k]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[k][j];
+            }
+        }
+        const float mean = gg_wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(gg_wave_sum(q) / (float)C + eps);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (v[k][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j];
+                Vec8<TO>::store(out + m * C + ch * 8, o);
+            }
+        }
+        if (mean_out && lane == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+    }
+}
+
+// dx = rstd*(dxh - mean(dxh) - xhat*mean(dxh*xhat)) [+ dres],  dxh = dout*gamma
+// param partials: part [gridDim.x][2][C] = (sum dout*xhat, sum dout) over this block's rows (if part != null)
+template <typename TI, typename TG>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG* __restrict__ dout, const TI* __restrict__ x,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            const float* __restrict__ gamma, int64_t M, int C,
+                                                            const TG* __restrict__ dres, TG* __restrict__ dx, float* __restrict__ part) {
+    extern __shared__ float sred[];   // [4 waves][2][C] when part != null
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t wave = blockIdx.x * (int64_t)(blockDim.x >> 6) + w;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int nch = C >> 3;
+    float dg[2][8], db[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dg[k][j] = db[k][j] = 0.f;
+    for (int64_t m = wave; m < M; m += nwaves) {
+        const float mean = mean_in[m], rstd = rstd_in[m];
+        float xh[2][8], dxh[2][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nch) {
+                float xv[8], dv[8];
+                Vec8<TI>::load(x + m * C + ch * 8, xv);
+                Vec8<TG>::load(dout + m * C + ch * 8, dv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    xh[k][j] = (xv[j] - mean) * rstd;
+                    dxh[k][j] = dv[j] * gamma[ch * 8 + j];
+                    s1 += dxh[k][j];
+                    s2 += dxh[k][j] * xh[k][j];
+                    dg[k][j] += dv[j] * xh[k][j];
+                    db[k][j] += dv[j];
+                }
+            }
+        }
+        s1 = gg_wave_sum(s1) / (float)C;
+        s2 = gg_wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nch) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = rstd * (dxh[k][j] - s1 - xh[k][j] * s2);
+                if (dres) {
+                    float r[8];
+                    Vec8<TG>::load(dres + m * C + ch * 8, r);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += r[j];
+                }
+                Vec8<TG>::store(dx + m * C + ch * 8, o);
+            }
+        }
+    }
+    if (part) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sred[(w * 2 + 0) * C + ch * 8 + j] = dg[k][j];
+                    sred[(w * 2 + 1) * C + ch * 8 + j] = db[k][j];
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < 4; ++k) t += sred[k * 2 * C + i];
+            part[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+}
+// part [nparts][2][C] -> dgamma (+)= part[.][0], dbeta (+)= part[.][1]
+__global__ void ln_param_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nparts; ++i) {
+        s += (double)part[(int64_t)i * 2 * C + c];
+        q += (double)part[(int64_t)i * 2 * C + C + c];
+    }
+    dgamma[c] = accumulate ? dgamma[c] + (float)s : (float)s;
+    dbeta[c] = accumulate ? dbeta[c] + (float)q : (float)q;
+}
+
+// ------------------------------------------------------------------------------ pooling / means
+// x bf16 [B*T, C] -> out f32 [B, C] = mean over T tokens
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const bf16* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)B * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t b = i / cg;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int t = 0; t < T; ++t) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (b * T + t) * C + g * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+        const float inv = 1.f / (float)T;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[b * C + g * 8 + j] = acc[j] * inv;
+    }
+}
+// dout f32 [B, C] -> dx bf16 [B*T, C] = dout / T
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, bf16* __restrict__ dx, int B, int T, int C) {
+    const int cg = C >> 3;
+    const int64_t total = (int64_t)B * T * cg;
+    const float inv = 1.f / (float)T;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t bt = i / cg;
+        const int64_t b = bt / T;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(dout[b * C + g * 8 + j] * inv);
+        *reinterpret_cast<bf16x8*>(dx + bt * C + g * 8) = o;
+    }
+}
+// emb f32 [N, V, C] -> out bf16 [N, ldo] (mean over V views; SuperGuessr panorama combine)
+__global__ void view_mean_fwd_kernel(const float* __restrict__ emb, bf16* __restrict__ out, int64_t ldo, int N, int V, int C) {
+    const int64_t total = (int64_t)N * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t n = i / C;
+        float s = 0.f;
+        for (int v = 0; v < V; ++v) s += emb[(n * V + v) * C + c];
+        out[n * ldo + c] = (bf16)(s / (float)V);
+    }
+}
+// dmean bf16 [N, ld] -> demb f32 [N, V, C] = dmean / V
+__global__ void view_mean_bwd_kernel(const bf16* __restrict__ dmean, int64_t ld, float* __restrict__ demb, int N, int V, int C) {
+    const int64_t total = (int64_t)N * V * C;
+    const float inv = 1.f / (float)V;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t n = i / ((int64_t)V * C);
+        demb[i] = (float)dmean[n * ld + c] * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- host
+static int grid_for(int64_t n, int cap = 16384) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(n, 256), cap)); }
+
+extern "C" int gg_bn_finalize(const float* part, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
+                              float* running_mean, float* running_var, void* stream) {
+    GG_CHECK(part && stat && nparts > 0 && C > 0 && count > 0, "gg_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, part, nparts, C,
+                       (double)count, eps, momentum, stat, running_mean, running_var);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_bn_eval_stat(const float* running_mean, const float* running_var, int C, float eps, float* stat, void* stream) {
+    GG_CHECK(running_mean && running_var && stat && C > 0, "gg_bn_eval_stat: bad args");
+    hipLaunchKernelGGL(bn_eval_stat_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
+                       running_var, C, eps, stat);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_bn_apply(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                           const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream) {
+    GG_CHECK(y && stat && gamma && beta && out && M > 0 && (C & 7) == 0, "gg_bn_apply: bad args");
+    GG_CHECK(!rowscale || rows_per_scale > 0, "gg_bn_apply: rows_per_scale");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8), 32768)), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, stat,
+                       gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)out);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+struct RowGeom { int CG, PP, threads, rows_per_block, nblocks; };
+static RowGeom row_geom(int64_t M, int C) {
+    RowGeom g;
+    g.CG = C / 8;
+    g.PP = std::max(1, std::min(256 / g.CG, 15360 / (2 * C)));
+    g.threads = g.CG * g.PP;
+    int64_t rpb = std::max<int64_t>(gg_cdiv(M, 4096), (int64_t)g.PP * 4);
+    rpb = gg_align(rpb, g.PP);
+    g.rows_per_block = (int)rpb;
+    g.nblocks = (int)gg_cdiv(M, rpb);
+    return g;
+}
+extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return (int64_t)row_geom(M, C).nblocks * 2 * C + 2 * C; }
+// scratch: [nblocks][2][C] partials followed by sums [2][C]
+extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                         int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
+                         float* dgamma, float* dbeta, int accumulate, void* stream) {
+    GG_CHECK(dout && y && stat && gamma && beta && dz && dy && scratch && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd: bad args");
+    RowGeom g = row_geom(M, C);
+    GG_CHECK(g.threads <= 1024, "gg_bn_bwd: C too large");
+    float* part = scratch;
+    float* sums = scratch + (int64_t)g.nblocks * 2 * C;
+    size_t lds = (size_t)g.PP * 2 * C * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)dout,
+                       (const bf16*)y, stat, gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)dz, part,
+                       g.CG, g.PP, g.rows_per_block);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, part, g.nblocks, C,
+                       sums, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8), 32768)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dz,
+                       (const bf16*)y, stat, gamma, sums, M, C, residual ? rowscale : nullptr, rows_per_scale, (bf16*)dy);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int ln_blocks(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(M, 4), 2048)); }
+extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, int64_t M, int C, float eps, void* out,
+                                int out_f32, float* mean, float* rstd, void* stream) {
+    GG_CHECK(x && gamma && beta && out && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_fwd: bad args (C %% 8, C <= 1024)");
+    dim3 grid(ln_blocks(M)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (!x_f32 && !out_f32)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, bf16>), grid, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);
+    else if (x_f32 && out_f32)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<float, float>), grid, block, 0, s, (const float*)x, gamma, beta, M, C, eps, (float*)out, mean, rstd);
+    else if (x_f32 && !out_f32)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<float, bf16>), grid, block, 0, s, (const float*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);
+    else
+        hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (float*)out, mean, rstd);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C) { return (int64_t)ln_blocks(M) * 2 * C; }
+// f32 != 0: x, dout, dres, dx are all f32 (head norm); else all bf16
+extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma,
+                                int64_t M, int C, const void* dres, void* dx, float* scratch, float* dgamma, float* dbeta,
+                                int accumulate, void* stream) {
+    GG_CHECK(dout && x && mean && rstd && gamma && dx && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_bwd: bad args");
+    GG_CHECK(!dgamma || (scratch && dbeta), "gg_layernorm_bwd: parameter grads need scratch + dbeta");
+    const int nb = ln_blocks(M);
+    float* part = dgamma ? scratch : nullptr;
+    size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (f32)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<float, float>), dim3(nb), dim3(256), lds, s, (const float*)dout, (const float*)x, mean, rstd,
+                           gamma, M, C, (const float*)dres, (float*)dx, part);
+    else
+        hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, bf16>), dim3(nb), dim3(256), lds, s, (const bf16*)dout, (const bf16*)x, mean, rstd,
+                           gamma, M, C, (const bf16*)dres, (bf16*)dx, part);
+    if (dgamma)
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, s, part, nb, C, dgamma, dbeta, accumulate);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_token_mean_fwd(const void* x, float* out, int B, int T, int C, void* stream) {
+    GG_CHECK(x && out && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_fwd: bad args");
+    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3(grid_for((int64_t)B * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, B, T, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_token_mean_bwd(const float* dout, void* dx, int B, int T, int C, void* stream) {
+    GG_CHECK(dout && dx && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_bwd: bad args");
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for((int64_t)B * T * (C / 8))), dim3(256), 0, (hipStream_t)stream, dout, (bf16*)dx, B, T, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_view_mean_fwd(const float* emb, void* out, int64_t ldo, int N, int V, int C, void* stream) {
+    GG_CHECK(emb && out && N > 0 && V > 0 && C > 0 && ldo >= C, "gg_view_mean_fwd: bad args");
+    hipLaunchKernelGGL(view_mean_fwd_kernel, dim3(grid_for((int64_t)N * C)), dim3(256), 0, (hipStream_t)stream, emb, (bf16*)out, ldo, N, V, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_view_mean_bwd(const void* dmean, int64_t ld, float* demb, int N, int V, int C, void* stream) {
+    GG_CHECK(dmean && demb && N > 0 && V > 0 && C > 0 && ld >= C, "gg_view_mean_bwd: bad args");
+    hipLaunchKernelGGL(view_mean_bwd_kernel, dim3(grid_for((int64_t)N * V * C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dmean, ld, demb, N, V, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,813 @@
+// TinyViT encoder runtime: parameter table, bf16 weight cache, workspace plan, whole-network forward and
+// backward as a static schedule of libgg kernels on one HIP stream (no tracing compiler, no per-op host
+// round trips).  Architecture: timm TinyVit (TinyViT, Wu et al. 2022) as instantiated by the reference through
+// timm.create_model(name, num_classes=0, global_pool="avg") -- models/tinyvit.py:48-53,135; SURVEY.md App. A.
+// Activations are NHWC bf16 ([tokens, channels]), so every 1x1 conv / Linear is a plain GEMM and the
+// BHWC<->BCHW permutes of TinyVitBlock vanish.
+#include <string>
+#include <vector>
+#include <map>
+#include <string.h>
+#include <stdio.h>
+#include "common.h"
+#include "../../include/gg.h"
+
+namespace {
+
+struct TensorInfo { std::string name; int64_t offset; int64_t numel; int ndim; int64_t shape[4]; int kind; };
+struct DenseW { int t_w = -1, t_b = -1; int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, cin = 0; int64_t wn = 0, wt = 0; };
+struct BNP { int t_g = -1, t_b = -1; int64_t rm = 0, rv = 0; int cnt = 0; int C = 0; };
+struct DwW { int t_w = -1; int C = 0; int64_t taps = 0; };
+struct LNP { int t_g = -1, t_b = -1; int C = 0; };
+struct ConvBNDense { DenseW w; BNP bn; };
+struct ConvBNDw { DwW w; BNP bn; };
+struct MBConvL { ConvBNDense c1; ConvBNDw c2; ConvBNDense c3; };
+struct MergeL { ConvBNDense c1; ConvBNDw c2; ConvBNDense c3; };
+struct BlockL { int t_ab = -1; LNP ln1; DenseW qkv, proj; LNP ln2; DenseW fc1, fc2; ConvBNDw local; };
+struct StageL { MergeL merge; std::vector<BlockL> blocks; int C, heads, ws, res; };
+
+struct Model {
+    GgTinyVitCfg cfg;
+    std::vector<TensorInfo> tensors;
+    int64_t param_floats = 0, buffer_floats = 0, wcache_bytes = 0;
+    int num_counters = 0;
+    ConvBNDense pe1, pe2;
+    std::vector<MBConvL> mb;
+    StageL stages[3];
+    LNP head;
+    int res0;   // spatial size of stage 0 (img/4)
+};
+
+static int add_tensor(Model& m, const std::string& name, std::initializer_list<int64_t> shape, int kind) {
+    TensorInfo t;
+    t.name = name; t.kind = kind; t.ndim = (int)shape.size(); t.numel = 1;
+    int i = 0;
+    for (int j = 0; j < 4; ++j) t.shape[j] = 1;
+    for (auto s : shape) { t.shape[i++] = s; t.numel *= s; }
+    if (kind == GG_KIND_PARAM) { t.offset = m.param_floats; m.param_floats += gg_align(t.numel, 8); }
+    else if (kind == GG_KIND_BUFFER) { t.offset = m.buffer_floats; m.buffer_floats += gg_align(t.numel, 8); }
+    else { t.offset = m.num_counters++; }
+    m.tensors.push_back(t);
+    return (int)m.tensors.size() - 1;
+}
+static int64_t wc_alloc(Model& m, int64_t bytes) {
+    int64_t o = m.wcache_bytes;
+    m.wcache_bytes += gg_align(bytes, 256);
+    return o;
+}
+static void make_dense(Model& m, DenseW& w, const std::string& wname, int N, int cin, int taps, const std::string* bname, bool conv) {
+    w.N = N; w.cin = cin; w.taps = taps; w.K = cin * taps; w.Kp = (int)gg_align(w.K, 8); w.Np = (int)gg_align(N, 8);
+    if (conv) { const int ks = taps == 9 ? 3 : 1; w.t_w = add_tensor(m, wname, {N, cin, ks, ks}, GG_KIND_PARAM); }
+    else w.t_w = add_tensor(m, wname, {N, cin}, GG_KIND_PARAM);
+    if (bname) w.t_b = add_tensor(m, *bname, {N}, GG_KIND_PARAM);
+    w.wn = wc_alloc(m, (int64_t)N * w.Kp * 2);
+    w.wt = wc_alloc(m, (int64_t)w.Kp * w.Np * 2);
+}
+static void make_bn(Model& m, BNP& bn, const std::string& prefix, int C) {
+    bn.C = C;
+    bn.t_g = add_tensor(m, prefix + ".bn.weight", {C}, GG_KIND_PARAM);
+    bn.t_b = add_tensor(m, prefix + ".bn.bias", {C}, GG_KIND_PARAM);
+    bn.rm = m.tensors[add_tensor(m, prefix + ".bn.running_mean", {C}, GG_KIND_BUFFER)].offset;
+    bn.rv = m.tensors[add_tensor(m, prefix + ".bn.running_var", {C}, GG_KIND_BUFFER)].offset;
+    bn.cnt = (int)m.tensors[add_tensor(m, prefix + ".bn.num_batches_tracked", {}, GG_KIND_COUNTER)].offset;
+}
+static void make_convbn_dense(Model& m, ConvBNDense& c, const std::string& prefix, int cin, int cout, int taps) {
+    make_dense(m, c.w, prefix + ".conv.weight", cout, cin, taps, nullptr, true);
+    make_bn(m, c.bn, prefix, cout);
+}
+static void make_convbn_dw(Model& m, ConvBNDw& c, const std::string& prefix, int C) {
+    c.w.C = C;
+    c.w.t_w = add_tensor(m, prefix + ".conv.weight", {C, 1, 3, 3}, GG_KIND_PARAM);
+    c.w.taps = wc_alloc(m, (int64_t)9 * C * 4);
+    make_bn(m, c.bn, prefix, C);
+}
+static void make_ln(Model& m, LNP& l, const std::string& prefix, int C) {
+    l.C = C;
+    l.t_g = add_tensor(m, prefix + ".weight", {C}, GG_KIND_PARAM);
+    l.t_b = add_tensor(m, prefix + ".bias", {C}, GG_KIND_PARAM);
+}
+
+static int build_model(const GgTinyVitCfg* cfg, Model& m) {
+    GG_CHECK(cfg, "tinyvit: null config");
+    m.cfg = *cfg;
+    const int* d = cfg->embed_dims;
+    GG_CHECK(cfg->img_size > 0 && cfg->img_size % 32 == 0, "tinyvit: img_size must be a multiple of 32");
+    GG_CHECK(cfg->in_chans == 3, "tinyvit: in_chans must be 3");
+    for (int s = 0; s < 4; ++s) {
+        GG_CHECK(d[s] > 0 && d[s] % 16 == 0, "tinyvit: embed_dims[%d]=%d must be a multiple of 16", s, d[s]);
+        GG_CHECK(cfg->depths[s] > 0, "tinyvit: depths[%d] must be > 0", s);
+        if (s > 0) GG_CHECK(d[s] == cfg->num_heads[s] * 32, "tinyvit: head_dim must be 32 (dim %d, heads %d)", d[s], cfg->num_heads[s]);
+    }
+    m.res0 = cfg->img_size / 4;
+    make_convbn_dense(m, m.pe1, "patch_embed.conv1", cfg->in_chans, d[0] / 2, 9);
+    make_convbn_dense(m, m.pe2, "patch_embed.conv2", d[0] / 2, d[0], 9);
+    const int mid = (int)(d[0] * cfg->mbconv_expand_ratio);
+    GG_CHECK(mid % 8 == 0, "tinyvit: mbconv mid channels must be a multiple of 8");
+    m.mb.resize(cfg->depths[0]);
+    for (int i = 0; i < cfg->depths[0]; ++i) {
+        const std::string p = "stages.0.blocks." + std::to_string(i);
+        make_convbn_dense(m, m.mb[i].c1, p + ".conv1", d[0], mid, 1);
+        make_convbn_dw(m, m.mb[i].c2, p + ".conv2", mid);
+        make_convbn_dense(m, m.mb[i].c3, p + ".conv3", mid, d[0], 1);
+    }
+    int res = m.res0;
+    for (int s = 1; s < 4; ++s) {
+        StageL& st = m.stages[s - 1];
+        const int C = d[s], ws = cfg->window_sizes[s], nh = cfg->num_heads[s];
+        res /= 2;
+        st.C = C; st.heads = nh; st.ws = ws; st.res = res;
+        GG_CHECK(res % ws == 0, "tinyvit: stage %d map %d not divisible by window %d (padding path not built)", s, res, ws);
+        GG_CHECK(ws * ws <= 256 && ws <= 16, "tinyvit: window %d unsupported (max 16x16 tokens)", ws);
+        const std::string pm = "stages." + std::to_string(s) + ".downsample";
+        make_convbn_dense(m, st.merge.c1, pm + ".conv1", d[s - 1], C, 1);
+        make_convbn_dw(m, st.merge.c2, pm + ".conv2", C);
+        make_convbn_dense(m, st.merge.c3, pm + ".conv3", C, C, 1);
+        const int hid = (int)(C * cfg->mlp_ratio);
+        st.blocks.resize(cfg->depths[s]);
+        for (int i = 0; i < cfg->depths[s]; ++i) {
+            BlockL& b = st.blocks[i];
+            const std::string p = "stages." + std::to_string(s) + ".blocks." + std::to_string(i);
+            b.t_ab = add_tensor(m, p + ".attn.attention_biases", {nh, ws * ws}, GG_KIND_PARAM);
+            make_ln(m, b.ln1, p + ".attn.norm", C);
+            std::string bn = p + ".attn.qkv.bias";
+            make_dense(m, b.qkv, p + ".attn.qkv.weight", 3 * C, C, 1, &bn, false);
+            bn = p + ".attn.proj.bias";
+            make_dense(m, b.proj, p + ".attn.proj.weight", C, C, 1, &bn, false);
+            make_ln(m, b.ln2, p + ".mlp.norm", C);
+            bn = p + ".mlp.fc1.bias";
+            make_dense(m, b.fc1, p + ".mlp.fc1.weight", hid, C, 1, &bn, false);
+            bn = p + ".mlp.fc2.bias";
+            make_dense(m, b.fc2, p + ".mlp.fc2.weight", C, hid, 1, &bn, false);
+            make_convbn_dw(m, b.local, p + ".local_conv", C);
+        }
+    }
+    make_ln(m, m.head, "head.norm", d[3]);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- workspace plan
+struct Region { std::string name; int64_t offset, bytes; };
+struct Plan {
+    bool training = true;
+    bool dry = true;
+    std::vector<Region> regs;
+    std::map<std::string, int> index;
+    int64_t total = 0;
+    int64_t max_transient = 0;
+    int ring_next = 0;
+    int64_t ring_base = 0;
+    static constexpr int RING = 10;
+    // persistent: always gets its own storage; transient activations share a ring in inference mode
+    int64_t alloc(const std::string& name, int64_t bytes, bool transient = true) {
+        bytes = gg_align(std::max<int64_t>(bytes, 16), 256);
+        int64_t off;
+        if (!training && transient) {
+            max_transient = std::max(max_transient, bytes);
+            off = dry ? 0 : ring_base + (int64_t)(ring_next % RING) * max_transient;
+            ring_next++;
+        } else {
+            off = total;
+            total += bytes;
+        }
+        index[name] = (int)regs.size();
+        regs.push_back({name, off, bytes});
+        return off;
+    }
+};
+
+struct Act {   // offsets (bytes) of the saved tensors of one ConvNorm
+    int64_t y = 0, stat = 0;
+};
+struct MBAct { int64_t x, a1, a2, out; Act c1, c2, c3; };
+struct MergeAct { int64_t a1, a2, out; Act c1, c2, c3; };
+struct BlockAct { int64_t x0, a, mean1, rstd1, qkv, o, x1, x2, b, mean2, rstd2, hpre, h, x3; Act local; };
+struct Layout {
+    int64_t col1, a_pe1, col2, x_pe; Act pe1, pe2;
+    std::vector<MBAct> mb;
+    MergeAct merge[3];
+    std::vector<BlockAct> blocks[3];
+    int64_t pooled, mean_h, rstd_h;
+    // scratch
+    int64_t statpart, bnscratch, lnscratch, colsum, splitk, G[5];
+    int64_t gbytes;
+};
+
+static int64_t bn_part_floats(int64_t M, int C, int B, int Ho, int Wo, bool dw) {
+    const int rows = dw ? gg_dwconv_stat_rows(B, Ho, Wo, C) : gg_gemm_colstats_rows((int)M);
+    return (int64_t)rows * 2 * C;
+}
+
+static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
+    const GgTinyVitCfg& c = m.cfg;
+    const int* d = c.embed_dims;
+    const int H1 = c.img_size / 2, H0 = m.res0;
+    const int64_t M1 = (int64_t)B * H1 * H1, M0 = (int64_t)B * H0 * H0;
+    int64_t gmax = 0, statmax = 0, bnsmax = 0, lnsmax = 0, csmax = 0;
+    auto track = [&](int64_t elems) { gmax = std::max(gmax, elems * 2); };
+    auto bnreg = [&](const std::string& n, Act& a, int64_t M, int C, bool dw, int Bn, int Ho, int Wo) {
+        a.y = p.alloc(n + ".y", M * C * 2);
+        a.stat = p.alloc(n + ".stat", 2 * C * 4, false);
+        statmax = std::max(statmax, bn_part_floats(M, C, Bn, Ho, Wo, dw) * 4);
+        bnsmax = std::max(bnsmax, gg_bn_bwd_scratch_floats(M, C) * 4);
+        track(M * C);
+    };
+    L.col1 = p.alloc("patch_embed.col1", M1 * 32 * 2);
+    bnreg("patch_embed.conv1", L.pe1, M1, d[0] / 2, false, B, H1, H1);
+    L.a_pe1 = p.alloc("patch_embed.act1", M1 * (d[0] / 2) * 2);
+    L.col2 = p.alloc("patch_embed.col2", M0 * m.pe2.w.Kp * 2);
+    track(M0 * m.pe2.w.Kp); track(M1 * 32);
+    bnreg("patch_embed.conv2", L.pe2, M0, d[0], false, B, H0, H0);
+    L.x_pe = p.alloc("patch_embed.out", M0 * d[0] * 2);
+    const int mid = (int)(d[0] * c.mbconv_expand_ratio);
+    L.mb.resize(m.mb.size());
+    int64_t prev = L.x_pe;
+    for (size_t i = 0; i < m.mb.size(); ++i) {
+        const std::string n = "stages.0.blocks." + std::to_string(i);
+        MBAct& a = L.mb[i];
+        a.x = prev;
+        bnreg(n + ".conv1", a.c1, M0, mid, false, B, H0, H0);
+        a.a1 = p.alloc(n + ".act1", M0 * mid * 2);
+        bnreg(n + ".conv2", a.c2, M0, mid, true, B, H0, H0);
+        a.a2 = p.alloc(n + ".act2", M0 * mid * 2);
+        bnreg(n + ".conv3", a.c3, M0, d[0], false, B, H0, H0);
+        a.out = p.alloc(n + ".out", M0 * d[0] * 2);
+        prev = a.out;
+    }
+    int res = H0;
+    int64_t Mprev = M0;
+    for (int s = 0; s < 3; ++s) {
+        const StageL& st = m.stages[s];
+        const int C = st.C;
+        const int64_t M = (int64_t)B * st.res * st.res;
+        const std::string n = "stages." + std::to_string(s + 1) + ".downsample";
+        MergeAct& ma = L.merge[s];
+        bnreg(n + ".conv1", ma.c1, Mprev, C, false, B, res, res);
+        ma.a1 = p.alloc(n + ".act1", Mprev * C * 2);
+        bnreg(n + ".conv2", ma.c2, M, C, true, B, st.res, st.res);
+        ma.a2 = p.alloc(n + ".act2", M * C * 2);
+        bnreg(n + ".conv3", ma.c3, M, C, false, B, st.res, st.res);
+        ma.out = p.alloc(n + ".out", M * C * 2);
+        prev = ma.out;
+        const int hid = (int)(C * c.mlp_ratio);
+        L.blocks[s].resize(st.blocks.size());
+        for (size_t i = 0; i < st.blocks.size(); ++i) {
+            const std::string bn = "stages." + std::to_string(s + 1) + ".blocks." + std::to_string(i);
+            BlockAct& a = L.blocks[s][i];
+            a.x0 = prev;
+            a.a = p.alloc(bn + ".ln1", M * C * 2);
+            a.mean1 = p.alloc(bn + ".mean1", M * 4);
+            a.rstd1 = p.alloc(bn + ".rstd1", M * 4);
+            a.qkv = p.alloc(bn + ".qkv", M * 3 * C * 2);
+            a.o = p.alloc(bn + ".attn.out", M * C * 2);
+            a.x1 = p.alloc(bn + ".x1", M * C * 2);
+            bnreg(bn + ".local_conv", a.local, M, C, true, B, st.res, st.res);
+            a.x2 = p.alloc(bn + ".x2", M * C * 2);
+            a.b = p.alloc(bn + ".ln2", M * C * 2);
+            a.mean2 = p.alloc(bn + ".mean2", M * 4);
+            a.rstd2 = p.alloc(bn + ".rstd2", M * 4);
+            a.hpre = p.alloc(bn + ".fc1.pre", M * hid * 2);
+            a.h = p.alloc(bn + ".fc1.act", M * hid * 2);
+            a.x3 = p.alloc(bn + ".out", M * C * 2);
+            prev = a.x3;
+            track(M * hid); track(M * 3 * C);
+            lnsmax = std::max(lnsmax, gg_layernorm_bwd_scratch_floats(M, C) * 4);
+            csmax = std::max(csmax, gg_colsum_scratch_floats((int)M, hid) * 4);
+            csmax = std::max(csmax, gg_colsum_scratch_floats((int)M, 3 * C) * 4);
+        }
+        res = st.res;
+        Mprev = M;
+    }
+    L.pooled = p.alloc("head.pooled", (int64_t)B * d[3] * 4, false);
+    L.mean_h = p.alloc("head.mean", (int64_t)B * 4, false);
+    L.rstd_h = p.alloc("head.rstd", (int64_t)B * 4, false);
+    lnsmax = std::max(lnsmax, gg_layernorm_bwd_scratch_floats(B, d[3]) * 4);
+    L.statpart = p.alloc("scratch.statpart", statmax, false);
+    if (p.training) {
+        // dw wgrad scratch may exceed the BN scratch
+        int64_t dwmax = 0;
+        dwmax = std::max(dwmax, gg_dwconv_wgrad_scratch_floats(B, H0, H0, mid, 1) * 4);
+        for (int s = 0; s < 3; ++s) {
+            const int rin = s == 0 ? H0 : m.stages[s - 1].res;
+            dwmax = std::max(dwmax, gg_dwconv_wgrad_scratch_floats(B, rin, rin, m.stages[s].C, 2) * 4);
+            dwmax = std::max(dwmax, gg_dwconv_wgrad_scratch_floats(B, m.stages[s].res, m.stages[s].res, m.stages[s].C, 1) * 4);
+        }
+        L.bnscratch = p.alloc("scratch.bn", std::max(bnsmax, dwmax), false);
+        L.lnscratch = p.alloc("scratch.ln", lnsmax, false);
+        L.colsum = p.alloc("scratch.colsum", std::max<int64_t>(csmax, 1024), false);
+        L.splitk = p.alloc("scratch.splitk", (int64_t)64 << 20, false);
+        L.gbytes = gg_align(gmax, 256);
+        for (int i = 0; i < 5; ++i) L.G[i] = p.alloc("scratch.G" + std::to_string(i), L.gbytes, false);
+    }
+}
+static void plan_make(const Model& m, int B, bool training, Plan& p, Layout& L) {
+    p.training = training;
+    p.dry = true;
+    plan_build(m, B, p, L);
+    if (!training) {
+        Plan q;
+        q.training = false; q.dry = false; q.max_transient = p.max_transient;
+        q.ring_base = p.total;                     // persistent regions first, ring after
+        Layout L2;
+        plan_build(m, B, q, L2);
+        q.total = q.ring_base + (int64_t)Plan::RING * q.max_transient;
+        p = q; L = L2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- execution context
+struct Exec {
+    const Model* m; const Layout* L;
+    int B; bool training;
+    const float* params; float* buffers; int64_t* counters;
+    const char* wc; char* ws; hipStream_t st;
+    const float* drop;   // [slots][B] or null
+    float* grads; const uint8_t* trainable;
+    const float* P(int t) const { return params + m->tensors[t].offset; }
+    float* Gd(int t) const { return grads + m->tensors[t].offset; }
+    bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
+    bf16* A(int64_t off) const { return reinterpret_cast<bf16*>(ws + off); }
+    float* F(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
+    const bf16* Wn(const DenseW& w) const { return reinterpret_cast<const bf16*>(wc + w.wn); }
+    const bf16* Wt(const DenseW& w) const { return reinterpret_cast<const bf16*>(wc + w.wt); }
+    const float* Taps(const DwW& w) const { return reinterpret_cast<const float*>(wc + w.taps); }
+    const float* dropv(int slot) const { return drop ? drop + (int64_t)slot * B : nullptr; }
+};
+
+static int gemm(const Exec& e, const bf16* A, int64_t lda, const bf16* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
+                const float* bias = nullptr, int act = 0, void* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
+                const bf16* residual = nullptr, float* colstats = nullptr, const bf16* dact_pre = nullptr, int dact = 0) {
+    GgGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K;
+    g.bias = bias; g.act = act; g.preact = preact; g.rowscale = rowscale; g.rows_per_scale = rps;
+    g.residual = residual; g.ldr = ldc; g.colstats = colstats; g.dact_preact = dact_pre; g.dact = dact;
+    return gg_gemm_nt(&g, e.st);
+}
+
+// BatchNorm statistics for a ConvNorm whose producer wrote `nparts` partial rows into statpart
+static int bn_stats(const Exec& e, const BNP& bn, const Act& a, int nparts, int64_t count) {
+    if (e.training) {
+        GG_TRY(gg_bn_finalize(e.F(e.L->statpart), nparts, bn.C, count, e.m->cfg.bn_eps, e.m->cfg.bn_momentum, e.F(a.stat),
+                              e.buffers + bn.rm, e.buffers + bn.rv, e.st));
+    } else {
+        GG_TRY(gg_bn_eval_stat(e.buffers + bn.rm, e.buffers + bn.rv, bn.C, e.m->cfg.bn_eps, e.F(a.stat), e.st));
+    }
+    return 0;
+}
+// dense ConvNorm: y = A . Wn^T (+ partial stats) ; stat
+static int conv_dense_fwd(const Exec& e, const ConvBNDense& c, const Act& a, const bf16* A, int64_t lda, int64_t M) {
+    float* part = e.training ? e.F(e.L->statpart) : nullptr;
+    GG_TRY(gemm(e, A, lda, e.Wn(c.w), c.w.Kp, e.A(a.y), c.w.N, M, c.w.N, c.w.Kp, nullptr, 0, nullptr, nullptr, 0, nullptr, part));
+    return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
+}
+static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const bf16* x, int B, int H, int W, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    float* part = e.training ? e.F(e.L->statpart) : nullptr;
+    GG_TRY(gg_dwconv3x3_fwd(x, e.Taps(c.w), e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
+    return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+}
+static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
+                    const float* rowscale = nullptr, int rps = 0) {
+    return gg_bn_apply(e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, residual, rowscale, rps, out, e.st);
+}
+
+// ------------------------------------------------------------------------------------------- forward
+static int forward_impl(Exec& e, const float* x, float* out) {
+    const Model& m = *e.m; const Layout& L = *e.L; const GgTinyVitCfg& c = m.cfg;
+    const int B = e.B;
+    const int* d = c.embed_dims;
+    const int H = c.img_size, H1 = H / 2, H0 = m.res0;
+    const int64_t M1 = (int64_t)B * H1 * H1, M0 = (int64_t)B * H0 * H0;
+    // (num_batches_tracked counters are bumped by the host shim: they are int64 bookkeeping, not arithmetic)
+
+    // PatchEmbed: conv3x3 s2 + BN + GELU, conv3x3 s2 + BN
+    GG_TRY(gg_im2col_nchw3_f32(x, e.A(L.col1), B, H, H, 2, e.st));
+    GG_TRY(conv_dense_fwd(e, m.pe1, L.pe1, e.A(L.col1), 32, M1));
+    GG_TRY(bn_apply(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, e.A(L.a_pe1)));
+    GG_CHECK(m.pe2.w.Kp == m.pe2.w.K, "tinyvit: patch_embed.conv2 K=%d must be a multiple of 8", m.pe2.w.K);
+    GG_TRY(gg_im2col_nhwc_bf16(e.A(L.a_pe1), e.A(L.col2), B, H1, H1, d[0] / 2, 2, e.st));
+    GG_TRY(conv_dense_fwd(e, m.pe2, L.pe2, e.A(L.col2), m.pe2.w.Kp, M0));
+    GG_TRY(bn_apply(e, m.pe2.bn, L.pe2, M0, GG_ACT_NONE, e.A(L.x_pe)));
+
+    // stage 0: MBConv blocks
+    const int mid = (int)(d[0] * c.mbconv_expand_ratio);
+    int slot = 0;
+    const int rps0 = H0 * H0;
+    for (size_t i = 0; i < m.mb.size(); ++i) {
+        const MBConvL& l = m.mb[i]; const MBAct& a = L.mb[i];
+        GG_TRY(conv_dense_fwd(e, l.c1, a.c1, e.A(a.x), d[0], M0));
+        GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
+        GG_TRY(conv_dw_fwd(e, l.c2, a.c2, e.A(a.a1), B, H0, H0, 1));
+        GG_TRY(bn_apply(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, e.A(a.a2)));
+        GG_TRY(conv_dense_fwd(e, l.c3, a.c3, e.A(a.a2), mid, M0));
+        GG_TRY(bn_apply(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, e.A(a.out), e.A(a.x), e.training ? e.dropv(slot) : nullptr, rps0));
+        slot++;
+    }
+    int64_t prev = L.mb.empty() ? L.x_pe : L.mb.back().out;
+    int res = H0, Cprev = d[0];
+    int64_t Mprev = M0;
+    for (int s = 0; s < 3; ++s) {
+        const StageL& st = m.stages[s];
+        const int C = st.C;
+        const int64_t M = (int64_t)B * st.res * st.res;
+        const MergeAct& ma = L.merge[s];
+        // PatchMerging
+        GG_TRY(conv_dense_fwd(e, st.merge.c1, ma.c1, e.A(prev), Cprev, Mprev));
+        GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Mprev, GG_ACT_GELU, e.A(ma.a1)));
+        GG_TRY(conv_dw_fwd(e, st.merge.c2, ma.c2, e.A(ma.a1), B, res, res, 2));
+        GG_TRY(bn_apply(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, e.A(ma.a2)));
+        GG_TRY(conv_dense_fwd(e, st.merge.c3, ma.c3, e.A(ma.a2), C, M));
+        GG_TRY(bn_apply(e, st.merge.c3.bn, ma.c3, M, GG_ACT_NONE, e.A(ma.out)));
+        const int hid = (int)(C * c.mlp_ratio);
+        const int rps = st.res * st.res;
+        for (size_t i = 0; i < st.blocks.size(); ++i) {
+            const BlockL& l = st.blocks[i]; const BlockAct& a = L.blocks[s][i];
+            const float* s1 = e.training ? e.dropv(slot) : nullptr;
+            const float* s2 = e.training ? e.dropv(slot + 1) : nullptr;
+            slot += 2;
+            GG_TRY(gg_layernorm_fwd(e.A(a.x0), 0, e.P(l.ln1.t_g), e.P(l.ln1.t_b), M, C, c.ln_eps, e.A(a.a), 0, e.F(a.mean1), e.F(a.rstd1), e.st));
+            GG_TRY(gemm(e, e.A(a.a), C, e.Wn(l.qkv), l.qkv.Kp, e.A(a.qkv), 3 * C, M, 3 * C, l.qkv.Kp, e.P(l.qkv.t_b)));
+            GgAttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.qkv = e.A(a.qkv); at.ld = 3 * C; at.q_off = 0; at.k_off = 32; at.v_off = 64; at.head_stride = 96; at.head_dim = 32;
+            at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
+            at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
+            at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
+            at.bias = e.P(l.t_ab); at.scale = 0.17677669529663687f;   // 32^-0.5
+            at.out = e.A(a.o); at.ldo = C;
+            GG_TRY(gg_attention_fwd(&at, e.st));
+            GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
+            GG_TRY(conv_dw_fwd(e, l.local, a.local, e.A(a.x1), B, st.res, st.res, 1));
+            GG_TRY(bn_apply(e, l.local.bn, a.local, M, GG_ACT_NONE, e.A(a.x2)));
+            GG_TRY(gg_layernorm_fwd(e.A(a.x2), 0, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), 0, e.F(a.mean2), e.F(a.rstd2), e.st));
+            GG_TRY(gemm(e, e.A(a.b), C, e.Wn(l.fc1), l.fc1.Kp, e.A(a.h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU,
+                        e.training ? (void*)e.A(a.hpre) : nullptr));
+            GG_TRY(gemm(e, e.A(a.h), hid, e.Wn(l.fc2), l.fc2.Kp, e.A(a.x3), C, M, C, l.fc2.Kp, e.P(l.fc2.t_b), 0, nullptr, s2, rps, e.A(a.x2)));
+            prev = a.x3;
+        }
+        if (st.blocks.empty()) prev = ma.out;
+        res = st.res; Cprev = C; Mprev = M;
+    }
+    // head: global average pool -> LayerNorm
+    const int T = res * res, C3 = d[3];
+    GG_TRY(gg_token_mean_fwd(e.A(prev), e.F(L.pooled), B, T, C3, e.st));
+    GG_TRY(gg_layernorm_fwd(e.F(L.pooled), 1, e.P(m.head.t_g), e.P(m.head.t_b), B, C3, c.ln_eps, out, 1, e.F(L.mean_h), e.F(L.rstd_h), e.st));
+    return 0;
+}
+
+__global__ void conv_wgrad_scatter_kernel(const float* __restrict__ src, int N, int Kp, int cin, int taps, float* __restrict__ grad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over N * cin * taps (grad layout (co, ci, tap))
+    if (i >= N * cin * taps) return;
+    const int tap = i % taps, ci = (i / taps) % cin, co = i / (taps * cin);
+    grad[i] += src[(int64_t)co * Kp + tap * cin + ci];
+}
+static int conv_wgrad_scatter(const float* src, int N, int Kp, int cin, int taps, float* grad, hipStream_t st) {
+    const int n = N * cin * taps;
+    hipLaunchKernelGGL(conv_wgrad_scatter_kernel, dim3((unsigned)gg_cdiv(n, 256)), dim3(256), 0, st, src, N, Kp, cin, taps, grad);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- backward helpers
+// wgrad of a dense weight: dW[N,K] (+)= dY^T[N,M] . X[M,K]   (transposes into scratch, split-K over M)
+static int dense_wgrad(const Exec& e, const DenseW& w, const bf16* X, int64_t ldx, const bf16* dY, int64_t ldy, int64_t M,
+                       const float* rowscale, int rps, bf16* T0, bf16* T1, bool conv_reorder) {
+    const int64_t Mp = gg_align(M, 8);
+    const int K = conv_reorder ? w.Kp : w.K;   // im2col'd operand has Kp columns
+    // X^T [K, Mp], dY^T [N, Mp]; pad columns (M..Mp) must be zero
+    if (Mp != M) {
+        GG_HIP(hipMemsetAsync(T0, 0, (size_t)K * Mp * 2, e.st));
+        GG_HIP(hipMemsetAsync(T1, 0, (size_t)w.N * Mp * 2, e.st));
+    }
+    GG_TRY(gg_transpose_bf16(X, ldx, T0, Mp, (int)M, K, nullptr, 0, e.st));
+    GG_TRY(gg_transpose_bf16(dY, ldy, T1, Mp, (int)M, w.N, rowscale, rps, e.st));
+    const int tiles = (int)(gg_cdiv(w.N, 128) * gg_cdiv(K, 128));
+    int split = (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(1024, tiles), gg_cdiv(Mp, 2048)));
+    const int64_t part_bytes = (int64_t)split * w.N * K * 4;
+    if (part_bytes > ((int64_t)64 << 20)) split = (int)std::max<int64_t>(1, ((int64_t)64 << 20) / ((int64_t)w.N * K * 4));
+    GgGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = T1; g.lda = Mp; g.B = T0; g.ldb = Mp; g.M = w.N; g.N = K; g.K = (int)Mp;
+    g.C = e.F(e.L->splitk); g.ldc = K; g.out_f32 = 1; g.split_k = split;
+    if (split == 1) {
+        // single pass still goes through the f32 scratch so that the accumulate + layout fix-up is uniform
+        g.split_k = 1;
+    }
+    GG_TRY(gg_gemm_nt(&g, e.st));
+    // partial layout [split][N][K] -> grad layout
+    float* gw = e.Gd(w.t_w);
+    if (!conv_reorder) {
+        GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), gw, (int64_t)w.N * K, split, 1, 1.0f, e.st));
+    } else {
+        // reduce in place, then scatter (co,(ky,kx,ci)) -> (co,ci,ky,kx)
+        GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), e.F(e.L->splitk), (int64_t)w.N * K, split, 0, 1.0f, e.st));
+        GG_TRY(conv_wgrad_scatter(e.F(e.L->splitk), w.N, K, w.cin, w.taps, gw, e.st));
+    }
+    return 0;
+}
+static int bias_grad(const Exec& e, int t_b, const bf16* dY, int64_t ld, int64_t M, int N, const float* rowscale, int rps) {
+    return gg_colsum_bf16(dY, ld, (int)M, N, rowscale, rps, e.F(e.L->colsum), e.Gd(t_b), 1, e.st);
+}
+// BatchNorm backward of one ConvNorm: dout (grad wrt post-activation output) -> dy (grad wrt the conv output)
+static int bn_bwd(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz, bf16* dy,
+                  const bf16* residual = nullptr, const float* rowscale = nullptr, int rps = 0) {
+    const bool tr = e.tr(bn.t_g);
+    return gg_bn_bwd(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, residual, rowscale, rps, dz, dy,
+                     e.F(e.L->bnscratch), tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
+}
+
+static int backward_impl(Exec& e, const float* d_out) {
+    const Model& m = *e.m; const Layout& L = *e.L; const GgTinyVitCfg& c = m.cfg;
+    const int B = e.B;
+    const int* d = c.embed_dims;
+    const int H = c.img_size, H1 = H / 2, H0 = m.res0;
+    const int64_t M1 = (int64_t)B * H1 * H1, M0 = (int64_t)B * H0 * H0;
+    bf16* G0 = e.A(L.G[0]); bf16* G1 = e.A(L.G[1]); bf16* G2 = e.A(L.G[2]); bf16* G3 = e.A(L.G[3]); bf16* G4 = e.A(L.G[4]);
+
+    // drop-path slot bookkeeping mirrors forward
+    int nslots = (int)m.mb.size();
+    for (int s = 0; s < 3; ++s) nslots += 2 * (int)m.stages[s].blocks.size();
+    int slot = nslots;
+
+    // ---- head: LayerNorm (f32) + average pool ----
+    const int res3 = m.stages[2].res, T = res3 * res3, C3 = d[3];
+    {
+        const bool tr = e.tr(m.head.t_g);
+        float* dpool = reinterpret_cast<float*>(G1);
+        GG_TRY(gg_layernorm_bwd(d_out, e.F(L.pooled), 1, e.F(L.mean_h), e.F(L.rstd_h), e.P(m.head.t_g), B, C3, nullptr, dpool,
+                                e.F(L.lnscratch), tr ? e.Gd(m.head.t_g) : nullptr, tr ? e.Gd(m.head.t_b) : nullptr, 1, e.st));
+        GG_TRY(gg_token_mean_bwd(dpool, G0, B, T, C3, e.st));
+    }
+    bf16* dx = G0;      // gradient w.r.t. the current activation (block output), bf16 [M, C]
+    // free buffers for the block-level temporaries
+    for (int s = 2; s >= 0; --s) {
+        const StageL& st = m.stages[s];
+        const int C = st.C;
+        const int64_t M = (int64_t)B * st.res * st.res;
+        const int hid = (int)(C * c.mlp_ratio);
+        const int rps = st.res * st.res;
+        const int rin = s == 0 ? H0 : m.stages[s - 1].res;
+        const int Cin = s == 0 ? d[0] : m.stages[s - 1].C;
+        const int64_t Min = (int64_t)B * rin * rin;
+        for (int i = (int)st.blocks.size() - 1; i >= 0; --i) {
+            const BlockL& l = st.blocks[i]; const BlockAct& a = L.blocks[s][i];
+            slot -= 2;
+            const float* s1 = e.dropv(slot);
+            const float* s2 = e.dropv(slot + 1);
+            // dx == d(x3).  MLP branch: x3 = x2 + s2*(fc2(gelu(fc1(ln2(x2)))))
+            bf16* t_a = (dx == G0) ? G1 : G0;    // scratch distinct from dx
+            bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+            // dh = (s2*dx) . W2  * gelu'(hpre)                      [M, hid]
+            GG_TRY(gemm(e, dx, C, e.Wt(l.fc2), l.fc2.Np, t_b, hid, M, hid, C, nullptr, 0, nullptr, s2, rps, nullptr, nullptr, e.A(a.hpre), GG_ACT_GELU));
+            if (e.tr(l.fc2.t_w)) {
+                GG_TRY(dense_wgrad(e, l.fc2, e.A(a.h), hid, dx, C, M, s2, rps, t_c, t_d, false));
+                GG_TRY(bias_grad(e, l.fc2.t_b, dx, C, M, C, s2, rps));
+            }
+            // db = dh . W1                                           [M, C]
+            GG_TRY(gemm(e, t_b, hid, e.Wt(l.fc1), l.fc1.Np, t_a, C, M, C, hid));
+            if (e.tr(l.fc1.t_w)) {
+                GG_TRY(dense_wgrad(e, l.fc1, e.A(a.b), C, t_b, hid, M, nullptr, 0, t_c, t_d, false));
+                GG_TRY(bias_grad(e, l.fc1.t_b, t_b, hid, M, hid, nullptr, 0));
+            }
+            // dx2 = LN2bwd(db) + dx                                   -> t_b
+            {
+                const bool tr = e.tr(l.ln2.t_g);
+                GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x2), 0, e.F(a.mean2), e.F(a.rstd2), e.P(l.ln2.t_g), M, C, dx, t_b, e.F(L.lnscratch),
+                                        tr ? e.Gd(l.ln2.t_g) : nullptr, tr ? e.Gd(l.ln2.t_b) : nullptr, 1, e.st));
+            }
+            // local_conv: x2 = BN(dw(x1)).  dy -> t_a (dz scratch t_c), dx1 = dwT(dy) -> t_c
+            GG_TRY(bn_bwd(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, t_c, t_a));
+            if (e.tr(l.local.w.t_w))
+                GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.x1), t_a, B, st.res, st.res, C, 1, e.F(L.bnscratch), e.Gd(l.local.w.t_w), 1, e.st));
+            GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.local.w), t_c, B, st.res, st.res, C, 1, e.st));
+            bf16* dx1 = t_c;
+            // attention branch: x1 = x0 + s1*(proj(o)+b)
+            // do = (s1*dx1) . Wproj                                   -> t_a  [M, C]
+            GG_TRY(gemm(e, dx1, C, e.Wt(l.proj), l.proj.Np, t_a, C, M, C, C, nullptr, 0, nullptr, s1, rps));
+            if (e.tr(l.proj.t_w)) {
+                GG_TRY(dense_wgrad(e, l.proj, e.A(a.o), C, dx1, C, M, s1, rps, t_b, t_d, false));
+                GG_TRY(bias_grad(e, l.proj.t_b, dx1, C, M, C, s1, rps));
+            }
+            // dqkv                                                     -> t_b  [M, 3C]
+            GgAttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.qkv = e.A(a.qkv); at.ld = 3 * C; at.q_off = 0; at.k_off = 32; at.v_off = 64; at.head_stride = 96; at.head_dim = 32;
+            at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
+            at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
+            at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
+            at.bias = e.P(l.t_ab); at.scale = 0.17677669529663687f;
+            at.dout = t_a; at.lddo = C; at.dqkv = t_b;
+            at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
+            GG_TRY(gg_attention_bwd(&at, e.st));
+            // da = dqkv . Wqkv                                         -> t_a  [M, C]
+            GG_TRY(gemm(e, t_b, 3 * C, e.Wt(l.qkv), l.qkv.Np, t_a, C, M, C, 3 * C));
+            if (e.tr(l.qkv.t_w)) {
+                bf16* t_e = dx;   // the old block-output gradient is dead by now
+                GG_TRY(dense_wgrad(e, l.qkv, e.A(a.a), C, t_b, 3 * C, M, nullptr, 0, t_e, t_d, false));
+                GG_TRY(bias_grad(e, l.qkv.t_b, t_b, 3 * C, M, 3 * C, nullptr, 0));
+            }
+            // dx0 = LN1bwd(da) + dx1                                   -> old dx buffer
+            {
+                const bool tr = e.tr(l.ln1.t_g);
+                GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x0), 0, e.F(a.mean1), e.F(a.rstd1), e.P(l.ln1.t_g), M, C, dx1, dx, e.F(L.lnscratch),
+                                        tr ? e.Gd(l.ln1.t_g) : nullptr, tr ? e.Gd(l.ln1.t_b) : nullptr, 1, e.st));
+            }
+            (void)hid;
+        }
+        // ---- PatchMerging backward: out = BN3(conv3(a2)); a2 = gelu(BN2(dw s2(a1))); a1 = gelu(BN1(conv1(x))) ----
+        const MergeAct& ma = L.merge[s];
+        bf16* t_a = (dx == G0) ? G1 : G0;
+        bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+        const int64_t xin = s == 0 ? (L.mb.empty() ? L.x_pe : L.mb.back().out)
+                                   : (L.blocks[s - 1].empty() ? L.merge[s - 1].out : L.blocks[s - 1].back().x3);
+        GG_TRY(bn_bwd(e, st.merge.c3.bn, ma.c3, M, GG_ACT_NONE, dx, t_b, t_a));                         // dy3 -> t_a
+        if (e.tr(st.merge.c3.w.t_w)) GG_TRY(dense_wgrad(e, st.merge.c3.w, e.A(ma.a2), C, t_a, C, M, nullptr, 0, t_b, t_c, false));
+        GG_TRY(gemm(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_b, C, M, C, C));                 // da2 -> t_b
+        GG_TRY(bn_bwd(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, t_b, t_c, t_a));                          // dy2 -> t_a
+        if (e.tr(st.merge.c2.w.t_w))
+            GG_TRY(gg_dwconv3x3_bwd_weight(e.A(ma.a1), t_a, B, rin, rin, C, 2, e.F(L.bnscratch), e.Gd(st.merge.c2.w.t_w), 1, e.st));
+        GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(st.merge.c2.w), t_b, B, rin, rin, C, 2, e.st));        // da1 -> t_b [Min, C]
+        GG_TRY(bn_bwd(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, t_b, t_c, t_a));                        // dy1 -> t_a
+        if (e.tr(st.merge.c1.w.t_w)) GG_TRY(dense_wgrad(e, st.merge.c1.w, e.A(xin), Cin, t_a, C, Min, nullptr, 0, t_b, t_c, false));
+        GG_TRY(gemm(e, t_a, C, e.Wt(st.merge.c1.w), st.merge.c1.w.Np, dx, Cin, Min, Cin, C));             // dx_in -> dx
+    }
+    // ---- stage 0: MBConv backward ----
+    const int mid = (int)(d[0] * c.mbconv_expand_ratio);
+    const int rps0 = H0 * H0;
+    for (int i = (int)m.mb.size() - 1; i >= 0; --i) {
+        const MBConvL& l = m.mb[i]; const MBAct& a = L.mb[i];
+        slot -= 1;
+        const float* s0 = e.dropv(slot);
+        bf16* t_a = (dx == G0) ? G1 : G0;
+        bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+        // out = gelu(x + s*BN3(y3)):  dz(=dpre, also the skip gradient) -> t_b, dy3 -> t_a
+        GG_TRY(bn_bwd(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, dx, t_b, t_a, e.A(a.x), s0, rps0));
+        if (e.tr(l.c3.w.t_w)) GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
+        GG_TRY(gemm(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_c, mid, M0, mid, d[0]));                     // da2 -> t_c [M0, mid]
+        GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                                  // dy2 -> t_a
+        if (e.tr(l.c2.w.t_w))
+            GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+        GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));               // da1 -> t_c
+        GG_TRY(bn_bwd(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d, t_a));                                  // dy1 -> t_a
+        if (e.tr(l.c1.w.t_w)) GG_TRY(dense_wgrad(e, l.c1.w, e.A(a.x), d[0], t_a, mid, M0, nullptr, 0, t_c, t_d, false));
+        // dx_in = dy1 . W1 + dpre
+        GG_TRY(gemm(e, t_a, mid, e.Wt(l.c1.w), l.c1.w.Np, dx, d[0], M0, d[0], mid, nullptr, 0, nullptr, nullptr, 0, t_b));
+    }
+    // ---- PatchEmbed backward (dgrad only to conv1's output; the image needs no gradient) ----
+    {
+        bf16* t_a = (dx == G0) ? G1 : G0;
+        bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+        const bool need1 = e.tr(m.pe1.w.t_w) || e.tr(m.pe1.bn.t_g);
+        const bool need2 = e.tr(m.pe2.w.t_w) || e.tr(m.pe2.bn.t_g) || need1;
+        if (need2) {
+            GG_TRY(bn_bwd(e, m.pe2.bn, L.pe2, M0, GG_ACT_NONE, dx, t_b, t_a));                             // dy2 -> t_a [M0, C0]
+            if (e.tr(m.pe2.w.t_w)) GG_TRY(dense_wgrad(e, m.pe2.w, e.A(L.col2), m.pe2.w.Kp, t_a, d[0], M0, nullptr, 0, t_b, t_c, true));
+        }
+        if (need1) {
+            GG_TRY(gemm(e, t_a, d[0], e.Wt(m.pe2.w), m.pe2.w.Np, t_b, m.pe2.w.Kp, M0, m.pe2.w.Kp, d[0])); // dcol2 -> t_b
+            GG_TRY(gg_col2im_nhwc_bf16(t_b, t_c, B, H1, H1, d[0] / 2, 2, e.st));                           // da1 -> t_c [M1, C0/2]
+            GG_TRY(bn_bwd(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, t_c, t_d, t_a));                             // dy1 -> t_a
+            if (e.tr(m.pe1.w.t_w)) GG_TRY(dense_wgrad(e, m.pe1.w, e.A(L.col1), 32, t_a, d[0] / 2, M1, nullptr, 0, t_b, t_c, true));
+        }
+    }
+    return 0;
+}
+
+__global__ void repack_weight_kernel(const float* __restrict__ src, int N, int cin, int taps, bf16* __restrict__ Wn, int ldn,
+                                     bf16* __restrict__ Wt, int ldt) {
+    const int K = cin * taps;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * K) return;
+    const int co = i / K, k = i % K;
+    const int tap = k / cin, ci = k % cin;
+    const bf16 v = (bf16)src[((int64_t)co * cin + ci) * taps + tap];
+    Wn[(int64_t)co * ldn + k] = v;
+    Wt[(int64_t)k * ldt + co] = v;
+}
+__global__ void repack_taps_kernel(const float* __restrict__ src, int C, float* __restrict__ taps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * C) return;
+    const int t = i / C, c = i % C;
+    taps[i] = src[c * 9 + t];
+}
+static int repack_dense(const DenseW& w, const float* params, const Model& m, char* wc, hipStream_t st) {
+    const int n = w.N * w.K;
+    hipLaunchKernelGGL(repack_weight_kernel, dim3((unsigned)gg_cdiv(n, 256)), dim3(256), 0, st, params + m.tensors[w.t_w].offset, w.N,
+                       w.cin, w.taps, reinterpret_cast<bf16*>(wc + w.wn), w.Kp, reinterpret_cast<bf16*>(wc + w.wt), w.Np);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+static int repack_dw(const DwW& w, const float* params, const Model& m, char* wc, hipStream_t st) {
+    hipLaunchKernelGGL(repack_taps_kernel, dim3((unsigned)gg_cdiv(9 * w.C, 256)), dim3(256), 0, st, params + m.tensors[w.t_w].offset, w.C,
+                       reinterpret_cast<float*>(wc + w.taps));
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- C ABI
+extern "C" int gg_tinyvit_num_tensors(const GgTinyVitCfg* cfg) {
+    Model m;
+    if (build_model(cfg, m)) return -1;
+    return (int)m.tensors.size();
+}
+extern "C" int gg_tinyvit_tensor_info(const GgTinyVitCfg* cfg, int i, char* name, int name_cap, int64_t* offset, int64_t* numel,
+                                      int* ndim, int64_t* shape4, int* kind) {
+    Model m;
+    GG_TRY(build_model(cfg, m));
+    GG_CHECK(i >= 0 && i < (int)m.tensors.size(), "gg_tinyvit_tensor_info: index %d out of range", i);
+    const TensorInfo& t = m.tensors[i];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", t.name.c_str());
+    if (offset) *offset = t.offset;
+    if (numel) *numel = t.numel;
+    if (ndim) *ndim = t.ndim;
+    if (shape4) for (int j = 0; j < 4; ++j) shape4[j] = t.shape[j];
+    if (kind) *kind = t.kind;
+    return 0;
+}
+extern "C" int64_t gg_tinyvit_param_floats(const GgTinyVitCfg* cfg) { Model m; return build_model(cfg, m) ? -1 : m.param_floats; }
+extern "C" int64_t gg_tinyvit_buffer_floats(const GgTinyVitCfg* cfg) { Model m; return build_model(cfg, m) ? -1 : m.buffer_floats; }
+extern "C" int gg_tinyvit_num_counters(const GgTinyVitCfg* cfg) { Model m; return build_model(cfg, m) ? -1 : m.num_counters; }
+extern "C" int gg_tinyvit_num_drop_slots(const GgTinyVitCfg* cfg) {
+    Model m;
+    if (build_model(cfg, m)) return -1;
+    int n = (int)m.mb.size();
+    for (int s = 0; s < 3; ++s) n += 2 * (int)m.stages[s].blocks.size();
+    return n;
+}
+extern "C" int64_t gg_tinyvit_wcache_bytes(const GgTinyVitCfg* cfg) { Model m; return build_model(cfg, m) ? -1 : m.wcache_bytes; }
+extern "C" int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training) {
+    Model m;
+    if (build_model(cfg, m)) return -1;
+    if (batch <= 0) { gg_set_error("gg_tinyvit_workspace_bytes: batch must be > 0"); return -1; }
+    Plan p; Layout L;
+    plan_make(m, batch, training != 0, p, L);
+    return p.total;
+}
+extern "C" int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes) {
+    Model m;
+    GG_TRY(build_model(cfg, m));
+    Plan p; Layout L;
+    plan_make(m, batch, true, p, L);
+    auto it = p.index.find(name);
+    GG_CHECK(it != p.index.end(), "gg_tinyvit_activation_info: no activation named '%s'", name);
+    if (offset) *offset = p.regs[it->second].offset;
+    if (bytes) *bytes = p.regs[it->second].bytes;
+    return 0;
+}
+extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream) {
+    Model m;
+    GG_TRY(build_model(cfg, m));
+    GG_CHECK(params && wcache, "gg_tinyvit_refresh_weights: null pointer");
+    char* wc = (char*)wcache;
+    hipStream_t st = (hipStream_t)stream;
+    GG_TRY(repack_dense(m.pe1.w, params, m, wc, st));
+    GG_TRY(repack_dense(m.pe2.w, params, m, wc, st));
+    for (auto& l : m.mb) {
+        GG_TRY(repack_dense(l.c1.w, params, m, wc, st));
+        GG_TRY(repack_dw(l.c2.w, params, m, wc, st));
+        GG_TRY(repack_dense(l.c3.w, params, m, wc, st));
+    }
+    for (int s = 0; s < 3; ++s) {
+        GG_TRY(repack_dense(m.stages[s].merge.c1.w, params, m, wc, st));
+        GG_TRY(repack_dw(m.stages[s].merge.c2.w, params, m, wc, st));
+        GG_TRY(repack_dense(m.stages[s].merge.c3.w, params, m, wc, st));
+        for (auto& b : m.stages[s].blocks) {
+            GG_TRY(repack_dense(b.qkv, params, m, wc, st));
+            GG_TRY(repack_dense(b.proj, params, m, wc, st));
+            GG_TRY(repack_dense(b.fc1, params, m, wc, st));
+            GG_TRY(repack_dense(b.fc2, params, m, wc, st));
+            GG_TRY(repack_dw(b.local.w, params, m, wc, st));
+        }
+    }
+    return 0;
+}
+extern "C" int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int training, const float* params, float* buffers,
+                                  int64_t* counters, const void* wcache, const float* x, const float* drop_scales, void* workspace,
+                                  float* out, void* stream) {
+    Model m;
+    GG_TRY(build_model(cfg, m));
+    GG_CHECK(batch > 0 && params && buffers && wcache && x && workspace && out, "gg_tinyvit_forward: null pointer / bad batch");
+    GG_CHECK(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, "gg_tinyvit_forward: workspace/wcache must be 256-byte aligned");
+    Plan p; Layout L;
+    plan_make(m, batch, training != 0, p, L);
+    Exec e;
+    e.m = &m; e.L = &L; e.B = batch; e.training = training != 0; e.params = params; e.buffers = buffers; e.counters = counters;
+    e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = nullptr;
+    e.trainable = nullptr;
+    return forward_impl(e, x, out);
+}
+extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,
+                                   void* workspace, const float* d_out, float* grads, const uint8_t* trainable, void* stream) {
+    Model m;
+    GG_TRY(build_model(cfg, m));
+    GG_CHECK(batch > 0 && params && wcache && workspace && d_out && grads, "gg_tinyvit_backward: null pointer / bad batch");
+    Plan p; Layout L;
+    plan_make(m, batch, true, p, L);
+    Exec e;
+    e.m = &m; e.L = &L; e.B = batch; e.training = true; e.params = params; e.buffers = nullptr; e.counters = nullptr;
+    e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = grads;
+    e.trainable = trainable;
+    return backward_impl(e, d_out);
+}

@@ -1,0 +1,412 @@
+"""Drop-in for the reference's ``models/tinyvit.py`` (``TinyViTAdapter``, :17-150): same constructor, same
+``.config`` / ``.vision_model.encoder.layers`` shims, same ``freeze_*`` / ``train`` semantics, same forward return
+(``pooler_output`` (B,C), ``last_hidden_state`` (B,1,C)), same ``backbone.*`` state-dict keys (timm names,
+SURVEY.md App. A.5) -- but the encoder itself is the HIP runtime in ``csrc/tinyvit.hip`` (one C call for the
+whole forward, one for the whole backward) instead of ``timm.create_model``.
+
+Parameters are views into ONE flat fp32 device buffer (gradients likewise), which is what the RCCL gradient
+all-reduce and the fused AdamW kernel operate on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import warnings
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+# timm variants; drop_path_rate is timm's per-variant default
+VARIANTS = {
+    "tiny_vit_5m_224": dict(embed_dims=(64, 128, 160, 320), num_heads=(2, 4, 5, 10), window_sizes=(7, 7, 14, 7),
+                            img_size=224, drop_path_rate=0.0),
+    "tiny_vit_11m_224": dict(embed_dims=(64, 128, 256, 448), num_heads=(2, 4, 8, 14), window_sizes=(7, 7, 14, 7),
+                             img_size=224, drop_path_rate=0.1),
+    "tiny_vit_21m_224": dict(embed_dims=(96, 192, 384, 576), num_heads=(3, 6, 12, 18), window_sizes=(7, 7, 14, 7),
+                             img_size=224, drop_path_rate=0.2),
+    "tiny_vit_21m_384": dict(embed_dims=(96, 192, 384, 576), num_heads=(3, 6, 12, 18), window_sizes=(12, 12, 24, 12),
+                             img_size=384, drop_path_rate=0.1),
+    "tiny_vit_21m_512": dict(embed_dims=(96, 192, 384, 576), num_heads=(3, 6, 12, 18), window_sizes=(16, 16, 32, 16),
+                             img_size=512, drop_path_rate=0.1),
+}
+DEPTHS = (2, 2, 6, 2)
+
+
+def make_cfg(model_name: str, **overrides) -> tuple:
+    base = model_name.split(".")[0]
+    if base not in VARIANTS:
+        raise ValueError(f"unknown TinyViT variant '{model_name}' (known: {sorted(VARIANTS)})")
+    v = dict(VARIANTS[base])
+    v.update(overrides)
+    depths = tuple(v.get("depths", DEPTHS))
+    c = L.TinyVitCfg()
+    c.img_size, c.in_chans = v["img_size"], 3
+    c.embed_dims = (C.c_int * 4)(*v["embed_dims"])
+    c.depths = (C.c_int * 4)(*depths)
+    c.num_heads = (C.c_int * 4)(*v["num_heads"])
+    c.window_sizes = (C.c_int * 4)(*v["window_sizes"])
+    c.mlp_ratio, c.mbconv_expand_ratio = 4.0, 4.0
+    c.bn_eps, c.ln_eps, c.bn_momentum = 1e-5, 1e-5, 0.1
+    return c, v, depths
+
+
+class _Tree(nn.Module):
+    """Anonymous container mirroring timm's module nesting so that state-dict keys come out with timm names."""
+
+    def __iter__(self):
+        return iter(self.children())
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __getitem__(self, i):
+        return list(self.children())[i]
+
+
+def _tensor_table(cfg: L.TinyVitCfg):
+    lib = L.lib()
+    n = lib.gg_tinyvit_num_tensors(C.byref(cfg))
+    if n < 0:
+        raise L.GgError(lib.gg_last_error().decode())
+    out = []
+    name = C.create_string_buffer(256)
+    off, numel, ndim, kind = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+    shape = (C.c_int64 * 4)()
+    for i in range(n):
+        L.check(lib.gg_tinyvit_tensor_info(C.byref(cfg), i, name, 256, C.byref(off), C.byref(numel), C.byref(ndim), shape,
+                                           C.byref(kind)), "gg_tinyvit_tensor_info")
+        out.append(dict(name=name.value.decode(), offset=off.value, numel=numel.value,
+                        shape=tuple(shape[j] for j in range(ndim.value)), kind=kind.value, index=i))
+    return out
+
+
+def _init_tensor(name: str, shape, g: torch.Generator) -> torch.Tensor:
+    """timm TinyVit init: Linear trunc_normal(.02)/0, LayerNorm 1/0, Conv2d torch default, BN 1/0 except the last
+    BN of an MBConv (0), attention biases 0."""
+    if name.endswith("conv.weight"):
+        fan_in = shape[1] * shape[2] * shape[3]
+        return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+    if name.endswith("bn.weight"):
+        return torch.zeros(shape) if (name.startswith("stages.0.") and ".conv3." in name) else torch.ones(shape)
+    if name.endswith("norm.weight"):
+        return torch.ones(shape)
+    if name.endswith("attention_biases") or name.endswith(".bias"):
+        return torch.zeros(shape)
+    if name.endswith(".weight"):
+        t = torch.empty(shape)
+        nn.init.trunc_normal_(t, std=0.02, generator=g)
+        return t
+    raise AssertionError(name)
+
+
+class TinyVitBackbone(_Tree):
+    """Owner of the flat parameter / buffer storage and of the HIP workspace (``self.backbone`` of the adapter)."""
+
+    def __init__(self, model_name: str, seed: Optional[int] = None, **overrides):
+        super().__init__()
+        self.cfg, self.variant, self.depths = make_cfg(model_name, **overrides)
+        self.model_name = model_name.split(".")[0]
+        self.table = _tensor_table(self.cfg)
+        lib = L.lib()
+        self.num_features = int(self.variant["embed_dims"][-1])
+        self.param_floats = lib.gg_tinyvit_param_floats(C.byref(self.cfg))
+        self.buffer_floats = lib.gg_tinyvit_buffer_floats(C.byref(self.cfg))
+        self.num_counters = lib.gg_tinyvit_num_counters(C.byref(self.cfg))
+        self.num_drop_slots = lib.gg_tinyvit_num_drop_slots(C.byref(self.cfg))
+        n_blocks = sum(self.depths)
+        rates = torch.linspace(0, float(self.variant["drop_path_rate"]), n_blocks).tolist()
+        slot_rates: List[float] = []
+        for b in range(n_blocks):
+            slot_rates += [rates[b]] if b < self.depths[0] else [rates[b], rates[b]]
+        self.drop_rates = slot_rates
+        g = torch.Generator().manual_seed(torch.initial_seed() if seed is None else seed)
+        self._flat = torch.zeros(self.param_floats)
+        self._flat_buf = torch.zeros(self.buffer_floats)
+        self._counters = torch.zeros(self.num_counters, dtype=torch.int64)
+        self._flat_grad: Optional[torch.Tensor] = None
+        self._params: Dict[str, nn.Parameter] = {}
+        for t in self.table:
+            parent, leaf = self._walk(t["name"])
+            if t["kind"] == 0:
+                view = self._flat[t["offset"]:t["offset"] + t["numel"]].view(t["shape"])
+                view.copy_(_init_tensor(t["name"], t["shape"], g))
+                p = nn.Parameter(view)
+                parent.register_parameter(leaf, p)
+                self._params[t["name"]] = p
+            elif t["kind"] == 1:
+                view = self._flat_buf[t["offset"]:t["offset"] + t["numel"]].view(t["shape"])
+                view.fill_(1.0 if leaf == "running_var" else 0.0)
+                parent.register_buffer(leaf, view)
+            else:
+                parent.register_buffer(leaf, self._counters[t["offset"]])
+        self._wcache = None
+        self._wcache_version = -1
+        self._ws: Dict[bool, torch.Tensor] = {}
+        self._last = None
+
+    # -- module tree helpers ---------------------------------------------------------------------------
+    def _walk(self, name: str):
+        parts = name.split(".")
+        mod = self
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, _Tree())
+            mod = mod._modules[p]
+        return mod, parts[-1]
+
+    def _apply(self, fn, *a, **k):
+        """``.to(device)`` moves every parameter separately; re-point them into fresh flat buffers afterwards."""
+        super()._apply(fn, *a, **k)
+        self._reflatten()
+        return self
+
+    def _reflatten(self):
+        some = next(iter(self._params.values()))
+        dev = some.device
+        flat = torch.zeros(self.param_floats, device=dev)
+        buf = torch.zeros(self.buffer_floats, device=dev)
+        cnt = torch.zeros(self.num_counters, dtype=torch.int64, device=dev)
+        grad = None
+        if any(p.grad is not None for p in self._params.values()):
+            grad = torch.zeros(self.param_floats, device=dev)
+        for t in self.table:
+            parent, leaf = self._walk(t["name"])
+            sl = slice(t["offset"], t["offset"] + t["numel"])
+            if t["kind"] == 0:
+                p = parent._parameters[leaf]
+                flat[sl].view(t["shape"]).copy_(p.data.to(torch.float32))
+                p.data = flat[sl].view(t["shape"])
+                if p.grad is not None:
+                    grad[sl].view(t["shape"]).copy_(p.grad)
+                    p.grad = grad[sl].view(t["shape"])
+            elif t["kind"] == 1:
+                buf[sl].view(t["shape"]).copy_(parent._buffers[leaf].to(torch.float32))
+                parent._buffers[leaf] = buf[sl].view(t["shape"])
+            else:
+                cnt[t["offset"]] = parent._buffers[leaf].to(torch.int64)
+                parent._buffers[leaf] = cnt[t["offset"]]
+        self._flat, self._flat_buf, self._counters, self._flat_grad = flat, buf, cnt, grad
+        self._wcache, self._wcache_version, self._ws = None, -1, {}
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+
+    # -- flat views used by the optimizer / all-reduce ---------------------------------------------------
+    @property
+    def flat_params(self) -> torch.Tensor:
+        return self._flat
+
+    def flat_grads(self) -> torch.Tensor:
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def attach_grads(self, zero_missing: bool = True):
+        """Make every trainable parameter's ``.grad`` a view of the flat gradient buffer.  If a ``zero_grad(set_to_none)``
+        dropped the views the buffer is zeroed first (its contents belonged to the previous step)."""
+        fg = self.flat_grads()
+        dropped = any(p.requires_grad and p.grad is None for p in self._params.values())
+        if dropped and zero_missing:
+            fg.zero_()
+        for t in self.table:
+            if t["kind"] != 0:
+                continue
+            p = self._params[t["name"]]
+            if p.requires_grad:
+                if p.grad is None or p.grad.data_ptr() != fg.data_ptr() + 4 * t["offset"]:
+                    p.grad = fg[t["offset"]:t["offset"] + t["numel"]].view(t["shape"])
+        return fg
+
+    def trainable_mask(self) -> bytes:
+        return bytes(int(t["kind"] == 0 and self._params[t["name"]].requires_grad) for t in self.table)
+
+    def trainable_ranges(self):
+        """Contiguous [start, end) float ranges of the flat buffer covering runs of trainable tensors."""
+        ranges, cur = [], None
+        for t in self.table:
+            if t["kind"] != 0:
+                continue
+            tr = self._params[t["name"]].requires_grad
+            end = t["offset"] + (t["numel"] + 7) // 8 * 8
+            if tr:
+                cur = [t["offset"], end] if cur is None else [cur[0], end]
+            elif cur is not None:
+                ranges.append(tuple(cur)); cur = None
+        if cur is not None:
+            ranges.append(tuple(cur))
+        return ranges
+
+    def mark_params_dirty(self):
+        self._wcache_version = -1
+
+    # -- HIP calls ------------------------------------------------------------------------------------------
+    def _ensure_weights(self):
+        lib = L.lib()
+        if self._wcache is None:
+            nbytes = lib.gg_tinyvit_wcache_bytes(C.byref(self.cfg))
+            self._wcache = torch.zeros(nbytes, dtype=torch.uint8, device=self._flat.device)
+            self._wcache_version = -1
+        if self._wcache_version != self._flat._version:
+            L.check(lib.gg_tinyvit_refresh_weights(C.byref(self.cfg), L.ptr(self._flat, torch.float32, "params"),
+                                                   L.ptr(self._wcache), L.stream()), "gg_tinyvit_refresh_weights")
+            self._wcache_version = self._flat._version
+
+    def _workspace(self, batch: int, training: bool) -> torch.Tensor:
+        need = L.lib().gg_tinyvit_workspace_bytes(C.byref(self.cfg), batch, int(training))
+        if need < 0:
+            raise L.GgError(L.lib().gg_last_error().decode())
+        ws = self._ws.get(training)
+        if ws is None or ws.numel() < need or ws.device != self._flat.device:
+            self._ws[training] = None
+            ws = torch.empty(need, dtype=torch.uint8, device=self._flat.device)
+            self._ws[training] = ws
+        return ws
+
+    def make_drop_scales(self, batch: int, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
+        """timm DropPath (scale_by_keep): per-sample Bernoulli(1-p)/(1-p), one row per slot."""
+        if max(self.drop_rates) <= 0:
+            return None
+        keep = 1.0 - torch.tensor(self.drop_rates, device=self._flat.device).unsqueeze(1)
+        u = torch.rand((self.num_drop_slots, batch), device=self._flat.device, generator=generator)
+        return ((u < keep).to(torch.float32) / keep).contiguous()
+
+    def forward_hip(self, x: torch.Tensor, training: bool, drop_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+        L.require_gpu()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.cfg.img_size or x.shape[3] != self.cfg.img_size:
+            raise L.GgError(f"TinyViT expects (B,3,{self.cfg.img_size},{self.cfg.img_size}) pixel_values, got {tuple(x.shape)}")
+        if not self._flat.is_cuda:
+            raise L.GgError("TinyViTAdapter parameters are on the CPU; call .to('cuda') -- there is no CPU fallback")
+        x = x.to(device=self._flat.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        self._ensure_weights()
+        ws = self._workspace(B, training)
+        out = torch.empty((B, self.num_features), dtype=torch.float32, device=x.device)
+        if drop_scales is not None:
+            assert drop_scales.shape == (self.num_drop_slots, B) and drop_scales.dtype == torch.float32
+        L.check(L.lib().gg_tinyvit_forward(C.byref(self.cfg), B, int(training), L.ptr(self._flat), L.ptr(self._flat_buf),
+                                           L.ptr(self._counters), L.ptr(self._wcache), L.ptr(x), L.ptr(drop_scales), L.ptr(ws),
+                                           L.ptr(out), L.stream()), "gg_tinyvit_forward")
+        if training:
+            self._counters += 1          # num_batches_tracked (int64 bookkeeping)
+            self._flat_buf_dirty = True
+        self._last = (B, drop_scales)
+        return out
+
+    def backward_hip(self, d_out: torch.Tensor):
+        B, drop = self._last
+        fg = self.attach_grads()
+        ws = self._ws[True]
+        mask = self.trainable_mask()
+        L.check(L.lib().gg_tinyvit_backward(C.byref(self.cfg), B, L.ptr(self._flat), L.ptr(self._wcache), L.ptr(drop), L.ptr(ws),
+                                            L.ptr(d_out.contiguous(), torch.float32, "d_out"), L.ptr(fg), mask, L.stream()),
+                "gg_tinyvit_backward")
+
+    def activation(self, name: str, batch: int) -> torch.Tensor:
+        """Raw bytes of a saved activation of the last training forward (parity tests)."""
+        off, nbytes = C.c_int64(), C.c_int64()
+        L.check(L.lib().gg_tinyvit_activation_info(C.byref(self.cfg), batch, name.encode(), C.byref(off), C.byref(nbytes)),
+                "gg_tinyvit_activation_info")
+        return self._ws[True][off.value:off.value + nbytes.value]
+
+    def forward(self, x):
+        return _EncoderFn.apply(self, x, _anchor(self))
+
+
+def _anchor(bb: TinyVitBackbone) -> torch.Tensor:
+    a = getattr(bb, "_anchor_t", None)
+    if a is None or a.device != bb._flat.device:
+        a = torch.zeros((), device=bb._flat.device, requires_grad=True)
+        bb._anchor_t = a
+    return a
+
+
+class _EncoderFn(torch.autograd.Function):
+    """Whole-encoder autograd node.  Parameter gradients are accumulated straight into the flat gradient buffer
+    (``p.grad`` views), not returned through autograd; the zero-dim ``anchor`` input only keeps the node alive."""
+
+    @staticmethod
+    def forward(ctx, bb: TinyVitBackbone, x: torch.Tensor, anchor: torch.Tensor):
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in bb._params.values())
+        training = bb.training
+        drop = bb.make_drop_scales(x.shape[0]) if training else None
+        out = bb.forward_hip(x, training, drop)
+        ctx.bb = bb
+        ctx.valid = training and need_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        if not ctx.valid:
+            raise L.GgError("backward through a TinyViT forward that ran in eval mode (running-stat BatchNorm keeps no "
+                            "activations); call .train() before the forward pass")
+        ctx.bb.backward_hip(d_out)
+        return None, None, torch.zeros((), device=d_out.device)
+
+
+class TinyViTAdapter(nn.Module):
+    """See module docstring.  ``pretrained=True`` cannot download (no network): weights are looked up in
+    ``$GG_PRETRAINED_DIR/<model_name>.pt`` (a timm state dict) and otherwise a warning is issued and the timm
+    initialisation is used."""
+
+    def __init__(self, model_name: str = "tiny_vit_21m_512.dist_in22k_ft_in1k", pretrained: bool = True,
+                 global_pool: str = "avg", features_only: bool = False, **overrides):
+        super().__init__()
+        if global_pool != "avg":
+            raise NotImplementedError("only global_pool='avg' (the reference's setting) is built")
+        self.features_only = features_only   # pooled last feature map == num_classes=0 output before head.norm; see forward
+        self.backbone = TinyVitBackbone(model_name, **overrides)
+        hidden = self.backbone.num_features
+        self.config = SimpleNamespace(hidden_size=hidden, hidden_sizes=[hidden], _name_or_path=model_name)
+        stages = self.backbone._modules["stages"]
+        self.vision_model = SimpleNamespace(encoder=SimpleNamespace(layers=list(stages)))
+        self._fully_frozen = False
+        if pretrained:
+            d = os.environ.get("GG_PRETRAINED_DIR")
+            path = os.path.join(d, model_name + ".pt") if d else None
+            if path and os.path.exists(path):
+                self.backbone.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+            else:
+                warnings.warn(f"pretrained weights for {model_name} not available offline (set GG_PRETRAINED_DIR); "
+                              "using the timm initialisation")
+        if features_only:
+            raise NotImplementedError("features_only=True (list of feature maps) is not on the reference's hot path")
+
+    def build_transform(self):
+        raise RuntimeError("timm data transforms not available in this environment.")   # models/tinyvit.py:83-86
+
+    def freeze_all(self, eval_mode: bool = True):
+        for p in self.parameters():
+            p.requires_grad = False
+        self._fully_frozen = True
+        if eval_mode:
+            super().train(False)
+        return self
+
+    def unfreeze_all(self):
+        for p in self.parameters():
+            p.requires_grad = True
+        self._fully_frozen = False
+        return self
+
+    def freeze_all_but_last_stage(self):
+        layers = list(self.vision_model.encoder.layers)
+        for m in layers[:-1]:
+            for p in m.parameters():
+                p.requires_grad = False
+        return self
+
+    def train(self, mode: bool = True):
+        if self._fully_frozen:
+            return super().train(False)
+        return super().train(mode)
+
+    def forward(self, pixel_values: torch.Tensor = None, x: Optional[torch.Tensor] = None):
+        if pixel_values is None and x is not None:
+            pixel_values = x
+        out = self.backbone(pixel_values)
+        return SimpleNamespace(pooler_output=out, last_hidden_state=out.unsqueeze(1))

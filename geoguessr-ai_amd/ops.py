@@ -1,0 +1,304 @@
+"""Thin tensor-level wrappers over the primitive C-ABI entry points (used by the model shims and by the
+per-kernel parity tests).  bf16 activations are ``torch.bfloat16`` tensors; everything is enqueued on the
+current torch stream.  No arithmetic happens in Python."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+ACT = {"none": 0, None: 0, "gelu": 1, "quick_gelu": 2}
+BF16, F32, I64 = torch.bfloat16, torch.float32, torch.int64
+
+
+def _p(t, dtype=None, name="tensor"):
+    return L.ptr(t, dtype, name)
+
+
+def _pr(t, dtype=None, name="matrix"):
+    """Pointer of a 2-D row-major matrix whose rows may be strided (a column slice of a wider buffer)."""
+    if t is None:
+        return None
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise L.GgError(f"{name} must be a 2-D matrix with unit column stride")
+    if not t.is_cuda:
+        raise L.GgError(f"{name} must live on the GPU (got device {t.device}); there is no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise L.GgError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def gemm_nt(A, B, *, bias=None, act=None, preact=False, rowscale=None, rows_per_scale=0, residual=None,
+            dact_preact=None, dact=None, colstats=False, out_f32=False, out=None, M=None, N=None, K=None,
+            lda=None, ldb=None, ldc=None):
+    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Returns C (and preact / colstats when requested)."""
+    L.require_gpu()
+    M = A.shape[0] if M is None else M
+    K = A.shape[1] if K is None else K
+    N = B.shape[0] if N is None else N
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    dev = A.device
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if out_f32 else BF16, device=dev)
+    ldc = out.stride(0) if ldc is None else ldc
+    pre = torch.empty((M, N), dtype=BF16, device=dev) if preact else None
+    stats = None
+    if colstats:
+        stats = torch.empty((L.lib().gg_gemm_colstats_rows(M), 2, N), dtype=F32, device=dev)
+    a = L.GemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(A, BF16, "A"), lda, _pr(B, BF16, "B"), ldb, _pr(out), ldc
+    a.M, a.N, a.K = M, N, K
+    a.bias = _p(bias, F32, "bias")
+    a.act = ACT[act]
+    a.preact = _p(pre)
+    a.rowscale, a.rows_per_scale = _p(rowscale, F32, "rowscale"), rows_per_scale
+    a.residual, a.ldr = _p(residual, BF16, "residual"), (residual.stride(0) if residual is not None else 0)
+    a.dact_preact, a.dact = _p(dact_preact, BF16, "dact_preact"), ACT[dact]
+    a.colstats = _p(stats)
+    a.out_f32, a.split_k = int(out_f32), 1
+    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    res = [out]
+    if preact:
+        res.append(pre)
+    if colstats:
+        res.append(stats)
+    return res[0] if len(res) == 1 else tuple(res)
+
+
+def gemm_splitk(A, B, split_k: int, accumulate_into: Optional[torch.Tensor] = None, scale: float = 1.0):
+    """f32 C[M,N] = A[M,K] @ B[N,K]^T with the reduction split over blockIdx.y, then reduced."""
+    M, K, N = A.shape[0], A.shape[1], B.shape[0]
+    part = torch.empty((split_k, M, N), dtype=F32, device=A.device)
+    a = L.GemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _p(A, BF16), A.stride(0), _p(B, BF16), B.stride(0), _p(part), N
+    a.M, a.N, a.K, a.out_f32, a.split_k = M, N, K, 1, split_k
+    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt(split)")
+    out = accumulate_into if accumulate_into is not None else torch.empty((M, N), dtype=F32, device=A.device)
+    L.check(L.lib().gg_splitk_reduce(_p(part), _p(out, F32), M * N, split_k, int(accumulate_into is not None),
+                                     scale, L.stream()), "gg_splitk_reduce")
+    return out
+
+
+def transpose_bf16(x, rowscale=None, rows_per_scale=0, pad_to: int = 8):
+    R, Cc = x.shape
+    ldo = (R + pad_to - 1) // pad_to * pad_to
+    out = torch.zeros((Cc, ldo), dtype=BF16, device=x.device)
+    L.check(L.lib().gg_transpose_bf16(_pr(x, BF16), x.stride(0), _p(out), ldo, R, Cc, _p(rowscale, F32), rows_per_scale,
+                                      L.stream()), "gg_transpose_bf16")
+    return out
+
+
+def colsum_bf16(x, rowscale=None, rows_per_scale=0, out=None):
+    M, Cc = x.shape
+    scratch = torch.empty((L.lib().gg_colsum_scratch_floats(M, Cc),), dtype=F32, device=x.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((Cc,), dtype=F32, device=x.device)
+    L.check(L.lib().gg_colsum_bf16(_pr(x, BF16), x.stride(0), M, Cc, _p(rowscale, F32), rows_per_scale, _p(scratch),
+                                   _p(out, F32), int(acc), L.stream()), "gg_colsum_bf16")
+    return out
+
+
+def im2col_nchw3(x, stride=2):
+    B, Cc, H, W = x.shape
+    assert Cc == 3
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    col = torch.empty((B * Ho * Wo, 32), dtype=BF16, device=x.device)
+    L.check(L.lib().gg_im2col_nchw3_f32(_p(x, F32), _p(col), B, H, W, stride, L.stream()), "gg_im2col_nchw3_f32")
+    return col
+
+
+def im2col_nhwc(x, stride=2):
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    col = torch.empty((B * Ho * Wo, 9 * Cc), dtype=BF16, device=x.device)
+    L.check(L.lib().gg_im2col_nhwc_bf16(_p(x, BF16), _p(col), B, H, W, Cc, stride, L.stream()), "gg_im2col_nhwc_bf16")
+    return col
+
+
+def col2im_nhwc(dcol, B, H, W, Cc, stride=2):
+    dx = torch.empty((B, H, W, Cc), dtype=BF16, device=dcol.device)
+    L.check(L.lib().gg_col2im_nhwc_bf16(_p(dcol, BF16), _p(dx), B, H, W, Cc, stride, L.stream()), "gg_col2im_nhwc_bf16")
+    return dx
+
+
+def dwconv3x3_fwd(x, taps, stride=1, colstats=False):
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=x.device)
+    stats = None
+    if colstats:
+        stats = torch.empty((L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc), 2, Cc), dtype=F32, device=x.device)
+    L.check(L.lib().gg_dwconv3x3_fwd(_p(x, BF16), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
+            "gg_dwconv3x3_fwd")
+    return (y, stats) if colstats else y
+
+
+def dwconv3x3_bwd_data(dy, taps, B, H, W, Cc, stride=1):
+    dx = torch.empty((B, H, W, Cc), dtype=BF16, device=dy.device)
+    L.check(L.lib().gg_dwconv3x3_bwd_data(_p(dy, BF16), _p(taps, F32), _p(dx), B, H, W, Cc, stride, L.stream()),
+            "gg_dwconv3x3_bwd_data")
+    return dx
+
+
+def dwconv3x3_bwd_weight(x, dy, stride=1, grad=None):
+    B, H, W, Cc = x.shape
+    scratch = torch.empty((L.lib().gg_dwconv_wgrad_scratch_floats(B, H, W, Cc, stride),), dtype=F32, device=x.device)
+    acc = grad is not None
+    if grad is None:
+        grad = torch.empty((Cc, 1, 3, 3), dtype=F32, device=x.device)
+    L.check(L.lib().gg_dwconv3x3_bwd_weight(_p(x, BF16), _p(dy, BF16), B, H, W, Cc, stride, _p(scratch), _p(grad, F32),
+                                            int(acc), L.stream()), "gg_dwconv3x3_bwd_weight")
+    return grad
+
+
+def bn_finalize(partials, count, eps=1e-5, momentum=0.1, running_mean=None, running_var=None):
+    nparts, _, Cc = partials.shape
+    stat = torch.empty((2, Cc), dtype=F32, device=partials.device)
+    L.check(L.lib().gg_bn_finalize(_p(partials, F32), nparts, Cc, count, eps, momentum, _p(stat), _p(running_mean, F32),
+                                   _p(running_var, F32), L.stream()), "gg_bn_finalize")
+    return stat
+
+
+def bn_eval_stat(running_mean, running_var, eps=1e-5):
+    Cc = running_mean.numel()
+    stat = torch.empty((2, Cc), dtype=F32, device=running_mean.device)
+    L.check(L.lib().gg_bn_eval_stat(_p(running_mean, F32), _p(running_var, F32), Cc, eps, _p(stat), L.stream()),
+            "gg_bn_eval_stat")
+    return stat
+
+
+def bn_apply(y, stat, gamma, beta, act=None, residual=None, rowscale=None, rows_per_scale=0):
+    M, Cc = y.shape
+    out = torch.empty_like(y)
+    L.check(L.lib().gg_bn_apply(_p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), M, Cc, ACT[act],
+                                _p(residual, BF16), _p(rowscale, F32), rows_per_scale, _p(out), L.stream()), "gg_bn_apply")
+    return out
+
+
+def bn_bwd(dout, y, stat, gamma, beta, act=None, residual=None, rowscale=None, rows_per_scale=0, want_param_grads=True):
+    M, Cc = y.shape
+    dev = y.device
+    dz, dy = torch.empty_like(y), torch.empty_like(y)
+    scratch = torch.empty((L.lib().gg_bn_bwd_scratch_floats(M, Cc),), dtype=F32, device=dev)
+    dg = torch.zeros((Cc,), dtype=F32, device=dev) if want_param_grads else None
+    db = torch.zeros((Cc,), dtype=F32, device=dev) if want_param_grads else None
+    L.check(L.lib().gg_bn_bwd(_p(dout, BF16), _p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), M, Cc, ACT[act],
+                              _p(residual, BF16), _p(rowscale, F32), rows_per_scale, _p(dz), _p(dy), _p(scratch), _p(dg),
+                              _p(db), 1, L.stream()), "gg_bn_bwd")
+    return dz, dy, dg, db
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5, out_f32=None, save_stats=True):
+    M, Cc = x.shape
+    x_f32 = x.dtype == F32
+    out_f32 = x_f32 if out_f32 is None else out_f32
+    out = torch.empty((M, Cc), dtype=F32 if out_f32 else BF16, device=x.device)
+    mean = torch.empty((M,), dtype=F32, device=x.device) if save_stats else None
+    rstd = torch.empty((M,), dtype=F32, device=x.device) if save_stats else None
+    L.check(L.lib().gg_layernorm_fwd(_p(x), int(x_f32), _p(gamma, F32), _p(beta, F32), M, Cc, eps, _p(out), int(out_f32),
+                                     _p(mean), _p(rstd), L.stream()), "gg_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dout, x, mean, rstd, gamma, dres=None, want_param_grads=True):
+    M, Cc = x.shape
+    f32 = x.dtype == F32
+    dx = torch.empty_like(x)
+    scratch = torch.empty((L.lib().gg_layernorm_bwd_scratch_floats(M, Cc),), dtype=F32, device=x.device)
+    dg = torch.zeros((Cc,), dtype=F32, device=x.device) if want_param_grads else None
+    db = torch.zeros((Cc,), dtype=F32, device=x.device) if want_param_grads else None
+    L.check(L.lib().gg_layernorm_bwd(_p(dout), _p(x), int(f32), _p(mean, F32), _p(rstd, F32), _p(gamma, F32), M, Cc, _p(dres),
+                                     _p(dx), _p(scratch), _p(dg), _p(db), 1, L.stream()), "gg_layernorm_bwd")
+    return dx, dg, db
+
+
+def token_mean_fwd(x, B, T):
+    Cc = x.shape[-1]
+    out = torch.empty((B, Cc), dtype=F32, device=x.device)
+    L.check(L.lib().gg_token_mean_fwd(_p(x, BF16), _p(out), B, T, Cc, L.stream()), "gg_token_mean_fwd")
+    return out
+
+
+def token_mean_bwd(dout, T):
+    B, Cc = dout.shape
+    dx = torch.empty((B * T, Cc), dtype=BF16, device=dout.device)
+    L.check(L.lib().gg_token_mean_bwd(_p(dout, F32), _p(dx), B, T, Cc, L.stream()), "gg_token_mean_bwd")
+    return dx
+
+
+def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off, k_off, v_off, head_stride,
+              window_size=0, map_h=0, map_w=0, bias=None, scale=None, dout=None, want_dbias=False):
+    """forward when ``dout`` is None, else backward -> (dqkv, dbias)."""
+    a = L.AttnArgs()
+    a.qkv, a.ld = _p(qkv, BF16, "qkv"), qkv.stride(0)
+    a.q_off, a.k_off, a.v_off, a.head_stride, a.head_dim = q_off, k_off, v_off, head_stride, head_dim
+    a.num_heads, a.num_windows, a.tokens_per_window = num_heads, num_windows, tokens_per_window
+    a.window_size, a.map_h, a.map_w = window_size, map_h, map_w
+    a.bias = _p(bias, F32, "bias")
+    a.scale = head_dim ** -0.5 if scale is None else scale
+    tokens = qkv.shape[0]
+    if dout is None:
+        out = torch.empty((tokens, num_heads * head_dim), dtype=BF16, device=qkv.device)
+        a.out, a.ldo = _p(out), out.stride(0)
+        L.check(L.lib().gg_attention_fwd(C.byref(a), L.stream()), "gg_attention_fwd")
+        return out
+    dqkv = torch.zeros_like(qkv)
+    dbias = torch.zeros_like(bias) if (want_dbias and bias is not None) else None
+    a.dout, a.lddo, a.dqkv, a.dbias = _p(dout, BF16, "dout"), dout.stride(0), _p(dqkv), _p(dbias)
+    L.check(L.lib().gg_attention_bwd(C.byref(a), L.stream()), "gg_attention_bwd")
+    return dqkv, dbias
+
+
+def geo_head(logits, centroids, *, labels=None, labels_clf=None, mode=0, smoothing_km=65.0, grad_scale=None,
+             want_dlogits=False, num_candidates=5, want_nearest=False, K=None):
+    """Fused SuperGuessr head epilogue.  Returns a dict of device tensors."""
+    N = logits.shape[0]
+    K = logits.shape[1] if K is None else K
+    dev = logits.device
+    r = dict(loss_rows=torch.empty((N,), dtype=F32, device=dev), loss=torch.zeros((1,), dtype=F32, device=dev),
+             preds=torch.empty((N,), dtype=I64, device=dev), llh=torch.empty((N, 2), dtype=F32, device=dev),
+             topk_vals=torch.empty((N, num_candidates), dtype=F32, device=dev),
+             topk_idx=torch.empty((N, num_candidates), dtype=I64, device=dev))
+    if want_dlogits:
+        ldd = (K + 7) // 8 * 8
+        r["dlogits"] = torch.empty((N, ldd), dtype=BF16, device=dev)
+    if want_nearest:
+        r["nearest"] = torch.empty((N,), dtype=I64, device=dev)
+    a = L.GeoHeadArgs()
+    a.logits, a.ldl, a.N, a.K = _p(logits, F32, "logits"), logits.stride(0), N, K
+    a.labels, a.centroids, a.labels_clf = _p(labels, F32, "labels"), _p(centroids, F32, "centroids"), _p(labels_clf, I64, "labels_clf")
+    a.mode, a.smoothing_km = mode, smoothing_km
+    a.grad_scale = (1.0 / N) if grad_scale is None else grad_scale
+    a.loss_rows, a.loss = _p(r["loss_rows"]), _p(r["loss"])
+    if want_dlogits:
+        a.dlogits, a.ldd = _p(r["dlogits"]), r["dlogits"].stride(0)
+    a.preds, a.llh, a.topk_vals, a.topk_idx, a.num_candidates = _p(r["preds"]), _p(r["llh"]), _p(r["topk_vals"]), _p(r["topk_idx"]), num_candidates
+    a.nearest = _p(r.get("nearest"))
+    L.check(L.lib().gg_geo_head(C.byref(a), L.stream()), "gg_geo_head")
+    return r
+
+
+def haversine_matrix(x, centroids):
+    """models/utils.py:39 with y given as (K,2) centroids (the reference passes centroids.t())."""
+    N, K = x.shape[0], centroids.shape[0]
+    out = torch.empty((N, K), dtype=F32, device=x.device)
+    L.check(L.lib().gg_haversine_matrix(_p(x, F32), _p(centroids, F32), _p(out), N, K, L.stream()), "gg_haversine_matrix")
+    return out
+
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, grad_scale=1.0):
+    L.check(L.lib().gg_adamw_step(_p(p, F32), _p(g, F32), _p(m, F32), _p(v, F32), p.numel(), step, lr, beta1, beta2, eps,
+                                  weight_decay, grad_scale, L.stream()), "gg_adamw_step")
+
+
+def geoguessr_score(pred_llh, true_llh):
+    N = pred_llh.shape[0]
+    d = torch.empty((N,), dtype=F32, device=pred_llh.device)
+    s = torch.empty((N,), dtype=F32, device=pred_llh.device)
+    L.check(L.lib().gg_geoguessr_score(_p(pred_llh, F32), _p(true_llh, F32), N, _p(d), _p(s), L.stream()), "gg_geoguessr_score")
+    return d, s

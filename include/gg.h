@@ -1,0 +1,205 @@
+/* libgg -- C-ABI of the MI355X-native (gfx950) hot path of CogitoNTNU/geoguessr-ai.
+ *
+ * The reference has no FFI layer: its boundary is a duck-typed Python nn.Module interface
+ * (SURVEY.md 8b).  This header is what the drop-in Python shims under geoguessr-ai_amd/ bind with
+ * ctypes (INTEGRATION.md shows the stubs).  Conventions for every entry point:
+ *   - returns 0 on success, < 0 on error; gg_last_error() gives the thread-local message;
+ *   - all pointers are CALLER-OWNED DEVICE pointers unless marked "host"; the library never
+ *     allocates or frees device memory and keeps no global state;
+ *   - `stream` is a hipStream_t; work is only enqueued, nothing here synchronises;
+ *   - bf16 tensors are passed as void*; matrices are row-major with an explicit leading dimension
+ *     in ELEMENTS; activations are NHWC / [tokens, channels].
+ * Reference citations are relative to the reference repository root.
+ */
+#ifndef GG_H
+#define GG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GG_VERSION 1
+int gg_version(void);
+const char* gg_last_error(void);          /* host string, valid until the next failing call on this thread */
+
+enum { GG_ACT_CODE_NONE = 0, GG_ACT_CODE_GELU = 1, GG_ACT_CODE_QUICK_GELU = 2 };
+
+/* ---------------------------------------------------------------- dense contractions (MFMA)
+ * C[M,N] = epilogue( A[M,K] . B[N,K]^T ).  Replaces every nn.Linear / 1x1 Conv2d / im2col'd 3x3 Conv2d the
+ * reference reaches through timm (models/tinyvit.py:135), transformers CLIP (pretrain/clip_embedder.py:63)
+ * and SuperGuessr.cell_layer (models/super_guessr.py:354), plus their autograd dgrad / wgrad.
+ * epilogue order: +bias[n] -> (store preact) -> act -> *act'(dact_preact) -> *rowscale[m/rows_per_scale]
+ *                 -> +residual[m,n] -> store (bf16 or f32).  K, lda, ldb multiples of 8. */
+typedef struct GgGemmArgs {
+    const void* A; int64_t lda;           /* bf16 [M,K] */
+    const void* B; int64_t ldb;           /* bf16 [N,K] */
+    void* C; int64_t ldc;                 /* bf16 or f32 [M,N]; split_k>1: f32 [split_k][M][ldc] partials */
+    int M, N, K;
+    const float* bias;                    /* f32 [N] or NULL */
+    int act;                              /* GG_ACT_CODE_* */
+    void* preact;                         /* bf16 [M,ldc] or NULL */
+    const float* rowscale; int rows_per_scale;   /* DropPath per-sample scale, f32 [ceil(M/rows_per_scale)] or NULL */
+    const void* residual; int64_t ldr;    /* bf16 [M,N] or NULL */
+    const void* dact_preact; int dact;    /* bf16 [M,ldc]: multiply by act'(.) (backward through an activation) */
+    float* colstats;                      /* f32 [gg_gemm_colstats_rows(M)][2][N] BatchNorm partials or NULL */
+    int out_f32;
+    int split_k;
+} GgGemmArgs;
+int gg_gemm_nt(const GgGemmArgs* args, void* stream);
+int gg_gemm_colstats_rows(int M);
+int gg_splitk_reduce(const float* partials, float* out, int64_t n, int splits, int accumulate, float scale, void* stream);
+int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
+                      int rows_per_scale, void* stream);
+int gg_cast_transpose_f32(const float* in, int R, int C, void* out, int64_t ldo, void* outT, int64_t ldt, void* stream);
+int gg_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int gg_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+int64_t gg_colsum_scratch_floats(int M, int C);
+int gg_colsum_bf16(const void* x, int64_t ld, int M, int C, const float* rowscale, int rows_per_scale, float* scratch,
+                   float* out, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- 3x3 convolutions (timm ConvNorm convs)
+ * Dense 3x3 (PatchEmbed) = im2col + gg_gemm_nt, k order (ky,kx,ci); depthwise 3x3 (MBConv.conv2,
+ * PatchMerging.conv2, TinyVitBlock.local_conv) direct, taps f32 [9][C]. */
+int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int W, int stride, void* stream);   /* (B,3,H,W) f32 -> bf16 [B*Ho*Wo,32] */
+int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, int stride, void* stream);
+int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream);
+int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C);
+int gg_dwconv3x3_fwd(const void* x, const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
+int gg_dwconv3x3_bwd_data(const void* dy, const float* taps, void* dx, int B, int H, int W, int C, int stride, void* stream);
+int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride);
+int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch, float* grad /* (C,1,3,3) */,
+                            int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- BatchNorm2d (train-mode batch statistics)
+ * stat = [2][C] (mean, rstd).  Partials come from gg_gemm_nt.colstats / gg_dwconv3x3_fwd.colstats. */
+int gg_bn_finalize(const float* partials, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
+                   float* running_mean, float* running_var, void* stream);
+int gg_bn_eval_stat(const float* running_mean, const float* running_var, int C, float eps, float* stat, void* stream);
+int gg_bn_apply(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream);
+int64_t gg_bn_bwd_scratch_floats(int64_t M, int C);
+int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+              const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
+              float* dgamma, float* dbeta, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------- LayerNorm / pooling */
+int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, int64_t M, int C, float eps, void* out,
+                     int out_f32, float* mean, float* rstd, void* stream);
+int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C);
+int gg_layernorm_bwd(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma, int64_t M,
+                     int C, const void* dres, void* dx, float* scratch, float* dgamma, float* dbeta, int accumulate, void* stream);
+int gg_token_mean_fwd(const void* x, float* out, int B, int T, int C, void* stream);
+int gg_token_mean_bwd(const float* dout, void* dx, int B, int T, int C, void* stream);
+int gg_view_mean_fwd(const float* emb, void* out, int64_t ldo, int N, int V, int C, void* stream);   /* models/super_guessr.py:347 */
+int gg_view_mean_bwd(const void* dmean, int64_t ld, float* demb, int N, int V, int C, void* stream);
+
+/* ---------------------------------------------------------------- window attention (timm Attention.forward; CLIP MHSA) */
+typedef struct GgAttnArgs {
+    const void* qkv; int64_t ld;          /* bf16 [tokens, ld] */
+    int q_off, k_off, v_off, head_stride; /* column of head h = off + h*head_stride */
+    int head_dim;                         /* 32 (TinyViT) or 64 (CLIP) */
+    int num_heads, num_windows, tokens_per_window;
+    int window_size, map_h, map_w;        /* window_size > 0: ws x ws windows of an (map_h, map_w) NHWC token map; 0: linear */
+    const float* bias;                    /* attention_biases f32 [num_heads][ws*ws] or NULL */
+    float scale;
+    void* out; int64_t ldo;               /* forward: bf16 [tokens, ldo], head h at column h*head_dim */
+    const void* dout; int64_t lddo;       /* backward */
+    void* dqkv;                           /* backward: same layout as qkv */
+    float* dbias;                         /* backward: f32 [num_heads][ws*ws], ACCUMULATED, or NULL */
+} GgAttnArgs;
+int gg_attention_fwd(const GgAttnArgs* args, void* stream);
+int gg_attention_bwd(const GgAttnArgs* args, void* stream);
+
+/* ---------------------------------------------------------------- SuperGuessr head + loss (models/super_guessr.py:355-383,
+ * models/utils.py:20-57, main_coordinator_idun_s3.py:390-391) fused per row over the (N,K) logits. */
+typedef struct GgGeoHeadArgs {
+    const float* logits; int64_t ldl;     /* f32 [N, ldl] */
+    int N, K;
+    const float* labels;                  /* f32 (N,2) lon,lat degrees or NULL */
+    const float* centroids;               /* f32 (K,2) lon,lat degrees (geocell_centroid_coords) */
+    const int64_t* labels_clf;            /* (N,) or NULL */
+    int mode;                             /* 0 predictions only, 1 haversine-smoothed soft CE, 2 hard CE */
+    float smoothing_km;                   /* LABEL_SMOOTHING_CONSTANT (config.py:52) = 65 */
+    float grad_scale;                     /* dlogits = dloss_row/dlogits * grad_scale (pass upstream_grad / N) */
+    float* loss_rows;                     /* f32 (N,) or NULL */
+    float* loss;                          /* f32 scalar = mean(loss_rows) or NULL */
+    void* dlogits; int64_t ldd;           /* bf16 [N, ldd] (columns K..ldd zeroed) or NULL */
+    int64_t* preds; float* llh;           /* argmax geocell (N,), its centroid (N,2) */
+    float* topk_vals; int64_t* topk_idx; int num_candidates;   /* (N,num_candidates) softmax probabilities / indices */
+    int64_t* nearest;                     /* (N,) argmin_k haversine(labels, centroids) or NULL */
+} GgGeoHeadArgs;
+int gg_geo_head(const GgGeoHeadArgs* args, void* stream);
+int gg_haversine_matrix(const float* x, const float* centroids, float* out, int N, int K, void* stream);   /* models/utils.py:39 */
+
+/* ---------------------------------------------------------------- ProtoRefiner.forward (models/proto_refiner.py:129-237) */
+typedef struct GgProtoRefineArgs {
+    const float* embedding; int B, V, D;  /* f32 (B,V,D); V views are averaged (:150-151); V=1 for (B,D) */
+    const float* initial_preds;           /* f32 (B,2) lon,lat */
+    const int64_t* candidate_cells;       /* (B,num_candidates) */
+    const float* candidate_probs;         /* f32 (B,num_candidates) or NULL (=> one-hot on candidate 0, :154-156) */
+    int num_candidates, topk;
+    const int64_t* cell_ptr; int num_cells;   /* CSR (num_cells+1) */
+    const float* proto_emb;               /* f32 (P,D) */
+    const float* proto_lnglat;            /* f32 (P,2) */
+    float max_refinement, temperature;
+    float* out_llh; int64_t* out_cell; int64_t* out_idx;
+} GgProtoRefineArgs;
+int gg_proto_refine(const GgProtoRefineArgs* args, void* stream);
+int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, float* dist_km, float* score, void* stream); /* run_benchmark.py:28-65 */
+
+/* ---------------------------------------------------------------- optimizer (main_coordinator_idun_s3.py:286-291) */
+int gg_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+int gg_fill_f32(float* p, int64_t n, float value, void* stream);
+
+/* ---------------------------------------------------------------- TinyViT encoder (timm TinyVit as built by
+ * models/tinyvit.py:48-53 with num_classes=0, global_pool="avg"): whole forward / backward in one call.
+ * Parameters live in one flat f32 buffer, BN running stats in a second one; tensor i of the table has the timm
+ * state-dict name returned by gg_tinyvit_tensor_info. */
+typedef struct GgTinyVitCfg {
+    int img_size, in_chans;
+    int embed_dims[4], depths[4], num_heads[4], window_sizes[4];
+    float mlp_ratio, mbconv_expand_ratio;
+    float bn_eps, ln_eps, bn_momentum;
+} GgTinyVitCfg;
+enum { GG_KIND_PARAM = 0, GG_KIND_BUFFER = 1, GG_KIND_COUNTER = 2 };
+int gg_tinyvit_num_tensors(const GgTinyVitCfg* cfg);
+int gg_tinyvit_tensor_info(const GgTinyVitCfg* cfg, int i, char* name /* host */, int name_cap, int64_t* offset, int64_t* numel,
+                           int* ndim, int64_t* shape4 /* host[4] */, int* kind);
+int64_t gg_tinyvit_param_floats(const GgTinyVitCfg* cfg);      /* flat f32 parameter buffer length (padded) */
+int64_t gg_tinyvit_buffer_floats(const GgTinyVitCfg* cfg);     /* flat f32 running_mean/var buffer length */
+int gg_tinyvit_num_counters(const GgTinyVitCfg* cfg);          /* num_batches_tracked entries (int64) */
+int gg_tinyvit_num_drop_slots(const GgTinyVitCfg* cfg);        /* DropPath slots: 1 per MBConv, 2 per TinyVitBlock */
+int64_t gg_tinyvit_wcache_bytes(const GgTinyVitCfg* cfg);      /* bf16 copies (W and W^T) of the GEMM weights */
+int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training);
+int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream);
+/* x: f32 NCHW (batch,in_chans,img,img).  drop_scales: f32 [num_drop_slots][batch] = keep/(1-p) or NULL.
+ * out: f32 (batch, embed_dims[3]).  training: batch-stat BN + running-stat update + activations kept for backward. */
+int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int training, const float* params, float* buffers, int64_t* counters,
+                       const void* wcache, const float* x, const float* drop_scales, void* workspace, float* out, void* stream);
+/* d_out: f32 (batch, C).  grads: flat f32 like params, ACCUMULATED into.  trainable: host uint8[num_tensors]
+ * (wgrad computed only where 1; dgrad always flows to patch_embed -- SURVEY.md C1). */
+int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,
+                        void* workspace, const float* d_out, float* grads, const uint8_t* trainable /* host */, void* stream);
+/* debug / parity: byte offset of a named saved activation inside the workspace (host) */
+int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes);
+
+/* ---------------------------------------------------------------- CLIP vision tower, inference
+ * (transformers CLIPVisionModel as used by pretrain/clip_embedder.py:63-65: mean over all tokens of last_hidden_state) */
+typedef struct GgClipCfg {
+    int hidden_size, intermediate_size, num_layers, num_heads, image_size, patch_size;
+    float ln_eps;
+} GgClipCfg;
+int gg_clip_num_tensors(const GgClipCfg* cfg);
+int gg_clip_tensor_info(const GgClipCfg* cfg, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4);
+int64_t gg_clip_param_floats(const GgClipCfg* cfg);
+int64_t gg_clip_wcache_bytes(const GgClipCfg* cfg);
+int64_t gg_clip_workspace_bytes(const GgClipCfg* cfg, int batch);
+int gg_clip_refresh_weights(const GgClipCfg* cfg, const float* params, void* wcache, void* stream);
+int gg_clip_forward(const GgClipCfg* cfg, int batch, const float* params, const void* wcache, const float* x, void* workspace,
+                    float* out /* f32 (batch, hidden) */, float* last_hidden /* f32 (batch,T,hidden) or NULL */, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,383 @@
+"""Per-kernel parity: every HIP primitive behind the C-ABI against a plain fp32 CPU reference of the same op on the
+same (bf16-representable) inputs.  Tolerances: bf16 outputs carry one rounding of 2^-9 relative; contractions are
+accumulated in fp32 on both sides.  All tests call through ``libgg.so``."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from geoguessr_ai_amd import ops as o
+    from geoguessr_ai_amd import _lib
+    _lib.require_gpu()
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).float()      # bf16-representable fp32
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def close(got, ref, rtol=1e-2, atol=1e-2, what=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.4g} (ref max {float(ref.abs().max()):.4g})"
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def test_mfma_fragment_layout(ops):
+    """A = permutation-like, B asymmetric: catches swapped row/col maps and transposed outputs."""
+    M = N = K = 128
+    A = torch.zeros(M, K)
+    A[torch.arange(M), (torch.arange(M) * 7 + 3) % K] = 1.0
+    B = (torch.arange(N)[:, None] * 0.5 + torch.arange(K)[None, :] * 0.03125).to(BF).float()
+    got = ops.gemm_nt(dev(A, BF), dev(B, BF), out_f32=True)
+    close(got, A @ B.t(), rtol=1e-6, atol=1e-6, what="mfma layout")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 96), (1000, 48, 32), (4099, 384, 96), (96, 576, 2304),
+                                   (64, 12647, 576), (257, 96, 432)])
+def test_gemm_plain(ops, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
+    ref = A @ B.t()
+    got = ops.gemm_nt(dev(A, BF), dev(B, BF), out_f32=True)
+    close(got, ref, rtol=1e-4, atol=1e-3, what=f"gemm f32 {M}x{N}x{K}")
+    got16 = ops.gemm_nt(dev(A, BF), dev(B, BF))
+    close(got16, ref, rtol=1e-2, atol=1e-2, what="gemm bf16 out")
+
+
+def test_gemm_epilogues(ops):
+    M, N, K, T = 520, 200, 96, 130            # 4 "samples" of 130 rows
+    A, B = rnd(M, K, seed=3), rnd(N, K, seed=4, scale=0.2)
+    bias = rnd(N, seed=5)
+    res = rnd(M, N, seed=6)
+    rs = torch.tensor([0.0, 1.25, 1.25, 0.0])
+    z = A @ B.t() + bias
+    # fc1-style: bias + gelu, pre-activation saved
+    out, pre = ops.gemm_nt(dev(A, BF), dev(B, BF), bias=dev(bias), act="gelu", preact=True)
+    close(pre, z, what="preact")
+    close(out, F.gelu(z), what="gelu")
+    # proj/fc2-style: bias, DropPath row scale, residual
+    out = ops.gemm_nt(dev(A, BF), dev(B, BF), bias=dev(bias), rowscale=dev(rs), rows_per_scale=T, residual=dev(res, BF))
+    close(out, res + rs.repeat_interleave(T)[:, None] * z, what="rowscale+residual")
+    # quick_gelu
+    out = ops.gemm_nt(dev(A, BF), dev(B, BF), bias=dev(bias), act="quick_gelu")
+    close(out, z * torch.sigmoid(1.702 * z), what="quick_gelu")
+    # backward through GELU: out = (A B^T) * gelu'(pre)
+    pre_in = rnd(M, N, seed=7)
+    xg = pre_in.clone().requires_grad_(True)
+    F.gelu(xg).sum().backward()
+    out = ops.gemm_nt(dev(A, BF), dev(B, BF), dact_preact=dev(pre_in, BF), dact="gelu")
+    close(out, (A @ B.t()) * xg.grad, what="dact gelu")
+    # BatchNorm column statistics of the raw accumulators
+    out, stats = ops.gemm_nt(dev(A, BF), dev(B, BF), colstats=True)
+    raw = A @ B.t()
+    s = stats.cpu().sum(0)
+    close(s[0], raw.sum(0), rtol=1e-4, atol=1e-2, what="colsum")
+    close(s[1], (raw * raw).sum(0), rtol=1e-4, atol=1e-2, what="colsumsq")
+
+
+def test_gemm_splitk_and_wgrad_form(ops):
+    """wgrad: dW[N,K] = dY^T X with the reduction (rows) split across blockIdx.y."""
+    Mrows, N, K = 5000, 96, 160
+    X, dY = rnd(Mrows, K, seed=8), rnd(Mrows, N, seed=9, scale=0.1)
+    XT, dYT = ops.transpose_bf16(dev(X, BF)), ops.transpose_bf16(dev(dY, BF))
+    assert XT.shape == (K, 5000) and dYT.shape == (N, 5000)
+    close(XT, X.t(), rtol=0, atol=0, what="transpose")
+    acc = torch.ones(N, K, device="cuda")
+    got = ops.gemm_splitk(dYT, XT, split_k=7, accumulate_into=acc)
+    close(got, 1.0 + dY.t() @ X, rtol=1e-4, atol=1e-2, what="split-k wgrad")
+    # row-scaled transpose (DropPath) and odd row count (zero padded to a multiple of 8)
+    rs = torch.tensor([2.0, 0.0, 0.5])
+    Y = rnd(333, 40, seed=10)
+    YT = ops.transpose_bf16(dev(Y, BF), rowscale=dev(rs), rows_per_scale=111)
+    assert YT.shape == (40, 336)
+    close(YT[:, :333], (Y * rs.repeat_interleave(111)[:, None]).t(), what="scaled transpose")
+    assert float(YT[:, 333:].abs().max()) == 0.0
+    close(ops.colsum_bf16(dev(Y, BF), rowscale=dev(rs), rows_per_scale=111), (Y * rs.repeat_interleave(111)[:, None]).sum(0),
+          rtol=1e-4, atol=1e-3, what="colsum_bf16")
+
+
+# ------------------------------------------------------------------------------------------- convolutions
+def test_im2col_matches_conv(ops):
+    B, H = 2, 20
+    x = rnd(B, 3, H, H, seed=11)
+    w = rnd(16, 3, 3, 3, seed=12, scale=0.3)
+    col = ops.im2col_nchw3(dev(x), stride=2)                      # [B*10*10, 32], k = (ky,kx,ci)
+    wk = torch.zeros(16, 32)
+    wk[:, :27] = w.permute(0, 2, 3, 1).reshape(16, 27)
+    got = ops.gemm_nt(col, dev(wk, BF), out_f32=True).view(B, 10, 10, 16).permute(0, 3, 1, 2)
+    close(got, F.conv2d(x, w, None, 2, 1), rtol=1e-4, atol=1e-3, what="conv1 via im2col")
+    C = 16
+    xh = rnd(B, H, H, C, seed=13)
+    w2 = rnd(24, C, 3, 3, seed=14, scale=0.2)
+    col2 = ops.im2col_nhwc(dev(xh, BF), stride=2)
+    got = ops.gemm_nt(col2, dev(w2.permute(0, 2, 3, 1).reshape(24, 9 * C), BF), out_f32=True).view(B, 10, 10, 24).permute(0, 3, 1, 2)
+    ref = F.conv2d(xh.permute(0, 3, 1, 2), w2, None, 2, 1)
+    close(got, ref, rtol=1e-4, atol=1e-3, what="conv2 via im2col")
+    # col2im is the adjoint of im2col: <im2col(x), d> == <x, col2im(d)>
+    d = rnd(B * 10 * 10, 9 * C, seed=15)
+    dx = ops.col2im_nhwc(dev(d, BF), B, H, H, C, stride=2)
+    xr = xh.clone().requires_grad_(True)
+    cols_ref = F.unfold(xr.permute(0, 3, 1, 2), 3, padding=1, stride=2)             # (B, C*9, L), k = (c,ky,kx)
+    cols_ref = cols_ref.view(B, C, 9, 100).permute(0, 3, 2, 1).reshape(B * 100, 9 * C)   # -> (ky,kx,c)
+    (cols_ref * d).sum().backward()
+    close(dx, xr.grad, what="col2im")
+
+
+@pytest.mark.parametrize("C,stride,H", [(16, 1, 12), (48, 2, 14), (384, 1, 8), (576, 2, 14), (40, 1, 7)])
+def test_dwconv(ops, C, stride, H):
+    B = 3
+    x = rnd(B, H, H, C, seed=20)
+    w = rnd(C, 1, 3, 3, seed=21, scale=0.4)
+    taps = w.view(C, 9).t().contiguous()
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yref = F.conv2d(xr, wr, None, stride, 1, 1, C)
+    y, stats = ops.dwconv3x3_fwd(dev(x, BF), dev(taps), stride=stride, colstats=True)
+    close(y.permute(0, 3, 1, 2), yref, what="dwconv fwd")
+    s = stats.cpu().sum(0)
+    close(s[0], yref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="dw colsum")
+    close(s[1], (yref * yref).sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="dw colsumsq")
+    Ho = yref.shape[-1]
+    dy = rnd(B, Ho, Ho, C, seed=22)
+    yref.backward(dy.permute(0, 3, 1, 2))
+    dx = ops.dwconv3x3_bwd_data(dev(dy, BF), dev(taps), B, H, H, C, stride=stride)
+    close(dx.permute(0, 3, 1, 2), xr.grad, what="dwconv dgrad")
+    dw = ops.dwconv3x3_bwd_weight(dev(x, BF), dev(dy, BF), stride=stride)
+    close(dw, wr.grad, rtol=1e-3, atol=1e-2, what="dwconv wgrad")
+
+
+# ------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("act,with_res", [(None, False), ("gelu", False), ("gelu", True)])
+def test_batchnorm_train(ops, act, with_res):
+    M, C, T = 840, 48, 210
+    y = rnd(M, C, seed=30, scale=2.0) + 0.5
+    gamma, beta = 1 + 0.2 * rnd(C, seed=31), 0.1 * rnd(C, seed=32)
+    res = rnd(M, C, seed=33)
+    rs = torch.tensor([1.25, 0.0, 1.25, 1.25])
+    rsr = rs.repeat_interleave(T)[:, None]
+    # statistics from synthetic per-block partials
+    parts = torch.stack([torch.stack([y[i:i + 128].sum(0), (y[i:i + 128] ** 2).sum(0)]) for i in range(0, M, 128)])
+    rm, rv = torch.zeros(C), torch.ones(C)
+    stat = ops.bn_finalize(dev(parts), M, 1e-5, 0.1, rmd := dev(rm.clone()), rvd := dev(rv.clone()))
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    close(stat[0], mean, rtol=1e-5, atol=1e-5, what="bn mean")
+    close(stat[1], torch.rsqrt(var + 1e-5), rtol=1e-4, atol=1e-5, what="bn rstd")
+    close(rmd, 0.1 * mean, rtol=1e-5, atol=1e-6, what="running_mean")
+    close(rvd, 0.9 + 0.1 * y.var(0, unbiased=True), rtol=1e-4, atol=1e-6, what="running_var")
+
+    yr = y.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.batch_norm(yr, None, None, g_, b_, True, 0.1, 1e-5)
+    if with_res:
+        z = res + rsr * z
+    out_ref = F.gelu(z) if act else z
+    out = ops.bn_apply(dev(y, BF), stat, dev(gamma), dev(beta), act=act, residual=dev(res, BF) if with_res else None,
+                       rowscale=dev(rs) if with_res else None, rows_per_scale=T)
+    close(out, out_ref, what="bn apply")
+    dout = rnd(M, C, seed=34)
+    out_ref.backward(dout)
+    dz, dy, dg, db = ops.bn_bwd(dev(dout, BF), dev(y, BF), stat, dev(gamma), dev(beta), act=act,
+                                residual=dev(res, BF) if with_res else None, rowscale=dev(rs) if with_res else None, rows_per_scale=T)
+    close(dy, yr.grad, rtol=2e-2, atol=1e-2, what="bn dy")
+    close(dg, g_.grad, rtol=1e-2, atol=0.5, what="bn dgamma")
+    close(db, b_.grad, rtol=1e-2, atol=0.5, what="bn dbeta")
+    if with_res:   # dz is the gradient w.r.t. the pre-activation = skip-path gradient of an MBConv
+        zz = z.detach().clone().requires_grad_(True)
+        F.gelu(zz).backward(dout)
+        close(dz, zz.grad, what="bn dz (skip grad)")
+
+
+@pytest.mark.parametrize("C,f32", [(192, False), (576, False), (160, False), (768, False), (576, True), (1024, False)])
+def test_layernorm(ops, C, f32):
+    M = 301
+    x = rnd(M, C, seed=40, scale=1.5) + 0.3
+    gamma, beta = 1 + 0.2 * rnd(C, seed=41), 0.1 * rnd(C, seed=42)
+    xr, g_, b_ = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), g_, b_, 1e-5)
+    xin = dev(x) if f32 else dev(x, BF)
+    out, mean, rstd = ops.layernorm_fwd(xin, dev(gamma), dev(beta))
+    close(out, ref, rtol=1e-4 if f32 else 1e-2, atol=1e-4 if f32 else 1e-2, what="ln fwd")
+    close(mean, x.mean(1), rtol=1e-5, atol=1e-5, what="ln mean")
+    dout, dres = rnd(M, C, seed=43), rnd(M, C, seed=44)
+    ref.backward(dout)
+    dx, dg, db = ops.layernorm_bwd(dev(dout) if f32 else dev(dout, BF), xin, mean, rstd, dev(gamma), dres=dev(dres) if f32 else dev(dres, BF))
+    close(dx, xr.grad + dres, rtol=1e-4 if f32 else 2e-2, atol=1e-4 if f32 else 2e-2, what="ln dx")
+    close(dg, g_.grad, rtol=1e-2, atol=0.3, what="ln dgamma")
+    close(db, b_.grad, rtol=1e-2, atol=0.3, what="ln dbeta")
+
+
+def test_pooling(ops):
+    B, T, C = 5, 49, 64
+    x = rnd(B * T, C, seed=50)
+    close(ops.token_mean_fwd(dev(x, BF), B, T), x.view(B, T, C).mean(1), rtol=1e-5, atol=1e-5, what="token mean")
+    d = rnd(B, C, seed=51)
+    close(ops.token_mean_bwd(dev(d), T), (d / T).repeat_interleave(T, 0), what="token mean bwd")
+
+
+# ------------------------------------------------------------------------------------------- attention
+def _attn_ref(qkv, nh, hd, ws, Hm, Wm, B, bias, layout):
+    """fp32 reference of timm Attention (per-head interleaved qkv, window partition, rel-pos bias) / CLIP MHSA."""
+    from oracle.tinyvit_ref import attention_bias_idxs
+    M = qkv.shape[0]
+    if layout == "tinyvit":
+        x = qkv.view(B, Hm // ws, ws, Wm // ws, ws, nh, 3 * hd).permute(0, 1, 3, 5, 2, 4, 6).reshape(-1, nh, ws * ws, 3 * hd)
+        q, k, v = x.split([hd, hd, hd], -1)
+        s = q @ k.transpose(-1, -2) * hd ** -0.5 + bias[:, attention_bias_idxs(ws)][None]
+    else:
+        T = M // B
+        x = qkv.view(B, T, 3, nh, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = x[0], x[1], x[2]
+        s = q @ k.transpose(-1, -2) * hd ** -0.5
+    o = s.softmax(-1) @ v
+    if layout == "tinyvit":
+        o = o.view(B, Hm // ws, Wm // ws, nh, ws, ws, hd).permute(0, 1, 4, 2, 5, 3, 6).reshape(M, nh * hd)
+    else:
+        o = o.permute(0, 2, 1, 3).reshape(M, nh * hd)
+    return o
+
+
+@pytest.mark.parametrize("ws,Hm,nh", [(7, 14, 2), (14, 14, 3), (7, 7, 2), (12, 12, 1), (16, 16, 1)])
+def test_window_attention_fwd_bwd(ops, ws, Hm, nh):
+    B, hd = 3, 32
+    C = nh * hd
+    M = B * Hm * Hm
+    qkv = rnd(M, 3 * C, seed=60, scale=1.0)
+    bias = rnd(nh, ws * ws, seed=61, scale=0.5)
+    qr, br = qkv.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    ref = _attn_ref(qr, nh, hd, ws, Hm, Hm, B, br, "tinyvit")
+    kw = dict(num_windows=B * (Hm // ws) ** 2, tokens_per_window=ws * ws, num_heads=nh, head_dim=hd, q_off=0, k_off=hd,
+              v_off=2 * hd, head_stride=3 * hd, window_size=ws, map_h=Hm, map_w=Hm, bias=dev(bias))
+    out = ops.attention(dev(qkv, BF), **kw)
+    close(out, ref, rtol=2e-2, atol=2e-2, what="attn fwd")
+    dout = rnd(M, C, seed=62)
+    ref.backward(dout)
+    dqkv, dbias = ops.attention(dev(qkv, BF), dout=dev(dout, BF), want_dbias=True, **kw)
+    close(dqkv, qr.grad, rtol=3e-2, atol=3e-2, what="attn dqkv")
+    close(dbias, br.grad, rtol=3e-2, atol=5e-2, what="attn dbias")
+
+
+def test_clip_attention_fwd(ops):
+    B, T, nh, hd = 4, 50, 3, 64
+    D = nh * hd
+    qkv = rnd(B * T, 3 * D, seed=63)
+    ref = _attn_ref(qkv, nh, hd, 0, 0, 0, B, None, "clip")
+    out = ops.attention(dev(qkv, BF), num_windows=B, tokens_per_window=T, num_heads=nh, head_dim=hd, q_off=0, k_off=D, v_off=2 * D,
+                        head_stride=hd)
+    close(out, ref, rtol=2e-2, atol=2e-2, what="clip attn")
+
+
+# ------------------------------------------------------------------------------------------- head / loss / geo
+def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
+    import os
+    from oracle import geo_ref as G
+    g = np.load(os.path.join(golden_dir, "geo_loss.npz"))
+    labels = g["labels"]
+    logits = np.random.default_rng(int(g["logits_seed"])).standard_normal((16, 12647), dtype=np.float32) * np.float32(g["logits_scale"])
+    cent = dev(torch.from_numpy(centroids))
+    r = ops.geo_head(dev(torch.from_numpy(logits)), cent, labels=dev(torch.from_numpy(labels)), mode=1, want_dlogits=True,
+                     want_nearest=True)
+    np.testing.assert_allclose(float(r["loss"]), float(g["loss"]), rtol=2e-4)            # vs the REFERENCE (fixture)
+    dl = r["dlogits"].float().cpu().numpy()[:, :12647]
+    np.testing.assert_allclose(dl, g["dlogits"], rtol=2e-2, atol=2e-6)                   # bf16 storage of dlogits
+    near = r["nearest"].cpu().numpy()
+    np.testing.assert_allclose(g["distances"][np.arange(16), near], g["distances"][np.arange(16), g["argmin"]], atol=0.05)
+    d = ops.haversine_matrix(dev(torch.from_numpy(labels)), cent).cpu().numpy()
+    np.testing.assert_allclose(d, g["distances"], rtol=2e-4, atol=0.05)                  # 0.05 km (SURVEY 8c tolerance)
+    # predictions vs the oracle
+    lp = G.log_softmax(logits)
+    idx = np.argsort(-lp, axis=-1, kind="stable")[:, :5]
+    np.testing.assert_array_equal(r["topk_idx"].cpu().numpy(), idx)
+    np.testing.assert_allclose(r["topk_vals"].cpu().numpy(), np.exp(np.take_along_axis(lp, idx, -1)), rtol=1e-4)
+    np.testing.assert_array_equal(r["preds"].cpu().numpy(), idx[:, 0])
+    np.testing.assert_allclose(r["llh"].cpu().numpy(), centroids[idx[:, 0]])
+    # hard CE
+    r2 = ops.geo_head(dev(torch.from_numpy(logits)), cent, labels_clf=dev(torch.from_numpy(g["argmin"])), mode=2, want_dlogits=True)
+    np.testing.assert_allclose(float(r2["loss"]), float(g["hard_ce"]), rtol=2e-5)
+    lh, dlh = G.hard_ce(logits, g["argmin"])
+    np.testing.assert_allclose(r2["dlogits"].float().cpu().numpy()[:, :12647], dlh, rtol=2e-2, atol=2e-6)
+
+
+def test_geo_head_small_k_and_edge_rows(ops):
+    """ragged K (not a multiple of the block), a single row, ties broken towards the lower index."""
+    from oracle import geo_ref as G
+    rng = np.random.default_rng(3)
+    K = 1000
+    cent = np.stack([rng.uniform(-180, 180, K), rng.uniform(-90, 90, K)], 1).astype(np.float32)
+    logits = rng.standard_normal((1, K), dtype=np.float32)
+    logits[0, 17] = logits[0, 400] = 9.0                      # tie for the arg-max
+    labels = np.asarray([[cent[5, 0], cent[5, 1]]], np.float32)
+    r = ops.geo_head(dev(torch.from_numpy(logits)), dev(torch.from_numpy(cent)), labels=dev(torch.from_numpy(labels)), mode=1,
+                     want_dlogits=True, want_nearest=True)
+    loss, dl, _, _ = G.soft_ce(logits, labels, cent)
+    np.testing.assert_allclose(float(r["loss"]), loss, rtol=1e-4)
+    assert int(r["nearest"][0]) == 5 and int(r["preds"][0]) == 17 and r["topk_idx"][0, :2].tolist() == [17, 400]
+    np.testing.assert_allclose(r["dlogits"].float().cpu().numpy()[:, :K], dl, rtol=2e-2, atol=1e-5)
+
+
+def test_adamw_matches_torch(ops):
+    n = 1003
+    p, g = rnd(n, seed=70), rnd(n, seed=71, scale=0.1)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=2e-5)
+    pd, md, vd = dev(torch.cat([p, torch.zeros(1)])), torch.zeros(n + 1, device="cuda"), torch.zeros(n + 1, device="cuda")
+    for step in range(1, 4):
+        ref.grad = g * step
+        opt.step()
+        ops.adamw_step(pd[:n], dev(g * step), md[:n], vd[:n], step, 2e-5)
+    close(pd[:n], ref.data, rtol=1e-6, atol=1e-7, what="adamw")
+    assert float(pd[n]) == 0.0
+
+
+def test_proto_refine_matches_oracle():
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    from oracle import proto_ref as P
+    rng = np.random.default_rng(11)
+    Kc, D, B = 40, 64, 33
+    counts = rng.poisson(2.0, Kc)
+    counts[[3, 7]] = 0
+    gi = np.repeat(np.arange(Kc), counts)
+    emb = rng.standard_normal((len(gi), D), dtype=np.float32)
+    lng, lat = rng.uniform(-180, 180, len(gi)).astype(np.float32), rng.uniform(-90, 90, len(gi)).astype(np.float32)
+    ref = ProtoRefiner.from_clusters(gi, emb, lng, lat, Kc, topk=5).cuda().eval()
+    q = rng.standard_normal((B, 4, D), dtype=np.float32)
+    cands = np.stack([rng.permutation(Kc)[:5] for _ in range(B)]).astype(np.int64)
+    cands[0, 0] = 3                                                    # a cell without prototypes
+    probs = np.sort(rng.dirichlet(np.ones(5), B).astype(np.float32), 1)[:, ::-1].copy()
+    init = np.stack([rng.uniform(-180, 180, B), rng.uniform(-90, 90, B)], 1).astype(np.float32)
+    loss, llh, cell = ref(torch.from_numpy(q), torch.from_numpy(init), torch.from_numpy(cands), torch.from_numpy(probs))
+    ptr = ref.cell_ptr.cpu().numpy()
+    o_llh, o_cell, o_idx = P.refine(q, init, cands, probs, ptr, ref.proto_emb.cpu().numpy(), ref.proto_lnglat.cpu().numpy())
+    assert loss is None
+    np.testing.assert_array_equal(cell.cpu().numpy(), o_cell)
+    np.testing.assert_allclose(llh.cpu().numpy(), o_llh)
+    np.testing.assert_array_equal(ref.last_guess_index.cpu().numpy(), o_idx)
+
+
+def test_scoring(ops):
+    from oracle import geo_ref as G
+    rng = np.random.default_rng(2)
+    a = np.stack([rng.uniform(-180, 180, 50), rng.uniform(-90, 90, 50)], 1).astype(np.float32)
+    b = np.stack([rng.uniform(-180, 180, 50), rng.uniform(-90, 90, 50)], 1).astype(np.float32)
+    d, s = ops.geoguessr_score(dev(torch.from_numpy(a)), dev(torch.from_numpy(b)))
+    dref = G.haversine_np_score(a[:, 1], a[:, 0], b[:, 1], b[:, 0])
+    np.testing.assert_allclose(d.cpu().numpy(), dref, rtol=1e-5)
+    np.testing.assert_allclose(s.cpu().numpy(), G.geoguessr_score(dref), rtol=1e-4)
