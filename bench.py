@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the TinyViT-21M-224 4-heading fine-tune step (BASELINE.json configs[1]:
+256 panoramas = 1024 images per GPU per step; forward + backward + AdamW, haversine-smoothed soft-CE over 12 647
+geocells, reference freeze policy ``freeze_all_but_last_stage``, DropPath 0.2, batch-stat BatchNorm) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One process per GPU; ranks shard the global batch (weak scaling: 256 panoramas per GPU) and exchange only gradients
+(sum all-reduce over RCCL, average folded into the AdamW kernel).  Inputs are synthetic and resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.
+
+``roofline``: the dominant kernel is the bf16 MFMA GEMM (``gemm_nt_kernel``, every Linear / 1x1 conv / im2col'd conv and
+their dgrad / wgrad).  achieved = sum of the algorithmic GEMM FLOPs (2MNK per launch) / sum of the launch durations,
+both taken with HIP events recorded on the launch stream inside libgg (``gg_prof_*``) over an instrumented replay of the
+timed steps.  peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
+``cpu_baseline``: the CPU oracle's identical step (torch fp32, all host cores) on a bounded sample, rank 0 / N=1 only.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CATS = ["gemm", "attention", "dwconv", "norm_elementwise", "head_loss", "optimizer", "data_movement"]
+GFLOP_PER_IMAGE = 18.2          # fwd 8.50 + dgrad 8.50 + wgrad(patch_embed + stage 3) 1.20
+
+
+def cpu_baseline(seconds_budget: float = 20.0):
+    """Oracle train step (TinyViT-21M-224 + head, reference freeze policy) on the host cores."""
+    import torch
+    from oracle import step_ref as S, tinyvit_ref as R
+    import numpy as np
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = R.config_for("tiny_vit_21m_224", drop_path_rate=0.0)
+    st = R.init_state(cfg, 0)
+    cent = torch.from_numpy(np.load(os.path.join(ROOT, "geoguessr-ai_amd", "data", "centroids_12647x2_f32.npy")))
+    g = torch.Generator().manual_seed(1234)
+    n = 2
+    x = torch.randn(n, 4, 3, 224, 224, generator=g)
+    labels = torch.stack([torch.rand(n, generator=g) * 360 - 180, torch.rand(n, generator=g) * 180 - 90], 1)
+    W, b = torch.randn(12647, 576, generator=g) * 0.02, torch.zeros(12647)
+    trainable = [k for k in st if k.startswith(("patch_embed", "stages.3", "head")) and "running" not in k and "num_batches" not in k]
+    S.train_step(cfg, st, W, b, cent, x, labels, trainable=trainable)       # warm-up
+    t0, steps = time.time(), 0
+    while steps < 1 or (time.time() - t0) < seconds_budget:
+        S.train_step(cfg, st, W, b, cent, x, labels, trainable=trainable)
+        steps += 1
+    dt = time.time() - t0
+    return dict(value=round(steps * n * 4 / dt, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} oracle train steps (fwd+bwd, torch fp32) of {n} panoramas = {n * 4} images, TinyViT-21M-224 + 12647-cell head, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--panoramas", type=int, default=256, help="panoramas per GPU per step (BASELINE: 256)")
+    ap.add_argument("--model", default="tiny_vit_21m_224")
+    ap.add_argument("--unfrozen", action="store_true", help="train every parameter instead of the reference freeze policy")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from geoguessr_ai_amd import _lib as L
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.optim import AdamW
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    L.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    base = TinyViTAdapter(args.model, pretrained=False)
+    model = SuperGuessr(base, panorama=True, should_smooth_labels=True, serving=False).to(dev).train()
+    if args.unfrozen:
+        base.unfreeze_all()
+    opt = AdamW(model, lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)    # main_coordinator_idun_s3.py:246-248
+    N = args.panoramas
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)              # SURVEY.md 8(d) synthetic inputs
+    x = torch.randn(N, 4, 3, 224, 224, device=dev, generator=g)
+    lab = torch.stack([torch.rand(N, device=dev, generator=g) * 360 - 180, torch.rand(N, device=dev, generator=g) * 180 - 90], 1)
+
+    def step():
+        out = model(pixel_values=x, labels=lab)            # nearest-centroid labels + soft targets fused in the head kernel
+        out.loss.backward()
+        opt.allreduce_grads()
+        opt.step()
+        opt.zero_grad()
+        return out
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out.loss)
+    images = args.steps * N * 4 * world
+    value = images / dt
+
+    roof, breakdown = None, None
+    if not args.no_roofline:
+        lib = L.lib()
+        lib.gg_prof_reset(); lib.gg_prof_enable(1)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        dt_prof = time.perf_counter() - t1
+        lib.gg_prof_enable(0)
+        breakdown = {}
+        for c, name in enumerate(CATS):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            L.check(lib.gg_prof_read(c, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "gg_prof_read")
+            breakdown[name] = dict(ms_per_step=round(ms.value / args.steps, 3), launches_per_step=n.value // args.steps,
+                                   tflops=round(fl.value / max(ms.value, 1e-9) / 1e9, 2) if fl.value else None,
+                                   gbps=round(by.value / max(ms.value, 1e-9) / 1e6, 1) if by.value else None)
+            if name == "gemm":
+                ach = fl.value / max(ms.value, 1e-9) / 1e9
+                roof = dict(bound="mfma", kernel="gemm_nt_kernel", achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s",
+                            frac=round(ach / 2500.0, 4), traffic=None, launches=n.value // args.steps,
+                            avg_launch_us=round(1e3 * ms.value / max(n.value, 1), 2),
+                            gemm_ms_per_step=round(ms.value / args.steps, 3),
+                            algorithmic_gflop_per_launch=round(fl.value / max(n.value, 1) / 1e9, 3))
+        lib.gg_prof_reset()
+        breakdown["instrumented_ms_per_step"] = round(1e3 * dt_prof / args.steps, 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = dict(metric="images/sec TinyViT-21M-224 train, 4-heading batch", value=round(value, 2), unit="images/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+                    config=dict(workload=f"{args.model} 4x224x224 panoramas, fwd+bwd+AdamW, soft-CE over 12647 geocells, "
+                                         f"{'all params' if args.unfrozen else 'freeze_all_but_last_stage'}, DropPath, train-mode BN",
+                                panoramas_per_gpu=N, images_per_gpu=N * 4, global_batch_panoramas=N * world, parallelism=f"dp{world}"),
+                    step_tflops=round(value * GFLOP_PER_IMAGE / 1e3, 2), step_frac_of_mfma_peak=round(value * GFLOP_PER_IMAGE / 1e3 / 2500.0 / world, 4),
+                    loss=round(loss, 5), roofline=roof, cpu_baseline=cpu, kernel_breakdown=breakdown)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -68,6 +68,7 @@ SIGNATURES = {
     "gg_last_error": (C.c_char_p, []),
     "gg_gemm_nt": (_I, [C.POINTER(GemmArgs), _P]),
     "gg_gemm_colstats_rows": (_I, [_I]),
+    "gg_stat_rows_capacity": (_I, [_I]),
     "gg_splitk_reduce": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "gg_transpose_bf16": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "gg_cast_transpose_f32": (_I, [_P, _I, _I, _P, _L, _P, _L, _P]),
@@ -103,6 +104,9 @@ SIGNATURES = {
     "gg_geoguessr_score": (_I, [_P, _P, _I, _P, _P, _P]),
     "gg_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P]),
     "gg_fill_f32": (_I, [_P, _L, _F, _P]),
+    "gg_prof_enable": (_I, [_I]),
+    "gg_prof_reset": (_I, []),
+    "gg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gg_tinyvit_num_tensors": (_I, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_tensor_info": (_I, [C.POINTER(TinyVitCfg), _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I),
                                     C.POINTER(_L), C.POINTER(_I)]),

@@ -1,7 +1,10 @@
 // Error plumbing of libgg (thread-local last-error string).
 #include <stdarg.h>
 #include <stdio.h>
+#include <hip/hip_runtime.h>
+#include <vector>
 #include "../../include/gg.h"
+#include "prof.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -13,3 +16,50 @@ void gg_set_error(const char* fmt, ...) {
 }
 extern "C" const char* gg_last_error(void) { return g_err; }
 extern "C" int gg_version(void) { return GG_VERSION; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Optional per-category kernel timing with HIP events recorded on the launch stream (bench.py roofline numbers).
+// Disabled by default: zero events, zero overhead.
+namespace {
+struct Rec { int cat; hipEvent_t a, b; double flops, bytes; };
+bool g_on = false;
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_next = 0;
+hipEvent_t get_event() {
+    if (g_pool_next == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_next++];
+}
+}  // namespace
+GgProfScope::GgProfScope(int cat, double flops, double bytes, void* stream) : idx_(-1), stream_(stream) {
+    if (!g_on) return;
+    Rec r{cat, get_event(), get_event(), flops, bytes};
+    if (!r.a || !r.b) return;
+    hipEventRecord(r.a, (hipStream_t)stream);
+    g_recs.push_back(r);
+    idx_ = (int)g_recs.size() - 1;
+}
+GgProfScope::~GgProfScope() {
+    if (idx_ >= 0) hipEventRecord(g_recs[idx_].b, (hipStream_t)stream_);
+}
+extern "C" int gg_prof_enable(int on) { g_on = on != 0; return 0; }
+extern "C" int gg_prof_reset(void) { g_recs.clear(); g_pool_next = 0; return 0; }
+extern "C" int gg_prof_read(int cat, double* ms, int64_t* launches, double* flops, double* bytes) {
+    double t = 0, f = 0, b = 0; int64_t n = 0;
+    for (auto& r : g_recs) {
+        if (r.cat != cat) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) { gg_set_error("gg_prof_read: event sync failed"); return -2; }
+        float e = 0;
+        if (hipEventElapsedTime(&e, r.a, r.b) != hipSuccess) { gg_set_error("gg_prof_read: elapsed failed"); return -2; }
+        t += e; f += r.flops; b += r.bytes; ++n;
+    }
+    if (ms) *ms = t;
+    if (launches) *launches = n;
+    if (flops) *flops = f;
+    if (bytes) *bytes = b;
+    return 0;
+}

@@ -403,6 +403,7 @@ extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
     GG_CHECK(a->out && (a->ldo & 3) == 0, "gg_attention_fwd: bad out");
     dim3 grid((unsigned)(a->num_windows * a->num_heads)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 8.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
     const int nkt = attn_nkt(p.N);
 #define GG_FWD(D_, K_) hipLaunchKernelGGL((attn_fwd_kernel<D_, K_>), grid, block, 0, s, p)
     if (a->head_dim == 32) {
@@ -421,6 +422,7 @@ extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
     GG_CHECK(a->head_dim == 32, "gg_attention_bwd: only head_dim 32 (TinyViT) is built");
     dim3 grid((unsigned)(a->num_windows * a->num_heads)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 16.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
     const int nkt = attn_nkt(p.N);
 #define GG_BWD(K_) hipLaunchKernelGGL((attn_bwd_kernel<32, K_>), grid, block, 0, s, p)
     if (nkt == 4) GG_BWD(4); else if (nkt == 10) GG_BWD(10); else if (nkt == 14) GG_BWD(14); else GG_BWD(16);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include "prof.h"
 
 typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -15,7 +16,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- error plumbing (api.cpp) -------------------------------------------------
 extern "C" const char* gg_last_error(void);
-void gg_set_error(const char* fmt, ...);
 #define GG_CHECK(cond, ...)                         \
     do {                                            \
         if (!(cond)) {                              \
@@ -109,6 +109,35 @@ __device__ __forceinline__ float gg_block_max(float v, float* red) {
 #pragma unroll
     for (int i = 0; i < NT / 64; ++i) t = fmaxf(t, red[i]);
     return t;
+}
+
+// ---- two-stage column reduction of per-block partial rows ---------------------------------------------
+// Producers (GEMM / dwconv / BN / LN kernels) leave one partial row per block: part[nparts][W].  With tens of
+// thousands of producer blocks a one-thread-per-column finalize is a serial latency chain, so rows are first
+// folded to <= GG_REDUCE_SLICES rows by a bandwidth-shaped kernel (coalesced along W, fp64 accumulation).  The folded
+// rows are written BEHIND the valid rows of the same buffer, which therefore needs nparts + GG_REDUCE_SLICES rows.
+#define GG_REDUCE_SLICES 64
+static __global__ __launch_bounds__(256) void gg_reduce_rows_kernel(const float* __restrict__ part, int nparts, int W,
+                                                                    float* __restrict__ out, int rows_per_slice) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    const int r0 = blockIdx.y * rows_per_slice, r1 = min(nparts, r0 + rows_per_slice);
+    double s = 0.0;
+    if (col < W)
+        for (int r = r0 + ty; r < r1; r += 4) s += (double)part[(int64_t)r * W + col];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && col < W) out[(int64_t)blockIdx.y * W + col] = (float)(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+// returns the rows to finalize from (either the originals or the folded ones) through *rows / *nrows
+static inline void gg_reduce_rows(float* part, int nparts, int W, hipStream_t st, const float** rows, int* nrows) {
+    if (nparts <= GG_REDUCE_SLICES) { *rows = part; *nrows = nparts; return; }
+    const int rps = (int)((nparts + GG_REDUCE_SLICES - 1) / GG_REDUCE_SLICES);
+    const int slices = (nparts + rps - 1) / rps;
+    float* out = part + (int64_t)nparts * W;
+    hipLaunchKernelGGL(gg_reduce_rows_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)slices), dim3(256), 0, st, part, nparts, W, out, rps);
+    *rows = out; *nrows = slices;
 }
 
 // XCD-aware block remap: consecutive logical ids land on the same XCD (bijective for any n).

@@ -262,6 +262,7 @@ static int grid_for(int64_t n, int cap = 16384) { return (int)std::min<int64_t>(
 extern "C" int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int W, int stride, void* stream) {
     GG_CHECK(x && col && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gg_im2col_nchw3_f32: bad args");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 12.0 * B * H * W + 64.0 * B * Ho * Wo, stream);
     hipLaunchKernelGGL(im2col_nchw3_kernel, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)col, B,
                        H, W, Ho, Wo, stride);
     GG_LAUNCH_CHECK();
@@ -270,6 +271,7 @@ extern "C" int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int 
 extern "C" int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(x && col && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_im2col_nhwc_bf16: bad args (C %% 8)");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 2.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
     hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 9 * (C / 8), 65536)), dim3(256), 0,
                        (hipStream_t)stream, (const bf16*)x, (bf16*)col, B, H, W, C, Ho, Wo, stride);
     GG_LAUNCH_CHECK();
@@ -278,6 +280,7 @@ extern "C" int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W
 extern "C" int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dcol && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_col2im_nhwc_bf16: bad args");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 2.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
     hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)dcol, (bf16*)dx, B, H, W, C, Ho, Wo, stride);
     GG_LAUNCH_CHECK();
@@ -306,6 +309,7 @@ extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, 
     DwGeom g = dw_geom((int64_t)B * Ho * Wo, C, 2 * C);
     GG_CHECK(g.threads <= 1024, "gg_dwconv3x3_fwd: C too large");
     size_t lds = colstats ? (size_t)g.PP * 2 * C * sizeof(float) : 0;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
     hipLaunchKernelGGL(dwconv3x3_fwd_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
                        B, H, W, C, Ho, Wo, stride, g.CG, g.PP, g.pix_per_block, colstats);
     GG_LAUNCH_CHECK();
@@ -314,6 +318,7 @@ extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, 
 extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
     hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0,
                        (hipStream_t)stream, (const bf16*)dy, wt, (bf16*)dx, B, H, W, C, Ho, Wo, stride);
     GG_LAUNCH_CHECK();
@@ -321,7 +326,7 @@ extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, 
 }
 extern "C" int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    return (int64_t)dw_geom((int64_t)B * Ho * Wo, C, 9 * C).nblocks * 9 * C;
+    return ((int64_t)dw_geom((int64_t)B * Ho * Wo, C, 9 * C).nblocks + GG_REDUCE_SLICES) * 9 * C;
 }
 extern "C" int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch,
                                        float* grad, int accumulate, void* stream) {
@@ -329,11 +334,14 @@ extern "C" int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     DwGeom g = dw_geom((int64_t)B * Ho * Wo, C, 9 * C);
     size_t lds = (size_t)g.PP * 9 * C * sizeof(float);
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
     GG_CHECK(lds <= 64 * 1024, "gg_dwconv3x3_bwd_weight: LDS budget exceeded for C=%d", C);
     hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)x,
                        (const bf16*)dy, B, H, W, C, Ho, Wo, stride, g.CG, g.PP, g.pix_per_block, scratch);
-    hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3((unsigned)gg_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, scratch,
-                       g.nblocks, C, grad, accumulate);
+    const float* rows; int nrows;
+    gg_reduce_rows(scratch, g.nblocks, 9 * C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3((unsigned)gg_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                       nrows, C, grad, accumulate);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -337,15 +337,18 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     kps = (int)gg_align(kps, BK);
     p.k_per_split = kps;
     p.tilesM = (int)gg_cdiv(a->M, BM); p.tilesN = (int)gg_cdiv(a->N, BN);
+    GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream);
     dim3 grid(p.tilesM * p.tilesN, split);
     hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int gg_gemm_colstats_rows(int M) { return (int)gg_cdiv(M, BM); }
+extern "C" int gg_stat_rows_capacity(int rows) { return rows + GG_REDUCE_SLICES; }
 
 extern "C" int gg_splitk_reduce(const float* part, float* out, int64_t n, int splits, int accumulate, float scale, void* stream) {
     GG_CHECK(part && out && n > 0 && splits > 0, "gg_splitk_reduce: bad args");
+    GG_PROF(GG_CAT_MOVE, 0, 4.0 * n * (splits + 1), stream);
     int blocks = (int)std::min<int64_t>(gg_cdiv(n, 256), 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, out, n, splits, accumulate, scale);
     GG_LAUNCH_CHECK();
@@ -354,6 +357,7 @@ extern "C" int gg_splitk_reduce(const float* part, float* out, int64_t n, int sp
 extern "C" int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
                                  int rows_per_scale, void* stream) {
     GG_CHECK(in && out && R > 0 && C > 0 && ld >= C && ldo >= R, "gg_transpose_bf16: bad args");
+    GG_PROF(GG_CAT_MOVE, 0, 4.0 * R * C, stream);
     dim3 grid((unsigned)gg_cdiv(C, 64), (unsigned)gg_cdiv(R, 64));
     GG_CHECK(grid.y <= 65535 * 32u, "gg_transpose_bf16: too many rows");
     // gridDim.y limit is 2^31-1 on HIP for y? keep it safe: y <= 65535 requires R <= 4.19M; larger R is chunked
@@ -392,16 +396,19 @@ extern "C" int gg_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* 
     return 0;
 }
 // out[C] (+)= column sums of x[M,C]; scratch must hold gg_colsum_scratch_floats(M, C) floats
-extern "C" int64_t gg_colsum_scratch_floats(int M, int C) { return (int64_t)gg_cdiv(M, 512) * C; }
+extern "C" int64_t gg_colsum_scratch_floats(int M, int C) { return ((int64_t)gg_cdiv(M, 512) + GG_REDUCE_SLICES) * C; }
 extern "C" int gg_colsum_bf16(const void* x, int64_t ld, int M, int C, const float* rowscale, int rows_per_scale,
                               float* scratch, float* out, int accumulate, void* stream) {
     GG_CHECK(x && scratch && out && M > 0 && C > 0, "gg_colsum_bf16: bad args");
+    GG_PROF(GG_CAT_NORM, 0, 2.0 * M * C, stream);
     const int rpb = 512;
     const int nparts = (int)gg_cdiv(M, rpb);
     GG_CHECK(nparts <= 65535, "gg_colsum_bf16: M too large");
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)gg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, scratch, nparts, C, out, accumulate);
+    const float* rows; int nrows;
+    gg_reduce_rows(scratch, nparts, C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)gg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, out, accumulate);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -281,6 +281,7 @@ extern "C" int gg_geo_head(const GgGeoHeadArgs* a, void* stream) {
     p.num_candidates = a->num_candidates > 0 ? a->num_candidates : 1;
     p.nearest = a->nearest;
     const int per = (int)gg_cdiv(a->K, GEO_NT);
+    GG_PROF(GG_CAT_HEAD, 0, (a->dlogits ? 6.0 : 4.0) * a->N * (double)a->K, stream);
     dim3 grid(a->N), block(GEO_NT);
     hipStream_t s = (hipStream_t)stream;
     if (per <= 4) hipLaunchKernelGGL(geo_head_kernel<4>, grid, block, 0, s, p);

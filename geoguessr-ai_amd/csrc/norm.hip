@@ -390,10 +390,12 @@ __global__ void view_mean_bwd_kernel(const bf16* __restrict__ dmean, int64_t ld,
 // ------------------------------------------------------------------------------------------- host
 static int grid_for(int64_t n, int cap = 16384) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(n, 256), cap)); }
 
-extern "C" int gg_bn_finalize(const float* part, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
+extern "C" int gg_bn_finalize(float* part, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
                               float* running_mean, float* running_var, void* stream) {
     GG_CHECK(part && stat && nparts > 0 && C > 0 && count > 0, "gg_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, part, nparts, C,
+    const float* rows; int nrows;
+    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
                        (double)count, eps, momentum, stat, running_mean, running_var);
     GG_LAUNCH_CHECK();
     return 0;
@@ -409,6 +411,7 @@ extern "C" int gg_bn_apply(const void* y, const float* stat, const float* gamma,
                            const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream) {
     GG_CHECK(y && stat && gamma && beta && out && M > 0 && (C & 7) == 0, "gg_bn_apply: bad args");
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_bn_apply: rows_per_scale");
+    GG_PROF(GG_CAT_NORM, 0, (residual ? 6.0 : 4.0) * M * C, stream);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8), 32768)), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, stat,
                        gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)out);
     GG_LAUNCH_CHECK();
@@ -426,7 +429,7 @@ static RowGeom row_geom(int64_t M, int C) {
     g.nblocks = (int)gg_cdiv(M, rpb);
     return g;
 }
-extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return (int64_t)row_geom(M, C).nblocks * 2 * C + 2 * C; }
+extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)row_geom(M, C).nblocks + GG_REDUCE_SLICES) * 2 * C + 2 * C; }
 // scratch: [nblocks][2][C] partials followed by sums [2][C]
 extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
                          int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
@@ -434,13 +437,16 @@ extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, con
     GG_CHECK(dout && y && stat && gamma && beta && dz && dy && scratch && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd: bad args");
     RowGeom g = row_geom(M, C);
     GG_CHECK(g.threads <= 1024, "gg_bn_bwd: C too large");
+    GG_PROF(GG_CAT_NORM, 0, (residual ? 14.0 : 12.0) * M * C, stream);
     float* part = scratch;
-    float* sums = scratch + (int64_t)g.nblocks * 2 * C;
+    float* sums = scratch + ((int64_t)g.nblocks + GG_REDUCE_SLICES) * 2 * C;
     size_t lds = (size_t)g.PP * 2 * C * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)dout,
                        (const bf16*)y, stat, gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)dz, part,
                        g.CG, g.PP, g.rows_per_block);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, part, g.nblocks, C,
+    const float* rows; int nrows;
+    gg_reduce_rows(part, g.nblocks, 2 * C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
                        sums, dgamma, dbeta, accumulate);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8), 32768)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dz,
                        (const bf16*)y, stat, gamma, sums, M, C, residual ? rowscale : nullptr, rows_per_scale, (bf16*)dy);
@@ -453,6 +459,7 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
                                 int out_f32, float* mean, float* rstd, void* stream) {
     GG_CHECK(x && gamma && beta && out && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_fwd: bad args (C %% 8, C <= 1024)");
     dim3 grid(ln_blocks(M)), block(256);
+    GG_PROF(GG_CAT_NORM, 0, 4.0 * M * C, stream);
     hipStream_t s = (hipStream_t)stream;
     if (!x_f32 && !out_f32)
         hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, bf16>), grid, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);
@@ -465,7 +472,7 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
     GG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C) { return (int64_t)ln_blocks(M) * 2 * C; }
+extern "C" int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)ln_blocks(M) + GG_REDUCE_SLICES) * 2 * C; }
 // f32 != 0: x, dout, dres, dx are all f32 (head norm); else all bf16
 extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma,
                                 int64_t M, int C, const void* dres, void* dx, float* scratch, float* dgamma, float* dbeta,
@@ -473,6 +480,7 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
     GG_CHECK(dout && x && mean && rstd && gamma && dx && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_bwd: bad args");
     GG_CHECK(!dgamma || (scratch && dbeta), "gg_layernorm_bwd: parameter grads need scratch + dbeta");
     const int nb = ln_blocks(M);
+    GG_PROF(GG_CAT_NORM, 0, (dres ? 8.0 : 6.0) * M * C, stream);
     float* part = dgamma ? scratch : nullptr;
     size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
     hipStream_t s = (hipStream_t)stream;
@@ -482,8 +490,11 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
     else
         hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, bf16>), dim3(nb), dim3(256), lds, s, (const bf16*)dout, (const bf16*)x, mean, rstd,
                            gamma, M, C, (const bf16*)dres, (bf16*)dx, part);
-    if (dgamma)
-        hipLaunchKernelGGL(ln_param_final_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, s, part, nb, C, dgamma, dbeta, accumulate);
+    if (dgamma) {
+        const float* rows; int nrows;
+        gg_reduce_rows(part, nb, 2 * C, s, &rows, &nrows);
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, s, rows, nrows, C, dgamma, dbeta, accumulate);
+    }
     GG_LAUNCH_CHECK();
     return 0;
 }

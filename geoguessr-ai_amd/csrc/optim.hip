@@ -46,6 +46,7 @@ extern "C" int gg_adamw_step(float* params, const float* grads, float* exp_avg, 
     GG_CHECK(params && grads && exp_avg && exp_avg_sq && n > 0 && step > 0, "gg_adamw_step: bad args");
     GG_CHECK(((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0 && ((uintptr_t)exp_avg & 15) == 0 &&
                  ((uintptr_t)exp_avg_sq & 15) == 0, "gg_adamw_step: ranges must start 16-byte aligned");
+    GG_PROF(GG_CAT_OPTIM, 0, 28.0 * n, stream);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(n / 4 + 1, 256), 8192));
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1,

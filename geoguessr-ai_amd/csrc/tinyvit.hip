@@ -194,7 +194,7 @@ struct Layout {
 
 static int64_t bn_part_floats(int64_t M, int C, int B, int Ho, int Wo, bool dw) {
     const int rows = dw ? gg_dwconv_stat_rows(B, Ho, Wo, C) : gg_gemm_colstats_rows((int)M);
-    return (int64_t)rows * 2 * C;
+    return (int64_t)gg_stat_rows_capacity(rows) * 2 * C;
 }
 
 static void plan_build(const Model& m, int B, Plan& p, Layout& L) {

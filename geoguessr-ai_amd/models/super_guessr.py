@@ -52,7 +52,7 @@ class _HeadFn(torch.autograd.Function):
         wn, wt = model._weight_cache()
         logits = torch.empty((N, Kp), dtype=torch.float32, device=dev)
         ops.gemm_nt(xm, wn, bias=bias.detach(), out_f32=True, out=logits, N=K, ldc=Kp)
-        need_grad = mode != 0 and torch.is_grad_enabled() and (embedding.requires_grad or weight.requires_grad)
+        need_grad = mode != 0 and any(ctx.needs_input_grad)      # grad mode is off inside Function.forward
         r = ops.geo_head(logits, model.geocell_centroid_coords.data, labels=labels, labels_clf=labels_clf, mode=mode,
                          smoothing_km=float(LABEL_SMOOTHING_CONSTANT), want_dlogits=need_grad,
                          num_candidates=model.num_candidates, K=K)

@@ -314,7 +314,8 @@ class TinyVitBackbone(_Tree):
         return self._ws[True][off.value:off.value + nbytes.value]
 
     def forward(self, x):
-        return _EncoderFn.apply(self, x, _anchor(self))
+        need = torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values())
+        return _EncoderFn.apply(self, x, _anchor(self) if need else _anchor(self).detach())
 
 
 def _anchor(bb: TinyVitBackbone) -> torch.Tensor:
@@ -331,7 +332,7 @@ class _EncoderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bb: TinyVitBackbone, x: torch.Tensor, anchor: torch.Tensor):
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in bb._params.values())
+        need_grad = ctx.needs_input_grad[2]      # (grad mode is off inside Function.forward)
         training = bb.training
         drop = bb.make_drop_scales(x.shape[0]) if training else None
         out = bb.forward_hip(x, training, drop)

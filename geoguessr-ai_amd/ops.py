@@ -48,7 +48,9 @@ def gemm_nt(A, B, *, bias=None, act=None, preact=False, rowscale=None, rows_per_
     pre = torch.empty((M, N), dtype=BF16, device=dev) if preact else None
     stats = None
     if colstats:
-        stats = torch.empty((L.lib().gg_gemm_colstats_rows(M), 2, N), dtype=F32, device=dev)
+        rows = L.lib().gg_gemm_colstats_rows(M)
+        stats_buf = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), dtype=F32, device=dev)
+        stats = stats_buf[:rows]
     a = L.GemmArgs()
     a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(A, BF16, "A"), lda, _pr(B, BF16, "B"), ldb, _pr(out), ldc
     a.M, a.N, a.K = M, N, K
@@ -132,7 +134,8 @@ def dwconv3x3_fwd(x, taps, stride=1, colstats=False):
     y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=x.device)
     stats = None
     if colstats:
-        stats = torch.empty((L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc), 2, Cc), dtype=F32, device=x.device)
+        rows = L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc)
+        stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=x.device)[:rows]
     L.check(L.lib().gg_dwconv3x3_fwd(_p(x, BF16), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
             "gg_dwconv3x3_fwd")
     return (y, stats) if colstats else y
@@ -158,6 +161,9 @@ def dwconv3x3_bwd_weight(x, dy, stride=1, grad=None):
 
 def bn_finalize(partials, count, eps=1e-5, momentum=0.1, running_mean=None, running_var=None):
     nparts, _, Cc = partials.shape
+    buf = torch.zeros((L.lib().gg_stat_rows_capacity(nparts), 2, Cc), dtype=F32, device=partials.device)
+    buf[:nparts] = partials
+    partials = buf
     stat = torch.empty((2, Cc), dtype=F32, device=partials.device)
     L.check(L.lib().gg_bn_finalize(_p(partials, F32), nparts, Cc, count, eps, momentum, _p(stat), _p(running_mean, F32),
                                    _p(running_var, F32), L.stream()), "gg_bn_finalize")

@@ -47,6 +47,7 @@ typedef struct GgGemmArgs {
 } GgGemmArgs;
 int gg_gemm_nt(const GgGemmArgs* args, void* stream);
 int gg_gemm_colstats_rows(int M);
+int gg_stat_rows_capacity(int rows);       /* rows a partial-statistics buffer must hold (valid rows + reduction scratch) */
 int gg_splitk_reduce(const float* partials, float* out, int64_t n, int splits, int accumulate, float scale, void* stream);
 int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
                       int rows_per_scale, void* stream);
@@ -72,7 +73,7 @@ int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, 
 
 /* ---------------------------------------------------------------- BatchNorm2d (train-mode batch statistics)
  * stat = [2][C] (mean, rstd).  Partials come from gg_gemm_nt.colstats / gg_dwconv3x3_fwd.colstats. */
-int gg_bn_finalize(const float* partials, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
+int gg_bn_finalize(float* partials /* capacity gg_stat_rows_capacity(nparts) rows */, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
                    float* running_mean, float* running_var, void* stream);
 int gg_bn_eval_stat(const float* running_mean, const float* running_var, int C, float eps, float* stat, void* stream);
 int gg_bn_apply(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
@@ -151,6 +152,12 @@ int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, floa
 int gg_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 int gg_fill_f32(float* p, int64_t n, float value, void* stream);
+
+/* ---------------------------------------------------------------- optional kernel timing (HIP events on the launch stream)
+ * categories: 0 gemm, 1 attention, 2 dwconv, 3 norm/elementwise, 4 head-loss, 5 optimizer, 6 data movement */
+int gg_prof_enable(int on);
+int gg_prof_reset(void);
+int gg_prof_read(int category, double* ms /* host */, int64_t* launches /* host */, double* flops /* host */, double* bytes /* host */);
 
 /* ---------------------------------------------------------------- TinyViT encoder (timm TinyVit as built by
  * models/tinyvit.py:48-53 with num_classes=0, global_pool="avg"): whole forward / backward in one call.

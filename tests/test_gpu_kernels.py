@@ -169,7 +169,7 @@ def test_dwconv(ops, C, stride, H):
 @pytest.mark.parametrize("act,with_res", [(None, False), ("gelu", False), ("gelu", True)])
 def test_batchnorm_train(ops, act, with_res):
     M, C, T = 840, 48, 210
-    y = rnd(M, C, seed=30, scale=2.0) + 0.5
+    y = (rnd(M, C, seed=30, scale=2.0) + 0.5).to(BF).float()
     gamma, beta = 1 + 0.2 * rnd(C, seed=31), 0.1 * rnd(C, seed=32)
     res = rnd(M, C, seed=33)
     rs = torch.tensor([1.25, 0.0, 1.25, 1.25])
@@ -209,7 +209,7 @@ def test_batchnorm_train(ops, act, with_res):
 @pytest.mark.parametrize("C,f32", [(192, False), (576, False), (160, False), (768, False), (576, True), (1024, False)])
 def test_layernorm(ops, C, f32):
     M = 301
-    x = rnd(M, C, seed=40, scale=1.5) + 0.3
+    x = (rnd(M, C, seed=40, scale=1.5) + 0.3).to(BF).float()
     gamma, beta = 1 + 0.2 * rnd(C, seed=41), 0.1 * rnd(C, seed=42)
     xr, g_, b_ = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
     ref = F.layer_norm(xr, (C,), g_, b_, 1e-5)
