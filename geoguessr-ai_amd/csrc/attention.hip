@@ -27,6 +27,7 @@ struct AttnParams {
     const bf16* dout; int64_t lddo;   // [tokens, lddo]
     bf16* dqkv;                       // same layout as qkv
     float* dbias;                     // [nh][nbias] accumulated with atomics, or null
+    float* lse;                       // [tokens][nh] log-sum-exp of the scaled+biased scores (fwd writes, bwd reads)
 };
 
 __device__ __forceinline__ int attn_token(const AttnParams& p, int w, int t) {
@@ -55,6 +56,31 @@ __device__ __forceinline__ bf16x8 attn_pack(const f32x4& a, const f32x4& b) {
     bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
     return v;
 }
+// row-major staging of a [N, D] column block of `src` into X[Np][RS] (zero rows for padded tokens)
+template <int D>
+__device__ __forceinline__ void attn_stage_rows(bf16* X, int RS, const bf16* src, int64_t ld, int col, const int* tok, int Np) {
+    constexpr int CH = D / 8;
+    for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {
+        const int key = idx / CH, dc = idx % CH;
+        *reinterpret_cast<bf16x8*>(X + key * RS + dc * 8) = attn_row_frag(src, ld, tok[key], col + dc * 8);
+    }
+}
+// MFMA operand fragment of row `row`: 8 consecutive bf16 at column 8*lg (+32*ks)
+__device__ __forceinline__ bf16x8 attn_lds_row_frag(const bf16* X, int RS, int row, int col) {
+    return *reinterpret_cast<const bf16x8*>(X + row * RS + col);
+}
+// "k-major" fragment straight from the row-major image with the transposing LDS read (ds_read_b64_tr_b16): lane (lr, lg)
+// receives X[kbase + 4lg + q][d0 + lr] (q = 0..3) and X[kbase + 16 + 4lg + q][d0 + lr]; within each 16-lane group lane
+// 4q+p supplies the address of row q, columns 4p..4p+3.  EXEC must be all ones (all call sites are wave-uniform).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 attn_lds_tr_frag(const bf16* X, int RS, int d0, int kbase, int lr, int lg) {
+    const bf16* p0 = X + (kbase + 4 * lg + (lr >> 2)) * RS + d0 + 4 * (lr & 3);
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * RS));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = a; u.s[1] = b;
+    return u.v;
+}
 // transposed staging of a [N, D] column block of `src` into T[D][stride] (zero for padded keys)
 template <int D>
 __device__ __forceinline__ void attn_stage_transposed(bf16* T, int stride, const bf16* src, int64_t ld, int col, const int* tok,
@@ -72,10 +98,11 @@ __device__ __forceinline__ void attn_stage_transposed(bf16* T, int stride, const
 template <int D, int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     constexpr int Np = NKT * 16;
-    constexpr int VS = Np + 8;
+    constexpr int RS = D + 8;     // 80 / 144-byte rows: 16-B aligned fragments, 8-B aligned transposing reads
     constexpr int KS = D / 32;    // MFMA k-steps over the head dim
     constexpr int DT = D / 16;    // output d tiles
-    __shared__ __attribute__((aligned(16))) bf16 Vt[D * VS];
+    __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
     __shared__ int tok[Np];
     __shared__ float bias_s[256];
     __shared__ unsigned char ci[Np], cj[Np];
@@ -92,7 +119,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     }
     if (p.bias) for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) bias_s[t] = p.bias[h * p.nbias + t];
     __syncthreads();
-    attn_stage_transposed<D>(Vt, VS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok, Np);
+    attn_stage_rows<D>(Ks, RS, p.qkv, p.ld, p.k_off + h * p.head_stride, tok, Np);
+    attn_stage_rows<D>(Vs, RS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok, Np);
     __syncthreads();
 
     const int nqt = (p.N + 15) / 16;
@@ -109,10 +137,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            const int ktok = tok[kt * 16 + lr];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = attn_row_frag(p.qkv, p.ld, ktok, p.k_off + h * p.head_stride + ks * 32 + lg * 8);
+                const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);   // D[i=key][j=query]
             }
 #pragma unroll
@@ -148,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
             const bf16x8 pf = attn_pack(s[2 * kp], s[2 * kp + 1]);   // k = key 32kp + 16(jj>>2) + 4lg + (jj&3)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 vf = attn_tr_frag(Vt, VS, dt * 16 + lr, kp * 32 + lg * 4);
+                const bf16x8 vf = attn_lds_tr_frag(Vs, RS, dt * 16, kp * 32, lr, lg);
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);   // D[i=d][j=query]
             }
         }
@@ -159,24 +186,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(p.out + (int64_t)qtok * p.ldo + h * D + dt * 16 + lg * 4) = ov;
             }
+            if (p.lse && lg == 0) p.lse[(int64_t)qtok * p.nh + h] = mx + __logf(l);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------- backward
+// Flash-style: P is recomputed from the forward's per-row log-sum-exp, delta_q = sum_d dO[q][d] O[q][d] comes from the
+// saved forward output, so no score row has to stay in registers (3+ waves per SIMD instead of 1).
 template <int D, int NKT>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     constexpr int Np = NKT * 16;
-    constexpr int TS = Np + 8;
+    constexpr int RS = D + 8;
     constexpr int KS = D / 32;
     constexpr int DT = D / 16;
-    __shared__ __attribute__((aligned(16))) bf16 Qt[D * TS];
-    __shared__ __attribute__((aligned(16))) bf16 Kt[D * TS];
-    __shared__ __attribute__((aligned(16))) bf16 dOt[D * TS];
-    __shared__ __attribute__((aligned(16))) float row_m[Np], row_linv[Np], row_delta[Np];
+    __shared__ __attribute__((aligned(16))) bf16 Qs[Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 dOs[Np * RS];
+    __shared__ __attribute__((aligned(16))) float row_lse[Np], row_delta[Np];
     __shared__ int tok[Np];
     __shared__ float bias_s[256], dbias_s[256];
-    __shared__ unsigned char ci[Np], cj[Np];
+    __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];
 
     const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -185,103 +216,88 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     const int ocol = h * D;
 
     for (int t = threadIdx.x; t < Np; t += blockDim.x) {
-        tok[t] = attn_token(p, w, t);
+        const int tk = attn_token(p, w, t);
+        tok[t] = tk;
         const int tt = min(t, p.N - 1);
         ci[t] = p.ws ? (unsigned char)(tt / p.ws) : 0;
         cj[t] = p.ws ? (unsigned char)(tt % p.ws) : 0;
+        row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
     }
     for (int t = threadIdx.x; t < 256; t += blockDim.x) {
         bias_s[t] = (p.bias && t < p.nbias) ? p.bias[h * p.nbias + t] : 0.f;
         dbias_s[t] = 0.f;
     }
     __syncthreads();
-    attn_stage_transposed<D>(Qt, TS, p.qkv, p.ld, qcol, tok, Np);
-    attn_stage_transposed<D>(Kt, TS, p.qkv, p.ld, kcol, tok, Np);
-    attn_stage_transposed<D>(dOt, TS, p.dout, p.lddo, ocol, tok, Np);
+    attn_stage_rows<D>(Qs, RS, p.qkv, p.ld, qcol, tok, Np);
+    attn_stage_rows<D>(Ks, RS, p.qkv, p.ld, kcol, tok, Np);
+    attn_stage_rows<D>(Vs, RS, p.qkv, p.ld, vcol, tok, Np);
+    {   // dO rows + delta = rowsum(dO * O)
+        constexpr int CH = D / 8;
+        for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {       // Np*CH is a multiple of 64: full waves
+            const int row = idx / CH, dc = idx % CH;
+            const bf16x8 dv = attn_row_frag(p.dout, p.lddo, tok[row], ocol + dc * 8);
+            const bf16x8 ov = attn_row_frag(p.out, p.ldo, tok[row], ocol + dc * 8);
+            *reinterpret_cast<bf16x8*>(dOs + row * RS + dc * 8) = dv;
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)dv[j] * (float)ov[j];
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);
+            if (dc == 0) row_delta[row] = s;
+        }
+    }
     __syncthreads();
 
     const int nt = (p.N + 15) / 16;
-    // ---- phase 1: a wave owns a query tile; row statistics, delta, dQ, dbias ----
+    // ---- phase 1: a wave owns a query tile -> dQ (and dbias) ----
     for (int qt = wave; qt < nt; qt += 4) {
         const int qi = qt * 16 + lr;
         const int qtok = tok[qi];
         bf16x8 qf[KS], dof[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, qcol + ks * 32 + lg * 8);
-            dof[ks] = attn_row_frag(p.dout, p.lddo, qtok, ocol + ks * 32 + lg * 8);
+            qf[ks] = attn_lds_row_frag(Qs, RS, qi, ks * 32 + lg * 8);
+            dof[ks] = attn_lds_row_frag(dOs, RS, qi, ks * 32 + lg * 8);
         }
         const int qci = ci[qi], qcj = cj[qi];
-        f32x4 s[NKT], dp[NKT];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-            const int ktok = tok[kt * 16 + lr];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = attn_row_frag(p.qkv, p.ld, ktok, kcol + ks * 32 + lg * 8);
-                const bf16x8 vf = attn_row_frag(p.qkv, p.ld, ktok, vcol + ks * 32 + lg * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);      // S^T  [key][query]
-                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc2, 0, 0, 0);   // dP^T [key][query]
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + lg * 4 + r;
-                float v = acc[r] * p.scale;
-                if (p.bias) v += bias_s[abs(qci - (int)ci[key]) * p.ws + abs(qcj - (int)cj[key])];
-                v = key < p.N ? v : -INFINITY;
-                acc[r] = v;
-                mx = fmaxf(mx, v);
-            }
-            s[kt] = acc;
-            dp[kt] = acc2;
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][r] - mx);
-                s[kt][r] = e;
-                l += e;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-        const float linv = 1.f / l;
-        float delta = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[kt][r] *= linv;                 // P
-                delta += s[kt][r] * dp[kt][r];
-            }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);
-        if (lg == 0) { row_m[qi] = mx; row_linv[qi] = linv; row_delta[qi] = delta; }
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ds = s[kt][r] * (dp[kt][r] - delta);
-                dp[kt][r] = ds;                   // dS^T
-                if (p.dbias && qtok >= 0) {
-                    const int key = kt * 16 + lg * 4 + r;
-                    if (key < p.N) atomicAdd(&dbias_s[abs(qci - (int)ci[key]) * p.ws + abs(qcj - (int)cj[key])], ds);
-                }
-            }
+        const float lse_q = row_lse[qi], delta_q = row_delta[qi];
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1
         for (int kp = 0; kp < NKT / 2; ++kp) {
-            const bf16x8 df = attn_pack(dp[2 * kp], dp[2 * kp + 1]);
+            f32x4 dst[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int kt = kp * 2 + u;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
+                    const bf16x8 vf = attn_lds_row_frag(Vs, RS, kt * 16 + lr, ks * 32 + lg * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);      // S^T  [key][query]
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc2, 0, 0, 0);   // dP^T [key][query]
+                }
+                const int key0 = kt * 16 + lg * 4;
+                const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
+                const uchar4 kcj = *reinterpret_cast<const uchar4*>(&cj[key0]);
+                const int kcis[4] = {kci.x, kci.y, kci.z, kci.w}, kcjs[4] = {kcj.x, kcj.y, kcj.z, kcj.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[r] * p.scale;
+                    int bidx = 0;
+                    if (p.bias) { bidx = abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r]); v += bias_s[bidx]; }
+                    const float pr = (key0 + r < p.N) ? __expf(v - lse_q) : 0.f;
+                    const float ds = pr * (acc2[r] - delta_q);
+                    acc2[r] = ds;
+                    if (p.dbias && qtok >= 0 && key0 + r < p.N) atomicAdd(&dbias_s[bidx], ds);
+                }
+                dst[u] = acc2;
+            }
+            const bf16x8 df = attn_pack(dst[0], dst[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 kf = attn_tr_frag(Kt, TS, dt * 16 + lr, kp * 32 + lg * 4);
+                const bf16x8 kf = attn_lds_tr_frag(Ks, RS, dt * 16, kp * 32, lr, lg);
                 dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, df, dq[dt], 0, 0, 0);   // dQ^T [d][query]
             }
         }
@@ -294,53 +310,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             }
         }
     }
-    __syncthreads();
-    if (p.dbias)
-        for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) atomicAdd(&p.dbias[h * p.nbias + t], dbias_s[t]);
-
-    // ---- phase 2: a wave owns a key tile; dK, dV ----
+    // ---- phase 2: a wave owns a key tile -> dK, dV ----
     for (int kt = wave; kt < nt; kt += 4) {
         const int ki = kt * 16 + lr;
         const int ktok = tok[ki];
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = attn_row_frag(p.qkv, p.ld, ktok, kcol + ks * 32 + lg * 8);
-            vf[ks] = attn_row_frag(p.qkv, p.ld, ktok, vcol + ks * 32 + lg * 8);
+            kf[ks] = attn_lds_row_frag(Ks, RS, ki, ks * 32 + lg * 8);
+            vf[ks] = attn_lds_row_frag(Vs, RS, ki, ks * 32 + lg * 8);
         }
         const int kci = ci[ki], kcj = cj[ki];
         const bool kvalid = ki < p.N;
         f32x4 dk[DT], dv[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
+#pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
             f32x4 pt[2], dst[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int qt = qp * 2 + u;
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-                const int qtok = tok[qt * 16 + lr];
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 qf = attn_row_frag(p.qkv, p.ld, qtok, qcol + ks * 32 + lg * 8);
-                    const bf16x8 dof = attn_row_frag(p.dout, p.lddo, qtok, ocol + ks * 32 + lg * 8);
+                    const bf16x8 qf = attn_lds_row_frag(Qs, RS, qt * 16 + lr, ks * 32 + lg * 8);
+                    const bf16x8 dof = attn_lds_row_frag(dOs, RS, qt * 16 + lr, ks * 32 + lg * 8);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], acc, 0, 0, 0);     // S  [query][key]
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[ks], acc2, 0, 0, 0);  // dP [query][key]
                 }
                 const int q0 = qt * 16 + lg * 4;
-                const f32x4 m4 = *reinterpret_cast<const f32x4*>(&row_m[q0]);
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_linv[q0]);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_lse[q0]);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(&row_delta[q0]);
+                const uchar4 qci4 = *reinterpret_cast<const uchar4*>(&ci[q0]);
+                const uchar4 qcj4 = *reinterpret_cast<const uchar4*>(&cj[q0]);
+                const int qcis[4] = {qci4.x, qci4.y, qci4.z, qci4.w}, qcjs[4] = {qcj4.x, qcj4.y, qcj4.z, qcj4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int q = q0 + r;
                     float v = acc[r] * p.scale;
-                    if (p.bias) v += bias_s[abs((int)ci[q] - kci) * p.ws + abs((int)cj[q] - kcj)];
-                    const bool ok = kvalid && q < p.N;    // rows >= N hold uninitialised statistics
-                    const float pr = ok ? __expf(v - m4[r]) * l4[r] : 0.f;
+                    if (p.bias) v += bias_s[abs(qcis[r] - kci) * p.ws + abs(qcjs[r] - kcj)];
+                    const bool ok = kvalid && (q0 + r) < p.N;
+                    const float pr = ok ? __expf(v - l4[r]) : 0.f;
                     acc[r] = pr;
-                    acc2[r] = ok ? pr * (acc2[r] - d4[r]) : 0.f;
+                    acc2[r] = pr * (acc2[r] - d4[r]);      // rows >= N: lse = delta = 0 (initialised), pr = 0
                 }
                 pt[u] = acc;
                 dst[u] = acc2;
@@ -349,8 +361,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             const bf16x8 df = attn_pack(dst[0], dst[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 qtf = attn_tr_frag(Qt, TS, dt * 16 + lr, qp * 32 + lg * 4);
-                const bf16x8 dotf = attn_tr_frag(dOt, TS, dt * 16 + lr, qp * 32 + lg * 4);
+                const bf16x8 qtf = attn_lds_tr_frag(Qs, RS, dt * 16, qp * 32, lr, lg);
+                const bf16x8 dotf = attn_lds_tr_frag(dOs, RS, dt * 16, qp * 32, lr, lg);
                 dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[dt], 0, 0, 0);    // dK^T [d][key]
                 dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[dt], 0, 0, 0);   // dV^T [d][key]
             }
@@ -364,6 +376,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                 *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)ktok * p.ld + vcol + dt * 16 + lg * 4) = b;
             }
         }
+    }
+    if (p.dbias) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) atomicAdd(&p.dbias[h * p.nbias + t], dbias_s[t]);
     }
 }
 
@@ -392,7 +408,7 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
     p.nWx = a->window_size ? a->map_w / a->window_size : 1;
     p.nWy = a->window_size ? a->map_h / a->window_size : 1;
     p.N = a->tokens_per_window; p.nh = a->num_heads; p.scale = a->scale;
-    p.dout = (const bf16*)a->dout; p.lddo = a->lddo; p.dqkv = (bf16*)a->dqkv; p.dbias = a->dbias;
+    p.dout = (const bf16*)a->dout; p.lddo = a->lddo; p.dqkv = (bf16*)a->dqkv; p.dbias = a->dbias; p.lse = a->lse;
     return 0;
 }
 static int attn_nkt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 224 ? 14 : 16)); }
@@ -419,6 +435,7 @@ extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
     AttnParams p;
     GG_TRY(attn_fill(p, a, "gg_attention_bwd"));
     GG_CHECK(a->dout && a->dqkv && (a->lddo & 7) == 0, "gg_attention_bwd: bad dout/dqkv");
+    GG_CHECK(a->lse && a->out && (a->ldo & 7) == 0, "gg_attention_bwd: needs the forward's lse and out");
     GG_CHECK(a->head_dim == 32, "gg_attention_bwd: only head_dim 32 (TinyViT) is built");
     dim3 grid((unsigned)(a->num_windows * a->num_heads)), block(256);
     hipStream_t s = (hipStream_t)stream;

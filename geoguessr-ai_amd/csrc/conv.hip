@@ -11,9 +11,10 @@ __global__ __launch_bounds__(256) void im2col_nchw3_kernel(const float* __restri
                                                            int W, int Ho, int Wo, int stride) {
     const int64_t total = (int64_t)B * Ho * Wo;
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
-        const int ox = (int)(p % Wo);
-        const int oy = (int)((p / Wo) % Ho);
-        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const unsigned pu = (unsigned)p;
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
         const float* xb = x + (int64_t)b * 3 * H * W;
         bf16 v[32];
 #pragma unroll
@@ -46,13 +47,14 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const bf16* __restrict
     const int per_pix = 9 * cg;
     const int64_t total = (int64_t)B * Ho * Wo * per_pix;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % per_pix);
-        const int64_t p = i / per_pix;
+        const int ch = (int)((unsigned)i % (unsigned)per_pix);
+        const int64_t p = (unsigned)i / (unsigned)per_pix;
         const int tap = ch / cg, g = ch % cg;
         const int ky = tap / 3, kx = tap % 3;
-        const int ox = (int)(p % Wo);
-        const int oy = (int)((p / Wo) % Ho);
-        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const unsigned pu = (unsigned)p;
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
         const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (iy >= 0 && iy < H && ix >= 0 && ix < W)
@@ -67,11 +69,12 @@ __global__ __launch_bounds__(256) void col2im_nhwc_kernel(const bf16* __restrict
     const int cg = C >> 3;
     const int64_t total = (int64_t)B * H * W * cg;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const int64_t p = i / cg;
-        const int ix = (int)(p % W);
-        const int iy = (int)((p / W) % H);
-        const int b = (int)(p / ((int64_t)W * H));
+        const int g = (int)((unsigned)i % (unsigned)cg);
+        const int64_t p = (unsigned)i / (unsigned)cg;
+        const unsigned pu = (unsigned)p;
+        const int ix = (int)(pu % (unsigned)W);
+        const int iy = (int)((pu / (unsigned)W) % (unsigned)H);
+        const int b = (int)(pu / ((unsigned)W * (unsigned)H));
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -119,9 +122,10 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
     for (int64_t p = p0 + pp; p < p1; p += PP) {
-        const int ox = (int)(p % Wo);
-        const int oy = (int)((p / Wo) % Ho);
-        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const unsigned pu = (unsigned)p;
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -167,11 +171,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const bf16* __r
     const int cg = C >> 3;
     const int64_t total = (int64_t)B * H * W * cg;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const int64_t p = i / cg;
-        const int ix = (int)(p % W);
-        const int iy = (int)((p / W) % H);
-        const int b = (int)(p / ((int64_t)W * H));
+        const int g = (int)((unsigned)i % (unsigned)cg);
+        const int64_t p = (unsigned)i / (unsigned)cg;
+        const unsigned pu = (unsigned)p;
+        const int ix = (int)(pu % (unsigned)W);
+        const int iy = (int)((pu / (unsigned)W) % (unsigned)H);
+        const int b = (int)(pu / ((unsigned)W * (unsigned)H));
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -213,9 +218,10 @@ __global__ void dwconv3x3_bwd_weight_kernel(const bf16* __restrict__ x, const bf
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
     for (int64_t p = p0 + pp; p < p1; p += PP) {
-        const int ox = (int)(p % Wo);
-        const int oy = (int)((p / Wo) % Ho);
-        const int b = (int)(p / ((int64_t)Wo * Ho));
+        const unsigned pu = (unsigned)p;
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
         const bf16x8 d = *reinterpret_cast<const bf16x8*>(dy + p * C + g * 8);
         float df[8];
 #pragma unroll
@@ -270,6 +276,7 @@ extern "C" int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int 
 }
 extern "C" int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(x && col && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_im2col_nhwc_bf16: bad args (C %% 8)");
+    GG_CHECK((int64_t)B * H * W * 9 * (C / 8) < ((int64_t)1 << 32), "gg_im2col_nhwc_bf16: tensor too large for 32-bit indexing");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_MOVE, 0, 2.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
     hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 9 * (C / 8), 65536)), dim3(256), 0,
@@ -279,6 +286,7 @@ extern "C" int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W
 }
 extern "C" int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dcol && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_col2im_nhwc_bf16: bad args");
+    GG_CHECK((int64_t)B * H * W * (C / 8) < ((int64_t)1 << 32), "gg_col2im_nhwc_bf16: tensor too large for 32-bit indexing");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_MOVE, 0, 2.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
     hipLaunchKernelGGL(col2im_nhwc_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0, (hipStream_t)stream,
@@ -317,6 +325,7 @@ extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, 
 }
 extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");
+    GG_CHECK((int64_t)B * H * W * (C / 8) < ((int64_t)1 << 32), "gg_dwconv3x3_bwd_data: tensor too large for 32-bit indexing");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
     hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0,

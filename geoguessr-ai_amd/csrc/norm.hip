@@ -37,30 +37,33 @@ __global__ void bn_eval_stat_kernel(const float* __restrict__ rm, const float* _
 }
 
 // out = act( [residual + rs *] (gamma * (y - mean) * rstd + beta) )
-__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ stat,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int64_t M, int C,
-                                                       int act, const bf16* __restrict__ residual, const float* __restrict__ rowscale,
-                                                       int rows_per_scale, bf16* __restrict__ out) {
-    const int cg = C >> 3;
-    const int64_t total = M * cg;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const int64_t m = i / cg;
-        const int c0 = g * 8;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
-        bf16x8 r;
-        float rs = 1.f;
-        if (residual) {
-            r = *reinterpret_cast<const bf16x8*>(residual + m * C + c0);
-            if (rowscale) rs = rowscale[m / rows_per_scale];
-        }
-        bf16x8 o;
+// Thread = (row-lane pp, channel group g): g is fixed per thread, so the folded per-channel scale / shift live in
+// registers and the row loop issues only the 16-byte streaming accesses.
+__global__ void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ stat, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int64_t M, int C, int act, const bf16* __restrict__ residual,
+                                const float* __restrict__ rowscale, int rows_per_scale, bf16* __restrict__ out, int CG, int PP,
+                                int rows_per_block) {
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int c0 = g * 8;
+    float sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            float z = ((float)v[j] - stat[c]) * stat[C + c] * gamma[c] + beta[c];
-            if (residual) z = (float)r[j] + rs * z;
-            o[j] = (bf16)gg_act(z, act);
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = stat[C + c0 + j] * gamma[c0 + j];
+        sh[j] = beta[c0 + j] - stat[c0 + j] * sc[j];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t m = r0 + pp; m < r1; m += PP) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+        bf16x8 o;
+        if (residual) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(residual + m * C + c0);
+            const float rs = rowscale ? rowscale[m / rows_per_scale] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)gg_act((float)r[j] + rs * ((float)v[j] * sc[j] + sh[j]), act);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)gg_act((float)v[j] * sc[j] + sh[j], act);
         }
         *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
     }
@@ -137,30 +140,33 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int npart
         dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
     }
 }
-// dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  g = rs*dz
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y,
-                                                           const float* __restrict__ stat, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, int64_t M, int C,
-                                                           const float* __restrict__ rowscale, int rows_per_scale,
-                                                           bf16* __restrict__ dy) {
-    const int cg = C >> 3;
-    const int64_t total = M * cg;
+// dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  g = rs*dz     (same thread geometry as bn_apply)
+__global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y, const float* __restrict__ stat,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, int64_t M, int C,
+                                    const float* __restrict__ rowscale, int rows_per_scale, bf16* __restrict__ dy, int CG, int PP,
+                                    int rows_per_block) {
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int c0 = g * 8;
     const float invM = 1.0f / (float)M;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const int64_t m = i / cg;
-        const int c0 = g * 8;
+    float mu[8], rstd[8], k1[8], k2[8], k3[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = stat[c0 + j]; rstd[j] = stat[C + c0 + j];
+        k1[j] = gamma[c0 + j] * rstd[j];
+        k2[j] = sums[c0 + j] * invM;
+        k3[j] = sums[C + c0 + j] * invM;
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t m = r0 + pp; m < r1; m += PP) {
         const bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + m * C + c0);
         const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
         const float rs = rowscale ? rowscale[m / rows_per_scale] : 1.f;
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = c0 + j;
-            const float rstd = stat[C + c];
-            const float xh = ((float)v[j] - stat[c]) * rstd;
-            const float gg = rs * (float)d[j];
-            o[j] = (bf16)(gamma[c] * rstd * (gg - sums[c] * invM - xh * sums[C + c] * invM));
+            const float xh = ((float)v[j] - mu[j]) * rstd[j];
+            o[j] = (bf16)(k1[j] * (rs * (float)d[j] - k2[j] - xh * k3[j]));
         }
         *reinterpret_cast<bf16x8*>(dy + m * C + c0) = o;
     }
@@ -390,6 +396,18 @@ __global__ void view_mean_bwd_kernel(const bf16* __restrict__ dmean, int64_t ld,
 // ------------------------------------------------------------------------------------------- host
 static int grid_for(int64_t n, int cap = 16384) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(n, 256), cap)); }
 
+struct RowGeom { int CG, PP, threads, rows_per_block, nblocks; };
+static RowGeom row_geom(int64_t M, int C) {
+    RowGeom g;
+    g.CG = C / 8;
+    g.PP = std::max(1, std::min(256 / g.CG, 15360 / (2 * C)));
+    g.threads = g.CG * g.PP;
+    int64_t rpb = std::max<int64_t>(gg_cdiv(M, 8192), (int64_t)g.PP * 4);
+    rpb = gg_align(rpb, g.PP);
+    g.rows_per_block = (int)rpb;
+    g.nblocks = (int)gg_cdiv(M, rpb);
+    return g;
+}
 extern "C" int gg_bn_finalize(float* part, int nparts, int C, int64_t count, float eps, float momentum, float* stat,
                               float* running_mean, float* running_var, void* stream) {
     GG_CHECK(part && stat && nparts > 0 && C > 0 && count > 0, "gg_bn_finalize: bad args");
@@ -412,22 +430,12 @@ extern "C" int gg_bn_apply(const void* y, const float* stat, const float* gamma,
     GG_CHECK(y && stat && gamma && beta && out && M > 0 && (C & 7) == 0, "gg_bn_apply: bad args");
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_bn_apply: rows_per_scale");
     GG_PROF(GG_CAT_NORM, 0, (residual ? 6.0 : 4.0) * M * C, stream);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * (C / 8), 32768)), dim3(256), 0, (hipStream_t)stream, (const bf16*)y, stat,
-                       gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)out);
+    GG_CHECK(C <= 2048, "gg_bn_apply: C too large");
+    RowGeom g = row_geom(M, C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)y, stat, gamma, beta, M, C,
+                       act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)out, g.CG, g.PP, g.rows_per_block);
     GG_LAUNCH_CHECK();
     return 0;
-}
-struct RowGeom { int CG, PP, threads, rows_per_block, nblocks; };
-static RowGeom row_geom(int64_t M, int C) {
-    RowGeom g;
-    g.CG = C / 8;
-    g.PP = std::max(1, std::min(256 / g.CG, 15360 / (2 * C)));
-    g.threads = g.CG * g.PP;
-    int64_t rpb = std::max<int64_t>(gg_cdiv(M, 4096), (int64_t)g.PP * 4);
-    rpb = gg_align(rpb, g.PP);
-    g.rows_per_block = (int)rpb;
-    g.nblocks = (int)gg_cdiv(M, rpb);
-    return g;
 }
 extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)row_geom(M, C).nblocks + GG_REDUCE_SLICES) * 2 * C + 2 * C; }
 // scratch: [nblocks][2][C] partials followed by sums [2][C]
@@ -448,8 +456,8 @@ extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, con
     gg_reduce_rows(part, g.nblocks, 2 * C, (hipStream_t)stream, &rows, &nrows);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
                        sums, dgamma, dbeta, accumulate);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * (C / 8), 32768)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dz,
-                       (const bf16*)y, stat, gamma, sums, M, C, residual ? rowscale : nullptr, rows_per_scale, (bf16*)dy);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)y,
+                       stat, gamma, sums, M, C, residual ? rowscale : nullptr, rows_per_scale, (bf16*)dy, g.CG, g.PP, g.rows_per_block);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -180,7 +180,7 @@ struct Act {   // offsets (bytes) of the saved tensors of one ConvNorm
 };
 struct MBAct { int64_t x, a1, a2, out; Act c1, c2, c3; };
 struct MergeAct { int64_t a1, a2, out; Act c1, c2, c3; };
-struct BlockAct { int64_t x0, a, mean1, rstd1, qkv, o, x1, x2, b, mean2, rstd2, hpre, h, x3; Act local; };
+struct BlockAct { int64_t x0, a, mean1, rstd1, qkv, o, lse, x1, x2, b, mean2, rstd2, hpre, h, x3; Act local; };
 struct Layout {
     int64_t col1, a_pe1, col2, x_pe; Act pe1, pe2;
     std::vector<MBAct> mb;
@@ -259,6 +259,7 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
             a.rstd1 = p.alloc(bn + ".rstd1", M * 4);
             a.qkv = p.alloc(bn + ".qkv", M * 3 * C * 2);
             a.o = p.alloc(bn + ".attn.out", M * C * 2);
+            a.lse = p.alloc(bn + ".attn.lse", M * st.heads * 4);
             a.x1 = p.alloc(bn + ".x1", M * C * 2);
             bnreg(bn + ".local_conv", a.local, M, C, true, B, st.res, st.res);
             a.x2 = p.alloc(bn + ".x2", M * C * 2);
@@ -434,7 +435,7 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
             at.bias = e.P(l.t_ab); at.scale = 0.17677669529663687f;   // 32^-0.5
-            at.out = e.A(a.o); at.ldo = C;
+            at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             GG_TRY(gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
             GG_TRY(conv_dw_fwd(e, l.local, a.local, e.A(a.x1), B, st.res, st.res, 1));
@@ -596,7 +597,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
             at.bias = e.P(l.t_ab); at.scale = 0.17677669529663687f;
-            at.dout = t_a; at.lddo = C; at.dqkv = t_b;
+            at.dout = t_a; at.lddo = C; at.dqkv = t_b; at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
             GG_TRY(gg_attention_bwd(&at, e.st));
             // da = dqkv . Wqkv                                         -> t_a  [M, C]

@@ -238,8 +238,10 @@ def token_mean_bwd(dout, T):
 
 
 def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off, k_off, v_off, head_stride,
-              window_size=0, map_h=0, map_w=0, bias=None, scale=None, dout=None, want_dbias=False):
-    """forward when ``dout`` is None, else backward -> (dqkv, dbias)."""
+              window_size=0, map_h=0, map_w=0, bias=None, scale=None, dout=None, want_dbias=False, out=None, lse=None,
+              want_lse=False):
+    """forward when ``dout`` is None (returns out, or (out, lse) with ``want_lse``); else backward given the forward's
+    ``out`` and ``lse`` -> (dqkv, dbias)."""
     a = L.AttnArgs()
     a.qkv, a.ld = _p(qkv, BF16, "qkv"), qkv.stride(0)
     a.q_off, a.k_off, a.v_off, a.head_stride, a.head_dim = q_off, k_off, v_off, head_stride, head_dim
@@ -251,11 +253,14 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
     if dout is None:
         out = torch.empty((tokens, num_heads * head_dim), dtype=BF16, device=qkv.device)
         a.out, a.ldo = _p(out), out.stride(0)
+        lse_t = torch.empty((tokens, num_heads), dtype=F32, device=qkv.device) if want_lse else None
+        a.lse = _p(lse_t)
         L.check(L.lib().gg_attention_fwd(C.byref(a), L.stream()), "gg_attention_fwd")
-        return out
+        return (out, lse_t) if want_lse else out
     dqkv = torch.zeros_like(qkv)
     dbias = torch.zeros_like(bias) if (want_dbias and bias is not None) else None
     a.dout, a.lddo, a.dqkv, a.dbias = _p(dout, BF16, "dout"), dout.stride(0), _p(dqkv), _p(dbias)
+    a.out, a.ldo, a.lse = _p(out, BF16, "out"), out.stride(0), _p(lse, F32, "lse")
     L.check(L.lib().gg_attention_bwd(C.byref(a), L.stream()), "gg_attention_bwd")
     return dqkv, dbias
 

@@ -107,6 +107,8 @@ typedef struct GgAttnArgs {
     const void* dout; int64_t lddo;       /* backward */
     void* dqkv;                           /* backward: same layout as qkv */
     float* dbias;                         /* backward: f32 [num_heads][ws*ws], ACCUMULATED, or NULL */
+    float* lse;                           /* f32 [tokens][num_heads] row log-sum-exp: forward writes (may be NULL), backward reads;
+                                             backward also reads `out` (the forward result) */
 } GgAttnArgs;
 int gg_attention_fwd(const GgAttnArgs* args, void* stream);
 int gg_attention_bwd(const GgAttnArgs* args, void* stream);

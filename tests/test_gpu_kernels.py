@@ -266,11 +266,11 @@ def test_window_attention_fwd_bwd(ops, ws, Hm, nh):
     ref = _attn_ref(qr, nh, hd, ws, Hm, Hm, B, br, "tinyvit")
     kw = dict(num_windows=B * (Hm // ws) ** 2, tokens_per_window=ws * ws, num_heads=nh, head_dim=hd, q_off=0, k_off=hd,
               v_off=2 * hd, head_stride=3 * hd, window_size=ws, map_h=Hm, map_w=Hm, bias=dev(bias))
-    out = ops.attention(dev(qkv, BF), **kw)
+    out, lse = ops.attention(dev(qkv, BF), want_lse=True, **kw)
     close(out, ref, rtol=2e-2, atol=2e-2, what="attn fwd")
     dout = rnd(M, C, seed=62)
     ref.backward(dout)
-    dqkv, dbias = ops.attention(dev(qkv, BF), dout=dev(dout, BF), want_dbias=True, **kw)
+    dqkv, dbias = ops.attention(dev(qkv, BF), dout=dev(dout, BF), want_dbias=True, out=out, lse=lse, **kw)
     close(dqkv, qr.grad, rtol=3e-2, atol=3e-2, what="attn dqkv")
     close(dbias, br.grad, rtol=3e-2, atol=5e-2, what="attn dbias")
 
