@@ -49,11 +49,30 @@ static inline int64_t gg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t gg_align(int64_t a, int64_t b) { return gg_cdiv(a, b) * b; }
 
 // ---- device math ---------------------------------------------------------------
-__device__ __forceinline__ float gg_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off level) -- libm's erff costs ~5x more
+// VALU and made the GELU epilogues, not HBM, the limiter of the fc1 GEMMs.  The exp(-u^2) term is shared with the
+// Gaussian pdf needed by the derivative.
+__device__ __forceinline__ void gg_erf_parts(float x, float& erf_v, float& expmu2) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, u, 1.0f));
+    const float e = __expf(-u * u);
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float er = fmaf(-poly * t, e, 1.0f);
+    erf_v = copysignf(er, x);
+    expmu2 = e;
+}
+__device__ __forceinline__ float gg_gelu(float x) {
+    float er, e;
+    gg_erf_parts(x, er, e);
+    return 0.5f * x * (1.0f + er);
+}
 __device__ __forceinline__ float gg_gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float er, e;
+    gg_erf_parts(x, er, e);
+    return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.0f + er));
 }
 __device__ __forceinline__ float gg_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gg_quick_gelu_grad(float x) {

@@ -13,8 +13,7 @@
 
 #define BM 128
 #define BN 128
-#define BK 32
-#define LDS_STRIDE (BK + 8)   // 80-byte rows: 16-B aligned, spreads ds_read_b128 over banks
+#define BK 64
 
 struct GemmParams {
     const bf16* A; int64_t lda;
@@ -33,85 +32,22 @@ struct GemmParams {
     int tilesM, tilesN;
 };
 
-__device__ __forceinline__ void load_tile_regs(const bf16* __restrict__ P, int64_t ld, int rows, int K,
-                                               int row0, int k0, int kend, bf16x8 (&r)[2]) {
-    // 128 rows x 32 k = 512 chunks of 8 bf16; thread t takes chunks t and t+256
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = threadIdx.x + i * 256;
-        const int row = c >> 2, kc = (c & 3) * 8;
-        const int gr = row0 + row, gk = k0 + kc;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (gr < rows && gk < kend) v = *reinterpret_cast<const bf16x8*>(P + (int64_t)gr * ld + gk);
-        r[i] = v;
-    }
-}
-__device__ __forceinline__ void store_tile_lds(bf16* __restrict__ S, const bf16x8 (&r)[2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = threadIdx.x + i * 256;
-        const int row = c >> 2, kc = (c & 3) * 8;
-        *reinterpret_cast<bf16x8*>(S + row * LDS_STRIDE + kc) = r[i];
-    }
+// LDS image of a 128 x 64 operand tile: unpadded 128-byte rows, the eight 16-byte chunks of a row XOR-swizzled with
+//   T(row) = 2*bit1(row) + 4*bit3(row)
+// which makes every 16-lane group of the fragment ds_read_b128 (lanes = 16 rows x 4 k-chunks) hit 16 distinct
+// 16-byte bank slots, and keeps the staging ds_write_b128 (8 lanes = one whole row) conflict-free.
+__device__ __forceinline__ int lds_chunk_off(int row, int kc) {
+    return row * BK + ((kc ^ ((row & 2) | ((row >> 1) & 4))) << 3);
 }
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) bf16 smem[2 * 2 * BM * LDS_STRIDE];
-#define AS_(b) (smem + (b) * (BM * LDS_STRIDE))
-#define BS_(b) (smem + (2 + (b)) * (BM * LDS_STRIDE))
-
-    const int tiles = p.tilesM * p.tilesN;
-    const int bid = gg_xcd_remap(blockIdx.x, tiles);
-    const int tm = bid / p.tilesN, tn = bid % p.tilesN;   // consecutive ids share the A row panel
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
-    const int kbeg = z * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 ra[2], rb[2];
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile_regs(p.A, p.lda, p.M, p.K, m0, kbeg, kend, ra);
-        load_tile_regs(p.B, p.ldb, p.N, p.K, n0, kbeg, kend, rb);
-        store_tile_lds(AS_(0), ra);
-        store_tile_lds(BS_(0), rb);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            load_tile_regs(p.A, p.lda, p.M, p.K, m0, kbeg + (kt + 1) * BK, kend, ra);
-            load_tile_regs(p.B, p.ldb, p.N, p.K, n0, kbeg + (kt + 1) * BK, kend, rb);
-        }
-        bf16x8 xf[4], wf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            xf[i] = *reinterpret_cast<const bf16x8*>(AS_(cur) + (wm * 64 + i * 16 + lr) * LDS_STRIDE + lg * 8);
-            wf[i] = *reinterpret_cast<const bf16x8*>(BS_(cur) + (wn * 64 + i * 16 + lr) * LDS_STRIDE + lg * 8);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        if (kt + 1 < nk) {
-            store_tile_lds(AS_(cur ^ 1), ra);
-            store_tile_lds(BS_(cur ^ 1), rb);
-        }
-        __syncthreads();
-    }
-
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f32x4 (&acc)[4][4], int m0, int n0, int tm, int z,
+                                              int wm, int wn, int lr, int lg) {
     // ---------------- epilogue: lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
+    // bf16 results are staged through LDS (the k-loop buffers are dead) so that global stores are 16 bytes per lane
+    // along full 256-byte tile rows instead of 8-byte fragments of 16 different rows.
+    constexpr int CS = BN + 8;                      // staged tile row stride (elements): 272 B, 16-B aligned
+    bf16* Cs = smem;                                // [BM][CS] = 34 816 B
+    const bool staged = !p.out_f32 && p.split_k <= 1;
     const bool vec_ok = ((p.ldc & 3) == 0) && (p.residual == nullptr || (p.ldr & 3) == 0);
     float csum[4][4], csq[4][4];
     if (p.colstats) {
@@ -119,6 +55,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) csum[i][r] = csq[i][r] = 0.f;
+    }
+    // cooperative wide store of the staged tile: 16 lanes x 16 B per row, 16 rows per pass
+    auto flush_tile = [&](bf16* dst) {
+        __syncthreads();
+        const int chunk = threadIdx.x & 15, rr = threadIdx.x >> 4;
+        const int n = n0 + chunk * 8;
+        const bool wide = ((p.ldc & 7) == 0) && (n + 7 < p.N);
+#pragma unroll
+        for (int pass = 0; pass < BM / 16; ++pass) {
+            const int row = pass * 16 + rr, m = m0 + row;
+            if (m >= p.M || n >= p.N) continue;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
+            bf16* g = dst + (int64_t)m * p.ldc + n;
+            if (wide) *reinterpret_cast<bf16x8*>(g) = v;
+            else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
+        }
+        __syncthreads();
+    };
+    if (staged && p.preact) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + wn * 64 + nt * 16 + lg * 4;
+                f32x4 v = acc[nt][mt];
+                if (p.bias) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+                }
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(Cs + (wm * 64 + mt * 16 + lr) * CS + wn * 64 + nt * 16 + lg * 4) = o;
+            }
+        flush_tile(p.preact);
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -134,65 +103,68 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { csum[nt][r] += v[r]; csq[nt][r] += v[r] * v[r]; }
             }
-            if (!mok || n >= p.N) continue;
+            const bool inb = mok && n < p.N;
             if (p.split_k > 1) {
+                if (!inb) continue;
                 float* Cz = reinterpret_cast<float*>(p.C) + ((int64_t)z * p.M + m) * p.ldc + n;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r < p.N) Cz[r] = v[r];
                 continue;
             }
             const bool full = vec_ok && (n + 3 < p.N);
-            if (p.bias) {
+            if (inb) {
+                if (p.bias) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
-            }
-            if (p.preact) {
-                bf16* P = p.preact + (int64_t)m * p.ldc + n;
-                if (full) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *reinterpret_cast<bf16x4*>(P) = o; }
-                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) P[r] = (bf16)v[r]; }
-            }
-            if (p.act) {
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+                }
+                if (p.preact && !staged) {
+                    bf16* P = p.preact + (int64_t)m * p.ldc + n;
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) P[r] = (bf16)v[r];
+                }
+                if (p.act) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gg_act(v[r], p.act);
-            }
-            if (p.dact) {
-                const bf16* D = p.dact_preact + (int64_t)m * p.ldc + n;
-                if (full) {
-                    bf16x4 d = *reinterpret_cast<const bf16x4*>(D);
+                    for (int r = 0; r < 4; ++r) v[r] = gg_act(v[r], p.act);
+                }
+                if (p.dact) {
+                    const bf16* D = p.dact_preact + (int64_t)m * p.ldc + n;
+                    if (full) {
+                        bf16x4 d = *reinterpret_cast<const bf16x4*>(D);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= gg_act_grad((float)d[r], p.dact);
-                } else {
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= gg_act_grad((float)D[r], p.dact);
+                        for (int r = 0; r < 4; ++r) v[r] *= gg_act_grad((float)d[r], p.dact);
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= gg_act_grad((float)D[r], p.dact);
+                    }
+                }
+                if (p.rowscale) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= rs;
+                }
+                if (p.residual) {
+                    const bf16* R = p.residual + (int64_t)m * p.ldr + n;
+                    if (full) {
+                        bf16x4 d = *reinterpret_cast<const bf16x4*>(R);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)d[r];
+                    } else {
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += (float)R[r];
+                    }
                 }
             }
-            if (p.rowscale) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= rs;
-            }
-            if (p.residual) {
-                const bf16* R = p.residual + (int64_t)m * p.ldr + n;
-                if (full) {
-                    bf16x4 d = *reinterpret_cast<const bf16x4*>(R);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)d[r];
-                } else {
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += (float)R[r];
-                }
-            }
-            if (p.out_f32) {
+            if (staged) {
+                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(Cs + (wm * 64 + mt * 16 + lr) * CS + wn * 64 + nt * 16 + lg * 4) = o;
+            } else if (inb) {
                 float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
                 if (full) *reinterpret_cast<f32x4*>(Cf) = v;
                 else { for (int r = 0; r < 4; ++r) if (n + r < p.N) Cf[r] = v[r]; }
-            } else {
-                bf16* Cb = reinterpret_cast<bf16*>(p.C) + (int64_t)m * p.ldc + n;
-                if (full) { bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]}; *reinterpret_cast<bf16x4*>(Cb) = o; }
-                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) Cb[r] = (bf16)v[r]; }
             }
         }
     }
+    if (staged) flush_tile(reinterpret_cast<bf16*>(p.C));
     if (p.colstats) {
         // rows beyond M and k beyond K contributed exact zeros.  Reduce over the 16 lanes sharing lg,
-        // then over the two wm waves through LDS (the staging buffers are dead after the k loop).
+        // then over the two wm waves through LDS.
+        if (!staged) __syncthreads();
         float* red = reinterpret_cast<float*>(smem);   // [2 wm][2 {sum,sq}][128 n]
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -217,6 +189,93 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
             }
         }
     }
+    if (p.colstats) __syncthreads();     // the next tile's operand stores reuse this buffer
+}
+
+__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
+    // one operand stage (A 16 KiB + B 16 KiB); the next k-tile travels through registers while this one is consumed.
+    // The epilogue reuses the buffer as a [128][136] bf16 staging tile (34 816 B).  (A persistent variant with
+    // cross-tile prefetch was measured slower at 2 and 3 workgroups per CU: register pressure / spills.)
+    __shared__ __attribute__((aligned(16))) bf16 smem[BM * (BN + 8)];
+    bf16* As = smem;
+    bf16* Bs = smem + BM * BK;
+
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    const int tm = bid / p.tilesN, tn = bid % p.tilesN;   // consecutive ids share the A row panel
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int kbeg = z * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // ---- per-thread staging geometry, fixed for the whole k loop: chunk c = tid + 256*i -> row c>>3, k-chunk c&7 ----
+    const int srow = threadIdx.x >> 3, skc = threadIdx.x & 7;          // rows srow + 32*i
+    const bf16* ga[4]; const bf16* gb[4];
+    bool va[4], vb[4];
+    int lds_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        va[i] = (m0 + row) < p.M;
+        vb[i] = (n0 + row) < p.N;
+        ga[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + kbeg + skc * 8;
+        gb[i] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + kbeg + skc * 8;
+        lds_off[i] = lds_chunk_off(row, skc);
+    }
+    // fragment read offsets (elements): row = w*64 + i*16 + lr; only bits 1,3 of lr enter the swizzle
+    const int sw = (lr & 2) | ((lr >> 1) & 4);
+    const int a_base = (wm * 64 + lr) * BK, b_base = (wn * 64 + lr) * BK;
+    const int kc0 = ((0 + lg) ^ sw) << 3, kc1 = ((4 + lg) ^ sw) << 3;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 ra[4], rb[4];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int nk = (kend - kbeg + BK - 1) / BK;
+    auto load_tile = [&](int kt) {
+        const int koff = kt * BK;
+        const bool kok = (kbeg + koff + skc * 8) < kend;     // K % 8 == 0: a chunk is entirely in or out
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = (va[i] && kok) ? *reinterpret_cast<const bf16x8*>(ga[i] + koff) : zero8;
+            rb[i] = (vb[i] && kok) ? *reinterpret_cast<const bf16x8*>(gb[i] + koff) : zero8;
+        }
+    };
+    if (nk > 0) load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<bf16x8*>(As + lds_off[i]) = ra[i];
+            *reinterpret_cast<bf16x8*>(Bs + lds_off[i]) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = ks ? kc1 : kc0;
+            bf16x8 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xf[i] = *reinterpret_cast<const bf16x8*>(As + a_base + i * 16 * BK + kc);
+                wf[i] = *reinterpret_cast<const bf16x8*>(Bs + b_base + i * 16 * BK + kc);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg);
 }
 
 // sum split-K partials: out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i]
