@@ -74,9 +74,9 @@ __device__ __forceinline__ float gg_gelu_grad(float x) {
     gg_erf_parts(x, er, e);
     return fmaf(x * 0.3989422804014327f, e, 0.5f * (1.0f + er));
 }
-__device__ __forceinline__ float gg_quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float gg_quick_gelu(float x) { return x * __frcp_rn(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gg_quick_gelu_grad(float x) {
-    const float s = 1.0f / (1.0f + __expf(-1.702f * x));
+    const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
     return s + 1.702f * x * s * (1.0f - s);
 }
 // act codes shared by GEMM epilogues and norm kernels

