@@ -164,6 +164,128 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
     }
 }
 
+// ---------------------------------------------------------------- LDS-tiled depthwise 3x3
+// Block = (image, band of 8 output rows, chunk of 64 channels); it walks the band in 8-pixel-wide tiles.  The input
+// tile (+halo) is staged once in LDS (next tile prefetched through registers), so HBM sees every input byte once and
+// each output costs 9 LDS reads instead of 9 global loads.  Optional fused producer: the staged values are
+// act(gamma*(x-mean)*rstd+beta) of the previous ConvNorm (BatchNorm + GELU applied on the fly; zero padding stays
+// zero), which removes the separate bn_apply pass and its 2 x [M,C] of traffic.  `flip` reverses the taps (= the
+// data gradient of a stride-1 depthwise conv).  Per-channel sum / sum-of-squares of the result (BatchNorm partials) are
+// written as one row per (image, band): colstats[row][2][C].
+template <int S>
+__global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __restrict__ x, const float* __restrict__ wt,
+                                                              bf16* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo,
+                                                              int nbands, int nchunks, int flip, const float* __restrict__ in_stat,
+                                                              const float* __restrict__ in_gamma, const float* __restrict__ in_beta,
+                                                              int in_act, float* __restrict__ colstats) {
+    // thread = (channel quad g of 16, pixel slot ps of 16): 4 channels (8-byte accesses) keep the 9x4 taps, the
+    // accumulators and the prefetched chunks within ~100 VGPRs
+    constexpr int TH = 8, TW = 8, CT = 64, Q = 4, NG = CT / Q;
+    constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    constexpr int NCH = IH * IW * NG;
+    constexpr int LPT = (NCH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16 tile[IH * IW * CT];
+    const int cc = blockIdx.x % nchunks;
+    const int band = (blockIdx.x / nchunks) % nbands;
+    const int b = blockIdx.x / (nchunks * nbands);
+    const int c0 = cc * CT;
+    const int g = threadIdx.x & (NG - 1), ps = threadIdx.x / NG;
+    const int cg0 = c0 + g * Q;
+    const bool cok = cg0 < C;                       // C % 8 == 0; the last chunk may be partial (C % 64 != 0)
+    float wreg[9][Q];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) wreg[t][j] = cok ? wt[(flip ? 8 - t : t) * C + cg0 + j] : 0.f;
+    float sc[Q], sh[Q];
+    const bool fused = in_stat != nullptr;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        sc[j] = (fused && cok) ? in_stat[C + cg0 + j] * in_gamma[cg0 + j] : 1.f;
+        sh[j] = (fused && cok) ? in_beta[cg0 + j] - in_stat[cg0 + j] * sc[j] : 0.f;
+    }
+    const int oy0 = band * TH;
+    const int iy0 = oy0 * S - 1;
+    const bf16* xb = x + (int64_t)b * H * W * C;
+    bf16x4 pre[LPT];
+    const bf16x4 zero4 = {0, 0, 0, 0};
+    auto load_tile = [&](int ox0) {
+        const int ix0 = ox0 * S - 1;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int ch = threadIdx.x + i * 256;            // chunk = (pixel, channel quad): quad == g for every i
+            const int pix = ch / NG;
+            const int py = pix / IW, px = pix - py * IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            bf16x4 v = zero4;
+            if (ch < NCH && cok && iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                v = *reinterpret_cast<const bf16x4*>(xb + ((int64_t)iy * W + ix) * C + cg0);
+                if (fused) {
+#pragma unroll
+                    for (int j = 0; j < Q; ++j) v[j] = (bf16)gg_act((float)v[j] * sc[j] + sh[j], in_act);
+                }
+            }
+            pre[i] = v;
+        }
+    };
+    float s[Q], q[Q];
+#pragma unroll
+    for (int j = 0; j < Q; ++j) s[j] = q[j] = 0.f;
+    const int ntx = (Wo + TW - 1) / TW;
+    load_tile(0);
+    for (int tx = 0; tx < ntx; ++tx) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int ch = threadIdx.x + i * 256;
+            if (ch < NCH) *reinterpret_cast<bf16x4*>(tile + ch * Q) = pre[i];
+        }
+        __syncthreads();
+        if (tx + 1 < ntx) load_tile((tx + 1) * TW);
+#pragma unroll 1
+        for (int pi = 0; pi < (TH * TW) / 16; ++pi) {
+            const int p = ps + 16 * pi;
+            const int oyl = p >> 3, oxl = p & 7;
+            const int oy = oy0 + oyl, ox = tx * TW + oxl;
+            float acc[Q] = {0, 0, 0, 0};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(tile + ((oyl * S + ky) * IW + oxl * S + kx) * CT + g * Q);
+#pragma unroll
+                    for (int j = 0; j < Q; ++j) acc[j] += (float)v[j] * wreg[ky * 3 + kx][j];
+                }
+            if (oy < Ho && ox < Wo && cok) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {
+                    o[j] = (bf16)acc[j];
+                    s[j] += acc[j];
+                    q[j] += acc[j] * acc[j];
+                }
+                *reinterpret_cast<bf16x4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * C + cg0) = o;
+            }
+        }
+        __syncthreads();
+    }
+    if (colstats) {
+        float* red = reinterpret_cast<float*>(tile);        // [16 slots][2][64]  (8 KiB <= tile)
+#pragma unroll
+        for (int j = 0; j < Q; ++j) {
+            red[(ps * 2 + 0) * CT + g * Q + j] = s[j];
+            red[(ps * 2 + 1) * CT + g * Q + j] = q[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * CT) {
+            const int which = threadIdx.x / CT, col = threadIdx.x % CT;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[(k * 2 + which) * CT + col];
+            if (c0 + col < C) colstats[((int64_t)(b * nbands + band) * 2 + which) * C + c0 + col] = t;
+        }
+    }
+}
+
 // dx[b,iy,ix,c] = sum_{ky,kx} w[ky][kx][c] * dy[b,oy,ox,c],  oy*stride + ky - 1 == iy
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const bf16* __restrict__ dy, const float* __restrict__ wt,
                                                                  bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
@@ -308,24 +430,42 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
     g.nblocks = (int)gg_cdiv(npix, ppb);
     return g;
 }
-extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C) { return dw_geom((int64_t)B * Ho * Wo, C, 2 * C).nblocks; }
+extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C) { return B * (int)gg_cdiv(Ho, 8); }
 
-extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats,
-                                void* stream) {
-    GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && C <= 2048 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
+static int dwconv_tiled_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, int flip,
+                               const float* in_stat, const float* in_gamma, const float* in_beta, int in_act, float* colstats,
+                               void* stream) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    DwGeom g = dw_geom((int64_t)B * Ho * Wo, C, 2 * C);
-    GG_CHECK(g.threads <= 1024, "gg_dwconv3x3_fwd: C too large");
-    size_t lds = colstats ? (size_t)g.PP * 2 * C * sizeof(float) : 0;
+    const int nbands = (int)gg_cdiv(Ho, 8), nchunks = (int)gg_cdiv(C, 64);
+    const int64_t blocks = (int64_t)B * nbands * nchunks;
+    GG_CHECK(blocks < ((int64_t)1 << 31), "dwconv: grid too large");
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
-    hipLaunchKernelGGL(dwconv3x3_fwd_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
-                       B, H, W, C, Ho, Wo, stride, g.CG, g.PP, g.pix_per_block, colstats);
+    if (stride == 1)
+        hipLaunchKernelGGL(dwconv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
+                           B, H, W, C, Ho, Wo, nbands, nchunks, flip, in_stat, in_gamma, in_beta, in_act, colstats);
+    else
+        hipLaunchKernelGGL(dwconv3x3_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
+                           B, H, W, C, Ho, Wo, nbands, nchunks, flip, in_stat, in_gamma, in_beta, in_act, colstats);
     GG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats,
+                                void* stream) {
+    GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
+    return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, nullptr, nullptr, nullptr, 0, colstats, stream);
+}
+// fused producer: x is the PRE-BatchNorm output of the previous ConvNorm; act(BN(x)) is formed while staging
+extern "C" int gg_dwconv3x3_fwd_fused(const void* x, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act,
+                                      const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream) {
+    GG_CHECK(x && wt && y && in_stat && in_gamma && in_beta && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2),
+             "gg_dwconv3x3_fwd_fused: bad args");
+    return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, in_stat, in_gamma, in_beta, in_act, colstats, stream);
 }
 extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");
     GG_CHECK((int64_t)B * H * W * (C / 8) < ((int64_t)1 << 32), "gg_dwconv3x3_bwd_data: tensor too large for 32-bit indexing");
+    if (stride == 1)     // data gradient of a stride-1 depthwise conv == the same conv with flipped taps
+        return dwconv_tiled_launch(dy, wt, dx, B, H, W, C, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, stream);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
     hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0,

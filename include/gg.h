@@ -66,6 +66,8 @@ int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, in
 int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream);
 int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C);
 int gg_dwconv3x3_fwd(const void* x, const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
+int gg_dwconv3x3_fwd_fused(const void* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act,
+                           const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
 int gg_dwconv3x3_bwd_data(const void* dy, const float* taps, void* dx, int B, int H, int W, int C, int stride, void* stream);
 int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride);
 int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch, float* grad /* (C,1,3,3) */,
