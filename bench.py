@@ -36,13 +36,15 @@ def cpu_baseline(seconds_budget: float = 20.0):
     import torch
     from oracle import step_ref as S, tinyvit_ref as R
     import numpy as np
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool degrades badly when oversubscribed with the many small ops of a 224-px ViT step
+    # (256 threads: 169 s/step on the GPU box; 8/16/32/64 threads: 10.7/11.3/8.3/4.4 images/s): use 16 worker threads and report that number as `cores`
+    cores = min(os.cpu_count() or 1, int(os.environ.get("GG_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     cfg = R.config_for("tiny_vit_21m_224", drop_path_rate=0.0)
     st = R.init_state(cfg, 0)
     cent = torch.from_numpy(np.load(os.path.join(ROOT, "geoguessr-ai_amd", "data", "centroids_12647x2_f32.npy")))
     g = torch.Generator().manual_seed(1234)
-    n = 2
+    n = 4
     x = torch.randn(n, 4, 3, 224, 224, generator=g)
     labels = torch.stack([torch.rand(n, generator=g) * 360 - 180, torch.rand(n, generator=g) * 180 - 90], 1)
     W, b = torch.randn(12647, 576, generator=g) * 0.02, torch.zeros(12647)

@@ -9,6 +9,7 @@
 #include <map>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/gg.h"
 
@@ -323,6 +324,9 @@ struct Exec {
     const char* wc; char* ws; hipStream_t st;
     const float* drop;   // [slots][B] or null
     float* grads; const uint8_t* trainable;
+    // Fusing BatchNorm+GELU of the producer into the depthwise conv's staging removes one [M,C] write+read but makes the
+    // conv VALU-bound (erf on tile + halo): measured +6.6 ms conv vs -3.1 ms elementwise at 1024 images -> off by default.
+    bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
@@ -367,6 +371,15 @@ static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const bf1
     GG_TRY(gg_dwconv3x3_fwd(x, e.Taps(c.w), e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
     return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
 }
+// depthwise ConvNorm whose input is act(BN(prev.y)) of the preceding ConvNorm, formed on the fly while staging
+static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, const BNP& prev_bn, const Act& prev, int in_act, int B, int H,
+                             int W, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    float* part = e.training ? e.F(e.L->statpart) : nullptr;
+    GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
+                                  c.w.C, stride, part, e.st));
+    return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+}
 static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
                     const float* rowscale = nullptr, int rps = 0) {
     return gg_bn_apply(e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, residual, rowscale, rps, out, e.st);
@@ -397,8 +410,12 @@ static int forward_impl(Exec& e, const float* x, float* out) {
     for (size_t i = 0; i < m.mb.size(); ++i) {
         const MBConvL& l = m.mb[i]; const MBAct& a = L.mb[i];
         GG_TRY(conv_dense_fwd(e, l.c1, a.c1, e.A(a.x), d[0], M0));
-        GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
-        GG_TRY(conv_dw_fwd(e, l.c2, a.c2, e.A(a.a1), B, H0, H0, 1));
+        if (e.fuse_dw) {
+            GG_TRY(conv_dw_fwd_fused(e, l.c2, a.c2, l.c1.bn, a.c1, GG_ACT_GELU, B, H0, H0, 1));   // act1 is never materialised
+        } else {
+            GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
+            GG_TRY(conv_dw_fwd(e, l.c2, a.c2, e.A(a.a1), B, H0, H0, 1));
+        }
         GG_TRY(bn_apply(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, e.A(a.a2)));
         GG_TRY(conv_dense_fwd(e, l.c3, a.c3, e.A(a.a2), mid, M0));
         GG_TRY(bn_apply(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, e.A(a.out), e.A(a.x), e.training ? e.dropv(slot) : nullptr, rps0));
@@ -414,8 +431,12 @@ static int forward_impl(Exec& e, const float* x, float* out) {
         const MergeAct& ma = L.merge[s];
         // PatchMerging
         GG_TRY(conv_dense_fwd(e, st.merge.c1, ma.c1, e.A(prev), Cprev, Mprev));
-        GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Mprev, GG_ACT_GELU, e.A(ma.a1)));
-        GG_TRY(conv_dw_fwd(e, st.merge.c2, ma.c2, e.A(ma.a1), B, res, res, 2));
+        if (e.fuse_dw) {
+            GG_TRY(conv_dw_fwd_fused(e, st.merge.c2, ma.c2, st.merge.c1.bn, ma.c1, GG_ACT_GELU, B, res, res, 2));
+        } else {
+            GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Mprev, GG_ACT_GELU, e.A(ma.a1)));
+            GG_TRY(conv_dw_fwd(e, st.merge.c2, ma.c2, e.A(ma.a1), B, res, res, 2));
+        }
         GG_TRY(bn_apply(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, e.A(ma.a2)));
         GG_TRY(conv_dense_fwd(e, st.merge.c3, ma.c3, e.A(ma.a2), C, M));
         GG_TRY(bn_apply(e, st.merge.c3.bn, ma.c3, M, GG_ACT_NONE, e.A(ma.out)));
@@ -625,8 +646,10 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (e.tr(st.merge.c3.w.t_w)) GG_TRY(dense_wgrad(e, st.merge.c3.w, e.A(ma.a2), C, t_a, C, M, nullptr, 0, t_b, t_c, false));
         GG_TRY(gemm(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_b, C, M, C, C));                 // da2 -> t_b
         GG_TRY(bn_bwd(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, t_b, t_c, t_a));                          // dy2 -> t_a
-        if (e.tr(st.merge.c2.w.t_w))
+        if (e.tr(st.merge.c2.w.t_w)) {
+            if (e.fuse_dw) GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, e.A(ma.a1)));      // act1 was fused away in forward
             GG_TRY(gg_dwconv3x3_bwd_weight(e.A(ma.a1), t_a, B, rin, rin, C, 2, e.F(L.bnscratch), e.Gd(st.merge.c2.w.t_w), 1, e.st));
+        }
         GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(st.merge.c2.w), t_b, B, rin, rin, C, 2, e.st));        // da1 -> t_b [Min, C]
         GG_TRY(bn_bwd(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, t_b, t_c, t_a));                        // dy1 -> t_a
         if (e.tr(st.merge.c1.w.t_w)) GG_TRY(dense_wgrad(e, st.merge.c1.w, e.A(xin), Cin, t_a, C, Min, nullptr, 0, t_b, t_c, false));
@@ -646,8 +669,10 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (e.tr(l.c3.w.t_w)) GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
         GG_TRY(gemm(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_c, mid, M0, mid, d[0]));                     // da2 -> t_c [M0, mid]
         GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                                  // dy2 -> t_a
-        if (e.tr(l.c2.w.t_w))
+        if (e.tr(l.c2.w.t_w)) {
+            if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));                 // act1 was fused away in forward
             GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+        }
         GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));               // da1 -> t_c
         GG_TRY(bn_bwd(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d, t_a));                                  // dy1 -> t_a
         if (e.tr(l.c1.w.t_w)) GG_TRY(dense_wgrad(e, l.c1.w, e.A(a.x), d[0], t_a, mid, M0, nullptr, 0, t_c, t_d, false));
