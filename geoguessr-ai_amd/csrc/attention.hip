@@ -18,7 +18,8 @@ struct AttnParams {
     const bf16* qkv; int64_t ld;
     int q_off, k_off, v_off, head_stride;
     bf16* out; int64_t ldo;           // forward output [tokens, ldo], head h at column h*D
-    const float* bias; int nbias;     // [nh][nbias] relative-position table or null; idx = |di|*ws + |dj|
+    const float* bias; int nbias;     // EXPANDED bias [nh][Np][Np] f32 (gg_attention_expand_bias; padded keys = -inf) or null;
+                                      // nbias = ws*ws = size of the table the bias gradient is reduced into
     int ws, nWx, nWy, H, W;           // ws > 0: windows of ws x ws tokens inside an H x W map; ws == 0: linear
     int N;                            // tokens per window
     int nh;
@@ -94,6 +95,22 @@ __device__ __forceinline__ void attn_stage_transposed(bf16* T, int stride, const
     }
 }
 
+// attention_biases[h][|di|*ws+|dj|] -> full[h][q][k] (Np x Np, row-major): the kernels then fetch 4 consecutive keys of a
+// query row with one 16-byte load instead of 4 x (index arithmetic + LDS gather).  Padded keys carry -inf so no mask
+// select is needed; the matrix is symmetric, which the backward's [query][key] orientation uses.
+__global__ void attn_expand_bias_kernel(const float* __restrict__ table, int nh, int ws, int N, int Np, float* __restrict__ full) {
+    const int64_t total = (int64_t)nh * Np * Np;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Np), q = (int)((i / Np) % Np), h = (int)(i / ((int64_t)Np * Np));
+        float v = -INFINITY;
+        if (k < N) {
+            const int qq = min(q, N - 1);
+            v = table[h * ws * ws + abs(qq / ws - k / ws) * ws + abs(qq % ws - k % ws)];
+        }
+        full[i] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- forward
 template <int D, int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
@@ -104,20 +121,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
     __shared__ int tok[Np];
-    __shared__ float bias_s[256];
-    __shared__ unsigned char ci[Np], cj[Np];
 
     const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
+    const float* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
 
-    for (int t = threadIdx.x; t < Np; t += blockDim.x) {
-        tok[t] = attn_token(p, w, t);
-        const int tt = min(t, p.N - 1);
-        ci[t] = p.ws ? (unsigned char)(tt / p.ws) : 0;
-        cj[t] = p.ws ? (unsigned char)(tt % p.ws) : 0;
-    }
-    if (p.bias) for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) bias_s[t] = p.bias[h * p.nbias + t];
+    for (int t = threadIdx.x; t < Np; t += blockDim.x) tok[t] = attn_token(p, w, t);
     __syncthreads();
     attn_stage_rows<D>(Ks, RS, p.qkv, p.ld, p.k_off + h * p.head_stride, tok, Np);
     attn_stage_rows<D>(Vs, RS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok, Np);
@@ -130,8 +140,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         bf16x8 qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
-        const int qci = ci[qi], qcj = cj[qi];
-
         f32x4 s[NKT];
         float mx = -INFINITY;
 #pragma unroll
@@ -142,15 +150,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);   // D[i=key][j=query]
             }
+            const int key0 = kt * 16 + lg * 4;
+            if (bias_h) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + key0);   // -inf on padded keys
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + lg * 4 + r;
-                float v = acc[r] * p.scale;
-                if (p.bias) v += bias_s[abs(qci - (int)ci[key]) * p.ws + abs(qcj - (int)cj[key])];
-                v = key < p.N ? v : -INFINITY;
-                acc[r] = v;
-                mx = fmaxf(mx, v);
+                for (int r = 0; r < 4; ++r) acc[r] = fmaf(acc[r], p.scale, bv[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (key0 + r < p.N) ? acc[r] * p.scale : -INFINITY;
             }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[r]);
             s[kt] = acc;
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -206,8 +216,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16 dOs[Np * RS];
     __shared__ __attribute__((aligned(16))) float row_lse[Np], row_delta[Np];
     __shared__ int tok[Np];
-    __shared__ float bias_s[256], dbias_s[256];
-    __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];
+    __shared__ float dbias_s[256];
+    __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];   // window coordinates: bias-gradient binning only
 
     const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -223,10 +233,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         cj[t] = p.ws ? (unsigned char)(tt % p.ws) : 0;
         row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
     }
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) {
-        bias_s[t] = (p.bias && t < p.nbias) ? p.bias[h * p.nbias + t] : 0.f;
-        dbias_s[t] = 0.f;
-    }
+    for (int t = threadIdx.x; t < 256; t += blockDim.x) dbias_s[t] = 0.f;
+    const float* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
     __syncthreads();
     attn_stage_rows<D>(Qs, RS, p.qkv, p.ld, qcol, tok, Np);
     attn_stage_rows<D>(Ks, RS, p.qkv, p.ld, kcol, tok, Np);
@@ -279,18 +287,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc2, 0, 0, 0);   // dP^T [key][query]
                 }
                 const int key0 = kt * 16 + lg * 4;
-                const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
-                const uchar4 kcj = *reinterpret_cast<const uchar4*>(&cj[key0]);
-                const int kcis[4] = {kci.x, kci.y, kci.z, kci.w}, kcjs[4] = {kcj.x, kcj.y, kcj.z, kcj.w};
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias_h) bv = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + key0);   // -inf on padded keys
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[r] * p.scale;
-                    int bidx = 0;
-                    if (p.bias) { bidx = abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r]); v += bias_s[bidx]; }
-                    const float pr = (key0 + r < p.N) ? __expf(v - lse_q) : 0.f;
-                    const float ds = pr * (acc2[r] - delta_q);
-                    acc2[r] = ds;
-                    if (p.dbias && qtok >= 0 && key0 + r < p.N) atomicAdd(&dbias_s[bidx], ds);
+                    const float v = fmaf(acc[r], p.scale, bv[r]);
+                    const float pr = (bias_h || key0 + r < p.N) ? __expf(v - lse_q) : 0.f;
+                    acc2[r] = pr * (acc2[r] - delta_q);
+                }
+                if (p.dbias && qtok >= 0) {     // bias gradient, binned by |di|,|dj| (only the trainable last stage takes this path)
+                    const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
+                    const uchar4 kcj = *reinterpret_cast<const uchar4*>(&cj[key0]);
+                    const int kcis[4] = {kci.x, kci.y, kci.z, kci.w}, kcjs[4] = {kcj.x, kcj.y, kcj.z, kcj.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (key0 + r < p.N) atomicAdd(&dbias_s[abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r])], acc2[r]);
                 }
                 dst[u] = acc2;
             }
@@ -320,7 +331,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             kf[ks] = attn_lds_row_frag(Ks, RS, ki, ks * 32 + lg * 8);
             vf[ks] = attn_lds_row_frag(Vs, RS, ki, ks * 32 + lg * 8);
         }
-        const int kci = ci[ki], kcj = cj[ki];
         const bool kvalid = ki < p.N;
         f32x4 dk[DT], dv[DT];
 #pragma unroll
@@ -342,13 +352,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                 const int q0 = qt * 16 + lg * 4;
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_lse[q0]);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(&row_delta[q0]);
-                const uchar4 qci4 = *reinterpret_cast<const uchar4*>(&ci[q0]);
-                const uchar4 qcj4 = *reinterpret_cast<const uchar4*>(&cj[q0]);
-                const int qcis[4] = {qci4.x, qci4.y, qci4.z, qci4.w}, qcjs[4] = {qcj4.x, qcj4.y, qcj4.z, qcj4.w};
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias_h) bv = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)min(ki, p.N - 1) * Np + q0);   // symmetric: bias[q][k] == bias[k][q]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = acc[r] * p.scale;
-                    if (p.bias) v += bias_s[abs(qcis[r] - kci) * p.ws + abs(qcjs[r] - kcj)];
+                    const float v = fmaf(acc[r], p.scale, bv[r]);
                     const bool ok = kvalid && (q0 + r) < p.N;
                     const float pr = ok ? __expf(v - l4[r]) : 0.f;
                     acc[r] = pr;
@@ -398,7 +406,8 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
         GG_CHECK(a->num_windows % ((a->map_h / a->window_size) * (a->map_w / a->window_size)) == 0, "%s: window count", who);
         GG_CHECK(a->window_size <= 16, "%s: window_size > 16 unsupported", who);
     }
-    if (a->bias) GG_CHECK(a->window_size > 0 && a->tokens_per_window <= 256, "%s: bias needs a window geometry", who);
+    if (a->bias || a->dbias) GG_CHECK(a->window_size > 0 && a->tokens_per_window <= 256, "%s: bias needs a window geometry", who);
+    if (a->bias) GG_CHECK(((uintptr_t)a->bias & 15) == 0, "%s: expanded bias must be 16-byte aligned", who);
     p.qkv = (const bf16*)a->qkv; p.ld = a->ld;
     p.q_off = a->q_off; p.k_off = a->k_off; p.v_off = a->v_off; p.head_stride = a->head_stride;
     p.out = (bf16*)a->out; p.ldo = a->ldo;
@@ -412,6 +421,16 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
     return 0;
 }
 static int attn_nkt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 224 ? 14 : 16)); }
+extern "C" int gg_attention_padded_tokens(int tokens_per_window) { return 16 * attn_nkt(tokens_per_window); }
+extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int window_size, float* full, void* stream) {
+    GG_CHECK(table && full && num_heads > 0 && window_size > 0 && window_size <= 16, "gg_attention_expand_bias: bad args");
+    const int N = window_size * window_size, Np = 16 * attn_nkt(N);
+    const int64_t total = (int64_t)num_heads * Np * Np;
+    hipLaunchKernelGGL(attn_expand_bias_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
+                       table, num_heads, window_size, N, Np, full);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
     AttnParams p;

@@ -24,7 +24,7 @@ struct ConvBNDense { DenseW w; BNP bn; };
 struct ConvBNDw { DwW w; BNP bn; };
 struct MBConvL { ConvBNDense c1; ConvBNDw c2; ConvBNDense c3; };
 struct MergeL { ConvBNDense c1; ConvBNDw c2; ConvBNDense c3; };
-struct BlockL { int t_ab = -1; LNP ln1; DenseW qkv, proj; LNP ln2; DenseW fc1, fc2; ConvBNDw local; };
+struct BlockL { int t_ab = -1; int64_t bias_full = 0; LNP ln1; DenseW qkv, proj; LNP ln2; DenseW fc1, fc2; ConvBNDw local; };
 struct StageL { MergeL merge; std::vector<BlockL> blocks; int C, heads, ws, res; };
 
 struct Model {
@@ -129,6 +129,10 @@ static int build_model(const GgTinyVitCfg* cfg, Model& m) {
             BlockL& b = st.blocks[i];
             const std::string p = "stages." + std::to_string(s) + ".blocks." + std::to_string(i);
             b.t_ab = add_tensor(m, p + ".attn.attention_biases", {nh, ws * ws}, GG_KIND_PARAM);
+            {
+                const int np_ = gg_attention_padded_tokens(ws * ws);
+                b.bias_full = wc_alloc(m, (int64_t)nh * np_ * np_ * 4);
+            }
             make_ln(m, b.ln1, p + ".attn.norm", C);
             std::string bn = p + ".attn.qkv.bias";
             make_dense(m, b.qkv, p + ".attn.qkv.weight", 3 * C, C, 1, &bn, false);
@@ -455,7 +459,7 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = e.P(l.t_ab); at.scale = 0.17677669529663687f;   // 32^-0.5
+            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = 0.17677669529663687f;   // 32^-0.5
             at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             GG_TRY(gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
@@ -617,7 +621,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = e.P(l.t_ab); at.scale = 0.17677669529663687f;
+            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = 0.17677669529663687f;
             at.dout = t_a; at.lddo = C; at.dqkv = t_b; at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
             GG_TRY(gg_attention_bwd(&at, e.st));
@@ -805,6 +809,8 @@ extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* 
             GG_TRY(repack_dense(b.fc1, params, m, wc, st));
             GG_TRY(repack_dense(b.fc2, params, m, wc, st));
             GG_TRY(repack_dw(b.local.w, params, m, wc, st));
+            GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws,
+                                            reinterpret_cast<float*>(wc + b.bias_full), stream));
         }
     }
     return 0;

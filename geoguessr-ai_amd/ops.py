@@ -247,7 +247,13 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
     a.q_off, a.k_off, a.v_off, a.head_stride, a.head_dim = q_off, k_off, v_off, head_stride, head_dim
     a.num_heads, a.num_windows, a.tokens_per_window = num_heads, num_windows, tokens_per_window
     a.window_size, a.map_h, a.map_w = window_size, map_h, map_w
-    a.bias = _p(bias, F32, "bias")
+    full = None
+    if bias is not None:      # relative-position table [heads][ws*ws] -> expanded [heads][Np][Np]
+        Np = L.lib().gg_attention_padded_tokens(tokens_per_window)
+        full = torch.empty((num_heads, Np, Np), dtype=F32, device=qkv.device)
+        L.check(L.lib().gg_attention_expand_bias(_p(bias, F32, "bias"), num_heads, window_size, _p(full), L.stream()),
+                "gg_attention_expand_bias")
+    a.bias = _p(full)
     a.scale = head_dim ** -0.5 if scale is None else scale
     tokens = qkv.shape[0]
     if dout is None:

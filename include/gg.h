@@ -103,7 +103,8 @@ typedef struct GgAttnArgs {
     int head_dim;                         /* 32 (TinyViT) or 64 (CLIP) */
     int num_heads, num_windows, tokens_per_window;
     int window_size, map_h, map_w;        /* window_size > 0: ws x ws windows of an (map_h, map_w) NHWC token map; 0: linear */
-    const float* bias;                    /* attention_biases f32 [num_heads][ws*ws] or NULL */
+    const float* bias;                    /* EXPANDED attention_biases f32 [num_heads][Np][Np] (gg_attention_expand_bias,
+                                             Np = gg_attention_padded_tokens(tokens_per_window)) or NULL */
     float scale;
     void* out; int64_t ldo;               /* forward: bf16 [tokens, ldo], head h at column h*head_dim */
     const void* dout; int64_t lddo;       /* backward */
@@ -112,6 +113,8 @@ typedef struct GgAttnArgs {
     float* lse;                           /* f32 [tokens][num_heads] row log-sum-exp: forward writes (may be NULL), backward reads;
                                              backward also reads `out` (the forward result) */
 } GgAttnArgs;
+int gg_attention_padded_tokens(int tokens_per_window);
+int gg_attention_expand_bias(const float* table /* [num_heads][ws*ws] */, int num_heads, int window_size, float* full, void* stream);
 int gg_attention_fwd(const GgAttnArgs* args, void* stream);
 int gg_attention_bwd(const GgAttnArgs* args, void* stream);
 
