@@ -82,6 +82,7 @@ SIGNATURES = {
     "gg_dwconv_stat_rows": (_I, [_I, _I, _I, _I]),
     "gg_dwconv3x3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_fwd_fused": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "gg_dwconv3x3_bwd_data_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_wgrad_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
     "gg_dwconv3x3_bwd_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
@@ -89,6 +90,10 @@ SIGNATURES = {
     "gg_bn_eval_stat": (_I, [_P, _P, _I, _F, _P, _P]),
     "gg_bn_apply": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P]),
     "gg_bn_bwd_scratch_floats": (_L, [_L, _I]),
+    "gg_bn_bwd_rows": (_I, [_L, _I]),
+    "gg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "gg_bn_bwd_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P]),
+    "gg_bn_bwd_apply": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
     "gg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gg_layernorm_fwd": (_I, [_P, _I, _P, _P, _L, _I, _F, _P, _I, _P, _P, _P]),
     "gg_layernorm_bwd_scratch_floats": (_L, [_L, _I]),

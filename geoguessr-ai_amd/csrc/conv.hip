@@ -172,12 +172,23 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
 // zero), which removes the separate bn_apply pass and its 2 x [M,C] of traffic.  `flip` reverses the taps (= the
 // data gradient of a stride-1 depthwise conv).  Per-channel sum / sum-of-squares of the result (BatchNorm partials) are
 // written as one row per (image, band): colstats[row][2][C].
-template <int S>
+// MODE 0: plain (forward / flipped-tap data gradient); 1: fused producer BN+act while staging; 2: backward fusions
+// (2-input staging and/or act'(BN) epilogue).  Compile-time so that the plain kernel keeps its register budget.
+template <int S, int MODE>
 __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __restrict__ x, const float* __restrict__ wt,
                                                               bf16* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo,
                                                               int nbands, int nchunks, int flip, const float* __restrict__ in_stat,
                                                               const float* __restrict__ in_gamma, const float* __restrict__ in_beta,
-                                                              int in_act, float* __restrict__ colstats) {
+                                                              int in_act, float* __restrict__ colstats,
+                                                              const bf16* __restrict__ in2, const float* __restrict__ in_coef,
+                                                              const bf16* __restrict__ ep_y, const float* __restrict__ ep_stat,
+                                                              const float* __restrict__ ep_gamma, const float* __restrict__ ep_beta,
+                                                              int ep_act) {
+    // backward-pass fusions (both optional):
+    //  in2/in_coef : the staged value is  coef0*x + coef1*in2 + coef2  = BatchNorm-backward "apply" of the ConvNorm BEHIND this
+    //                conv, formed on the fly from (dz, y) -- the separate apply pass and the dy tensor disappear;
+    //  ep_*        : the stored value is  acc * act'(BN(ep_y))  = gradient w.r.t. the pre-activation of the ConvNorm IN FRONT,
+    //                and colstats becomes (sum dz, sum dz*xhat): that ConvNorm's BatchNorm-backward "reduce" pass disappears.
     // thread = (channel quad g of 16, pixel slot ps of 16): 4 channels (8-byte accesses) keep the 9x4 taps, the
     // accumulators and the prefetched chunks within ~100 VGPRs
     constexpr int TH = 8, TW = 8, CT = 64, Q = 4, NG = CT / Q;
@@ -197,13 +208,25 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < Q; ++j) wreg[t][j] = cok ? wt[(flip ? 8 - t : t) * C + cg0 + j] : 0.f;
-    float sc[Q], sh[Q];
-    const bool fused = in_stat != nullptr;
+    float sc[Q], sh[Q], s2[Q];
+    const bool fused = MODE == 1 && in_stat != nullptr, fused2 = MODE == 2 && in_coef != nullptr;
 #pragma unroll
     for (int j = 0; j < Q; ++j) {
         sc[j] = (fused && cok) ? in_stat[C + cg0 + j] * in_gamma[cg0 + j] : 1.f;
         sh[j] = (fused && cok) ? in_beta[cg0 + j] - in_stat[cg0 + j] * sc[j] : 0.f;
+        s2[j] = 0.f;
+        if (fused2 && cok) { sc[j] = in_coef[cg0 + j]; s2[j] = in_coef[C + cg0 + j]; sh[j] = in_coef[2 * C + cg0 + j]; }
     }
+    float esc[Q], esh[Q], ers[Q], emr[Q];
+    const bool epi = MODE == 2 && ep_y != nullptr;
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        ers[j] = (epi && cok) ? ep_stat[C + cg0 + j] : 0.f;
+        emr[j] = (epi && cok) ? ep_stat[cg0 + j] * ers[j] : 0.f;
+        esc[j] = (epi && cok) ? ers[j] * ep_gamma[cg0 + j] : 0.f;
+        esh[j] = (epi && cok) ? ep_beta[cg0 + j] - ep_stat[cg0 + j] * esc[j] : 0.f;
+    }
+    const bf16* x2b = in2 ? in2 + (int64_t)b * H * W * C : nullptr;
     const int oy0 = band * TH;
     const int iy0 = oy0 * S - 1;
     const bf16* xb = x + (int64_t)b * H * W * C;
@@ -220,7 +243,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
             bf16x4 v = zero4;
             if (ch < NCH && cok && iy >= 0 && iy < H && ix >= 0 && ix < W) {
                 v = *reinterpret_cast<const bf16x4*>(xb + ((int64_t)iy * W + ix) * C + cg0);
-                if (fused) {
+                if (fused2) {
+                    const bf16x4 w2 = *reinterpret_cast<const bf16x4*>(x2b + ((int64_t)iy * W + ix) * C + cg0);
+#pragma unroll
+                    for (int j = 0; j < Q; ++j) v[j] = (bf16)fmaf(sc[j], (float)v[j], fmaf(s2[j], (float)w2[j], sh[j]));
+                } else if (fused) {
 #pragma unroll
                     for (int j = 0; j < Q; ++j) v[j] = (bf16)gg_act((float)v[j] * sc[j] + sh[j], in_act);
                 }
@@ -241,8 +268,18 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
         }
         __syncthreads();
         if (tx + 1 < ntx) load_tile((tx + 1) * TW);
+        // fused epilogue: y of the NEXT output pixel is fetched while the current one is computed
+        auto ep_load = [&](int pi) {
+            const int p = ps + 16 * pi;
+            const int oy = oy0 + (p >> 3), ox = tx * TW + (p & 7);
+            return (oy < Ho && ox < Wo && cok) ? *reinterpret_cast<const bf16x4*>(ep_y + (((int64_t)b * Ho + oy) * Wo + ox) * C + cg0) : zero4;
+        };
+        bf16x4 ep_next = zero4;
+        if (epi) ep_next = ep_load(0);
 #pragma unroll 1
         for (int pi = 0; pi < (TH * TW) / 16; ++pi) {
+            const bf16x4 ep_cur = ep_next;
+            if (epi && pi + 1 < (TH * TW) / 16) ep_next = ep_load(pi + 1);
             const int p = ps + 16 * pi;
             const int oyl = p >> 3, oxl = p & 7;
             const int oy = oy0 + oyl, ox = tx * TW + oxl;
@@ -257,13 +294,26 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
                 }
             if (oy < Ho && ox < Wo && cok) {
                 bf16x4 o;
+                const int64_t oidx = (((int64_t)b * Ho + oy) * Wo + ox) * C + cg0;
+                if (epi) {
+                    const bf16x4 yv = ep_cur;
 #pragma unroll
-                for (int j = 0; j < Q; ++j) {
-                    o[j] = (bf16)acc[j];
-                    s[j] += acc[j];
-                    q[j] += acc[j] * acc[j];
+                    for (int j = 0; j < Q; ++j) {
+                        const float yy = (float)yv[j];
+                        const float dzv = acc[j] * gg_act_grad(fmaf(esc[j], yy, esh[j]), ep_act);
+                        o[j] = (bf16)dzv;
+                        s[j] += dzv;
+                        q[j] += dzv * fmaf(ers[j], yy, -emr[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < Q; ++j) {
+                        o[j] = (bf16)acc[j];
+                        s[j] += acc[j];
+                        q[j] += acc[j] * acc[j];
+                    }
                 }
-                *reinterpret_cast<bf16x4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * C + cg0) = o;
+                *reinterpret_cast<bf16x4*>(y + oidx) = o;
             }
         }
         __syncthreads();
@@ -432,20 +482,30 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
 }
 extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C) { return B * (int)gg_cdiv(Ho, 8); }
 
+struct DwFuse {
+    const void* in2 = nullptr; const float* in_coef = nullptr;
+    const void* ep_y = nullptr; const float* ep_stat = nullptr; const float* ep_gamma = nullptr; const float* ep_beta = nullptr; int ep_act = 0;
+};
 static int dwconv_tiled_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, int flip,
                                const float* in_stat, const float* in_gamma, const float* in_beta, int in_act, float* colstats,
-                               void* stream) {
+                               void* stream, const DwFuse& f = DwFuse()) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     const int nbands = (int)gg_cdiv(Ho, 8), nchunks = (int)gg_cdiv(C, 64);
     const int64_t blocks = (int64_t)B * nbands * nchunks;
     GG_CHECK(blocks < ((int64_t)1 << 31), "dwconv: grid too large");
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
-    if (stride == 1)
-        hipLaunchKernelGGL(dwconv3x3_tiled_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
-                           B, H, W, C, Ho, Wo, nbands, nchunks, flip, in_stat, in_gamma, in_beta, in_act, colstats);
-    else
-        hipLaunchKernelGGL(dwconv3x3_tiled_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
-                           B, H, W, C, Ho, Wo, nbands, nchunks, flip, in_stat, in_gamma, in_beta, in_act, colstats);
+    const int mode = (f.in_coef || f.ep_y) ? 2 : (in_stat ? 1 : 0);
+#define GG_DW_LAUNCH(S_, M_)                                                                                                          \
+    hipLaunchKernelGGL((dwconv3x3_tiled_kernel<S_, M_>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, wt, \
+                       (bf16*)y, B, H, W, C, Ho, Wo, nbands, nchunks, flip, in_stat, in_gamma, in_beta, in_act, colstats,               \
+                       (const bf16*)f.in2, f.in_coef, (const bf16*)f.ep_y, f.ep_stat, f.ep_gamma, f.ep_beta, f.ep_act)
+    if (stride == 1) {
+        if (mode == 0) GG_DW_LAUNCH(1, 0); else if (mode == 1) GG_DW_LAUNCH(1, 1); else GG_DW_LAUNCH(1, 2);
+    } else {
+        GG_CHECK(mode != 2, "dwconv: backward fusions are stride-1 only");
+        if (mode == 0) GG_DW_LAUNCH(2, 0); else GG_DW_LAUNCH(2, 1);
+    }
+#undef GG_DW_LAUNCH
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -460,6 +520,20 @@ extern "C" int gg_dwconv3x3_fwd_fused(const void* x, const float* in_stat, const
     GG_CHECK(x && wt && y && in_stat && in_gamma && in_beta && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2),
              "gg_dwconv3x3_fwd_fused: bad args");
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, in_stat, in_gamma, in_beta, in_act, colstats, stream);
+}
+// stride-1 data gradient with the BatchNorm-backward passes on both sides folded in (see the kernel comment):
+//   input  = coef0*dz_in + coef1*y_in + coef2   when in_coef != NULL (else dz_in is used as is)
+//   output = conv_T(input) * act'(BN(ep_y))      and stats rows (sum, sum*xhat) when ep_y != NULL (else the plain gradient)
+extern "C" int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, const float* in_coef, const float* wt, void* out, int B, int H,
+                                           int W, int C, const void* ep_y, const float* ep_stat, const float* ep_gamma,
+                                           const float* ep_beta, int ep_act, float* ep_part, void* stream) {
+    GG_CHECK(dz_in && wt && out && B > 0 && (C & 7) == 0, "gg_dwconv3x3_bwd_data_fused: bad args");
+    GG_CHECK(!in_coef || y_in, "gg_dwconv3x3_bwd_data_fused: in_coef needs y_in");
+    GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_part), "gg_dwconv3x3_bwd_data_fused: epilogue needs stat/gamma/beta/partials");
+    DwFuse f;
+    f.in2 = in_coef ? y_in : nullptr; f.in_coef = in_coef;
+    f.ep_y = ep_y; f.ep_stat = ep_stat; f.ep_gamma = ep_gamma; f.ep_beta = ep_beta; f.ep_act = ep_act;
+    return dwconv_tiled_launch(dz_in, wt, out, B, H, W, C, 1, 1, nullptr, nullptr, nullptr, 0, ep_y ? ep_part : nullptr, stream, f);
 }
 extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");

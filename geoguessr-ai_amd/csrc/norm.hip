@@ -123,9 +123,11 @@ __global__ void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* 
         part[(int64_t)blockIdx.x * 2 * C + i] = t;
     }
 }
-// part [nparts][2][C] -> sums [2][C] (sum g, sum g*xhat); optional dgamma (+)= sum g*xhat, dbeta (+)= sum g
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+// part [nparts][2][C] (sum g, sum g*xhat) -> coef [3][C] with  dy = coef0*g + coef1*y + coef2  ==
+// gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  optional dgamma (+)= sum g*xhat, dbeta (+)= sum g
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ stat,
+                                       const float* __restrict__ gamma, float* __restrict__ coef, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s = 0.0, q = 0.0;
@@ -133,29 +135,25 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int npart
         s += (double)part[(int64_t)i * 2 * C + c];
         q += (double)part[(int64_t)i * 2 * C + C + c];
     }
-    sums[c] = (float)s;
-    sums[C + c] = (float)q;
+    const double mu = stat[c], rstd = stat[C + c];
+    const double a = (double)gamma[c] * rstd, k2 = s / count, k3 = q / count;
+    coef[c] = (float)a;
+    coef[C + c] = (float)(-a * k3 * rstd);
+    coef[2 * C + c] = (float)(-a * k2 + a * k3 * rstd * mu);
     if (dgamma) {
         dgamma[c] = accumulate ? dgamma[c] + (float)q : (float)q;
         dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
     }
 }
-// dy = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)),  g = rs*dz     (same thread geometry as bn_apply)
-__global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y, const float* __restrict__ stat,
-                                    const float* __restrict__ gamma, const float* __restrict__ sums, int64_t M, int C,
-                                    const float* __restrict__ rowscale, int rows_per_scale, bf16* __restrict__ dy, int CG, int PP,
+// dy = coef0*(rs*dz) + coef1*y + coef2     (same thread geometry as bn_apply)
+__global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y, const float* __restrict__ coef, int64_t M,
+                                    int C, const float* __restrict__ rowscale, int rows_per_scale, bf16* __restrict__ dy, int CG, int PP,
                                     int rows_per_block) {
     const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
     const int c0 = g * 8;
-    const float invM = 1.0f / (float)M;
-    float mu[8], rstd[8], k1[8], k2[8], k3[8];
+    float ca[8], cb[8], cc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        mu[j] = stat[c0 + j]; rstd[j] = stat[C + c0 + j];
-        k1[j] = gamma[c0 + j] * rstd[j];
-        k2[j] = sums[c0 + j] * invM;
-        k3[j] = sums[C + c0 + j] * invM;
-    }
+    for (int j = 0; j < 8; ++j) { ca[j] = coef[c0 + j]; cb[j] = coef[C + c0 + j]; cc[j] = coef[2 * C + c0 + j]; }
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
     for (int64_t m = r0 + pp; m < r1; m += PP) {
@@ -164,10 +162,7 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
         const float rs = rowscale ? rowscale[m / rows_per_scale] : 1.f;
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float xh = ((float)v[j] - mu[j]) * rstd[j];
-            o[j] = (bf16)(k1[j] * (rs * (float)d[j] - k2[j] - xh * k3[j]));
-        }
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(ca[j] * rs, (float)d[j], fmaf(cb[j], (float)v[j], cc[j]));
         *reinterpret_cast<bf16x8*>(dy + m * C + c0) = o;
     }
 }
@@ -437,29 +432,54 @@ extern "C" int gg_bn_apply(const void* y, const float* stat, const float* gamma,
     GG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)row_geom(M, C).nblocks + GG_REDUCE_SLICES) * 2 * C + 2 * C; }
-// scratch: [nblocks][2][C] partials followed by sums [2][C]
-extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
-                         int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
-                         float* dgamma, float* dbeta, int accumulate, void* stream) {
-    GG_CHECK(dout && y && stat && gamma && beta && dz && dy && scratch && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd: bad args");
+extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)row_geom(M, C).nblocks + GG_REDUCE_SLICES) * 2 * C + 3 * C; }
+extern "C" int gg_bn_bwd_rows(int64_t M, int C) { return row_geom(M, C).nblocks; }
+// part: [gg_stat_rows_capacity(gg_bn_bwd_rows(M,C))][2][C]; dz may be NULL (no activation / no residual: dz == dout)
+extern "C" int gg_bn_bwd_reduce(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                                int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, float* part, void* stream) {
+    GG_CHECK(dout && y && stat && gamma && beta && part && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd_reduce: bad args");
     RowGeom g = row_geom(M, C);
-    GG_CHECK(g.threads <= 1024, "gg_bn_bwd: C too large");
-    GG_PROF(GG_CAT_NORM, 0, (residual ? 14.0 : 12.0) * M * C, stream);
-    float* part = scratch;
-    float* sums = scratch + ((int64_t)g.nblocks + GG_REDUCE_SLICES) * 2 * C;
+    GG_CHECK(g.threads <= 1024, "gg_bn_bwd_reduce: C too large");
+    GG_PROF(GG_CAT_NORM, 0, (residual ? 8.0 : (dz ? 6.0 : 4.0)) * M * C, stream);
     size_t lds = (size_t)g.PP * 2 * C * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)dout,
                        (const bf16*)y, stat, gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)dz, part,
                        g.CG, g.PP, g.rows_per_block);
-    const float* rows; int nrows;
-    gg_reduce_rows(part, g.nblocks, 2 * C, (hipStream_t)stream, &rows, &nrows);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
-                       sums, dgamma, dbeta, accumulate);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)y,
-                       stat, gamma, sums, M, C, residual ? rowscale : nullptr, rows_per_scale, (bf16*)dy, g.CG, g.PP, g.rows_per_block);
     GG_LAUNCH_CHECK();
     return 0;
+}
+// part rows -> coef [3][C] (dy = coef0*g + coef1*y + coef2) and the parameter gradients
+extern "C" int gg_bn_bwd_finalize(float* part, int nparts, int C, int64_t count, const float* stat, const float* gamma, float* coef,
+                                  float* dgamma, float* dbeta, int accumulate, void* stream) {
+    GG_CHECK(part && stat && gamma && coef && nparts > 0 && C > 0 && count > 0, "gg_bn_bwd_finalize: bad args");
+    const float* rows; int nrows;
+    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
+                       (double)count, stat, gamma, coef, dgamma, dbeta, accumulate);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_bn_bwd_apply(const void* dz, const void* y, const float* coef, int64_t M, int C, const float* rowscale,
+                               int rows_per_scale, void* dy, void* stream) {
+    GG_CHECK(dz && y && coef && dy && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd_apply: bad args");
+    RowGeom g = row_geom(M, C);
+    GG_PROF(GG_CAT_NORM, 0, 6.0 * M * C, stream);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)y, coef,
+                       M, C, rowscale, rows_per_scale, (bf16*)dy, g.CG, g.PP, g.rows_per_block);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// scratch: [nblocks + slices][2][C] partial rows followed by coef [3][C]
+extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                         int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
+                         float* dgamma, float* dbeta, int accumulate, void* stream) {
+    GG_CHECK(dz && dy && scratch, "gg_bn_bwd: bad args");
+    const int nb = row_geom(M, C).nblocks;
+    float* part = scratch;
+    float* coef = scratch + ((int64_t)nb + GG_REDUCE_SLICES) * 2 * C;
+    GG_TRY(gg_bn_bwd_reduce(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, part, stream));
+    GG_TRY(gg_bn_bwd_finalize(part, nb, C, M, stat, gamma, coef, dgamma, dbeta, accumulate, stream));
+    return gg_bn_bwd_apply(dz, y, coef, M, C, residual ? rowscale : nullptr, rows_per_scale, dy, stream);
 }
 
 static int ln_blocks(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(M, 4), 2048)); }

@@ -331,6 +331,9 @@ struct Exec {
     // Fusing BatchNorm+GELU of the producer into the depthwise conv's staging removes one [M,C] write+read but makes the
     // conv VALU-bound (erf on tile + halo): measured +6.6 ms conv vs -3.1 ms elementwise at 1024 images -> off by default.
     bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
+    // Folding BatchNorm-backward apply/reduce into the depthwise data gradient (frozen taps) trades 4 [M,C] passes for a
+    // slower conv kernel; measured a net loss so far (-6.6 ms elementwise, +13 ms conv) -> off by default.
+    bool fuse_bnbwd = getenv("GG_FUSE_BNBWD") != nullptr;
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
@@ -481,6 +484,16 @@ static int forward_impl(Exec& e, const float* x, float* out) {
     return 0;
 }
 
+// BatchNorm-backward pieces on the shared scratch: partial rows at the start of `bnscratch`, coef [3][C] right behind them
+static float* bn_coef(const Exec& e, int64_t M, int C) { return e.F(e.L->bnscratch) + ((int64_t)gg_bn_bwd_rows(M, C) + 64) * 2 * C; }
+static int bn_bwd_reduce_fin(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz) {
+    const bool tr = e.tr(bn.t_g);
+    GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz,
+                            e.F(e.L->bnscratch), e.st));
+    return gg_bn_bwd_finalize(e.F(e.L->bnscratch), gg_bn_bwd_rows(M, bn.C), bn.C, M, e.F(a.stat), e.P(bn.t_g), bn_coef(e, M, bn.C),
+                              tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
+}
+
 __global__ void conv_wgrad_scatter_kernel(const float* __restrict__ src, int N, int Kp, int cin, int taps, float* __restrict__ grad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // over N * cin * taps (grad layout (co, ci, tap))
     if (i >= N * cin * taps) return;
@@ -602,10 +615,17 @@ static int backward_impl(Exec& e, const float* d_out) {
                                         tr ? e.Gd(l.ln2.t_g) : nullptr, tr ? e.Gd(l.ln2.t_b) : nullptr, 1, e.st));
             }
             // local_conv: x2 = BN(dw(x1)).  dy -> t_a (dz scratch t_c), dx1 = dwT(dy) -> t_c
-            GG_TRY(bn_bwd(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, t_c, t_a));
-            if (e.tr(l.local.w.t_w))
-                GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.x1), t_a, B, st.res, st.res, C, 1, e.F(L.bnscratch), e.Gd(l.local.w.t_w), 1, e.st));
-            GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.local.w), t_c, B, st.res, st.res, C, 1, e.st));
+            if (e.tr(l.local.w.t_w) || !e.fuse_bnbwd) {
+                GG_TRY(bn_bwd(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, t_c, t_a));
+                if (e.tr(l.local.w.t_w))
+                    GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.x1), t_a, B, st.res, st.res, C, 1, e.F(L.bnscratch), e.Gd(l.local.w.t_w), 1, e.st));
+                GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.local.w), t_c, B, st.res, st.res, C, 1, e.st));
+            } else {
+                // frozen taps: BN-backward apply is folded into the conv's staging (no dz / dy tensors at all)
+                GG_TRY(bn_bwd_reduce_fin(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, nullptr));
+                GG_TRY(gg_dwconv3x3_bwd_data_fused(t_b, e.A(a.local.y), bn_coef(e, M, C), e.Taps(l.local.w), t_c, B, st.res, st.res, C,
+                                                   nullptr, nullptr, nullptr, nullptr, 0, nullptr, e.st));
+            }
             bf16* dx1 = t_c;
             // attention branch: x1 = x0 + s1*(proj(o)+b)
             // do = (s1*dx1) . Wproj                                   -> t_a  [M, C]
@@ -672,13 +692,25 @@ static int backward_impl(Exec& e, const float* d_out) {
         GG_TRY(bn_bwd(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, dx, t_b, t_a, e.A(a.x), s0, rps0));
         if (e.tr(l.c3.w.t_w)) GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
         GG_TRY(gemm(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_c, mid, M0, mid, d[0]));                     // da2 -> t_c [M0, mid]
-        GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                                  // dy2 -> t_a
-        if (e.tr(l.c2.w.t_w)) {
-            if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));                 // act1 was fused away in forward
-            GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+        if (e.tr(l.c2.w.t_w) || !e.fuse_bnbwd) {
+            GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy2 -> t_a
+            if (e.tr(l.c2.w.t_w)) {
+                if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));             // act1 was fused away in forward
+                GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+            }
+            GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));           // da1 -> t_c
+            GG_TRY(bn_bwd(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy1 -> t_a
+        } else {
+            // frozen taps: 3 streaming passes instead of 5.  reduce(c2) -> dz2; the depthwise data gradient forms dy2 from
+            // (dz2, y2) while staging and emits dz1 = da1*GELU'(BN1(y1)) + BN1's backward statistics; apply(c1) -> dy1.
+            GG_TRY(bn_bwd_reduce_fin(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d));                        // dz2 -> t_d
+            GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
+                                               e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
+            const bool tr1 = e.tr(l.c1.bn.t_g);
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                                      bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
+            GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                              // dy1 -> t_a
         }
-        GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));               // da1 -> t_c
-        GG_TRY(bn_bwd(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d, t_a));                                  // dy1 -> t_a
         if (e.tr(l.c1.w.t_w)) GG_TRY(dense_wgrad(e, l.c1.w, e.A(a.x), d[0], t_a, mid, M0, nullptr, 0, t_c, t_d, false));
         // dx_in = dy1 . W1 + dpre
         GG_TRY(gemm(e, t_a, mid, e.Wt(l.c1.w), l.c1.w.Np, dx, d[0], M0, d[0], mid, nullptr, 0, nullptr, nullptr, 0, t_b));

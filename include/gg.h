@@ -68,6 +68,9 @@ int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C);
 int gg_dwconv3x3_fwd(const void* x, const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
 int gg_dwconv3x3_fwd_fused(const void* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act,
                            const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
+int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, const float* in_coef, const float* taps, void* out, int B, int H, int W,
+                                int C, const void* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
+                                float* ep_partials, void* stream);
 int gg_dwconv3x3_bwd_data(const void* dy, const float* taps, void* dx, int B, int H, int W, int C, int stride, void* stream);
 int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride);
 int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch, float* grad /* (C,1,3,3) */,
@@ -81,6 +84,16 @@ int gg_bn_eval_stat(const float* running_mean, const float* running_var, int C, 
 int gg_bn_apply(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
                 const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream);
 int64_t gg_bn_bwd_scratch_floats(int64_t M, int C);
+int gg_bn_bwd_rows(int64_t M, int C);
+/* the three passes of BatchNorm backward, separately (producers / consumers can absorb the outer two):
+ *   reduce: dz = dout*act'(BN(y)) [+residual/DropPath form], partial rows (sum g, sum g*xhat);  finalize: rows -> coef [3][C]
+ *   with dy = coef0*g + coef1*y + coef2, plus dgamma/dbeta;  apply: dy from (dz, y, coef) */
+int gg_bn_bwd_reduce(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                     const void* residual, const float* rowscale, int rows_per_scale, void* dz, float* partials, void* stream);
+int gg_bn_bwd_finalize(float* partials, int nparts, int C, int64_t count, const float* stat, const float* gamma, float* coef,
+                       float* dgamma, float* dbeta, int accumulate, void* stream);
+int gg_bn_bwd_apply(const void* dz, const void* y, const float* coef, int64_t M, int C, const float* rowscale, int rows_per_scale,
+                    void* dy, void* stream);
 int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
               const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
               float* dgamma, float* dbeta, int accumulate, void* stream);
