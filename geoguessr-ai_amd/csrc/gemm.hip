@@ -300,6 +300,101 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
     gemm_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg);
 }
 
+// ------------------------------------------------------------------------------------------- TN GEMM (weight gradients)
+// dW[N,K] = sum_m dY[m,n] * X[m,k]: both operands are row-major over the REDUCTION index m, so their MFMA fragments
+// (8 consecutive m for a fixed n / k) are read from the row-major LDS tiles with the transposing ds_read_b64_tr_b16 --
+// no transposed copies of dY and X in HBM.  Output tile 128(n) x 128(k), 2x2 waves; the m range is split over
+// blockIdx.y and each split writes an fp32 slab part[split][N][K] (deterministic; reduced by splitk_reduce_kernel).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tn_frag(const bf16* T, int RS, int col, int lr, int lg) {
+    // lane (lr, lg) <- T[4lg + q][col + lr], T[16 + 4lg + q][col + lr]  (q = 0..3); lane 4q+p of a 16-lane group supplies the
+    // address of row q, columns 4p..4p+3
+    const bf16* p0 = T + (4 * lg + (lr >> 2)) * RS + col + 4 * (lr & 3);
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * RS));
+    union { s16x4 s[2]; bf16x8 v; } u;
+    u.s[0] = a; u.s[1] = b;
+    return u.v;
+}
+struct TnParams {
+    const bf16* dY; int64_t ldy; const bf16* X; int64_t ldx;
+    int M, N, K;
+    const float* rowscale; int rows_per_scale;
+    float* part;          // [splits][N][K]
+    int tilesN, tilesK, m_per_split;
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
+    constexpr int TB = 128, MS = 32, RS = TB + 8;          // 32-row m-step; 272-byte LDS rows (8-byte aligned transposing reads)
+    __shared__ __attribute__((aligned(16))) bf16 Ys[MS * RS];
+    __shared__ __attribute__((aligned(16))) bf16 Xs[MS * RS];
+    const int tn = blockIdx.x / p.tilesK, tk = blockIdx.x % p.tilesK;
+    const int n0 = tn * TB, k0 = tk * TB;
+    const int mbeg = blockIdx.y * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    // staging: 32 rows x 16 chunks (16 B) per operand = 512 chunks -> 2 per thread: row = c >> 4, chunk = c & 15
+    const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
+    const bool yok = (n0 + sch * 8) < p.N, xok = (k0 + sch * 8) < p.K;      // N, K multiples of 8
+    bf16x8 ry[2], rx[2];
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto load_step = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + srow + 16 * i;
+            const bool mok = m < mend;
+            bf16x8 vy = (mok && yok) ? *reinterpret_cast<const bf16x8*>(p.dY + (int64_t)m * p.ldy + n0 + sch * 8) : zero8;
+            if (p.rowscale && mok && yok) {
+                const float rs = p.rowscale[m / p.rows_per_scale];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vy[j] = (bf16)((float)vy[j] * rs);
+            }
+            ry[i] = vy;
+            rx[i] = (mok && xok) ? *reinterpret_cast<const bf16x8*>(p.X + (int64_t)m * p.ldx + k0 + sch * 8) : zero8;
+        }
+    };
+    f32x4 acc[4][4];     // [k tile][n tile]: D[i = n][j = k] with A = dY^T fragment, B = X fragment
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (mbeg < mend) load_step(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += MS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<bf16x8*>(Ys + (srow + 16 * i) * RS + sch * 8) = ry[i];
+            *reinterpret_cast<bf16x8*>(Xs + (srow + 16 * i) * RS + sch * 8) = rx[i];
+        }
+        __syncthreads();
+        if (m0 + MS < mend) load_step(m0 + MS);
+        bf16x8 yf[4], xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yf[i] = tn_frag(Ys, RS, wn * 64 + i * 16, lr, lg);
+            xf[i] = tn_frag(Xs, RS, wk * 64 + i * 16, lr, lg);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
+        __syncthreads();
+    }
+    // lane holds D[n = .. + nt*16 + 4lg + r][k = .. + kt*16 + lr]
+    float* out = p.part + (int64_t)blockIdx.y * p.N * p.K;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wk * 64 + kt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + lg * 4 + r;
+                if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[kt][nt][r];
+            }
+        }
+}
+
 // sum split-K partials: out[i] = (accumulate ? out[i] : 0) + sum_z part[z][i]
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int splits,
                                      int accumulate, float scale) {
@@ -528,6 +623,31 @@ extern "C" int gg_colsum_bf16(const void* x, int64_t ld, int M, int C, const flo
     const float* rows; int nrows;
     gg_reduce_rows(scratch, nparts, C, (hipStream_t)stream, &rows, &nrows);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)gg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, out, accumulate);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dW partial slabs: part[splits][N][K] = per-split  dY[M,N]^T . X[M,K]   (rowscale: optional per-sample scale on dY rows)
+extern "C" int gg_gemm_tn_splits(int M, int N, int K) {
+    const int64_t tiles = gg_cdiv(N, 128) * gg_cdiv(K, 128);
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(1536, tiles), gg_cdiv(M, 1024)));
+    const int64_t cap = ((int64_t)64 << 20) / ((int64_t)N * K * 4);        // 64 MiB of slabs at most
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, cap));
+}
+extern "C" int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale,
+                          int rows_per_scale, float* partials, int splits, void* stream) {
+    GG_CHECK(dY && X && partials && M > 0 && N > 0 && K > 0 && splits > 0, "gg_gemm_tn: bad args");
+    GG_CHECK((N & 7) == 0 && (K & 7) == 0 && (ldy & 7) == 0 && (ldx & 7) == 0, "gg_gemm_tn: N, K, ldy, ldx must be multiples of 8");
+    GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gg_gemm_tn: operands must be 16-byte aligned");
+    GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn: rows_per_scale");
+    TnParams p;
+    p.dY = (const bf16*)dY; p.ldy = ldy; p.X = (const bf16*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
+    p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
+    p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
+    p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 32);
+    GG_CHECK(splits <= 65535, "gg_gemm_tn: too many splits");
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 2.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tilesN * p.tilesK, splits), dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }

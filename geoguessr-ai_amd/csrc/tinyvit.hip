@@ -511,29 +511,10 @@ static int conv_wgrad_scatter(const float* src, int N, int Kp, int cin, int taps
 // wgrad of a dense weight: dW[N,K] (+)= dY^T[N,M] . X[M,K]   (transposes into scratch, split-K over M)
 static int dense_wgrad(const Exec& e, const DenseW& w, const bf16* X, int64_t ldx, const bf16* dY, int64_t ldy, int64_t M,
                        const float* rowscale, int rps, bf16* T0, bf16* T1, bool conv_reorder) {
-    const int64_t Mp = gg_align(M, 8);
+    (void)T0; (void)T1;
     const int K = conv_reorder ? w.Kp : w.K;   // im2col'd operand has Kp columns
-    // X^T [K, Mp], dY^T [N, Mp]; pad columns (M..Mp) must be zero
-    if (Mp != M) {
-        GG_HIP(hipMemsetAsync(T0, 0, (size_t)K * Mp * 2, e.st));
-        GG_HIP(hipMemsetAsync(T1, 0, (size_t)w.N * Mp * 2, e.st));
-    }
-    GG_TRY(gg_transpose_bf16(X, ldx, T0, Mp, (int)M, K, nullptr, 0, e.st));
-    GG_TRY(gg_transpose_bf16(dY, ldy, T1, Mp, (int)M, w.N, rowscale, rps, e.st));
-    const int tiles = (int)(gg_cdiv(w.N, 128) * gg_cdiv(K, 128));
-    int split = (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(1024, tiles), gg_cdiv(Mp, 2048)));
-    const int64_t part_bytes = (int64_t)split * w.N * K * 4;
-    if (part_bytes > ((int64_t)64 << 20)) split = (int)std::max<int64_t>(1, ((int64_t)64 << 20) / ((int64_t)w.N * K * 4));
-    GgGemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = T1; g.lda = Mp; g.B = T0; g.ldb = Mp; g.M = w.N; g.N = K; g.K = (int)Mp;
-    g.C = e.F(e.L->splitk); g.ldc = K; g.out_f32 = 1; g.split_k = split;
-    if (split == 1) {
-        // single pass still goes through the f32 scratch so that the accumulate + layout fix-up is uniform
-        g.split_k = 1;
-    }
-    GG_TRY(gg_gemm_nt(&g, e.st));
-    // partial layout [split][N][K] -> grad layout
+    const int split = gg_gemm_tn_splits((int)M, w.N, K);
+    GG_TRY(gg_gemm_tn(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
     float* gw = e.Gd(w.t_w);
     if (!conv_reorder) {
         GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), gw, (int64_t)w.N * K, split, 1, 1.0f, e.st));

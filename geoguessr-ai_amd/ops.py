@@ -85,6 +85,20 @@ def gemm_splitk(A, B, split_k: int, accumulate_into: Optional[torch.Tensor] = No
     return out
 
 
+def gemm_tn(dY, X, rowscale=None, rows_per_scale=0, accumulate_into=None):
+    """f32 dW[N,K] = dY[M,N]^T @ X[M,K] (weight-gradient form, reduction over rows split across workgroups)."""
+    M, N = dY.shape
+    K = X.shape[1]
+    splits = L.lib().gg_gemm_tn_splits(M, N, K)
+    part = torch.empty((splits, N, K), dtype=F32, device=dY.device)
+    L.check(L.lib().gg_gemm_tn(_pr(dY, BF16, "dY"), dY.stride(0), _pr(X, BF16, "X"), X.stride(0), M, N, K, _p(rowscale, F32), rows_per_scale,
+                               _p(part), splits, L.stream()), "gg_gemm_tn")
+    out = accumulate_into if accumulate_into is not None else torch.empty((N, K), dtype=F32, device=dY.device)
+    L.check(L.lib().gg_splitk_reduce(_p(part), _p(out, F32), N * K, splits, int(accumulate_into is not None), 1.0, L.stream()),
+            "gg_splitk_reduce")
+    return out
+
+
 def transpose_bf16(x, rowscale=None, rows_per_scale=0, pad_to: int = 8):
     R, Cc = x.shape
     ldo = (R + pad_to - 1) // pad_to * pad_to

@@ -48,6 +48,10 @@ typedef struct GgGemmArgs {
 int gg_gemm_nt(const GgGemmArgs* args, void* stream);
 int gg_gemm_colstats_rows(int M);
 int gg_stat_rows_capacity(int rows);       /* rows a partial-statistics buffer must hold (valid rows + reduction scratch) */
+/* weight-gradient form: partials[splits][N][K] (f32) = per m-split  dY[M,N]^T . X[M,K]  (no transposed operand copies) */
+int gg_gemm_tn_splits(int M, int N, int K);
+int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale,
+               float* partials, int splits, void* stream);
 int gg_splitk_reduce(const float* partials, float* out, int64_t n, int splits, int accumulate, float scale, void* stream);
 int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
                       int rows_per_scale, void* stream);

@@ -115,6 +115,20 @@ def test_gemm_splitk_and_wgrad_form(ops):
           rtol=1e-4, atol=1e-3, what="colsum_bf16")
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 96, 160), (4099, 48, 32), (1030, 576, 2304), (777, 1728, 576), (9000, 96, 432)])
+def test_gemm_tn_weight_gradient(ops, M, N, K):
+    """dW = dY^T X straight from the row-major operands (transposing LDS reads), with a DropPath row scale."""
+    X, dY = rnd(M, K, seed=81), rnd(M, N, seed=82, scale=0.1)
+    got = ops.gemm_tn(dev(dY, BF), dev(X, BF))
+    close(got, dY.t() @ X, rtol=1e-4, atol=2e-2, what="gemm_tn")
+    T = 10
+    rs = (torch.arange((M + T - 1) // T) % 3).float() * 0.75
+    acc = torch.full((N, K), 2.0, device="cuda")
+    got = ops.gemm_tn(dev(dY, BF), dev(X, BF), rowscale=dev(rs), rows_per_scale=T, accumulate_into=acc)
+    dYs = (dY * rs.repeat_interleave(T)[:M, None]).to(BF).float()
+    close(got, 2.0 + dYs.t() @ X, rtol=1e-4, atol=2e-2, what="gemm_tn rowscale")
+
+
 # ------------------------------------------------------------------------------------------- convolutions
 def test_im2col_matches_conv(ops):
     B, H = 2, 20
