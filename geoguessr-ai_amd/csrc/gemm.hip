@@ -59,147 +59,168 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     // ---------------- lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
-    // bf16 results are staged through LDS (the k-loop buffers are dead) so that global stores are 16 bytes per lane
-    // along full tile rows instead of 8-byte fragments of 16 different rows.
-    constexpr int CS = BN + 8;                      // staged tile row stride (elements), 16-B aligned
-    constexpr int CPR = BN / 8;                     // 16-byte chunks per staged row
-    constexpr int RPP = 256 / CPR;                  // rows per cooperative pass
-    bf16* Cs = smem;
-    constexpr bool staged = EPI != EPI_F32;
-    const bool vec_ok = ((p.ldc & 3) == 0) && (p.residual == nullptr || (p.ldr & 3) == 0);
-    auto flush_tile = [&](bf16* dst, bool stats) {
-        __syncthreads();
-        const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
-        const int n = n0 + chunk * 8;
-        const bool wide = ((p.ldc & 7) == 0) && (n + 7 < p.N);
-        float cs[8], cq[8];
+    // Fragment phase: bias / per-row scale on the fp32 accumulators.  Everything it needs from memory is fetched up
+    // front as one batch of independent loads: issued inside the (mt, nt) loop they serialise 16 L2 round trips per tile,
+    // which cost more than the whole k-loop of a K = 384 GEMM.
+    constexpr bool has_bias = EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_F32;
+    float bs[TN][4];
+    if (has_bias) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+        for (int nt = 0; nt < TN; ++nt) {
+            const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
 #pragma unroll
-        for (int pass = 0; pass < BM / RPP; ++pass) {
-            const int row = pass * RPP + rr, m = m0 + row;
-            if (m >= p.M || n >= p.N) continue;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
-            if (EPI == EPI_PLAIN && stats) {
-                // BatchNorm partial statistics of the stored (bf16-rounded) conv output, taken on the way out
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; cs[j] += f; cq[j] += f * f; }
-            }
-            if (p.debug & 2) continue;
-            bf16* g = dst + (int64_t)m * p.ldc + n;
-            if (wide) *reinterpret_cast<bf16x8*>(g) = v;
-            else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
+            for (int r = 0; r < 4; ++r) bs[nt][r] = p.bias ? p.bias[min(n + r, p.N - 1)] : 0.f;
         }
-        __syncthreads();
-        if (EPI == EPI_PLAIN && stats) {
-            // threads sharing a column chunk: lanes l, l+CPR, ... within a wave, then the 4 waves through LDS
-            float* red = reinterpret_cast<float*>(smem);         // [4 waves][2][BN]
+    }
+    if (EPI == EPI_F32) {
+        // f32 results (head logits, split-K slabs) go out straight from the fragments: 16-byte stores
+        const bool vec_ok = (p.ldc & 3) == 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                for (int o = CPR; o < 64; o <<= 1) { cs[j] += __shfl_xor(cs[j], o, 64); cq[j] += __shfl_xor(cq[j], o, 64); }
-            }
-            const int wv = threadIdx.x >> 6;
-            if ((threadIdx.x & 63) < CPR) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    red[(wv * 2 + 0) * BN + chunk * 8 + j] = cs[j];
-                    red[(wv * 2 + 1) * BN + chunk * 8 + j] = cq[j];
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x < 2 * BN) {
-                const int which = threadIdx.x / BN, col = threadIdx.x % BN;
-                const float s = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
-                                red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
-                if (n0 + col < p.N) p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = s;
-            }
-        }
-    };
-    if (EPI == EPI_GELU && p.preact) {
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt)
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m0 + wm * WROWS + mt * 16 + lr;
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
                 const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
                 f32x4 v = acc[nt][mt];
-                if (p.bias) {
+                if (m >= p.M || n >= p.N) continue;
+                float* Cf = reinterpret_cast<float*>(p.C) + ((int64_t)(p.split_k > 1 ? z : 0) * p.M + m) * p.ldc + n;
+                if (p.split_k <= 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+                    for (int r = 0; r < 4; ++r) v[r] += bs[nt][r];
                 }
-                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
-            }
-        flush_tile(p.preact, false);
-    }
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-        const int m = m0 + wm * WROWS + mt * 16 + lr;
-        const bool mok = m < p.M;
-        float rs = 1.f;
-        if (p.rowscale && mok) rs = p.rowscale[m / p.rows_per_scale];
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-            const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
-            f32x4 v = acc[nt][mt];
-            const bool inb = mok && n < p.N;
-            if (EPI == EPI_F32 && p.split_k > 1) {
-                if (!inb) continue;
-                float* Cz = reinterpret_cast<float*>(p.C) + ((int64_t)z * p.M + m) * p.ldc + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) Cz[r] = v[r];
-                continue;
-            }
-            const bool full = vec_ok && (n + 3 < p.N);
-            if (inb) {
-                if (EPI != EPI_PLAIN && EPI != EPI_DGELU && p.bias) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
-                }
-                if (EPI == EPI_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gg_gelu(v[r]);
-                }
-                if (EPI == EPI_QGELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gg_quick_gelu(v[r]);
-                }
-                if (EPI == EPI_DGELU) {
-                    const bf16* D = p.dact_preact + (int64_t)m * p.ldc + n;
-                    if (full) {
-                        bf16x4 d = *reinterpret_cast<const bf16x4*>(D);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= gg_gelu_grad((float)d[r]);
-                    } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] *= gg_gelu_grad((float)D[r]);
-                    }
-                }
-                if ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= rs;
-                }
-                if (EPI == EPI_LINEAR && p.residual) {
-                    const bf16* R = p.residual + (int64_t)m * p.ldr + n;
-                    if (full) {
-                        bf16x4 d = *reinterpret_cast<const bf16x4*>(R);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)d[r];
-                    } else {
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += (float)R[r];
-                    }
-                }
-            }
-            if (staged) {
-                bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                *reinterpret_cast<bf16x4*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
-            } else if (inb) {
-                float* Cf = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-                if (full) *reinterpret_cast<f32x4*>(Cf) = v;
+                if (vec_ok && n + 3 < p.N) *reinterpret_cast<f32x4*>(Cf) = v;
                 else { for (int r = 0; r < 4; ++r) if (n + r < p.N) Cf[r] = v[r]; }
             }
         }
+        return;
     }
-    if (staged) flush_tile(reinterpret_cast<bf16*>(p.C), p.colstats != nullptr);
+    // bf16 results are staged through LDS (the k-loop buffers are dead) so that global traffic is 16 bytes per lane
+    // along full tile rows instead of 8-byte fragments of 16 different rows.  The element-wise tail that needs a second
+    // tensor (GELU + pre-activation copy, GELU' * saved pre-activation, residual add) runs on the staged, bf16-rounded
+    // tile in that row layout -- the same rounding points as the reference's bf16 autocast graph, where the Linear's
+    // output is a bf16 tensor before the activation / residual op reads it.
+    constexpr int CS = BN + 8;                      // staged tile row stride (elements), 16-B aligned
+    constexpr int CPR = BN / 8;                     // 16-byte chunks per staged row
+    constexpr int RPP = 256 / CPR;                  // rows per cooperative pass
+    constexpr int NP = BM / RPP;
+    bf16* Cs = smem;
+    float rsv[TM];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+        const int m = min(m0 + wm * WROWS + mt * 16 + lr, p.M - 1);
+        rsv[mt] = ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) ? p.rowscale[m / p.rows_per_scale] : 1.f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            f32x4 v = acc[nt][mt];
+            if (has_bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += bs[nt][r];
+            }
+            if (EPI == EPI_QGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gg_quick_gelu(v[r]);
+            }
+            if (EPI == EPI_LINEAR || EPI == EPI_DGELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= rsv[mt];
+            }
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
+        }
+    // ---------------- row phase: thread = (row rr + pass*RPP, 16-byte column chunk) ----------------
+    const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
+    const int n = n0 + chunk * 8;
+    const bool wide = ((p.ldc & 7) == 0) && (n + 7 < p.N);
+    const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : nullptr);
+    const int64_t lde = EPI == EPI_DGELU ? p.ldc : p.ldr;
+    bf16x8 ex[NP];
+    if ((EPI == EPI_DGELU || EPI == EPI_LINEAR) && ext) {
+        if (((lde & 7) == 0) && ((p.N & 7) == 0) && (((uintptr_t)ext & 15) == 0)) {
+            // range-checked 16-byte buffer loads, all passes in flight before the first use; rows beyond M and column
+            // chunks beyond N come back as zeros
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned bytesE = (unsigned)min(p.M - m0, BM) * (unsigned)lde * 2u;
+            const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(ext + (int64_t)m0 * lde), 0, (int)bytesE, 0x00020000);
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const unsigned vo = ((unsigned)(pass * RPP + rr) * (unsigned)lde + (unsigned)n) * 2u;
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)(n < p.N ? vo : 0xFFFFFFF0u), 0, 0);
+                ex[pass] = __builtin_bit_cast(bf16x8, raw);
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int m = m0 + pass * RPP + rr;
+                bf16x8 d = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < p.M) { for (int j = 0; j < 8; ++j) if (n + j < p.N) d[j] = ext[(int64_t)m * lde + n + j]; }
+                ex[pass] = d;
+            }
+        }
+    }
+    __syncthreads();
+    const bool stats = EPI == EPI_PLAIN && p.colstats != nullptr;
+    float cs[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+    auto store8 = [&](bf16* base, int m, const bf16x8& v) {
+        bf16* g = base + (int64_t)m * p.ldc + n;
+        if (wide) *reinterpret_cast<bf16x8*>(g) = v;
+        else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
+    };
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int row = pass * RPP + rr, m = m0 + row;
+        if (m >= p.M || n >= p.N) continue;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
+        if (stats) {
+            // BatchNorm partial statistics of the stored (bf16-rounded) conv output, taken on the way out
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; cs[j] += f; cq[j] += f * f; }
+        }
+        if (p.debug & 2) continue;
+        if (EPI == EPI_GELU) {
+            if (p.preact) store8(p.preact, m, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)gg_gelu((float)v[j]);
+        }
+        if (EPI == EPI_DGELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * gg_gelu_grad((float)ex[pass][j]));
+        }
+        if (EPI == EPI_LINEAR && p.residual) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)ex[pass][j]);
+        }
+        store8(reinterpret_cast<bf16*>(p.C), m, v);
+    }
+    if (stats) {
+        __syncthreads();
+        // threads sharing a column chunk: lanes l, l+CPR, ... within a wave, then the 4 waves through LDS
+        float* red = reinterpret_cast<float*>(smem);         // [4 waves][2][BN]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int o = CPR; o < 64; o <<= 1) { cs[j] += __shfl_xor(cs[j], o, 64); cq[j] += __shfl_xor(cq[j], o, 64); }
+        }
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) < CPR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(wv * 2 + 0) * BN + chunk * 8 + j] = cs[j];
+                red[(wv * 2 + 1) * BN + chunk * 8 + j] = cq[j];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * BN) {
+            const int which = threadIdx.x / BN, col = threadIdx.x % BN;
+            const float sum = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col] +
+                              red[(2 * 2 + which) * BN + col] + red[(3 * 2 + which) * BN + col];
+            if (n0 + col < p.N) p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = sum;
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int MINW, int EPI>
@@ -497,6 +518,8 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     GG_CHECK(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "gg_gemm_nt: leading dimension too small");
     GG_CHECK(a->lda * 256 < 0xFFFFFF00LL && a->ldb * 256 < 0xFFFFFF00LL && (int64_t)a->K * 2 < 0x7FFFFFFFLL,
              "gg_gemm_nt: leading dimension too large for 32-bit tile offsets (ld < 16.7M elements)");
+    GG_CHECK((!a->residual || a->ldr * 256 < 0xFFFFFF00LL) && (!a->dact_preact || a->ldc * 256 < 0xFFFFFF00LL),
+             "gg_gemm_nt: residual / pre-activation leading dimension too large for 32-bit tile offsets");
     const int split = a->split_k > 1 ? a->split_k : 1;
     if (split > 1)
         GG_CHECK(!a->bias && !a->act && !a->preact && !a->residual && !a->colstats && !a->dact && !a->rowscale,

@@ -15,6 +15,7 @@ shapes = [
     ("s1.fc1", Ms1, 768, 192, {"bias": True, "act": "gelu", "preact": True}), ("s1.fc2", Ms1, 192, 768, {"bias": True, "residual": True}),
     ("s1.fc2.dgrad", Ms1, 768, 192, {"dact": True}),
     ("s2.qkv", Ms2, 1152, 384, {"bias": True}), ("s2.fc1", Ms2, 1536, 384, {"bias": True, "act": "gelu", "preact": True}),
+    ("s2.fc1.nopre", Ms2, 1536, 384, {"bias": True, "act": "gelu"}), ("s2.fc1.bias", Ms2, 1536, 384, {"bias": True}), ("s2.fc1.plain", Ms2, 1536, 384, {}),
     ("s2.fc2", Ms2, 384, 1536, {"bias": True, "residual": True}), ("s2.fc2.dgrad", Ms2, 1536, 384, {"dact": True}),
     ("s3.fc1", Ms3, 2304, 576, {"bias": True, "act": "gelu", "preact": True}), ("s3.fc2", Ms3, 576, 2304, {"bias": True, "residual": True}),
     ("head", 256, 12647, 576, {"bias": True, "out_f32": True}),
