@@ -22,7 +22,9 @@ class GemmArgs(C.Structure):
                 ("ldc", C.c_int64), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("bias", C.c_void_p),
                 ("act", C.c_int), ("preact", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_scale", C.c_int),
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("dact_preact", C.c_void_p), ("dact", C.c_int),
-                ("colstats", C.c_void_p), ("out_f32", C.c_int), ("split_k", C.c_int)]
+                ("colstats", C.c_void_p), ("out_f32", C.c_int), ("split_k", C.c_int), ("A2", C.c_void_p), ("k_split", C.c_int),
+                ("bn_y", C.c_void_p), ("bn_stat", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("bn_act", C.c_int)]
 
 
 class AttnArgs(C.Structure):
@@ -96,6 +98,7 @@ SIGNATURES = {
     "gg_bn_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
     "gg_bn_bwd_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P]),
     "gg_bn_bwd_apply": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
+    "gg_bn_bwd_fold_weights": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "gg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gg_layernorm_fwd": (_I, [_P, _I, _P, _P, _L, _I, _F, _P, _I, _P, _P, _P]),
     "gg_layernorm_bwd_scratch_floats": (_L, [_L, _I]),

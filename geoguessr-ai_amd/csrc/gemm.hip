@@ -30,6 +30,8 @@ struct GemmParams {
     int split_k, k_per_split;     // split_k > 1: C is f32 [split][M][N] partials
     int tilesM, tilesN;
     int debug;                    // timing experiments only: 1 = no operand loads, 2 = no result stores
+    const bf16* A2; int k_split;  // optional second A source for contraction columns k >= k_split (same lda)
+    const bf16* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;   // EPI_BNBWD
 };
 
 // LDS image of an R x 64 operand tile: unpadded 128-byte rows, the eight 16-byte chunks of a row XOR-swizzled with
@@ -51,7 +53,8 @@ enum { EPI_PLAIN = 0,    // raw accumulators (+ optional BatchNorm column statis
        EPI_GELU = 2,     // + bias?, optional pre-activation copy, exact GELU        : fc1
        EPI_QGELU = 3,    // + bias?, quick_gelu                                      : CLIP fc1
        EPI_DGELU = 4,    // * GELU'(saved pre-activation) * rowscale?                : fc2 dgrad
-       EPI_F32 = 5 };    // f32 output (+ bias?) or split-K partial slabs            : head logits, wgrads
+       EPI_F32 = 5,      // f32 output (+ bias?) or split-K partial slabs            : head logits, wgrads
+       EPI_BNBWD = 6 };  // * act'(BN(y)) of the ConvNorm the gradient flows into, + its backward column sums: conv dgrads
 
 template <int BM, int BN, int WM, int WN, int EPI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
@@ -134,10 +137,19 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
     const int n = n0 + chunk * 8;
     const bool wide = ((p.ldc & 7) == 0) && (n + 7 < p.N);
-    const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : nullptr);
-    const int64_t lde = EPI == EPI_DGELU ? p.ldc : p.ldr;
+    const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : (EPI == EPI_BNBWD ? p.bn_y : nullptr));
+    const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
     bf16x8 ex[NP];
-    if ((EPI == EPI_DGELU || EPI == EPI_LINEAR) && ext) {
+    float bsc[8], bsh[8], brs[8], bnm[8];      // EPI_BNBWD: z = y*bsc + bsh, xhat = y*brs + bnm for this thread's 8 columns
+    if (EPI == EPI_BNBWD) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = min(n + j, p.N - 1);
+            const float mu = p.bn_stat[c], rstd = p.bn_stat[p.N + c], ga = p.bn_gamma[c], be = p.bn_beta[c];
+            bsc[j] = ga * rstd; bsh[j] = be - mu * ga * rstd; brs[j] = rstd; bnm[j] = -mu * rstd;
+        }
+    }
+    if ((EPI == EPI_DGELU || EPI == EPI_LINEAR || EPI == EPI_BNBWD) && ext) {
         if (((lde & 7) == 0) && ((p.N & 7) == 0) && (((uintptr_t)ext & 15) == 0)) {
             // range-checked 16-byte buffer loads, all passes in flight before the first use; rows beyond M and column
             // chunks beyond N come back as zeros
@@ -161,7 +173,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         }
     }
     __syncthreads();
-    const bool stats = EPI == EPI_PLAIN && p.colstats != nullptr;
+    const bool stats = (EPI == EPI_PLAIN || EPI == EPI_BNBWD) && p.colstats != nullptr;
     float cs[8], cq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
@@ -175,7 +187,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         const int row = pass * RPP + rr, m = m0 + row;
         if (m >= p.M || n >= p.N) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
-        if (stats) {
+        if (EPI == EPI_BNBWD) {
+            // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat (of the stored, bf16-rounded dz)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float y = (float)ex[pass][j];
+                const bf16 dz = (bf16)((float)v[j] * gg_act_grad(fmaf(y, bsc[j], bsh[j]), p.bn_act));
+                v[j] = dz;
+                cs[j] += (float)dz; cq[j] += (float)dz * fmaf(y, brs[j], bnm[j]);
+            }
+        } else if (stats) {
             // BatchNorm partial statistics of the stored (bf16-rounded) conv output, taken on the way out
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; cs[j] += f; cq[j] += f * f; }
@@ -257,6 +278,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
     const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 2u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.A2 ? p.A2 : p.A) + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
     unsigned voa[LA], vob[LB];
     int lds_a[LA], lds_b[LB];
 #pragma unroll
@@ -286,8 +308,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
         const int k0 = kbeg + kt * BK;
         const bool kin = (k0 + skc * 8) < kend;                       // K % 8 == 0: a chunk is entirely in or out
         const int so = k0 * 2;
+        if (p.A2 && k0 >= p.k_split) {       // uniform: k_split is a multiple of the k-tile
 #pragma unroll
-        for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voa[i] : 0xFFFFFFF0u), so, 0);
+            for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, (int)(kin ? voa[i] : 0xFFFFFFF0u), so - p.k_split * 2, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voa[i] : 0xFFFFFFF0u), so, 0);
+        }
 #pragma unroll
         for (int i = 0; i < LB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kin ? vob[i] : 0xFFFFFFF0u), so, 0);
     };
@@ -515,7 +542,8 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
              "gg_gemm_nt: K, lda, ldb must be multiples of 8 (16-byte rows): K=%d lda=%lld ldb=%lld", a->K,
              (long long)a->lda, (long long)a->ldb);
     GG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "gg_gemm_nt: A/B must be 16-byte aligned");
-    GG_CHECK(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "gg_gemm_nt: leading dimension too small");
+    GG_CHECK(a->lda >= (a->A2 ? std::max(a->k_split, a->K - a->k_split) : a->K) && a->ldb >= a->K && a->ldc >= a->N,
+             "gg_gemm_nt: leading dimension too small");
     GG_CHECK(a->lda * 256 < 0xFFFFFF00LL && a->ldb * 256 < 0xFFFFFF00LL && (int64_t)a->K * 2 < 0x7FFFFFFFLL,
              "gg_gemm_nt: leading dimension too large for 32-bit tile offsets (ld < 16.7M elements)");
     GG_CHECK((!a->residual || a->ldr * 256 < 0xFFFFFF00LL) && (!a->dact_preact || a->ldc * 256 < 0xFFFFFF00LL),
@@ -530,9 +558,20 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt: an activation epilogue excludes rowscale/residual");
     GG_CHECK(!a->preact || a->act == GG_ACT_GELU, "gg_gemm_nt: preact is only available with the GELU epilogue");
     GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->out_f32),
-             "gg_gemm_nt: colstats is only available on the plain bf16 epilogue");
+             "gg_gemm_nt: colstats is only available on the plain and BatchNorm-backward bf16 epilogues");
     GG_CHECK(!a->out_f32 || !(a->act || a->rowscale || a->residual || a->dact_preact || a->preact), "gg_gemm_nt: f32 output supports bias only");
+    if (a->A2)
+        GG_CHECK(a->k_split > 0 && a->k_split < a->K && (a->k_split % BK) == 0 && split == 1 && ((uintptr_t)a->A2 & 15) == 0,
+                 "gg_gemm_nt: A2 needs 0 < k_split < K, k_split %% 64 == 0, no split-K, 16-byte alignment (k_split=%d K=%d)", a->k_split, a->K);
+    if (a->bn_y) {
+        GG_CHECK(a->bn_stat && a->bn_gamma && a->bn_beta && a->colstats, "gg_gemm_nt: the BatchNorm-backward epilogue needs stat, gamma, beta, colstats");
+        GG_CHECK(!(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->out_f32 || a->preact) && split == 1,
+                 "gg_gemm_nt: the BatchNorm-backward epilogue excludes every other epilogue option");
+        GG_CHECK(a->ldc * 256 < 0xFFFFFF00LL, "gg_gemm_nt: ldc too large for 32-bit tile offsets");
+    }
     GemmParams p;
+    p.A2 = (const bf16*)a->A2; p.k_split = a->k_split;
+    p.bn_y = (const bf16*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
     p.A = (const bf16*)a->A; p.lda = a->lda; p.B = (const bf16*)a->B; p.ldb = a->ldb;
     p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K;
     p.bias = a->bias; p.act = a->act; p.preact = (bf16*)a->preact;
@@ -545,9 +584,9 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     kps = (int)gg_align(kps, BK);
     p.k_per_split = kps;
     // tile choice: HBM-bound shapes (short K loop or a single narrow N tile) take the light 128x64 tile
-    const char* dbg = getenv("GG_GEMM_DEBUG");
+    static const char* dbg = getenv("GG_GEMM_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
-    const char* force = getenv("GG_GEMM_TILE");
+    static const char* force = getenv("GG_GEMM_TILE");
     const int rem = a->N % 128;
     bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);     // a 128-wide tile would be at most half full
     if (force) narrow = force[0] == 'n';
@@ -557,6 +596,7 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     dim3 grid(p.tilesM * p.tilesN, split);
     int epi;
     if (a->out_f32 || split > 1) epi = EPI_F32;
+    else if (p.bn_y) epi = EPI_BNBWD;
     else if (p.dact) epi = EPI_DGELU;
     else if (a->act == GG_ACT_GELU) epi = EPI_GELU;
     else if (a->act == GG_ACT_QUICK_GELU) epi = EPI_QGELU;
@@ -574,6 +614,7 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
         case EPI_GELU: GG_LAUNCH_EPI(EPI_GELU); break;
         case EPI_QGELU: GG_LAUNCH_EPI(EPI_QGELU); break;
         case EPI_DGELU: GG_LAUNCH_EPI(EPI_DGELU); break;
+        case EPI_BNBWD: GG_LAUNCH_EPI(EPI_BNBWD); break;
         default: GG_LAUNCH_EPI(EPI_F32); break;
     }
 #undef GG_LAUNCH_EPI

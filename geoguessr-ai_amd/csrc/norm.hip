@@ -167,6 +167,30 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
     }
 }
 
+// Folds BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) into the weights of the 1x1-conv dgrad that consumes dy:
+//   dx[m][ci] = sum_co dy[m][co] W[co][ci] = [dz | y][m][:] . Bf[ci][:] + bias[ci]
+//   Bf[ci][co] = bf16(c0[co] W[co][ci]),  Bf[ci][Cout + co] = bf16(c1[co] W[co][ci]),
+//   bias[ci]   = sum_co c2[co] W[co][ci] + (c1[co] W[co][ci] - Bf[ci][Cout + co]) * mean[co]
+// The second bias term moves the bf16 rounding error of the y-weights off the batch mean of y (it would otherwise scale
+// with |mean|/std of the channel) onto the centred activations.  One block per input channel.
+__global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const float* __restrict__ W, const float* __restrict__ coef,
+                                                          const float* __restrict__ stat, int Cout, int Cin, bf16* __restrict__ Bf,
+                                                          float* __restrict__ bias) {
+    __shared__ float red[32];
+    const int ci = blockIdx.x;
+    float acc = 0.f;
+    for (int co = threadIdx.x; co < Cout; co += blockDim.x) {
+        const float w = W[(int64_t)co * Cin + ci];
+        const float w0 = coef[co] * w, w1 = coef[Cout + co] * w;
+        const bf16 b0 = (bf16)w0, b1 = (bf16)w1;
+        Bf[(int64_t)ci * 2 * Cout + co] = b0;
+        Bf[(int64_t)ci * 2 * Cout + Cout + co] = b1;
+        acc += coef[2 * Cout + co] * w + (w1 - (float)b1) * stat[co];
+    }
+    acc = gg_block_sum<256>(acc, red);
+    if (threadIdx.x == 0) bias[ci] = acc;
+}
+
 // ------------------------------------------------------------------------------ LayerNorm
 // One wave per row, 8-element chunks: lane takes chunks lane, lane+64 (C <= 1024).
 template <typename T> struct Vec8;
@@ -466,6 +490,13 @@ extern "C" int gg_bn_bwd_apply(const void* dz, const void* y, const float* coef,
     GG_PROF(GG_CAT_NORM, 0, 6.0 * M * C, stream);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)y, coef,
                        M, C, rowscale, rows_per_scale, (bf16*)dy, g.CG, g.PP, g.rows_per_block);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_bn_bwd_fold_weights(const float* W, const float* coef, const float* stat, int Cout, int Cin, void* Bf, float* bias,
+                                      void* stream) {
+    GG_CHECK(W && coef && stat && Bf && bias && Cout > 0 && Cin > 0, "gg_bn_bwd_fold_weights: bad args");
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3(Cin), dim3(256), 0, (hipStream_t)stream, W, coef, stat, Cout, Cin, (bf16*)Bf, bias);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -194,6 +194,7 @@ struct Layout {
     int64_t pooled, mean_h, rstd_h;
     // scratch
     int64_t statpart, bnscratch, lnscratch, colsum, splitk, G[5];
+    int64_t foldw, foldb;        // BatchNorm-backward-folded dgrad weights bf16 [Cin][2*Cout] and bias f32 [Cin]
     int64_t gbytes;
 };
 
@@ -301,6 +302,10 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         L.lnscratch = p.alloc("scratch.ln", lnsmax, false);
         L.colsum = p.alloc("scratch.colsum", std::max<int64_t>(csmax, 1024), false);
         L.splitk = p.alloc("scratch.splitk", (int64_t)64 << 20, false);
+        int64_t fold = (int64_t)d[0] * 2 * mid;
+        for (int s = 0; s < 3; ++s) fold = std::max(fold, (int64_t)(s == 0 ? d[0] : m.stages[s - 1].C) * 2 * m.stages[s].C);
+        L.foldw = p.alloc("scratch.foldw", fold * 2, false);
+        L.foldb = p.alloc("scratch.foldb", 4096 * 4, false);
         L.gbytes = gg_align(gmax, 256);
         for (int i = 0; i < 5; ++i) L.G[i] = p.alloc("scratch.G" + std::to_string(i), L.gbytes, false);
     }
@@ -334,6 +339,9 @@ struct Exec {
     // Folding BatchNorm-backward apply/reduce into the depthwise data gradient (frozen taps) trades 4 [M,C] passes for a
     // slower conv kernel; measured a net loss so far (-6.6 ms elementwise, +13 ms conv) -> off by default.
     bool fuse_bnbwd = getenv("GG_FUSE_BNBWD") != nullptr;
+    // Frozen ConvNorm chains: BatchNorm backward's reduce rides in the epilogue of the conv dgrad that produces its input
+    // gradient, and its apply step is folded into the weights of the 1x1 dgrad that consumes its output gradient.
+    bool fuse_bngemm = getenv("GG_NO_BNGEMM") == nullptr;
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
@@ -345,6 +353,28 @@ struct Exec {
     const float* dropv(int slot) const { return drop ? drop + (int64_t)slot * B : nullptr; }
 };
 
+// conv dgrad with the BatchNorm-backward reduce of the ConvNorm it feeds as epilogue: dz = (dY . W) * act'(BN(y)), partial
+// column sums -> statpart
+static int gemm_bnbwd(const Exec& e, const bf16* dY, int64_t ldy, const bf16* Wt, int64_t ldw, bf16* dz, int64_t M, int N, int K,
+                      const BNP& bn, const Act& a, int act) {
+    GgGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dY; g.lda = ldy; g.B = Wt; g.ldb = ldw; g.C = dz; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
+    g.bn_y = e.A(a.y); g.bn_stat = e.F(a.stat); g.bn_gamma = e.P(bn.t_g); g.bn_beta = e.P(bn.t_b); g.bn_act = act;
+    g.colstats = e.F(e.L->statpart);
+    return gg_gemm_nt(&g, e.st);
+}
+// 1x1-conv dgrad straight from (dz, y): BatchNorm backward's apply step is folded into the weights (gg_bn_bwd_fold_weights)
+static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const bf16* dz, const bf16* y, const float* coef, const float* stat,
+                             bf16* dx, int64_t M, const bf16* residual) {
+    const int Cout = w.N, Cin = w.K;
+    GG_TRY(gg_bn_bwd_fold_weights(e.P(w.t_w), coef, stat, Cout, Cin, e.A(e.L->foldw), e.F(e.L->foldb), e.st));
+    GgGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = dz; g.lda = Cout; g.A2 = y; g.k_split = Cout; g.B = e.A(e.L->foldw); g.ldb = 2 * Cout; g.C = dx; g.ldc = Cin;
+    g.M = (int)M; g.N = Cin; g.K = 2 * Cout; g.bias = e.F(e.L->foldb); g.residual = residual; g.ldr = Cin;
+    return gg_gemm_nt(&g, e.st);
+}
 static int gemm(const Exec& e, const bf16* A, int64_t lda, const bf16* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
                 const float* bias = nullptr, int act = 0, void* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
                 const bf16* residual = nullptr, float* colstats = nullptr, const bf16* dact_pre = nullptr, int dact = 0) {
@@ -491,6 +521,13 @@ static int bn_bwd_reduce_fin(const Exec& e, const BNP& bn, const Act& a, int64_t
     GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz,
                             e.F(e.L->bnscratch), e.st));
     return gg_bn_bwd_finalize(e.F(e.L->bnscratch), gg_bn_bwd_rows(M, bn.C), bn.C, M, e.F(a.stat), e.P(bn.t_g), bn_coef(e, M, bn.C),
+                              tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
+}
+
+// finalize BatchNorm-backward sums that a GEMM epilogue left in statpart
+static int bn_bwd_fin_gemm(const Exec& e, const BNP& bn, const Act& a, int64_t M) {
+    const bool tr = e.tr(bn.t_g);
+    return gg_bn_bwd_finalize(e.F(e.L->statpart), gg_gemm_colstats_rows((int)M), bn.C, M, e.F(a.stat), e.P(bn.t_g), bn_coef(e, M, bn.C),
                               tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
 }
 
@@ -649,6 +686,15 @@ static int backward_impl(Exec& e, const float* d_out) {
                                    : (L.blocks[s - 1].empty() ? L.merge[s - 1].out : L.blocks[s - 1].back().x3);
         GG_TRY(bn_bwd(e, st.merge.c3.bn, ma.c3, M, GG_ACT_NONE, dx, t_b, t_a));                         // dy3 -> t_a
         if (e.tr(st.merge.c3.w.t_w)) GG_TRY(dense_wgrad(e, st.merge.c3.w, e.A(ma.a2), C, t_a, C, M, nullptr, 0, t_b, t_c, false));
+        if (e.fuse_bngemm && !e.tr(st.merge.c1.w.t_w) && !e.tr(st.merge.c2.w.t_w) && C % 64 == 0) {
+            GG_TRY(gemm_bnbwd(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_d, M, C, C, st.merge.c2.bn, ma.c2, GG_ACT_GELU));   // dz2 -> t_d
+            GG_TRY(bn_bwd_fin_gemm(e, st.merge.c2.bn, ma.c2, M));
+            GG_TRY(gg_bn_bwd_apply(t_d, e.A(ma.c2.y), bn_coef(e, M, C), M, C, nullptr, 0, t_a, e.st));       // dy2 -> t_a
+            GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(st.merge.c2.w), t_b, B, rin, rin, C, 2, e.st));         // da1 -> t_b [Min, C]
+            GG_TRY(bn_bwd_reduce_fin(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, t_b, t_d));                 // dz1 -> t_d
+            GG_TRY(gemm_folded_dgrad(e, st.merge.c1.w, t_d, e.A(ma.c1.y), bn_coef(e, Min, C), e.F(ma.c1.stat), dx, Min, nullptr));
+            continue;
+        }
         GG_TRY(gemm(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_b, C, M, C, C));                 // da2 -> t_b
         GG_TRY(bn_bwd(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, t_b, t_c, t_a));                          // dy2 -> t_a
         if (e.tr(st.merge.c2.w.t_w)) {
@@ -672,6 +718,26 @@ static int backward_impl(Exec& e, const float* d_out) {
         // out = gelu(x + s*BN3(y3)):  dz(=dpre, also the skip gradient) -> t_b, dy3 -> t_a
         GG_TRY(bn_bwd(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, dx, t_b, t_a, e.A(a.x), s0, rps0));
         if (e.tr(l.c3.w.t_w)) GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
+        if (e.fuse_bngemm && !e.tr(l.c1.w.t_w) && !e.tr(l.c2.w.t_w) && mid % 64 == 0) {
+            GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));                   // dz2 -> t_d
+            GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
+            bf16* dz1;
+            if (e.fuse_bnbwd) {
+                GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
+                                                   e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
+                const bool tr1 = e.tr(l.c1.bn.t_g);
+                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                                          bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
+                dz1 = t_c;
+            } else {
+                GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));   // dy2 -> t_a
+                GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));             // da1 -> t_c
+                GG_TRY(bn_bwd_reduce_fin(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d));                        // dz1 -> t_d
+                dz1 = t_d;
+            }
+            GG_TRY(gemm_folded_dgrad(e, l.c1.w, dz1, e.A(a.c1.y), bn_coef(e, M0, mid), e.F(a.c1.stat), dx, M0, t_b));   // + dpre
+            continue;
+        }
         GG_TRY(gemm(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_c, mid, M0, mid, d[0]));                     // da2 -> t_c [M0, mid]
         if (e.tr(l.c2.w.t_w) || !e.fuse_bnbwd) {
             GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy2 -> t_a

@@ -213,6 +213,55 @@ def bn_bwd(dout, y, stat, gamma, beta, act=None, residual=None, rowscale=None, r
     return dz, dy, dg, db
 
 
+def conv_dgrad_bn_bwd(dY, Wt, y, stat, gamma, beta, act=None, want_param_grads=True):
+    """dz = (dY @ Wt^T) * act'(BN(y)) with BatchNorm backward's column sums taken in the GEMM epilogue, then finalize.
+
+    dY [M,K] bf16, Wt [N,K] bf16 (the conv weight transposed), y [M,N] bf16 (the ConvNorm's saved conv output).
+    Returns (dz, coef [3,N], dgamma, dbeta) with dy = coef0*dz + coef1*y + coef2."""
+    L.require_gpu()
+    M, K = dY.shape
+    N = Wt.shape[0]
+    dev = dY.device
+    dz = torch.empty((M, N), dtype=BF16, device=dev)
+    rows = L.lib().gg_gemm_colstats_rows(M)
+    part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), dtype=F32, device=dev)
+    a = L.GemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(dY, BF16, "dY"), dY.stride(0), _pr(Wt, BF16, "Wt"), Wt.stride(0), _pr(dz), N
+    a.M, a.N, a.K = M, N, K
+    a.bn_y, a.bn_stat, a.bn_gamma, a.bn_beta, a.bn_act = _p(y, BF16, "y"), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act]
+    a.colstats = _p(part)
+    a.split_k = 1
+    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    coef = torch.empty((3, N), dtype=F32, device=dev)
+    dg = torch.zeros((N,), dtype=F32, device=dev) if want_param_grads else None
+    db = torch.zeros((N,), dtype=F32, device=dev) if want_param_grads else None
+    L.check(L.lib().gg_bn_bwd_finalize(_p(part), rows, N, M, _p(stat, F32), _p(gamma, F32), _p(coef), _p(dg), _p(db), 0,
+                                       L.stream()), "gg_bn_bwd_finalize")
+    return dz, coef, dg, db
+
+
+def folded_dgrad(dz, y, W, coef, stat, residual=None):
+    """dx = BNbwd_apply(dz, y, coef) @ W  for a 1x1 conv W [Cout, Cin] f32, without forming dy: [dz | y] @ Bf^T + bias."""
+    L.require_gpu()
+    M, Cout = dz.shape
+    Cin = W.shape[1]
+    dev = dz.device
+    Bf = torch.empty((Cin, 2 * Cout), dtype=BF16, device=dev)
+    bias = torch.empty((Cin,), dtype=F32, device=dev)
+    L.check(L.lib().gg_bn_bwd_fold_weights(_p(W, F32, "W"), _p(coef, F32), _p(stat, F32), Cout, Cin, _p(Bf), _p(bias),
+                                           L.stream()), "gg_bn_bwd_fold_weights")
+    dx = torch.empty((M, Cin), dtype=BF16, device=dev)
+    a = L.GemmArgs()
+    a.A, a.lda, a.A2, a.k_split = _pr(dz, BF16, "dz"), dz.stride(0), _pr(y, BF16, "y"), Cout
+    a.B, a.ldb, a.C, a.ldc = _p(Bf), 2 * Cout, _p(dx), Cin
+    a.M, a.N, a.K = M, Cin, 2 * Cout
+    a.bias = _p(bias)
+    a.residual, a.ldr = _p(residual, BF16, "residual"), Cin
+    a.split_k = 1
+    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    return dx
+
+
 def layernorm_fwd(x, gamma, beta, eps=1e-5, out_f32=None, save_stats=True):
     M, Cc = x.shape
     x_f32 = x.dtype == F32

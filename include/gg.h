@@ -44,6 +44,14 @@ typedef struct GgGemmArgs {
     float* colstats;                      /* f32 [gg_gemm_colstats_rows(M)][2][N] BatchNorm partials or NULL */
     int out_f32;
     int split_k;
+    /* optional second A source: contraction columns k >= k_split come from A2[M, K - k_split] (same lda; k_split % 64 == 0).
+     * With B = [diag(c0) W ; diag(c1) W] and bias = c2 . W this is the dgrad of a ConvNorm taken straight from
+     * (dz, y): BatchNorm backward's  dy = c0*dz + c1*y + c2  never touches memory (gg_bn_bwd_fold_weights). */
+    const void* A2; int k_split;
+    /* BatchNorm-backward epilogue (conv dgrads feeding act(BN(y)), timm ConvNorm + GELU, models/tinyvit.py:135):
+     * C = dz = acc * act'(gamma*xhat + beta), xhat = (bn_y - mean)*rstd with stat = [mean[N], rstd[N]], bn_y bf16 [M,ldc];
+     * colstats <- per M-tile column sums of (dz, dz*xhat) for gg_bn_bwd_finalize. */
+    const void* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;
 } GgGemmArgs;
 int gg_gemm_nt(const GgGemmArgs* args, void* stream);
 int gg_gemm_colstats_rows(int M);
@@ -98,6 +106,9 @@ int gg_bn_bwd_finalize(float* partials, int nparts, int C, int64_t count, const 
                        float* dgamma, float* dbeta, int accumulate, void* stream);
 int gg_bn_bwd_apply(const void* dz, const void* y, const float* coef, int64_t M, int C, const float* rowscale, int rows_per_scale,
                     void* dy, void* stream);
+/* W f32 [Cout][Cin] (1x1 conv), coef [3][Cout], stat [2][Cout] -> Bf bf16 [Cin][2*Cout], bias f32 [Cin] for the two-source
+ * dgrad  dx = [dz | y] . Bf^T + bias  (GgGemmArgs.A2) */
+int gg_bn_bwd_fold_weights(const float* W, const float* coef, const float* stat, int Cout, int Cin, void* Bf, float* bias, void* stream);
 int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
               const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
               float* dgamma, float* dbeta, int accumulate, void* stream);

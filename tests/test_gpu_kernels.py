@@ -115,6 +115,35 @@ def test_gemm_splitk_and_wgrad_form(ops):
           rtol=1e-4, atol=1e-3, what="colsum_bf16")
 
 
+@pytest.mark.parametrize("M,Cin,Cmid,Cout", [(3000, 96, 384, 96), (1111, 64, 128, 192)])
+def test_convnorm_chain_backward_fused_into_gemms(ops, M, Cin, Cmid, Cout):
+    """x -conv1-> y1 -BN(train)+GELU-> a1 -conv3-> y3: dgrad of conv3 carries BN backward's reduce in its epilogue, dgrad of
+    conv1 reads (dz1, y1) through BN-folded weights.  Checked against fp32 autograd."""
+    x = rnd(M, Cin, seed=70).to(BF).float()
+    W1 = (rnd(Cmid, Cin, seed=71) / Cin ** 0.5)
+    W3 = (rnd(Cout, Cmid, seed=72) / Cmid ** 0.5).to(BF).float()
+    gamma, beta = 1 + 0.2 * rnd(Cmid, seed=73), 0.3 * rnd(Cmid, seed=74)
+    G = rnd(M, Cout, seed=75).to(BF).float()
+    skip = rnd(M, Cin, seed=76).to(BF).float()
+    y1 = ((x @ W1.to(BF).float().T) + 1.5).to(BF).float()          # off-centre channels: exercises the mean correction
+    yr = y1.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a1 = F.gelu(F.batch_norm(yr, None, None, g_, b_, True, 0.1, 1e-5))
+    (a1 @ W3.T).backward(G)
+    dx_ref = yr.grad @ W1 + skip
+
+    mean, var = y1.mean(0), y1.var(0, unbiased=False)
+    stat = dev(torch.stack([mean, torch.rsqrt(var + 1e-5)]))
+    W3t = dev(W3.T.contiguous(), BF)                                 # [Cmid, Cout]
+    dz, coef, dg, db = ops.conv_dgrad_bn_bwd(dev(G, BF), W3t, dev(y1, BF), stat, dev(gamma), dev(beta), act="gelu")
+    dy = coef[0] * dz.float() + coef[1] * dev(y1) + coef[2]
+    close(dy, yr.grad, rtol=2e-2, atol=2e-2, what="dy from gemm-epilogue dz + coef")
+    close(dg, g_.grad, rtol=2e-2, atol=0.5, what="dgamma")
+    close(db, b_.grad, rtol=2e-2, atol=0.5, what="dbeta")
+    dx = ops.folded_dgrad(dz, dev(y1, BF), dev(W1), coef, stat, residual=dev(skip, BF))
+    close(dx, dx_ref, rtol=2e-2, atol=3e-2, what="folded dgrad")
+
+
 @pytest.mark.parametrize("M,N,K", [(5000, 96, 160), (4099, 48, 32), (1030, 576, 2304), (777, 1728, 576), (9000, 96, 432)])
 def test_gemm_tn_weight_gradient(ops, M, N, K):
     """dW = dY^T X straight from the row-major operands (transposing LDS reads), with a DropPath row scale."""
