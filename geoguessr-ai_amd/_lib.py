@@ -108,7 +108,7 @@ SIGNATURES = {
     "gg_view_mean_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),
     "gg_view_mean_bwd": (_I, [_P, _L, _P, _I, _I, _I, _P]),
     "gg_attention_padded_tokens": (_I, [_I]),
-    "gg_attention_expand_bias": (_I, [_P, _I, _I, _P, _P]),
+    "gg_attention_expand_bias": (_I, [_P, _I, _I, _F, _P, _P]),
     "gg_attention_fwd": (_I, [C.POINTER(AttnArgs), _P]),
     "gg_attention_bwd": (_I, [C.POINTER(AttnArgs), _P]),
     "gg_geo_head": (_I, [C.POINTER(GeoHeadArgs), _P]),

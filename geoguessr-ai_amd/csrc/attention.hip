@@ -18,7 +18,7 @@ struct AttnParams {
     const bf16* qkv; int64_t ld;
     int q_off, k_off, v_off, head_stride;
     bf16* out; int64_t ldo;           // forward output [tokens, ldo], head h at column h*D
-    const float* bias; int nbias;     // EXPANDED bias [nh][Np][Np] f32 (gg_attention_expand_bias; padded keys = -inf) or null;
+    const float* bias; int nbias;     // EXPANDED bias / scale [nh][Np][Np] f32 (gg_attention_expand_bias; padded keys = -inf) or null;
                                       // nbias = ws*ws = size of the table the bias gradient is reduced into
     int ws, nWx, nWy, H, W;           // ws > 0: windows of ws x ws tokens inside an H x W map; ws == 0: linear
     int N;                            // tokens per window
@@ -57,13 +57,23 @@ __device__ __forceinline__ bf16x8 attn_pack(const f32x4& a, const f32x4& b) {
     bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
     return v;
 }
-// row-major staging of a [N, D] column block of `src` into X[Np][RS] (zero rows for padded tokens)
-template <int D>
-__device__ __forceinline__ void attn_stage_rows(bf16* X, int RS, const bf16* src, int64_t ld, int col, const int* tok, int Np) {
+// row-major staging of a [N, D] column block of `src` into X[Np][RS] (zero rows for padded tokens).  All of a thread's
+// 16-byte loads are issued before the first LDS write (one memory round trip instead of one per chunk).
+template <int D, int Np>
+__device__ __forceinline__ void attn_stage_rows(bf16* X, int RS, const bf16* src, int64_t ld, int col, const int* tok) {
     constexpr int CH = D / 8;
-    for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {
-        const int key = idx / CH, dc = idx % CH;
-        *reinterpret_cast<bf16x8*>(X + key * RS + dc * 8) = attn_row_frag(src, ld, tok[key], col + dc * 8);
+    constexpr int IT = (Np * CH + 255) / 256;
+    bf16x8 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        const int key = min(idx / CH, Np - 1), dc = idx % CH;
+        v[i] = attn_row_frag(src, ld, tok[key], col + dc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < Np * CH) *reinterpret_cast<bf16x8*>(X + (idx / CH) * RS + (idx % CH) * 8) = v[i];
     }
 }
 // MFMA operand fragment of row `row`: 8 consecutive bf16 at column 8*lg (+32*ks)
@@ -98,14 +108,15 @@ __device__ __forceinline__ void attn_stage_transposed(bf16* T, int stride, const
 // attention_biases[h][|di|*ws+|dj|] -> full[h][q][k] (Np x Np, row-major): the kernels then fetch 4 consecutive keys of a
 // query row with one 16-byte load instead of 4 x (index arithmetic + LDS gather).  Padded keys carry -inf so no mask
 // select is needed; the matrix is symmetric, which the backward's [query][key] orientation uses.
-__global__ void attn_expand_bias_kernel(const float* __restrict__ table, int nh, int ws, int N, int Np, float* __restrict__ full) {
+__global__ void attn_expand_bias_kernel(const float* __restrict__ table, int nh, int ws, int N, int Np, float inv_scale,
+                                        float* __restrict__ full) {
     const int64_t total = (int64_t)nh * Np * Np;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % Np), q = (int)((i / Np) % Np), h = (int)(i / ((int64_t)Np * Np));
         float v = -INFINITY;
         if (k < N) {
             const int qq = min(q, N - 1);
-            v = table[h * ws * ws + abs(qq / ws - k / ws) * ws + abs(qq % ws - k % ws)];
+            v = table[h * ws * ws + abs(qq / ws - k / ws) * ws + abs(qq % ws - k % ws)] * inv_scale;
         }
         full[i] = v;
     }
@@ -129,8 +140,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
     for (int t = threadIdx.x; t < Np; t += blockDim.x) tok[t] = attn_token(p, w, t);
     __syncthreads();
-    attn_stage_rows<D>(Ks, RS, p.qkv, p.ld, p.k_off + h * p.head_stride, tok, Np);
-    attn_stage_rows<D>(Vs, RS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok, Np);
+    attn_stage_rows<D, Np>(Ks, RS, p.qkv, p.ld, p.k_off + h * p.head_stride, tok);
+    attn_stage_rows<D, Np>(Vs, RS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok);
     __syncthreads();
 
     const int nqt = (p.N + 15) / 16;
@@ -140,37 +151,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         bf16x8 qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
+        // The score accumulators START as the relative-position bias (the expanded table holds bias / scale, -inf on padded
+        // keys), so the bias costs no VALU work and all NKT tile loads are in flight together before the first MFMA.
         f32x4 s[NKT];
+        if (bias_h) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) s[kt] = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + kt * 16 + lg * 4);
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + lg * 4 + r < p.N) ? 0.f : -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);   // D[i=key][j=query]
-            }
-            const int key0 = kt * 16 + lg * 4;
-            if (bias_h) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + key0);   // -inf on padded keys
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = fmaf(acc[r], p.scale, bv[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = (key0 + r < p.N) ? acc[r] * p.scale : -INFINITY;
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);   // D[i=key][j=query]
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[r]);
-            s[kt] = acc;
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float c2 = p.scale * 1.4426950408889634f, mb = mx * c2;       // exp(scale*(s - mx)) = 2^(s*c2 - mx*c2)
         float l = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mb));
                 s[kt][r] = e;
                 l += e;
             }
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                 bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
                 *reinterpret_cast<bf16x4*>(p.out + (int64_t)qtok * p.ldo + h * D + dt * 16 + lg * 4) = ov;
             }
-            if (p.lse && lg == 0) p.lse[(int64_t)qtok * p.nh + h] = mx + __logf(l);
+            if (p.lse && lg == 0) p.lse[(int64_t)qtok * p.nh + h] = mx * p.scale + __logf(l);
         }
     }
 }
@@ -236,9 +248,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     for (int t = threadIdx.x; t < 256; t += blockDim.x) dbias_s[t] = 0.f;
     const float* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
     __syncthreads();
-    attn_stage_rows<D>(Qs, RS, p.qkv, p.ld, qcol, tok, Np);
-    attn_stage_rows<D>(Ks, RS, p.qkv, p.ld, kcol, tok, Np);
-    attn_stage_rows<D>(Vs, RS, p.qkv, p.ld, vcol, tok, Np);
+    attn_stage_rows<D, Np>(Qs, RS, p.qkv, p.ld, qcol, tok);
+    attn_stage_rows<D, Np>(Ks, RS, p.qkv, p.ld, kcol, tok);
+    attn_stage_rows<D, Np>(Vs, RS, p.qkv, p.ld, vcol, tok);
     {   // dO rows + delta = rowsum(dO * O)
         constexpr int CH = D / 8;
         for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {       // Np*CH is a multiple of 64: full waves
@@ -272,13 +284,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float c2 = p.scale * 1.4426950408889634f, lq2 = lse_q * 1.4426950408889634f;
+        // score accumulators start as bias / scale (see forward); the next pair of tiles is fetched one iteration ahead
+        auto bias_tiles = [&](int kp, f32x4 (&b)[2]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int key0 = (kp * 2 + u) * 16 + lg * 4;
+                if (bias_h) b[u] = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + key0);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[u][r] = (key0 + r < p.N) ? 0.f : -INFINITY;
+                }
+            }
+        };
+        f32x4 bnext[2];
+        bias_tiles(0, bnext);
 #pragma unroll 1
         for (int kp = 0; kp < NKT / 2; ++kp) {
             f32x4 dst[2];
+            f32x4 bcur[2] = {bnext[0], bnext[1]};
+            if (kp + 1 < NKT / 2) bias_tiles(kp + 1, bnext);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int kt = kp * 2 + u;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = bcur[u], acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
@@ -287,12 +316,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc2, 0, 0, 0);   // dP^T [key][query]
                 }
                 const int key0 = kt * 16 + lg * 4;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (bias_h) bv = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + key0);   // -inf on padded keys
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaf(acc[r], p.scale, bv[r]);
-                    const float pr = (bias_h || key0 + r < p.N) ? __expf(v - lse_q) : 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -lq2));      // padded keys: 2^-inf = 0
                     acc2[r] = pr * (acc2[r] - delta_q);
                 }
                 if (p.dbias && qtok >= 0) {     // bias gradient, binned by |di|,|dj| (only the trainable last stage takes this path)
@@ -335,13 +361,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         f32x4 dk[DT], dv[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        const float c2 = p.scale * 1.4426950408889634f;
+        const int64_t brow = (int64_t)min(ki, p.N - 1) * Np;      // symmetric table: bias[q][k] == bias[k][q]; columns >= N hold -inf
+        auto bias_tiles = [&](int qp, f32x4 (&b)[2]) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q0 = (qp * 2 + u) * 16 + lg * 4;
+                if (bias_h) b[u] = *reinterpret_cast<const f32x4*>(bias_h + brow + q0);
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) b[u][r] = (q0 + r < p.N) ? 0.f : -INFINITY;
+                }
+            }
+        };
+        f32x4 bnext[2];
+        bias_tiles(0, bnext);
 #pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
             f32x4 pt[2], dst[2];
+            f32x4 bcur[2] = {bnext[0], bnext[1]};
+            if (qp + 1 < NKT / 2) bias_tiles(qp + 1, bnext);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int qt = qp * 2 + u;
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = bcur[u], acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 qf = attn_lds_row_frag(Qs, RS, qt * 16 + lr, ks * 32 + lg * 8);
@@ -352,13 +395,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                 const int q0 = qt * 16 + lg * 4;
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_lse[q0]);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(&row_delta[q0]);
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (bias_h) bv = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)min(ki, p.N - 1) * Np + q0);   // symmetric: bias[q][k] == bias[k][q]
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaf(acc[r], p.scale, bv[r]);
-                    const bool ok = kvalid && (q0 + r) < p.N;
-                    const float pr = ok ? __expf(v - l4[r]) : 0.f;
+                    // padded queries: -inf score -> 0;  padded keys (kvalid false) produce rows that are never stored
+                    const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -l4[r] * 1.4426950408889634f)) : 0.f;
                     acc[r] = pr;
                     acc2[r] = pr * (acc2[r] - d4[r]);      // rows >= N: lse = delta = 0 (initialised), pr = 0
                 }
@@ -422,12 +462,12 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
 }
 static int attn_nkt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 224 ? 14 : 16)); }
 extern "C" int gg_attention_padded_tokens(int tokens_per_window) { return 16 * attn_nkt(tokens_per_window); }
-extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int window_size, float* full, void* stream) {
-    GG_CHECK(table && full && num_heads > 0 && window_size > 0 && window_size <= 16, "gg_attention_expand_bias: bad args");
+extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int window_size, float scale, float* full, void* stream) {
+    GG_CHECK(table && full && num_heads > 0 && window_size > 0 && window_size <= 16 && scale > 0.f, "gg_attention_expand_bias: bad args");
     const int N = window_size * window_size, Np = 16 * attn_nkt(N);
     const int64_t total = (int64_t)num_heads * Np * Np;
     hipLaunchKernelGGL(attn_expand_bias_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
-                       table, num_heads, window_size, N, Np, full);
+                       table, num_heads, window_size, N, Np, 1.0f / scale, full);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -69,7 +69,7 @@ __device__ __forceinline__ float gg_erf_sqrt2(float x) {
     return copysignf(fminf(p * u, 1.0f), x);
 }
 __device__ __forceinline__ float gg_gelu(float x) { return 0.5f * x * (1.0f + gg_erf_sqrt2(x)); }
-__device__ __forceinline__ float gg_gelu_grad(float x) {
+__device__ __forceinline__ float gg_gelu_grad_exp(float x) {       // Phi-polynomial + exp form (kept for reference / tests)
     const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
     return fmaf(x, pdf, 0.5f * (1.0f + gg_erf_sqrt2(x)));
 }
@@ -78,6 +78,53 @@ __device__ __forceinline__ float gg_quick_gelu_grad(float x) {
     const float s = __frcp_rn(1.0f + __expf(-1.702f * x));
     return s + 1.702f * x * s * (1.0f - s);
 }
+// ---- two-at-a-time forms: every multiply-add below is a v_pk_fma_f32 (2 lanes of work per VALU slot) --------------
+// The GELU epilogues and BatchNorm(+GELU) passes are VALU-bound once their memory traffic is fused away, so the hot
+// element-wise code runs on float2 values.  erf: same polynomial as gg_erf_sqrt2, sign handled by the odd form
+// (clamped signed argument, v_med3_f32) instead of abs / copysign.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 gg_clamp2(f32x2 x, float a) {
+    return (f32x2){__builtin_amdgcn_fmed3f(x.x, -a, a), __builtin_amdgcn_fmed3f(x.y, -a, a)};
+}
+__device__ __forceinline__ f32x2 gg_erf_sqrt2_v2(f32x2 x) {
+    const f32x2 u = gg_clamp2(x * 0.70710678118654752f, 3.0f);
+    const f32x2 t = u * u;
+    f32x2 p = (f32x2)(3.912539981e-08f);
+    p = p * t + (f32x2)(-1.883036475e-06f);
+    p = p * t + (f32x2)(4.008835822e-05f);
+    p = p * t + (f32x2)(-5.029218737e-04f);
+    p = p * t + (f32x2)(4.196857568e-03f);
+    p = p * t + (f32x2)(-2.499890141e-02f);
+    p = p * t + (f32x2)(1.109308004e-01f);
+    p = p * t + (f32x2)(-3.752196431e-01f);
+    p = p * t + (f32x2)(1.128250599e+00f);
+    return gg_clamp2(p * u, 1.0f);
+}
+__device__ __forceinline__ f32x2 gg_gelu_v2(f32x2 x) {
+    const f32x2 h = x * 0.5f;
+    return h * gg_erf_sqrt2_v2(x) + h;
+}
+// GELU'(x) = Phi(x) + x*phi(x) = 0.5 + u*Q(s), u = clamp(x, +-4.75), s = 2u^2/4.75^2 - 1  (odd part fitted directly,
+// degree 23, Horner in the centred variable; |error| <= 1.2e-5 incl. fp32 evaluation; beyond the clamp GELU' is 0 / 1
+// to 2.4e-5).  No exp, no erf: 8 VALU slots per element against 25 for Phi-polynomial + exp.
+__device__ __forceinline__ f32x2 gg_gelu_grad_v2(f32x2 x) {
+    const f32x2 u = gg_clamp2(x, 4.75f);
+    const f32x2 s = (u * u) * 8.864265928e-02f + (f32x2)(-1.0f);
+    f32x2 p = (f32x2)(-1.329242953e-02f);
+    p = p * s + (f32x2)(2.763605337e-02f);
+    p = p * s + (f32x2)(-1.633125265e-02f);
+    p = p * s + (f32x2)(2.348791181e-02f);
+    p = p * s + (f32x2)(-6.481112773e-02f);
+    p = p * s + (f32x2)(8.656523583e-02f);
+    p = p * s + (f32x2)(-8.702833417e-02f);
+    p = p * s + (f32x2)(8.773912323e-02f);
+    p = p * s + (f32x2)(-8.319626930e-02f);
+    p = p * s + (f32x2)(7.598317362e-02f);
+    p = p * s + (f32x2)(-8.164826059e-02f);
+    p = p * s + (f32x2)(1.501617604e-01f);
+    return p * u + (f32x2)(0.5f);
+}
+__device__ __forceinline__ float gg_gelu_grad(float x) { return gg_gelu_grad_v2((f32x2){x, x}).x; }
 // act codes shared by GEMM epilogues and norm kernels
 enum { GG_ACT_NONE = 0, GG_ACT_GELU = 1, GG_ACT_QUICK_GELU = 2 };
 __device__ __forceinline__ float gg_act(float x, int act) {
@@ -86,6 +133,9 @@ __device__ __forceinline__ float gg_act(float x, int act) {
 __device__ __forceinline__ float gg_act_grad(float x, int act) {
     return act == GG_ACT_GELU ? gg_gelu_grad(x) : (act == GG_ACT_QUICK_GELU ? gg_quick_gelu_grad(x) : 1.0f);
 }
+// pairwise NONE / GELU only (the BatchNorm paths of TinyViT); `gelu` is wave-uniform
+__device__ __forceinline__ f32x2 gg_act_v2(f32x2 x, bool gelu) { return gelu ? gg_gelu_v2(x) : x; }
+__device__ __forceinline__ f32x2 gg_act_grad_v2(f32x2 x, bool gelu) { return gelu ? gg_gelu_grad_v2(x) : (f32x2)(1.0f); }
 
 // ---- wave / block reductions (wave = 64 lanes) -----------------------------------
 __device__ __forceinline__ float gg_wave_sum(float v) {

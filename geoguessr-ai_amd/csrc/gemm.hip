@@ -140,13 +140,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : (EPI == EPI_BNBWD ? p.bn_y : nullptr));
     const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
     bf16x8 ex[NP];
-    float bsc[8], bsh[8], brs[8], bnm[8];      // EPI_BNBWD: z = y*bsc + bsh, xhat = y*brs + bnm for this thread's 8 columns
+    f32x2 bsc[4], bsh[4], brs[4], bnm[4];      // EPI_BNBWD: z = y*bsc + bsh, xhat = y*brs + bnm for this thread's 8 columns
     if (EPI == EPI_BNBWD) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = min(n + j, p.N - 1);
             const float mu = p.bn_stat[c], rstd = p.bn_stat[p.N + c], ga = p.bn_gamma[c], be = p.bn_beta[c];
-            bsc[j] = ga * rstd; bsh[j] = be - mu * ga * rstd; brs[j] = rstd; bnm[j] = -mu * rstd;
+            bsc[j >> 1][j & 1] = ga * rstd; bsh[j >> 1][j & 1] = be - mu * ga * rstd;
+            brs[j >> 1][j & 1] = rstd; bnm[j >> 1][j & 1] = -mu * rstd;
         }
     }
     if ((EPI == EPI_DGELU || EPI == EPI_LINEAR || EPI == EPI_BNBWD) && ext) {
@@ -174,9 +175,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     }
     __syncthreads();
     const bool stats = (EPI == EPI_PLAIN || EPI == EPI_BNBWD) && p.colstats != nullptr;
-    float cs[8], cq[8];
+    f32x2 cs2[4], cq2[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) cs[j] = cq[j] = 0.f;
+    for (int j = 0; j < 4; ++j) cs2[j] = cq2[j] = (f32x2)(0.f);
+    const bool bn_gelu = p.bn_act == GG_ACT_GELU;
     auto store8 = [&](bf16* base, int m, const bf16x8& v) {
         bf16* g = base + (int64_t)m * p.ldc + n;
         if (wide) *reinterpret_cast<bf16x8*>(g) = v;
@@ -190,26 +192,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         if (EPI == EPI_BNBWD) {
             // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat (of the stored, bf16-rounded dz)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float y = (float)ex[pass][j];
-                const bf16 dz = (bf16)((float)v[j] * gg_act_grad(fmaf(y, bsc[j], bsh[j]), p.bn_act));
-                v[j] = dz;
-                cs[j] += (float)dz; cq[j] += (float)dz * fmaf(y, brs[j], bnm[j]);
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 y = {(float)ex[pass][2 * j], (float)ex[pass][2 * j + 1]};
+                const f32x2 d = (f32x2){(float)v[2 * j], (float)v[2 * j + 1]} * gg_act_grad_v2(y * bsc[j] + bsh[j], bn_gelu);
+                const bf16 d0 = (bf16)d.x, d1 = (bf16)d.y;
+                v[2 * j] = d0; v[2 * j + 1] = d1;
+                const f32x2 dr = {(float)d0, (float)d1};
+                cs2[j] += dr; cq2[j] += dr * (y * brs[j] + bnm[j]);
             }
         } else if (stats) {
             // BatchNorm partial statistics of the stored (bf16-rounded) conv output, taken on the way out
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; cs[j] += f; cq[j] += f * f; }
+            for (int j = 0; j < 4; ++j) { const f32x2 f = {(float)v[2 * j], (float)v[2 * j + 1]}; cs2[j] += f; cq2[j] += f * f; }
         }
         if (p.debug & 2) continue;
         if (EPI == EPI_GELU) {
             if (p.preact) store8(p.preact, m, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)gg_gelu((float)v[j]);
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2 r = gg_gelu_v2((f32x2){(float)v[j], (float)v[j + 1]});
+                v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+            }
         }
         if (EPI == EPI_DGELU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * gg_gelu_grad((float)ex[pass][j]));
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2 r = (f32x2){(float)v[j], (float)v[j + 1]} * gg_gelu_grad_v2((f32x2){(float)ex[pass][j], (float)ex[pass][j + 1]});
+                v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+            }
         }
         if (EPI == EPI_LINEAR && p.residual) {
 #pragma unroll
@@ -219,6 +229,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     }
     if (stats) {
         __syncthreads();
+        float cs[8], cq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cs[j] = cs2[j >> 1][j & 1]; cq[j] = cq2[j >> 1][j & 1]; }
         // threads sharing a column chunk: lanes l, l+CPR, ... within a wave, then the 4 waves through LDS
         float* red = reinterpret_cast<float*>(smem);         // [4 waves][2][BN]
 #pragma unroll

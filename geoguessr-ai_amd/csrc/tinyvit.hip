@@ -16,6 +16,7 @@
 namespace {
 
 struct TensorInfo { std::string name; int64_t offset; int64_t numel; int ndim; int64_t shape[4]; int kind; };
+static const float kAttnScale = 0.17677669529663687f;   // head_dim 32 ^ -0.5; the expanded bias tables are divided by it
 struct DenseW { int t_w = -1, t_b = -1; int N = 0, K = 0, Kp = 0, Np = 0, taps = 1, cin = 0; int64_t wn = 0, wt = 0; };
 struct BNP { int t_g = -1, t_b = -1; int64_t rm = 0, rv = 0; int cnt = 0; int C = 0; };
 struct DwW { int t_w = -1; int C = 0; int64_t taps = 0; };
@@ -492,7 +493,7 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = 0.17677669529663687f;   // 32^-0.5
+            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = kAttnScale;
             at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             GG_TRY(gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
@@ -659,7 +660,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = 0.17677669529663687f;
+            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = kAttnScale;
             at.dout = t_a; at.lddo = C; at.dqkv = t_b; at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
             GG_TRY(gg_attention_bwd(&at, e.st));
@@ -888,7 +889,7 @@ extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* 
             GG_TRY(repack_dense(b.fc1, params, m, wc, st));
             GG_TRY(repack_dense(b.fc2, params, m, wc, st));
             GG_TRY(repack_dw(b.local.w, params, m, wc, st));
-            GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws,
+            GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws, kAttnScale,
                                             reinterpret_cast<float*>(wc + b.bias_full), stream));
         }
     }

@@ -44,3 +44,49 @@ for name, M, N, K, o in shapes:
     if o.get("out_f32"): byt += 2 * M * N
     print(f"{name:16s} M={M:9d} N={N:5d} K={K:5d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s  {byt/ms/1e6:8.1f} GB/s")
     del A, W, out, kw
+
+# ---- BatchNorm-backward-fused dgrads (raw GemmArgs so that only the kernel is timed) ----
+import ctypes as C
+from geoguessr_ai_amd import _lib as L
+
+
+def timed(fn, n=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+for name, M, N, K in [("mb.c3.dgrad+bnbwd", M0, 384, 96), ("mg1.c3.dgrad+bnbwd", Ms1, 192, 192), ("mg2.c3.dgrad+bnbwd", Ms2, 384, 384)]:
+    dY = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") * 0.05).bfloat16()
+    y = torch.randn(M, N, device="cuda").bfloat16(); dz = torch.empty_like(y)
+    stat = torch.stack([torch.zeros(N), torch.ones(N)]).cuda(); g = torch.ones(N, device="cuda"); b = torch.zeros(N, device="cuda")
+    rows = L.lib().gg_gemm_colstats_rows(M)
+    part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), device="cuda")
+    for act in (1, 0):
+        a = L.GemmArgs()
+        a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N, a.K = dY.data_ptr(), K, Wt.data_ptr(), K, dz.data_ptr(), N, M, N, K
+        a.bn_y, a.bn_stat, a.bn_gamma, a.bn_beta, a.bn_act, a.colstats, a.split_k = y.data_ptr(), stat.data_ptr(), g.data_ptr(), b.data_ptr(), act, part.data_ptr(), 1
+        ms = timed(lambda: L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream())))
+        byt = 2 * (M * K + 2 * M * N)
+        print(f"{name:20s} act={act} M={M:9d} N={N:5d} K={K:5d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s  {byt/ms/1e6:8.1f} GB/s")
+    a = L.GemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc, a.M, a.N, a.K = dY.data_ptr(), K, Wt.data_ptr(), K, dz.data_ptr(), N, M, N, K
+    a.colstats, a.split_k = part.data_ptr(), 1
+    ms = timed(lambda: L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream())))
+    print(f"{name:20s} plain+stats            {ms*1e3:9.1f} us")
+    del dY, Wt, y, dz, part
+for name, M, Cin, Cout in [("mb.c1.dgrad.fold", M0, 96, 384), ("mg1.c1.dgrad.fold", M0, 96, 192), ("mg2.c1.dgrad.fold", Ms1, 192, 384)]:
+    dz = torch.randn(M, Cout, device="cuda").bfloat16(); y = torch.randn(M, Cout, device="cuda").bfloat16()
+    Bf = (torch.randn(Cin, 2 * Cout, device="cuda") * 0.05).bfloat16(); bias = torch.zeros(Cin, device="cuda")
+    dx = torch.empty(M, Cin, device="cuda").bfloat16(); res = torch.randn(M, Cin, device="cuda").bfloat16()
+    a = L.GemmArgs()
+    a.A, a.lda, a.A2, a.k_split, a.B, a.ldb, a.C, a.ldc = dz.data_ptr(), Cout, y.data_ptr(), Cout, Bf.data_ptr(), 2 * Cout, dx.data_ptr(), Cin
+    a.M, a.N, a.K, a.bias, a.residual, a.ldr, a.split_k = M, Cin, 2 * Cout, bias.data_ptr(), res.data_ptr(), Cin, 1
+    ms = timed(lambda: L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream())))
+    byt = 2 * (2 * M * Cout + 2 * M * Cin)
+    print(f"{name:20s} M={M:9d} N={Cin:5d} K={2*Cout:5d}  {ms*1e3:9.1f} us  {2*M*Cin*2*Cout/ms/1e9:8.1f} TF/s  {byt/ms/1e6:8.1f} GB/s")
+    del dz, y, Bf, dx, res
