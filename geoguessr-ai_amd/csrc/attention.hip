@@ -18,9 +18,10 @@ struct AttnParams {
     const bf16* qkv; int64_t ld;
     int q_off, k_off, v_off, head_stride;
     bf16* out; int64_t ldo;           // forward output [tokens, ldo], head h at column h*D
-    const float* bias; int nbias;     // EXPANDED bias / scale [nh][Np][Np] f32 (gg_attention_expand_bias; padded keys = -inf) or null;
+    const bf16* bias; int nbias;      // EXPANDED bias / scale [nh][Np][Np] bf16 (gg_attention_expand_bias; padded keys = -inf) or null;
                                       // nbias = ws*ws = size of the table the bias gradient is reduced into
     int ws, nWx, nWy, H, W;           // ws > 0: windows of ws x ws tokens inside an H x W map; ws == 0: linear
+    int ws_inv;                       // ceil(65536 / ws)
     int N;                            // tokens per window
     int nh;
     float scale;
@@ -31,14 +32,34 @@ struct AttnParams {
     float* lse;                       // [tokens][nh] log-sum-exp of the scaled+biased scores (fwd writes, bwd reads)
 };
 
-__device__ __forceinline__ int attn_token(const AttnParams& p, int w, int t) {
-    if (t >= p.N) return -1;
-    if (p.ws == 0) return w * p.N + t;
+// token index of window-local position t: the window origin is block-uniform (computed once), the in-window split
+// t -> (t / ws, t % ws) uses a 16-bit reciprocal (exact for t < 256, ws <= 16) -- no integer division per token
+__device__ __forceinline__ int attn_origin(const AttnParams& p, int w) {
+    if (p.ws == 0) return w * p.N;
     const int per_img = p.nWx * p.nWy;
     const int b = w / per_img, r = w % per_img;
     const int wy = r / p.nWx, wx = r % p.nWx;
-    const int i = t / p.ws, j = t % p.ws;
-    return (b * p.H + wy * p.ws + i) * p.W + wx * p.ws + j;
+    return (b * p.H + wy * p.ws) * p.W + wx * p.ws;
+}
+__device__ __forceinline__ int attn_token(const AttnParams& p, int origin, int t) {
+    if (t >= p.N) return -1;
+    if (p.ws == 0) return origin + t;
+    const int i = (t * p.ws_inv) >> 16, j = t - i * p.ws;
+    return origin + i * p.W + j;
+}
+// 4 consecutive entries of the expanded bf16 bias table as an MFMA accumulator tile (bf16 -> f32 is a 16-bit shift)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 attn_bias_cvt(u32x2 raw) {
+    return (f32x4){__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                   __uint_as_float(raw.y & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 attn_bias4(const bf16* ptr) { return attn_bias_cvt(*reinterpret_cast<const u32x2*>(ptr)); }
+// the same 4 entries for the bias-free case: 0 for valid positions, -inf (bf16 0xFF80) beyond N
+__device__ __forceinline__ u32x2 attn_mask_raw(int pos0, int N) {
+    u32x2 r;
+    r.x = (pos0 < N ? 0u : 0xFF80u) | (pos0 + 1 < N ? 0u : 0xFF800000u);
+    r.y = (pos0 + 2 < N ? 0u : 0xFF80u) | (pos0 + 3 < N ? 0u : 0xFF800000u);
+    return r;
 }
 // 8 consecutive bf16 of row `tok` at column `col` (zeros for padded rows)
 __device__ __forceinline__ bf16x8 attn_row_frag(const bf16* base, int64_t ld, int tok, int col) {
@@ -57,24 +78,34 @@ __device__ __forceinline__ bf16x8 attn_pack(const f32x4& a, const f32x4& b) {
     bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
     return v;
 }
-// row-major staging of a [N, D] column block of `src` into X[Np][RS] (zero rows for padded tokens).  All of a thread's
-// 16-byte loads are issued before the first LDS write (one memory round trip instead of one per chunk).
+// row-major staging of a [N, D] column block of `src` into X[Np][RS] (zero rows for padded tokens), split into the load
+// half and the LDS-write half so that a kernel can put every operand load in flight before the first write waits.
 template <int D, int Np>
-__device__ __forceinline__ void attn_stage_rows(bf16* X, int RS, const bf16* src, int64_t ld, int col, const int* tok) {
+__device__ __forceinline__ void attn_load_rows(bf16x8 (&v)[(Np * (D / 8) + 255) / 256], const bf16* src, int64_t ld, int col,
+                                               const int (&tokv)[(Np * (D / 8) + 255) / 256]) {
     constexpr int CH = D / 8;
     constexpr int IT = (Np * CH + 255) / 256;
-    bf16x8 v[IT];
 #pragma unroll
-    for (int i = 0; i < IT; ++i) {
-        const int idx = threadIdx.x + i * 256;
-        const int key = min(idx / CH, Np - 1), dc = idx % CH;
-        v[i] = attn_row_frag(src, ld, tok[key], col + dc * 8);
-    }
+    for (int i = 0; i < IT; ++i) v[i] = attn_row_frag(src, ld, tokv[i], col + ((threadIdx.x + i * 256) % CH) * 8);
+}
+template <int D, int Np>
+__device__ __forceinline__ void attn_store_rows(bf16* X, int RS, const bf16x8 (&v)[(Np * (D / 8) + 255) / 256]) {
+    constexpr int CH = D / 8;
+    constexpr int IT = (Np * CH + 255) / 256;
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int idx = threadIdx.x + i * 256;
         if (idx < Np * CH) *reinterpret_cast<bf16x8*>(X + (idx / CH) * RS + (idx % CH) * 8) = v[i];
     }
+}
+// token ids of the rows this thread stages (chunk idx = tid + 256 i -> row idx / CH): computed arithmetically, so the
+// operand loads do not wait for an LDS token table + barrier
+template <int D, int Np>
+__device__ __forceinline__ void attn_stage_tokens(const AttnParams& p, int origin, int (&tokv)[(Np * (D / 8) + 255) / 256]) {
+    constexpr int CH = D / 8;
+    constexpr int IT = (Np * CH + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) tokv[i] = attn_token(p, origin, min((int)(threadIdx.x + i * 256) / CH, Np - 1));
 }
 // MFMA operand fragment of row `row`: 8 consecutive bf16 at column 8*lg (+32*ks)
 __device__ __forceinline__ bf16x8 attn_lds_row_frag(const bf16* X, int RS, int row, int col) {
@@ -92,24 +123,11 @@ __device__ __forceinline__ bf16x8 attn_lds_tr_frag(const bf16* X, int RS, int d0
     u.s[0] = a; u.s[1] = b;
     return u.v;
 }
-// transposed staging of a [N, D] column block of `src` into T[D][stride] (zero for padded keys)
-template <int D>
-__device__ __forceinline__ void attn_stage_transposed(bf16* T, int stride, const bf16* src, int64_t ld, int col, const int* tok,
-                                                      int Np) {
-    constexpr int CH = D / 8;
-    for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {
-        const int key = idx / CH, dc = idx % CH;
-        const bf16x8 v = attn_row_frag(src, ld, tok[key], col + dc * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) T[(dc * 8 + j) * stride + key] = v[j];
-    }
-}
-
 // attention_biases[h][|di|*ws+|dj|] -> full[h][q][k] (Np x Np, row-major): the kernels then fetch 4 consecutive keys of a
 // query row with one 16-byte load instead of 4 x (index arithmetic + LDS gather).  Padded keys carry -inf so no mask
 // select is needed; the matrix is symmetric, which the backward's [query][key] orientation uses.
 __global__ void attn_expand_bias_kernel(const float* __restrict__ table, int nh, int ws, int N, int Np, float inv_scale,
-                                        float* __restrict__ full) {
+                                        bf16* __restrict__ full) {
     const int64_t total = (int64_t)nh * Np * Np;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(i % Np), q = (int)((i / Np) % Np), h = (int)(i / ((int64_t)Np * Np));
@@ -118,89 +136,139 @@ __global__ void attn_expand_bias_kernel(const float* __restrict__ table, int nh,
             const int qq = min(q, N - 1);
             v = table[h * ws * ws + abs(qq / ws - k / ws) * ws + abs(qq % ws - k % ws)] * inv_scale;
         }
-        full[i] = v;
+        full[i] = (bf16)v;
+    }
+}
+
+// One chunk of KN key tiles (starting at tile K0) of one query tile.  The score accumulators START as the relative-position
+// bias (the expanded table holds bias / scale, -inf on padded keys), so the bias costs no VALU work and the chunk's tile loads
+// are in flight together before the first MFMA.
+template <int D, int NKT, int K0, int KN>
+__device__ __forceinline__ void attn_fwd_chunk(const AttnParams& p, const bf16* Ks, const bf16* Vs, const bf16* bias_h,
+                                               const bf16x8 (&qf)[D / 32], int qi, int lr, int lg, float c2, float& m, float& l,
+                                               f32x4 (&o)[D / 16]) {
+    constexpr int Np = NKT * 16, RS = D + 8, KS = D / 32, DT = D / 16;
+    static_assert((K0 & 1) == 0 && (KN & 1) == 0, "key tiles are consumed in pairs");
+    // keep the scheduler from hoisting this chunk's loads above the previous chunk's tail: it trades the occupancy the chunking
+    // buys (registers) for latency hiding that the other resident waves already provide
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 s[KN];
+    if (bias_h) {
+#pragma unroll
+        for (int kt = 0; kt < KN; ++kt) s[kt] = attn_bias4(bias_h + (int64_t)qi * Np + (K0 + kt) * 16 + lg * 4);
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < KN; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[kt][r] = ((K0 + kt) * 16 + lg * 4 + r < p.N) ? 0.f : -INFINITY;
+    }
+    float mx = m;
+#pragma unroll
+    for (int kt = 0; kt < KN; ++kt) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = attn_lds_row_frag(Ks, RS, (K0 + kt) * 16 + lr, ks * 32 + lg * 8);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);   // D[i=key][j=query]
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (K0 > 0) {       // carry rescale (the first chunk starts from m = -inf, l = 0, o = 0)
+        const float alpha = __builtin_amdgcn_exp2f((m - mx) * c2);
+        l *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    }
+    m = mx;
+    const float mb = mx * c2;
+#pragma unroll
+    for (int kt = 0; kt < KN; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mb));
+            s[kt][r] = e;
+            l += e;
+        }
+#pragma unroll
+    for (int kp = 0; kp < KN / 2; ++kp) {
+        const bf16x8 pf = attn_pack(s[2 * kp], s[2 * kp + 1]);   // k = key 32kp + 16(jj>>2) + 4lg + (jj&3)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16x8 vf = attn_lds_tr_frag(Vs, RS, dt * 16, (K0 / 2 + kp) * 32, lr, lg);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);   // D[i=d][j=query]
+        }
+    }
+}
+
+#ifndef GG_ATTN_CK
+#define GG_ATTN_CK 8
+#endif
+template <int D, int NKT, int K0>
+__device__ __forceinline__ void attn_fwd_chunks(const AttnParams& p, const bf16* Ks, const bf16* Vs, const bf16* bias_h,
+                                                const bf16x8 (&qf)[D / 32], int qi, int lr, int lg, float c2, float& m, float& l,
+                                                f32x4 (&o)[D / 16]) {
+    if constexpr (K0 < NKT) {
+        constexpr int KN = (NKT - K0) < GG_ATTN_CK ? (NKT - K0) : GG_ATTN_CK;
+        attn_fwd_chunk<D, NKT, K0, KN>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
+        attn_fwd_chunks<D, NKT, K0 + KN>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
     }
 }
 
 // ------------------------------------------------------------------------------------------- forward
 template <int D, int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
     constexpr int Np = NKT * 16;
     constexpr int RS = D + 8;     // 80 / 144-byte rows: 16-B aligned fragments, 8-B aligned transposing reads
     constexpr int KS = D / 32;    // MFMA k-steps over the head dim
     constexpr int DT = D / 16;    // output d tiles
     __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
-    __shared__ int tok[Np];
 
     const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+    const int origin = attn_origin(p, w);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
-    const float* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
-
-    for (int t = threadIdx.x; t < Np; t += blockDim.x) tok[t] = attn_token(p, w, t);
-    __syncthreads();
-    attn_stage_rows<D, Np>(Ks, RS, p.qkv, p.ld, p.k_off + h * p.head_stride, tok);
-    attn_stage_rows<D, Np>(Vs, RS, p.qkv, p.ld, p.v_off + h * p.head_stride, tok);
-    __syncthreads();
-
+    const bf16* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
     const int nqt = (p.N + 15) / 16;
+
+    // every global operand of the first query tile is requested before the first wait: K / V rows, the Q fragment, the bias
+    int tokv[(Np * (D / 8) + 255) / 256];
+    attn_stage_tokens<D, Np>(p, origin, tokv);
+    int qtok = wave < nqt ? attn_token(p, origin, wave * 16 + lr) : -1;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
+    {
+        bf16x8 kr[(Np * (D / 8) + 255) / 256], vr[(Np * (D / 8) + 255) / 256];
+        attn_load_rows<D, Np>(kr, p.qkv, p.ld, p.k_off + h * p.head_stride, tokv);
+        attn_load_rows<D, Np>(vr, p.qkv, p.ld, p.v_off + h * p.head_stride, tokv);
+        attn_store_rows<D, Np>(Ks, RS, kr);
+        attn_store_rows<D, Np>(Vs, RS, vr);
+    }
+    __syncthreads();
+
     for (int qt = wave; qt < nqt; qt += 4) {
         const int qi = qt * 16 + lr;
-        const int qtok = tok[qi];
-        bf16x8 qf[KS];
+        if (qt != wave) {
+            qtok = attn_token(p, origin, qi);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
-        // The score accumulators START as the relative-position bias (the expanded table holds bias / scale, -inf on padded
-        // keys), so the bias costs no VALU work and all NKT tile loads are in flight together before the first MFMA.
-        f32x4 s[NKT];
-        if (bias_h) {
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) s[kt] = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + kt * 16 + lg * 4);
-        } else {
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + lg * 4 + r < p.N) ? 0.f : -INFINITY;
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
         }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);   // D[i=key][j=query]
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float c2 = p.scale * 1.4426950408889634f, mb = mx * c2;       // exp(scale*(s - mx)) = 2^(s*c2 - mx*c2)
-        float l = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, -mb));
-                s[kt][r] = e;
-                l += e;
-            }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
-
+        // Keys are visited in chunks of <= 8 tiles with an online-softmax carry (running max m, partial sum l, output o):
+        // a chunk's scores are the only big live register array (32 instead of 4*NKT), which is what sets occupancy.
+        float m = -INFINITY, l = 0.f;
         f32x4 o[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kp = 0; kp < NKT / 2; ++kp) {
-            const bf16x8 pf = attn_pack(s[2 * kp], s[2 * kp + 1]);   // k = key 32kp + 16(jj>>2) + 4lg + (jj&3)
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const bf16x8 vf = attn_lds_tr_frag(Vs, RS, dt * 16, kp * 32, lr, lg);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);   // D[i=d][j=query]
-            }
-        }
+        const float c2 = p.scale * 1.4426950408889634f;       // exp(scale*(s - m)) = 2^(s*c2 - m*c2)
+        attn_fwd_chunks<D, NKT, 0>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float mx = m;
         if (qtok >= 0) {
             const float inv = 1.f / l;
 #pragma unroll
@@ -227,43 +295,52 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
     __shared__ __attribute__((aligned(16))) bf16 dOs[Np * RS];
     __shared__ __attribute__((aligned(16))) float row_lse[Np], row_delta[Np];
-    __shared__ int tok[Np];
     __shared__ float dbias_s[256];
     __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];   // window coordinates: bias-gradient binning only
 
     const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+    const int origin = attn_origin(p, w);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
     const int qcol = p.q_off + h * p.head_stride, kcol = p.k_off + h * p.head_stride, vcol = p.v_off + h * p.head_stride;
     const int ocol = h * D;
 
-    for (int t = threadIdx.x; t < Np; t += blockDim.x) {
-        const int tk = attn_token(p, w, t);
-        tok[t] = tk;
-        const int tt = min(t, p.N - 1);
-        ci[t] = p.ws ? (unsigned char)(tt / p.ws) : 0;
-        cj[t] = p.ws ? (unsigned char)(tt % p.ws) : 0;
-        row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
-    }
-    for (int t = threadIdx.x; t < 256; t += blockDim.x) dbias_s[t] = 0.f;
-    const float* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
-    __syncthreads();
-    attn_stage_rows<D, Np>(Qs, RS, p.qkv, p.ld, qcol, tok);
-    attn_stage_rows<D, Np>(Ks, RS, p.qkv, p.ld, kcol, tok);
-    attn_stage_rows<D, Np>(Vs, RS, p.qkv, p.ld, vcol, tok);
-    {   // dO rows + delta = rowsum(dO * O)
+    const bf16* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
+    {
+        // all operand rows (Q, K, V, dO, O) are requested before anything waits; token ids are computed, not looked up
         constexpr int CH = D / 8;
-        for (int idx = threadIdx.x; idx < Np * CH; idx += blockDim.x) {       // Np*CH is a multiple of 64: full waves
-            const int row = idx / CH, dc = idx % CH;
-            const bf16x8 dv = attn_row_frag(p.dout, p.lddo, tok[row], ocol + dc * 8);
-            const bf16x8 ov = attn_row_frag(p.out, p.ldo, tok[row], ocol + dc * 8);
-            *reinterpret_cast<bf16x8*>(dOs + row * RS + dc * 8) = dv;
-            float s = 0.f;
+        constexpr int IT = (Np * CH + 255) / 256;
+        int tokv[IT];
+        attn_stage_tokens<D, Np>(p, origin, tokv);
+        bf16x8 qr[IT], kr[IT], vr[IT], dr[IT], orr[IT];
+        attn_load_rows<D, Np>(qr, p.qkv, p.ld, qcol, tokv);
+        attn_load_rows<D, Np>(kr, p.qkv, p.ld, kcol, tokv);
+        attn_load_rows<D, Np>(vr, p.qkv, p.ld, vcol, tokv);
+        attn_load_rows<D, Np>(dr, p.dout, p.lddo, ocol, tokv);
+        attn_load_rows<D, Np>(orr, p.out, p.ldo, ocol, tokv);
+        for (int t = threadIdx.x; t < Np; t += blockDim.x) {
+            const int tk = attn_token(p, origin, t);
+            const int tt = min(t, p.N - 1);
+            const int ti = (tt * p.ws_inv) >> 16;
+            ci[t] = p.ws ? (unsigned char)ti : 0;
+            cj[t] = p.ws ? (unsigned char)(tt - ti * p.ws) : 0;
+            row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
+        }
+        for (int t = threadIdx.x; t < 256; t += blockDim.x) dbias_s[t] = 0.f;
+        attn_store_rows<D, Np>(Qs, RS, qr);
+        attn_store_rows<D, Np>(Ks, RS, kr);
+        attn_store_rows<D, Np>(Vs, RS, vr);
+        attn_store_rows<D, Np>(dOs, RS, dr);
+        // delta = rowsum(dO * O): the CH chunks of a row sit in adjacent lanes (Np*CH is a multiple of 64: full waves)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)dv[j] * (float)ov[j];
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            float sm = 0.f;
 #pragma unroll
-            for (int o = 1; o < CH; o <<= 1) s += __shfl_xor(s, o, 64);
-            if (dc == 0) row_delta[row] = s;
+            for (int j = 0; j < 8; ++j) sm += (float)dr[i][j] * (float)orr[i][j];
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) sm += __shfl_xor(sm, o, 64);
+            if (idx < Np * CH && (idx % CH) == 0) row_delta[idx / CH] = sm;
         }
     }
     __syncthreads();
@@ -272,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     // ---- phase 1: a wave owns a query tile -> dQ (and dbias) ----
     for (int qt = wave; qt < nt; qt += 4) {
         const int qi = qt * 16 + lr;
-        const int qtok = tok[qi];
+        const int qtok = attn_token(p, origin, qi);
         bf16x8 qf[KS], dof[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -286,23 +363,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float c2 = p.scale * 1.4426950408889634f, lq2 = lse_q * 1.4426950408889634f;
         // score accumulators start as bias / scale (see forward); the next pair of tiles is fetched one iteration ahead
-        auto bias_tiles = [&](int kp, f32x4 (&b)[2]) {
+        // (kept raw: converting at the prefetch point would wait for the load right there)
+        auto bias_tiles = [&](int kp, u32x2 (&b)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int key0 = (kp * 2 + u) * 16 + lg * 4;
-                if (bias_h) b[u] = *reinterpret_cast<const f32x4*>(bias_h + (int64_t)qi * Np + key0);
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[u][r] = (key0 + r < p.N) ? 0.f : -INFINITY;
-                }
+                b[u] = bias_h ? *reinterpret_cast<const u32x2*>(bias_h + (int64_t)qi * Np + key0) : attn_mask_raw(key0, p.N);
             }
         };
-        f32x4 bnext[2];
+        u32x2 bnext[2];
         bias_tiles(0, bnext);
 #pragma unroll 1
         for (int kp = 0; kp < NKT / 2; ++kp) {
             f32x4 dst[2];
-            f32x4 bcur[2] = {bnext[0], bnext[1]};
+            const f32x4 bcur[2] = {attn_bias_cvt(bnext[0]), attn_bias_cvt(bnext[1])};
             if (kp + 1 < NKT / 2) bias_tiles(kp + 1, bnext);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -350,7 +424,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     // ---- phase 2: a wave owns a key tile -> dK, dV ----
     for (int kt = wave; kt < nt; kt += 4) {
         const int ki = kt * 16 + lr;
-        const int ktok = tok[ki];
+        const int ktok = attn_token(p, origin, ki);
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -363,23 +437,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         const float c2 = p.scale * 1.4426950408889634f;
         const int64_t brow = (int64_t)min(ki, p.N - 1) * Np;      // symmetric table: bias[q][k] == bias[k][q]; columns >= N hold -inf
-        auto bias_tiles = [&](int qp, f32x4 (&b)[2]) {
+        auto bias_tiles = [&](int qp, u32x2 (&b)[2]) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int q0 = (qp * 2 + u) * 16 + lg * 4;
-                if (bias_h) b[u] = *reinterpret_cast<const f32x4*>(bias_h + brow + q0);
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b[u][r] = (q0 + r < p.N) ? 0.f : -INFINITY;
-                }
+                b[u] = bias_h ? *reinterpret_cast<const u32x2*>(bias_h + brow + q0) : attn_mask_raw(q0, p.N);
             }
         };
-        f32x4 bnext[2];
+        u32x2 bnext[2];
         bias_tiles(0, bnext);
 #pragma unroll 1
         for (int qp = 0; qp < NKT / 2; ++qp) {
             f32x4 pt[2], dst[2];
-            f32x4 bcur[2] = {bnext[0], bnext[1]};
+            const f32x4 bcur[2] = {attn_bias_cvt(bnext[0]), attn_bias_cvt(bnext[1])};
             if (qp + 1 < NKT / 2) bias_tiles(qp + 1, bnext);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -447,12 +517,13 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
         GG_CHECK(a->window_size <= 16, "%s: window_size > 16 unsupported", who);
     }
     if (a->bias || a->dbias) GG_CHECK(a->window_size > 0 && a->tokens_per_window <= 256, "%s: bias needs a window geometry", who);
-    if (a->bias) GG_CHECK(((uintptr_t)a->bias & 15) == 0, "%s: expanded bias must be 16-byte aligned", who);
+    if (a->bias) GG_CHECK(((uintptr_t)a->bias & 7) == 0, "%s: expanded bias must be 8-byte aligned", who);
     p.qkv = (const bf16*)a->qkv; p.ld = a->ld;
     p.q_off = a->q_off; p.k_off = a->k_off; p.v_off = a->v_off; p.head_stride = a->head_stride;
     p.out = (bf16*)a->out; p.ldo = a->ldo;
-    p.bias = a->bias; p.nbias = a->window_size * a->window_size;
+    p.bias = (const bf16*)a->bias; p.nbias = a->window_size * a->window_size;
     p.ws = a->window_size;
+    p.ws_inv = a->window_size ? (65536 + a->window_size - 1) / a->window_size : 0;
     p.H = a->map_h; p.W = a->map_w;
     p.nWx = a->window_size ? a->map_w / a->window_size : 1;
     p.nWy = a->window_size ? a->map_h / a->window_size : 1;
@@ -462,12 +533,12 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
 }
 static int attn_nkt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 224 ? 14 : 16)); }
 extern "C" int gg_attention_padded_tokens(int tokens_per_window) { return 16 * attn_nkt(tokens_per_window); }
-extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int window_size, float scale, float* full, void* stream) {
+extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int window_size, float scale, void* full, void* stream) {
     GG_CHECK(table && full && num_heads > 0 && window_size > 0 && window_size <= 16 && scale > 0.f, "gg_attention_expand_bias: bad args");
     const int N = window_size * window_size, Np = 16 * attn_nkt(N);
     const int64_t total = (int64_t)num_heads * Np * Np;
     hipLaunchKernelGGL(attn_expand_bias_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(total, 256), 4096)), dim3(256), 0, (hipStream_t)stream,
-                       table, num_heads, window_size, N, Np, 1.0f / scale, full);
+                       table, num_heads, window_size, N, Np, 1.0f / scale, (bf16*)full);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -132,7 +132,7 @@ static int build_model(const GgTinyVitCfg* cfg, Model& m) {
             b.t_ab = add_tensor(m, p + ".attn.attention_biases", {nh, ws * ws}, GG_KIND_PARAM);
             {
                 const int np_ = gg_attention_padded_tokens(ws * ws);
-                b.bias_full = wc_alloc(m, (int64_t)nh * np_ * np_ * 4);
+                b.bias_full = wc_alloc(m, (int64_t)nh * np_ * np_ * 2);
             }
             make_ln(m, b.ln1, p + ".attn.norm", C);
             std::string bn = p + ".attn.qkv.bias";
@@ -493,7 +493,7 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = kAttnScale;
+            at.bias = e.wc + l.bias_full; at.scale = kAttnScale;
             at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             GG_TRY(gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
@@ -660,7 +660,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
             at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
             at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = reinterpret_cast<const float*>(e.wc + l.bias_full); at.scale = kAttnScale;
+            at.bias = e.wc + l.bias_full; at.scale = kAttnScale;
             at.dout = t_a; at.lddo = C; at.dqkv = t_b; at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
             GG_TRY(gg_attention_bwd(&at, e.st));
@@ -890,7 +890,7 @@ extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* 
             GG_TRY(repack_dense(b.fc2, params, m, wc, st));
             GG_TRY(repack_dw(b.local.w, params, m, wc, st));
             GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws, kAttnScale,
-                                            reinterpret_cast<float*>(wc + b.bias_full), stream));
+                                            wc + b.bias_full, stream));
         }
     }
     return 0;

@@ -313,7 +313,7 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
     full = None
     if bias is not None:      # relative-position table [heads][ws*ws] -> expanded [heads][Np][Np]
         Np = L.lib().gg_attention_padded_tokens(tokens_per_window)
-        full = torch.empty((num_heads, Np, Np), dtype=F32, device=qkv.device)
+        full = torch.empty((num_heads, Np, Np), dtype=BF16, device=qkv.device)
     a.scale = head_dim ** -0.5 if scale is None else scale
     if bias is not None:
         L.check(L.lib().gg_attention_expand_bias(_p(bias, F32, "bias"), num_heads, window_size, a.scale, _p(full),

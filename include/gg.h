@@ -131,7 +131,7 @@ typedef struct GgAttnArgs {
     int head_dim;                         /* 32 (TinyViT) or 64 (CLIP) */
     int num_heads, num_windows, tokens_per_window;
     int window_size, map_h, map_w;        /* window_size > 0: ws x ws windows of an (map_h, map_w) NHWC token map; 0: linear */
-    const float* bias;                    /* EXPANDED attention_biases / scale, f32 [num_heads][Np][Np] (gg_attention_expand_bias with
+    const void* bias;                     /* EXPANDED attention_biases / scale, bf16 [num_heads][Np][Np] (gg_attention_expand_bias with
                                              the same `scale`; Np = gg_attention_padded_tokens(tokens_per_window)) or NULL */
     float scale;
     void* out; int64_t ldo;               /* forward: bf16 [tokens, ldo], head h at column h*head_dim */
@@ -142,9 +142,9 @@ typedef struct GgAttnArgs {
                                              backward also reads `out` (the forward result) */
 } GgAttnArgs;
 int gg_attention_padded_tokens(int tokens_per_window);
-/* full[h][q][k] = table[h][|dy|*ws+|dx|] / scale (-inf for padded keys): the kernels start their score accumulators from it,
+/* full[h][q][k] = bf16(table[h][|dy|*ws+|dx|] / scale) (-inf for padded keys): the kernels start their score accumulators from it,
  * softmax(scale * (q.k + bias/scale)) == softmax(scale*q.k + bias)  (timm TinyVit Attention, models/tinyvit.py:135) */
-int gg_attention_expand_bias(const float* table /* [num_heads][ws*ws] */, int num_heads, int window_size, float scale, float* full, void* stream);
+int gg_attention_expand_bias(const float* table /* [num_heads][ws*ws] */, int num_heads, int window_size, float scale, void* full /* bf16 */, void* stream);
 int gg_attention_fwd(const GgAttnArgs* args, void* stream);
 int gg_attention_bwd(const GgAttnArgs* args, void* stream);
 

@@ -27,7 +27,7 @@ for name, res, ws, Cc, nh in [("s1", 28, 7, 192, 6), ("s2", 14, 14, 384, 12), ("
     dqkv = torch.empty_like(qkv); lse = torch.empty(M, nh, device="cuda")
     table = torch.randn(nh, N, device="cuda") * 0.1
     Np = L.lib().gg_attention_padded_tokens(N)
-    full = torch.empty(nh, Np, Np, device="cuda")
+    full = torch.empty(nh, Np, Np, device="cuda").bfloat16()
     L.check(L.lib().gg_attention_expand_bias(table.data_ptr(), nh, ws, 32 ** -0.5, full.data_ptr(), L.stream()))
     dbias = torch.zeros_like(table)
     for with_bias in (True, False):
