@@ -290,10 +290,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     constexpr int RS = D + 8;
     constexpr int KS = D / 32;
     constexpr int DT = D / 16;
-    __shared__ __attribute__((aligned(16))) bf16 Qs[Np * RS];
-    __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
-    __shared__ __attribute__((aligned(16))) bf16 dOs[Np * RS];
+    // Two operand images at a time: phase 1 (dQ) contracts against K and V, phase 2 (dK, dV) against Q and dO, and each
+    // wave's own tile rows come straight from global memory -- half the LDS of keeping all four resident, i.e. 4 instead of
+    // 2 workgroups per CU for 14x14 windows.
+    // Small windows (7x7) are not LDS-limited and keep all four images resident (no reload, no extra barriers).
+    constexpr bool TWO_PHASE = NKT > 4;
+    __shared__ __attribute__((aligned(16))) bf16 buf0[Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 buf1[Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 buf2[TWO_PHASE ? 8 : Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 buf3[TWO_PHASE ? 8 : Np * RS];
+    bf16* const Ks = buf0; bf16* const Vs = buf1;                                       // phase 1
+    bf16* const Qs = TWO_PHASE ? buf0 : buf2; bf16* const dOs = TWO_PHASE ? buf1 : buf3;   // phase 2
     __shared__ __attribute__((aligned(16))) float row_lse[Np], row_delta[Np];
     __shared__ float dbias_s[256];
     __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];   // window coordinates: bias-gradient binning only
@@ -307,13 +314,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 
     const bf16* bias_h = p.bias ? p.bias + (int64_t)h * Np * Np : nullptr;
     {
-        // all operand rows (Q, K, V, dO, O) are requested before anything waits; token ids are computed, not looked up
+        // all operand rows (K, V, dO, O) are requested before anything waits; token ids are computed, not looked up
         constexpr int CH = D / 8;
         constexpr int IT = (Np * CH + 255) / 256;
         int tokv[IT];
         attn_stage_tokens<D, Np>(p, origin, tokv);
-        bf16x8 qr[IT], kr[IT], vr[IT], dr[IT], orr[IT];
-        attn_load_rows<D, Np>(qr, p.qkv, p.ld, qcol, tokv);
+        bf16x8 kr[IT], vr[IT], dr[IT], orr[IT];
         attn_load_rows<D, Np>(kr, p.qkv, p.ld, kcol, tokv);
         attn_load_rows<D, Np>(vr, p.qkv, p.ld, vcol, tokv);
         attn_load_rows<D, Np>(dr, p.dout, p.lddo, ocol, tokv);
@@ -327,10 +333,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
         }
         for (int t = threadIdx.x; t < 256; t += blockDim.x) dbias_s[t] = 0.f;
-        attn_store_rows<D, Np>(Qs, RS, qr);
         attn_store_rows<D, Np>(Ks, RS, kr);
         attn_store_rows<D, Np>(Vs, RS, vr);
-        attn_store_rows<D, Np>(dOs, RS, dr);
+        if constexpr (!TWO_PHASE) {
+            bf16x8 qr[IT];
+            attn_load_rows<D, Np>(qr, p.qkv, p.ld, qcol, tokv);
+            attn_store_rows<D, Np>(dOs, RS, dr);
+            attn_store_rows<D, Np>(Qs, RS, qr);
+        }
         // delta = rowsum(dO * O): the CH chunks of a row sit in adjacent lanes (Np*CH is a multiple of 64: full waves)
 #pragma unroll
         for (int i = 0; i < IT; ++i) {
@@ -353,8 +363,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         bf16x8 qf[KS], dof[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qf[ks] = attn_lds_row_frag(Qs, RS, qi, ks * 32 + lg * 8);
-            dof[ks] = attn_lds_row_frag(dOs, RS, qi, ks * 32 + lg * 8);
+            if constexpr (TWO_PHASE) {
+                qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, qcol + ks * 32 + lg * 8);
+                dof[ks] = attn_row_frag(p.dout, p.lddo, qtok, ocol + ks * 32 + lg * 8);
+            } else {
+                qf[ks] = attn_lds_row_frag(Qs, RS, qi, ks * 32 + lg * 8);
+                dof[ks] = attn_lds_row_frag(dOs, RS, qi, ks * 32 + lg * 8);
+            }
         }
         const int qci = ci[qi], qcj = cj[qi];
         const float lse_q = row_lse[qi], delta_q = row_delta[qi];
@@ -421,6 +436,19 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             }
         }
     }
+    // ---- phase switch: K, V images -> Q, dO images ----
+    if constexpr (TWO_PHASE) {
+        constexpr int IT = (Np * (D / 8) + 255) / 256;
+        int tokv[IT];
+        attn_stage_tokens<D, Np>(p, origin, tokv);
+        bf16x8 qr[IT], dr[IT];
+        attn_load_rows<D, Np>(qr, p.qkv, p.ld, qcol, tokv);
+        attn_load_rows<D, Np>(dr, p.dout, p.lddo, ocol, tokv);
+        __syncthreads();                       // every wave is done reading K / V
+        attn_store_rows<D, Np>(Qs, RS, qr);
+        attn_store_rows<D, Np>(dOs, RS, dr);
+        __syncthreads();
+    }
     // ---- phase 2: a wave owns a key tile -> dK, dV ----
     for (int kt = wave; kt < nt; kt += 4) {
         const int ki = kt * 16 + lr;
@@ -428,8 +456,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         bf16x8 kf[KS], vf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kf[ks] = attn_lds_row_frag(Ks, RS, ki, ks * 32 + lg * 8);
-            vf[ks] = attn_lds_row_frag(Vs, RS, ki, ks * 32 + lg * 8);
+            if constexpr (TWO_PHASE) {
+                kf[ks] = attn_row_frag(p.qkv, p.ld, ktok, kcol + ks * 32 + lg * 8);
+                vf[ks] = attn_row_frag(p.qkv, p.ld, ktok, vcol + ks * 32 + lg * 8);
+            } else {
+                kf[ks] = attn_lds_row_frag(Ks, RS, ki, ks * 32 + lg * 8);
+                vf[ks] = attn_lds_row_frag(Vs, RS, ki, ks * 32 + lg * 8);
+            }
         }
         const bool kvalid = ki < p.N;
         f32x4 dk[DT], dv[DT];
