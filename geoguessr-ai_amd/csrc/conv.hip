@@ -144,8 +144,9 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             o[j] = (bf16)acc[j];
-            s[j] += acc[j];
-            q[j] += acc[j] * acc[j];
+            const float r = (float)o[j];
+            s[j] += r;
+            q[j] += r * r;
         }
         *reinterpret_cast<bf16x8*>(y + p * C + g * 8) = o;
     }
@@ -159,6 +160,108 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
         for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
             float t = 0.f;
             for (int k = 0; k < PP; ++k) t += sred[k * 2 * C + i];
+            colstats[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- column-walking depthwise 3x3 (stride 1)
+// Thread = (8 channels, one output column); the block covers PX adjacent columns x all C channels and walks down the whole
+// image.  Lanes run over channels first, then columns, so every wave-level access is one contiguous run of the NHWC row
+// (16 bytes per lane, full cache lines) -- the LDS-tiled kernel's 128-byte channel chunks at a C*2-byte stride reached only
+// 2.8 TB/s.  A 3x3 input window lives in registers as fp32; each step loads the three columns of one new input row (the
+// left / right neighbours come out of L1: HBM sees every input byte once), rotates the window by renaming (the loop is
+// unrolled by 3) and emits one output row.  Rows / columns outside the image are zero through the buffer range check.
+// colstats: one row per block, [gridDim.x][2][C] = per-channel sum / sum of squares of the stored (bf16-rounded) result.
+typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dw_unpack8(const dw_u32x4 r, f32x2 (&o)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = (f32x2){__uint_as_float(r[q] << 16), __uint_as_float(r[q] & 0xffff0000u)};
+}
+__global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
+                                                             int H, int W, int C, int CG, int PX, int nbx, int flip,
+                                                             float* __restrict__ colstats) {
+    extern __shared__ float dw_red[];          // [PX][2][C]
+    const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
+    const int bx = blockIdx.x % nbx, b = blockIdx.x / nbx;
+    const int xo = bx * PX + px;
+    const int c0 = cg * 8;
+    f32x2 tap[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float* wp = wt + (flip ? 8 - t : t) * C + c0;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(wp), c = *reinterpret_cast<const f32x4*>(wp + 4);
+        tap[t][0] = (f32x2){a[0], a[1]}; tap[t][1] = (f32x2){a[2], a[3]}; tap[t][2] = (f32x2){c[0], c[1]}; tap[t][3] = (f32x2){c[2], c[3]};
+    }
+    const int64_t img = (int64_t)b * H * W * C;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + img), 0, H * W * C * 2, 0x00020000);
+    // byte offsets of the three columns inside a row (out of range -> beyond the descriptor -> zeros)
+    unsigned colo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ix = xo + k - 1;
+        colo[k] = (ix >= 0 && ix < W && xo < W) ? (unsigned)(ix * C + c0) * 2u : 0xFFFFFFF0u;
+    }
+    const unsigned rowb = (unsigned)W * C * 2u;
+    auto load_row = [&](int iy, dw_u32x4 (&raw)[3]) {
+        const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((rok && colo[k] != 0xFFFFFFF0u) ? colo[k] + (unsigned)iy * rowb : 0xFFFFFFF0u), 0, 0);
+    };
+    f32x2 win[3][3][4];           // [row slot][column][channel pair]
+    dw_u32x4 raw[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) win[0][k][q] = (f32x2)(0.f);          // row -1
+    load_row(0, raw);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dw_unpack8(raw[k], win[1][k]);
+    load_row(1, raw);
+    f32x2 s2[4], q2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s2[q] = q2[q] = (f32x2)(0.f);
+    bf16* yb = y + img + (int64_t)xo * C + c0;
+    const bool store_ok = xo < W;
+    // one output row: slot RC receives input row yy+1 (already in flight), rows yy-1 / yy sit in slots RA / RB
+#define GG_DW_STEP(RA, RB, RC, yy)                                                                                         \
+    {                                                                                                                      \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) dw_unpack8(raw[k], win[RC][k]);                                      \
+        load_row((yy) + 2, raw);                                                                                           \
+        f32x2 acc[4];                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+            f32x2 a = win[RA][0][q] * tap[0][q];                                                                           \
+            a = win[RA][1][q] * tap[1][q] + a; a = win[RA][2][q] * tap[2][q] + a;                                          \
+            a = win[RB][0][q] * tap[3][q] + a; a = win[RB][1][q] * tap[4][q] + a; a = win[RB][2][q] * tap[5][q] + a;       \
+            a = win[RC][0][q] * tap[6][q] + a; a = win[RC][1][q] * tap[7][q] + a; a = win[RC][2][q] * tap[8][q] + a;       \
+            acc[q] = a;                                                                                                    \
+        }                                                                                                                  \
+        bf16x8 o;                                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+            o[2 * q] = (bf16)acc[q].x; o[2 * q + 1] = (bf16)acc[q].y;                                                      \
+            const f32x2 r = {(float)o[2 * q], (float)o[2 * q + 1]};                                                        \
+            s2[q] += r; q2[q] += r * r;                                                                                    \
+        }                                                                                                                  \
+        if (store_ok) *reinterpret_cast<bf16x8*>(yb + (int64_t)(yy) * W * C) = o;                                          \
+    }
+    for (int y0 = 0; y0 < H; y0 += 3) {
+        GG_DW_STEP(0, 1, 2, y0)
+        if (y0 + 1 < H) GG_DW_STEP(1, 2, 0, y0 + 1)
+        if (y0 + 2 < H) GG_DW_STEP(2, 0, 1, y0 + 2)
+    }
+#undef GG_DW_STEP
+    if (colstats) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // columns beyond the image produced zeros (all inputs out of range): they add nothing
+            dw_red[(px * 2 + 0) * C + c0 + 2 * q] = s2[q].x; dw_red[(px * 2 + 0) * C + c0 + 2 * q + 1] = s2[q].y;
+            dw_red[(px * 2 + 1) * C + c0 + 2 * q] = q2[q].x; dw_red[(px * 2 + 1) * C + c0 + 2 * q + 1] = q2[q].y;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < PX; ++k) t += dw_red[k * 2 * C + i];
             colstats[(int64_t)blockIdx.x * 2 * C + i] = t;
         }
     }
@@ -309,8 +412,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
 #pragma unroll
                     for (int j = 0; j < Q; ++j) {
                         o[j] = (bf16)acc[j];
-                        s[j] += acc[j];
-                        q[j] += acc[j] * acc[j];
+                        const float r = (float)o[j];       // statistics of the stored value
+                        s[j] += r;
+                        q[j] += r * r;
                     }
                 }
                 *reinterpret_cast<bf16x4*>(y + oidx) = o;
@@ -480,7 +584,25 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
     g.nblocks = (int)gg_cdiv(npix, ppb);
     return g;
 }
-extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C) { return B * (int)gg_cdiv(Ho, 8); }
+// stride-1 convs take the column-walking kernel: PX columns x C/8 channel groups per block (<= 256 threads), whole image height
+static int dw_walk_px(int C) { return std::max(1, 256 / (C / 8)); }
+static bool dw_walk_ok(int C, int stride) { return stride == 1 && (C / 8) <= 256 && getenv("GG_DW_TILED") == nullptr; }
+extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride) {
+    if (dw_walk_ok(C, stride)) return B * (int)gg_cdiv(Wo, dw_walk_px(C));
+    return B * (int)gg_cdiv(Ho, 8);
+}
+extern "C" int gg_dwconv_tiled_stat_rows(int B, int Ho) { return B * (int)gg_cdiv(Ho, 8); }
+static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int flip, float* colstats, void* stream) {
+    const int CG = C / 8, PX = dw_walk_px(C), nbx = (int)gg_cdiv(W, PX);
+    GG_CHECK((int64_t)H * W * C * 2 < 0x7FFFFFF0LL, "dwconv: image too large for 32-bit offsets");
+    GG_CHECK(((uintptr_t)wt & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "dwconv: operands must be 16-byte aligned");
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 4.0 * B * C * (double)H * W, stream);
+    const size_t lds = colstats ? (size_t)PX * 2 * C * sizeof(float) : 0;
+    hipLaunchKernelGGL(dwconv3x3_walk_kernel, dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
+                       H, W, C, CG, PX, nbx, flip, colstats);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 
 struct DwFuse {
     const void* in2 = nullptr; const float* in_coef = nullptr;
@@ -512,6 +634,7 @@ static int dwconv_tiled_launch(const void* x, const float* wt, void* y, int B, i
 extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats,
                                 void* stream) {
     GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
+    if (dw_walk_ok(C, stride)) return dwconv_walk_launch(x, wt, y, B, H, W, C, 0, colstats, stream);
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, nullptr, nullptr, nullptr, 0, colstats, stream);
 }
 // fused producer: x is the PRE-BatchNorm output of the previous ConvNorm; act(BN(x)) is formed while staging
@@ -538,6 +661,7 @@ extern "C" int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, 
 extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");
     GG_CHECK((int64_t)B * H * W * (C / 8) < ((int64_t)1 << 32), "gg_dwconv3x3_bwd_data: tensor too large for 32-bit indexing");
+    if (dw_walk_ok(C, stride)) return dwconv_walk_launch(dy, wt, dx, B, H, W, C, 1, nullptr, stream);
     if (stride == 1)     // data gradient of a stride-1 depthwise conv == the same conv with flipped taps
         return dwconv_tiled_launch(dy, wt, dx, B, H, W, C, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, stream);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;

@@ -200,7 +200,8 @@ struct Layout {
 };
 
 static int64_t bn_part_floats(int64_t M, int C, int B, int Ho, int Wo, bool dw) {
-    const int rows = dw ? gg_dwconv_stat_rows(B, Ho, Wo, C) : gg_gemm_colstats_rows((int)M);
+    const int rows = dw ? std::max(std::max(gg_dwconv_stat_rows(B, Ho, Wo, C, 1), gg_dwconv_stat_rows(B, Ho, Wo, C, 2)), gg_dwconv_tiled_stat_rows(B, Ho))
+                        : gg_gemm_colstats_rows((int)M);
     return (int64_t)gg_stat_rows_capacity(rows) * 2 * C;
 }
 
@@ -407,7 +408,7 @@ static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const bf1
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     GG_TRY(gg_dwconv3x3_fwd(x, e.Taps(c.w), e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
-    return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+    return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C, stride), (int64_t)B * Ho * Wo);
 }
 // depthwise ConvNorm whose input is act(BN(prev.y)) of the preceding ConvNorm, formed on the fly while staging
 static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, const BNP& prev_bn, const Act& prev, int in_act, int B, int H,
@@ -416,7 +417,7 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
                                   c.w.C, stride, part, e.st));
-    return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+    return bn_stats(e, c.bn, a, gg_dwconv_tiled_stat_rows(B, Ho), (int64_t)B * Ho * Wo);
 }
 static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
                     const float* rowscale = nullptr, int rps = 0) {
@@ -727,7 +728,7 @@ static int backward_impl(Exec& e, const float* d_out) {
                 GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                    e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
                 const bool tr1 = e.tr(l.c1.bn.t_g);
-                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_tiled_stat_rows(B, H0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                           bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
                 dz1 = t_c;
             } else {
@@ -755,7 +756,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
             const bool tr1 = e.tr(l.c1.bn.t_g);
-            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_tiled_stat_rows(B, H0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                       bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
             GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                              // dy1 -> t_a
         }

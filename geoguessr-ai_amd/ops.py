@@ -148,7 +148,7 @@ def dwconv3x3_fwd(x, taps, stride=1, colstats=False):
     y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=x.device)
     stats = None
     if colstats:
-        rows = L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc)
+        rows = L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, stride)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=x.device)[:rows]
     L.check(L.lib().gg_dwconv3x3_fwd(_p(x, BF16), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
             "gg_dwconv3x3_fwd")

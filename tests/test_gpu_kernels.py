@@ -197,8 +197,11 @@ def test_dwconv(ops, C, stride, H):
     y, stats = ops.dwconv3x3_fwd(dev(x, BF), dev(taps), stride=stride, colstats=True)
     close(y.permute(0, 3, 1, 2), yref, what="dwconv fwd")
     s = stats.cpu().sum(0)
-    close(s[0], yref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="dw colsum")
-    close(s[1], (yref * yref).sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="dw colsumsq")
+    # BatchNorm partials are taken over the STORED (bf16-rounded) result, as the reference's autocast BatchNorm sees it
+    yq = y.float().cpu()
+    close(s[0], yq.sum((0, 1, 2)), rtol=1e-3, atol=1e-2, what="dw colsum")
+    close(s[1], (yq * yq).sum((0, 1, 2)), rtol=1e-3, atol=1e-2, what="dw colsumsq")
+    close(s[0], yref.sum((0, 2, 3)), rtol=5e-3, atol=0.3, what="dw colsum vs fp32 reference")
     Ho = yref.shape[-1]
     dy = rnd(B, Ho, Ho, C, seed=22)
     yref.backward(dy.permute(0, 3, 1, 2))
