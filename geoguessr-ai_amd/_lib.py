@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgg.so")
+LIB_PATH = os.environ.get("GG_LIB") or os.path.join(_HERE, "lib", "libgg.so")   # GG_LIB: dev override (A/B builds)
 _lib = None
 
 

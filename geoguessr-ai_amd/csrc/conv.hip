@@ -4,6 +4,7 @@
 // convs are computed here directly with fp32 taps.
 #include "common.h"
 #include "../../include/gg.h"
+#include <string.h>
 
 // ---------------------------------------------------------------- im2col (dense 3x3, pad 1)
 // x f32 NCHW (B,3,H,W) -> col bf16 [B*Ho*Wo, 32]; k = (ky*3+kx)*3 + ci for k < 27, zeros above.
@@ -174,81 +175,209 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
 // unrolled by 3) and emits one output row.  Rows / columns outside the image are zero through the buffer range check.
 // colstats: one row per block, [gridDim.x][2][C] = per-channel sum / sum of squares of the stored (bf16-rounded) result.
 typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
+#define DW_COL_OOB 0x80000000u
+#define DW_ROW_OOB 0x40000000u
 __device__ __forceinline__ void dw_unpack8(const dw_u32x4 r, f32x2 (&o)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = (f32x2){__uint_as_float(r[q] << 16), __uint_as_float(r[q] & 0xffff0000u)};
 }
-__global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
+// Backward fusions (stride-1 data gradient, both optional, compile-time):
+//   IN2 : the conv input is  coef0*x + coef1*in2 + coef2  = BatchNorm backward's "apply" of the ConvNorm BEHIND this conv, formed
+//         from (dz, y) while loading -- the separate apply pass and the dy tensor disappear;
+//   EPI : the stored value is  acc * act'(BN(ep_y))  = gradient w.r.t. the pre-activation of the ConvNorm IN FRONT, and colstats
+//         becomes (sum dz, sum dz*xhat): that ConvNorm's "reduce" pass disappears.
+// The per-channel coefficient tables sit in LDS (they are touched once per row; registers go to the window and the taps).
+template <bool PACKED> struct DwWin;
+template <> struct DwWin<false> {
+    struct T { f32x2 v[4]; };
+    static __device__ __forceinline__ void zero(T& t) { for (int q = 0; q < 4; ++q) t.v[q] = (f32x2)(0.f); }
+    static __device__ __forceinline__ void get(const T& t, f32x2 (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = t.v[q]; }
+    static __device__ __forceinline__ f32x2 at(const T& t, int q) { return t.v[q]; }
+};
+template <> struct DwWin<true> {
+    struct T { unsigned r[4]; };
+    static __device__ __forceinline__ void zero(T& t) { for (int q = 0; q < 4; ++q) t.r[q] = 0u; }
+    static __device__ __forceinline__ f32x2 at(const T& t, int q) { return (f32x2){__uint_as_float(t.r[q] << 16), __uint_as_float(t.r[q] & 0xffff0000u)}; }
+    static __device__ __forceinline__ void get(const T& t, f32x2 (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = at(t, q); }
+};
+struct DwWalkFuse {
+    const bf16* in2; const float* in_coef;                                         // IN2
+    const bf16* ep_y; const float* ep_stat; const float* ep_gamma; const float* ep_beta; int ep_act;   // EPI
+};
+template <bool IN2, bool EPI>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
                                                              int H, int W, int C, int CG, int PX, int nbx, int flip,
-                                                             float* __restrict__ colstats) {
-    extern __shared__ float dw_red[];          // [PX][2][C]
+                                                             float* __restrict__ colstats, DwWalkFuse f) {
+    extern __shared__ float dw_red[];          // [PX][2][C] statistics scratch; then (fusions) 7 coefficient rows [C]
+    float* ctab = dw_red + PX * 2 * C;         // [0..2] in coef a,b,c   [3] ep scale  [4] ep shift  [5] ep rstd  [6] ep -mean*rstd  [7..15] taps
+    constexpr bool TAPS_LDS = IN2 || EPI;      // the fused variants have no registers left for 72 tap values
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
     const int bx = blockIdx.x % nbx, b = blockIdx.x / nbx;
     const int xo = bx * PX + px;
     const int c0 = cg * 8;
-    f32x2 tap[9][4];
+    if (IN2 || EPI) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (IN2) { ctab[c] = f.in_coef[c]; ctab[C + c] = f.in_coef[C + c]; ctab[2 * C + c] = f.in_coef[2 * C + c]; }
+            if (EPI) {
+                const float mu = f.ep_stat[c], rstd = f.ep_stat[C + c], sc = rstd * f.ep_gamma[c];
+                ctab[3 * C + c] = sc; ctab[4 * C + c] = f.ep_beta[c] - mu * sc; ctab[5 * C + c] = rstd; ctab[6 * C + c] = -mu * rstd;
+            }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const float* wp = wt + (flip ? 8 - t : t) * C + c0;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(wp), c = *reinterpret_cast<const f32x4*>(wp + 4);
-        tap[t][0] = (f32x2){a[0], a[1]}; tap[t][1] = (f32x2){a[2], a[3]}; tap[t][2] = (f32x2){c[0], c[1]}; tap[t][3] = (f32x2){c[2], c[3]};
+            for (int t = 0; t < 9; ++t) ctab[(7 + t) * C + c] = wt[(flip ? 8 - t : t) * C + c];
+        }
+        __syncthreads();
+    }
+    // `cofs` is laundered through an empty asm once per row step: the table reads are loop-invariant, and hoisting them would
+    // put all 16 rows x 8 channels back into registers
+    int cofs = c0;
+    auto ctab2 = [&](int row, f32x2 (&o)[4]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ctab + row * C + cofs), c = *reinterpret_cast<const f32x4*>(ctab + row * C + cofs + 4);
+        o[0] = (f32x2){a[0], a[1]}; o[1] = (f32x2){a[2], a[3]}; o[2] = (f32x2){c[0], c[1]}; o[3] = (f32x2){c[2], c[3]};
+    };
+    f32x2 tap[TAPS_LDS ? 1 : 9][4];
+    if (!TAPS_LDS) {
+#pragma unroll
+        for (int t = 0; t < (TAPS_LDS ? 1 : 9); ++t) {
+            const float* wp = wt + (flip ? 8 - t : t) * C + c0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(wp), c = *reinterpret_cast<const f32x4*>(wp + 4);
+            tap[t][0] = (f32x2){a[0], a[1]}; tap[t][1] = (f32x2){a[2], a[3]}; tap[t][2] = (f32x2){c[0], c[1]}; tap[t][3] = (f32x2){c[2], c[3]};
+        }
     }
     const int64_t img = (int64_t)b * H * W * C;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(x + img), 0, H * W * C * 2, 0x00020000);
+    // (the image bases are block-uniform; saying so keeps the descriptors in SGPRs -- otherwise every buffer load is wrapped in a
+    // waterfall loop over "divergent" descriptors)
+    auto uniform_ptr = [](const bf16* ptr) {
+        const unsigned long long a = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    const int img_bytes = __builtin_amdgcn_readfirstlane(H * W * C * 2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + img), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((IN2 ? f.in2 : x) + img), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((EPI ? f.ep_y : x) + img), 0, img_bytes, 0x00020000);
     // byte offsets of the three columns inside a row (out of range -> beyond the descriptor -> zeros)
     unsigned colo[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int ix = xo + k - 1;
-        colo[k] = (ix >= 0 && ix < W && xo < W) ? (unsigned)(ix * C + c0) * 2u : 0xFFFFFFF0u;
+        colo[k] = (ix >= 0 && ix < W && xo < W) ? (unsigned)(ix * C + c0) * 2u : DW_COL_OOB;
     }
     const unsigned rowb = (unsigned)W * C * 2u;
-    auto load_row = [&](int iy, dw_u32x4 (&raw)[3]) {
-        const bool rok = iy >= 0 && iy < H;
+    // branch-free addressing: an invalid column carries bit 31, an invalid row adds bit 30; either pushes the offset past the
+    // (< 1 GiB) descriptor, and no combination wraps back into range.  (Branches around the loads made the compiler wait for
+    // ALL outstanding loads at the join, which serialised the row prefetch.)
+    auto load_row = [&](int iy, dw_u32x4 (&raw)[3], dw_u32x4 (&raw2)[3]) {
+        const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((rok && colo[k] != 0xFFFFFFF0u) ? colo[k] + (unsigned)iy * rowb : 0xFFFFFFF0u), 0, 0);
+        for (int k = 0; k < 3; ++k) {
+            const int vo = (int)(colo[k] + ro);
+            raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
+            if (IN2) raw2[k] = __builtin_amdgcn_raw_buffer_load_b128(rs2, vo, 0, 0);
+        }
     };
-    f32x2 win[3][3][4];           // [row slot][column][channel pair]
-    dw_u32x4 raw[3];
+    // raw row -> fp32 window slot; IN2: the BatchNorm-backward apply on the way (positions outside the image stay exactly 0)
+    auto fill = [&](int iy, const dw_u32x4 (&raw)[3], const dw_u32x4 (&raw2)[3], typename DwWin<IN2>::T (&slot)[3]) {
+        if constexpr (!IN2) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+            for (int k = 0; k < 3; ++k) dw_unpack8(raw[k], slot[k].v);
+        } else {
+            f32x2 ca[4], cb[4], cc[4];
+            ctab2(0, ca); ctab2(1, cb); ctab2(2, cc);
+            const bool rok = iy >= 0 && iy < H;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) win[0][k][q] = (f32x2)(0.f);          // row -1
-    load_row(0, raw);
+            for (int k = 0; k < 3; ++k) {
+                f32x2 d[4], v[4];
+                dw_unpack8(raw[k], d); dw_unpack8(raw2[k], v);
+                const bool ok = rok && colo[k] != DW_COL_OOB;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) dw_unpack8(raw[k], win[1][k]);
-    load_row(1, raw);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 r = ca[q] * d[q] + (cb[q] * v[q] + cc[q]);
+                    const bf16 lo = (bf16)r.x, hi = (bf16)r.y;
+                    const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                    slot[k].r[q] = ok ? pk : 0u;
+                }
+            }
+        }
+    };
+    // window [row slot][column]: fp32 channel pairs, or (IN2, where registers are short) the bf16 values the unfused path would
+    // have stored in dy, unpacked at use
+    typename DwWin<IN2>::T win[3][3];
+    dw_u32x4 raw[3], raw2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) DwWin<IN2>::zero(win[0][k]);          // row -1
+    load_row(0, raw, raw2);
+    fill(0, raw, raw2, win[1]);
+    load_row(1, raw, raw2);
     f32x2 s2[4], q2[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) s2[q] = q2[q] = (f32x2)(0.f);
     bf16* yb = y + img + (int64_t)xo * C + c0;
     const bool store_ok = xo < W;
+    const unsigned ctr = store_ok ? (unsigned)(xo * C + c0) * 2u : DW_COL_OOB;
+    const bool ep_gelu = f.ep_act == GG_ACT_GELU;
+    dw_u32x4 eraw;
+    if (EPI) eraw = __builtin_amdgcn_raw_buffer_load_b128(rse, (int)ctr, 0, 0);
     // one output row: slot RC receives input row yy+1 (already in flight), rows yy-1 / yy sit in slots RA / RB
 #define GG_DW_STEP(RA, RB, RC, yy)                                                                                         \
     {                                                                                                                      \
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) dw_unpack8(raw[k], win[RC][k]);                                      \
-        load_row((yy) + 2, raw);                                                                                           \
+        if (IN2 || EPI) asm volatile("" : "+v"(cofs));                                                                     \
+        fill((yy) + 1, raw, raw2, win[RC]);                                                                                \
+        load_row((yy) + 2, raw, raw2);                                                                                     \
+        if (IN2 || EPI) __builtin_amdgcn_sched_barrier(0);                                                                 \
+        const float live = (yy) < H ? 1.f : 0.f;                                                                           \
         f32x2 acc[4];                                                                                                      \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
-            f32x2 a = win[RA][0][q] * tap[0][q];                                                                           \
-            a = win[RA][1][q] * tap[1][q] + a; a = win[RA][2][q] * tap[2][q] + a;                                          \
-            a = win[RB][0][q] * tap[3][q] + a; a = win[RB][1][q] * tap[4][q] + a; a = win[RB][2][q] * tap[5][q] + a;       \
-            a = win[RC][0][q] * tap[6][q] + a; a = win[RC][1][q] * tap[7][q] + a; a = win[RC][2][q] * tap[8][q] + a;       \
-            acc[q] = a;                                                                                                    \
+        if (TAPS_LDS) {                                                                                                    \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[q] = (f32x2)(0.f);                                           \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                \
+                f32x2 tp[4];                                                                                               \
+                ctab2(7 + t, tp);                                                                                          \
+                const int rsl = t < 3 ? RA : (t < 6 ? RB : RC);                                                            \
+                f32x2 wv[4];                                                                                               \
+                DwWin<IN2>::get(win[rsl][t % 3], wv);                                                                      \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[q] = wv[q] * tp[q] + acc[q];               \
+                if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);   /* <= 3 taps' worth of LDS reads in flight */          \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+                f32x2 a = DwWin<IN2>::at(win[RA][0], q) * tap[0][q];                                                       \
+                a = DwWin<IN2>::at(win[RA][1], q) * tap[1][q] + a; a = DwWin<IN2>::at(win[RA][2], q) * tap[2][q] + a;      \
+                a = DwWin<IN2>::at(win[RB][0], q) * tap[3][q] + a; a = DwWin<IN2>::at(win[RB][1], q) * tap[4][q] + a;      \
+                a = DwWin<IN2>::at(win[RB][2], q) * tap[5][q] + a;                                                         \
+                a = DwWin<IN2>::at(win[RC][0], q) * tap[6][q] + a; a = DwWin<IN2>::at(win[RC][1], q) * tap[7][q] + a;      \
+                a = DwWin<IN2>::at(win[RC][2], q) * tap[8][q] + a;                                                         \
+                acc[q] = a;                                                                                                \
+            }                                                                                                              \
         }                                                                                                                  \
         bf16x8 o;                                                                                                          \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
-            o[2 * q] = (bf16)acc[q].x; o[2 * q + 1] = (bf16)acc[q].y;                                                      \
-            const f32x2 r = {(float)o[2 * q], (float)o[2 * q + 1]};                                                        \
-            s2[q] += r; q2[q] += r * r;                                                                                    \
+        if (EPI) {                                                                                                         \
+            f32x2 yv[4];                                                                                                   \
+            dw_unpack8(eraw, yv);                                                                                          \
+            eraw = __builtin_amdgcn_raw_buffer_load_b128(rse, (int)(ctr + ((yy) + 1 < H ? (unsigned)((yy) + 1) * rowb : DW_ROW_OOB)), 0, 0); \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {       /* one channel pair at a time: short live ranges */       \
+                const f32x2 esc = *reinterpret_cast<const f32x2*>(ctab + 3 * C + cofs + 2 * q);                            \
+                const f32x2 esh = *reinterpret_cast<const f32x2*>(ctab + 4 * C + cofs + 2 * q);                            \
+                const f32x2 dz = acc[q] * gg_act_grad_v2(yv[q] * esc + esh, ep_gelu);                                      \
+                o[2 * q] = (bf16)dz.x; o[2 * q + 1] = (bf16)dz.y;                                                          \
+                const f32x2 ers = *reinterpret_cast<const f32x2*>(ctab + 5 * C + cofs + 2 * q);                            \
+                const f32x2 emr = *reinterpret_cast<const f32x2*>(ctab + 6 * C + cofs + 2 * q);                            \
+                const f32x2 r = (f32x2){(float)o[2 * q], (float)o[2 * q + 1]} * live;                                      \
+                s2[q] += r; q2[q] += r * (yv[q] * ers + emr);                                                              \
+                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+                o[2 * q] = (bf16)acc[q].x; o[2 * q + 1] = (bf16)acc[q].y;                                                  \
+                const f32x2 r = (f32x2){(float)o[2 * q], (float)o[2 * q + 1]} * live;                                      \
+                s2[q] += r; q2[q] += r * r;                                                                                \
+            }                                                                                                              \
         }                                                                                                                  \
-        if (store_ok) *reinterpret_cast<bf16x8*>(yb + (int64_t)(yy) * W * C) = o;                                          \
+        if (store_ok && (yy) < H) *reinterpret_cast<bf16x8*>(yb + (int64_t)(yy) * W * C) = o;                              \
     }
+    // (the tail of the last trip may run 1-2 rows past the image: its loads are out of range, its store and statistics masked)
     for (int y0 = 0; y0 < H; y0 += 3) {
         GG_DW_STEP(0, 1, 2, y0)
-        if (y0 + 1 < H) GG_DW_STEP(1, 2, 0, y0 + 1)
-        if (y0 + 2 < H) GG_DW_STEP(2, 0, 1, y0 + 2)
+        GG_DW_STEP(1, 2, 0, y0 + 1)
+        GG_DW_STEP(2, 0, 1, y0 + 2)
     }
 #undef GG_DW_STEP
     if (colstats) {
@@ -592,14 +721,23 @@ extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride) {
     return B * (int)gg_cdiv(Ho, 8);
 }
 extern "C" int gg_dwconv_tiled_stat_rows(int B, int Ho) { return B * (int)gg_cdiv(Ho, 8); }
-static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int flip, float* colstats, void* stream) {
+static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int flip, float* colstats, void* stream,
+                              const DwWalkFuse* fuse = nullptr) {
     const int CG = C / 8, PX = dw_walk_px(C), nbx = (int)gg_cdiv(W, PX);
-    GG_CHECK((int64_t)H * W * C * 2 < 0x7FFFFFF0LL, "dwconv: image too large for 32-bit offsets");
+    GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");
     GG_CHECK(((uintptr_t)wt & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "dwconv: operands must be 16-byte aligned");
-    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 4.0 * B * C * (double)H * W, stream);
-    const size_t lds = colstats ? (size_t)PX * 2 * C * sizeof(float) : 0;
-    hipLaunchKernelGGL(dwconv3x3_walk_kernel, dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y,
-                       H, W, C, CG, PX, nbx, flip, colstats);
+    DwWalkFuse f;
+    memset(&f, 0, sizeof(f));
+    if (fuse) f = *fuse;
+    const bool in2 = f.in_coef != nullptr, epi = f.ep_y != nullptr;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 2.0 * B * C * (double)H * W * (2 + in2 + epi), stream);
+    const size_t lds = ((size_t)PX * 2 * C + ((in2 || epi) ? 16 * (size_t)C : 0)) * sizeof(float);
+    GG_CHECK(lds <= 64 * 1024, "dwconv: C=%d needs %zu bytes of LDS", C, lds);
+    const dim3 grid((unsigned)(B * nbx)), block(CG * PX);
+#define GG_DW_WALK(I_, E_) hipLaunchKernelGGL((dwconv3x3_walk_kernel<I_, E_>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y, \
+                                              H, W, C, CG, PX, nbx, flip, colstats, f)
+    if (in2 && epi) GG_DW_WALK(true, true); else if (in2) GG_DW_WALK(true, false); else if (epi) GG_DW_WALK(false, true); else GG_DW_WALK(false, false);
+#undef GG_DW_WALK
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -653,6 +791,12 @@ extern "C" int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, 
     GG_CHECK(dz_in && wt && out && B > 0 && (C & 7) == 0, "gg_dwconv3x3_bwd_data_fused: bad args");
     GG_CHECK(!in_coef || y_in, "gg_dwconv3x3_bwd_data_fused: in_coef needs y_in");
     GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_part), "gg_dwconv3x3_bwd_data_fused: epilogue needs stat/gamma/beta/partials");
+    if (dw_walk_ok(C, 1)) {
+        DwWalkFuse wf;
+        wf.in2 = in_coef ? (const bf16*)y_in : nullptr; wf.in_coef = in_coef;
+        wf.ep_y = (const bf16*)ep_y; wf.ep_stat = ep_stat; wf.ep_gamma = ep_gamma; wf.ep_beta = ep_beta; wf.ep_act = ep_act;
+        return dwconv_walk_launch(dz_in, wt, out, B, H, W, C, 1, ep_y ? ep_part : nullptr, stream, &wf);
+    }
     DwFuse f;
     f.in2 = in_coef ? y_in : nullptr; f.in_coef = in_coef;
     f.ep_y = ep_y; f.ep_stat = ep_stat; f.ep_gamma = ep_gamma; f.ep_beta = ep_beta; f.ep_act = ep_act;

@@ -338,9 +338,11 @@ struct Exec {
     // Fusing BatchNorm+GELU of the producer into the depthwise conv's staging removes one [M,C] write+read but makes the
     // conv VALU-bound (erf on tile + halo): measured +6.6 ms conv vs -3.1 ms elementwise at 1024 images -> off by default.
     bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
-    // Folding BatchNorm-backward apply/reduce into the depthwise data gradient (frozen taps) trades 4 [M,C] passes for a
-    // slower conv kernel; measured a net loss so far (-6.6 ms elementwise, +13 ms conv) -> off by default.
-    bool fuse_bnbwd = getenv("GG_FUSE_BNBWD") != nullptr;
+    // Frozen depthwise taps: BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) is formed while the data gradient loads
+    // its input (GG_NO_FUSE_BNBWD=1 restores the separate pass).  The matching output-side fusion (act'(BN) + reduce of the
+    // ConvNorm in front) does not fit the register file at 2 waves/SIMD yet and spills -> opt-in (GG_FUSE_BNBWD_EPI=1).
+    bool fuse_bnbwd = getenv("GG_NO_FUSE_BNBWD") == nullptr;
+    bool fuse_bnbwd_epi = getenv("GG_FUSE_BNBWD_EPI") != nullptr;
     // Frozen ConvNorm chains: BatchNorm backward's reduce rides in the epilogue of the conv dgrad that produces its input
     // gradient, and its apply step is folded into the weights of the 1x1 dgrad that consumes its output gradient.
     bool fuse_bngemm = getenv("GG_NO_BNGEMM") == nullptr;
@@ -724,16 +726,21 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));                   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
             bf16* dz1;
-            if (e.fuse_bnbwd) {
+            if (e.fuse_bnbwd && e.fuse_bnbwd_epi) {
                 GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                    e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
                 const bool tr1 = e.tr(l.c1.bn.t_g);
-                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_tiled_stat_rows(B, H0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                           bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
                 dz1 = t_c;
             } else {
-                GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));   // dy2 -> t_a
-                GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));             // da1 -> t_c
+                if (e.fuse_bnbwd) {      // dy2 is formed from (dz2, y2) inside the conv; da1 -> t_c
+                    GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, nullptr,
+                                                       nullptr, nullptr, nullptr, 0, nullptr, e.st));
+                } else {
+                    GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));   // dy2 -> t_a
+                    GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));             // da1 -> t_c
+                }
                 GG_TRY(bn_bwd_reduce_fin(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d));                        // dz1 -> t_d
                 dz1 = t_d;
             }
@@ -741,7 +748,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             continue;
         }
         GG_TRY(gemm(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_c, mid, M0, mid, d[0]));                     // da2 -> t_c [M0, mid]
-        if (e.tr(l.c2.w.t_w) || !e.fuse_bnbwd) {
+        if (e.tr(l.c2.w.t_w) || !e.fuse_bnbwd || !e.fuse_bnbwd_epi) {
             GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy2 -> t_a
             if (e.tr(l.c2.w.t_w)) {
                 if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));             // act1 was fused away in forward
@@ -756,7 +763,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
             const bool tr1 = e.tr(l.c1.bn.t_g);
-            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_tiled_stat_rows(B, H0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                       bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
             GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                              // dy1 -> t_a
         }
