@@ -539,6 +539,37 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
     }
     part[(int64_t)blockIdx.y * C + c] = s;
 }
+// 16-byte version: thread = (8-column group of 32, row lane of 8); a block covers 256 columns x rows_per_block rows
+__global__ __launch_bounds__(256) void colsum_partial_v8_kernel(const bf16* __restrict__ x, int64_t ld, int M, int C,
+                                                                const float* rowscale, int rows_per_scale,
+                                                                float* __restrict__ part, int rows_per_block) {
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, pp = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cg * 8;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    if (c0 < C) {
+#pragma unroll 4
+        for (int r = r0 + pp; r < r1; r += 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (int64_t)r * ld + c0);
+            const float rs = rowscale ? rowscale[r / rows_per_scale] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = fmaf((float)v[j], rs, s[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[pp][cg * 8 + j] = s[j];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        part[(int64_t)blockIdx.y * C + c] = t;
+    }
+}
 __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -695,8 +726,12 @@ extern "C" int gg_colsum_bf16(const void* x, int64_t ld, int M, int C, const flo
     const int rpb = 512;
     const int nparts = (int)gg_cdiv(M, rpb);
     GG_CHECK(nparts <= 65535, "gg_colsum_bf16: M too large");
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
+    if ((C & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial_v8_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
     const float* rows; int nrows;
     gg_reduce_rows(scratch, nparts, C, (hipStream_t)stream, &rows, &nrows);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)gg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, out, accumulate);

@@ -264,6 +264,158 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict
     }
 }
 
+// ---- bf16 LayerNorm, 16 lanes per row ----------------------------------------------------------------------------
+// A 64-lane wave per row leaves 25-60 % of the lanes idle at C = 192 / 384 (24 / 48 16-byte chunks).  Here a row belongs
+// to a 16-lane group (4 rows per wave, 16 per block); lane l of the group owns chunks l, l+16, ... (NCH of them), so a
+// group reads 256 contiguous bytes per step, reductions are 4 shuffles, and gamma / beta stay in registers.
+__device__ __forceinline__ float gg_group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int64_t M, int C, float eps,
+                                                                bf16* __restrict__ out, float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out) {
+    const int l16 = threadIdx.x & 15;
+    const int nch = C >> 3;
+    float g[NCH][8], b[NCH][8];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = min(l16 + 16 * k, nch - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { g[k][j] = gamma[ch * 8 + j]; b[k][j] = beta[ch * 8 + j]; }
+    }
+    const float invC = 1.f / (float)C;
+    for (int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (int64_t)gridDim.x * 16) {
+        bf16x8 raw[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = l16 + 16 * k;
+            raw[k] = ch < nch ? *reinterpret_cast<const bf16x8*>(x + m * C + ch * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[k][j] = (float)raw[k][j]; s += v[k][j]; }
+        const float mean = gg_group16_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const bool ok = l16 + 16 * k < nch;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = ok ? v[k][j] - mean : 0.f; v[k][j] = d; q += d * d; }
+        }
+        const float rstd = rsqrtf(gg_group16_sum(q) * invC + eps);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = l16 + 16 * k;
+            if (ch < nch) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(v[k][j] * rstd, g[k][j], b[k][j]);
+                *reinterpret_cast<bf16x8*>(out + m * C + ch * 8) = o;
+            }
+        }
+        if (mean_out && l16 == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
+    }
+}
+// backward, same geometry.  PARAMS: accumulate (sum dout*xhat, sum dout) per channel -> part [gridDim.x][2][C]
+template <int NCH, bool PARAMS>
+__global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ x,
+                                                                const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                                const float* __restrict__ gamma, int64_t M, int C,
+                                                                const bf16* __restrict__ dres, bf16* __restrict__ dx,
+                                                                float* __restrict__ part) {
+    extern __shared__ float sred[];   // [4 waves][2][C] when PARAMS
+    const int l16 = threadIdx.x & 15;
+    const int nch = C >> 3;
+    float g[NCH][8];
+    float dg[PARAMS ? NCH : 1][8], db[PARAMS ? NCH : 1][8];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = min(l16 + 16 * k, nch - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[k][j] = gamma[ch * 8 + j];
+    }
+    if (PARAMS) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dg[k][j] = db[k][j] = 0.f;
+    }
+    const float invC = 1.f / (float)C;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (int64_t)gridDim.x * 16) {
+        bf16x8 xr[NCH], dr[NCH], rr[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = l16 + 16 * k;
+            const bool ok = ch < nch;
+            xr[k] = ok ? *reinterpret_cast<const bf16x8*>(x + m * C + ch * 8) : zero8;
+            dr[k] = ok ? *reinterpret_cast<const bf16x8*>(dout + m * C + ch * 8) : zero8;
+            if (dres) rr[k] = ok ? *reinterpret_cast<const bf16x8*>(dres + m * C + ch * 8) : zero8;
+        }
+        const float mean = mean_in[m], rstd = rstd_in[m];
+        float xh[NCH][8], dxh[NCH][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const bool ok = l16 + 16 * k < nch;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float dv = (float)dr[k][j];
+                xh[k][j] = ok ? ((float)xr[k][j] - mean) * rstd : 0.f;
+                dxh[k][j] = dv * g[k][j];
+                s1 += dxh[k][j];
+                s2 = fmaf(dxh[k][j], xh[k][j], s2);
+                if (PARAMS) { dg[k][j] = fmaf(dv, xh[k][j], dg[k][j]); db[k][j] += dv; }
+            }
+        }
+        s1 = gg_group16_sum(s1) * invC;
+        s2 = gg_group16_sum(s2) * invC;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = l16 + 16 * k;
+            if (ch < nch) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float r = rstd * (dxh[k][j] - s1 - xh[k][j] * s2);
+                    if (dres) r += (float)rr[k][j];
+                    o[j] = (bf16)r;
+                }
+                *reinterpret_cast<bf16x8*>(dx + m * C + ch * 8) = o;
+            }
+        }
+    }
+    if (PARAMS) {
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = l16 + 16 * k;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {      // the wave's 4 row groups first
+                float a = dg[k][j], c = db[k][j];
+                a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+                c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+                if ((threadIdx.x & 63) < 16 && ch < nch) {
+                    sred[(w * 2 + 0) * C + ch * 8 + j] = a;
+                    sred[(w * 2 + 1) * C + ch * 8 + j] = c;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < 4; ++k) t += sred[k * 2 * C + i];
+            part[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+}
+
 // dx = rstd*(dxh - mean(dxh) - xhat*mean(dxh*xhat)) [+ dres],  dxh = dout*gamma
 // param partials: part [gridDim.x][2][C] = (sum dout*xhat, sum dout) over this block's rows (if part != null)
 template <typename TI, typename TG>
@@ -520,7 +672,13 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
     dim3 grid(ln_blocks(M)), block(256);
     GG_PROF(GG_CAT_NORM, 0, 4.0 * M * C, stream);
     hipStream_t s = (hipStream_t)stream;
-    if (!x_f32 && !out_f32)
+    const int nchl = (C / 8 + 15) / 16;          // 16-byte chunks per lane in the 16-lanes-per-row kernels
+    if (!x_f32 && !out_f32 && nchl <= 5) {
+        const dim3 g16((unsigned)std::min<int64_t>(gg_cdiv(M, 16), 8192));
+#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<N_>), g16, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd)
+        switch (nchl) { case 1: GG_LN_FWD(1); break; case 2: GG_LN_FWD(2); break; case 3: GG_LN_FWD(3); break; case 4: GG_LN_FWD(4); break; default: GG_LN_FWD(5); }
+#undef GG_LN_FWD
+    } else if (!x_f32 && !out_f32)
         hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, bf16>), grid, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);
     else if (x_f32 && out_f32)
         hipLaunchKernelGGL((layernorm_fwd_kernel<float, float>), grid, block, 0, s, (const float*)x, gamma, beta, M, C, eps, (float*)out, mean, rstd);
@@ -543,10 +701,21 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
     float* part = dgamma ? scratch : nullptr;
     size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
     hipStream_t s = (hipStream_t)stream;
+    const int nchl = (C / 8 + 15) / 16;
     if (f32)
         hipLaunchKernelGGL((layernorm_bwd_kernel<float, float>), dim3(nb), dim3(256), lds, s, (const float*)dout, (const float*)x, mean, rstd,
                            gamma, M, C, (const float*)dres, (float*)dx, part);
-    else
+    else if (nchl <= 5) {
+#define GG_LN_BWD(N_)                                                                                                                  \
+    do {                                                                                                                               \
+        if (part) hipLaunchKernelGGL((layernorm_bwd_g16_kernel<N_, true>), dim3(nb), dim3(256), lds, s, (const bf16*)dout, (const bf16*)x, \
+                                     mean, rstd, gamma, M, C, (const bf16*)dres, (bf16*)dx, part);                                      \
+        else hipLaunchKernelGGL((layernorm_bwd_g16_kernel<N_, false>), dim3(nb), dim3(256), 0, s, (const bf16*)dout, (const bf16*)x,   \
+                                mean, rstd, gamma, M, C, (const bf16*)dres, (bf16*)dx, part);                                           \
+    } while (0)
+        switch (nchl) { case 1: GG_LN_BWD(1); break; case 2: GG_LN_BWD(2); break; case 3: GG_LN_BWD(3); break; case 4: GG_LN_BWD(4); break; default: GG_LN_BWD(5); }
+#undef GG_LN_BWD
+    } else
         hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, bf16>), dim3(nb), dim3(256), lds, s, (const bf16*)dout, (const bf16*)x, mean, rstd,
                            gamma, M, C, (const bf16*)dres, (bf16*)dx, part);
     if (dgamma) {
