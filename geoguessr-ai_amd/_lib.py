@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int64), ("dact_preact", C.c_void_p), ("dact", C.c_int),
                 ("colstats", C.c_void_p), ("out_f32", C.c_int), ("split_k", C.c_int), ("A2", C.c_void_p), ("k_split", C.c_int),
                 ("bn_y", C.c_void_p), ("bn_stat", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
-                ("bn_act", C.c_int)]
+                ("bn_act", C.c_int), ("a_bn_stat", C.c_void_p), ("a_bn_gamma", C.c_void_p), ("a_bn_beta", C.c_void_p),
+                ("a_bn_act", C.c_int)]
 
 
 class AttnArgs(C.Structure):
@@ -131,7 +132,7 @@ SIGNATURES = {
     "gg_tinyvit_wcache_bytes": (_L, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_workspace_bytes": (_L, [C.POINTER(TinyVitCfg), _I, _I]),
     "gg_tinyvit_refresh_weights": (_I, [C.POINTER(TinyVitCfg), _P, _P, _P]),
-    "gg_tinyvit_forward": (_I, [C.POINTER(TinyVitCfg), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gg_tinyvit_forward": (_I, [C.POINTER(TinyVitCfg), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
     "gg_tinyvit_backward": (_I, [C.POINTER(TinyVitCfg), _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
     "gg_tinyvit_activation_info": (_I, [C.POINTER(TinyVitCfg), _I, C.c_char_p, C.POINTER(_L), C.POINTER(_L)]),
     "gg_clip_num_tensors": (_I, [C.POINTER(ClipCfg)]),

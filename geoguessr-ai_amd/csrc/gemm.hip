@@ -32,6 +32,7 @@ struct GemmParams {
     int debug;                    // timing experiments only: 1 = no operand loads, 2 = no result stores
     const bf16* A2; int k_split;  // optional second A source for contraction columns k >= k_split (same lda)
     const bf16* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;   // EPI_BNBWD
+    const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;   // PRO: A := act(BN(A)) while staging
 };
 
 // LDS image of an R x 64 operand tile: unpadded 128-byte rows, the eight 16-byte chunks of a row XOR-swizzled with
@@ -257,7 +258,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MINW, int EPI>
+// PRO: the A operand is the SAVED PRE-BatchNorm output of the previous ConvNorm and act(gamma*(a-mean)*rstd+beta) is applied
+// to each 16-byte chunk between the register prefetch and the LDS store -- the separate BatchNorm-apply pass and the
+// activation tensor it would write disappear (frozen ConvNorm chains: nothing downstream needs that tensor).
+template <int BM, int BN, int WM, int WN, int MINW, int EPI, bool PRO = false>
 __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
     // one operand stage; the next k-tile travels through registers while this one is consumed.  The epilogue reuses
     // the buffer as a [BM][BN+8] bf16 staging tile.
@@ -265,8 +269,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;     // 16-byte chunks per thread per k-tile
     constexpr int OPER = (BM + BN) * BK, STAGE = BM * (BN + 8);
     __shared__ __attribute__((aligned(16))) bf16 smem[OPER > STAGE ? OPER : STAGE];
+    __shared__ __attribute__((aligned(16))) float ptab[PRO ? 2048 : 4];      // PRO: [scale[K] | shift[K]], K <= 1024
     bf16* As = smem;
     bf16* Bs = smem + BM * BK;
+    if (PRO) {
+        for (int k = threadIdx.x; k < p.K; k += 256) {
+            const float sc = p.a_gamma[k] * p.a_stat[p.K + k];
+            ptab[k] = sc;
+            ptab[p.K + k] = p.a_beta[k] - p.a_stat[k] * sc;
+        }
+        __syncthreads();
+    }
 
     const int tiles = p.tilesM * p.tilesN;
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
@@ -332,7 +345,28 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
         for (int i = 0; i < LB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kin ? vob[i] : 0xFFFFFFF0u), so, 0);
     };
     if (nk > 0) load_tile(0);
+    const bool pro_gelu = p.a_act == GG_ACT_GELU;
     for (int kt = 0; kt < nk; ++kt) {
+        if (PRO) {
+            // this thread's chunk covers channels k0 + 8*skc .. +7 of every staged row
+            const int kc = min(kbeg + kt * BK + skc * 8, p.K - 8);
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(ptab + kc), s1 = *reinterpret_cast<const f32x4*>(ptab + kc + 4);
+            const f32x4 h0 = *reinterpret_cast<const f32x4*>(ptab + p.K + kc), h1 = *reinterpret_cast<const f32x4*>(ptab + p.K + kc + 4);
+            const f32x2 sc[4] = {{s0[0], s0[1]}, {s0[2], s0[3]}, {s1[0], s1[1]}, {s1[2], s1[3]}};
+            const f32x2 sh[4] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]}};
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const bool rok = m0 + srow + 32 * i < p.M;       // rows beyond M must stay zero (they feed the column statistics)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 v = {__uint_as_float(ra[i][q] << 16), __uint_as_float(ra[i][q] & 0xffff0000u)};
+                    const f32x2 r = gg_act_v2(v * sc[q] + sh[q], pro_gelu);
+                    const bf16 lo = (bf16)r.x, hi = (bf16)r.y;
+                    const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+                    ra[i][q] = rok ? pk : 0u;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(As + lds_a[i]) = ra[i];
 #pragma unroll
@@ -613,7 +647,14 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
                  "gg_gemm_nt: the BatchNorm-backward epilogue excludes every other epilogue option");
         GG_CHECK(a->ldc * 256 < 0xFFFFFF00LL, "gg_gemm_nt: ldc too large for 32-bit tile offsets");
     }
+    if (a->a_bn_stat) {
+        GG_CHECK(a->a_bn_gamma && a->a_bn_beta && a->K <= 1024 && split == 1 && !a->A2,
+                 "gg_gemm_nt: the BatchNorm prologue needs gamma/beta, K <= 1024, no split-K, a single A source");
+        GG_CHECK(!(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->out_f32 || a->preact || a->bn_y),
+                 "gg_gemm_nt: the BatchNorm prologue is built for the plain (+ column statistics) epilogue only");
+    }
     GemmParams p;
+    p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     p.A2 = (const bf16*)a->A2; p.k_split = a->k_split;
     p.bn_y = (const bf16*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
     p.A = (const bf16*)a->A; p.lda = a->lda; p.B = (const bf16*)a->B; p.ldb = a->ldb;
@@ -652,6 +693,12 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
         if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1, 5, E>), grid, dim3(256), 0, st, p);             \
         else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 3, E>), grid, dim3(256), 0, st, p);                   \
     } while (0)
+    if (p.a_stat) {       // (implies EPI_PLAIN)
+        if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1, 5, EPI_PLAIN, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 3, EPI_PLAIN, true>), grid, dim3(256), 0, st, p);
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     switch (epi) {
         case EPI_PLAIN: GG_LAUNCH_EPI(EPI_PLAIN); break;
         case EPI_LINEAR: GG_LAUNCH_EPI(EPI_LINEAR); break;

@@ -346,6 +346,8 @@ struct Exec {
     // Frozen ConvNorm chains: BatchNorm backward's reduce rides in the epilogue of the conv dgrad that produces its input
     // gradient, and its apply step is folded into the weights of the 1x1 dgrad that consumes its output gradient.
     bool fuse_bngemm = getenv("GG_NO_BNGEMM") == nullptr;
+    // MBConv conv3 applies BatchNorm2 + GELU in its A prologue (one N tile: each element is transformed once)
+    bool fuse_pro = getenv("GG_NO_PRO") == nullptr;
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
@@ -406,6 +408,17 @@ static int conv_dense_fwd(const Exec& e, const ConvBNDense& c, const Act& a, con
     GG_TRY(gemm(e, A, lda, e.Wn(c.w), c.w.Kp, e.A(a.y), c.w.N, M, c.w.N, c.w.Kp, nullptr, 0, nullptr, nullptr, 0, nullptr, part));
     return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
 }
+// dense ConvNorm whose input is act(BN(prev.y)) of the preceding ConvNorm, formed while the GEMM stages its A tile
+static int conv_dense_fwd_pro(const Exec& e, const ConvBNDense& c, const Act& a, const BNP& prev_bn, const Act& prev, int in_act, int64_t M) {
+    GgGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = e.A(prev.y); g.lda = c.w.Kp; g.B = e.Wn(c.w); g.ldb = c.w.Kp; g.C = e.A(a.y); g.ldc = c.w.N;
+    g.M = (int)M; g.N = c.w.N; g.K = c.w.Kp;
+    g.colstats = e.training ? e.F(e.L->statpart) : nullptr;
+    g.a_bn_stat = e.F(prev.stat); g.a_bn_gamma = e.P(prev_bn.t_g); g.a_bn_beta = e.P(prev_bn.t_b); g.a_bn_act = in_act;
+    GG_TRY(gg_gemm_nt(&g, e.st));
+    return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
+}
 static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const bf16* x, int B, int H, int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
@@ -457,8 +470,13 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
             GG_TRY(conv_dw_fwd(e, l.c2, a.c2, e.A(a.a1), B, H0, H0, 1));
         }
-        GG_TRY(bn_apply(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, e.A(a.a2)));
-        GG_TRY(conv_dense_fwd(e, l.c3, a.c3, e.A(a.a2), mid, M0));
+        // conv3 reads BN2+GELU of conv2's output through its A prologue unless its weight gradient needs that tensor
+        if (e.fuse_pro && !(e.training && e.tr(l.c3.w.t_w)) && l.c3.w.Kp == mid && mid <= 1024 && l.c3.w.N <= 128) {
+            GG_TRY(conv_dense_fwd_pro(e, l.c3, a.c3, l.c2.bn, a.c2, GG_ACT_GELU, M0));
+        } else {
+            GG_TRY(bn_apply(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, e.A(a.a2)));
+            GG_TRY(conv_dense_fwd(e, l.c3, a.c3, e.A(a.a2), mid, M0));
+        }
         GG_TRY(bn_apply(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, e.A(a.out), e.A(a.x), e.training ? e.dropv(slot) : nullptr, rps0));
         slot++;
     }
@@ -721,7 +739,11 @@ static int backward_impl(Exec& e, const float* d_out) {
         bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
         // out = gelu(x + s*BN3(y3)):  dz(=dpre, also the skip gradient) -> t_b, dy3 -> t_a
         GG_TRY(bn_bwd(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, dx, t_b, t_a, e.A(a.x), s0, rps0));
-        if (e.tr(l.c3.w.t_w)) GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
+        if (e.tr(l.c3.w.t_w)) {
+            // the forward may have run conv3 through its BatchNorm prologue (a2 never written): re-form it for the weight gradient
+            if (e.fuse_pro) GG_TRY(bn_apply(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, e.A(a.a2)));
+            GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
+        }
         if (e.fuse_bngemm && !e.tr(l.c1.w.t_w) && !e.tr(l.c2.w.t_w) && mid % 64 == 0) {
             GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));                   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
@@ -905,7 +927,7 @@ extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* 
 }
 extern "C" int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int training, const float* params, float* buffers,
                                   int64_t* counters, const void* wcache, const float* x, const float* drop_scales, void* workspace,
-                                  float* out, void* stream) {
+                                  float* out, const uint8_t* trainable, void* stream) {
     Model m;
     GG_TRY(build_model(cfg, m));
     GG_CHECK(batch > 0 && params && buffers && wcache && x && workspace && out, "gg_tinyvit_forward: null pointer / bad batch");
@@ -915,7 +937,7 @@ extern "C" int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int traini
     Exec e;
     e.m = &m; e.L = &L; e.B = batch; e.training = training != 0; e.params = params; e.buffers = buffers; e.counters = counters;
     e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = nullptr;
-    e.trainable = nullptr;
+    e.trainable = trainable;       // NULL: keep every activation a weight gradient could need
     return forward_impl(e, x, out);
 }
 extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,

@@ -290,7 +290,8 @@ class TinyVitBackbone(_Tree):
             assert drop_scales.shape == (self.num_drop_slots, B) and drop_scales.dtype == torch.float32
         L.check(L.lib().gg_tinyvit_forward(C.byref(self.cfg), B, int(training), L.ptr(self._flat), L.ptr(self._flat_buf),
                                            L.ptr(self._counters), L.ptr(self._wcache), L.ptr(x), L.ptr(drop_scales), L.ptr(ws),
-                                           L.ptr(out), L.stream()), "gg_tinyvit_forward")
+                                           L.ptr(out), self.trainable_mask() if training else None, L.stream()),
+                "gg_tinyvit_forward")
         if training:
             self._counters += 1          # num_batches_tracked (int64 bookkeeping)
             self._flat_buf_dirty = True

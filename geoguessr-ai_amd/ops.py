@@ -213,6 +213,29 @@ def bn_bwd(dout, y, stat, gamma, beta, act=None, residual=None, rowscale=None, r
     return dz, dy, dg, db
 
 
+def conv_bn_prologue(y_prev, stat, gamma, beta, W, act=None, colstats=False):
+    """C = act(BN(y_prev)) @ W^T with the BatchNorm + activation applied while the GEMM stages its A tile.
+
+    y_prev [M,K] bf16 is the previous ConvNorm's saved pre-BatchNorm output, stat = [mean[K], rstd[K]]."""
+    L.require_gpu()
+    M, K = y_prev.shape
+    N = W.shape[0]
+    dev = y_prev.device
+    out = torch.empty((M, N), dtype=BF16, device=dev)
+    stats = None
+    if colstats:
+        rows = L.lib().gg_gemm_colstats_rows(M)
+        stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), dtype=F32, device=dev)[:rows]
+    a = L.GemmArgs()
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(y_prev, BF16, "y_prev"), y_prev.stride(0), _pr(W, BF16, "W"), W.stride(0), _p(out), N
+    a.M, a.N, a.K = M, N, K
+    a.a_bn_stat, a.a_bn_gamma, a.a_bn_beta, a.a_bn_act = _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act]
+    a.colstats = _p(stats)
+    a.split_k = 1
+    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    return (out, stats) if colstats else out
+
+
 def conv_dgrad_bn_bwd(dY, Wt, y, stat, gamma, beta, act=None, want_param_grads=True):
     """dz = (dY @ Wt^T) * act'(BN(y)) with BatchNorm backward's column sums taken in the GEMM epilogue, then finalize.
 

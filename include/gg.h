@@ -52,6 +52,9 @@ typedef struct GgGemmArgs {
      * C = dz = acc * act'(gamma*xhat + beta), xhat = (bn_y - mean)*rstd with stat = [mean[N], rstd[N]], bn_y bf16 [M,ldc];
      * colstats <- per M-tile column sums of (dz, dz*xhat) for gg_bn_bwd_finalize. */
     const void* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;
+    /* BatchNorm prologue: A holds the PRE-BatchNorm output of the previous ConvNorm; act(gamma*(A-mean)*rstd+beta) with
+     * a_bn_stat = [mean[K], rstd[K]] is applied while the A tile is staged (plain / colstats epilogue only, K <= 1024). */
+    const float* a_bn_stat; const float* a_bn_gamma; const float* a_bn_beta; int a_bn_act;
 } GgGemmArgs;
 int gg_gemm_nt(const GgGemmArgs* args, void* stream);
 int gg_gemm_colstats_rows(int M);
@@ -220,8 +223,11 @@ int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int train
 int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream);
 /* x: f32 NCHW (batch,in_chans,img,img).  drop_scales: f32 [num_drop_slots][batch] = keep/(1-p) or NULL.
  * out: f32 (batch, embed_dims[3]).  training: batch-stat BN + running-stat update + activations kept for backward. */
+/* trainable: host uint8[num_tensors] or NULL -- the freeze policy the backward will run with; activations that only a frozen
+ * weight's gradient would read are fused away (e.g. MBConv act2 goes through conv3's BatchNorm prologue). */
 int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int training, const float* params, float* buffers, int64_t* counters,
-                       const void* wcache, const float* x, const float* drop_scales, void* workspace, float* out, void* stream);
+                       const void* wcache, const float* x, const float* drop_scales, void* workspace, float* out,
+                       const uint8_t* trainable /* host */, void* stream);
 /* d_out: f32 (batch, C).  grads: flat f32 like params, ACCUMULATED into.  trainable: host uint8[num_tensors]
  * (wgrad computed only where 1; dgrad always flows to patch_embed -- SURVEY.md C1). */
 int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,

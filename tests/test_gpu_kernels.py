@@ -115,6 +115,25 @@ def test_gemm_splitk_and_wgrad_form(ops):
           rtol=1e-4, atol=1e-3, what="colsum_bf16")
 
 
+@pytest.mark.parametrize("M,K,N,act", [(3000, 384, 96, "gelu"), (1000, 160, 48, "gelu"), (777, 64, 200, None)])
+def test_gemm_batchnorm_prologue(ops, M, K, N, act):
+    """conv3(act(BN2(y2))) with BN+act applied in the GEMM's A prologue == bn_apply followed by the plain GEMM."""
+    y = (rnd(M, K, seed=80, scale=1.5) + 0.4).to(BF).float()
+    W = (rnd(N, K, seed=81) / K ** 0.5).to(BF).float()
+    gamma, beta = 1 + 0.2 * rnd(K, seed=82), 0.3 * rnd(K, seed=83)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    stat = dev(torch.stack([mean, torch.rsqrt(var + 1e-5)]))
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    a = (F.gelu(z) if act else z).to(BF).float()
+    ref = a @ W.T
+    out, stats = ops.conv_bn_prologue(dev(y, BF), stat, dev(gamma), dev(beta), dev(W, BF), act=act, colstats=True)
+    close(out, ref, rtol=2e-2, atol=2e-2, what="prologue gemm")
+    s = stats.cpu().sum(0)
+    oq = out.float().cpu()
+    close(s[0], oq.sum(0), rtol=1e-3, atol=0.05, what="prologue colsum")
+    close(s[1], (oq * oq).sum(0), rtol=1e-3, atol=0.05, what="prologue colsumsq")
+
+
 @pytest.mark.parametrize("M,Cin,Cmid,Cout", [(3000, 96, 384, 96), (1111, 64, 128, 192)])
 def test_convnorm_chain_backward_fused_into_gemms(ops, M, Cin, Cmid, Cout):
     """x -conv1-> y1 -BN(train)+GELU-> a1 -conv3-> y3: dgrad of conv3 carries BN backward's reduce in its epilogue, dgrad of
