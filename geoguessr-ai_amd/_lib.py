@@ -86,6 +86,7 @@ SIGNATURES = {
     "gg_col2im_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv_tiled_stat_rows": (_I, [_I, _I]),
+    "gg_dwconv_fused_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv3x3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_fwd_fused": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

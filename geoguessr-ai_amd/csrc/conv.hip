@@ -174,12 +174,23 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
 // left / right neighbours come out of L1: HBM sees every input byte once), rotates the window by renaming (the loop is
 // unrolled by 3) and emits one output row.  Rows / columns outside the image are zero through the buffer range check.
 // colstats: one row per block, [gridDim.x][2][C] = per-channel sum / sum of squares of the stored (bf16-rounded) result.
-typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
 #define DW_COL_OOB 0x80000000u
 #define DW_ROW_OOB 0x40000000u
-__device__ __forceinline__ void dw_unpack8(const dw_u32x4 r, f32x2 (&o)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = (f32x2){__uint_as_float(r[q] << 16), __uint_as_float(r[q] & 0xffff0000u)};
+// NQ channel pairs per thread: 4 (16-byte accesses; the plain kernel) or 2 (8-byte accesses; the fused backward kernels, whose
+// per-channel state does not fit the register file at 8 channels per thread -- measured 2.8 ms vs 1.9 ms at 56x56x384)
+template <int NQ> struct DwRaw;
+template <> struct DwRaw<4> {
+    typedef unsigned int T __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int vo) { return __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0); }
+};
+template <> struct DwRaw<2> {
+    typedef unsigned int T __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ T load(__amdgpu_buffer_rsrc_t rs, int vo) { return __builtin_amdgcn_raw_buffer_load_b64(rs, vo, 0, 0); }
+};
+__device__ __forceinline__ f32x2 dw_unpack2(unsigned r) { return (f32x2){__uint_as_float(r << 16), __uint_as_float(r & 0xffff0000u)}; }
+__device__ __forceinline__ unsigned dw_pack2(f32x2 v) {
+    const bf16 lo = (bf16)v.x, hi = (bf16)v.y;
+    return (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
 }
 // Backward fusions (stride-1 data gradient, both optional, compile-time):
 //   IN2 : the conv input is  coef0*x + coef1*in2 + coef2  = BatchNorm backward's "apply" of the ConvNorm BEHIND this conv, formed
@@ -187,34 +198,36 @@ __device__ __forceinline__ void dw_unpack8(const dw_u32x4 r, f32x2 (&o)[4]) {
 //   EPI : the stored value is  acc * act'(BN(ep_y))  = gradient w.r.t. the pre-activation of the ConvNorm IN FRONT, and colstats
 //         becomes (sum dz, sum dz*xhat): that ConvNorm's "reduce" pass disappears.
 // The per-channel coefficient tables sit in LDS (they are touched once per row; registers go to the window and the taps).
+// Window element: fp32 pairs, or (IN2) the packed bf16 pair the unfused path would have stored in dy, unpacked at use.
 template <bool PACKED> struct DwWin;
 template <> struct DwWin<false> {
-    struct T { f32x2 v[4]; };
-    static __device__ __forceinline__ void zero(T& t) { for (int q = 0; q < 4; ++q) t.v[q] = (f32x2)(0.f); }
-    static __device__ __forceinline__ void get(const T& t, f32x2 (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = t.v[q]; }
-    static __device__ __forceinline__ f32x2 at(const T& t, int q) { return t.v[q]; }
+    typedef f32x2 E;
+    static __device__ __forceinline__ E zero() { return (f32x2)(0.f); }
+    static __device__ __forceinline__ f32x2 get(E e) { return e; }
 };
 template <> struct DwWin<true> {
-    struct T { unsigned r[4]; };
-    static __device__ __forceinline__ void zero(T& t) { for (int q = 0; q < 4; ++q) t.r[q] = 0u; }
-    static __device__ __forceinline__ f32x2 at(const T& t, int q) { return (f32x2){__uint_as_float(t.r[q] << 16), __uint_as_float(t.r[q] & 0xffff0000u)}; }
-    static __device__ __forceinline__ void get(const T& t, f32x2 (&o)[4]) { for (int q = 0; q < 4; ++q) o[q] = at(t, q); }
+    typedef unsigned E;
+    static __device__ __forceinline__ E zero() { return 0u; }
+    static __device__ __forceinline__ f32x2 get(E e) { return dw_unpack2(e); }
 };
 struct DwWalkFuse {
     const bf16* in2; const float* in_coef;                                         // IN2
     const bf16* ep_y; const float* ep_stat; const float* ep_gamma; const float* ep_beta; int ep_act;   // EPI
 };
-template <bool IN2, bool EPI>
-__global__ __launch_bounds__(256, 2) void dwconv3x3_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
-                                                             int H, int W, int C, int CG, int PX, int nbx, int flip,
-                                                             float* __restrict__ colstats, DwWalkFuse f) {
-    extern __shared__ float dw_red[];          // [PX][2][C] statistics scratch; then (fusions) 7 coefficient rows [C]
+template <bool IN2, bool EPI, int NQ>
+__global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt,
+                                                                              bf16* __restrict__ y, int H, int W, int C, int CG, int PX, int nbx,
+                                                                              int flip, float* __restrict__ colstats, DwWalkFuse f) {
+    typedef typename DwRaw<NQ>::T Raw;
+    typedef typename DwWin<IN2>::E WinE;
+    constexpr int NC = 2 * NQ;                 // channels per thread
+    extern __shared__ float dw_red[];          // [PX][2][C] statistics scratch; then (fusions) 16 coefficient rows [C]
     float* ctab = dw_red + PX * 2 * C;         // [0..2] in coef a,b,c   [3] ep scale  [4] ep shift  [5] ep rstd  [6] ep -mean*rstd  [7..15] taps
-    constexpr bool TAPS_LDS = IN2 || EPI;      // the fused variants have no registers left for 72 tap values
+    constexpr bool TAPS_LDS = IN2 || EPI;      // the fused variants have no registers left for the tap values
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
     const int bx = blockIdx.x % nbx, b = blockIdx.x / nbx;
     const int xo = bx * PX + px;
-    const int c0 = cg * 8;
+    const int c0 = cg * NC;
     if (IN2 || EPI) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             if (IN2) { ctab[c] = f.in_coef[c]; ctab[C + c] = f.in_coef[C + c]; ctab[2 * C + c] = f.in_coef[2 * C + c]; }
@@ -228,20 +241,15 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_walk_kernel(const bf16* __re
         __syncthreads();
     }
     // `cofs` is laundered through an empty asm once per row step: the table reads are loop-invariant, and hoisting them would
-    // put all 16 rows x 8 channels back into registers
+    // put all 16 rows back into registers
     int cofs = c0;
-    auto ctab2 = [&](int row, f32x2 (&o)[4]) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ctab + row * C + cofs), c = *reinterpret_cast<const f32x4*>(ctab + row * C + cofs + 4);
-        o[0] = (f32x2){a[0], a[1]}; o[1] = (f32x2){a[2], a[3]}; o[2] = (f32x2){c[0], c[1]}; o[3] = (f32x2){c[2], c[3]};
-    };
-    f32x2 tap[TAPS_LDS ? 1 : 9][4];
+    auto ctab2 = [&](int row, int q) { return *reinterpret_cast<const f32x2*>(ctab + row * C + cofs + 2 * q); };
+    f32x2 tap[TAPS_LDS ? 1 : 9][NQ];
     if (!TAPS_LDS) {
 #pragma unroll
-        for (int t = 0; t < (TAPS_LDS ? 1 : 9); ++t) {
-            const float* wp = wt + (flip ? 8 - t : t) * C + c0;
-            const f32x4 a = *reinterpret_cast<const f32x4*>(wp), c = *reinterpret_cast<const f32x4*>(wp + 4);
-            tap[t][0] = (f32x2){a[0], a[1]}; tap[t][1] = (f32x2){a[2], a[3]}; tap[t][2] = (f32x2){c[0], c[1]}; tap[t][3] = (f32x2){c[2], c[3]};
-        }
+        for (int t = 0; t < (TAPS_LDS ? 1 : 9); ++t)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) tap[t][q] = *reinterpret_cast<const f32x2*>(wt + (flip ? 8 - t : t) * C + c0 + 2 * q);
     }
     const int64_t img = (int64_t)b * H * W * C;
     // (the image bases are block-uniform; saying so keeps the descriptors in SGPRs -- otherwise every buffer load is wrapped in a
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_walk_kernel(const bf16* __re
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + img), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((IN2 ? f.in2 : x) + img), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((EPI ? f.ep_y : x) + img), 0, img_bytes, 0x00020000);
-    // byte offsets of the three columns inside a row (out of range -> beyond the descriptor -> zeros)
+    // byte offsets of the three columns inside a row
     unsigned colo[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -266,112 +274,89 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_walk_kernel(const bf16* __re
     // branch-free addressing: an invalid column carries bit 31, an invalid row adds bit 30; either pushes the offset past the
     // (< 1 GiB) descriptor, and no combination wraps back into range.  (Branches around the loads made the compiler wait for
     // ALL outstanding loads at the join, which serialised the row prefetch.)
-    auto load_row = [&](int iy, dw_u32x4 (&raw)[3], dw_u32x4 (&raw2)[3]) {
+    auto load_row = [&](int iy, Raw (&raw)[3], Raw (&raw2)[3]) {
         const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int vo = (int)(colo[k] + ro);
-            raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, 0, 0);
-            if (IN2) raw2[k] = __builtin_amdgcn_raw_buffer_load_b128(rs2, vo, 0, 0);
+            raw[k] = DwRaw<NQ>::load(rs, vo);
+            if (IN2) raw2[k] = DwRaw<NQ>::load(rs2, vo);
         }
     };
-    // raw row -> fp32 window slot; IN2: the BatchNorm-backward apply on the way (positions outside the image stay exactly 0)
-    auto fill = [&](int iy, const dw_u32x4 (&raw)[3], const dw_u32x4 (&raw2)[3], typename DwWin<IN2>::T (&slot)[3]) {
+    // raw row -> window slot; IN2: the BatchNorm-backward apply on the way (positions outside the image stay exactly 0)
+    auto fill = [&](int iy, const Raw (&raw)[3], const Raw (&raw2)[3], WinE (&slot)[3][NQ]) {
         if constexpr (!IN2) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) dw_unpack8(raw[k], slot[k].v);
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) slot[k][q] = dw_unpack2(raw[k][q]);
         } else {
-            f32x2 ca[4], cb[4], cc[4];
-            ctab2(0, ca); ctab2(1, cb); ctab2(2, cc);
             const bool rok = iy >= 0 && iy < H;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                f32x2 d[4], v[4];
-                dw_unpack8(raw[k], d); dw_unpack8(raw2[k], v);
-                const bool ok = rok && colo[k] != DW_COL_OOB;
+            for (int q = 0; q < NQ; ++q) {
+                const f32x2 ca = ctab2(0, q), cb = ctab2(1, q), cc = ctab2(2, q);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x2 r = ca[q] * d[q] + (cb[q] * v[q] + cc[q]);
-                    const bf16 lo = (bf16)r.x, hi = (bf16)r.y;
-                    const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
-                    slot[k].r[q] = ok ? pk : 0u;
+                for (int k = 0; k < 3; ++k) {
+                    const f32x2 r = ca * dw_unpack2(raw[k][q]) + (cb * dw_unpack2(raw2[k][q]) + cc);
+                    slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? dw_pack2(r) : 0u;
                 }
             }
         }
     };
-    // window [row slot][column]: fp32 channel pairs, or (IN2, where registers are short) the bf16 values the unfused path would
-    // have stored in dy, unpacked at use
-    typename DwWin<IN2>::T win[3][3];
-    dw_u32x4 raw[3], raw2[3];
+    WinE win[3][3][NQ];           // [row slot][column][channel pair]
+    Raw raw[3], raw2[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) DwWin<IN2>::zero(win[0][k]);          // row -1
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) win[0][k][q] = DwWin<IN2>::zero();          // row -1
     load_row(0, raw, raw2);
     fill(0, raw, raw2, win[1]);
     load_row(1, raw, raw2);
-    f32x2 s2[4], q2[4];
+    f32x2 s2[NQ], q2[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s2[q] = q2[q] = (f32x2)(0.f);
+    for (int q = 0; q < NQ; ++q) s2[q] = q2[q] = (f32x2)(0.f);
     bf16* yb = y + img + (int64_t)xo * C + c0;
     const bool store_ok = xo < W;
     const unsigned ctr = store_ok ? (unsigned)(xo * C + c0) * 2u : DW_COL_OOB;
     const bool ep_gelu = f.ep_act == GG_ACT_GELU;
-    dw_u32x4 eraw;
-    if (EPI) eraw = __builtin_amdgcn_raw_buffer_load_b128(rse, (int)ctr, 0, 0);
+    Raw eraw;
+    if (EPI) eraw = DwRaw<NQ>::load(rse, (int)ctr);
     // one output row: slot RC receives input row yy+1 (already in flight), rows yy-1 / yy sit in slots RA / RB
 #define GG_DW_STEP(RA, RB, RC, yy)                                                                                         \
     {                                                                                                                      \
         if (IN2 || EPI) asm volatile("" : "+v"(cofs));                                                                     \
         fill((yy) + 1, raw, raw2, win[RC]);                                                                                \
         load_row((yy) + 2, raw, raw2);                                                                                     \
-        if (IN2 || EPI) __builtin_amdgcn_sched_barrier(0);                                                                 \
         const float live = (yy) < H ? 1.f : 0.f;                                                                           \
-        f32x2 acc[4];                                                                                                      \
-        if (TAPS_LDS) {                                                                                                    \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[q] = (f32x2)(0.f);                                           \
+        f32x2 acc[NQ];                                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                                   \
+            f32x2 a = (f32x2)(0.f);                                                                                        \
             _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                \
-                f32x2 tp[4];                                                                                               \
-                ctab2(7 + t, tp);                                                                                          \
                 const int rsl = t < 3 ? RA : (t < 6 ? RB : RC);                                                            \
-                f32x2 wv[4];                                                                                               \
-                DwWin<IN2>::get(win[rsl][t % 3], wv);                                                                      \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[q] = wv[q] * tp[q] + acc[q];               \
-                if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);   /* <= 3 taps' worth of LDS reads in flight */          \
+                const f32x2 tp = TAPS_LDS ? ctab2(7 + t, q) : tap[TAPS_LDS ? 0 : t][q];                                    \
+                a = DwWin<IN2>::get(win[rsl][t % 3][q]) * tp + a;                                                          \
             }                                                                                                              \
-        } else {                                                                                                           \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
-                f32x2 a = DwWin<IN2>::at(win[RA][0], q) * tap[0][q];                                                       \
-                a = DwWin<IN2>::at(win[RA][1], q) * tap[1][q] + a; a = DwWin<IN2>::at(win[RA][2], q) * tap[2][q] + a;      \
-                a = DwWin<IN2>::at(win[RB][0], q) * tap[3][q] + a; a = DwWin<IN2>::at(win[RB][1], q) * tap[4][q] + a;      \
-                a = DwWin<IN2>::at(win[RB][2], q) * tap[5][q] + a;                                                         \
-                a = DwWin<IN2>::at(win[RC][0], q) * tap[6][q] + a; a = DwWin<IN2>::at(win[RC][1], q) * tap[7][q] + a;      \
-                a = DwWin<IN2>::at(win[RC][2], q) * tap[8][q] + a;                                                         \
-                acc[q] = a;                                                                                                \
-            }                                                                                                              \
+            acc[q] = a;                                                                                                    \
         }                                                                                                                  \
-        bf16x8 o;                                                                                                          \
+        Raw o;                                                                                                             \
         if (EPI) {                                                                                                         \
-            f32x2 yv[4];                                                                                                   \
-            dw_unpack8(eraw, yv);                                                                                          \
-            eraw = __builtin_amdgcn_raw_buffer_load_b128(rse, (int)(ctr + ((yy) + 1 < H ? (unsigned)((yy) + 1) * rowb : DW_ROW_OOB)), 0, 0); \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {       /* one channel pair at a time: short live ranges */       \
-                const f32x2 esc = *reinterpret_cast<const f32x2*>(ctab + 3 * C + cofs + 2 * q);                            \
-                const f32x2 esh = *reinterpret_cast<const f32x2*>(ctab + 4 * C + cofs + 2 * q);                            \
-                const f32x2 dz = acc[q] * gg_act_grad_v2(yv[q] * esc + esh, ep_gelu);                                      \
-                o[2 * q] = (bf16)dz.x; o[2 * q + 1] = (bf16)dz.y;                                                          \
-                const f32x2 ers = *reinterpret_cast<const f32x2*>(ctab + 5 * C + cofs + 2 * q);                            \
-                const f32x2 emr = *reinterpret_cast<const f32x2*>(ctab + 6 * C + cofs + 2 * q);                            \
-                const f32x2 r = (f32x2){(float)o[2 * q], (float)o[2 * q + 1]} * live;                                      \
-                s2[q] += r; q2[q] += r * (yv[q] * ers + emr);                                                              \
-                __builtin_amdgcn_sched_barrier(0);                                                                         \
+            const Raw ycur = eraw;                                                                                         \
+            eraw = DwRaw<NQ>::load(rse, (int)(ctr + ((yy) + 1 < H ? (unsigned)((yy) + 1) * rowb : DW_ROW_OOB)));          \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) {       /* one channel pair at a time: short live ranges */      \
+                const f32x2 yv = dw_unpack2(ycur[q]);                                                                      \
+                const f32x2 dz = acc[q] * gg_act_grad_v2(yv * ctab2(3, q) + ctab2(4, q), ep_gelu);                         \
+                o[q] = dw_pack2(dz);                                                                                       \
+                const f32x2 r = dw_unpack2(o[q]) * live;                                                                   \
+                s2[q] += r; q2[q] += r * (yv * ctab2(5, q) + ctab2(6, q));                                                 \
             }                                                                                                              \
         } else {                                                                                                           \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
-                o[2 * q] = (bf16)acc[q].x; o[2 * q + 1] = (bf16)acc[q].y;                                                  \
-                const f32x2 r = (f32x2){(float)o[2 * q], (float)o[2 * q + 1]} * live;                                      \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                               \
+                o[q] = dw_pack2(acc[q]);                                                                                   \
+                const f32x2 r = dw_unpack2(o[q]) * live;                                                                   \
                 s2[q] += r; q2[q] += r * r;                                                                                \
             }                                                                                                              \
         }                                                                                                                  \
-        if (store_ok && (yy) < H) *reinterpret_cast<bf16x8*>(yb + (int64_t)(yy) * W * C) = o;                              \
+        if (store_ok && (yy) < H) *reinterpret_cast<Raw*>(yb + (int64_t)(yy) * W * C) = o;                                 \
     }
     // (the tail of the last trip may run 1-2 rows past the image: its loads are out of range, its store and statistics masked)
     for (int y0 = 0; y0 < H; y0 += 3) {
@@ -382,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_walk_kernel(const bf16* __re
 #undef GG_DW_STEP
     if (colstats) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             // columns beyond the image produced zeros (all inputs out of range): they add nothing
             dw_red[(px * 2 + 0) * C + c0 + 2 * q] = s2[q].x; dw_red[(px * 2 + 0) * C + c0 + 2 * q + 1] = s2[q].y;
             dw_red[(px * 2 + 1) * C + c0 + 2 * q] = q2[q].x; dw_red[(px * 2 + 1) * C + c0 + 2 * q + 1] = q2[q].y;
@@ -713,30 +698,43 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
     g.nblocks = (int)gg_cdiv(npix, ppb);
     return g;
 }
-// stride-1 convs take the column-walking kernel: PX columns x C/8 channel groups per block (<= 256 threads), whole image height
-static int dw_walk_px(int C) { return std::max(1, 256 / (C / 8)); }
+// stride-1 convs take the column-walking kernel: PX columns x C/NC channel groups per block (<= 256 threads), whole image height.
+// NC = 8 channels per thread, 4 for the doubly fused backward kernel.
+static int dw_walk_px(int C, int nc = 8) { return std::max(1, 256 / (C / nc)); }
 static bool dw_walk_ok(int C, int stride) { return stride == 1 && (C / 8) <= 256 && getenv("GG_DW_TILED") == nullptr; }
+static bool dw_walk_fused4(int C) { return (C / 4) <= 256; }       // both fusions at once run 4 channels per thread
 extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride) {
     if (dw_walk_ok(C, stride)) return B * (int)gg_cdiv(Wo, dw_walk_px(C));
     return B * (int)gg_cdiv(Ho, 8);
 }
 extern "C" int gg_dwconv_tiled_stat_rows(int B, int Ho) { return B * (int)gg_cdiv(Ho, 8); }
+/* rows written by gg_dwconv3x3_bwd_data_fused with an output-side fusion */
+extern "C" int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_input_fusion) {
+    if (!dw_walk_ok(C, 1)) return B * (int)gg_cdiv(H, 8);
+    (void)with_input_fusion;
+    const int nc = dw_walk_fused4(C) ? 4 : 8;
+    return B * (int)gg_cdiv(W, dw_walk_px(C, nc));
+}
 static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int flip, float* colstats, void* stream,
                               const DwWalkFuse* fuse = nullptr) {
-    const int CG = C / 8, PX = dw_walk_px(C), nbx = (int)gg_cdiv(W, PX);
     GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");
     GG_CHECK(((uintptr_t)wt & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "dwconv: operands must be 16-byte aligned");
     DwWalkFuse f;
     memset(&f, 0, sizeof(f));
     if (fuse) f = *fuse;
     const bool in2 = f.in_coef != nullptr, epi = f.ep_y != nullptr;
+    const int nc = ((in2 || epi) && dw_walk_fused4(C)) ? 4 : 8;      // every fused variant: 4 channels per thread
+    const int CG = C / nc, PX = dw_walk_px(C, nc), nbx = (int)gg_cdiv(W, PX);
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 2.0 * B * C * (double)H * W * (2 + in2 + epi), stream);
     const size_t lds = ((size_t)PX * 2 * C + ((in2 || epi) ? 16 * (size_t)C : 0)) * sizeof(float);
     GG_CHECK(lds <= 64 * 1024, "dwconv: C=%d needs %zu bytes of LDS", C, lds);
     const dim3 grid((unsigned)(B * nbx)), block(CG * PX);
-#define GG_DW_WALK(I_, E_) hipLaunchKernelGGL((dwconv3x3_walk_kernel<I_, E_>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y, \
-                                              H, W, C, CG, PX, nbx, flip, colstats, f)
-    if (in2 && epi) GG_DW_WALK(true, true); else if (in2) GG_DW_WALK(true, false); else if (epi) GG_DW_WALK(false, true); else GG_DW_WALK(false, false);
+#define GG_DW_WALK(I_, E_, N_) hipLaunchKernelGGL((dwconv3x3_walk_kernel<I_, E_, N_>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, \
+                                                  (bf16*)y, H, W, C, CG, PX, nbx, flip, colstats, f)
+    if (in2 && epi) { if (nc == 4) GG_DW_WALK(true, true, 2); else GG_DW_WALK(true, true, 4); }
+    else if (in2) { if (nc == 4) GG_DW_WALK(true, false, 2); else GG_DW_WALK(true, false, 4); }
+    else if (epi) { if (nc == 4) GG_DW_WALK(false, true, 2); else GG_DW_WALK(false, true, 4); }
+    else GG_DW_WALK(false, false, 4);
 #undef GG_DW_WALK
     GG_LAUNCH_CHECK();
     return 0;

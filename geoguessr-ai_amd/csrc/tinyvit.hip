@@ -200,7 +200,8 @@ struct Layout {
 };
 
 static int64_t bn_part_floats(int64_t M, int C, int B, int Ho, int Wo, bool dw) {
-    const int rows = dw ? std::max(std::max(gg_dwconv_stat_rows(B, Ho, Wo, C, 1), gg_dwconv_stat_rows(B, Ho, Wo, C, 2)), gg_dwconv_tiled_stat_rows(B, Ho))
+    const int rows = dw ? std::max(std::max(gg_dwconv_stat_rows(B, Ho, Wo, C, 1), gg_dwconv_stat_rows(B, Ho, Wo, C, 2)),
+                                   std::max(gg_dwconv_tiled_stat_rows(B, Ho), gg_dwconv_fused_stat_rows(B, Ho, Wo, C, 1)))
                         : gg_gemm_colstats_rows((int)M);
     return (int64_t)gg_stat_rows_capacity(rows) * 2 * C;
 }
@@ -338,11 +339,11 @@ struct Exec {
     // Fusing BatchNorm+GELU of the producer into the depthwise conv's staging removes one [M,C] write+read but makes the
     // conv VALU-bound (erf on tile + halo): measured +6.6 ms conv vs -3.1 ms elementwise at 1024 images -> off by default.
     bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
-    // Frozen depthwise taps: BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) is formed while the data gradient loads
-    // its input (GG_NO_FUSE_BNBWD=1 restores the separate pass).  The matching output-side fusion (act'(BN) + reduce of the
-    // ConvNorm in front) does not fit the register file at 2 waves/SIMD yet and spills -> opt-in (GG_FUSE_BNBWD_EPI=1).
+    // Frozen depthwise taps: the data gradient forms BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) while it loads its
+    // input, and (MBConv) emits dz = da*act'(BN(y)) + the reduce sums of the ConvNorm in front: apply and reduce passes and
+    // the dy / da tensors disappear.  GG_NO_FUSE_BNBWD=1 / GG_NO_FUSE_BNBWD_EPI=1 restore the separate passes.
     bool fuse_bnbwd = getenv("GG_NO_FUSE_BNBWD") == nullptr;
-    bool fuse_bnbwd_epi = getenv("GG_FUSE_BNBWD_EPI") != nullptr;
+    bool fuse_bnbwd_epi = getenv("GG_NO_FUSE_BNBWD_EPI") == nullptr;
     // Frozen ConvNorm chains: BatchNorm backward's reduce rides in the epilogue of the conv dgrad that produces its input
     // gradient, and its apply step is folded into the weights of the 1x1 dgrad that consumes its output gradient.
     bool fuse_bngemm = getenv("GG_NO_BNGEMM") == nullptr;
@@ -752,7 +753,7 @@ static int backward_impl(Exec& e, const float* d_out) {
                 GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                    e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
                 const bool tr1 = e.tr(l.c1.bn.t_g);
-                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_fused_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                           bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
                 dz1 = t_c;
             } else {
@@ -785,7 +786,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
             const bool tr1 = e.tr(l.c1.bn.t_g);
-            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_fused_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                       bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
             GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                              // dy1 -> t_a
         }

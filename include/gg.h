@@ -80,7 +80,8 @@ int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int W, int stri
 int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, int stride, void* stream);
 int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream);
 int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride);   /* partial-statistics rows gg_dwconv3x3_fwd writes */
-int gg_dwconv_tiled_stat_rows(int B, int Ho);                          /* ... and the fused (LDS-tiled) variants */
+int gg_dwconv_tiled_stat_rows(int B, int Ho);                          /* ... the producer-fused forward variant (LDS-tiled kernel) */
+int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_input_fusion);   /* ... the fused data gradient with ep_y */
 int gg_dwconv3x3_fwd(const void* x, const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
 int gg_dwconv3x3_fwd_fused(const void* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act,
                            const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);

@@ -27,3 +27,17 @@ for name, H, Cc in [("mb", 56, 384), ("s1.local", 28, 192), ("s2.local", 14, 384
     tb = timed(lambda: L.check(L.lib().gg_dwconv3x3_bwd_data(x.data_ptr(), taps.data_ptr(), y.data_ptr(), B, H, H, Cc, 1, L.stream())))
     byt = 4 * B * H * H * Cc
     print(f"{name:10s} {H}x{H}x{Cc}  fwd+stats {tf*1e3:8.1f} us ({byt/tf/1e6:7.1f} GB/s)   bwd_data {tb*1e3:8.1f} us ({byt/tb/1e6:7.1f} GB/s)   stat rows {rows}")
+
+# ---- backward fusions (MBConv shape) ----
+for name, H, Cc in [("mb", 56, 384), ("s2.local", 14, 384)]:
+    dz = torch.randn(B, H, H, Cc, device="cuda").bfloat16(); yin = torch.randn_like(dz); out = torch.empty_like(dz); epy = torch.randn_like(dz)
+    taps = torch.randn(9, Cc, device="cuda"); coef = torch.randn(3, Cc, device="cuda") * 0.1
+    stat = torch.stack([torch.zeros(Cc), torch.ones(Cc)]).cuda(); g = torch.ones(Cc, device="cuda"); bt = torch.zeros(Cc, device="cuda")
+    rows = L.lib().gg_dwconv_fused_stat_rows(B, H, H, Cc, 1)
+    part = torch.zeros(L.lib().gg_stat_rows_capacity(max(rows, L.lib().gg_dwconv_fused_stat_rows(B, H, H, Cc, 0))), 2, Cc, device="cuda")
+    N = None
+    t_in = timed(lambda: L.check(L.lib().gg_dwconv3x3_bwd_data_fused(dz.data_ptr(), yin.data_ptr(), coef.data_ptr(), taps.data_ptr(), out.data_ptr(), B, H, H, Cc, N, N, N, N, 0, N, L.stream())))
+    t_ep = timed(lambda: L.check(L.lib().gg_dwconv3x3_bwd_data_fused(dz.data_ptr(), N, N, taps.data_ptr(), out.data_ptr(), B, H, H, Cc, epy.data_ptr(), stat.data_ptr(), g.data_ptr(), bt.data_ptr(), 1, part.data_ptr(), L.stream())))
+    t_both = timed(lambda: L.check(L.lib().gg_dwconv3x3_bwd_data_fused(dz.data_ptr(), yin.data_ptr(), coef.data_ptr(), taps.data_ptr(), out.data_ptr(), B, H, H, Cc, epy.data_ptr(), stat.data_ptr(), g.data_ptr(), bt.data_ptr(), 1, part.data_ptr(), L.stream())))
+    L1 = 2 * B * H * H * Cc
+    print(f"{name:10s} fused bwd: in2 {t_in*1e3:8.1f} us ({3*L1/t_in/1e6:7.1f} GB/s)  epi {t_ep*1e3:8.1f} us ({3*L1/t_ep/1e6:7.1f} GB/s)  both {t_both*1e3:8.1f} us ({4*L1/t_both/1e6:7.1f} GB/s)")
