@@ -59,6 +59,18 @@ def cpu_baseline(seconds_budget: float = 20.0):
                 sample=f"{steps} oracle train steps (fwd+bwd, torch fp32) of {n} panoramas = {n * 4} images, TinyViT-21M-224 + 12647-cell head, {dt:.1f} s")
 
 
+def pmc_traffic(kernel_class):
+    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+    separate runs of this same command; profiles/r01_hbm_traffic_pmc.json).  PMC collection cannot run inside the timed
+    process, so this is the offline measurement of the same workload; None when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["per_kernel_class"][kernel_class]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +162,7 @@ def main():
             if name == "gemm":
                 ach = fl.value / max(ms.value, 1e-9) / 1e9
                 roof = dict(bound="mfma", kernel="gemm_nt_kernel", achieved=round(ach, 2), peak=2500.0, unit="TFLOP/s",
-                            frac=round(ach / 2500.0, 4), traffic=None, launches=n.value // args.steps,
+                            frac=round(ach / 2500.0, 4), traffic=pmc_traffic("gemm_nt"), launches=n.value // args.steps,
                             avg_launch_us=round(1e3 * ms.value / max(n.value, 1), 2),
                             gemm_ms_per_step=round(ms.value / args.steps, 3),
                             algorithmic_gflop_per_launch=round(fl.value / max(n.value, 1) / 1e9, 3))

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Secondary numbers of SURVEY.md 8(d) on one MI355X (the headline c2 line is bench.py's):
+  c1  TinyViT-5M-224, batch 8, forward + geocell hard-CE + backward + AdamW (panorama=False)
+  c2u TinyViT-21M-224, 256 panoramas, every parameter trainable
+  c4  CLIP ViT-B/32 vision tower, batch 1024, inference (random weights, bf16 MFMA)
+  c5  SuperGuessr head (serving) + ProtoRefiner on precomputed embeddings, batch 4096
+Prints one JSON object per case.  Synthetic inputs as in bench.py."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from geoguessr_ai_amd import _lib as L
+from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+from geoguessr_ai_amd.optim import AdamW
+
+L.require_gpu()
+dev = torch.device("cuda", 0)
+cases = sys.argv[1:] or ["c1", "c2u", "c4", "c5"]
+
+
+def timed(fn, steps, warmup):
+    for _ in range(warmup): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def train_case(name, model_name, n, panorama, unfrozen, smooth, steps, warmup):
+    torch.manual_seed(0)
+    base = TinyViTAdapter(model_name, pretrained=False)
+    model = SuperGuessr(base, panorama=panorama, should_smooth_labels=smooth, serving=False).to(dev).train()
+    if unfrozen: base.unfreeze_all()
+    opt = AdamW(model, lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    x = torch.randn((n, 4, 3, 224, 224) if panorama else (n, 3, 224, 224), device=dev, generator=g)
+    lab = torch.stack([torch.rand(n, device=dev, generator=g) * 360 - 180, torch.rand(n, device=dev, generator=g) * 180 - 90], 1)
+    clf = torch.randint(0, model.num_cells, (n,), device=dev, generator=g)
+    def step():
+        out = model(pixel_values=x, labels=lab) if smooth else model(pixel_values=x, labels=lab, labels_clf=clf)   # soft / hard CE
+        out.loss.backward(); opt.step(); opt.zero_grad()
+    dt = timed(step, steps, warmup)
+    imgs = n * (4 if panorama else 1)
+    print(json.dumps(dict(case=name, model=model_name, images_per_step=imgs, ms_per_step=round(dt * 1e3, 3), images_per_s=round(imgs / dt, 1),
+                          trainable="all" if unfrozen else "freeze_all_but_last_stage")))
+    del model, base, opt, x
+
+
+if "c1" in cases:
+    train_case("c1", "tiny_vit_5m_224", 8, False, False, False, 20, 5)
+if "c2u" in cases:
+    train_case("c2-unfrozen", "tiny_vit_21m_224", 256, True, True, True, 5, 2)
+if "c4" in cases:
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
+    tower = CLIPVisionTower("openai/clip-vit-base-patch32").to(dev).eval()
+    x = torch.randn(1024, 3, 224, 224, device=dev)
+    with torch.no_grad():
+        dt = timed(lambda: tower(pixel_values=x), 5, 2)
+    print(json.dumps(dict(case="c4", model="CLIP ViT-B/32 vision tower (random weights)", images_per_step=1024, ms_per_step=round(dt * 1e3, 3),
+                          images_per_s=round(1024 / dt, 1))))
+    del tower, x
+if "c5" in cases:
+    torch.manual_seed(0)
+    Bq, D, K = 4096, 576, 12647
+    head = SuperGuessr(None, panorama=True, serving=True, embed_dim=D).to(dev).eval()
+    rng = np.random.default_rng(0)
+    counts = rng.poisson(4.0, K)
+    gi = np.repeat(np.arange(K), counts)
+    refiner = ProtoRefiner.from_clusters(gi, rng.standard_normal((len(gi), D), dtype=np.float32), rng.uniform(-180, 180, len(gi)).astype(np.float32),
+                                         rng.uniform(-90, 90, len(gi)).astype(np.float32), K, topk=5).to(dev).eval()
+    emb = torch.randn(Bq, 4, D, device=dev)
+    def full():
+        with torch.no_grad():
+            llh, topk, e = head(embedding=emb)               # serving eval: (pred_LLH, TopK(values, indices), embedding)
+            refiner(e, llh, topk.indices, topk.values)
+    dt = timed(full, 10, 3)
+    print(json.dumps(dict(case="c5", what="SuperGuessr serving head + ProtoRefiner on precomputed embeddings", batch=Bq, prototypes=int(len(gi)),
+                          ms_per_step=round(dt * 1e3, 3), samples_per_s=round(Bq / dt, 1))))
