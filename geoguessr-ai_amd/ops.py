@@ -406,3 +406,31 @@ def geoguessr_score(pred_llh, true_llh):
     s = torch.empty((N,), dtype=F32, device=pred_llh.device)
     L.check(L.lib().gg_geoguessr_score(_p(pred_llh, F32), _p(true_llh, F32), N, _p(d), _p(s), L.stream()), "gg_geoguessr_score")
     return d, s
+
+
+def preprocess_bilinear(images, size=None, mean=None, std=None):
+    """Batch conditioning of the training loop (main_coordinator_idun_s3.py:337-381) as one kernel: bilinear resize
+    (align_corners=False) -> /255 for uint8 input -> (x - mean)/std.  images: (N,3,H,W) or (B,V,3,H,W), f32 or u8, on the GPU."""
+    L.require_gpu()
+    assert images.is_cuda and images.dtype in (torch.float32, torch.uint8), "preprocess_bilinear: CUDA f32 / u8 images"
+    lead = images.shape[:-3]
+    c, h, w = images.shape[-3:]
+    assert c == 3, "preprocess_bilinear: 3-channel images"
+    x = images.contiguous().view(-1, 3, h, w)
+    hd, wd = (h, w) if size is None else (int(size[0]), int(size[1]))
+    out = torch.empty((x.shape[0], 3, hd, wd), dtype=F32, device=images.device)
+    m3 = (C.c_float * 3)(*[float(v) for v in mean]) if mean is not None else None
+    s3 = (C.c_float * 3)(*[float(v) for v in std]) if std is not None else None
+    L.check(L.lib().gg_preprocess_bilinear(_p(x), int(images.dtype == torch.uint8), x.shape[0], h, w, _p(out), hd, wd, m3, s3,
+                                           L.stream()), "gg_preprocess_bilinear")
+    return out.view(*lead, 3, hd, wd)
+
+
+def segment_mean(emb, ptr, member):
+    """out[k] = mean of emb[member[ptr[k]:ptr[k+1]]] in list order (prototype building); zeros for empty segments."""
+    L.require_gpu()
+    K = ptr.numel() - 1
+    out = torch.empty((K, emb.shape[1]), dtype=F32, device=emb.device)
+    L.check(L.lib().gg_segment_mean(_p(emb, F32, "emb"), emb.stride(0), _p(ptr, I64, "ptr"), _p(member, I64, "member"), K, emb.shape[1],
+                                    _p(out), L.stream()), "gg_segment_mean")
+    return out

@@ -236,6 +236,17 @@ int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params,
 /* debug / parity: byte offset of a named saved activation inside the workspace (host) */
 int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes);
 
+/* ---------------------------------------------------------------- either side of the encoder ("next" rows)
+ * f3: the batch loop's input conditioning as one kernel (main_coordinator_idun_s3.py:337-381): bilinear resize
+ * (F.interpolate align_corners=False) -> /255 when the source is uint8 -> (x - mean)/std.  src: NCHW f32 or u8 [N,3,Hs,Ws];
+ * dst: NCHW f32 [N,3,Hd,Wd]; mean3/std3: HOST float[3] or both NULL (no normalisation). */
+int gg_preprocess_bilinear(const void* src, int src_u8, int N, int Hs, int Ws, float* dst, int Hd, int Wd,
+                           const float* mean3 /* host */, const float* std3 /* host */, void* stream);
+/* f2: prototype building (models/proto_refiner.py:461-517): per-segment mean of embedding rows, CSR segments ptr[K+1] over the
+ * member row list, summed in list order in fp32 (the reference's running sum), zeros for empty segments. */
+int gg_segment_mean(const float* emb, int64_t ld, const int64_t* ptr, const int64_t* member, int num_segments, int D, float* out,
+                    void* stream);
+
 /* ---------------------------------------------------------------- CLIP vision tower, inference
  * (transformers CLIPVisionModel as used by pretrain/clip_embedder.py:63-65: mean over all tokens of last_hidden_state) */
 typedef struct GgClipCfg {

@@ -2,6 +2,7 @@
 same (bf16-representable) inputs.  Tolerances: bf16 outputs carry one rounding of 2^-9 relative; contractions are
 accumulated in fp32 on both sides.  All tests call through ``libgg.so``."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -446,3 +447,39 @@ def test_scoring(ops):
     dref = G.haversine_np_score(a[:, 1], a[:, 0], b[:, 1], b[:, 0])
     np.testing.assert_allclose(d.cpu().numpy(), dref, rtol=1e-5)
     np.testing.assert_allclose(s.cpu().numpy(), G.geoguessr_score(dref), rtol=1e-4)
+
+
+def test_preprocess_bilinear_matches_reference_golden(ops, golden_dir):
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for name in ("pano_down", "single_up", "same_size", "resize_only"):
+        size = tuple(int(v) for v in g[name + ".size"])
+        norm = bool(g[name + ".norm"][0])
+        y = ops.preprocess_bilinear(dev(torch.from_numpy(g[name + ".x"])), None if size[0] < 0 else size,
+                                    mean if norm else None, std if norm else None)
+        ref = torch.from_numpy(g[name + ".y"])
+        assert tuple(y.shape) == tuple(ref.shape)
+        close(y, ref, rtol=0, atol=1e-5, what="preprocess " + name)          # fp32, FMA contraction only
+    u8 = torch.randint(0, 256, (2, 3, 9, 7), dtype=torch.uint8)
+    from oracle import preprocess_ref as P
+    close(ops.preprocess_bilinear(u8.cuda(), (12, 12), mean, std), torch.from_numpy(P.prepare_batch(u8.numpy(), (12, 12), mean, std)),
+          rtol=0, atol=1e-5, what="preprocess u8")
+
+
+def test_build_prototypes_matches_reference_golden(golden_dir):
+    from geoguessr_ai_amd.embedding_store import build_prototypes
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    ptr, member = g["proto.ptr"], g["proto.member"]
+    cluster = np.full(g["proto.emb"].shape[0], -1, np.int64)
+    for k in range(len(ptr) - 1):
+        cluster[member[ptr[k]:ptr[k + 1]]] = k
+    # members are accumulated in increasing panorama order; reorder the golden's member lists the same way
+    from oracle import preprocess_ref as P
+    order = np.concatenate([np.sort(member[ptr[k]:ptr[k + 1]]) for k in range(len(ptr) - 1)]).astype(np.int64)
+    want = P.cluster_mean(g["proto.pano_vec"], ptr, order)
+    protos, counts = build_prototypes(torch.from_numpy(g["proto.emb"]).cuda(), cluster, num_clusters=len(ptr) - 1)
+    np.testing.assert_array_equal(counts.numpy(), np.diff(ptr))
+    np.testing.assert_allclose(protos.cpu().numpy(), want, rtol=0, atol=2e-7)      # view mean is torch's, the segment sum is ordered
+    import geoguessr_ai_amd.ops as O
+    got = O.segment_mean(torch.from_numpy(g["proto.pano_vec"]).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(member).cuda())
+    np.testing.assert_array_equal(got.cpu().numpy(), g["proto.out"])              # same fp32 additions in the same order: bit-exact

@@ -212,3 +212,50 @@ def test_no_cpu_fallback():
     m = SuperGuessr(base_model=None, panorama=True, embed_dim=576)          # parameters left on the CPU
     with pytest.raises(L.GgError):
         m(embedding=torch.zeros(2, 4, 576), labels_clf=torch.zeros(2, dtype=torch.int64))
+
+
+def test_checkpoint_round_trip_in_reference_format(adapter5m, centroids, tmp_path):
+    """make_state / load_model_state / AdamW <-> torch.optim.AdamW state-dict layout (reference checkpoint compatibility, f4):
+    a model + optimizer restored from the saved dict continue on the same trajectory (the attention-bias gradient is summed
+    with atomics, so two runs agree to rounding, not bit for bit)."""
+    from geoguessr_ai_amd.checkpoint import make_state, load_model_state, adamw_state_from_torch, CheckpointKeeper
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.optim import AdamW
+
+    def build():
+        torch.manual_seed(3)
+        base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False)
+        return SuperGuessr(base, panorama=True, should_smooth_labels=True, centroids=centroids[:64]).cuda().train()
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(2, 4, 3, 224, 224, device="cuda", generator=g)
+    lab = torch.tensor([[10.0, 50.0], [-70.0, -20.0]], device="cuda")
+
+    def step(model, opt):
+        out = model(pixel_values=x, labels=lab)
+        out.loss.backward(); opt.step(); opt.zero_grad()
+
+    m1 = build(); o1 = AdamW(m1, lr=1e-3)
+    for _ in range(2):
+        step(m1, o1)
+    state = make_state(m1, o1, None, epoch=0, global_step=2, best_value=1.0, monitored_value=1.0, config={"lr": 1e-3})
+    sd = state["optimizer_state_dict"]
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(list(m1.parameters()))))
+    trainable = [i for i, p in enumerate(m1.parameters()) if p.requires_grad]
+    assert sorted(sd["state"]) == trainable and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd["state"].values())
+    assert all(k.startswith(("base_model.backbone.", "cell_layer.", "geocell_centroid_coords")) for k in state["model_state_dict"])
+    keeper = CheckpointKeeper(str(tmp_path), keep_last_n=1)
+    paths = keeper.update(state, 0, 1.0)
+    m2 = build()
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.add_(0.5) if p.requires_grad else None          # make sure the load really restores values
+    rep = load_model_state(m2, paths["last"])
+    assert not rep["skipped"]
+    o2 = AdamW(m2, lr=5.0)
+    adamw_state_from_torch(o2, torch.load(paths["last"], weights_only=False)["optimizer_state_dict"])
+    assert o2.step_count == 2 and o2.param_groups[0]["lr"] == 1e-3
+    step(m1, o1); step(m2, o2)
+    for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n1
