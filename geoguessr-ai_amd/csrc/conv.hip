@@ -211,26 +211,30 @@ template <> struct DwWin<true> {
     static __device__ __forceinline__ f32x2 get(E e) { return dw_unpack2(e); }
 };
 struct DwWalkFuse {
+    const float* in_stat; const float* in_gamma; const float* in_beta; int in_act;  // IN1
     const bf16* in2; const float* in_coef;                                         // IN2
     const bf16* ep_y; const float* ep_stat; const float* ep_gamma; const float* ep_beta; int ep_act;   // EPI
 };
-template <bool IN2, bool EPI, int NQ>
+template <int IN, bool EPI, int NQ>
 __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt,
                                                                               bf16* __restrict__ y, int H, int W, int C, int CG, int PX, int nbx,
                                                                               int flip, float* __restrict__ colstats, DwWalkFuse f) {
+    constexpr bool IN2 = IN == 2;              // backward: BatchNorm-backward apply of (x, in2) while loading
+    constexpr bool IN1 = IN == 1;              // forward: act(BatchNorm(x)) of the producer ConvNorm while loading (ctab rows 0 / 1 = scale / shift)
     typedef typename DwRaw<NQ>::T Raw;
-    typedef typename DwWin<IN2>::E WinE;
+    typedef typename DwWin<IN == 2>::E WinE;
     constexpr int NC = 2 * NQ;                 // channels per thread
     extern __shared__ float dw_red[];          // [PX][2][C] statistics scratch; then (fusions) 16 coefficient rows [C]
     float* ctab = dw_red + PX * 2 * C;         // [0..2] in coef a,b,c   [3] ep scale  [4] ep shift  [5] ep rstd  [6] ep -mean*rstd  [7..15] taps
-    constexpr bool TAPS_LDS = IN2 || EPI;      // the fused variants have no registers left for the tap values
+    constexpr bool TAPS_LDS = IN != 0 || EPI;      // the fused variants have no registers left for the tap values
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
     const int bx = blockIdx.x % nbx, b = blockIdx.x / nbx;
     const int xo = bx * PX + px;
     const int c0 = cg * NC;
-    if (IN2 || EPI) {
+    if (IN != 0 || EPI) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             if (IN2) { ctab[c] = f.in_coef[c]; ctab[C + c] = f.in_coef[C + c]; ctab[2 * C + c] = f.in_coef[2 * C + c]; }
+            if (IN1) { const float sc = f.in_stat[C + c] * f.in_gamma[c]; ctab[c] = sc; ctab[C + c] = f.in_beta[c] - f.in_stat[c] * sc; }
             if (EPI) {
                 const float mu = f.ep_stat[c], rstd = f.ep_stat[C + c], sc = rstd * f.ep_gamma[c];
                 ctab[3 * C + c] = sc; ctab[4 * C + c] = f.ep_beta[c] - mu * sc; ctab[5 * C + c] = rstd; ctab[6 * C + c] = -mu * rstd;
@@ -285,11 +289,24 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
     };
     // raw row -> window slot; IN2: the BatchNorm-backward apply on the way (positions outside the image stay exactly 0)
     auto fill = [&](int iy, const Raw (&raw)[3], const Raw (&raw2)[3], WinE (&slot)[3][NQ]) {
-        if constexpr (!IN2) {
+        if constexpr (IN == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) slot[k][q] = dw_unpack2(raw[k][q]);
+        } else if constexpr (IN1) {
+            const bool rok = iy >= 0 && iy < H;
+            const bool in_gelu = f.in_act == GG_ACT_GELU;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x2 sc = ctab2(0, q), sh = ctab2(1, q);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // the bf16 rounding of the activation tensor the unfused path stores is kept (same numerics)
+                    const f32x2 r = gg_act_v2(dw_unpack2(raw[k][q]) * sc + sh, in_gelu);
+                    slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? dw_unpack2(dw_pack2(r)) : (f32x2)(0.f);
+                }
+            }
         } else {
             const bool rok = iy >= 0 && iy < H;
 #pragma unroll
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) win[0][k][q] = DwWin<IN2>::zero();          // row -1
+        for (int q = 0; q < NQ; ++q) win[0][k][q] = DwWin<IN == 2>::zero();          // row -1
     load_row(0, raw, raw2);
     fill(0, raw, raw2, win[1]);
     load_row(1, raw, raw2);
@@ -324,7 +341,7 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
     // one output row: slot RC receives input row yy+1 (already in flight), rows yy-1 / yy sit in slots RA / RB
 #define GG_DW_STEP(RA, RB, RC, yy)                                                                                         \
     {                                                                                                                      \
-        if (IN2 || EPI) asm volatile("" : "+v"(cofs));                                                                     \
+        if (IN != 0 || EPI) asm volatile("" : "+v"(cofs));                                                                     \
         fill((yy) + 1, raw, raw2, win[RC]);                                                                                \
         load_row((yy) + 2, raw, raw2);                                                                                     \
         const float live = (yy) < H ? 1.f : 0.f;                                                                           \
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
             _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                \
                 const int rsl = t < 3 ? RA : (t < 6 ? RB : RC);                                                            \
                 const f32x2 tp = TAPS_LDS ? ctab2(7 + t, q) : tap[TAPS_LDS ? 0 : t][q];                                    \
-                a = DwWin<IN2>::get(win[rsl][t % 3][q]) * tp + a;                                                          \
+                a = DwWin<IN == 2>::get(win[rsl][t % 3][q]) * tp + a;                                                          \
             }                                                                                                              \
             acc[q] = a;                                                                                                    \
         }                                                                                                                  \
@@ -722,19 +739,20 @@ static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, in
     DwWalkFuse f;
     memset(&f, 0, sizeof(f));
     if (fuse) f = *fuse;
-    const bool in2 = f.in_coef != nullptr, epi = f.ep_y != nullptr;
-    const int nc = ((in2 || epi) && dw_walk_fused4(C)) ? 4 : 8;      // every fused variant: 4 channels per thread
+    const bool in2 = f.in_coef != nullptr, epi = f.ep_y != nullptr, in1 = f.in_stat != nullptr;
+    const int nc = ((in1 || in2 || epi) && dw_walk_fused4(C)) ? 4 : 8;      // every fused variant: 4 channels per thread
     const int CG = C / nc, PX = dw_walk_px(C, nc), nbx = (int)gg_cdiv(W, PX);
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 2.0 * B * C * (double)H * W * (2 + in2 + epi), stream);
-    const size_t lds = ((size_t)PX * 2 * C + ((in2 || epi) ? 16 * (size_t)C : 0)) * sizeof(float);
+    const size_t lds = ((size_t)PX * 2 * C + ((in1 || in2 || epi) ? 16 * (size_t)C : 0)) * sizeof(float);
     GG_CHECK(lds <= 64 * 1024, "dwconv: C=%d needs %zu bytes of LDS", C, lds);
     const dim3 grid((unsigned)(B * nbx)), block(CG * PX);
 #define GG_DW_WALK(I_, E_, N_) hipLaunchKernelGGL((dwconv3x3_walk_kernel<I_, E_, N_>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, \
                                                   (bf16*)y, H, W, C, CG, PX, nbx, flip, colstats, f)
-    if (in2 && epi) { if (nc == 4) GG_DW_WALK(true, true, 2); else GG_DW_WALK(true, true, 4); }
-    else if (in2) { if (nc == 4) GG_DW_WALK(true, false, 2); else GG_DW_WALK(true, false, 4); }
-    else if (epi) { if (nc == 4) GG_DW_WALK(false, true, 2); else GG_DW_WALK(false, true, 4); }
-    else GG_DW_WALK(false, false, 4);
+    if (in1) { GG_CHECK(!in2 && !epi, "dwconv: producer fusion excludes the backward fusions"); if (nc == 4) GG_DW_WALK(1, false, 2); else GG_DW_WALK(1, false, 4); }
+    else if (in2 && epi) { if (nc == 4) GG_DW_WALK(2, true, 2); else GG_DW_WALK(2, true, 4); }
+    else if (in2) { if (nc == 4) GG_DW_WALK(2, false, 2); else GG_DW_WALK(2, false, 4); }
+    else if (epi) { if (nc == 4) GG_DW_WALK(0, true, 2); else GG_DW_WALK(0, true, 4); }
+    else GG_DW_WALK(0, false, 4);
 #undef GG_DW_WALK
     GG_LAUNCH_CHECK();
     return 0;
@@ -778,6 +796,12 @@ extern "C" int gg_dwconv3x3_fwd_fused(const void* x, const float* in_stat, const
                                       const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream) {
     GG_CHECK(x && wt && y && in_stat && in_gamma && in_beta && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2),
              "gg_dwconv3x3_fwd_fused: bad args");
+    if (dw_walk_ok(C, stride)) {
+        DwWalkFuse wf;
+        memset(&wf, 0, sizeof(wf));
+        wf.in_stat = in_stat; wf.in_gamma = in_gamma; wf.in_beta = in_beta; wf.in_act = in_act;
+        return dwconv_walk_launch(x, wt, y, B, H, W, C, 0, colstats, stream, &wf);
+    }
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, in_stat, in_gamma, in_beta, in_act, colstats, stream);
 }
 // stride-1 data gradient with the BatchNorm-backward passes on both sides folded in (see the kernel comment):
@@ -791,6 +815,7 @@ extern "C" int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, 
     GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_part), "gg_dwconv3x3_bwd_data_fused: epilogue needs stat/gamma/beta/partials");
     if (dw_walk_ok(C, 1)) {
         DwWalkFuse wf;
+        memset(&wf, 0, sizeof(wf));
         wf.in2 = in_coef ? (const bf16*)y_in : nullptr; wf.in_coef = in_coef;
         wf.ep_y = (const bf16*)ep_y; wf.ep_stat = ep_stat; wf.ep_gamma = ep_gamma; wf.ep_beta = ep_beta; wf.ep_act = ep_act;
         return dwconv_walk_launch(dz_in, wt, out, B, H, W, C, 1, ep_y ? ep_part : nullptr, stream, &wf);

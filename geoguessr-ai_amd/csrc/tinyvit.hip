@@ -336,8 +336,9 @@ struct Exec {
     const char* wc; char* ws; hipStream_t st;
     const float* drop;   // [slots][B] or null
     float* grads; const uint8_t* trainable;
-    // Fusing BatchNorm+GELU of the producer into the depthwise conv's staging removes one [M,C] write+read but makes the
-    // conv VALU-bound (erf on tile + halo): measured +6.6 ms conv vs -3.1 ms elementwise at 1024 images -> off by default.
+    // Fusing BatchNorm+GELU of the producer into the depthwise conv's input load removes one [M,C] write+read, but each input is
+    // loaded (and transformed) by its three neighbouring columns: the erf work triples and the conv turns VALU-bound
+    // (measured at 1024 images: +4.7 ms conv vs -2.7 ms elementwise) -> off by default.
     bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
     // Frozen depthwise taps: the data gradient forms BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) while it loads its
     // input, and (MBConv) emits dz = da*act'(BN(y)) + the reduce sums of the ConvNorm in front: apply and reduce passes and
@@ -433,7 +434,7 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
                                   c.w.C, stride, part, e.st));
-    return bn_stats(e, c.bn, a, gg_dwconv_tiled_stat_rows(B, Ho), (int64_t)B * Ho * Wo);
+    return bn_stats(e, c.bn, a, stride == 1 ? gg_dwconv_fused_stat_rows(B, Ho, Wo, c.w.C, 1) : gg_dwconv_tiled_stat_rows(B, Ho), (int64_t)B * Ho * Wo);
 }
 static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
                     const float* rowscale = nullptr, int rps = 0) {
