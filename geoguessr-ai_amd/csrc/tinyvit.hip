@@ -741,11 +741,8 @@ static int backward_impl(Exec& e, const float* d_out) {
         bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
         // out = gelu(x + s*BN3(y3)):  dz(=dpre, also the skip gradient) -> t_b, dy3 -> t_a
         GG_TRY(bn_bwd(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, dx, t_b, t_a, e.A(a.x), s0, rps0));
-        if (e.tr(l.c3.w.t_w)) {
-            // the forward may have run conv3 through its BatchNorm prologue (a2 never written): re-form it for the weight gradient
-            if (e.fuse_pro) GG_TRY(bn_apply(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, e.A(a.a2)));
-            GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
-        }
+        // (a2 exists: the forward only skips it when its `trainable` mask freezes conv3 -- the two calls must get the same mask)
+        if (e.tr(l.c3.w.t_w)) GG_TRY(dense_wgrad(e, l.c3.w, e.A(a.a2), mid, t_a, d[0], M0, nullptr, 0, t_c, t_d, false));
         if (e.fuse_bngemm && !e.tr(l.c1.w.t_w) && !e.tr(l.c2.w.t_w) && mid % 64 == 0) {
             GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));                   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));

@@ -288,9 +288,11 @@ class TinyVitBackbone(_Tree):
         out = torch.empty((B, self.num_features), dtype=torch.float32, device=x.device)
         if drop_scales is not None:
             assert drop_scales.shape == (self.num_drop_slots, B) and drop_scales.dtype == torch.float32
+        mask = self.trainable_mask() if training else None      # the forward drops activations only frozen weights would need
+        self._fwd_mask = mask
         L.check(L.lib().gg_tinyvit_forward(C.byref(self.cfg), B, int(training), L.ptr(self._flat), L.ptr(self._flat_buf),
                                            L.ptr(self._counters), L.ptr(self._wcache), L.ptr(x), L.ptr(drop_scales), L.ptr(ws),
-                                           L.ptr(out), self.trainable_mask() if training else None, L.stream()),
+                                           L.ptr(out), mask, L.stream()),
                 "gg_tinyvit_forward")
         if training:
             self._counters += 1          # num_batches_tracked (int64 bookkeeping)
@@ -303,6 +305,11 @@ class TinyVitBackbone(_Tree):
         fg = self.attach_grads()
         ws = self._ws[True]
         mask = self.trainable_mask()
+        if getattr(self, "_fwd_mask", None) is not None and mask != self._fwd_mask:
+            extra = [t["name"] for t, a, b in zip([t for t in self.table], mask, self._fwd_mask) if a and not b]
+            if extra:
+                raise L.GgError("requires_grad was switched on between forward and backward for " + ", ".join(extra[:4]) +
+                                " ...: the training forward fused away activations their weight gradients need; run the forward again")
         L.check(L.lib().gg_tinyvit_backward(C.byref(self.cfg), B, L.ptr(self._flat), L.ptr(self._wcache), L.ptr(drop), L.ptr(ws),
                                             L.ptr(d_out.contiguous(), torch.float32, "d_out"), L.ptr(fg), mask, L.stream()),
                 "gg_tinyvit_backward")

@@ -225,7 +225,8 @@ int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, voi
 /* x: f32 NCHW (batch,in_chans,img,img).  drop_scales: f32 [num_drop_slots][batch] = keep/(1-p) or NULL.
  * out: f32 (batch, embed_dims[3]).  training: batch-stat BN + running-stat update + activations kept for backward. */
 /* trainable: host uint8[num_tensors] or NULL -- the freeze policy the backward will run with; activations that only a frozen
- * weight's gradient would read are fused away (e.g. MBConv act2 goes through conv3's BatchNorm prologue). */
+ * weight's gradient would read are fused away (e.g. MBConv act2 goes through conv3's BatchNorm prologue), so
+ * gg_tinyvit_backward must be given the SAME mask (NULL here = keep everything = any backward mask is fine). */
 int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int training, const float* params, float* buffers, int64_t* counters,
                        const void* wcache, const float* x, const float* drop_scales, void* workspace, float* out,
                        const uint8_t* trainable /* host */, void* stream);
