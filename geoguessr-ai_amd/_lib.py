@@ -33,7 +33,8 @@ class AttnArgs(C.Structure):
                 ("head_stride", C.c_int), ("head_dim", C.c_int), ("num_heads", C.c_int), ("num_windows", C.c_int),
                 ("tokens_per_window", C.c_int), ("window_size", C.c_int), ("map_h", C.c_int), ("map_w", C.c_int),
                 ("bias", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int64),
-                ("dout", C.c_void_p), ("lddo", C.c_int64), ("dqkv", C.c_void_p), ("dbias", C.c_void_p), ("lse", C.c_void_p)]
+                ("dout", C.c_void_p), ("lddo", C.c_int64), ("dqkv", C.c_void_p), ("dbias", C.c_void_p), ("dbias_scratch", C.c_void_p),
+                ("lse", C.c_void_p)]
 
 
 class GeoHeadArgs(C.Structure):

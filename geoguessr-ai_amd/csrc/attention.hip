@@ -28,7 +28,8 @@ struct AttnParams {
     // backward
     const bf16* dout; int64_t lddo;   // [tokens, lddo]
     bf16* dqkv;                       // same layout as qkv
-    float* dbias;                     // [nh][nbias] accumulated with atomics, or null
+    float* dbias;                     // [nh][nbias] accumulated into, or null
+    float* dbias_part;                // [num_windows + 64][nh][nbias] per-window partials (two-stage deterministic sum) or null: atomics
     float* lse;                       // [tokens][nh] log-sum-exp of the scaled+biased scores (fwd writes, bwd reads)
 };
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
 // ------------------------------------------------------------------------------------------- backward
 // Flash-style: P is recomputed from the forward's per-row log-sum-exp, delta_q = sum_d dO[q][d] O[q][d] comes from the
 // saved forward output, so no score row has to stay in registers (3+ waves per SIMD instead of 1).
-template <int D, int NKT>
+template <int D, int NKT, bool DBIAS>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     constexpr int Np = NKT * 16;
     constexpr int RS = D + 8;
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     bf16* const Ks = buf0; bf16* const Vs = buf1;                                       // phase 1
     bf16* const Qs = TWO_PHASE ? buf0 : buf2; bf16* const dOs = TWO_PHASE ? buf1 : buf3;   // phase 2
     __shared__ __attribute__((aligned(16))) float row_lse[Np], row_delta[Np];
-    __shared__ float dbias_s[256];
+    // bias-gradient bins, privatised 8 ways by query lane so that the LDS atomics of one instruction rarely collide (a single
+    // 196-bin table took 64-way conflicts and tripled the kernel time); compiled in only for trainable attention_biases
+    constexpr int DBC = 8;
+    __shared__ float dbias_s[DBIAS ? DBC * 256 : 1];
     __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];   // window coordinates: bias-gradient binning only
 
     const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             cj[t] = p.ws ? (unsigned char)(tt - ti * p.ws) : 0;
             row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
         }
-        for (int t = threadIdx.x; t < 256; t += blockDim.x) dbias_s[t] = 0.f;
+        if (DBIAS) { for (int t = threadIdx.x; t < DBC * 256; t += blockDim.x) dbias_s[t] = 0.f; }
         attn_store_rows<D, Np>(Ks, RS, kr);
         attn_store_rows<D, Np>(Vs, RS, vr);
         if constexpr (!TWO_PHASE) {
@@ -410,13 +414,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                     const float pr = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -lq2));      // padded keys: 2^-inf = 0
                     acc2[r] = pr * (acc2[r] - delta_q);
                 }
-                if (p.dbias && qtok >= 0) {     // bias gradient, binned by |di|,|dj| (only the trainable last stage takes this path)
+                if (DBIAS && qtok >= 0) {       // bias gradient, binned by |di|,|dj|
                     const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
                     const uchar4 kcj = *reinterpret_cast<const uchar4*>(&cj[key0]);
                     const int kcis[4] = {kci.x, kci.y, kci.z, kci.w}, kcjs[4] = {kcj.x, kcj.y, kcj.z, kcj.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (key0 + r < p.N) atomicAdd(&dbias_s[abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r])], acc2[r]);
+                        if (key0 + r < p.N) atomicAdd(&dbias_s[(lr & (DBC - 1)) * 256 + abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r])], acc2[r]);
                 }
                 dst[u] = acc2;
             }
@@ -528,10 +532,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             }
         }
     }
-    if (p.dbias) {
+    if (DBIAS) {
         __syncthreads();
-        for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) atomicAdd(&p.dbias[h * p.nbias + t], dbias_s[t]);
+        for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < DBC; ++c) sum += dbias_s[c * 256 + t];
+            if (p.dbias_part) p.dbias_part[((int64_t)w * p.nh + h) * p.nbias + t] = sum;       // deterministic: reduced over windows afterwards
+            else atomicAdd(&p.dbias[h * p.nbias + t], sum);
+        }
     }
+}
+// dbias[h][t] += sum over the (folded) window rows of part[row][h][t]
+__global__ void attn_dbias_final_kernel(const float* __restrict__ rows, int nrows, int W, float* __restrict__ dbias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W) return;
+    double s = 0.0;
+    for (int r = 0; r < nrows; ++r) s += (double)rows[(int64_t)r * W + i];
+    dbias[i] += (float)s;
 }
 
 // ------------------------------------------------------------------------------------------- host
@@ -561,7 +579,7 @@ static int attn_fill(AttnParams& p, const GgAttnArgs* a, const char* who) {
     p.nWx = a->window_size ? a->map_w / a->window_size : 1;
     p.nWy = a->window_size ? a->map_h / a->window_size : 1;
     p.N = a->tokens_per_window; p.nh = a->num_heads; p.scale = a->scale;
-    p.dout = (const bf16*)a->dout; p.lddo = a->lddo; p.dqkv = (bf16*)a->dqkv; p.dbias = a->dbias; p.lse = a->lse;
+    p.dout = (const bf16*)a->dout; p.lddo = a->lddo; p.dqkv = (bf16*)a->dqkv; p.dbias = a->dbias; p.dbias_part = a->dbias ? a->dbias_scratch : nullptr; p.lse = a->lse;
     return 0;
 }
 static int attn_nkt(int N) { return N <= 64 ? 4 : (N <= 160 ? 10 : (N <= 224 ? 14 : 16)); }
@@ -604,9 +622,19 @@ extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 16.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
     const int nkt = attn_nkt(p.N);
-#define GG_BWD(K_) hipLaunchKernelGGL((attn_bwd_kernel<32, K_>), grid, block, 0, s, p)
+#define GG_BWD(K_)                                                                                       \
+    do {                                                                                                 \
+        if (p.dbias) hipLaunchKernelGGL((attn_bwd_kernel<32, K_, true>), grid, block, 0, s, p);          \
+        else hipLaunchKernelGGL((attn_bwd_kernel<32, K_, false>), grid, block, 0, s, p);                 \
+    } while (0)
     if (nkt == 4) GG_BWD(4); else if (nkt == 10) GG_BWD(10); else if (nkt == 14) GG_BWD(14); else GG_BWD(16);
 #undef GG_BWD
+    if (p.dbias && p.dbias_part) {
+        const int Wd = p.nh * p.nbias;
+        const float* rows; int nrows;
+        gg_reduce_rows(p.dbias_part, a->num_windows, Wd, s, &rows, &nrows);
+        hipLaunchKernelGGL(attn_dbias_final_kernel, dim3((unsigned)gg_cdiv(Wd, 256)), dim3(256), 0, s, rows, nrows, Wd, p.dbias);
+    }
     GG_LAUNCH_CHECK();
     return 0;
 }

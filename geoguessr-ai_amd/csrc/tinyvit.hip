@@ -686,6 +686,8 @@ static int backward_impl(Exec& e, const float* d_out) {
             at.bias = e.wc + l.bias_full; at.scale = kAttnScale;
             at.dout = t_a; at.lddo = C; at.dqkv = t_b; at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
             at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
+            if (at.dbias && (int64_t)(at.num_windows + 64) * st.heads * st.ws * st.ws * 4 <= ((int64_t)64 << 20))
+                at.dbias_scratch = e.F(L.splitk);      // per-window partials -> deterministic second stage
             GG_TRY(gg_attention_bwd(&at, e.st));
             // da = dqkv . Wqkv                                         -> t_a  [M, C]
             GG_TRY(gemm(e, t_b, 3 * C, e.Wt(l.qkv), l.qkv.Np, t_a, C, M, C, 3 * C));

@@ -353,6 +353,10 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
     dqkv = torch.zeros_like(qkv)
     dbias = torch.zeros_like(bias) if (want_dbias and bias is not None) else None
     a.dout, a.lddo, a.dqkv, a.dbias = _p(dout, BF16, "dout"), dout.stride(0), _p(dqkv), _p(dbias)
+    scratch = None
+    if dbias is not None:      # per-window partials, summed deterministically in a second stage
+        scratch = torch.empty(((num_windows + 64) * num_heads * window_size * window_size,), dtype=F32, device=qkv.device)
+        a.dbias_scratch = _p(scratch)
     a.out, a.ldo, a.lse = _p(out, BF16, "out"), out.stride(0), _p(lse, F32, "lse")
     L.check(L.lib().gg_attention_bwd(C.byref(a), L.stream()), "gg_attention_bwd")
     return dqkv, dbias

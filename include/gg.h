@@ -143,6 +143,8 @@ typedef struct GgAttnArgs {
     const void* dout; int64_t lddo;       /* backward */
     void* dqkv;                           /* backward: same layout as qkv */
     float* dbias;                         /* backward: f32 [num_heads][ws*ws], ACCUMULATED, or NULL */
+    float* dbias_scratch;                 /* optional f32 [(num_windows + 64) * num_heads * ws*ws]: per-window partials, reduced in a
+                                             second deterministic stage; NULL: float atomics */
     float* lse;                           /* f32 [tokens][num_heads] row log-sum-exp: forward writes (may be NULL), backward reads;
                                              backward also reads `out` (the forward result) */
 } GgAttnArgs;
