@@ -610,6 +610,98 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const bf16* __r
     }
 }
 
+// Weight gradient of a stride-1 depthwise 3x3 in the column-walking geometry: dW[c][ky][kx] = sum_{b,y,x} x[b,y+ky-1,x+kx-1,c] dy[b,y,x,c].
+// Thread = (NQ channel pairs, one column), block = PX columns x all channels, walking down every image b = blockIdx.y,
+// blockIdx.y + gridDim.y, ...; the 3x3 window of x sits in registers (as in the forward), 9 x NQ fp32 pair accumulators.
+// One partial row [9][C] per block -> the usual two-stage reduction.  (The gather kernel it replaces issued 9 loads per output
+// and ran at 0.6 TB/s.)
+template <int NQ>
+__global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_wgrad_walk_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                                                    int B, int H, int W, int C, int CG, int PX, int nbx,
+                                                                                    float* __restrict__ part) {
+    typedef typename DwRaw<NQ>::T Raw;
+    constexpr int NC = 2 * NQ;
+    extern __shared__ float wg_red[];          // [PX][9][C]
+    const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
+    const int bx = blockIdx.x;
+    const int xo = bx * PX + px;
+    const int c0 = cg * NC;
+    auto uniform_ptr = [](const bf16* ptr) {
+        const unsigned long long a = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    const int img_bytes = __builtin_amdgcn_readfirstlane(H * W * C * 2);
+    unsigned colo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ix = xo + k - 1;
+        colo[k] = (ix >= 0 && ix < W && xo < W) ? (unsigned)(ix * C + c0) * 2u : DW_COL_OOB;
+    }
+    const unsigned rowb = (unsigned)W * C * 2u;
+    f32x2 acc[9][NQ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[t][q] = (f32x2)(0.f);
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const int64_t img = (int64_t)b * H * W * C;
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + img), 0, img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(dy + img), 0, img_bytes, 0x00020000);
+        auto load_row = [&](int iy, Raw (&raw)[3]) {
+            const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) raw[k] = DwRaw<NQ>::load(rsx, (int)(colo[k] + ro));
+        };
+        auto load_dy = [&](int iy) { return DwRaw<NQ>::load(rsd, (int)(colo[1] + ((iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB))); };
+        f32x2 win[3][3][NQ];
+        Raw raw[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) win[0][k][q] = (f32x2)(0.f);
+        load_row(0, raw);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) win[1][k][q] = dw_unpack2(raw[k][q]);
+        load_row(1, raw);
+        Raw draw = load_dy(0);
+#define GG_WG_STEP(RA, RB, RC, yy)                                                                                           \
+        {                                                                                                                    \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k)                                                                    \
+                _Pragma("unroll") for (int q = 0; q < NQ; ++q) win[RC][k][q] = dw_unpack2(raw[k][q]);                        \
+            load_row((yy) + 2, raw);                                                                                         \
+            f32x2 d[NQ];                                                                                                     \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) d[q] = dw_unpack2(draw[q]);                                       \
+            draw = load_dy((yy) + 1);                                                                                        \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                  \
+                const int rsl = t < 3 ? RA : (t < 6 ? RB : RC);                                                              \
+                _Pragma("unroll") for (int q = 0; q < NQ; ++q) acc[t][q] = win[rsl][t % 3][q] * d[q] + acc[t][q];            \
+            }                                                                                                                \
+        }
+        for (int y0 = 0; y0 < H; y0 += 3) {      // rows past the image read zeros from dy: no contribution
+            GG_WG_STEP(0, 1, 2, y0)
+            GG_WG_STEP(1, 2, 0, y0 + 1)
+            GG_WG_STEP(2, 0, 1, y0 + 2)
+        }
+#undef GG_WG_STEP
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            wg_red[(px * 9 + t) * C + c0 + 2 * q] = acc[t][q].x;
+            wg_red[(px * 9 + t) * C + c0 + 2 * q + 1] = acc[t][q].y;
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < PX; ++k) t += wg_red[k * 9 * C + i];
+        part[((int64_t)blockIdx.y * nbx + bx) * 9 * C + i] = t;
+    }
+}
+
 // dw partials [gridDim.x][9][C]: sum over this block's output pixels of dy * x_tap
 __global__ void dwconv3x3_bwd_weight_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, int B, int H, int W, int C,
                                             int Ho, int Wo, int stride, int CG, int PP, int pix_per_block,
@@ -838,17 +930,43 @@ extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, 
     GG_LAUNCH_CHECK();
     return 0;
 }
+// walking weight-gradient geometry: channels per thread, columns per block (LDS holds [PX][9][C] floats), image groups
+struct WgGeom { int nc, CG, PX, nbx, BG; };
+static WgGeom wg_geom(int B, int W, int C) {
+    WgGeom g;
+    g.nc = (C / 4) <= 256 ? 4 : 8;
+    g.CG = C / g.nc;
+    g.PX = std::max(1, std::min(256 / g.CG, (int)(15360 / (9 * (int64_t)C))));
+    g.nbx = (int)gg_cdiv(W, g.PX);
+    g.BG = std::max(1, std::min(B, 2048 / g.nbx));
+    return g;
+}
 extern "C" int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    return ((int64_t)dw_geom((int64_t)B * Ho * Wo, C, 9 * C).nblocks + GG_REDUCE_SLICES) * 9 * C;
+    const WgGeom w = wg_geom(B, W, C);
+    const int64_t nb = std::max<int64_t>(dw_geom((int64_t)B * Ho * Wo, C, 9 * C).nblocks, (int64_t)w.nbx * w.BG);
+    return (nb + GG_REDUCE_SLICES) * 9 * C;
 }
 extern "C" int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch,
                                        float* grad, int accumulate, void* stream) {
     GG_CHECK(x && dy && scratch && grad && B > 0 && (C & 7) == 0, "gg_dwconv3x3_bwd_weight: bad args");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    if (dw_walk_ok(C, stride) && (int64_t)H * W * C * 2 < 0x40000000LL && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0) {
+        const WgGeom w = wg_geom(B, W, C);
+        const size_t ldsw = (size_t)w.PX * 9 * C * sizeof(float);
+        const dim3 grid(w.nbx, w.BG), block(w.CG * w.PX);
+        if (w.nc == 4) hipLaunchKernelGGL((dwconv3x3_wgrad_walk_kernel<2>), grid, block, ldsw, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, B, H, W, C, w.CG, w.PX, w.nbx, scratch);
+        else hipLaunchKernelGGL((dwconv3x3_wgrad_walk_kernel<4>), grid, block, ldsw, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, B, H, W, C, w.CG, w.PX, w.nbx, scratch);
+        const float* rows; int nrows;
+        gg_reduce_rows(scratch, w.nbx * w.BG, 9 * C, (hipStream_t)stream, &rows, &nrows);
+        hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3((unsigned)gg_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, rows,
+                           nrows, C, grad, accumulate);
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     DwGeom g = dw_geom((int64_t)B * Ho * Wo, C, 9 * C);
     size_t lds = (size_t)g.PP * 9 * C * sizeof(float);
-    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
     GG_CHECK(lds <= 64 * 1024, "gg_dwconv3x3_bwd_weight: LDS budget exceeded for C=%d", C);
     hipLaunchKernelGGL(dwconv3x3_bwd_weight_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)x,
                        (const bf16*)dy, B, H, W, C, Ho, Wo, stride, g.CG, g.PP, g.pix_per_block, scratch);
