@@ -81,8 +81,10 @@ def test_tinyvit_eval_forward_matches_oracle(adapter5m):
     assert _cos(got, ref) > 0.999
 
 
-def test_tinyvit_train_step_matches_oracle(adapter5m, centroids):
-    """fwd (batch-stat BN, DropPath masks as inputs) + bwd under the reference freeze policy, SuperGuessr head on top."""
+@pytest.mark.parametrize("unfrozen", [False, True])
+def test_tinyvit_train_step_matches_oracle(adapter5m, centroids, unfrozen):
+    """fwd (batch-stat BN, DropPath masks as inputs) + bwd under the reference freeze policy (and with every parameter
+    trainable: the unfused BatchNorm / weight-gradient paths of all stages), SuperGuessr head on top."""
     from geoguessr_ai_amd.models.super_guessr import SuperGuessr
     from oracle import tinyvit_ref as R
     from oracle import step_ref as S
@@ -90,8 +92,13 @@ def test_tinyvit_train_step_matches_oracle(adapter5m, centroids):
     adapter5m.unfreeze_all()
     torch.manual_seed(3)
     model = SuperGuessr(adapter5m, panorama=True, should_smooth_labels=True).cuda().train()
+    if unfrozen:
+        adapter5m.unfreeze_all()
     trainable = [n for n, p in adapter5m.backbone.named_parameters() if p.requires_grad]
-    assert not any(n.startswith(("stages.0", "stages.1", "stages.2")) for n in trainable)     # freeze_all_but_last_stage
+    if unfrozen:
+        assert any(n.startswith("stages.0") for n in trainable) and any(n.startswith("stages.2") for n in trainable)
+    else:
+        assert not any(n.startswith(("stages.0", "stages.1", "stages.2")) for n in trainable)     # freeze_all_but_last_stage
     assert any(n.startswith("patch_embed") for n in trainable) and "head.norm.weight" in trainable
     N = 3
     g = torch.Generator().manual_seed(7)
@@ -125,6 +132,8 @@ def test_tinyvit_train_step_matches_oracle(adapter5m, centroids):
     assert not bad, bad
     # frozen tensors got no gradient
     assert all(bb._params[n].grad is None for n in bb._params if n not in trainable)
+    if unfrozen:
+        return
     # BN running statistics moved like torch's (momentum 0.1, unbiased variance)
     ref2 = R.forward(cfg, st2 := {k: v.clone() for k, v in st.items()}, x.view(-1, 3, 224, 224), training=True, drop_masks=masks, update_running=True)
     got_rm = bb.state_dict()["patch_embed.conv1.bn.running_mean"].cpu()
