@@ -419,7 +419,8 @@ struct TnParams {
     int tilesN, tilesK, m_per_split;
 };
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
-    constexpr int TB = 128, MS = 32, RS = TB + 8;          // 32-row m-step; 272-byte LDS rows (8-byte aligned transposing reads)
+    constexpr int TB = 128, MS = 64, RS = TB + 8;          // 64-row m-step = two MFMA k-steps per barrier pair; 272-byte LDS rows
+    constexpr int LS = MS / 16;                            // 16-byte chunks per thread per operand per step
     __shared__ __attribute__((aligned(16))) bf16 Ys[MS * RS];
     __shared__ __attribute__((aligned(16))) bf16 Xs[MS * RS];
     const int tn = blockIdx.x / p.tilesK, tk = blockIdx.x % p.tilesK;
@@ -428,14 +429,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
-    // staging: 32 rows x 16 chunks (16 B) per operand = 512 chunks -> 2 per thread: row = c >> 4, chunk = c & 15
+    // staging: MS rows x 16 chunks (16 B) per operand -> LS per thread: row = c >> 4 (+16 i), chunk = c & 15
     const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
     const bool yok = (n0 + sch * 8) < p.N, xok = (k0 + sch * 8) < p.K;      // N, K multiples of 8
-    bf16x8 ry[2], rx[2];
+    bf16x8 ry[LS], rx[LS];
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto load_step = [&](int m0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < LS; ++i) {
             const int m = m0 + srow + 16 * i;
             const bool mok = m < mend;
             bf16x8 vy = (mok && yok) ? *reinterpret_cast<const bf16x8*>(p.dY + (int64_t)m * p.ldy + n0 + sch * 8) : zero8;
@@ -456,23 +457,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     if (mbeg < mend) load_step(mbeg);
     for (int m0 = mbeg; m0 < mend; m0 += MS) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < LS; ++i) {
             *reinterpret_cast<bf16x8*>(Ys + (srow + 16 * i) * RS + sch * 8) = ry[i];
             *reinterpret_cast<bf16x8*>(Xs + (srow + 16 * i) * RS + sch * 8) = rx[i];
         }
         __syncthreads();
         if (m0 + MS < mend) load_step(m0 + MS);
-        bf16x8 yf[4], xf[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            yf[i] = tn_frag(Ys, RS, wn * 64 + i * 16, lr, lg);
-            xf[i] = tn_frag(Xs, RS, wk * 64 + i * 16, lr, lg);
+        for (int ms = 0; ms < MS / 32; ++ms) {
+            if (m0 + ms * 32 >= mend) break;         // uniform: the tail step may hold only one k-step of rows
+            bf16x8 yf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                yf[i] = tn_frag(Ys + ms * 32 * RS, RS, wn * 64 + i * 16, lr, lg);
+                xf[i] = tn_frag(Xs + ms * 32 * RS, RS, wk * 64 + i * 16, lr, lg);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
         }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
         __syncthreads();
     }
     // lane holds D[n = .. + nt*16 + 4lg + r][k = .. + kt*16 + lr]
@@ -803,7 +808,7 @@ extern "C" int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ld
     p.dY = (const bf16*)dY; p.ldy = ldy; p.X = (const bf16*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
     p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
     p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
-    p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 32);
+    p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 64);
     GG_CHECK(splits <= 65535, "gg_gemm_tn: too many splits");
     GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 2.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tilesN * p.tilesK, splits), dim3(256), 0, (hipStream_t)stream, p);
