@@ -505,6 +505,23 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
         out[i] = accumulate ? out[i] + s : s;
     }
 }
+// 16 bytes per lane, 4 slabs in flight (n % 4 == 0, 16-byte aligned slabs and output)
+__global__ __launch_bounds__(256) void splitk_reduce_v4_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n4,
+                                                               int splits, int accumulate, float scale) {
+    const f32x4* P = reinterpret_cast<const f32x4*>(part);
+    f32x4* O = reinterpret_cast<f32x4*>(out);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+            const f32x4 a = P[(int64_t)z * n4 + i], b = P[(int64_t)(z + 1) * n4 + i], c = P[(int64_t)(z + 2) * n4 + i], d = P[(int64_t)(z + 3) * n4 + i];
+            s += (a + b) + (c + d);
+        }
+        for (; z < splits; ++z) s += P[(int64_t)z * n4 + i];
+        s *= scale;
+        O[i] = accumulate ? O[i] + s : s;
+    }
+}
 
 // bf16 [R, C] (row stride ld) -> bf16 [C, R] (row stride ldo), optional per-row scale (drop-path) applied while
 // transposing.  Columns/rows beyond the source are not written: the caller zero-pads ldo.
@@ -724,7 +741,10 @@ extern "C" int gg_splitk_reduce(const float* part, float* out, int64_t n, int sp
     GG_CHECK(part && out && n > 0 && splits > 0, "gg_splitk_reduce: bad args");
     GG_PROF(GG_CAT_MOVE, 0, 4.0 * n * (splits + 1), stream);
     int blocks = (int)std::min<int64_t>(gg_cdiv(n, 256), 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, out, n, splits, accumulate, scale);
+    if ((n & 3) == 0 && ((uintptr_t)part & 15) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(splitk_reduce_v4_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(n / 4, 256), 16384)), dim3(256), 0, (hipStream_t)stream, part, out, n / 4, splits, accumulate, scale);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, out, n, splits, accumulate, scale);
     GG_LAUNCH_CHECK();
     return 0;
 }
