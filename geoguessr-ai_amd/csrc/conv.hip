@@ -174,6 +174,7 @@ __global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __
 // left / right neighbours come out of L1: HBM sees every input byte once), rotates the window by renaming (the loop is
 // unrolled by 3) and emits one output row.  Rows / columns outside the image are zero through the buffer range check.
 // colstats: one row per block, [gridDim.x][2][C] = per-channel sum / sum of squares of the stored (bf16-rounded) result.
+typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
 #define DW_COL_OOB 0x80000000u
 #define DW_ROW_OOB 0x40000000u
 // NQ channel pairs per thread: 4 (16-byte accesses; the plain kernel) or 2 (8-byte accesses; the fused backward kernels, whose
@@ -571,6 +572,46 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
     }
 }
 
+// stride-2 data gradient (PatchMerging.conv2): thread = (8-channel group g fixed, pixel lane); the taps of the thread's channels
+// sit in LDS; an input pixel receives only the taps whose parity matches -- ky = 1 for even rows, ky in {0, 2} for odd rows, same
+// in x -- i.e. 1, 2 or 4 of the 9, found with bit tests instead of the generic kernel's 9 x (modulo, divide, branch).
+__global__ __launch_bounds__(256) void dwconv3x3_s2_bwd_data_kernel(const bf16* __restrict__ dy, const float* __restrict__ wt,
+                                                                    bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
+                                                                    int CG, int PP) {
+    extern __shared__ float s2_taps[];      // [9][C]
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) s2_taps[i] = wt[i];
+    __syncthreads();
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int64_t npix = (int64_t)B * H * W;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    for (int64_t p = (int64_t)blockIdx.x * PP + pp; p < npix; p += (int64_t)gridDim.x * PP) {
+        const unsigned pu = (unsigned)p;
+        const unsigned b = pu / HW, rem = pu - b * HW;
+        const int iy = (int)(rem / (unsigned)W), ix = (int)(rem - (unsigned)iy * (unsigned)W);
+        f32x2 acc[4] = {(f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f)};
+        // contributing taps: oy = (iy + 1 - ky) / 2 with iy + 1 - ky even
+        const int ky0 = (iy & 1) ? 0 : 1, nky = (iy & 1) ? 2 : 1;
+        const int kx0 = (ix & 1) ? 0 : 1, nkx = (ix & 1) ? 2 : 1;
+        for (int a = 0; a < nky; ++a) {
+            const int ky = ky0 + 2 * a, oy = (iy + 1 - ky) >> 1;
+            if (oy < 0 || oy >= Ho) continue;
+            for (int c = 0; c < nkx; ++c) {
+                const int kx = kx0 + 2 * c, ox = (ix + 1 - kx) >> 1;
+                if (ox < 0 || ox >= Wo) continue;
+                const dw_u32x4 raw = *reinterpret_cast<const dw_u32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + g * 8);
+                const float* tp = s2_taps + (ky * 3 + kx) * C + g * 8;
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+                acc[0] = dw_unpack2(raw[0]) * (f32x2){t0[0], t0[1]} + acc[0];
+                acc[1] = dw_unpack2(raw[1]) * (f32x2){t0[2], t0[3]} + acc[1];
+                acc[2] = dw_unpack2(raw[2]) * (f32x2){t1[0], t1[1]} + acc[2];
+                acc[3] = dw_unpack2(raw[3]) * (f32x2){t1[2], t1[3]} + acc[3];
+            }
+        }
+        dw_u32x4 o = {dw_pack2(acc[0]), dw_pack2(acc[1]), dw_pack2(acc[2]), dw_pack2(acc[3])};
+        *reinterpret_cast<dw_u32x4*>(dx + p * C + g * 8) = o;
+    }
+}
+
 // dx[b,iy,ix,c] = sum_{ky,kx} w[ky][kx][c] * dy[b,oy,ox,c],  oy*stride + ky - 1 == iy
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_data_kernel(const bf16* __restrict__ dy, const float* __restrict__ wt,
                                                                  bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
@@ -925,6 +966,15 @@ extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, 
         return dwconv_tiled_launch(dy, wt, dx, B, H, W, C, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, stream);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    if (stride == 2 && (C / 8) <= 256 && 9 * C * 4 <= 48 * 1024 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)wt & 15) == 0) {
+        const int CG = C / 8, PP = std::max(1, 256 / CG);
+        const int64_t npix = (int64_t)B * H * W;
+        const unsigned blocks = (unsigned)std::min<int64_t>(gg_cdiv(npix, PP), 8192);
+        hipLaunchKernelGGL(dwconv3x3_s2_bwd_data_kernel, dim3(blocks), dim3(CG * PP), (size_t)9 * C * sizeof(float), (hipStream_t)stream,
+                           (const bf16*)dy, wt, (bf16*)dx, B, H, W, C, Ho, Wo, CG, PP);
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0,
                        (hipStream_t)stream, (const bf16*)dy, wt, (bf16*)dx, B, H, W, C, Ho, Wo, stride);
     GG_LAUNCH_CHECK();
