@@ -91,6 +91,8 @@ SIGNATURES = {
     "gg_dwconv3x3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_fwd_fused": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "gg_dwconv_s2_fused_stat_rows": (_I, [_I, _I, _I, _I]),
+    "gg_dwconv3x3_s2_bwd_data_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_wgrad_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
     "gg_dwconv3x3_bwd_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

@@ -575,19 +575,50 @@ __global__ __launch_bounds__(256) void dwconv3x3_tiled_kernel(const bf16* __rest
 // stride-2 data gradient (PatchMerging.conv2): thread = (8-channel group g fixed, pixel lane); the taps of the thread's channels
 // sit in LDS; an input pixel receives only the taps whose parity matches -- ky = 1 for even rows, ky in {0, 2} for odd rows, same
 // in x -- i.e. 1, 2 or 4 of the 9, found with bit tests instead of the generic kernel's 9 x (modulo, divide, branch).
+// Optional BatchNorm-backward fusions as in the stride-1 kernel: IN2 forms dy = c0*dz + c1*y + c2 at every tap from (dz, y_in);
+// EPI stores acc * act'(BN(ep_y)) and leaves one (sum dz, sum dz*xhat) row per block in `part`.
+struct DwS2Fuse {
+    const bf16* y_in; const float* in_coef;
+    const bf16* ep_y; const float* ep_stat; const float* ep_gamma; const float* ep_beta; int ep_act; float* part;
+};
+template <bool IN2, bool EPI>
 __global__ __launch_bounds__(256) void dwconv3x3_s2_bwd_data_kernel(const bf16* __restrict__ dy, const float* __restrict__ wt,
                                                                     bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
-                                                                    int CG, int PP) {
-    extern __shared__ float s2_taps[];      // [9][C]
-    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) s2_taps[i] = wt[i];
+                                                                    int CG, int PP, DwS2Fuse f) {
+    extern __shared__ float s2_lds[];       // taps [9][C]; IN2: coef [3][C]; EPI: scale, shift, rstd, -mean*rstd [4][C]; EPI: red [PP][2][C]
+    float* taps = s2_lds;
+    float* ctab = s2_lds + 9 * C;
+    float* red = s2_lds + 16 * C;
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) taps[i] = wt[i];
+    if (IN2 || EPI) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            if (IN2) { ctab[c] = f.in_coef[c]; ctab[C + c] = f.in_coef[C + c]; ctab[2 * C + c] = f.in_coef[2 * C + c]; }
+            if (EPI) {
+                const float mu = f.ep_stat[c], rstd = f.ep_stat[C + c], sc = rstd * f.ep_gamma[c];
+                ctab[3 * C + c] = sc; ctab[4 * C + c] = f.ep_beta[c] - mu * sc; ctab[5 * C + c] = rstd; ctab[6 * C + c] = -mu * rstd;
+            }
+        }
+    }
     __syncthreads();
     const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    auto row2 = [&](const float* base, f32x2 (&o)[4]) {
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(base + g * 8), t1 = *reinterpret_cast<const f32x4*>(base + g * 8 + 4);
+        o[0] = (f32x2){t0[0], t0[1]}; o[1] = (f32x2){t0[2], t0[3]}; o[2] = (f32x2){t1[0], t1[1]}; o[3] = (f32x2){t1[2], t1[3]};
+    };
+    f32x2 ca[4], cb[4], cc[4];
+    if (IN2) { row2(ctab, ca); row2(ctab + C, cb); row2(ctab + 2 * C, cc); }
+    f32x2 s2[4], q2[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s2[q] = q2[q] = (f32x2)(0.f);
+    const bool ep_gelu = f.ep_act == GG_ACT_GELU;
     const int64_t npix = (int64_t)B * H * W;
     const unsigned HW = (unsigned)H * (unsigned)W;
     for (int64_t p = (int64_t)blockIdx.x * PP + pp; p < npix; p += (int64_t)gridDim.x * PP) {
         const unsigned pu = (unsigned)p;
         const unsigned b = pu / HW, rem = pu - b * HW;
         const int iy = (int)(rem / (unsigned)W), ix = (int)(rem - (unsigned)iy * (unsigned)W);
+        dw_u32x4 eraw;
+        if (EPI) eraw = *reinterpret_cast<const dw_u32x4*>(f.ep_y + p * C + g * 8);
         f32x2 acc[4] = {(f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f)};
         // contributing taps: oy = (iy + 1 - ky) / 2 with iy + 1 - ky even
         const int ky0 = (iy & 1) ? 0 : 1, nky = (iy & 1) ? 2 : 1;
@@ -598,17 +629,52 @@ __global__ __launch_bounds__(256) void dwconv3x3_s2_bwd_data_kernel(const bf16* 
             for (int c = 0; c < nkx; ++c) {
                 const int kx = kx0 + 2 * c, ox = (ix + 1 - kx) >> 1;
                 if (ox < 0 || ox >= Wo) continue;
-                const dw_u32x4 raw = *reinterpret_cast<const dw_u32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + g * 8);
-                const float* tp = s2_taps + (ky * 3 + kx) * C + g * 8;
-                const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
-                acc[0] = dw_unpack2(raw[0]) * (f32x2){t0[0], t0[1]} + acc[0];
-                acc[1] = dw_unpack2(raw[1]) * (f32x2){t0[2], t0[3]} + acc[1];
-                acc[2] = dw_unpack2(raw[2]) * (f32x2){t1[0], t1[1]} + acc[2];
-                acc[3] = dw_unpack2(raw[3]) * (f32x2){t1[2], t1[3]} + acc[3];
+                const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * C + g * 8;
+                const dw_u32x4 raw = *reinterpret_cast<const dw_u32x4*>(dy + o);
+                f32x2 tp[4];
+                row2(taps + (ky * 3 + kx) * C, tp);
+                if (IN2) {
+                    const dw_u32x4 yr = *reinterpret_cast<const dw_u32x4*>(f.y_in + o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 v = dw_unpack2(dw_pack2(ca[q] * dw_unpack2(raw[q]) + (cb[q] * dw_unpack2(yr[q]) + cc[q])));   // dy as the unfused path stores it
+                        acc[q] = v * tp[q] + acc[q];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = dw_unpack2(raw[q]) * tp[q] + acc[q];
+                }
             }
         }
-        dw_u32x4 o = {dw_pack2(acc[0]), dw_pack2(acc[1]), dw_pack2(acc[2]), dw_pack2(acc[3])};
+        dw_u32x4 o;
+        if (EPI) {
+            f32x2 esc[4], esh[4], ers[4], emr[4];
+            row2(ctab + 3 * C, esc); row2(ctab + 4 * C, esh); row2(ctab + 5 * C, ers); row2(ctab + 6 * C, emr);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 yv = dw_unpack2(eraw[q]);
+                o[q] = dw_pack2(acc[q] * gg_act_grad_v2(yv * esc[q] + esh[q], ep_gelu));
+                const f32x2 r = dw_unpack2(o[q]);
+                s2[q] += r; q2[q] += r * (yv * ers[q] + emr[q]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = dw_pack2(acc[q]);
+        }
         *reinterpret_cast<dw_u32x4*>(dx + p * C + g * 8) = o;
+    }
+    if (EPI) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            red[(pp * 2 + 0) * C + g * 8 + 2 * q] = s2[q].x; red[(pp * 2 + 0) * C + g * 8 + 2 * q + 1] = s2[q].y;
+            red[(pp * 2 + 1) * C + g * 8 + 2 * q] = q2[q].x; red[(pp * 2 + 1) * C + g * 8 + 2 * q + 1] = q2[q].y;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < PP; ++k) t += red[k * 2 * C + i];
+            f.part[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
     }
 }
 
@@ -891,6 +957,42 @@ static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, in
     return 0;
 }
 
+// stride-2 data gradient geometry: 8-channel groups x pixel lanes, <= 4096 blocks (= partial statistics rows with ep_y)
+static bool dw_s2_ok(int C) { return (C / 8) <= 256 && (16 + 2 * std::max(1, 256 / (C / 8))) * (int64_t)C * 4 <= 60 * 1024; }
+static int dw_s2_blocks(int B, int H, int W, int C) { return (int)std::min<int64_t>(gg_cdiv((int64_t)B * H * W, std::max(1, 256 / (C / 8))), 4096); }
+extern "C" int gg_dwconv_s2_fused_stat_rows(int B, int H, int W, int C) { return dw_s2_blocks(B, H, W, C); }
+static int dwconv_s2_bwd_launch(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, const DwS2Fuse* fuse, void* stream) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int CG = C / 8, PP = std::max(1, 256 / CG);
+    DwS2Fuse f;
+    memset(&f, 0, sizeof(f));
+    if (fuse) f = *fuse;
+    const bool in2 = f.in_coef != nullptr, epi = f.ep_y != nullptr;
+    const size_t lds = ((size_t)16 * C + (epi ? (size_t)PP * 2 * C : 0)) * sizeof(float);
+    const dim3 grid((unsigned)dw_s2_blocks(B, H, W, C)), block(CG * PP);
+#define GG_S2(I_, E_) hipLaunchKernelGGL((dwconv3x3_s2_bwd_data_kernel<I_, E_>), grid, block, lds, (hipStream_t)stream, (const bf16*)dy, wt, \
+                                         (bf16*)dx, B, H, W, C, Ho, Wo, CG, PP, f)
+    if (in2 && epi) GG_S2(true, true); else if (in2) GG_S2(true, false); else if (epi) GG_S2(false, true); else GG_S2(false, false);
+#undef GG_S2
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// stride-2 data gradient with the BatchNorm-backward passes on both sides folded in (PatchMerging.conv2 with frozen taps); same
+// contract as gg_dwconv3x3_bwd_data_fused, partial rows = gg_dwconv_s2_fused_stat_rows
+extern "C" int gg_dwconv3x3_s2_bwd_data_fused(const void* dz_in, const void* y_in, const float* in_coef, const float* wt, void* out, int B,
+                                              int H, int W, int C, const void* ep_y, const float* ep_stat, const float* ep_gamma,
+                                              const float* ep_beta, int ep_act, float* ep_part, void* stream) {
+    GG_CHECK(dz_in && wt && out && B > 0 && (C & 7) == 0 && dw_s2_ok(C), "gg_dwconv3x3_s2_bwd_data_fused: bad args");
+    GG_CHECK(!in_coef || y_in, "gg_dwconv3x3_s2_bwd_data_fused: in_coef needs y_in");
+    GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_part), "gg_dwconv3x3_s2_bwd_data_fused: epilogue needs stat/gamma/beta/partials");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W * (ep_y ? 2 : 1) + (double)Ho * Wo * (in_coef ? 2 : 1)), stream);
+    DwS2Fuse f;
+    memset(&f, 0, sizeof(f));
+    f.y_in = in_coef ? (const bf16*)y_in : nullptr; f.in_coef = in_coef;
+    f.ep_y = (const bf16*)ep_y; f.ep_stat = ep_stat; f.ep_gamma = ep_gamma; f.ep_beta = ep_beta; f.ep_act = ep_act; f.part = ep_part;
+    return dwconv_s2_bwd_launch(dz_in, wt, out, B, H, W, C, &f, stream);
+}
 struct DwFuse {
     const void* in2 = nullptr; const float* in_coef = nullptr;
     const void* ep_y = nullptr; const float* ep_stat = nullptr; const float* ep_gamma = nullptr; const float* ep_beta = nullptr; int ep_act = 0;
@@ -966,15 +1068,8 @@ extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, 
         return dwconv_tiled_launch(dy, wt, dx, B, H, W, C, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, stream);
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
-    if (stride == 2 && (C / 8) <= 256 && 9 * C * 4 <= 48 * 1024 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)wt & 15) == 0) {
-        const int CG = C / 8, PP = std::max(1, 256 / CG);
-        const int64_t npix = (int64_t)B * H * W;
-        const unsigned blocks = (unsigned)std::min<int64_t>(gg_cdiv(npix, PP), 8192);
-        hipLaunchKernelGGL(dwconv3x3_s2_bwd_data_kernel, dim3(blocks), dim3(CG * PP), (size_t)9 * C * sizeof(float), (hipStream_t)stream,
-                           (const bf16*)dy, wt, (bf16*)dx, B, H, W, C, Ho, Wo, CG, PP);
-        GG_LAUNCH_CHECK();
-        return 0;
-    }
+    if (stride == 2 && dw_s2_ok(C) && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)dx & 15) == 0 && ((uintptr_t)wt & 15) == 0)
+        return dwconv_s2_bwd_launch(dy, wt, dx, B, H, W, C, nullptr, stream);
     hipLaunchKernelGGL(dwconv3x3_bwd_data_kernel, dim3(grid_for((int64_t)B * H * W * (C / 8), 65536)), dim3(256), 0,
                        (hipStream_t)stream, (const bf16*)dy, wt, (bf16*)dx, B, H, W, C, Ho, Wo, stride);
     GG_LAUNCH_CHECK();

@@ -438,3 +438,19 @@ def segment_mean(emb, ptr, member):
     L.check(L.lib().gg_segment_mean(_p(emb, F32, "emb"), emb.stride(0), _p(ptr, I64, "ptr"), _p(member, I64, "member"), K, emb.shape[1],
                                     _p(out), L.stream()), "gg_segment_mean")
     return out
+
+
+def dwconv3x3_s2_bwd_data_fused(dz_in, y_in, in_coef, taps, H, W, ep_y=None, ep_stat=None, ep_gamma=None, ep_beta=None, ep_act=None):
+    """Stride-2 depthwise data gradient with the BatchNorm-backward apply (input side) and act'(BN) + reduce (output side) fused.
+    dz_in / y_in: (B, Ho, Wo, C) bf16; returns (out (B,H,W,C) bf16, partial rows [rows,2,C] or None)."""
+    L.require_gpu()
+    B, Ho, Wo, Cc = dz_in.shape
+    out = torch.empty((B, H, W, Cc), dtype=BF16, device=dz_in.device)
+    part = None
+    if ep_y is not None:
+        rows = L.lib().gg_dwconv_s2_fused_stat_rows(B, H, W, Cc)
+        part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=dz_in.device)
+    L.check(L.lib().gg_dwconv3x3_s2_bwd_data_fused(_p(dz_in, BF16), _p(y_in, BF16), _p(in_coef, F32), _p(taps, F32), _p(out), B, H, W, Cc,
+                                                   _p(ep_y, BF16), _p(ep_stat, F32), _p(ep_gamma, F32), _p(ep_beta, F32), ACT[ep_act],
+                                                   _p(part), L.stream()), "gg_dwconv3x3_s2_bwd_data_fused")
+    return out, (part[:L.lib().gg_dwconv_s2_fused_stat_rows(B, H, W, Cc)] if part is not None else None)

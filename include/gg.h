@@ -88,6 +88,10 @@ int gg_dwconv3x3_fwd_fused(const void* x_prebn, const float* in_stat, const floa
 int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, const float* in_coef, const float* taps, void* out, int B, int H, int W,
                                 int C, const void* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
                                 float* ep_partials, void* stream);
+int gg_dwconv_s2_fused_stat_rows(int B, int H, int W, int C);            /* partial rows of the stride-2 fused data gradient */
+int gg_dwconv3x3_s2_bwd_data_fused(const void* dz_in, const void* y_in, const float* in_coef, const float* taps, void* out, int B, int H,
+                                   int W, int C, const void* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta,
+                                   int ep_act, float* ep_partials, void* stream);   /* (H, W) = the conv INPUT map; stride 2 */
 int gg_dwconv3x3_bwd_data(const void* dy, const float* taps, void* dx, int B, int H, int W, int C, int stride, void* stream);
 int64_t gg_dwconv_wgrad_scratch_floats(int B, int H, int W, int C, int stride);
 int gg_dwconv3x3_bwd_weight(const void* x, const void* dy, int B, int H, int W, int C, int stride, float* scratch, float* grad /* (C,1,3,3) */,

@@ -483,3 +483,33 @@ def test_build_prototypes_matches_reference_golden(golden_dir):
     import geoguessr_ai_amd.ops as O
     got = O.segment_mean(torch.from_numpy(g["proto.pano_vec"]).cuda(), torch.from_numpy(ptr).cuda(), torch.from_numpy(member).cuda())
     np.testing.assert_array_equal(got.cpu().numpy(), g["proto.out"])              # same fp32 additions in the same order: bit-exact
+
+
+@pytest.mark.parametrize("C,H", [(192, 12), (40, 7)])
+def test_dwconv_stride2_data_gradient_with_batchnorm_fusions(ops, C, H):
+    """gg_dwconv3x3_s2_bwd_data_fused == BN-backward apply -> stride-2 data gradient -> act'(BN) * . + column sums, composed from
+    fp32 torch math on the same bf16 inputs."""
+    B, Ho = 2, (H - 1) // 2 + 1
+    dz = rnd(B, Ho, Ho, C, seed=90).to(BF).float(); y2 = rnd(B, Ho, Ho, C, seed=91).to(BF).float()
+    coef = torch.stack([1 + 0.2 * rnd(C, seed=92), 0.3 * rnd(C, seed=93), 0.1 * rnd(C, seed=94)])
+    w = rnd(C, 1, 3, 3, seed=95, scale=0.4); taps = w.view(C, 9).t().contiguous()
+    y1 = (rnd(B, H, H, C, seed=96) + 0.3).to(BF).float()
+    gamma, beta = 1 + 0.2 * rnd(C, seed=97), 0.2 * rnd(C, seed=98)
+    mean, var = y1.mean((0, 1, 2)), y1.var((0, 1, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    dy = (coef[0] * dz + coef[1] * y2 + coef[2]).to(BF).float()
+    xr = torch.zeros(B, C, H, H, requires_grad=True)
+    F.conv2d(xr, w, None, 2, 1, 1, C).backward(dy.permute(0, 3, 1, 2))
+    da = xr.grad.permute(0, 2, 3, 1)
+    z = ((y1 - mean) * rstd * gamma + beta).requires_grad_(True)
+    F.gelu(z).sum().backward()
+    ref = da * z.grad
+    out, part = ops.dwconv3x3_s2_bwd_data_fused(dev(dz, BF), dev(y2, BF), dev(coef), dev(taps), H, H, ep_y=dev(y1, BF),
+                                                ep_stat=dev(torch.stack([mean, rstd])), ep_gamma=dev(gamma), ep_beta=dev(beta), ep_act="gelu")
+    close(out, ref, rtol=2e-2, atol=2e-2, what="s2 fused dgrad")
+    oq = out.float().cpu()
+    s = part.cpu().sum(0)
+    close(s[0], oq.sum((0, 1, 2)), rtol=1e-3, atol=2e-2, what="s2 fused sum dz")
+    close(s[1], (oq * ((y1 - mean) * rstd)).sum((0, 1, 2)), rtol=1e-3, atol=5e-2, what="s2 fused sum dz*xhat")
+    plain, _ = ops.dwconv3x3_s2_bwd_data_fused(dev(dy, BF), None, None, dev(taps), H, H)
+    close(plain, da, rtol=2e-2, atol=2e-2, what="s2 plain dgrad")
