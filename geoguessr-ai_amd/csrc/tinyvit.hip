@@ -783,6 +783,26 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(gemm_folded_dgrad(e, l.c1.w, dz1, e.A(a.c1.y), bn_coef(e, M0, mid), e.F(a.c1.stat), dx, M0, t_b));   // + dpre
             continue;
         }
+        if (e.fuse_bngemm && e.fuse_bnbwd && e.fuse_bnbwd_epi && mid % 64 == 0) {
+            // trainable weights: dy2 / dy1 are materialised for the weight gradients, but both BatchNorm-backward REDUCE passes still
+            // ride on the kernels that produce their inputs (conv3's dgrad epilogue, the depthwise data gradient's epilogue)
+            GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));   // dz2 -> t_d
+            GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
+            GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                // dy2 -> t_a
+            if (e.tr(l.c2.w.t_w)) {
+                if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
+                GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+            }
+            GG_TRY(gg_dwconv3x3_bwd_data_fused(t_a, nullptr, nullptr, e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y), e.F(a.c1.stat),
+                                               e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
+            const bool tr1 = e.tr(l.c1.bn.t_g);
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_fused_stat_rows(B, H0, H0, mid, 0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                                      bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
+            GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                // dy1 -> t_a
+            if (e.tr(l.c1.w.t_w)) GG_TRY(dense_wgrad(e, l.c1.w, e.A(a.x), d[0], t_a, mid, M0, nullptr, 0, t_c, t_d, false));
+            GG_TRY(gemm(e, t_a, mid, e.Wt(l.c1.w), l.c1.w.Np, dx, d[0], M0, d[0], mid, nullptr, 0, nullptr, nullptr, 0, t_b));
+            continue;
+        }
         GG_TRY(gemm(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_c, mid, M0, mid, d[0]));                     // da2 -> t_c [M0, mid]
         if (e.tr(l.c2.w.t_w) || !e.fuse_bnbwd || !e.fuse_bnbwd_epi) {
             GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy2 -> t_a
