@@ -180,10 +180,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs2[j] = cq2[j] = (f32x2)(0.f);
     const bool bn_gelu = p.bn_act == GG_ACT_GELU;
-    auto store8 = [&](bf16* base, int m, const bf16x8& v) {
+    auto store8 = [&](bf16* base, int m, const bf16x8& v, bool stream_out = false) {
         bf16* g = base + (int64_t)m * p.ldc + n;
-        if (wide) *reinterpret_cast<bf16x8*>(g) = v;
-        else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
+        if (wide) {
+            if (stream_out) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(g));    // read back only in the backward pass
+            else *reinterpret_cast<bf16x8*>(g) = v;
+        } else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
     };
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
@@ -208,7 +210,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         }
         if (p.debug & 2) continue;
         if (EPI == EPI_GELU) {
-            if (p.preact) store8(p.preact, m, v);
+            if (p.preact) store8(p.preact, m, v, true);
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 const f32x2 r = gg_gelu_v2((f32x2){(float)v[j], (float)v[j + 1]});
