@@ -229,7 +229,10 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
     __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
     __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
 
-    const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+    // all heads of a window run on one XCD (logical ids are laid out XCD by XCD): their 192-byte slices of a token row share
+    // 128-byte lines, which round-robin dispatch made every XCD fetch separately
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int w = bid / p.nh, h = bid % p.nh;
     const int origin = attn_origin(p, w);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
@@ -309,7 +312,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
     __shared__ float dbias_s[DBIAS ? DBC * 256 : 1];
     __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];   // window coordinates: bias-gradient binning only
 
-    const int w = blockIdx.x / p.nh, h = blockIdx.x % p.nh;
+    // all heads of a window run on one XCD (logical ids are laid out XCD by XCD): their 192-byte slices of a token row share
+    // 128-byte lines, which round-robin dispatch made every XCD fetch separately
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int w = bid / p.nh, h = bid % p.nh;
     const int origin = attn_origin(p, w);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;

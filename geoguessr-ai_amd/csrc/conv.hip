@@ -229,7 +229,11 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
     float* ctab = dw_red + PX * 2 * C;         // [0..2] in coef a,b,c   [3] ep scale  [4] ep shift  [5] ep rstd  [6] ep -mean*rstd  [7..15] taps
     constexpr bool TAPS_LDS = IN != 0 || EPI;      // the fused variants have no registers left for the tap values
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
-    const int bx = blockIdx.x % nbx, b = blockIdx.x / nbx;
+    // the strips of one image are neighbours in the logical block order, and that order is laid out XCD by XCD: the halo columns a
+    // strip shares with the next one are then served by the same L2 (round-robin dispatch put them on different XCDs and every
+    // strip fetched its halo from HBM again: measured 1.85x the algorithmic read traffic)
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % nbx, b = bid / nbx;
     const int xo = bx * PX + px;
     const int c0 = cg * NC;
     if (IN != 0 || EPI) {
