@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             const int ti = (tt * p.ws_inv) >> 16;
             ci[t] = p.ws ? (unsigned char)ti : 0;
             cj[t] = p.ws ? (unsigned char)(tt - ti * p.ws) : 0;
-            row_lse[t] = tk >= 0 ? p.lse[(int64_t)tk * p.nh + h] : 0.f;
+            row_lse[t] = tk >= 0 ? -1.4426950408889634f * p.lse[(int64_t)tk * p.nh + h] : 0.f;      // stored as -lse*log2(e): P = 2^(s*c2 + this)
         }
         if (DBIAS) { for (int t = threadIdx.x; t < DBC * 256; t += blockDim.x) dbias_s[t] = 0.f; }
         attn_store_rows<D, Np>(Ks, RS, kr);
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             for (int j = 0; j < 8; ++j) sm += (float)dr[i][j] * (float)orr[i][j];
 #pragma unroll
             for (int o = 1; o < CH; o <<= 1) sm += __shfl_xor(sm, o, 64);
-            if (idx < Np * CH && (idx % CH) == 0) row_delta[idx / CH] = sm;
+            if (idx < Np * CH && (idx % CH) == 0) row_delta[idx / CH] = -sm;      // stored negated: it is the dP accumulator's initial value
         }
     }
     __syncthreads();
@@ -382,11 +382,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
             }
         }
         const int qci = ci[qi], qcj = cj[qi];
-        const float lse_q = row_lse[qi], delta_q = row_delta[qi];
+        const float nlse_q = row_lse[qi], ndelta_q = row_delta[qi];        // -lse*log2(e), -delta
         f32x4 dq[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float c2 = p.scale * 1.4426950408889634f, lq2 = lse_q * 1.4426950408889634f;
+        const float c2 = p.scale * 1.4426950408889634f;
         // score accumulators start as bias / scale (see forward); the next pair of tiles is fetched one iteration ahead
         // (kept raw: converting at the prefetch point would wait for the load right there)
         auto bias_tiles = [&](int kp, u32x2 (&b)[2]) {
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int kt = kp * 2 + u;
-                f32x4 acc = bcur[u], acc2 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 acc = bcur[u], acc2 = {ndelta_q, ndelta_q, ndelta_q, ndelta_q};      // dP - delta comes straight out of the MFMA
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
@@ -417,8 +417,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                 const int key0 = kt * 16 + lg * 4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -lq2));      // padded keys: 2^-inf = 0
-                    acc2[r] = pr * (acc2[r] - delta_q);
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, nlse_q));     // padded keys: 2^-inf = 0
+                    acc2[r] *= pr;
                 }
                 if (DBIAS && qtok >= 0) {       // bias gradient, binned by |di|,|dj|
                     const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
@@ -474,7 +474,6 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                 vf[ks] = attn_lds_row_frag(Vs, RS, ki, ks * 32 + lg * 8);
             }
         }
-        const bool kvalid = ki < p.N;
         f32x4 dk[DT], dv[DT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -497,7 +496,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int qt = qp * 2 + u;
-                f32x4 acc = bcur[u], acc2 = {0.f, 0.f, 0.f, 0.f};
+                const int q0 = qt * 16 + lg * 4;
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_lse[q0]);          // -lse*log2(e) of the 4 queries
+                f32x4 acc = bcur[u], acc2 = *reinterpret_cast<const f32x4*>(&row_delta[q0]);   // -delta: dP - delta out of the MFMA
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const bf16x8 qf = attn_lds_row_frag(Qs, RS, qt * 16 + lr, ks * 32 + lg * 8);
@@ -505,15 +506,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], acc, 0, 0, 0);     // S  [query][key]
                     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[ks], acc2, 0, 0, 0);  // dP [query][key]
                 }
-                const int q0 = qt * 16 + lg * 4;
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_lse[q0]);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(&row_delta[q0]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // padded queries: -inf score -> 0;  padded keys (kvalid false) produce rows that are never stored
-                    const float pr = kvalid ? __builtin_amdgcn_exp2f(fmaf(acc[r], c2, -l4[r] * 1.4426950408889634f)) : 0.f;
+                    // padded queries: -inf score -> P = 0.  Padded keys need no mask: a lane's key column only feeds its own dK / dV
+                    // columns, and those are never stored.
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, l4[r]));
                     acc[r] = pr;
-                    acc2[r] = pr * (acc2[r] - d4[r]);      // rows >= N: lse = delta = 0 (initialised), pr = 0
+                    acc2[r] *= pr;
                 }
                 pt[u] = acc;
                 dst[u] = acc2;
