@@ -102,70 +102,6 @@ __global__ __launch_bounds__(256) void col2im_nhwc_kernel(const bf16* __restrict
     }
 }
 
-// ---------------------------------------------------------------- depthwise 3x3 (pad 1), NHWC
-// Thread = (pixel-lane pp, channel group g) with blockDim.x = CG * PP, g fixed per thread so that the
-// per-channel BatchNorm statistics (sum, sum of squares of the fp32 result) accumulate in registers.
-// wt: taps fp32 [9][C].  colstats: [gridDim.x][2][C] or null.
-__global__ void dwconv3x3_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y, int B, int H,
-                                     int W, int C, int Ho, int Wo, int stride, int CG, int PP, int pix_per_block,
-                                     float* __restrict__ colstats) {
-    extern __shared__ float sred[];   // [PP][2][C]
-    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
-    const int64_t total = (int64_t)B * Ho * Wo;
-    const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
-    const int64_t p1 = min(total, p0 + pix_per_block);
-    float wreg[9][8];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) wreg[t][j] = wt[t * C + g * 8 + j];
-    float s[8], q[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    for (int64_t p = p0 + pp; p < p1; p += PP) {
-        const unsigned pu = (unsigned)p;
-        const int ox = (int)(pu % (unsigned)Wo);
-        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
-        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * stride + ky - 1;
-            if (iy < 0 || iy >= H) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * stride + kx - 1;
-                if (ix < 0 || ix >= W) continue;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j] * wreg[ky * 3 + kx][j];
-            }
-        }
-        bf16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            o[j] = (bf16)acc[j];
-            const float r = (float)o[j];
-            s[j] += r;
-            q[j] += r * r;
-        }
-        *reinterpret_cast<bf16x8*>(y + p * C + g * 8) = o;
-    }
-    if (colstats) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sred[(pp * 2 + 0) * C + g * 8 + j] = s[j];
-            sred[(pp * 2 + 1) * C + g * 8 + j] = q[j];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-            float t = 0.f;
-            for (int k = 0; k < PP; ++k) t += sred[k * 2 * C + i];
-            colstats[(int64_t)blockIdx.x * 2 * C + i] = t;
-        }
-    }
-}
-
 // ---------------------------------------------------------------- column-walking depthwise 3x3 (stride 1)
 // Thread = (8 channels, one output column); the block covers PX adjacent columns x all C channels and walks down the whole
 // image.  Lanes run over channels first, then columns, so every wave-level access is one contiguous run of the NHWC row
