@@ -91,3 +91,40 @@ def test_fullsize_batchnorm_statistics_match_stored_tensor():
     ref1 = (yf.double() ** 2).sum(0)
     assert torch.allclose(s[0], ref0, rtol=1e-6, atol=1e-2)
     assert torch.allclose(s[1], ref1, rtol=1e-6, atol=1e-2)
+
+
+def test_fullsize_head_loss_properties(centroids):
+    """Fused head at the c5 size (4096 samples x 12 647 geocells): rows are independent, the soft-CE gradient of every row sums
+    to zero (softmax minus a target distribution), loss = mean of the row losses, top-5 is sorted and starts at the argmax."""
+    from geoguessr_ai_amd import ops
+    N, K = 4096, 12647
+    g = torch.Generator(device="cuda").manual_seed(11)
+    logits = torch.randn(N, K, device="cuda", generator=g) * 2
+    labels = torch.stack([torch.rand(N, device="cuda", generator=g) * 360 - 180, torch.rand(N, device="cuda", generator=g) * 180 - 90], 1)
+    cent = torch.from_numpy(centroids).cuda()
+    r = ops.geo_head(logits, cent, labels=labels, mode=1, want_dlogits=True, want_nearest=True)
+    loss_rows, dl = r["loss_rows"], r["dlogits"][:, :K].float()
+    assert torch.isfinite(loss_rows).all() and abs(float(r["loss"]) - float(loss_rows.mean())) < 1e-4 * float(loss_rows.mean())
+    assert float(dl.sum(1).abs().max()) < 2e-3 / N * 50            # rows of (softmax - target)/N sum to 0 up to bf16 rounding
+    assert torch.equal(r["preds"], logits.argmax(1))
+    tv, ti = r["topk_vals"], r["topk_idx"]
+    assert torch.equal(ti[:, 0], r["preds"]) and (tv[:, :-1] >= tv[:, 1:]).all()
+    sub = torch.tensor([0, 17, 4095], device="cuda")
+    r2 = ops.geo_head(logits[sub].contiguous(), cent, labels=labels[sub].contiguous(), mode=1, want_dlogits=True, want_nearest=True)
+    assert torch.equal(r2["loss_rows"], loss_rows[sub]) and torch.equal(r2["nearest"], r["nearest"][sub])     # per-row arithmetic
+    assert torch.allclose(r2["dlogits"][:, :K].float() * (3.0 / N), dl[sub], rtol=1e-2, atol=1e-9)           # only the 1/N scale differs
+
+
+def test_fullsize_clip_embeddings_are_per_sample():
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
+    tower = CLIPVisionTower("openai/clip-vit-base-patch32").cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(1024, 3, 224, 224, device="cuda", generator=g)
+    with torch.no_grad():
+        full = tower(pixel_values=x)
+        full = getattr(full, "last_hidden_state", full)
+        idx = torch.tensor([0, 3, 512, 1023], device="cuda")
+        small = tower(pixel_values=x[idx].contiguous())
+        small = getattr(small, "last_hidden_state", small)
+    assert torch.isfinite(full).all()
+    assert torch.allclose(full[idx], small, rtol=0, atol=1e-4), float((full[idx] - small).abs().max())
