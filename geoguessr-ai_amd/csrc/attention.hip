@@ -12,6 +12,7 @@
 // k_off + h*head_stride, v at v_off + h*head_stride (TinyViT: per-head interleaved 3*D blocks -> offsets
 // 0/D/2D, stride 3D; CLIP: [q|k|v] blocks of width nh*D -> offsets 0/C/2C, stride D).
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/gg.h"
 
 struct AttnParams {
@@ -281,6 +282,106 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
                 *reinterpret_cast<bf16x4*>(p.out + (int64_t)qtok * p.ldo + h * D + dt * 16 + lg * 4) = ov;
             }
             if (p.lse && lg == 0) p.lse[(int64_t)qtok * p.nh + h] = mx * p.scale + __logf(l);
+        }
+    }
+}
+
+// Small windows (N <= 64 tokens: the 7x7 stages, 4 key tiles = one query tile per wave): a workgroup walks GW consecutive windows
+// of one head.  The query tile's bias tiles stay in registers across the windows (they depend on the head and the tile only: the
+// per-window re-read was a third of this kernel's time), K / V of window g+1 travel through registers while window g is computed
+// (two LDS images), and launch + prologue cost is paid once per GW windows.
+template <int D, int GW>
+__global__ __launch_bounds__(256) void attn_fwd_small_kernel(AttnParams p, int num_windows) {
+    constexpr int NKT = 4, Np = 64, RS = D + 8, KS = D / 32, DT = D / 16;
+    constexpr int IT = (Np * (D / 8) + 255) / 256;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2][Np * RS];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2][Np * RS];
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int wb = bid / p.nh, h = bid % p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int nqt = (p.N + 15) / 16;
+    const int qi = wave * 16 + lr;
+    const int kcol = p.k_off + h * p.head_stride, vcol = p.v_off + h * p.head_stride, qcol = p.q_off + h * p.head_stride;
+    // bias tiles of this wave's query tile (raw bf16 pairs), or the padding mask
+    u32x2 braw[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+        braw[kt] = p.bias ? *reinterpret_cast<const u32x2*>(p.bias + ((int64_t)h * Np + qi) * Np + kt * 16 + lg * 4) : attn_mask_raw(kt * 16 + lg * 4, p.N);
+    const float c2 = p.scale * 1.4426950408889634f;
+    const int w0 = wb * GW, w1 = min(num_windows, w0 + GW);
+    bf16x8 kr[IT], vr[IT], qf[KS];
+    int qtok = -1;
+    auto fetch = [&](int w) {          // K / V rows and this wave's Q fragment of window w -> registers
+        const int origin = attn_origin(p, w);
+        int tokv[IT];
+        attn_stage_tokens<D, Np>(p, origin, tokv);
+        attn_load_rows<D, Np>(kr, p.qkv, p.ld, kcol, tokv);
+        attn_load_rows<D, Np>(vr, p.qkv, p.ld, vcol, tokv);
+        qtok = wave < nqt ? attn_token(p, origin, qi) : -1;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, qcol + ks * 32 + lg * 8);
+    };
+    if (w0 < w1) fetch(w0);
+    for (int w = w0; w < w1; ++w) {
+        const int sel = (w - w0) & 1;
+        attn_store_rows<D, Np>(Ks[sel], RS, kr);
+        attn_store_rows<D, Np>(Vs[sel], RS, vr);
+        bf16x8 qcur[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qcur[ks] = qf[ks];
+        const int qtok_cur = qtok;
+        __syncthreads();               // image `sel` complete; image `sel^1` was last read before the previous iteration's barrier
+        if (w + 1 < w1) fetch(w + 1);
+        if (wave < nqt) {
+            f32x4 sc[NKT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                sc[kt] = attn_bias_cvt(braw[kt]);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 kf = attn_lds_row_frag(Ks[sel], RS, kt * 16 + lr, ks * 32 + lg * 8);
+                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qcur[ks], sc[kt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mb = mx * c2;
+            float l = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], c2, -mb));
+                    sc[kt][r] = e;
+                    l += e;
+                }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            f32x4 o[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kp = 0; kp < NKT / 2; ++kp) {
+                const bf16x8 pf = attn_pack(sc[2 * kp], sc[2 * kp + 1]);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    const bf16x8 vf = attn_lds_tr_frag(Vs[sel], RS, dt * 16, kp * 32, lr, lg);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+            if (qtok_cur >= 0) {
+                const float inv = 1.f / l;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
+                    *reinterpret_cast<bf16x4*>(p.out + (int64_t)qtok_cur * p.ldo + h * D + dt * 16 + lg * 4) = ov;
+                }
+                if (p.lse && lg == 0) p.lse[(int64_t)qtok_cur * p.nh + h] = mx * p.scale + __logf(l);
+            }
         }
     }
 }
@@ -608,6 +709,14 @@ extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
     GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 8.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
     const int nkt = attn_nkt(p.N);
 #define GG_FWD(D_, K_) hipLaunchKernelGGL((attn_fwd_kernel<D_, K_>), grid, block, 0, s, p)
+    static const char* small_env = getenv("GG_ATTN_SMALL");
+    if (a->head_dim == 32 && nkt == 4 && !(small_env && small_env[0] == '0') && a->num_windows >= 64) {
+        constexpr int GW = 8;          // windows per workgroup
+        const dim3 g2((unsigned)(gg_cdiv(a->num_windows, GW) * a->num_heads));
+        hipLaunchKernelGGL((attn_fwd_small_kernel<32, GW>), g2, block, 0, s, p, a->num_windows);
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     if (a->head_dim == 32) {
         if (nkt == 4) GG_FWD(32, 4); else if (nkt == 10) GG_FWD(32, 10); else if (nkt == 14) GG_FWD(32, 14); else GG_FWD(32, 16);
     } else {
