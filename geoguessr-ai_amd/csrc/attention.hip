@@ -649,6 +649,207 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnParams p) {
         }
     }
 }
+// Backward for small windows (N <= 64 tokens), GW consecutive windows of one head per workgroup: Q, K, V, dO of window g+1 are in
+// flight while window g is computed (two sets of LDS images), the bias tiles of the wave's query tile (phase 1) and key tile
+// (phase 2) stay in registers for all GW windows, and the bias-gradient bins are flushed once per workgroup.
+template <int D, int GW, bool DBIAS>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnParams p, int num_windows) {
+    constexpr int NKT = 4, Np = 64, RS = D + 8, KS = D / 32, DT = D / 16, CH = D / 8;
+    constexpr int IT = (Np * CH + 255) / 256;
+    constexpr int DBC = 8;
+    __shared__ __attribute__((aligned(16))) bf16 img[2][4][Np * RS];          // [buffer][Q, K, V, dO]
+    __shared__ __attribute__((aligned(16))) float row_lse[2][Np], row_delta[2][Np];
+    __shared__ float dbias_s[DBIAS ? DBC * 256 : 1];
+    __shared__ __attribute__((aligned(4))) unsigned char ci[Np], cj[Np];
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int wb = bid / p.nh, h = bid % p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int qcol = p.q_off + h * p.head_stride, kcol = p.k_off + h * p.head_stride, vcol = p.v_off + h * p.head_stride;
+    const int ocol = h * D;
+    const int nt = (p.N + 15) / 16;
+    const int ti = wave * 16 + lr;                 // this lane's query row (phase 1) / key row (phase 2)
+    for (int t = threadIdx.x; t < Np; t += blockDim.x) {
+        const int tt = min(t, p.N - 1), i = (tt * p.ws_inv) >> 16;
+        ci[t] = p.ws ? (unsigned char)i : 0;
+        cj[t] = p.ws ? (unsigned char)(tt - i * p.ws) : 0;
+    }
+    if (DBIAS) { for (int t = threadIdx.x; t < DBC * 256; t += blockDim.x) dbias_s[t] = 0.f; }
+    // bias tiles: phase 1 reads row ti (query) x key tiles; phase 2 reads row min(ti, N-1) (key; symmetric table) x query tiles
+    u32x2 bq[NKT], bk[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int c0 = kt * 16 + lg * 4;
+        bq[kt] = p.bias ? *reinterpret_cast<const u32x2*>(p.bias + ((int64_t)h * Np + ti) * Np + c0) : attn_mask_raw(c0, p.N);
+        bk[kt] = p.bias ? *reinterpret_cast<const u32x2*>(p.bias + ((int64_t)h * Np + min(ti, p.N - 1)) * Np + c0) : attn_mask_raw(c0, p.N);
+    }
+    const float c2 = p.scale * 1.4426950408889634f;
+    const int w0 = wb * GW, w1 = min(num_windows, w0 + GW);
+    bf16x8 qr[IT], kr[IT], vr[IT], dr[IT], orr[IT];
+    float lse_r = 0.f;
+    auto fetch = [&](int w) {
+        const int origin = attn_origin(p, w);
+        int tokv[IT];
+        attn_stage_tokens<D, Np>(p, origin, tokv);
+        attn_load_rows<D, Np>(qr, p.qkv, p.ld, qcol, tokv);
+        attn_load_rows<D, Np>(kr, p.qkv, p.ld, kcol, tokv);
+        attn_load_rows<D, Np>(vr, p.qkv, p.ld, vcol, tokv);
+        attn_load_rows<D, Np>(dr, p.dout, p.lddo, ocol, tokv);
+        attn_load_rows<D, Np>(orr, p.out, p.ldo, ocol, tokv);
+        if (threadIdx.x < Np) {
+            const int tk = attn_token(p, origin, threadIdx.x);
+            lse_r = tk >= 0 ? -1.4426950408889634f * p.lse[(int64_t)tk * p.nh + h] : 0.f;
+        }
+    };
+    if (w0 < w1) fetch(w0);
+    for (int w = w0; w < w1; ++w) {
+        const int sel = (w - w0) & 1;
+        bf16* Qs = img[sel][0]; bf16* Ks = img[sel][1]; bf16* Vs = img[sel][2]; bf16* dOs = img[sel][3];
+        attn_store_rows<D, Np>(Qs, RS, qr);
+        attn_store_rows<D, Np>(Ks, RS, kr);
+        attn_store_rows<D, Np>(Vs, RS, vr);
+        attn_store_rows<D, Np>(dOs, RS, dr);
+        if (threadIdx.x < Np) row_lse[sel][threadIdx.x] = lse_r;
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm += (float)dr[i][j] * (float)orr[i][j];
+#pragma unroll
+            for (int o = 1; o < CH; o <<= 1) sm += __shfl_xor(sm, o, 64);
+            if (idx < Np * CH && (idx % CH) == 0) row_delta[sel][idx / CH] = -sm;
+        }
+        const int origin = attn_origin(p, w);
+        const int tok_own = wave < nt ? attn_token(p, origin, ti) : -1;
+        __syncthreads();
+        if (w + 1 < w1) fetch(w + 1);
+        if (wave < nt) {
+            // ---- phase 1: this wave's query tile -> dQ (and dbias) ----
+            {
+                bf16x8 qf[KS], dof[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    qf[ks] = attn_lds_row_frag(Qs, RS, ti, ks * 32 + lg * 8);
+                    dof[ks] = attn_lds_row_frag(dOs, RS, ti, ks * 32 + lg * 8);
+                }
+                const int qci = ci[ti], qcj = cj[ti];
+                const float nlse_q = row_lse[sel][ti], ndelta_q = row_delta[sel][ti];
+                f32x4 dq[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) dq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kp = 0; kp < NKT / 2; ++kp) {
+                    f32x4 dst[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int kt = kp * 2 + u;
+                        f32x4 acc = attn_bias_cvt(bq[kt]), acc2 = {ndelta_q, ndelta_q, ndelta_q, ndelta_q};
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 kf = attn_lds_row_frag(Ks, RS, kt * 16 + lr, ks * 32 + lg * 8);
+                            const bf16x8 vf = attn_lds_row_frag(Vs, RS, kt * 16 + lr, ks * 32 + lg * 8);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[ks], acc2, 0, 0, 0);
+                        }
+                        const int key0 = kt * 16 + lg * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc2[r] *= __builtin_amdgcn_exp2f(fmaf(acc[r], c2, nlse_q));
+                        if (DBIAS && tok_own >= 0) {
+                            const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
+                            const uchar4 kcj = *reinterpret_cast<const uchar4*>(&cj[key0]);
+                            const int kcis[4] = {kci.x, kci.y, kci.z, kci.w}, kcjs[4] = {kcj.x, kcj.y, kcj.z, kcj.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                if (key0 + r < p.N) atomicAdd(&dbias_s[(lr & (DBC - 1)) * 256 + abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r])], acc2[r]);
+                        }
+                        dst[u] = acc2;
+                    }
+                    const bf16x8 df = attn_pack(dst[0], dst[1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16x8 kf = attn_lds_tr_frag(Ks, RS, dt * 16, kp * 32, lr, lg);
+                        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, df, dq[dt], 0, 0, 0);
+                    }
+                }
+                if (tok_own >= 0) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        bf16x4 ov = {(bf16)(dq[dt][0] * p.scale), (bf16)(dq[dt][1] * p.scale), (bf16)(dq[dt][2] * p.scale), (bf16)(dq[dt][3] * p.scale)};
+                        *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)tok_own * p.ld + qcol + dt * 16 + lg * 4) = ov;
+                    }
+                }
+            }
+            // ---- phase 2: this wave's key tile -> dK, dV ----
+            {
+                bf16x8 kf[KS], vf[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    kf[ks] = attn_lds_row_frag(Ks, RS, ti, ks * 32 + lg * 8);
+                    vf[ks] = attn_lds_row_frag(Vs, RS, ti, ks * 32 + lg * 8);
+                }
+                f32x4 dk[DT], dv[DT];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { dk[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int qp = 0; qp < NKT / 2; ++qp) {
+                    f32x4 pt[2], dst[2];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int qt = qp * 2 + u;
+                        const int q0 = qt * 16 + lg * 4;
+                        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&row_lse[sel][q0]);
+                        f32x4 acc = attn_bias_cvt(bk[qt]), acc2 = *reinterpret_cast<const f32x4*>(&row_delta[sel][q0]);
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            const bf16x8 qf = attn_lds_row_frag(Qs, RS, qt * 16 + lr, ks * 32 + lg * 8);
+                            const bf16x8 dof = attn_lds_row_frag(dOs, RS, qt * 16 + lr, ks * 32 + lg * 8);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf[ks], acc, 0, 0, 0);
+                            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, vf[ks], acc2, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pr = __builtin_amdgcn_exp2f(fmaf(acc[r], c2, l4[r]));
+                            acc[r] = pr;
+                            acc2[r] *= pr;
+                        }
+                        pt[u] = acc;
+                        dst[u] = acc2;
+                    }
+                    const bf16x8 pf = attn_pack(pt[0], pt[1]);
+                    const bf16x8 df = attn_pack(dst[0], dst[1]);
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const bf16x8 qtf = attn_lds_tr_frag(Qs, RS, dt * 16, qp * 32, lr, lg);
+                        const bf16x8 dotf = attn_lds_tr_frag(dOs, RS, dt * 16, qp * 32, lr, lg);
+                        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, df, dk[dt], 0, 0, 0);
+                        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dotf, pf, dv[dt], 0, 0, 0);
+                    }
+                }
+                if (tok_own >= 0) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        bf16x4 a = {(bf16)(dk[dt][0] * p.scale), (bf16)(dk[dt][1] * p.scale), (bf16)(dk[dt][2] * p.scale), (bf16)(dk[dt][3] * p.scale)};
+                        bf16x4 b = {(bf16)dv[dt][0], (bf16)dv[dt][1], (bf16)dv[dt][2], (bf16)dv[dt][3]};
+                        *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)tok_own * p.ld + kcol + dt * 16 + lg * 4) = a;
+                        *reinterpret_cast<bf16x4*>(p.dqkv + (int64_t)tok_own * p.ld + vcol + dt * 16 + lg * 4) = b;
+                    }
+                }
+            }
+        }
+    }
+    if (DBIAS) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) {
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < DBC; ++c) sum += dbias_s[c * 256 + t];
+            if (p.dbias_part) p.dbias_part[((int64_t)wb * p.nh + h) * p.nbias + t] = sum;      // one row per (window group, head)
+            else atomicAdd(&p.dbias[h * p.nbias + t], sum);
+        }
+    }
+}
+
 // dbias[h][t] += sum over the (folded) window rows of part[row][h][t]
 __global__ void attn_dbias_final_kernel(const float* __restrict__ rows, int nrows, int W, float* __restrict__ dbias) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,12 +942,20 @@ extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
         if (p.dbias) hipLaunchKernelGGL((attn_bwd_kernel<32, K_, true>), grid, block, 0, s, p);          \
         else hipLaunchKernelGGL((attn_bwd_kernel<32, K_, false>), grid, block, 0, s, p);                 \
     } while (0)
-    if (nkt == 4) GG_BWD(4); else if (nkt == 10) GG_BWD(10); else if (nkt == 14) GG_BWD(14); else GG_BWD(16);
+    static const char* small_env = getenv("GG_ATTN_SMALL");
+    int part_rows = a->num_windows;
+    if (nkt == 4 && !(small_env && small_env[0] == '0') && a->num_windows >= 64) {
+        constexpr int GW = 8;
+        part_rows = (int)gg_cdiv(a->num_windows, GW);
+        const dim3 g2((unsigned)(part_rows * a->num_heads));
+        if (p.dbias) hipLaunchKernelGGL((attn_bwd_small_kernel<32, GW, true>), g2, block, 0, s, p, a->num_windows);
+        else hipLaunchKernelGGL((attn_bwd_small_kernel<32, GW, false>), g2, block, 0, s, p, a->num_windows);
+    } else if (nkt == 4) GG_BWD(4); else if (nkt == 10) GG_BWD(10); else if (nkt == 14) GG_BWD(14); else GG_BWD(16);
 #undef GG_BWD
     if (p.dbias && p.dbias_part) {
         const int Wd = p.nh * p.nbias;
         const float* rows; int nrows;
-        gg_reduce_rows(p.dbias_part, a->num_windows, Wd, s, &rows, &nrows);
+        gg_reduce_rows(p.dbias_part, part_rows, Wd, s, &rows, &nrows);
         hipLaunchKernelGGL(attn_dbias_final_kernel, dim3((unsigned)gg_cdiv(Wd, 256)), dim3(256), 0, s, rows, nrows, Wd, p.dbias);
     }
     GG_LAUNCH_CHECK();

@@ -321,7 +321,7 @@ def _attn_ref(qkv, nh, hd, ws, Hm, Wm, B, bias, layout):
     return o
 
 
-@pytest.mark.parametrize("ws,Hm,nh", [(7, 14, 2), (14, 14, 3), (7, 7, 2), (12, 12, 1), (16, 16, 1)])
+@pytest.mark.parametrize("ws,Hm,nh", [(7, 14, 2), (14, 14, 3), (7, 7, 2), (12, 12, 1), (16, 16, 1), (7, 35, 2), (7, 42, 3)])
 def test_window_attention_fwd_bwd(ops, ws, Hm, nh):
     B, hd = 3, 32
     C = nh * hd
@@ -339,6 +339,11 @@ def test_window_attention_fwd_bwd(ops, ws, Hm, nh):
     dqkv, dbias = ops.attention(dev(qkv, BF), dout=dev(dout, BF), want_dbias=True, out=out, lse=lse, **kw)
     close(dqkv, qr.grad, rtol=3e-2, atol=3e-2, what="attn dqkv")
     close(dbias, br.grad, rtol=3e-2, atol=5e-2, what="attn dbias")
+    # frozen-bias variant of the kernel (no dbias bins) must give the same dqkv; (7,35)/(7,42) have >= 64 windows and take the
+    # multi-window kernels (75 windows = a ragged last group of 8)
+    dqkv2 = ops.attention(dev(qkv, BF), dout=dev(dout, BF), out=out, lse=lse, **kw)
+    dqkv2 = dqkv2[0] if isinstance(dqkv2, tuple) else dqkv2
+    assert torch.equal(dqkv2, dqkv)
 
 
 def test_clip_attention_fwd(ops):
