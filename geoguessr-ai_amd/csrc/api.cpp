@@ -48,6 +48,18 @@ GgProfScope::~GgProfScope() {
 }
 extern "C" int gg_prof_enable(int on) { g_on = on != 0; return 0; }
 extern "C" int gg_prof_reset(void) { g_recs.clear(); g_pool_next = 0; return 0; }
+extern "C" int gg_prof_count(void) { return (int)g_recs.size(); }
+extern "C" int gg_prof_record(int index, int* cat, double* ms, double* flops, double* bytes) {
+    if (index < 0 || index >= (int)g_recs.size()) { gg_set_error("gg_prof_record: index %d out of range", index); return -1; }
+    Rec& r = g_recs[index];
+    float e = 0;
+    if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&e, r.a, r.b) != hipSuccess) { gg_set_error("gg_prof_record: event read failed"); return -2; }
+    if (cat) *cat = r.cat;
+    if (ms) *ms = e;
+    if (flops) *flops = r.flops;
+    if (bytes) *bytes = r.bytes;
+    return 0;
+}
 extern "C" int gg_prof_read(int cat, double* ms, int64_t* launches, double* flops, double* bytes) {
     double t = 0, f = 0, b = 0; int64_t n = 0;
     for (auto& r : g_recs) {

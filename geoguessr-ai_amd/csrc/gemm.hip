@@ -57,9 +57,43 @@ enum { EPI_PLAIN = 0,    // raw accumulators (+ optional BatchNorm column statis
        EPI_F32 = 5,      // f32 output (+ bias?) or split-K partial slabs            : head logits, wgrads
        EPI_BNBWD = 6 };  // * act'(BN(y)) of the ConvNorm the gradient flows into, + its backward column sums: conv dgrads
 
-template <int BM, int BN, int WM, int WN, int EPI>
+// The second tensor of the row phase (residual / saved pre-activation / saved BatchNorm input) for this thread's row-phase
+// slots: range-checked 16-byte buffer loads, all passes in flight at once; rows beyond M and chunks beyond N read as zeros.
+template <int BM, int BN, int EPI>
+__device__ __forceinline__ void gemm_ext_load(const GemmParams& p, int m0, int n0, bf16x8 (&ex)[BM / (256 / (BN / 8))]) {
+    constexpr int CPR = BN / 8, RPP = 256 / CPR, NP = BM / RPP;
+    const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
+    const int n = n0 + chunk * 8;
+    const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : (EPI == EPI_BNBWD ? p.bn_y : nullptr));
+    const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
+    if ((EPI == EPI_DGELU || EPI == EPI_LINEAR || EPI == EPI_BNBWD) && ext) {
+        if (((lde & 7) == 0) && ((p.N & 7) == 0) && (((uintptr_t)ext & 15) == 0)) {
+            // range-checked 16-byte buffer loads, all passes in flight before the first use; rows beyond M and column
+            // chunks beyond N come back as zeros
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned bytesE = (unsigned)min(p.M - m0, BM) * (unsigned)lde * 2u;
+            const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(ext + (int64_t)m0 * lde), 0, (int)bytesE, 0x00020000);
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const unsigned vo = ((unsigned)(pass * RPP + rr) * (unsigned)lde + (unsigned)n) * 2u;
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)(n < p.N ? vo : 0xFFFFFFF0u), 0, 0);
+                ex[pass] = __builtin_bit_cast(bf16x8, raw);
+            }
+        } else {
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int m = m0 + pass * RPP + rr;
+                bf16x8 d = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (m < p.M) { for (int j = 0; j < 8; ++j) if (n + j < p.N) d[j] = ext[(int64_t)m * lde + n + j]; }
+                ex[pass] = d;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, bool PRELOADED>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
-                                              int tm, int z, int wm, int wn, int lr, int lg) {
+                                              int tm, int z, int wm, int wn, int lr, int lg, bf16x8 (&ex)[BM / (256 / (BN / 8))], const float* btab) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     // ---------------- lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
@@ -68,12 +102,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     // which cost more than the whole k-loop of a K = 384 GEMM.
     constexpr bool has_bias = EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU || EPI == EPI_F32;
     float bs[TN][4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const bool bias_vec = has_bias && p.bias && (p.N & 3) == 0 && ((uintptr_t)p.bias & 15) == 0;
+    const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, bias_vec ? p.N * 4 : 0, 0x00020000);
     if (has_bias) {
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
             const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bs[nt][r] = p.bias ? p.bias[min(n + r, p.N - 1)] : 0.f;
+            for (int r = 0; r < 4; ++r) bs[nt][r] = 0.f;
+            if (!p.bias) continue;
+            if (bias_vec) {          // one range-checked 16-byte load per fragment column group (4 loads, not 16, per tile and thread)
+                const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, n * 4, 0, 0));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bs[nt][r] = b4[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bs[nt][r] = p.bias[min(n + r, p.N - 1)];
+            }
         }
     }
     if (EPI == EPI_F32) {
@@ -138,42 +184,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
     const int n = n0 + chunk * 8;
     const bool wide = ((p.ldc & 7) == 0) && (n + 7 < p.N);
-    const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : (EPI == EPI_BNBWD ? p.bn_y : nullptr));
-    const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
-    bf16x8 ex[NP];
     f32x2 bsc[4], bsh[4], brs[4], bnm[4];      // EPI_BNBWD: z = y*bsc + bsh, xhat = y*brs + bnm for this thread's 8 columns
     if (EPI == EPI_BNBWD) {
+        // btab = [bsc | bsh | brs | bnm][BN], one column per thread, written by the kernel before its k-loop (the k-loop's
+        // barriers order it): 32 scalar parameter loads per thread and tile cost more than the operand loads of a K = 96 dgrad
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = min(n + j, p.N - 1);
-            const float mu = p.bn_stat[c], rstd = p.bn_stat[p.N + c], ga = p.bn_gamma[c], be = p.bn_beta[c];
-            bsc[j >> 1][j & 1] = ga * rstd; bsh[j >> 1][j & 1] = be - mu * ga * rstd;
-            brs[j >> 1][j & 1] = rstd; bnm[j >> 1][j & 1] = -mu * rstd;
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(btab + 0 * BN + chunk * 8 + 4 * q), b = *reinterpret_cast<const f32x4*>(btab + 1 * BN + chunk * 8 + 4 * q);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(btab + 2 * BN + chunk * 8 + 4 * q), d = *reinterpret_cast<const f32x4*>(btab + 3 * BN + chunk * 8 + 4 * q);
+            bsc[2 * q] = (f32x2){a[0], a[1]}; bsc[2 * q + 1] = (f32x2){a[2], a[3]};
+            bsh[2 * q] = (f32x2){b[0], b[1]}; bsh[2 * q + 1] = (f32x2){b[2], b[3]};
+            brs[2 * q] = (f32x2){c[0], c[1]}; brs[2 * q + 1] = (f32x2){c[2], c[3]};
+            bnm[2 * q] = (f32x2){d[0], d[1]}; bnm[2 * q + 1] = (f32x2){d[2], d[3]};
         }
     }
-    if ((EPI == EPI_DGELU || EPI == EPI_LINEAR || EPI == EPI_BNBWD) && ext) {
-        if (((lde & 7) == 0) && ((p.N & 7) == 0) && (((uintptr_t)ext & 15) == 0)) {
-            // range-checked 16-byte buffer loads, all passes in flight before the first use; rows beyond M and column
-            // chunks beyond N come back as zeros
-            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-            const unsigned bytesE = (unsigned)min(p.M - m0, BM) * (unsigned)lde * 2u;
-            const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(ext + (int64_t)m0 * lde), 0, (int)bytesE, 0x00020000);
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const unsigned vo = ((unsigned)(pass * RPP + rr) * (unsigned)lde + (unsigned)n) * 2u;
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)(n < p.N ? vo : 0xFFFFFFF0u), 0, 0);
-                ex[pass] = __builtin_bit_cast(bf16x8, raw);
-            }
-        } else {
-#pragma unroll
-            for (int pass = 0; pass < NP; ++pass) {
-                const int m = m0 + pass * RPP + rr;
-                bf16x8 d = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (m < p.M) { for (int j = 0; j < 8; ++j) if (n + j < p.N) d[j] = ext[(int64_t)m * lde + n + j]; }
-                ex[pass] = d;
-            }
-        }
-    }
+    if (!PRELOADED) gemm_ext_load<BM, BN, EPI>(p, m0, n0, ex);
     __syncthreads();
     const bool stats = (EPI == EPI_PLAIN || EPI == EPI_BNBWD) && p.colstats != nullptr;
     f32x2 cs2[4], cq2[4];
@@ -192,7 +217,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         const int row = pass * RPP + rr, m = m0 + row;
         if (m >= p.M || n >= p.N) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
-        if (EPI == EPI_BNBWD) {
+        if (EPI == EPI_BNBWD && !(p.debug & 8)) {
             // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat (of the stored, bf16-rounded dz)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -230,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         }
         store8(reinterpret_cast<bf16*>(p.C), m, v);
     }
-    if (stats) {
+    if (stats && !(p.debug & 16)) {
         __syncthreads();
         float cs[8], cq[8];
 #pragma unroll
@@ -330,6 +355,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    constexpr bool EARLY = false;          // fetching the epilogue's second tensor before the k-loop: measured no gain, +24 VGPRs
+    bf16x8 ex[BM / (256 / (BN / 8))];
+    __shared__ __attribute__((aligned(16))) float btab[EPI == EPI_BNBWD ? 4 * BN : 4];
+    if (EPI == EPI_BNBWD && threadIdx.x < BN) {
+        const int c = min(n0 + (int)threadIdx.x, p.N - 1);
+        const float mu = p.bn_stat[c], rstd = p.bn_stat[p.N + c], ga = p.bn_gamma[c], be = p.bn_beta[c];
+        btab[0 * BN + threadIdx.x] = ga * rstd; btab[1 * BN + threadIdx.x] = be - mu * ga * rstd;
+        btab[2 * BN + threadIdx.x] = rstd; btab[3 * BN + threadIdx.x] = -mu * rstd;
+    }
+    if (EARLY && !(p.debug & 4)) gemm_ext_load<BM, BN, EPI>(p, m0, n0, ex);
+    if (EARLY && (p.debug & 4)) { for (auto& e : ex) e = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1}; }
     u32x4 ra[LA], rb[LB];
     const int nk = (kend - kbeg + BK - 1) / BK;
     auto load_tile = [&](int kt) {
@@ -394,7 +430,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
         }
         __syncthreads();
     }
-    gemm_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg);
+    gemm_epilogue<BM, BN, WM, WN, EPI, EARLY>(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg, ex, btab);
 }
 
 // ------------------------------------------------------------------------------------------- TN GEMM (weight gradients)

@@ -206,6 +206,9 @@ int gg_fill_f32(float* p, int64_t n, float value, void* stream);
 int gg_prof_enable(int on);
 int gg_prof_reset(void);
 int gg_prof_read(int category, double* ms /* host */, int64_t* launches /* host */, double* flops /* host */, double* bytes /* host */);
+/* per-launch records since the last reset, in launch order: count, then one record (category, duration, declared flops / bytes) */
+int gg_prof_count(void);
+int gg_prof_record(int index, int* category /* host */, double* ms /* host */, double* flops /* host */, double* bytes /* host */);
 
 /* ---------------------------------------------------------------- TinyViT encoder (timm TinyVit as built by
  * models/tinyvit.py:48-53 with num_classes=0, global_pool="avg"): whole forward / backward in one call.
