@@ -457,7 +457,9 @@ struct TnParams {
     int tilesN, tilesK, m_per_split;
 };
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
-    constexpr int TB = 128, MS = 64, RS = TB + 8;          // 64-row m-step = two MFMA k-steps per barrier pair; 272-byte LDS rows
+    // 64-row m-step = two MFMA k-steps per barrier pair.  LDS rows of 288 bytes: the 16 rows x 32 bytes that one transposing
+    // read touches then fall on 16 disjoint groups of 8 banks (a 272-byte stride overlaps neighbouring rows: 2-way conflicts)
+    constexpr int TB = 128, MS = 64, RS = TB + 16;
     constexpr int LS = MS / 16;                            // 16-byte chunks per thread per operand per step
     __shared__ __attribute__((aligned(16))) bf16 Ys[MS * RS];
     __shared__ __attribute__((aligned(16))) bf16 Xs[MS * RS];
@@ -467,24 +469,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
-    // staging: MS rows x 16 chunks (16 B) per operand -> LS per thread: row = c >> 4 (+16 i), chunk = c & 15
+    // staging: MS rows x 16 chunks (16 B) per operand -> LS per thread: row = c >> 4 (+16 i), chunk = c & 15.  Range-checked
+    // buffer loads over this split's rows: rows beyond mend read as zeros, a column chunk beyond N / K is pushed out of range
+    // through its offset -- no branches around the loads (N, K multiples of 8; host checks the split's byte range < 2^32)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int srow = threadIdx.x >> 4, sch = threadIdx.x & 15;
-    const bool yok = (n0 + sch * 8) < p.N, xok = (k0 + sch * 8) < p.K;      // N, K multiples of 8
+    const bool yok = (n0 + sch * 8) < p.N, xok = (k0 + sch * 8) < p.K;
+    const int nrows = max(mend - mbeg, 0);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + (int64_t)mbeg * p.ldy), 0, (int)((unsigned)nrows * (unsigned)p.ldy * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (int64_t)mbeg * p.ldx), 0, (int)((unsigned)nrows * (unsigned)p.ldx * 2u), 0x00020000);
+    unsigned voy[LS], vox[LS];
+#pragma unroll
+    for (int i = 0; i < LS; ++i) {
+        voy[i] = yok ? ((unsigned)(srow + 16 * i) * (unsigned)p.ldy + (unsigned)(n0 + sch * 8)) * 2u : 0xFFFFFFF0u;
+        vox[i] = xok ? ((unsigned)(srow + 16 * i) * (unsigned)p.ldx + (unsigned)(k0 + sch * 8)) * 2u : 0xFFFFFFF0u;
+    }
+    const unsigned stepY = (unsigned)MS * (unsigned)p.ldy * 2u, stepX = (unsigned)MS * (unsigned)p.ldx * 2u;
+    const float inv_rps = p.rowscale ? 1.f / (float)p.rows_per_scale : 0.f;
     bf16x8 ry[LS], rx[LS];
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     auto load_step = [&](int m0) {
+        const unsigned st = (unsigned)(m0 - mbeg) / MS;
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
-            const int m = m0 + srow + 16 * i;
-            const bool mok = m < mend;
-            bf16x8 vy = (mok && yok) ? *reinterpret_cast<const bf16x8*>(p.dY + (int64_t)m * p.ldy + n0 + sch * 8) : zero8;
-            if (p.rowscale && mok && yok) {
-                const float rs = p.rowscale[m / p.rows_per_scale];
+            // a pushed-out chunk stays out of range: its offset is only advanced when valid
+            ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
+            rx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(xok ? vox[i] + st * stepX : 0xFFFFFFF0u), 0, 0));
+        }
+        if (p.rowscale) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vy[j] = (bf16)((float)vy[j] * rs);
+            for (int i = 0; i < LS; ++i) {
+                const int m = min(m0 + srow + 16 * i, p.M - 1);
+                int q = (int)((float)m * inv_rps);                       // m / rows_per_scale without the integer division
+                q += ((q + 1) * p.rows_per_scale <= m) - (q * p.rows_per_scale > m);
+                const float rs = p.rowscale[q];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ry[i][j] = (bf16)((float)ry[i][j] * rs);
             }
-            ry[i] = vy;
-            rx[i] = (mok && xok) ? *reinterpret_cast<const bf16x8*>(p.X + (int64_t)m * p.ldx + k0 + sch * 8) : zero8;
         }
     };
     f32x4 acc[4][4];     // [k tile][n tile]: D[i = n][j = k] with A = dY^T fragment, B = X fragment
@@ -867,6 +887,7 @@ extern "C" int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ld
     p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
     p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
     p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 64);
+    GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 2 < ((int64_t)1 << 32), "gg_gemm_tn: a split's rows must span < 4 GiB per operand (use more splits)");
     GG_CHECK(splits <= 65535, "gg_gemm_tn: too many splits");
     GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 2.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tilesN * p.tilesK, splits), dim3(256), 0, (hipStream_t)stream, p);

@@ -90,3 +90,12 @@ for name, M, Cin, Cout in [("mb.c1.dgrad.fold", M0, 96, 384), ("mg1.c1.dgrad.fol
     byt = 2 * (2 * M * Cout + 2 * M * Cin)
     print(f"{name:20s} M={M:9d} N={Cin:5d} K={2*Cout:5d}  {ms*1e3:9.1f} us  {2*M*Cin*2*Cout/ms/1e9:8.1f} TF/s  {byt/ms/1e6:8.1f} GB/s")
     del dz, y, Bf, dx, res
+
+# ---- TN (weight-gradient) GEMMs: kernel + slab reduction ----
+for name, M, N, K, rs in [("s3.fc1.wgrad", Ms3, 2304, 576, True), ("s3.fc2.wgrad", Ms3, 576, 2304, True), ("s3.qkv.wgrad", Ms3, 1728, 576, True),
+                          ("s3.proj.wgrad", Ms3, 576, 576, True), ("pe.conv2.wgrad", M0, 96, 432, False), ("pe.conv1.wgrad", M1, 48, 32, False)]:
+    dY = torch.randn(M, N, device="cuda").bfloat16(); X = torch.randn(M, K, device="cuda").bfloat16()
+    scale = torch.rand(B, device="cuda") if rs else None
+    ms = timed(lambda: ops.gemm_tn(dY, X, rowscale=scale, rows_per_scale=M // B if rs else 0))
+    print(f"{name:16s} M={M:9d} N={N:5d} K={K:5d}  {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TF/s  {2*M*(N+K)/ms/1e6:8.1f} GB/s")
+    del dY, X
