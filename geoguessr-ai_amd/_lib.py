@@ -84,6 +84,7 @@ SIGNATURES = {
     "gg_colsum_bf16": (_I, [_P, _L, _I, _I, _P, _I, _P, _P, _I, _P]),
     "gg_im2col_nchw3_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "gg_im2col_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "gg_im2col_nhwc_bn_bf16": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "gg_col2im_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv_tiled_stat_rows": (_I, [_I, _I]),

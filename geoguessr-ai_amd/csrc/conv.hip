@@ -64,6 +64,47 @@ __global__ __launch_bounds__(256) void im2col_nhwc_kernel(const bf16* __restrict
     }
 }
 
+// im2col of act(BatchNorm(y)) without materialising that tensor: y is the producer ConvNorm's saved pre-BatchNorm output, the
+// affine + activation runs on each gathered 16-byte chunk (bf16-rounded exactly like the stored activation would be); padding
+// taps stay zero.  scale / shift per channel come from an LDS table (C <= 512).
+__global__ __launch_bounds__(256) void im2col_nhwc_bn_kernel(const bf16* __restrict__ x, const float* __restrict__ stat,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                             bf16* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int stride) {
+    __shared__ __attribute__((aligned(16))) float tab[2 * 512];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sc = stat[C + c] * gamma[c];
+        tab[c] = sc;
+        tab[C + c] = beta[c] - stat[c] * sc;
+    }
+    __syncthreads();
+    const int cg = C >> 3;
+    const int per_pix = 9 * cg;
+    const int64_t total = (int64_t)B * Ho * Wo * per_pix;
+    const bool gelu = act == GG_ACT_GELU;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)((unsigned)i % (unsigned)per_pix);
+        const int64_t p = (unsigned)i / (unsigned)per_pix;
+        const int tap = ch / cg, g = ch % cg;
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned pu = (unsigned)p;
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
+        const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const bf16x8 r = *reinterpret_cast<const bf16x8*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 sc = *reinterpret_cast<const f32x2*>(tab + g * 8 + 2 * q), sh = *reinterpret_cast<const f32x2*>(tab + C + g * 8 + 2 * q);
+                const f32x2 z = gg_act_v2((f32x2){(float)r[2 * q], (float)r[2 * q + 1]} * sc + sh, gelu);
+                v[2 * q] = (bf16)z.x; v[2 * q + 1] = (bf16)z.y;
+            }
+        }
+        *reinterpret_cast<bf16x8*>(col + p * (9 * C) + tap * C + g * 8) = v;
+    }
+}
+
 // transpose of im2col_nhwc: dcol bf16 [B*Ho*Wo, 9*C] -> dx bf16 NHWC (gather form, no atomics)
 __global__ __launch_bounds__(256) void col2im_nhwc_kernel(const bf16* __restrict__ dcol, bf16* __restrict__ dx, int B, int H, int W,
                                                           int C, int Ho, int Wo, int stride) {
@@ -827,6 +868,18 @@ extern "C" int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W
     GG_PROF(GG_CAT_MOVE, 0, 2.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
     hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 9 * (C / 8), 65536)), dim3(256), 0,
                        (hipStream_t)stream, (const bf16*)x, (bf16*)col, B, H, W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_im2col_nhwc_bn_bf16(const void* y, const float* stat, const float* gamma, const float* beta, int act, void* col, int B,
+                                      int H, int W, int C, int stride, void* stream) {
+    GG_CHECK(y && stat && gamma && beta && col && B > 0 && (C & 7) == 0 && C <= 512 && (stride == 1 || stride == 2), "gg_im2col_nhwc_bn_bf16: bad args (C %% 8, C <= 512)");
+    GG_CHECK(act == GG_ACT_NONE || act == GG_ACT_GELU, "gg_im2col_nhwc_bn_bf16: act must be none or gelu");
+    GG_CHECK((int64_t)B * H * W * 9 * (C / 8) < ((int64_t)1 << 32), "gg_im2col_nhwc_bn_bf16: tensor too large for 32-bit indexing");
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 2.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
+    hipLaunchKernelGGL(im2col_nhwc_bn_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 9 * (C / 8), 65536)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)y, stat, gamma, beta, act, (bf16*)col, B, H, W, C, Ho, Wo, stride);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -188,7 +188,7 @@ struct MBAct { int64_t x, a1, a2, out; Act c1, c2, c3; };
 struct MergeAct { int64_t a1, a2, out; Act c1, c2, c3; };
 struct BlockAct { int64_t x0, a, mean1, rstd1, qkv, o, lse, x1, x2, b, mean2, rstd2, hpre, h, x3; Act local; };
 struct Layout {
-    int64_t col1, a_pe1, col2, x_pe; Act pe1, pe2;
+    int64_t col1, col2, x_pe; Act pe1, pe2;
     std::vector<MBAct> mb;
     MergeAct merge[3];
     std::vector<BlockAct> blocks[3];
@@ -223,7 +223,6 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
     };
     L.col1 = p.alloc("patch_embed.col1", M1 * 32 * 2);
     bnreg("patch_embed.conv1", L.pe1, M1, d[0] / 2, false, B, H1, H1);
-    L.a_pe1 = p.alloc("patch_embed.act1", M1 * (d[0] / 2) * 2);
     L.col2 = p.alloc("patch_embed.col2", M0 * m.pe2.w.Kp * 2);
     track(M0 * m.pe2.w.Kp); track(M1 * 32);
     bnreg("patch_embed.conv2", L.pe2, M0, d[0], false, B, H0, H0);
@@ -454,9 +453,10 @@ static int forward_impl(Exec& e, const float* x, float* out) {
     // PatchEmbed: conv3x3 s2 + BN + GELU, conv3x3 s2 + BN
     GG_TRY(gg_im2col_nchw3_f32(x, e.A(L.col1), B, H, H, 2, e.st));
     GG_TRY(conv_dense_fwd(e, m.pe1, L.pe1, e.A(L.col1), 32, M1));
-    GG_TRY(bn_apply(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, e.A(L.a_pe1)));
     GG_CHECK(m.pe2.w.Kp == m.pe2.w.K, "tinyvit: patch_embed.conv2 K=%d must be a multiple of 8", m.pe2.w.K);
-    GG_TRY(gg_im2col_nhwc_bf16(e.A(L.a_pe1), e.A(L.col2), B, H1, H1, d[0] / 2, 2, e.st));
+    // BN1 + GELU ride on conv2's im2col gather: the activation tensor (M1 x 48, the largest of the model) is never written
+    GG_TRY(gg_im2col_nhwc_bn_bf16(e.A(L.pe1.y), e.F(L.pe1.stat), e.P(m.pe1.bn.t_g), e.P(m.pe1.bn.t_b), GG_ACT_GELU, e.A(L.col2), B, H1, H1,
+                                  d[0] / 2, 2, e.st));
     GG_TRY(conv_dense_fwd(e, m.pe2, L.pe2, e.A(L.col2), m.pe2.w.Kp, M0));
     GG_TRY(bn_apply(e, m.pe2.bn, L.pe2, M0, GG_ACT_NONE, e.A(L.x_pe)));
 

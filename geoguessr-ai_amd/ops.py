@@ -136,6 +136,16 @@ def im2col_nhwc(x, stride=2):
     return col
 
 
+def im2col_nhwc_bn(y, stat, gamma, beta, act="gelu", stride=2):
+    """im2col of act(BatchNorm(y)) for a saved pre-BatchNorm conv output y (B,H,W,C); the activation tensor is never stored."""
+    B, H, W, Cc = y.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    col = torch.empty((B * Ho * Wo, 9 * Cc), dtype=BF16, device=y.device)
+    L.check(L.lib().gg_im2col_nhwc_bn_bf16(_p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(col), B, H, W, Cc,
+                                           stride, L.stream()), "gg_im2col_nhwc_bn_bf16")
+    return col
+
+
 def col2im_nhwc(dcol, B, H, W, Cc, stride=2):
     dx = torch.empty((B, H, W, Cc), dtype=BF16, device=dcol.device)
     L.check(L.lib().gg_col2im_nhwc_bf16(_p(dcol, BF16), _p(dx), B, H, W, Cc, stride, L.stream()), "gg_col2im_nhwc_bf16")

@@ -78,6 +78,9 @@ int gg_colsum_bf16(const void* x, int64_t ld, int M, int C, const float* rowscal
  * PatchMerging.conv2, TinyVitBlock.local_conv) direct, taps f32 [9][C]. */
 int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int W, int stride, void* stream);   /* (B,3,H,W) f32 -> bf16 [B*Ho*Wo,32] */
 int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, int stride, void* stream);
+/* same gather over act(BatchNorm(y)) of a saved pre-BatchNorm conv output y (stat = [mean | rstd][C]); the activation tensor is not stored */
+int gg_im2col_nhwc_bn_bf16(const void* y, const float* stat, const float* gamma, const float* beta, int act, void* col, int B, int H, int W, int C,
+                          int stride, void* stream);
 int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream);
 int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride);   /* partial-statistics rows gg_dwconv3x3_fwd writes */
 int gg_dwconv_tiled_stat_rows(int B, int Ho);                          /* ... the producer-fused forward variant (LDS-tiled kernel) */

@@ -205,6 +205,24 @@ def test_im2col_matches_conv(ops):
     close(dx, xr.grad, what="col2im")
 
 
+def test_im2col_fused_batchnorm_gelu(ops):
+    """im2col over GELU(BatchNorm(y)) of a saved conv output == BatchNorm-apply pass followed by the plain im2col (the activation
+    tensor the reference materialises, patch_embed.conv1 -> conv2: tiny_vit.py PatchEmbed); padding taps stay exactly zero."""
+    B, H, C = 3, 18, 48
+    y = dev(rnd(B, H, H, C, seed=16, scale=2.0), BF)
+    mean, var = rnd(C, seed=17, scale=0.5), rnd(C, seed=18).abs() + 0.5
+    stat = dev(torch.stack([mean, (var + 1e-5).rsqrt()]))
+    gamma, beta = dev(rnd(C, seed=19) + 1.0), dev(rnd(C, seed=20, scale=0.3))
+    for act in ("gelu", None):
+        a = ops.bn_apply(y.view(-1, C), stat, gamma, beta, act=act).view(B, H, H, C)
+        want = ops.im2col_nhwc(a, stride=2)
+        got = ops.im2col_nhwc_bn(y, stat, gamma, beta, act=act, stride=2)
+        assert ((want == 0) == (got == 0)).all() or (want.float() - got.float()).abs().max() < 1e-2
+        close(got, want.float(), rtol=8e-3, atol=1e-3, what=f"fused im2col act={act}")      # <= 1 bf16 ulp (scalar vs paired GELU form)
+        border = got.view(B, H // 2, H // 2, 9, C)[:, 0, :, 0:3]                               # ky = 0 taps of the first output row: padding
+        assert (border == 0).all()
+
+
 @pytest.mark.parametrize("C,stride,H", [(16, 1, 12), (48, 2, 14), (384, 1, 8), (576, 2, 14), (40, 1, 7)])
 def test_dwconv(ops, C, stride, H):
     B = 3
