@@ -10,34 +10,62 @@
 // x f32 NCHW (B,3,H,W) -> col bf16 [B*Ho*Wo, 32]; k = (ky*3+kx)*3 + ci for k < 27, zeros above.
 __global__ __launch_bounds__(256) void im2col_nchw3_kernel(const float* __restrict__ x, bf16* __restrict__ col, int B, int H,
                                                            int W, int Ho, int Wo, int stride) {
-    const int64_t total = (int64_t)B * Ho * Wo;
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned pu = (unsigned)p;
+    // thread = (output pixel, 16-byte quarter of its 64-byte col row): a wave's store is 1 KiB contiguous
+    const int64_t total = (int64_t)B * Ho * Wo * 4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned pu = (unsigned)(i >> 2);
+        const int q = (int)(i & 3);
         const int ox = (int)(pu % (unsigned)Wo);
         const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
         const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
         const float* xb = x + (int64_t)b * 3 * H * W;
-        bf16 v[32];
+        bf16x8 t;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
-                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-#pragma unroll
-                for (int ci = 0; ci < 3; ++ci)
-                    v[(ky * 3 + kx) * 3 + ci] = ok ? (bf16)xb[((int64_t)ci * H + iy) * W + ix] : (bf16)0.f;
-            }
-#pragma unroll
-        for (int k = 27; k < 32; ++k) v[k] = (bf16)0.f;
-        bf16x8* o = reinterpret_cast<bf16x8*>(col + p * 32);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x8 t;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = v[i * 8 + j];
-            o[i] = t;
+        for (int j = 0; j < 8; ++j) {
+            const int k = q * 8 + j;
+            const int tap = (k * 11) >> 5, ci = k - tap * 3;          // k / 3, k % 3 for k < 32
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+            const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+            const bool ok = k < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            t[j] = ok ? (bf16)xb[((int64_t)ci * H + iy) * W + ix] : (bf16)0.f;
         }
+        *reinterpret_cast<bf16x8*>(col + (int64_t)pu * 32 + q * 8) = t;
+    }
+}
+
+// Same result through LDS: block = (image, band of RB output rows); the 2*RB+1 input rows of the 3 planes are read once as
+// full-width 16-byte loads (the per-pixel gather above issues 27 strided 4-byte loads per output pixel and is TA-bound at
+// 2.4 TB/s), then every (pixel, 16-byte quarter) picks its 8 values from LDS.  stride 2, W % 4 == 0.
+template <int RB>
+__global__ __launch_bounds__(256) void im2col_nchw3_s2_lds_kernel(const float* __restrict__ x, bf16* __restrict__ col, int B, int H,
+                                                                  int W, int Ho, int Wo, int nbands) {
+    extern __shared__ float im_lds[];                       // [3][2*RB+1][W]
+    constexpr int NR = 2 * RB + 1;
+    const int b = blockIdx.x / nbands, band = blockIdx.x % nbands;
+    const int oy0 = band * RB, iy0 = 2 * oy0 - 1;
+    const int w4 = W >> 2;
+    for (int i = threadIdx.x; i < 3 * NR * w4; i += blockDim.x) {
+        const int c4 = i % w4, r = (i / w4) % NR, ci = i / (w4 * NR);
+        const int iy = iy0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H) v = *reinterpret_cast<const f32x4*>(x + (((int64_t)b * 3 + ci) * H + iy) * W + c4 * 4);
+        *reinterpret_cast<f32x4*>(im_lds + (ci * NR + r) * W + c4 * 4) = v;
+    }
+    __syncthreads();
+    const int rows = min(RB, Ho - oy0);
+    for (int i = threadIdx.x; i < rows * Wo * 4; i += blockDim.x) {
+        const int q = i & 3, ox = (i >> 2) % Wo, ry = (i >> 2) / Wo;
+        bf16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = q * 8 + j;
+            const int tap = (k * 11) >> 5, ci = k - tap * 3;          // k / 3, k % 3 for k < 32
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+            const int ix = ox * 2 + kx - 1;
+            const bool ok = k < 27 && ix >= 0 && ix < W;              // rows outside the image were staged as zeros
+            t[j] = ok ? (bf16)im_lds[(ci * NR + 2 * ry + ky) * W + ix] : (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(col + (((int64_t)b * Ho + oy0 + ry) * Wo + ox) * 32 + q * 8) = t;
     }
 }
 
@@ -566,6 +594,9 @@ template <bool IN2, bool EPI>
 __global__ __launch_bounds__(256) void dwconv3x3_s2_bwd_data_kernel(const bf16* __restrict__ dy, const float* __restrict__ wt,
                                                                     bf16* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo,
                                                                     int CG, int PP, DwS2Fuse f) {
+    // One trip = the 2x2 input quad (2a..2a+1, 2c..2c+1): its four pixels draw on the same 2x2 neighbourhood of dy, {a, a+1} x {c, c+1},
+    // with 1 + 2 + 2 + 4 = all 9 taps between them -- 4 (IN2: 8) loads per quad instead of 9 (18), every load issued up front and
+    // range-checked by the buffer descriptor instead of branched around, and the IN2 affine applied once per dy element.
     extern __shared__ float s2_lds[];       // taps [9][C]; IN2: coef [3][C]; EPI: scale, shift, rstd, -mean*rstd [4][C]; EPI: red [PP][2][C]
     float* taps = s2_lds;
     float* ctab = s2_lds + 9 * C;
@@ -582,67 +613,111 @@ __global__ __launch_bounds__(256) void dwconv3x3_s2_bwd_data_kernel(const bf16* 
     }
     __syncthreads();
     const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    int gofs = g * 8;                       // laundered once per trip: keeps the table reads inside the loop (9 tap rows = 72 VGPRs if hoisted)
     auto row2 = [&](const float* base, f32x2 (&o)[4]) {
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(base + g * 8), t1 = *reinterpret_cast<const f32x4*>(base + g * 8 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(base + gofs), t1 = *reinterpret_cast<const f32x4*>(base + gofs + 4);
         o[0] = (f32x2){t0[0], t0[1]}; o[1] = (f32x2){t0[2], t0[3]}; o[2] = (f32x2){t1[0], t1[1]}; o[3] = (f32x2){t1[2], t1[3]};
     };
-    f32x2 ca[4], cb[4], cc[4];
-    if (IN2) { row2(ctab, ca); row2(ctab + C, cb); row2(ctab + 2 * C, cc); }
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, (int)((unsigned)B * Ho * Wo * C * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(IN2 ? f.y_in : dy), 0, (int)((unsigned)B * Ho * Wo * C * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI ? f.ep_y : dy), 0, EPI ? (int)((unsigned)B * H * W * C * 2u) : 0, 0x00020000);
     f32x2 s2[4], q2[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) s2[q] = q2[q] = (f32x2)(0.f);
     const bool ep_gelu = f.ep_act == GG_ACT_GELU;
-    const int64_t npix = (int64_t)B * H * W;
-    const unsigned HW = (unsigned)H * (unsigned)W;
-    for (int64_t p = (int64_t)blockIdx.x * PP + pp; p < npix; p += (int64_t)gridDim.x * PP) {
+    const int64_t nquad = (int64_t)B * Ho * Wo;
+    const unsigned HWo = (unsigned)Ho * (unsigned)Wo;
+    const unsigned rowO = (unsigned)Wo * C * 2u, rowI = (unsigned)W * C * 2u, pixB = (unsigned)C * 2u;
+    for (int64_t p = (int64_t)blockIdx.x * PP + pp; p < nquad; p += (int64_t)gridDim.x * PP) {
+        asm volatile("" : "+v"(gofs));
         const unsigned pu = (unsigned)p;
-        const unsigned b = pu / HW, rem = pu - b * HW;
-        const int iy = (int)(rem / (unsigned)W), ix = (int)(rem - (unsigned)iy * (unsigned)W);
-        dw_u32x4 eraw;
-        if (EPI) eraw = *reinterpret_cast<const dw_u32x4*>(f.ep_y + p * C + g * 8);
-        f32x2 acc[4] = {(f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f), (f32x2)(0.f)};
-        // contributing taps: oy = (iy + 1 - ky) / 2 with iy + 1 - ky even
-        const int ky0 = (iy & 1) ? 0 : 1, nky = (iy & 1) ? 2 : 1;
-        const int kx0 = (ix & 1) ? 0 : 1, nkx = (ix & 1) ? 2 : 1;
-        for (int a = 0; a < nky; ++a) {
-            const int ky = ky0 + 2 * a, oy = (iy + 1 - ky) >> 1;
-            if (oy < 0 || oy >= Ho) continue;
-            for (int c = 0; c < nkx; ++c) {
-                const int kx = kx0 + 2 * c, ox = (ix + 1 - kx) >> 1;
-                if (ox < 0 || ox >= Wo) continue;
-                const int64_t o = (((int64_t)b * Ho + oy) * Wo + ox) * C + g * 8;
-                const dw_u32x4 raw = *reinterpret_cast<const dw_u32x4*>(dy + o);
-                f32x2 tp[4];
-                row2(taps + (ky * 3 + kx) * C, tp);
-                if (IN2) {
-                    const dw_u32x4 yr = *reinterpret_cast<const dw_u32x4*>(f.y_in + o);
+        const unsigned b = pu / HWo, rem = pu - b * HWo;
+        const int a = (int)(rem / (unsigned)Wo), c = (int)(rem - (unsigned)a * (unsigned)Wo);
+        const bool a1 = a + 1 < Ho, c1 = c + 1 < Wo;                 // neighbours inside dy
+        const bool r1 = 2 * a + 1 < H, x1 = 2 * c + 1 < W;           // odd row / column of the quad inside dx
+        const unsigned o00 = pu * pixB + g * 16u;
+        const unsigned ofs[4] = {o00, c1 ? o00 + pixB : DW_COL_OOB, a1 ? o00 + rowO : DW_COL_OOB, (a1 && c1) ? o00 + rowO + pixB : DW_COL_OOB};
+        dw_u32x4 rd[4], ry[4], re[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x2 v = dw_unpack2(dw_pack2(ca[q] * dw_unpack2(raw[q]) + (cb[q] * dw_unpack2(yr[q]) + cc[q])));   // dy as the unfused path stores it
-                        acc[q] = v * tp[q] + acc[q];
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = dw_unpack2(raw[q]) * tp[q] + acc[q];
-                }
-            }
+        for (int k = 0; k < 4; ++k) {
+            rd[k] = __builtin_amdgcn_raw_buffer_load_b128(rsD, (int)ofs[k], 0, 0);
+            if (IN2) ry[k] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)ofs[k], 0, 0);
         }
-        dw_u32x4 o;
+        const unsigned i00 = ((b * (unsigned)H + 2u * a) * (unsigned)W + 2u * c) * pixB + g * 16u;
+        const unsigned iofs[4] = {i00, x1 ? i00 + pixB : DW_COL_OOB, r1 ? i00 + rowI : DW_COL_OOB, (r1 && x1) ? i00 + rowI + pixB : DW_COL_OOB};
         if (EPI) {
-            f32x2 esc[4], esh[4], ers[4], emr[4];
-            row2(ctab + 3 * C, esc); row2(ctab + 4 * C, esh); row2(ctab + 5 * C, ers); row2(ctab + 6 * C, emr);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x2 yv = dw_unpack2(eraw[q]);
-                o[q] = dw_pack2(acc[q] * gg_act_grad_v2(yv * esc[q] + esh[q], ep_gelu));
-                const f32x2 r = dw_unpack2(o[q]);
-                s2[q] += r; q2[q] += r * (yv * ers[q] + emr[q]);
+            for (int k = 0; k < 4; ++k) re[k] = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)iofs[k], 0, 0);
+        }
+        // v[k] = dy element k of the neighbourhood (00, 01, 10, 11); IN2: as the unfused path stores it (bf16-rounded), 0 outside dy
+        f32x2 v[4][4];
+        if (IN2) {
+            f32x2 ca[4], cb[4], cc[4];
+            row2(ctab, ca); row2(ctab + C, cb); row2(ctab + 2 * C, cc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = ofs[k] != DW_COL_OOB;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 t = dw_unpack2(dw_pack2(ca[q] * dw_unpack2(rd[k][q]) + (cb[q] * dw_unpack2(ry[k][q]) + cc[q])));
+                    v[k][q] = ok ? t : (f32x2)(0.f);
+                }
             }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = dw_pack2(acc[q]);
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[k][q] = dw_unpack2(rd[k][q]);
         }
-        *reinterpret_cast<dw_u32x4*>(dx + p * C + g * 8) = o;
+        // taps [ky][kx]; pixel (even,even): t11 v00 | (even,odd): t10 v01 + t12 v00 | (odd,even): t01 v10 + t21 v00 | (odd,odd): t00 v11 + t02 v10 + t20 v01 + t22 v00
+        f32x2 acc[4][4], tp[4];
+        row2(taps + 4 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[0][q] = v[0][q] * tp[q];
+        row2(taps + 3 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[1][q] = v[1][q] * tp[q];
+        row2(taps + 5 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[1][q] = v[0][q] * tp[q] + acc[1][q];
+        row2(taps + 1 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[2][q] = v[2][q] * tp[q];
+        row2(taps + 7 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[2][q] = v[0][q] * tp[q] + acc[2][q];
+        row2(taps + 0 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[3][q] = v[3][q] * tp[q];
+        row2(taps + 2 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[3][q] = v[2][q] * tp[q] + acc[3][q];
+        row2(taps + 6 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[3][q] = v[1][q] * tp[q] + acc[3][q];
+        row2(taps + 8 * C, tp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[3][q] = v[0][q] * tp[q] + acc[3][q];
+        f32x2 esc[4], esh[4], ers[4], emr[4];
+        if (EPI) { row2(ctab + 3 * C, esc); row2(ctab + 4 * C, esh); row2(ctab + 5 * C, ers); row2(ctab + 6 * C, emr); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool live = iofs[k] != DW_COL_OOB;
+            dw_u32x4 o;
+            if (EPI) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x2 yv = dw_unpack2(re[k][q]);
+                    o[q] = dw_pack2(acc[k][q] * gg_act_grad_v2(yv * esc[q] + esh[q], ep_gelu));
+                    const f32x2 r = live ? dw_unpack2(o[q]) : (f32x2)(0.f);
+                    s2[q] += r; q2[q] += r * (yv * ers[q] + emr[q]);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = dw_pack2(acc[k][q]);
+            }
+            if (live) *reinterpret_cast<dw_u32x4*>(reinterpret_cast<char*>(dx) + iofs[k]) = o;
+        }
     }
     if (EPI) {
 #pragma unroll
@@ -856,8 +931,16 @@ extern "C" int gg_im2col_nchw3_f32(const float* x, void* col, int B, int H, int 
     GG_CHECK(x && col && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gg_im2col_nchw3_f32: bad args");
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     GG_PROF(GG_CAT_MOVE, 0, 12.0 * B * H * W + 64.0 * B * Ho * Wo, stream);
-    hipLaunchKernelGGL(im2col_nchw3_kernel, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)col, B,
-                       H, W, Ho, Wo, stride);
+    constexpr int RB = 4;
+    const size_t lds = (size_t)3 * (2 * RB + 1) * W * sizeof(float);
+    if (stride == 2 && (W & 3) == 0 && ((uintptr_t)x & 15) == 0 && lds <= 64 * 1024) {
+        const int nbands = (int)gg_cdiv(Ho, RB);
+        hipLaunchKernelGGL(im2col_nchw3_s2_lds_kernel<RB>, dim3((unsigned)(B * nbands)), dim3(256), lds, (hipStream_t)stream, x, (bf16*)col, B, H, W,
+                           Ho, Wo, nbands);
+    } else {
+        hipLaunchKernelGGL(im2col_nchw3_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 4, 65536)), dim3(256), 0, (hipStream_t)stream, x, (bf16*)col, B,
+                           H, W, Ho, Wo, stride);
+    }
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -952,11 +1035,14 @@ static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, in
 
 // stride-2 data gradient geometry: 8-channel groups x pixel lanes, <= 4096 blocks (= partial statistics rows with ep_y)
 static bool dw_s2_ok(int C) { return (C / 8) <= 256 && (16 + 2 * std::max(1, 256 / (C / 8))) * (int64_t)C * 4 <= 60 * 1024; }
-static int dw_s2_blocks(int B, int H, int W, int C) { return (int)std::min<int64_t>(gg_cdiv((int64_t)B * H * W, std::max(1, 256 / (C / 8))), 4096); }
+static int dw_s2_blocks(int B, int H, int W, int C) {          // trips are 2x2 input quads = output-resolution pixels
+    return (int)std::min<int64_t>(gg_cdiv((int64_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1), std::max(1, 256 / (C / 8))), 4096);
+}
 extern "C" int gg_dwconv_s2_fused_stat_rows(int B, int H, int W, int C) { return dw_s2_blocks(B, H, W, C); }
 static int dwconv_s2_bwd_launch(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, const DwS2Fuse* fuse, void* stream) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int CG = C / 8, PP = std::max(1, 256 / CG);
+    GG_CHECK((int64_t)B * H * W * C * 2 < ((int64_t)1 << 31), "dwconv stride-2 data gradient: tensor too large for 32-bit offsets");
     DwS2Fuse f;
     memset(&f, 0, sizeof(f));
     if (fuse) f = *fuse;
