@@ -795,11 +795,35 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
 extern "C" int gg_gemm_colstats_rows(int M) { return (int)gg_cdiv(M, 128); }
 extern "C" int gg_stat_rows_capacity(int rows) { return rows + GG_REDUCE_SLICES; }
 
+// many slabs of a small matrix (patch_embed.conv1: 1536 x 6 KB): 64 float4 columns x 16 slab lanes per block, so a thread walks
+// splits / 16 slabs instead of all of them (the flat kernel spent 170 us on 9 MB here)
+__global__ __launch_bounds__(1024) void splitk_reduce_tall_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n4,
+                                                                  int splits, int accumulate, float scale) {
+    __shared__ f32x4 red[16][64];
+    const f32x4* P = reinterpret_cast<const f32x4*>(part);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n4)
+        for (int z = ty; z < splits; z += 16) s += P[(int64_t)z * n4 + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < n4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k][tx];
+        s *= scale;
+        f32x4* O = reinterpret_cast<f32x4*>(out);
+        O[i] = accumulate ? O[i] + s : s;
+    }
+}
 extern "C" int gg_splitk_reduce(const float* part, float* out, int64_t n, int splits, int accumulate, float scale, void* stream) {
     GG_CHECK(part && out && n > 0 && splits > 0, "gg_splitk_reduce: bad args");
     GG_PROF(GG_CAT_MOVE, 0, 4.0 * n * (splits + 1), stream);
     int blocks = (int)std::min<int64_t>(gg_cdiv(n, 256), 4096);
-    if ((n & 3) == 0 && ((uintptr_t)part & 15) == 0 && ((uintptr_t)out & 15) == 0)
+    const bool v4 = (n & 3) == 0 && ((uintptr_t)part & 15) == 0 && ((uintptr_t)out & 15) == 0;
+    if (v4 && splits >= 64 && n / 4 <= 16384)
+        hipLaunchKernelGGL(splitk_reduce_tall_kernel, dim3((unsigned)gg_cdiv(n / 4, 64)), dim3(1024), 0, (hipStream_t)stream, part, out, n / 4, splits, accumulate, scale);
+    else if (v4)
         hipLaunchKernelGGL(splitk_reduce_v4_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(n / 4, 256), 16384)), dim3(256), 0, (hipStream_t)stream, part, out, n / 4, splits, accumulate, scale);
     else
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, part, out, n, splits, accumulate, scale);
