@@ -757,7 +757,12 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     if (force) narrow = force[0] == 'n';
     const int bn = narrow ? 64 : 128;
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
-    GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K, 2.0 * ((double)a->M * a->K + (double)a->N * a->K + (double)a->M * a->N), stream);
+    // algorithmic bytes: A, B, C once each (bf16; f32 C = 4 bytes) plus every second tensor the epilogue reads or writes
+    const double mn = (double)a->M * a->N;
+    GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
+            2.0 * ((double)a->M * a->K + (double)a->N * a->K) + ((a->out_f32 || split > 1) ? 4.0 : 2.0) * mn * std::max(1, split) +
+                2.0 * mn * ((a->preact != nullptr) + (a->residual != nullptr) + (a->dact_preact != nullptr) + (a->bn_y != nullptr)),
+            stream);
     dim3 grid(p.tilesM * p.tilesN, split);
     int epi;
     if (a->out_f32 || split > 1) epi = EPI_F32;
