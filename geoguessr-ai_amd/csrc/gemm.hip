@@ -463,9 +463,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     constexpr int LS = MS / 16;                            // 16-byte chunks per thread per operand per step
     __shared__ __attribute__((aligned(16))) bf16 Ys[MS * RS];
     __shared__ __attribute__((aligned(16))) bf16 Xs[MS * RS];
-    const int tn = blockIdx.x / p.tilesK, tk = blockIdx.x % p.tilesK;
+    // flattened (split, tile) order laid out XCD by XCD: the tiles of one split re-read the same row range of dY (tilesK times) and
+    // X (tilesN times); dispatched round-robin they would pull it into all eight L2s
+    const int ntile = p.tilesN * p.tilesK;
+    const int lb = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int split_id = lb / ntile, tile_id = lb - split_id * ntile;
+    const int tn = tile_id / p.tilesK, tk = tile_id % p.tilesK;
     const int n0 = tn * TB, k0 = tk * TB;
-    const int mbeg = blockIdx.y * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+    const int mbeg = split_id * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wn = wave >> 1, wk = wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         __syncthreads();
     }
     // lane holds D[n = .. + nt*16 + 4lg + r][k = .. + kt*16 + lr]
-    float* out = p.part + (int64_t)blockIdx.y * p.N * p.K;
+    float* out = p.part + (int64_t)split_id * p.N * p.K;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -919,7 +924,8 @@ extern "C" int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ld
     GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 2 < ((int64_t)1 << 32), "gg_gemm_tn: a split's rows must span < 4 GiB per operand (use more splits)");
     GG_CHECK(splits <= 65535, "gg_gemm_tn: too many splits");
     GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 2.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(p.tilesN * p.tilesK, splits), dim3(256), 0, (hipStream_t)stream, p);
+    GG_CHECK((int64_t)p.tilesN * p.tilesK * splits < ((int64_t)1 << 31), "gg_gemm_tn: grid too large");
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
