@@ -75,6 +75,7 @@ SIGNATURES = {
     "gg_stat_rows_capacity": (_I, [_I]),
     "gg_gemm_tn_splits": (_I, [_I, _I, _I]),
     "gg_gemm_tn": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "gg_gemm_tn_bn": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _P, _I, _P]),
     "gg_splitk_reduce": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "gg_transpose_bf16": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "gg_cast_transpose_f32": (_I, [_P, _I, _I, _P, _L, _P, _L, _P]),

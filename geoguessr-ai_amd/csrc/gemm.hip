@@ -455,7 +455,10 @@ struct TnParams {
     const float* rowscale; int rows_per_scale;
     float* part;          // [splits][N][K]
     int tilesN, tilesK, m_per_split;
+    const bf16* Y2; const float* coef;    // optional: the dY operand is  coef0*dY + coef1*Y2 + coef2  per column (BatchNorm backward's
+                                          // apply step of a ConvNorm whose dy only feeds this weight gradient), bf16-rounded like the stored dy
 };
+template <bool BN>        // BN: dY := coef0*dY + coef1*Y2 + coef2 while loading (its 44 extra registers stay out of the plain kernel: 3 vs 2 waves/SIMD)
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     // 64-row m-step = two MFMA k-steps per barrier pair.  LDS rows of 288 bytes: the 16 rows x 32 bytes that one transposing
     // read touches then fall on 16 disjoint groups of 8 banks (a 272-byte stride overlaps neighbouring rows: 2-way conflicts)
@@ -491,7 +494,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     }
     const unsigned stepY = (unsigned)MS * (unsigned)p.ldy * 2u, stepX = (unsigned)MS * (unsigned)p.ldx * 2u;
     const float inv_rps = p.rowscale ? 1.f / (float)p.rows_per_scale : 0.f;
-    bf16x8 ry[LS], rx[LS];
+    const __amdgpu_buffer_rsrc_t rsY2 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.Y2 ? p.Y2 : p.dY) + (int64_t)mbeg * p.ldy), 0, (int)((unsigned)nrows * (unsigned)p.ldy * 2u), 0x00020000);
+    float ca[8], cb[8], cc[8];            // this thread's 8 columns (sch is fixed per thread)
+    if (BN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = min(n0 + sch * 8 + j, p.N - 1);
+            ca[j] = p.coef[c]; cb[j] = p.coef[p.N + c]; cc[j] = p.coef[2 * p.N + c];
+        }
+    }
+    bf16x8 ry[LS], rx[LS], ry2[LS];
+    float rsc[LS];
     auto load_step = [&](int m0) {
         const unsigned st = (unsigned)(m0 - mbeg) / MS;
 #pragma unroll
@@ -499,6 +512,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
             // a pushed-out chunk stays out of range: its offset is only advanced when valid
             ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
             rx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(xok ? vox[i] + st * stepX : 0xFFFFFFF0u), 0, 0));
+            if (BN) ry2[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsY2, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
         }
         if (p.rowscale) {
 #pragma unroll
@@ -506,9 +520,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
                 const int m = min(m0 + srow + 16 * i, p.M - 1);
                 int q = (int)((float)m * inv_rps);                       // m / rows_per_scale without the integer division
                 q += ((q + 1) * p.rows_per_scale <= m) - (q * p.rows_per_scale > m);
-                const float rs = p.rowscale[q];
+                rsc[i] = p.rowscale[q];
+            }
+        }
+    };
+    // element-wise work on the fetched dY rows, run when they are consumed (just before the LDS store), not where they are
+    // requested: touching them inside load_step would wait for the loads before the MFMAs they are meant to travel under
+    auto finish_step = [&](int m0) {
+        if (BN) {          // rows beyond the split / columns beyond N must stay zero: the affine's constant term does not apply there
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ry[i][j] = (bf16)((float)ry[i][j] * rs);
+            for (int i = 0; i < LS; ++i) {
+                const bool ok = yok && (m0 + srow + 16 * i) < mend;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ry[i][j] = ok ? (bf16)fmaf(ca[j], (float)ry[i][j], fmaf(cb[j], (float)ry2[i][j], cc[j])) : (bf16)0.f;
+            }
+        }
+        if (p.rowscale) {
+#pragma unroll
+            for (int i = 0; i < LS; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ry[i][j] = (bf16)((float)ry[i][j] * rsc[i]);
             }
         }
     };
@@ -519,6 +550,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (mbeg < mend) load_step(mbeg);
     for (int m0 = mbeg; m0 < mend; m0 += MS) {
+        finish_step(m0);
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
             *reinterpret_cast<bf16x8*>(Ys + (srow + 16 * i) * RS + sch * 8) = ry[i];
@@ -910,22 +942,37 @@ extern "C" int gg_gemm_tn_splits(int M, int N, int K) {
     const int64_t cap = ((int64_t)64 << 20) / ((int64_t)N * K * 4);        // 64 MiB of slabs at most
     return (int)std::max<int64_t>(1, std::min<int64_t>(s, cap));
 }
+static int gemm_tn_launch(const void* dY, int64_t ldy, const void* Y2, const float* coef, const void* X, int64_t ldx, int M, int N, int K,
+                          const float* rowscale, int rows_per_scale, float* partials, int splits, void* stream);
 extern "C" int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale,
                           int rows_per_scale, float* partials, int splits, void* stream) {
+    return gemm_tn_launch(dY, ldy, nullptr, nullptr, X, ldx, M, N, K, rowscale, rows_per_scale, partials, splits, stream);
+}
+// weight gradient of a ConvNorm straight from BatchNorm backward's (dz, y, coef): dW = (coef0*dz + coef1*y + coef2)^T X; the dy
+// tensor and the apply pass that would write it do not exist (valid when dy feeds nothing else, e.g. the network's first conv)
+extern "C" int gg_gemm_tn_bn(const void* dz, const void* y, int64_t ldy, const float* coef, const void* X, int64_t ldx, int M, int N, int K,
+                             float* partials, int splits, void* stream) {
+    GG_CHECK(y && coef && ((uintptr_t)y & 15) == 0, "gg_gemm_tn_bn: y / coef missing or misaligned");
+    return gemm_tn_launch(dz, ldy, y, coef, X, ldx, M, N, K, nullptr, 0, partials, splits, stream);
+}
+static int gemm_tn_launch(const void* dY, int64_t ldy, const void* Y2, const float* coef, const void* X, int64_t ldx, int M, int N, int K,
+                          const float* rowscale, int rows_per_scale, float* partials, int splits, void* stream) {
     GG_CHECK(dY && X && partials && M > 0 && N > 0 && K > 0 && splits > 0, "gg_gemm_tn: bad args");
     GG_CHECK((N & 7) == 0 && (K & 7) == 0 && (ldy & 7) == 0 && (ldx & 7) == 0, "gg_gemm_tn: N, K, ldy, ldx must be multiples of 8");
     GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gg_gemm_tn: operands must be 16-byte aligned");
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn: rows_per_scale");
     TnParams p;
     p.dY = (const bf16*)dY; p.ldy = ldy; p.X = (const bf16*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
-    p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
+    p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials; p.Y2 = (const bf16*)Y2; p.coef = coef;
     p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
     p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 64);
     GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 2 < ((int64_t)1 << 32), "gg_gemm_tn: a split's rows must span < 4 GiB per operand (use more splits)");
     GG_CHECK(splits <= 65535, "gg_gemm_tn: too many splits");
-    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 2.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 2.0 * M * ((double)N * (Y2 ? 2 : 1) + K) + 4.0 * splits * (double)N * K, stream);
     GG_CHECK((int64_t)p.tilesN * p.tilesK * splits < ((int64_t)1 << 31), "gg_gemm_tn: grid too large");
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(256), 0, (hipStream_t)stream, p);
+    const dim3 grid((unsigned)(p.tilesN * p.tilesK * splits));
+    if (coef) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -587,6 +587,25 @@ static int dense_wgrad(const Exec& e, const DenseW& w, const bf16* X, int64_t ld
     }
     return 0;
 }
+// weight gradient of a ConvNorm whose dy feeds nothing else (the first conv of the network): BatchNorm backward stops after
+// reduce + finalize, and the TN GEMM forms dy = c0*dz + c1*y + c2 from (dz, y) while loading -- no apply pass, no dy tensor
+static int convnorm_wgrad_from_dz(const Exec& e, const ConvBNDense& c, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz,
+                                  const bf16* X, int64_t ldx) {
+    const BNP& bn = c.bn;
+    const bool tr = e.tr(bn.t_g);
+    float* part = e.F(e.L->bnscratch);
+    const int nb = gg_bn_bwd_rows(M, bn.C);
+    float* coef = part + ((int64_t)nb + GG_REDUCE_SLICES) * 2 * bn.C;
+    GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz, part, e.st));
+    GG_TRY(gg_bn_bwd_finalize(part, nb, bn.C, M, e.F(a.stat), e.P(bn.t_g), coef, tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st));
+    if (!e.tr(c.w.t_w)) return 0;
+    const DenseW& w = c.w;
+    const int K = w.Kp;
+    const int split = gg_gemm_tn_splits((int)M, w.N, K);
+    GG_TRY(gg_gemm_tn_bn(dz, e.A(a.y), bn.C, coef, X, ldx, (int)M, w.N, K, e.F(e.L->splitk), split, e.st));
+    GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), e.F(e.L->splitk), (int64_t)w.N * K, split, 0, 1.0f, e.st));
+    return conv_wgrad_scatter(e.F(e.L->splitk), w.N, K, w.cin, w.taps, e.Gd(w.t_w), e.st);
+}
 static int bias_grad(const Exec& e, int t_b, const bf16* dY, int64_t ld, int64_t M, int N, const float* rowscale, int rps) {
     return gg_colsum_bf16(dY, ld, (int)M, N, rowscale, rps, e.F(e.L->colsum), e.Gd(t_b), 1, e.st);
 }
@@ -840,8 +859,12 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (need1) {
             GG_TRY(gemm(e, t_a, d[0], e.Wt(m.pe2.w), m.pe2.w.Np, t_b, m.pe2.w.Kp, M0, m.pe2.w.Kp, d[0])); // dcol2 -> t_b
             GG_TRY(gg_col2im_nhwc_bf16(t_b, t_c, B, H1, H1, d[0] / 2, 2, e.st));                           // da1 -> t_c [M1, C0/2]
-            GG_TRY(bn_bwd(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, t_c, t_d, t_a));                             // dy1 -> t_a
-            if (e.tr(m.pe1.w.t_w)) GG_TRY(dense_wgrad(e, m.pe1.w, e.A(L.col1), 32, t_a, d[0] / 2, M1, nullptr, 0, t_b, t_c, true));
+            if (e.fuse_bnbwd && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & 7) == 0) {
+                GG_TRY(convnorm_wgrad_from_dz(e, m.pe1, L.pe1, M1, GG_ACT_GELU, t_c, t_d, e.A(L.col1), 32));   // dz1 -> t_d; dy1 is never formed
+            } else {
+                GG_TRY(bn_bwd(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, t_c, t_d, t_a));                         // dy1 -> t_a
+                if (e.tr(m.pe1.w.t_w)) GG_TRY(dense_wgrad(e, m.pe1.w, e.A(L.col1), 32, t_a, d[0] / 2, M1, nullptr, 0, t_b, t_c, true));
+            }
         }
     }
     return 0;

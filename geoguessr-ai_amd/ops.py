@@ -99,6 +99,20 @@ def gemm_tn(dY, X, rowscale=None, rows_per_scale=0, accumulate_into=None):
     return out
 
 
+def gemm_tn_bn(dz, y, coef, X, accumulate_into=None):
+    """f32 dW[N,K] = (coef0*dz + coef1*y + coef2)^T @ X: a ConvNorm's weight gradient straight from BatchNorm backward's (dz, y, coef)."""
+    M, N = dz.shape
+    K = X.shape[1]
+    splits = L.lib().gg_gemm_tn_splits(M, N, K)
+    part = torch.empty((splits, N, K), dtype=F32, device=dz.device)
+    L.check(L.lib().gg_gemm_tn_bn(_pr(dz, BF16, "dz"), _pr(y, BF16, "y"), dz.stride(0), _p(coef, F32), _pr(X, BF16, "X"), X.stride(0), M, N, K,
+                                  _p(part), splits, L.stream()), "gg_gemm_tn_bn")
+    out = accumulate_into if accumulate_into is not None else torch.empty((N, K), dtype=F32, device=dz.device)
+    L.check(L.lib().gg_splitk_reduce(_p(part), _p(out, F32), N * K, splits, int(accumulate_into is not None), 1.0, L.stream()),
+            "gg_splitk_reduce")
+    return out
+
+
 def transpose_bf16(x, rowscale=None, rows_per_scale=0, pad_to: int = 8):
     R, Cc = x.shape
     ldo = (R + pad_to - 1) // pad_to * pad_to

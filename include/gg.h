@@ -63,6 +63,10 @@ int gg_stat_rows_capacity(int rows);       /* rows a partial-statistics buffer m
 int gg_gemm_tn_splits(int M, int N, int K);
 int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale,
                float* partials, int splits, void* stream);
+/* same with dY := coef0*dz + coef1*y + coef2 per column (coef = gg_bn_bwd_finalize's [3][N]), formed while loading: the weight gradient of a
+   ConvNorm whose dy feeds nothing else (patch_embed.conv1) without the BatchNorm-backward apply pass or the dy tensor */
+int gg_gemm_tn_bn(const void* dz, const void* y, int64_t ldy, const float* coef, const void* X, int64_t ldx, int M, int N, int K, float* partials,
+                  int splits, void* stream);
 int gg_splitk_reduce(const float* partials, float* out, int64_t n, int splits, int accumulate, float scale, void* stream);
 int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
                       int rows_per_scale, void* stream);

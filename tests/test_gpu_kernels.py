@@ -95,6 +95,20 @@ def test_gemm_epilogues(ops):
     close(s[1], (raw * raw).sum(0), rtol=1e-3, atol=0.3, what="colsumsq")
 
 
+@pytest.mark.parametrize("M,N,K", [(5003, 48, 32), (3000, 200, 96)])
+def test_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
+    """dW = (c0*dz + c1*y + c2)^T X with the BatchNorm-backward apply formed inside the TN GEMM's loader == apply pass (bf16 dy) + plain TN GEMM;
+    ragged rows / columns must not pick up the affine's constant term."""
+    dz, y, X = rnd(M, N, seed=90, scale=0.1), rnd(M, N, seed=91), rnd(M, K, seed=92)
+    coef = torch.stack([1.0 + 0.1 * rnd(N, seed=93), 0.05 * rnd(N, seed=94), 0.02 * rnd(N, seed=95)])
+    dzq, yq, Xq = dz.to(BF).float(), y.to(BF).float(), X.to(BF).float()
+    dy = (coef[0] * dzq + (coef[1] * yq + coef[2])).to(BF).float()
+    got = ops.gemm_tn_bn(dev(dz, BF), dev(y, BF), dev(coef), dev(X, BF))
+    close(got, dy.t() @ Xq, rtol=2e-3, atol=2e-2, what="tn gemm with bn apply")
+    plain = ops.gemm_tn(dev(dy, BF), dev(X, BF))
+    close(got, plain.cpu(), rtol=1e-3, atol=1e-2, what="tn fused vs unfused")
+
+
 def test_gemm_splitk_and_wgrad_form(ops):
     """wgrad: dW[N,K] = dY^T X with the reduction (rows) split across blockIdx.y."""
     Mrows, N, K = 5000, 96, 160
