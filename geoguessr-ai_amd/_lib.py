@@ -87,6 +87,7 @@ SIGNATURES = {
     "gg_im2col_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_im2col_nhwc_bn_bf16": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "gg_col2im_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "gg_col2im_nhwc_bnbwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv_tiled_stat_rows": (_I, [_I, _I]),
     "gg_dwconv_fused_stat_rows": (_I, [_I, _I, _I, _I, _I]),

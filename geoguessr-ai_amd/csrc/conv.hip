@@ -966,6 +966,77 @@ extern "C" int gg_im2col_nhwc_bn_bf16(const void* y, const float* stat, const fl
     GG_LAUNCH_CHECK();
     return 0;
 }
+// col2im + the BatchNorm-backward reduce of the ConvNorm whose output was gathered: the scattered gradient da is formed per pixel
+// (bf16-rounded as the unfused path stores it), multiplied by act'(BN(y)) and written as dz; the per-channel sums (sum dz, sum dz*xhat)
+// leave as one partial row per block.  da is never written, the reduce pass never runs.
+__global__ __launch_bounds__(256) void col2im_nhwc_bnbwd_kernel(const bf16* __restrict__ dcol, const bf16* __restrict__ y,
+                                                                const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int act, bf16* __restrict__ dz,
+                                                                float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int CG, int PP) {
+    extern __shared__ float c2i_red[];          // [PP][2][C]
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int c0 = g * 8;
+    float mu[8], rstd[8], ga[8], be[8], s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mu[j] = stat[c0 + j]; rstd[j] = stat[C + c0 + j]; ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j]; s[j] = q[j] = 0.f; }
+    const int64_t npix = (int64_t)B * H * W;
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    for (int64_t p = (int64_t)blockIdx.x * PP + pp; p < npix; p += (int64_t)gridDim.x * PP) {
+        const unsigned pu = (unsigned)p;
+        const unsigned b = pu / HW, rem = pu - b * HW;
+        const int iy = (int)(rem / (unsigned)W), ix = (int)(rem - (unsigned)iy * (unsigned)W);
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + p * C + c0);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // stride 2: oy = (iy + 1 - ky) / 2 with iy + 1 - ky even -> ky = 1 for even rows, ky in {0, 2} for odd rows; same in x
+        const int ky0 = (iy & 1) ? 0 : 1, nky = (iy & 1) ? 2 : 1;
+        const int kx0 = (ix & 1) ? 0 : 1, nkx = (ix & 1) ? 2 : 1;
+        for (int a = 0; a < nky; ++a) {
+            const int ky = ky0 + 2 * a, oy = (iy + 1 - ky) >> 1;
+            if (oy < 0 || oy >= Ho) continue;
+            for (int c = 0; c < nkx; ++c) {
+                const int kx = kx0 + 2 * c, ox = (ix + 1 - kx) >> 1;
+                if (ox < 0 || ox >= Wo) continue;
+                const bf16x8 d = *reinterpret_cast<const bf16x8*>(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * (9 * C) + (ky * 3 + kx) * C + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)d[j];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)v[j] - mu[j]) * rstd[j];
+            const float dpre = (float)(bf16)acc[j] * gg_act_grad(ga[j] * xh + be[j], act);
+            o[j] = (bf16)dpre;
+            s[j] += dpre;
+            q[j] += dpre * xh;
+        }
+        *reinterpret_cast<bf16x8*>(dz + p * C + c0) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { c2i_red[(pp * 2 + 0) * C + c0 + j] = s[j]; c2i_red[(pp * 2 + 1) * C + c0 + j] = q[j]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < PP; ++k) t += c2i_red[k * 2 * C + i];
+        part[(int64_t)blockIdx.x * 2 * C + i] = t;
+    }
+}
+// stride-2 3x3 only (PatchEmbed).  part: [nparts][2][C] with nparts rows as given (<= 65535); follow with gg_bn_bwd_finalize(part, nparts, ...)
+extern "C" int gg_col2im_nhwc_bnbwd_bf16(const void* dcol, const void* y, const float* stat, const float* gamma, const float* beta, int act,
+                                         void* dz, float* part, int nparts, int B, int H, int W, int C, void* stream) {
+    GG_CHECK(dcol && y && stat && gamma && beta && dz && part && nparts > 0 && nparts <= 65535 && B > 0 && (C & 7) == 0 && C / 8 <= 256,
+             "gg_col2im_nhwc_bnbwd_bf16: bad args");
+    GG_CHECK((int64_t)B * H * W < ((int64_t)1 << 32), "gg_col2im_nhwc_bnbwd_bf16: tensor too large for 32-bit pixel indexing");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int CG = C / 8, PP = std::max(1, 256 / CG);
+    const size_t lds = (size_t)PP * 2 * C * sizeof(float);
+    GG_CHECK(lds <= 64 * 1024, "gg_col2im_nhwc_bnbwd_bf16: C too large");
+    GG_PROF(GG_CAT_MOVE, 0, 6.0 * B * H * W * C + 18.0 * B * Ho * Wo * C, stream);
+    hipLaunchKernelGGL(col2im_nhwc_bnbwd_kernel, dim3((unsigned)nparts), dim3(CG * PP), lds, (hipStream_t)stream, (const bf16*)dcol, (const bf16*)y,
+                       stat, gamma, beta, act, (bf16*)dz, part, B, H, W, C, Ho, Wo, CG, PP);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dcol && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_col2im_nhwc_bf16: bad args");
     GG_CHECK((int64_t)B * H * W * (C / 8) < ((int64_t)1 << 32), "gg_col2im_nhwc_bf16: tensor too large for 32-bit indexing");

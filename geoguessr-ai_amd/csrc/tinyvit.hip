@@ -589,14 +589,16 @@ static int dense_wgrad(const Exec& e, const DenseW& w, const bf16* X, int64_t ld
 }
 // weight gradient of a ConvNorm whose dy feeds nothing else (the first conv of the network): BatchNorm backward stops after
 // reduce + finalize, and the TN GEMM forms dy = c0*dz + c1*y + c2 from (dz, y) while loading -- no apply pass, no dy tensor
+// (dcol != null: dout does not exist yet -- the reduce rides on the col2im that would have produced it from dcol [B, H, W] stride 2)
 static int convnorm_wgrad_from_dz(const Exec& e, const ConvBNDense& c, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz,
-                                  const bf16* X, int64_t ldx) {
+                                  const bf16* X, int64_t ldx, const bf16* dcol = nullptr, int B = 0, int H = 0, int W = 0) {
     const BNP& bn = c.bn;
     const bool tr = e.tr(bn.t_g);
     float* part = e.F(e.L->bnscratch);
-    const int nb = gg_bn_bwd_rows(M, bn.C);
-    float* coef = part + ((int64_t)nb + GG_REDUCE_SLICES) * 2 * bn.C;
-    GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz, part, e.st));
+    const int nb = std::min(gg_bn_bwd_rows(M, bn.C), 65535);
+    float* coef = part + ((int64_t)gg_bn_bwd_rows(M, bn.C) + GG_REDUCE_SLICES) * 2 * bn.C;
+    if (dcol) GG_TRY(gg_col2im_nhwc_bnbwd_bf16(dcol, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), act, dz, part, nb, B, H, W, bn.C, e.st));
+    else GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz, part, e.st));
     GG_TRY(gg_bn_bwd_finalize(part, nb, bn.C, M, e.F(a.stat), e.P(bn.t_g), coef, tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st));
     if (!e.tr(c.w.t_w)) return 0;
     const DenseW& w = c.w;
@@ -858,10 +860,11 @@ static int backward_impl(Exec& e, const float* d_out) {
         }
         if (need1) {
             GG_TRY(gemm(e, t_a, d[0], e.Wt(m.pe2.w), m.pe2.w.Np, t_b, m.pe2.w.Kp, M0, m.pe2.w.Kp, d[0])); // dcol2 -> t_b
-            GG_TRY(gg_col2im_nhwc_bf16(t_b, t_c, B, H1, H1, d[0] / 2, 2, e.st));                           // da1 -> t_c [M1, C0/2]
             if (e.fuse_bnbwd && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & 7) == 0) {
-                GG_TRY(convnorm_wgrad_from_dz(e, m.pe1, L.pe1, M1, GG_ACT_GELU, t_c, t_d, e.A(L.col1), 32));   // dz1 -> t_d; dy1 is never formed
+                // col2im + BN1-backward reduce in one pass (dz1 -> t_d; da1 and dy1 are never formed), weight gradient from (dz1, y1, coef)
+                GG_TRY(convnorm_wgrad_from_dz(e, m.pe1, L.pe1, M1, GG_ACT_GELU, nullptr, t_d, e.A(L.col1), 32, t_b, B, H1, H1));
             } else {
+                GG_TRY(gg_col2im_nhwc_bf16(t_b, t_c, B, H1, H1, d[0] / 2, 2, e.st));                       // da1 -> t_c [M1, C0/2]
                 GG_TRY(bn_bwd(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, t_c, t_d, t_a));                         // dy1 -> t_a
                 if (e.tr(m.pe1.w.t_w)) GG_TRY(dense_wgrad(e, m.pe1.w, e.A(L.col1), 32, t_a, d[0] / 2, M1, nullptr, 0, t_b, t_c, true));
             }

@@ -99,6 +99,16 @@ def gemm_tn(dY, X, rowscale=None, rows_per_scale=0, accumulate_into=None):
     return out
 
 
+def col2im_nhwc_bnbwd(dcol, y, stat, gamma, beta, act="gelu", nparts=1024):
+    """stride-2 col2im fused with BatchNorm backward's reduce: returns (dz [B,H,W,C] bf16, partial sums [nparts,2,C] f32)."""
+    B, H, W, Cc = y.shape
+    dz = torch.empty_like(y)
+    part = torch.zeros((nparts + 64, 2, Cc), dtype=F32, device=y.device)
+    L.check(L.lib().gg_col2im_nhwc_bnbwd_bf16(_p(dcol, BF16), _p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(dz),
+                                              _p(part), nparts, B, H, W, Cc, L.stream()), "gg_col2im_nhwc_bnbwd_bf16")
+    return dz, part[:nparts]
+
+
 def gemm_tn_bn(dz, y, coef, X, accumulate_into=None):
     """f32 dW[N,K] = (coef0*dz + coef1*y + coef2)^T @ X: a ConvNorm's weight gradient straight from BatchNorm backward's (dz, y, coef)."""
     M, N = dz.shape

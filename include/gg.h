@@ -86,6 +86,10 @@ int gg_im2col_nhwc_bf16(const void* x, void* col, int B, int H, int W, int C, in
 int gg_im2col_nhwc_bn_bf16(const void* y, const float* stat, const float* gamma, const float* beta, int act, void* col, int B, int H, int W, int C,
                           int stride, void* stream);
 int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int stride, void* stream);
+/* stride-2 col2im fused with the BatchNorm-backward reduce of the ConvNorm whose output was gathered: writes dz = da * act'(BN(y)) and
+   nparts partial rows [2][C] (sum dz, sum dz*xhat) for gg_bn_bwd_finalize; da is never stored */
+int gg_col2im_nhwc_bnbwd_bf16(const void* dcol, const void* y, const float* stat, const float* gamma, const float* beta, int act, void* dz,
+                              float* part, int nparts, int B, int H, int W, int C, void* stream);
 int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride);   /* partial-statistics rows gg_dwconv3x3_fwd writes */
 int gg_dwconv_tiled_stat_rows(int B, int Ho);                          /* ... the producer-fused forward variant (LDS-tiled kernel) */
 int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_input_fusion);   /* ... the fused data gradient with ep_y */

@@ -237,6 +237,29 @@ def test_im2col_fused_batchnorm_gelu(ops):
         assert (border == 0).all()
 
 
+@pytest.mark.parametrize("act", ["gelu", None])
+def test_col2im_fused_batchnorm_backward_reduce(ops, act):
+    """col2im + BN-backward reduce in one pass (patch_embed: conv2 dgrad -> BN1/GELU backward) == col2im, then dz = da * act'(BN(y)) and the
+    column sums (sum dz, sum dz * xhat) the reduce pass would produce."""
+    B, H, C = 3, 18, 48
+    Ho = H // 2
+    dcol = dev(rnd(B * Ho * Ho, 9 * C, seed=21, scale=0.5), BF)
+    y = rnd(B, H, H, C, seed=22, scale=1.5).to(BF).float()
+    mean, var = rnd(C, seed=23, scale=0.3), rnd(C, seed=24).abs() + 0.5
+    rstd = (var + 1e-5).rsqrt()
+    gamma, beta = rnd(C, seed=25) + 1.0, rnd(C, seed=26, scale=0.3)
+    da = ops.col2im_nhwc(dcol, B, H, H, C, stride=2).float().cpu()             # bf16-rounded, as the unfused path stores it
+    xh = (y - mean) * rstd
+    pre = (gamma * xh + beta).clone().requires_grad_(True)
+    (F.gelu(pre) if act else pre).sum().backward()
+    dpre = da * pre.grad
+    dz, part = ops.col2im_nhwc_bnbwd(dcol, dev(y, BF), dev(torch.stack([mean, rstd])), dev(gamma), dev(beta), act=act, nparts=37)
+    close(dz, dpre, rtol=8e-3, atol=1e-3, what="fused col2im dz")
+    sums = part.cpu().sum(0)
+    close(sums[0], dpre.sum((0, 1, 2)), rtol=2e-3, atol=2e-2, what="sum dz")
+    close(sums[1], (dpre * xh).sum((0, 1, 2)), rtol=2e-3, atol=2e-2, what="sum dz*xhat")
+
+
 @pytest.mark.parametrize("C,stride,H", [(16, 1, 12), (48, 2, 14), (384, 1, 8), (576, 2, 14), (40, 1, 7)])
 def test_dwconv(ops, C, stride, H):
     B = 3
