@@ -701,6 +701,9 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnParams p, int n
             lse_r = tk >= 0 ? -1.4426950408889634f * p.lse[(int64_t)tk * p.nh + h] : 0.f;
         }
     };
+    f32x4 dsum[DBIAS ? NKT : 1];           // dS of this lane's (query row, 4 keys x NKT tiles) summed over the workgroup's windows
+#pragma unroll
+    for (int kt = 0; kt < (DBIAS ? NKT : 1); ++kt) dsum[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (w0 < w1) fetch(w0);
     for (int w = w0; w < w1; ++w) {
         const int sel = (w - w0) & 1;
@@ -733,7 +736,6 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnParams p, int n
                     qf[ks] = attn_lds_row_frag(Qs, RS, ti, ks * 32 + lg * 8);
                     dof[ks] = attn_lds_row_frag(dOs, RS, ti, ks * 32 + lg * 8);
                 }
-                const int qci = ci[ti], qcj = cj[ti];
                 const float nlse_q = row_lse[sel][ti], ndelta_q = row_delta[sel][ti];
                 f32x4 dq[DT];
 #pragma unroll
@@ -755,14 +757,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnParams p, int n
                         const int key0 = kt * 16 + lg * 4;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc2[r] *= __builtin_amdgcn_exp2f(fmaf(acc[r], c2, nlse_q));
-                        if (DBIAS && tok_own >= 0) {
-                            const uchar4 kci = *reinterpret_cast<const uchar4*>(&ci[key0]);
-                            const uchar4 kcj = *reinterpret_cast<const uchar4*>(&cj[key0]);
-                            const int kcis[4] = {kci.x, kci.y, kci.z, kci.w}, kcjs[4] = {kcj.x, kcj.y, kcj.z, kcj.w};
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                if (key0 + r < p.N) atomicAdd(&dbias_s[(lr & (DBC - 1)) * 256 + abs(qci - kcis[r]) * p.ws + abs(qcj - kcjs[r])], acc2[r]);
-                        }
+                        if (DBIAS) dsum[kt] += acc2;        // same (query, key) slot in every window: scattered to the bias bins once per workgroup
                         dst[u] = acc2;
                     }
                     const bf16x8 df = attn_pack(dst[0], dst[1]);
@@ -839,6 +834,16 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(AttnParams p, int n
         }
     }
     if (DBIAS) {
+        if (wave < nt && ti < p.N) {           // LDS float atomics retire about one lane per clock: once per workgroup, not once per window
+            const int qci = ci[ti], qcj = cj[ti];
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                const int key0 = kt * 16 + lg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (key0 + r < p.N) atomicAdd(&dbias_s[(lr & (DBC - 1)) * 256 + abs(qci - (int)ci[key0 + r]) * p.ws + abs(qcj - (int)cj[key0 + r])], dsum[kt][r]);
+            }
+        }
         __syncthreads();
         for (int t = threadIdx.x; t < p.nbias; t += blockDim.x) {
             float sum = 0.f;
