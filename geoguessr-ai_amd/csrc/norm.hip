@@ -272,19 +272,30 @@ __device__ __forceinline__ float gg_group16_sum(float v) {
     v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
     return v;
 }
-template <int NCH>
+// BNIN: x is the saved pre-BatchNorm output of the ConvNorm in front (TinyViT local_conv); the BatchNorm apply runs on the way in
+// (bf16-rounded exactly as the separate apply pass stores it) and the applied tensor -- the residual stream -- is written to xout, so
+// the apply pass and one read of the stream disappear.
+template <int NCH, bool BNIN = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int64_t M, int C, float eps,
                                                                 bf16* __restrict__ out, float* __restrict__ mean_out,
-                                                                float* __restrict__ rstd_out) {
+                                                                float* __restrict__ rstd_out, const float* __restrict__ bn_stat = nullptr,
+                                                                const float* __restrict__ bn_gamma = nullptr,
+                                                                const float* __restrict__ bn_beta = nullptr, bf16* __restrict__ xout = nullptr) {
     const int l16 = threadIdx.x & 15;
     const int nch = C >> 3;
-    float g[NCH][8], b[NCH][8];
+    float g[NCH][8], b[NCH][8], sc[BNIN ? NCH : 1][8], sh[BNIN ? NCH : 1][8];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int ch = min(l16 + 16 * k, nch - 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { g[k][j] = gamma[ch * 8 + j]; b[k][j] = beta[ch * 8 + j]; }
+        for (int j = 0; j < 8; ++j) {
+            g[k][j] = gamma[ch * 8 + j]; b[k][j] = beta[ch * 8 + j];
+            if (BNIN) {
+                const float a = bn_stat[C + ch * 8 + j] * bn_gamma[ch * 8 + j];
+                sc[k][j] = a; sh[k][j] = bn_beta[ch * 8 + j] - bn_stat[ch * 8 + j] * a;
+            }
+        }
     }
     const float invC = 1.f / (float)C;
     for (int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (int64_t)gridDim.x * 16) {
@@ -293,6 +304,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __re
         for (int k = 0; k < NCH; ++k) {
             const int ch = l16 + 16 * k;
             raw[k] = ch < nch ? *reinterpret_cast<const bf16x8*>(x + m * C + ch * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (BNIN && ch < nch) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[k][j] = (bf16)((float)raw[k][j] * sc[k][j] + sh[k][j]);
+                *reinterpret_cast<bf16x8*>(xout + m * C + ch * 8) = raw[k];
+            }
         }
         float v[NCH][8];
         float s = 0.f;
@@ -686,6 +702,22 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
         hipLaunchKernelGGL((layernorm_fwd_kernel<float, bf16>), grid, block, 0, s, (const float*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);
     else
         hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (float*)out, mean, rstd);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// LayerNorm of BatchNorm(y) for a saved pre-BatchNorm conv output y: xout = bf16(BN(y)) (the residual stream), out = LN(xout)
+extern "C" int gg_layernorm_fwd_bn(const void* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, void* xout,
+                                   const float* gamma, const float* beta, int64_t M, int C, float eps, void* out, float* mean, float* rstd,
+                                   void* stream) {
+    GG_CHECK(y && bn_stat && bn_gamma && bn_beta && xout && gamma && beta && out && M > 0 && (C & 7) == 0, "gg_layernorm_fwd_bn: bad args");
+    const int nchl = (C / 8 + 15) / 16;
+    GG_CHECK(nchl <= 5, "gg_layernorm_fwd_bn: C <= 640");
+    GG_PROF(GG_CAT_NORM, 0, 6.0 * M * C, stream);
+    const dim3 g16((unsigned)std::min<int64_t>(gg_cdiv(M, 16), 8192)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<N_, true>), g16, block, 0, s, (const bf16*)y, gamma, beta, M, C, eps, (bf16*)out, mean, rstd, bn_stat, bn_gamma, bn_beta, (bf16*)xout)
+    switch (nchl) { case 1: GG_LN_FWD(1); break; case 2: GG_LN_FWD(2); break; case 3: GG_LN_FWD(3); break; case 4: GG_LN_FWD(4); break; default: GG_LN_FWD(5); }
+#undef GG_LN_FWD
     GG_LAUNCH_CHECK();
     return 0;
 }

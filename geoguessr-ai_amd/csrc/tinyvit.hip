@@ -522,8 +522,13 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             GG_TRY(gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
             GG_TRY(conv_dw_fwd(e, l.local, a.local, e.A(a.x1), B, st.res, st.res, 1));
-            GG_TRY(bn_apply(e, l.local.bn, a.local, M, GG_ACT_NONE, e.A(a.x2)));
-            GG_TRY(gg_layernorm_fwd(e.A(a.x2), 0, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), 0, e.F(a.mean2), e.F(a.rstd2), e.st));
+            if (C <= 640) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
+                GG_TRY(gg_layernorm_fwd_bn(e.A(a.local.y), e.F(a.local.stat), e.P(l.local.bn.t_g), e.P(l.local.bn.t_b), e.A(a.x2), e.P(l.ln2.t_g),
+                                           e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), e.F(a.mean2), e.F(a.rstd2), e.st));
+            } else {
+                GG_TRY(bn_apply(e, l.local.bn, a.local, M, GG_ACT_NONE, e.A(a.x2)));
+                GG_TRY(gg_layernorm_fwd(e.A(a.x2), 0, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), 0, e.F(a.mean2), e.F(a.rstd2), e.st));
+            }
             GG_TRY(gemm(e, e.A(a.b), C, e.Wn(l.fc1), l.fc1.Kp, e.A(a.h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU,
                         e.training ? (void*)e.A(a.hpre) : nullptr));
             GG_TRY(gemm(e, e.A(a.h), hid, e.Wn(l.fc2), l.fc2.Kp, e.A(a.x3), C, M, C, l.fc2.Kp, e.P(l.fc2.t_b), 0, nullptr, s2, rps, e.A(a.x2)));

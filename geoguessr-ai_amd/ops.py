@@ -331,6 +331,18 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_f32=None, save_stats=True):
     return out, mean, rstd
 
 
+def layernorm_fwd_bn(y, bn_stat, bn_gamma, bn_beta, gamma, beta, eps=1e-5):
+    """(x, LN(x), mean, rstd) with x = bf16(BatchNorm(y)) formed on the way in (TinyViT local_conv -> norm2)."""
+    M, Cc = y.shape
+    x = torch.empty_like(y)
+    out = torch.empty_like(y)
+    mean = torch.empty((M,), dtype=F32, device=y.device)
+    rstd = torch.empty((M,), dtype=F32, device=y.device)
+    L.check(L.lib().gg_layernorm_fwd_bn(_p(y, BF16), _p(bn_stat, F32), _p(bn_gamma, F32), _p(bn_beta, F32), _p(x), _p(gamma, F32), _p(beta, F32),
+                                        M, Cc, eps, _p(out), _p(mean), _p(rstd), L.stream()), "gg_layernorm_fwd_bn")
+    return x, out, mean, rstd
+
+
 def layernorm_bwd(dout, x, mean, rstd, gamma, dres=None, want_param_grads=True):
     M, Cc = x.shape
     f32 = x.dtype == F32

@@ -136,6 +136,10 @@ int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* g
 /* ---------------------------------------------------------------- LayerNorm / pooling */
 int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, const float* beta, int64_t M, int C, float eps, void* out,
                      int out_f32, float* mean, float* rstd, void* stream);
+/* LayerNorm of BatchNorm(y) for a saved pre-BatchNorm conv output y (TinyViT block: local_conv -> norm2): xout = bf16(BN(y)) is the
+   residual stream, out = LN(xout); replaces gg_bn_apply + gg_layernorm_fwd (tiny_vit.py TinyVitBlock.forward) */
+int gg_layernorm_fwd_bn(const void* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, void* xout, const float* gamma,
+                        const float* beta, int64_t M, int C, float eps, void* out, float* mean, float* rstd, void* stream);
 int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C);
 int gg_layernorm_bwd(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma, int64_t M,
                      int C, const void* dres, void* dx, float* scratch, float* dgamma, float* dbeta, int accumulate, void* stream);

@@ -354,6 +354,25 @@ def test_pooling(ops):
     close(ops.token_mean_bwd(dev(d), T), (d / T).repeat_interleave(T, 0), what="token mean bwd")
 
 
+@pytest.mark.parametrize("M,C", [(1000, 384), (333, 192), (77, 576), (50, 40)])
+def test_layernorm_with_batchnorm_apply_on_load(ops, M, C):
+    """LN(BN(y)) with the BatchNorm apply folded into the LayerNorm load == gg_bn_apply followed by gg_layernorm_fwd, bit for bit
+    (TinyVitBlock: local_conv's BatchNorm -> norm2; the applied tensor is the residual stream and is written by the same kernel)."""
+    y = dev(rnd(M, C, seed=70, scale=2.0), BF)
+    mean, var = rnd(C, seed=71, scale=0.5), rnd(C, seed=72).abs() + 0.5
+    stat = dev(torch.stack([mean, (var + 1e-5).rsqrt()]))
+    bg, bb = dev(rnd(C, seed=73) + 1.0), dev(rnd(C, seed=74, scale=0.3))
+    g, b = dev(rnd(C, seed=75) + 1.0), dev(rnd(C, seed=76, scale=0.2))
+    x_ref = ops.bn_apply(y, stat, bg, bb)
+    o_ref, m_ref, r_ref = ops.layernorm_fwd(x_ref, g, b)
+    x, o, m, r = ops.layernorm_fwd_bn(y, stat, bg, bb, g, b)
+    close(x, x_ref.float(), rtol=8e-3, atol=1e-3, what="bn-applied stream")          # <= 1 bf16 ulp (fma contraction may differ)
+    close(o, o_ref.float(), rtol=2e-2, atol=2e-2, what="ln of bn")
+    x32 = x.float().cpu()
+    close(o, F.layer_norm(x32, (C,), g.cpu(), b.cpu(), 1e-5), rtol=1e-2, atol=1e-2, what="ln vs torch on the written stream")
+    close(m, x32.mean(1), rtol=1e-4, atol=1e-4, what="ln mean")
+
+
 # ------------------------------------------------------------------------------------------- attention
 def _attn_ref(qkv, nh, hd, ws, Hm, Wm, B, bias, layout):
     """fp32 reference of timm Attention (per-head interleaved qkv, window partition, rel-pos bias) / CLIP MHSA."""
