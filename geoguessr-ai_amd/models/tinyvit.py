@@ -271,7 +271,9 @@ class TinyVitBackbone(_Tree):
         """timm DropPath (scale_by_keep): per-sample Bernoulli(1-p)/(1-p), one row per slot."""
         if max(self.drop_rates) <= 0:
             return None
-        keep = 1.0 - torch.tensor(self.drop_rates, device=self._flat.device).unsqueeze(1)
+        keep = getattr(self, "_keep_dev", None)
+        if keep is None or keep.device != self._flat.device:          # cached on the device: no host-to-device copy per step (graph-capturable)
+            keep = self._keep_dev = 1.0 - torch.tensor(self.drop_rates, device=self._flat.device).unsqueeze(1)
         u = torch.rand((self.num_drop_slots, batch), device=self._flat.device, generator=generator)
         return ((u < keep).to(torch.float32) / keep).contiguous()
 

@@ -13,22 +13,24 @@ L.require_gpu()
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False)
-model = SuperGuessr(base, panorama=False, should_smooth_labels=False, serving=False).to(dev).train()
+name = sys.argv[2] if len(sys.argv) > 2 else "tiny_vit_5m_224"
+pano = len(sys.argv) > 3 and sys.argv[3] == "pano"            # headline form: n panoramas x 4 headings, soft labels
+base = TinyViTAdapter(name, pretrained=False)
+model = SuperGuessr(base, panorama=pano, should_smooth_labels=pano, serving=False).to(dev).train()
 opt = AdamW(model, lr=5e-5)
 g = torch.Generator(device=dev).manual_seed(1234)
-x = torch.randn(n, 3, 224, 224, device=dev, generator=g)
+x = torch.randn((n, 4, 3, 224, 224) if pano else (n, 3, 224, 224), device=dev, generator=g)
 lab = torch.stack([torch.rand(n, device=dev, generator=g) * 360 - 180, torch.rand(n, device=dev, generator=g) * 180 - 90], 1)
 clf = torch.randint(0, model.num_cells, (n,), device=dev, generator=g)
 
 
 def step():
-    out = model(pixel_values=x, labels=lab, labels_clf=clf)
+    out = model(pixel_values=x, labels=lab) if pano else model(pixel_values=x, labels=lab, labels_clf=clf)
     out.loss.backward(); opt.step(); opt.zero_grad()
     return out.loss
 
 
-def timed(fn, steps=50, warmup=10):
+def timed(fn, steps=20 if pano else 50, warmup=5):
     for _ in range(warmup): fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -38,7 +40,7 @@ def timed(fn, steps=50, warmup=10):
 
 
 eager = timed(step)
-res = dict(case="c1", images_per_step=n, eager_ms=round(eager, 3))
+res = dict(case=name, images_per_step=n * (4 if pano else 1), eager_ms=round(eager, 3))
 try:
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
