@@ -284,18 +284,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __re
                                                                 const float* __restrict__ bn_beta = nullptr, bf16* __restrict__ xout = nullptr) {
     const int l16 = threadIdx.x & 15;
     const int nch = C >> 3;
-    float g[NCH][8], b[NCH][8], sc[BNIN ? NCH : 1][8], sh[BNIN ? NCH : 1][8];
+    float g[NCH][8], b[NCH][8];
+    // BatchNorm scale / shift live in LDS (another 48 registers per thread at C = 384 would cost two waves per SIMD of a streaming kernel)
+    __shared__ __attribute__((aligned(16))) float bn_tab[BNIN ? 2 * 640 : 4];
+    if (BNIN) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float a = bn_stat[C + c] * bn_gamma[c];
+            bn_tab[c] = a; bn_tab[640 + c] = bn_beta[c] - bn_stat[c] * a;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int ch = min(l16 + 16 * k, nch - 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            g[k][j] = gamma[ch * 8 + j]; b[k][j] = beta[ch * 8 + j];
-            if (BNIN) {
-                const float a = bn_stat[C + ch * 8 + j] * bn_gamma[ch * 8 + j];
-                sc[k][j] = a; sh[k][j] = bn_beta[ch * 8 + j] - bn_stat[ch * 8 + j] * a;
-            }
-        }
+        for (int j = 0; j < 8; ++j) { g[k][j] = gamma[ch * 8 + j]; b[k][j] = beta[ch * 8 + j]; }
     }
     const float invC = 1.f / (float)C;
     for (int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (int64_t)gridDim.x * 16) {
@@ -305,8 +308,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __re
             const int ch = l16 + 16 * k;
             raw[k] = ch < nch ? *reinterpret_cast<const bf16x8*>(x + m * C + ch * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
             if (BNIN && ch < nch) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(bn_tab + ch * 8), s1 = *reinterpret_cast<const f32x4*>(bn_tab + ch * 8 + 4);
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(bn_tab + 640 + ch * 8), h1 = *reinterpret_cast<const f32x4*>(bn_tab + 640 + ch * 8 + 4);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) raw[k][j] = (bf16)((float)raw[k][j] * sc[k][j] + sh[k][j]);
+                for (int j = 0; j < 4; ++j) {
+                    raw[k][j] = (bf16)((float)raw[k][j] * s0[j] + h0[j]);
+                    raw[k][j + 4] = (bf16)((float)raw[k][j + 4] * s1[j] + h1[j]);
+                }
                 *reinterpret_cast<bf16x8*>(xout + m * C + ch * 8) = raw[k];
             }
         }
