@@ -260,7 +260,7 @@ def test_col2im_fused_batchnorm_backward_reduce(ops, act):
     close(sums[1], (dpre * xh).sum((0, 1, 2)), rtol=2e-3, atol=2e-2, what="sum dz*xhat")
 
 
-@pytest.mark.parametrize("C,stride,H", [(16, 1, 12), (48, 2, 14), (384, 1, 8), (576, 2, 14), (40, 1, 7)])
+@pytest.mark.parametrize("C,stride,H", [(16, 1, 12), (48, 2, 14), (384, 1, 8), (576, 2, 14), (40, 1, 7), (24, 2, 9), (64, 2, 15)])
 def test_dwconv(ops, C, stride, H):
     B = 3
     x = rnd(B, H, H, C, seed=20)
