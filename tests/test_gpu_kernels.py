@@ -109,6 +109,18 @@ def test_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
     close(got, plain.cpu(), rtol=1e-3, atol=1e-2, what="tn fused vs unfused")
 
 
+def test_gemm_tn_many_slabs_small_matrix(ops):
+    """patch_embed.conv1's weight-gradient shape (48 x 32 from millions of rows): >= 64 split slabs of a tiny matrix take the
+    column x slab-lane reduction kernel."""
+    M, N, K = 70000, 48, 32
+    X, dY = rnd(M, K, seed=40), rnd(M, N, seed=41, scale=0.1)
+    got = ops.gemm_tn(dev(dY, BF), dev(X, BF))
+    close(got, dY.to(BF).float().t() @ X.to(BF).float(), rtol=1e-3, atol=2e-2, what="tn gemm, 68 slabs")
+    acc = torch.full((N, K), 2.0, device="cuda")
+    got = ops.gemm_tn(dev(dY, BF), dev(X, BF), accumulate_into=acc)
+    close(got, 2.0 + dY.to(BF).float().t() @ X.to(BF).float(), rtol=1e-3, atol=2e-2, what="tn gemm accumulate")
+
+
 def test_gemm_splitk_and_wgrad_form(ops):
     """wgrad: dW[N,K] = dY^T X with the reduction (rows) split across blockIdx.y."""
     Mrows, N, K = 5000, 96, 160
@@ -193,28 +205,30 @@ def test_gemm_tn_weight_gradient(ops, M, N, K):
 
 
 # ------------------------------------------------------------------------------------------- convolutions
-def test_im2col_matches_conv(ops):
-    B, H = 2, 20
+@pytest.mark.parametrize("H", [20, 18])          # W % 4 == 0: LDS-staged NCHW gather; otherwise the per-pixel gather
+def test_im2col_matches_conv(ops, H):
+    B = 2
     x = rnd(B, 3, H, H, seed=11)
     w = rnd(16, 3, 3, 3, seed=12, scale=0.3)
-    col = ops.im2col_nchw3(dev(x), stride=2)                      # [B*10*10, 32], k = (ky,kx,ci)
+    col = ops.im2col_nchw3(dev(x), stride=2)                      # [B*Ho*Ho, 32], k = (ky,kx,ci)
     wk = torch.zeros(16, 32)
     wk[:, :27] = w.permute(0, 2, 3, 1).reshape(16, 27)
-    got = ops.gemm_nt(col, dev(wk, BF), out_f32=True).view(B, 10, 10, 16).permute(0, 3, 1, 2)
+    Ho = H // 2
+    got = ops.gemm_nt(col, dev(wk, BF), out_f32=True).view(B, Ho, Ho, 16).permute(0, 3, 1, 2)
     close(got, F.conv2d(x, w, None, 2, 1), rtol=1e-4, atol=1e-3, what="conv1 via im2col")
     C = 16
     xh = rnd(B, H, H, C, seed=13)
     w2 = rnd(24, C, 3, 3, seed=14, scale=0.2)
     col2 = ops.im2col_nhwc(dev(xh, BF), stride=2)
-    got = ops.gemm_nt(col2, dev(w2.permute(0, 2, 3, 1).reshape(24, 9 * C), BF), out_f32=True).view(B, 10, 10, 24).permute(0, 3, 1, 2)
+    got = ops.gemm_nt(col2, dev(w2.permute(0, 2, 3, 1).reshape(24, 9 * C), BF), out_f32=True).view(B, Ho, Ho, 24).permute(0, 3, 1, 2)
     ref = F.conv2d(xh.permute(0, 3, 1, 2), w2, None, 2, 1)
     close(got, ref, rtol=1e-4, atol=1e-3, what="conv2 via im2col")
     # col2im is the adjoint of im2col: <im2col(x), d> == <x, col2im(d)>
-    d = rnd(B * 10 * 10, 9 * C, seed=15)
+    d = rnd(B * Ho * Ho, 9 * C, seed=15)
     dx = ops.col2im_nhwc(dev(d, BF), B, H, H, C, stride=2)
     xr = xh.clone().requires_grad_(True)
     cols_ref = F.unfold(xr.permute(0, 3, 1, 2), 3, padding=1, stride=2)             # (B, C*9, L), k = (c,ky,kx)
-    cols_ref = cols_ref.view(B, C, 9, 100).permute(0, 3, 2, 1).reshape(B * 100, 9 * C)   # -> (ky,kx,c)
+    cols_ref = cols_ref.view(B, C, 9, Ho * Ho).permute(0, 3, 2, 1).reshape(B * Ho * Ho, 9 * C)   # -> (ky,kx,c)
     (cols_ref * d).sum().backward()
     close(dx, xr.grad, what="col2im")
 
