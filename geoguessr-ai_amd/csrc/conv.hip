@@ -408,6 +408,129 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
     }
 }
 
+// ---------------------------------------------------------------- stride-2 column-walking depthwise 3x3 (PatchMerging.conv2 forward)
+// thread = (8 channels, one OUTPUT column), walking down the output rows: output row oy needs input rows 2oy-1 .. 2oy+1, of which
+// 2oy-1 was the last row of the previous step -> two new input rows x three columns per step (6 x 16-byte loads for a 16-byte
+// result; the LDS-tiled kernel staged 17x17 inputs per 8x8 outputs through LDS and ran at 3.6 TB/s).  IN1: the input is the saved
+// pre-BatchNorm output of the ConvNorm in front and act(BatchNorm(x)) is applied to every loaded element (bf16-rounded like the
+// stored activation; 1.5 evaluations per input element instead of a 2 x [M, C] apply pass); padding stays exactly zero.
+// BatchNorm partial statistics of the bf16-rounded result: one row per block in colstats [gridDim.x][2][C].
+template <bool IN1>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_s2_walk_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
+                                                                   int H, int W, int C, int Ho, int Wo, int CG, int PX, int nbx,
+                                                                   float* __restrict__ colstats, DwWalkFuse f) {
+    constexpr int NQ = 4;
+    typedef DwRaw<NQ>::T Raw;
+    extern __shared__ float dw2_red[];          // [PX][2][C] statistics scratch; IN1: scale, shift rows [2][C]
+    float* ctab = dw2_red + PX * 2 * C;
+    const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % nbx, b = bid / nbx;
+    const int ox = bx * PX + px;
+    const int c0 = cg * 8;
+    if (IN1) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float sc = f.in_stat[C + c] * f.in_gamma[c];
+            ctab[c] = sc; ctab[C + c] = f.in_beta[c] - f.in_stat[c] * sc;
+        }
+        __syncthreads();
+    }
+    f32x2 tap[9][NQ], isc[NQ], ish[NQ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tap[t][q] = *reinterpret_cast<const f32x2*>(wt + t * C + c0 + 2 * q);
+    if (IN1) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { isc[q] = *reinterpret_cast<const f32x2*>(ctab + c0 + 2 * q); ish[q] = *reinterpret_cast<const f32x2*>(ctab + C + c0 + 2 * q); }
+    }
+    const bool in_gelu = f.in_act == GG_ACT_GELU;
+    const int64_t img = (int64_t)b * H * W * C;
+    const unsigned long long xa = (unsigned long long)(x + img);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xa), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32));   // block-uniform: descriptor in SGPRs
+    const void* xb = (const void*)(((unsigned long long)xhi << 32) | xlo);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, __builtin_amdgcn_readfirstlane(H * W * C * 2), 0x00020000);
+    unsigned colo[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ix = 2 * ox + k - 1;
+        colo[k] = (ix >= 0 && ix < W && ox < Wo) ? (unsigned)(ix * C + c0) * 2u : DW_COL_OOB;
+    }
+    const unsigned rowb = (unsigned)W * C * 2u;
+    auto load_row = [&](int iy, Raw (&raw)[3]) {
+        const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw[k] = DwRaw<NQ>::load(rs, (int)(colo[k] + ro));
+    };
+    auto fill = [&](int iy, const Raw (&raw)[3], f32x2 (&slot)[3][NQ]) {
+        const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (IN1) {
+                    const f32x2 a = dw_unpack2(dw_pack2(gg_act_v2(dw_unpack2(raw[k][q]) * isc[q] + ish[q], in_gelu)));
+                    slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? a : (f32x2)(0.f);
+                } else {
+                    slot[k][q] = dw_unpack2(raw[k][q]);
+                }
+            }
+    };
+    f32x2 win[3][3][NQ];          // [row slot][column][channel pair]; slot 0 = input row 2oy-1, 1 = 2oy, 2 = 2oy+1
+    Raw ra[3], rb[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) win[0][k][q] = (f32x2)(0.f);      // row -1
+    load_row(0, ra);
+    load_row(1, rb);
+    f32x2 s2[NQ], q2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s2[q] = q2[q] = (f32x2)(0.f);
+    const bool store_ok = ox < Wo;
+    bf16* yb = y + (int64_t)b * Ho * Wo * C + (int64_t)ox * C + c0;
+    // one output row; TOP names the slot holding input row 2oy-1, the other two receive rows 2oy and 2oy+1; the slot that held 2oy+1
+    // is the next step's TOP, so two steps with the roles of slots 0 and 2 swapped make one trip (no register copies)
+#define GG_S2W_STEP(TOP, BOT, oy)                                                                                          \
+    {                                                                                                                      \
+        fill(2 * (oy), ra, win[1]);                                                                                        \
+        fill(2 * (oy) + 1, rb, win[BOT]);                                                                                  \
+        load_row(2 * (oy) + 2, ra);                                                                                        \
+        load_row(2 * (oy) + 3, rb);                                                                                        \
+        Raw o;                                                                                                             \
+        const float live = (oy) < Ho ? 1.f : 0.f;                                                                          \
+        _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                                   \
+            f32x2 a = (f32x2)(0.f);                                                                                        \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                                \
+                const int rsl = t < 3 ? TOP : (t < 6 ? 1 : BOT);                                                           \
+                a = win[rsl][t % 3][q] * tap[t][q] + a;                                                                    \
+            }                                                                                                              \
+            o[q] = dw_pack2(a);                                                                                            \
+            const f32x2 r = dw_unpack2(o[q]) * live;                                                                       \
+            s2[q] += r; q2[q] += r * r;                                                                                    \
+        }                                                                                                                  \
+        if (store_ok && (oy) < Ho) *reinterpret_cast<Raw*>(yb + (int64_t)(oy) * Wo * C) = o;                               \
+    }
+    for (int oy = 0; oy < Ho; oy += 2) {
+        GG_S2W_STEP(0, 2, oy)
+        GG_S2W_STEP(2, 0, oy + 1)
+    }
+#undef GG_S2W_STEP
+    if (colstats) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            dw2_red[(px * 2 + 0) * C + c0 + 2 * q] = s2[q].x; dw2_red[(px * 2 + 0) * C + c0 + 2 * q + 1] = s2[q].y;
+            dw2_red[(px * 2 + 1) * C + c0 + 2 * q] = q2[q].x; dw2_red[(px * 2 + 1) * C + c0 + 2 * q + 1] = q2[q].y;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < PX; ++k) t += dw2_red[k * 2 * C + i];
+            colstats[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- LDS-tiled depthwise 3x3
 // Block = (image, band of 8 output rows, chunk of 64 channels); it walks the band in 8-pixel-wide tiles.  The input
 // tile (+halo) is staged once in LDS (next tile prefetched through registers), so HBM sees every input byte once and
@@ -1066,7 +1189,32 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
 static int dw_walk_px(int C, int nc = 8) { return std::max(1, 256 / (C / nc)); }
 static bool dw_walk_ok(int C, int stride) { return stride == 1 && (C / 8) <= 256 && getenv("GG_DW_TILED") == nullptr; }
 static bool dw_walk_fused4(int C) { return (C / 4) <= 256; }       // both fusions at once run 4 channels per thread
+// stride-2 forward: the walking kernel when its per-thread state fits (8 channels per thread, <= 256 channel groups) and the image fits the
+// 30-bit offsets; GG_DW_TILED keeps the LDS-tiled kernel
+static bool dw_s2_walk_ok(int C) { return (C / 8) <= 256 && (C & 7) == 0 && getenv("GG_DW_TILED") == nullptr && getenv("GG_DW_S2_TILED") == nullptr; }
+static int dwconv_s2_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, float* colstats, void* stream,
+                                 const DwWalkFuse* fuse) {
+    GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");
+    GG_CHECK(((uintptr_t)wt & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0, "dwconv: operands must be 16-byte aligned");
+    DwWalkFuse f;
+    memset(&f, 0, sizeof(f));
+    if (fuse) f = *fuse;
+    const bool in1 = f.in_stat != nullptr;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int CG = C / 8, PX = dw_walk_px(C, 8), nbx = (int)gg_cdiv(Wo, PX);
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 2.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    const size_t lds = ((size_t)PX * 2 * C + (in1 ? 2 * (size_t)C : 0)) * sizeof(float);
+    GG_CHECK(lds <= 64 * 1024, "dwconv: C=%d needs %zu bytes of LDS", C, lds);
+    const dim3 grid((unsigned)(B * nbx)), block(CG * PX);
+    if (in1) hipLaunchKernelGGL((dwconv3x3_s2_walk_kernel<true>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y, H, W, C, Ho, Wo,
+                                CG, PX, nbx, colstats, f);
+    else hipLaunchKernelGGL((dwconv3x3_s2_walk_kernel<false>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, (bf16*)y, H, W, C, Ho, Wo,
+                            CG, PX, nbx, colstats, f);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride) {
+    if (stride == 2 && dw_s2_walk_ok(C)) return B * (int)gg_cdiv(Wo, dw_walk_px(C, 8));
     if (dw_walk_ok(C, stride)) return B * (int)gg_cdiv(Wo, dw_walk_px(C));
     return B * (int)gg_cdiv(Ho, 8);
 }
@@ -1174,6 +1322,7 @@ extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, 
                                 void* stream) {
     GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
     if (dw_walk_ok(C, stride)) return dwconv_walk_launch(x, wt, y, B, H, W, C, 0, colstats, stream);
+    if (stride == 2 && dw_s2_walk_ok(C)) return dwconv_s2_walk_launch(x, wt, y, B, H, W, C, colstats, stream, nullptr);
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, nullptr, nullptr, nullptr, 0, colstats, stream);
 }
 // fused producer: x is the PRE-BatchNorm output of the previous ConvNorm; act(BN(x)) is formed while staging
@@ -1186,6 +1335,12 @@ extern "C" int gg_dwconv3x3_fwd_fused(const void* x, const float* in_stat, const
         memset(&wf, 0, sizeof(wf));
         wf.in_stat = in_stat; wf.in_gamma = in_gamma; wf.in_beta = in_beta; wf.in_act = in_act;
         return dwconv_walk_launch(x, wt, y, B, H, W, C, 0, colstats, stream, &wf);
+    }
+    if (stride == 2 && dw_s2_walk_ok(C)) {
+        DwWalkFuse wf;
+        memset(&wf, 0, sizeof(wf));
+        wf.in_stat = in_stat; wf.in_gamma = in_gamma; wf.in_beta = in_beta; wf.in_act = in_act;
+        return dwconv_s2_walk_launch(x, wt, y, B, H, W, C, colstats, stream, &wf);
     }
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, in_stat, in_gamma, in_beta, in_act, colstats, stream);
 }

@@ -340,6 +340,9 @@ struct Exec {
     // loaded (and transformed) by its three neighbouring columns: the erf work triples and the conv turns VALU-bound
     // (measured at 1024 images: +4.7 ms conv vs -2.7 ms elementwise) -> off by default.
     bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
+    // the stride-2 depthwise conv of PatchMerging stages its input tile in LDS: BatchNorm1 + GELU are applied once per staged element
+    // (17x17 inputs per 8x8 outputs = 1.13x), the apply pass and the activation tensor disappear
+    bool fuse_dw_s2 = getenv("GG_NO_FUSE_DW_S2") == nullptr;
     // Frozen depthwise taps: the data gradient forms BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) while it loads its
     // input, and (MBConv) emits dz = da*act'(BN(y)) + the reduce sums of the ConvNorm in front: apply and reduce passes and
     // the dy / da tensors disappear.  GG_NO_FUSE_BNBWD=1 / GG_NO_FUSE_BNBWD_EPI=1 restore the separate passes.
@@ -434,7 +437,7 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
                                   c.w.C, stride, part, e.st));
-    return bn_stats(e, c.bn, a, stride == 1 ? gg_dwconv_fused_stat_rows(B, Ho, Wo, c.w.C, 1) : gg_dwconv_tiled_stat_rows(B, Ho), (int64_t)B * Ho * Wo);
+    return bn_stats(e, c.bn, a, stride == 1 ? gg_dwconv_fused_stat_rows(B, Ho, Wo, c.w.C, 1) : gg_dwconv_stat_rows(B, Ho, Wo, c.w.C, 2), (int64_t)B * Ho * Wo);
 }
 static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
                     const float* rowscale = nullptr, int rps = 0) {
@@ -493,7 +496,7 @@ static int forward_impl(Exec& e, const float* x, float* out) {
         const MergeAct& ma = L.merge[s];
         // PatchMerging
         GG_TRY(conv_dense_fwd(e, st.merge.c1, ma.c1, e.A(prev), Cprev, Mprev));
-        if (e.fuse_dw) {
+        if (e.fuse_dw || e.fuse_dw_s2) {
             GG_TRY(conv_dw_fwd_fused(e, st.merge.c2, ma.c2, st.merge.c1.bn, ma.c1, GG_ACT_GELU, B, res, res, 2));
         } else {
             GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Mprev, GG_ACT_GELU, e.A(ma.a1)));
@@ -763,7 +766,7 @@ static int backward_impl(Exec& e, const float* d_out) {
         GG_TRY(gemm(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_b, C, M, C, C));                 // da2 -> t_b
         GG_TRY(bn_bwd(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, t_b, t_c, t_a));                          // dy2 -> t_a
         if (e.tr(st.merge.c2.w.t_w)) {
-            if (e.fuse_dw) GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, e.A(ma.a1)));      // act1 was fused away in forward
+            if (e.fuse_dw || e.fuse_dw_s2) GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, e.A(ma.a1)));      // act1 was fused away in forward
             GG_TRY(gg_dwconv3x3_bwd_weight(e.A(ma.a1), t_a, B, rin, rin, C, 2, e.F(L.bnscratch), e.Gd(st.merge.c2.w.t_w), 1, e.st));
         }
         GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(st.merge.c2.w), t_b, B, rin, rin, C, 2, e.st));        // da1 -> t_b [Min, C]

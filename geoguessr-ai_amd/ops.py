@@ -189,6 +189,20 @@ def dwconv3x3_fwd(x, taps, stride=1, colstats=False):
     return (y, stats) if colstats else y
 
 
+def dwconv3x3_fwd_fused(y_in, stat, gamma, beta, taps, act="gelu", stride=2, colstats=True):
+    """depthwise conv over act(BatchNorm(y_in)) formed while loading (y_in = saved pre-BatchNorm output of the ConvNorm in front)."""
+    B, H, W, Cc = y_in.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=y_in.device)
+    stats = None
+    if colstats:
+        rows = L.lib().gg_dwconv_fused_stat_rows(B, Ho, Wo, Cc, 1) if stride == 1 else L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, 2)
+        stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=y_in.device)[:rows]
+    L.check(L.lib().gg_dwconv3x3_fwd_fused(_p(y_in, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(taps, F32), _p(y), B, H, W,
+                                           Cc, stride, _p(stats), L.stream()), "gg_dwconv3x3_fwd_fused")
+    return (y, stats) if colstats else y
+
+
 def dwconv3x3_bwd_data(dy, taps, B, H, W, Cc, stride=1):
     dx = torch.empty((B, H, W, Cc), dtype=BF16, device=dy.device)
     L.check(L.lib().gg_dwconv3x3_bwd_data(_p(dy, BF16), _p(taps, F32), _p(dx), B, H, W, Cc, stride, L.stream()),
