@@ -91,6 +91,7 @@ SIGNATURES = {
     "gg_dwconv_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv_tiled_stat_rows": (_I, [_I, _I]),
     "gg_dwconv_fused_stat_rows": (_I, [_I, _I, _I, _I, _I]),
+    "gg_dwconv_fwd_fused_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv3x3_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_fwd_fused": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

@@ -408,6 +408,119 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
     }
 }
 
+// ---------------------------------------------------------------- stride-1 walk, NCOL output columns per thread, producer BatchNorm + activation on load
+// MBConv.conv2 over GELU(BN1(y1)): with one column per thread every input element is transformed by the three threads whose windows
+// contain it (the IN = 1 variant of the kernel above: 2.6 ms against 1.24 + 1.0 ms for plain conv + apply pass).  Here a thread owns
+// NCOL adjacent columns x 4 channels: NCOL + 2 loads and transforms per row step for NCOL results -- 1.5 evaluations per element at
+// NCOL = 4 -- and the apply pass with its 2 x [M, C] of traffic disappears.  Forward only; statistics as in the other walkers.
+template <int NCOL>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
+                                                                    int H, int W, int C, int CG, int PX, int nbx, float* __restrict__ colstats,
+                                                                    DwWalkFuse f) {
+    constexpr int NQ = 2, NW = NCOL + 2;
+    typedef DwRaw<NQ>::T Raw;
+    extern __shared__ float dwm_red[];          // [PX][2][C] statistics scratch, then scale / shift rows [2][C]
+    float* ctab = dwm_red + PX * 2 * C;
+    const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
+    const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int bx = bid % nbx, b = bid / nbx;
+    const int x0 = (bx * PX + px) * NCOL;       // first output column of this thread
+    const int c0 = cg * 4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sc = f.in_stat[C + c] * f.in_gamma[c];
+        ctab[c] = sc; ctab[C + c] = f.in_beta[c] - f.in_stat[c] * sc;
+    }
+    __syncthreads();
+    f32x2 tap[9][NQ], isc[NQ], ish[NQ];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) tap[t][q] = *reinterpret_cast<const f32x2*>(wt + t * C + c0 + 2 * q);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { isc[q] = *reinterpret_cast<const f32x2*>(ctab + c0 + 2 * q); ish[q] = *reinterpret_cast<const f32x2*>(ctab + C + c0 + 2 * q); }
+    const bool in_gelu = f.in_act == GG_ACT_GELU;
+    const int64_t img = (int64_t)b * H * W * C;
+    const unsigned long long xa = (unsigned long long)(x + img);
+    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xa), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32));   // block-uniform: descriptor in SGPRs
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi << 32) | xlo), 0,
+                                                                        __builtin_amdgcn_readfirstlane(H * W * C * 2), 0x00020000);
+    unsigned colo[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const int ix = x0 + k - 1;
+        colo[k] = (ix >= 0 && ix < W) ? (unsigned)(ix * C + c0) * 2u : DW_COL_OOB;
+    }
+    const unsigned rowb = (unsigned)W * C * 2u;
+    auto load_row = [&](int iy, Raw (&raw)[NW]) {
+        const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) raw[k] = DwRaw<NQ>::load(rs, (int)(colo[k] + ro));
+    };
+    // raw row -> window slot: act(BN(.)) once per loaded element, bf16-rounded like the activation tensor the apply pass would store
+    auto fill = [&](int iy, const Raw (&raw)[NW], f32x2 (&slot)[NW][NQ]) {
+        const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const f32x2 a = dw_unpack2(dw_pack2(gg_act_v2(dw_unpack2(raw[k][q]) * isc[q] + ish[q], in_gelu)));
+                slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? a : (f32x2)(0.f);
+            }
+    };
+    f32x2 win[3][NW][NQ];
+    Raw raw[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) win[0][k][q] = (f32x2)(0.f);      // row -1
+    load_row(0, raw);
+    fill(0, raw, win[1]);
+    load_row(1, raw);
+    f32x2 s2[NQ], q2[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) s2[q] = q2[q] = (f32x2)(0.f);
+    bf16* yb = y + img + (int64_t)x0 * C + c0;
+#define GG_DWM_STEP(RA, RB, RC, yy)                                                                                        \
+    {                                                                                                                      \
+        fill((yy) + 1, raw, win[RC]);                                                                                      \
+        load_row((yy) + 2, raw);                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < NCOL; ++j) {                                                                 \
+            const bool live = (yy) < H && x0 + j < W;                                                                      \
+            Raw o;                                                                                                         \
+            _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                               \
+                f32x2 a = (f32x2)(0.f);                                                                                    \
+                _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                            \
+                    const int rsl = t < 3 ? RA : (t < 6 ? RB : RC);                                                        \
+                    a = win[rsl][j + t % 3][q] * tap[t][q] + a;                                                            \
+                }                                                                                                          \
+                o[q] = dw_pack2(a);                                                                                        \
+                const f32x2 r = live ? dw_unpack2(o[q]) : (f32x2)(0.f);                                                    \
+                s2[q] += r; q2[q] += r * r;                                                                                \
+            }                                                                                                              \
+            if (live) *reinterpret_cast<Raw*>(yb + ((int64_t)(yy) * W + j) * C) = o;                                       \
+        }                                                                                                                  \
+    }
+    for (int y0 = 0; y0 < H; y0 += 3) {
+        GG_DWM_STEP(0, 1, 2, y0)
+        GG_DWM_STEP(1, 2, 0, y0 + 1)
+        GG_DWM_STEP(2, 0, 1, y0 + 2)
+    }
+#undef GG_DWM_STEP
+    if (colstats) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            dwm_red[(px * 2 + 0) * C + c0 + 2 * q] = s2[q].x; dwm_red[(px * 2 + 0) * C + c0 + 2 * q + 1] = s2[q].y;
+            dwm_red[(px * 2 + 1) * C + c0 + 2 * q] = q2[q].x; dwm_red[(px * 2 + 1) * C + c0 + 2 * q + 1] = q2[q].y;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+            float t = 0.f;
+            for (int k = 0; k < PX; ++k) t += dwm_red[k * 2 * C + i];
+            colstats[(int64_t)blockIdx.x * 2 * C + i] = t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- stride-2 column-walking depthwise 3x3 (PatchMerging.conv2 forward)
 // thread = (8 channels, one OUTPUT column), walking down the output rows: output row oy needs input rows 2oy-1 .. 2oy+1, of which
 // 2oy-1 was the last row of the previous step -> two new input rows x three columns per step (6 x 16-byte loads for a 16-byte
@@ -1226,6 +1339,32 @@ extern "C" int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_in
     const int nc = dw_walk_fused4(C) ? 4 : 8;
     return B * (int)gg_cdiv(W, dw_walk_px(C, nc));
 }
+// fused stride-1 forward (producer BatchNorm + activation on load): 4 output columns x 4 channels per thread
+static const int kDwMultiCols = 4;
+static bool dw_multi_ok(int C) {
+    const int CG = C / 4, PX = std::max(1, 256 / std::max(CG, 1));
+    return (C & 3) == 0 && CG <= 256 && ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float) <= 64 * 1024 && getenv("GG_DW_TILED") == nullptr &&
+           getenv("GG_DW_NO_MULTI") == nullptr;
+}
+static int dw_multi_nbx(int W, int C) { return (int)gg_cdiv(W, std::max(1, 256 / (C / 4)) * kDwMultiCols); }
+/* partial-statistics rows gg_dwconv3x3_fwd_fused writes */
+extern "C" int gg_dwconv_fwd_fused_stat_rows(int B, int H, int W, int C, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    if (stride == 2) return gg_dwconv_stat_rows(B, Ho, Wo, C, 2);
+    if (dw_multi_ok(C)) return B * dw_multi_nbx(W, C);
+    return gg_dwconv_fused_stat_rows(B, H, W, C, 1);
+}
+static int dwconv_multi_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, float* colstats, void* stream, const DwWalkFuse& f) {
+    GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");
+    GG_CHECK(((uintptr_t)wt & 7) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0, "dwconv: operands must be 8-byte aligned");
+    const int CG = C / 4, PX = std::max(1, 256 / CG), nbx = dw_multi_nbx(W, C);
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 4.0 * B * C * (double)H * W, stream);
+    const size_t lds = ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float);
+    hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<kDwMultiCols>), dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream, (const bf16*)x, wt,
+                       (bf16*)y, H, W, C, CG, PX, nbx, colstats, f);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 static int dwconv_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int flip, float* colstats, void* stream,
                               const DwWalkFuse* fuse = nullptr) {
     GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");
@@ -1330,6 +1469,12 @@ extern "C" int gg_dwconv3x3_fwd_fused(const void* x, const float* in_stat, const
                                       const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream) {
     GG_CHECK(x && wt && y && in_stat && in_gamma && in_beta && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2),
              "gg_dwconv3x3_fwd_fused: bad args");
+    if (stride == 1 && dw_multi_ok(C)) {
+        DwWalkFuse wf;
+        memset(&wf, 0, sizeof(wf));
+        wf.in_stat = in_stat; wf.in_gamma = in_gamma; wf.in_beta = in_beta; wf.in_act = in_act;
+        return dwconv_multi_launch(x, wt, y, B, H, W, C, colstats, stream, wf);
+    }
     if (dw_walk_ok(C, stride)) {
         DwWalkFuse wf;
         memset(&wf, 0, sizeof(wf));

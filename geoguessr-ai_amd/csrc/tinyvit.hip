@@ -201,7 +201,7 @@ struct Layout {
 
 static int64_t bn_part_floats(int64_t M, int C, int B, int Ho, int Wo, bool dw) {
     const int rows = dw ? std::max(std::max(gg_dwconv_stat_rows(B, Ho, Wo, C, 1), gg_dwconv_stat_rows(B, Ho, Wo, C, 2)),
-                                   std::max(gg_dwconv_tiled_stat_rows(B, Ho), gg_dwconv_fused_stat_rows(B, Ho, Wo, C, 1)))
+                                   std::max(gg_dwconv_tiled_stat_rows(B, Ho), std::max(gg_dwconv_fused_stat_rows(B, Ho, Wo, C, 1), gg_dwconv_fwd_fused_stat_rows(B, Ho, Wo, C, 1))))
                         : gg_gemm_colstats_rows((int)M);
     return (int64_t)gg_stat_rows_capacity(rows) * 2 * C;
 }
@@ -343,6 +343,8 @@ struct Exec {
     // the stride-2 depthwise conv of PatchMerging stages its input tile in LDS: BatchNorm1 + GELU are applied once per staged element
     // (17x17 inputs per 8x8 outputs = 1.13x), the apply pass and the activation tensor disappear
     bool fuse_dw_s2 = getenv("GG_NO_FUSE_DW_S2") == nullptr;
+    // MBConv.conv2 likewise through the 4-columns-per-thread stride-1 kernel (1.5 BatchNorm+GELU evaluations per input element)
+    bool fuse_dw_s1 = getenv("GG_NO_FUSE_DW_S1") == nullptr;
     // Frozen depthwise taps: the data gradient forms BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) while it loads its
     // input, and (MBConv) emits dz = da*act'(BN(y)) + the reduce sums of the ConvNorm in front: apply and reduce passes and
     // the dy / da tensors disappear.  GG_NO_FUSE_BNBWD=1 / GG_NO_FUSE_BNBWD_EPI=1 restore the separate passes.
@@ -437,7 +439,7 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
                                   c.w.C, stride, part, e.st));
-    return bn_stats(e, c.bn, a, stride == 1 ? gg_dwconv_fused_stat_rows(B, Ho, Wo, c.w.C, 1) : gg_dwconv_stat_rows(B, Ho, Wo, c.w.C, 2), (int64_t)B * Ho * Wo);
+    return bn_stats(e, c.bn, a, gg_dwconv_fwd_fused_stat_rows(B, H, W, c.w.C, stride), (int64_t)B * Ho * Wo);
 }
 static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
                     const float* rowscale = nullptr, int rps = 0) {
@@ -470,7 +472,7 @@ static int forward_impl(Exec& e, const float* x, float* out) {
     for (size_t i = 0; i < m.mb.size(); ++i) {
         const MBConvL& l = m.mb[i]; const MBAct& a = L.mb[i];
         GG_TRY(conv_dense_fwd(e, l.c1, a.c1, e.A(a.x), d[0], M0));
-        if (e.fuse_dw) {
+        if (e.fuse_dw || e.fuse_dw_s1) {
             GG_TRY(conv_dw_fwd_fused(e, l.c2, a.c2, l.c1.bn, a.c1, GG_ACT_GELU, B, H0, H0, 1));   // act1 is never materialised
         } else {
             GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
@@ -819,7 +821,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
             GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                // dy2 -> t_a
             if (e.tr(l.c2.w.t_w)) {
-                if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
+                if (e.fuse_dw || e.fuse_dw_s1) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
                 GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
             }
             GG_TRY(gg_dwconv3x3_bwd_data_fused(t_a, nullptr, nullptr, e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y), e.F(a.c1.stat),
@@ -836,7 +838,7 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (e.tr(l.c2.w.t_w) || !e.fuse_bnbwd || !e.fuse_bnbwd_epi) {
             GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy2 -> t_a
             if (e.tr(l.c2.w.t_w)) {
-                if (e.fuse_dw) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));             // act1 was fused away in forward
+                if (e.fuse_dw || e.fuse_dw_s1) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));             // act1 was fused away in forward
                 GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
             }
             GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));           // da1 -> t_c

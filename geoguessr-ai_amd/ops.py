@@ -196,7 +196,7 @@ def dwconv3x3_fwd_fused(y_in, stat, gamma, beta, taps, act="gelu", stride=2, col
     y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=y_in.device)
     stats = None
     if colstats:
-        rows = L.lib().gg_dwconv_fused_stat_rows(B, Ho, Wo, Cc, 1) if stride == 1 else L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, 2)
+        rows = L.lib().gg_dwconv_fwd_fused_stat_rows(B, H, W, Cc, stride)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=y_in.device)[:rows]
     L.check(L.lib().gg_dwconv3x3_fwd_fused(_p(y_in, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(taps, F32), _p(y), B, H, W,
                                            Cc, stride, _p(stats), L.stream()), "gg_dwconv3x3_fwd_fused")

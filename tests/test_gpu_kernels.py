@@ -300,10 +300,12 @@ def test_dwconv(ops, C, stride, H):
     close(dw, wr.grad, rtol=1e-3, atol=1e-2, what="dwconv wgrad")
 
 
-@pytest.mark.parametrize("C,H,act", [(192, 28, "gelu"), (48, 15, "gelu"), (384, 14, None)])
-def test_dwconv_stride2_with_batchnorm_gelu_on_load(ops, C, H, act):
-    """PatchMerging.conv2 over GELU(BN1(y1)) formed while loading == BatchNorm-apply pass + plain stride-2 depthwise conv (same bf16
-    rounding of the activation), including the BatchNorm partial statistics of the result; odd sizes exercise the padding masks."""
+@pytest.mark.parametrize("C,H,act,stride", [(192, 28, "gelu", 2), (48, 15, "gelu", 2), (384, 14, None, 2),
+                                            (384, 14, "gelu", 1), (16, 13, "gelu", 1), (40, 7, None, 1), (96, 30, "gelu", 1)])
+def test_dwconv_with_batchnorm_gelu_on_load(ops, C, H, act, stride):
+    """PatchMerging.conv2 (stride 2) / MBConv.conv2 (stride 1) over GELU(BN1(y1)) formed while loading == BatchNorm-apply pass + plain
+    depthwise conv (same bf16 rounding of the activation), including the BatchNorm partial statistics of the result; odd sizes and
+    widths that are not a multiple of the 4 columns a thread owns exercise the padding and tail masks."""
     B = 3
     y1 = dev(rnd(B, H, H, C, seed=50, scale=1.5), BF)
     mean, var = rnd(C, seed=51, scale=0.4), rnd(C, seed=52).abs() + 0.5
@@ -311,12 +313,12 @@ def test_dwconv_stride2_with_batchnorm_gelu_on_load(ops, C, H, act):
     gamma, beta = dev(rnd(C, seed=53) + 1.0), dev(rnd(C, seed=54, scale=0.3))
     taps = dev(rnd(9, C, seed=55, scale=0.4))
     a1 = ops.bn_apply(y1.view(-1, C), stat, gamma, beta, act=act).view(B, H, H, C)
-    want, wstats = ops.dwconv3x3_fwd(a1, taps, stride=2, colstats=True)
-    got, gstats = ops.dwconv3x3_fwd_fused(y1, stat, gamma, beta, taps, act=act, stride=2, colstats=True)
-    close(got, want.float(), rtol=1e-2, atol=1e-2, what="fused stride-2 dwconv")
-    close(gstats.sum(0), wstats.sum(0).cpu(), rtol=2e-3, atol=5e-2, what="fused stride-2 dwconv statistics")
-    ref = F.conv2d(a1.float().cpu().permute(0, 3, 1, 2), taps.cpu().t().reshape(C, 1, 3, 3), None, 2, 1, 1, C)
-    close(got.permute(0, 3, 1, 2), ref, what="fused stride-2 dwconv vs conv2d")
+    want, wstats = ops.dwconv3x3_fwd(a1, taps, stride=stride, colstats=True)
+    got, gstats = ops.dwconv3x3_fwd_fused(y1, stat, gamma, beta, taps, act=act, stride=stride, colstats=True)
+    close(got, want.float(), rtol=1e-2, atol=1e-2, what="fused dwconv")
+    close(gstats.sum(0), wstats.sum(0).cpu(), rtol=2e-3, atol=5e-2, what="fused dwconv statistics")
+    ref = F.conv2d(a1.float().cpu().permute(0, 3, 1, 2), taps.cpu().t().reshape(C, 1, 3, 3), None, stride, 1, 1, C)
+    close(got.permute(0, 3, 1, 2), ref, what="fused dwconv vs conv2d")
 
 
 # ------------------------------------------------------------------------------------------- norms
