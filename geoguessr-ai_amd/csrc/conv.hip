@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
 // contain it (the IN = 1 variant of the kernel above: 2.6 ms against 1.24 + 1.0 ms for plain conv + apply pass).  Here a thread owns
 // NCOL adjacent columns x 4 channels: NCOL + 2 loads and transforms per row step for NCOL results -- 1.5 evaluations per element at
 // NCOL = 4 -- and the apply pass with its 2 x [M, C] of traffic disappears.  Forward only; statistics as in the other walkers.
-template <int NCOL>
+template <int NCOL, bool IN1 = true>
 __global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
                                                                     int H, int W, int C, int CG, int PX, int nbx, float* __restrict__ colstats,
                                                                     DwWalkFuse f) {
@@ -426,18 +426,22 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* 
     const int bx = bid % nbx, b = bid / nbx;
     const int x0 = (bx * PX + px) * NCOL;       // first output column of this thread
     const int c0 = cg * 4;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const float sc = f.in_stat[C + c] * f.in_gamma[c];
-        ctab[c] = sc; ctab[C + c] = f.in_beta[c] - f.in_stat[c] * sc;
+    if (IN1) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float sc = f.in_stat[C + c] * f.in_gamma[c];
+            ctab[c] = sc; ctab[C + c] = f.in_beta[c] - f.in_stat[c] * sc;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     f32x2 tap[9][NQ], isc[NQ], ish[NQ];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) tap[t][q] = *reinterpret_cast<const f32x2*>(wt + t * C + c0 + 2 * q);
+    if (IN1) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { isc[q] = *reinterpret_cast<const f32x2*>(ctab + c0 + 2 * q); ish[q] = *reinterpret_cast<const f32x2*>(ctab + C + c0 + 2 * q); }
+        for (int q = 0; q < NQ; ++q) { isc[q] = *reinterpret_cast<const f32x2*>(ctab + c0 + 2 * q); ish[q] = *reinterpret_cast<const f32x2*>(ctab + C + c0 + 2 * q); }
+    }
     const bool in_gelu = f.in_act == GG_ACT_GELU;
     const int64_t img = (int64_t)b * H * W * C;
     const unsigned long long xa = (unsigned long long)(x + img);
@@ -463,8 +467,12 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* 
         for (int k = 0; k < NW; ++k)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const f32x2 a = dw_unpack2(dw_pack2(gg_act_v2(dw_unpack2(raw[k][q]) * isc[q] + ish[q], in_gelu)));
-                slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? a : (f32x2)(0.f);
+                if (IN1) {
+                    const f32x2 a = dw_unpack2(dw_pack2(gg_act_v2(dw_unpack2(raw[k][q]) * isc[q] + ish[q], in_gelu)));
+                    slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? a : (f32x2)(0.f);
+                } else {
+                    slot[k][q] = dw_unpack2(raw[k][q]);
+                }
             }
     };
     f32x2 win[3][NW][NQ];
@@ -1302,6 +1310,15 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
 static int dw_walk_px(int C, int nc = 8) { return std::max(1, 256 / (C / nc)); }
 static bool dw_walk_ok(int C, int stride) { return stride == 1 && (C / 8) <= 256 && getenv("GG_DW_TILED") == nullptr; }
 static bool dw_walk_fused4(int C) { return (C / 4) <= 256; }       // both fusions at once run 4 channels per thread
+// fused stride-1 forward (producer BatchNorm + activation on load): 4 output columns x 4 channels per thread
+static const int kDwMultiCols = 4;
+static bool dw_multi_ok(int C) {
+    const int CG = C / 4, PX = std::max(1, 256 / std::max(CG, 1));
+    return (C & 3) == 0 && CG <= 256 && ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float) <= 64 * 1024 && getenv("GG_DW_TILED") == nullptr &&
+           getenv("GG_DW_NO_MULTI") == nullptr;
+}
+static bool dw_multi_plain(int C) { return getenv("GG_DW_NO_MULTI_PLAIN") == nullptr && dw_multi_ok(C); }      // the plain stride-1 forward too: half the loads per result (-8..15 % on 14x14 / 28x28 maps)
+static int dw_multi_nbx(int W, int C) { return (int)gg_cdiv(W, std::max(1, 256 / (C / 4)) * kDwMultiCols); }
 // stride-2 forward: the walking kernel when its per-thread state fits (8 channels per thread, <= 256 channel groups) and the image fits the
 // 30-bit offsets; GG_DW_TILED keeps the LDS-tiled kernel
 static bool dw_s2_walk_ok(int C) { return (C / 8) <= 256 && (C & 7) == 0 && getenv("GG_DW_TILED") == nullptr && getenv("GG_DW_S2_TILED") == nullptr; }
@@ -1327,6 +1344,7 @@ static int dwconv_s2_walk_launch(const void* x, const float* wt, void* y, int B,
     return 0;
 }
 extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride) {
+    if (stride == 1 && dw_multi_plain(C)) return B * dw_multi_nbx(Wo, C);
     if (stride == 2 && dw_s2_walk_ok(C)) return B * (int)gg_cdiv(Wo, dw_walk_px(C, 8));
     if (dw_walk_ok(C, stride)) return B * (int)gg_cdiv(Wo, dw_walk_px(C));
     return B * (int)gg_cdiv(Ho, 8);
@@ -1339,14 +1357,6 @@ extern "C" int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_in
     const int nc = dw_walk_fused4(C) ? 4 : 8;
     return B * (int)gg_cdiv(W, dw_walk_px(C, nc));
 }
-// fused stride-1 forward (producer BatchNorm + activation on load): 4 output columns x 4 channels per thread
-static const int kDwMultiCols = 4;
-static bool dw_multi_ok(int C) {
-    const int CG = C / 4, PX = std::max(1, 256 / std::max(CG, 1));
-    return (C & 3) == 0 && CG <= 256 && ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float) <= 64 * 1024 && getenv("GG_DW_TILED") == nullptr &&
-           getenv("GG_DW_NO_MULTI") == nullptr;
-}
-static int dw_multi_nbx(int W, int C) { return (int)gg_cdiv(W, std::max(1, 256 / (C / 4)) * kDwMultiCols); }
 /* partial-statistics rows gg_dwconv3x3_fwd_fused writes */
 extern "C" int gg_dwconv_fwd_fused_stat_rows(int B, int H, int W, int C, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -1360,8 +1370,10 @@ static int dwconv_multi_launch(const void* x, const float* wt, void* y, int B, i
     const int CG = C / 4, PX = std::max(1, 256 / CG), nbx = dw_multi_nbx(W, C);
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 4.0 * B * C * (double)H * W, stream);
     const size_t lds = ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float);
-    hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<kDwMultiCols>), dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream, (const bf16*)x, wt,
-                       (bf16*)y, H, W, C, CG, PX, nbx, colstats, f);
+    if (f.in_stat) hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<kDwMultiCols, true>), dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream,
+                                      (const bf16*)x, wt, (bf16*)y, H, W, C, CG, PX, nbx, colstats, f);
+    else hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<kDwMultiCols, false>), dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream,
+                            (const bf16*)x, wt, (bf16*)y, H, W, C, CG, PX, nbx, colstats, f);
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -1460,6 +1472,7 @@ static int dwconv_tiled_launch(const void* x, const float* wt, void* y, int B, i
 extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats,
                                 void* stream) {
     GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
+    if (stride == 1 && dw_multi_plain(C)) { DwWalkFuse wf; memset(&wf, 0, sizeof(wf)); return dwconv_multi_launch(x, wt, y, B, H, W, C, colstats, stream, wf); }
     if (dw_walk_ok(C, stride)) return dwconv_walk_launch(x, wt, y, B, H, W, C, 0, colstats, stream);
     if (stride == 2 && dw_s2_walk_ok(C)) return dwconv_s2_walk_launch(x, wt, y, B, H, W, C, colstats, stream, nullptr);
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, nullptr, nullptr, nullptr, 0, colstats, stream);
