@@ -413,41 +413,61 @@ __global__ __launch_bounds__(256, NQ == 4 ? 2 : 3) void dwconv3x3_walk_kernel(co
 // contain it (the IN = 1 variant of the kernel above: 2.6 ms against 1.24 + 1.0 ms for plain conv + apply pass).  Here a thread owns
 // NCOL adjacent columns x 4 channels: NCOL + 2 loads and transforms per row step for NCOL results -- 1.5 evaluations per element at
 // NCOL = 4 -- and the apply pass with its 2 x [M, C] of traffic disappears.  Forward only; statistics as in the other walkers.
-template <int NCOL, bool IN1 = true>
+// IN = 0 plain / 1 producer BatchNorm + activation (forward) / 2 BatchNorm-backward apply of (x, in2) (data gradient); EPI: the stored value
+// is acc * act'(BN(ep_y)) and the statistics are (sum dz, sum dz*xhat) -- the same fusions as dwconv3x3_walk_kernel, whose stride-1 uses
+// this kernel takes over: every per-element transform on the way in runs 1.5 instead of 3 times, and a result costs 1.5 instead of 3 loads.
+// `flip` reverses the taps (data gradient).  Per-channel coefficients live in registers (4 channels per thread).
+template <int NCOL, int IN, bool EPI>
 __global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* __restrict__ x, const float* __restrict__ wt, bf16* __restrict__ y,
-                                                                    int H, int W, int C, int CG, int PX, int nbx, float* __restrict__ colstats,
-                                                                    DwWalkFuse f) {
+                                                                    int H, int W, int C, int CG, int PX, int nbx, int flip,
+                                                                    float* __restrict__ colstats, DwWalkFuse f) {
+    constexpr bool IN1 = IN == 1, IN2 = IN == 2;
     constexpr int NQ = 2, NW = NCOL + 2;
     typedef DwRaw<NQ>::T Raw;
-    extern __shared__ float dwm_red[];          // [PX][2][C] statistics scratch, then scale / shift rows [2][C]
-    float* ctab = dwm_red + PX * 2 * C;
+    typedef typename DwWin<IN2>::E WinE;        // IN2: the packed bf16 pair the unfused path would have stored in dy
+    extern __shared__ float dwm_red[];          // [PX][2][C] statistics scratch
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
     const int bid = gg_xcd_remap(blockIdx.x, gridDim.x);
     const int bx = bid % nbx, b = bid / nbx;
     const int x0 = (bx * PX + px) * NCOL;       // first output column of this thread
     const int c0 = cg * 4;
-    if (IN1) {
-        for (int c = threadIdx.x; c < C; c += blockDim.x) {
-            const float sc = f.in_stat[C + c] * f.in_gamma[c];
-            ctab[c] = sc; ctab[C + c] = f.in_beta[c] - f.in_stat[c] * sc;
-        }
-        __syncthreads();
-    }
-    f32x2 tap[9][NQ], isc[NQ], ish[NQ];
+    f32x2 tap[9][NQ];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) tap[t][q] = *reinterpret_cast<const f32x2*>(wt + t * C + c0 + 2 * q);
-    if (IN1) {
+        for (int q = 0; q < NQ; ++q) tap[t][q] = *reinterpret_cast<const f32x2*>(wt + (flip ? 8 - t : t) * C + c0 + 2 * q);
+    f32x2 ia[NQ], ib[NQ], ic[NQ];               // IN1: scale, shift;  IN2: coef a, b, c
+    f32x2 esc[NQ], esh[NQ], ers[NQ], emr[NQ];   // EPI: scale, shift, rstd, -mean*rstd
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { isc[q] = *reinterpret_cast<const f32x2*>(ctab + c0 + 2 * q); ish[q] = *reinterpret_cast<const f32x2*>(ctab + C + c0 + 2 * q); }
+    for (int q = 0; q < NQ; ++q) {
+        const int c = c0 + 2 * q;
+        if (IN1) {
+            const f32x2 rs_ = *reinterpret_cast<const f32x2*>(f.in_stat + C + c), mu = *reinterpret_cast<const f32x2*>(f.in_stat + c);
+            ia[q] = rs_ * *reinterpret_cast<const f32x2*>(f.in_gamma + c);
+            ib[q] = *reinterpret_cast<const f32x2*>(f.in_beta + c) - mu * ia[q];
+        }
+        if (IN2) {
+            ia[q] = *reinterpret_cast<const f32x2*>(f.in_coef + c); ib[q] = *reinterpret_cast<const f32x2*>(f.in_coef + C + c);
+            ic[q] = *reinterpret_cast<const f32x2*>(f.in_coef + 2 * C + c);
+        }
+        if (EPI) {
+            const f32x2 mu = *reinterpret_cast<const f32x2*>(f.ep_stat + c), rstd = *reinterpret_cast<const f32x2*>(f.ep_stat + C + c);
+            esc[q] = rstd * *reinterpret_cast<const f32x2*>(f.ep_gamma + c);
+            esh[q] = *reinterpret_cast<const f32x2*>(f.ep_beta + c) - mu * esc[q];
+            ers[q] = rstd; emr[q] = (f32x2)(0.f) - mu * rstd;
+        }
     }
-    const bool in_gelu = f.in_act == GG_ACT_GELU;
+    const bool in_gelu = f.in_act == GG_ACT_GELU, ep_gelu = f.ep_act == GG_ACT_GELU;
     const int64_t img = (int64_t)b * H * W * C;
-    const unsigned long long xa = (unsigned long long)(x + img);
-    const unsigned xlo = __builtin_amdgcn_readfirstlane((unsigned)xa), xhi = __builtin_amdgcn_readfirstlane((unsigned)(xa >> 32));   // block-uniform: descriptor in SGPRs
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)xhi << 32) | xlo), 0,
-                                                                        __builtin_amdgcn_readfirstlane(H * W * C * 2), 0x00020000);
+    auto uniform_ptr = [](const bf16* ptr) {    // block-uniform bases: descriptors in SGPRs
+        const unsigned long long a = (unsigned long long)ptr;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (void*)(((unsigned long long)hi << 32) | lo);
+    };
+    const int img_bytes = __builtin_amdgcn_readfirstlane(H * W * C * 2);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(x + img), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((IN2 ? f.in2 : x) + img), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rse = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((EPI ? f.ep_y : x) + img), 0, img_bytes, 0x00020000);
     unsigned colo[NW];
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
@@ -455,43 +475,60 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* 
         colo[k] = (ix >= 0 && ix < W) ? (unsigned)(ix * C + c0) * 2u : DW_COL_OOB;
     }
     const unsigned rowb = (unsigned)W * C * 2u;
-    auto load_row = [&](int iy, Raw (&raw)[NW]) {
+    auto load_row = [&](int iy, Raw (&raw)[NW], Raw (&raw2)[NW]) {
         const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) raw[k] = DwRaw<NQ>::load(rs, (int)(colo[k] + ro));
+        for (int k = 0; k < NW; ++k) {
+            raw[k] = DwRaw<NQ>::load(rs, (int)(colo[k] + ro));
+            if (IN2) raw2[k] = DwRaw<NQ>::load(rs2, (int)(colo[k] + ro));
+        }
     };
-    // raw row -> window slot: act(BN(.)) once per loaded element, bf16-rounded like the activation tensor the apply pass would store
-    auto fill = [&](int iy, const Raw (&raw)[NW], f32x2 (&slot)[NW][NQ]) {
+    auto load_ep = [&](int iy, Raw (&er)[NCOL]) {
+        const unsigned ro = (iy >= 0 && iy < H) ? (unsigned)iy * rowb : DW_ROW_OOB;
+#pragma unroll
+        for (int j = 0; j < NCOL; ++j) er[j] = DwRaw<NQ>::load(rse, (int)(colo[j + 1] + ro));
+    };
+    // raw row -> window slot; the transform runs once per loaded element; positions outside the image stay exactly 0
+    auto fill = [&](int iy, const Raw (&raw)[NW], const Raw (&raw2)[NW], WinE (&slot)[NW][NQ]) {
         const bool rok = iy >= 0 && iy < H;
 #pragma unroll
         for (int k = 0; k < NW; ++k)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                if (IN1) {
-                    const f32x2 a = dw_unpack2(dw_pack2(gg_act_v2(dw_unpack2(raw[k][q]) * isc[q] + ish[q], in_gelu)));
+                if constexpr (IN1) {
+                    const f32x2 a = dw_unpack2(dw_pack2(gg_act_v2(dw_unpack2(raw[k][q]) * ia[q] + ib[q], in_gelu)));
                     slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? a : (f32x2)(0.f);
+                } else if constexpr (IN2) {
+                    const f32x2 r = ia[q] * dw_unpack2(raw[k][q]) + (ib[q] * dw_unpack2(raw2[k][q]) + ic[q]);
+                    slot[k][q] = (rok && colo[k] != DW_COL_OOB) ? dw_pack2(r) : 0u;
                 } else {
                     slot[k][q] = dw_unpack2(raw[k][q]);
                 }
             }
     };
-    f32x2 win[3][NW][NQ];
-    Raw raw[NW];
+    WinE win[3][NW][NQ];
+    Raw raw[NW], raw2[NW], eraw[NCOL];
 #pragma unroll
     for (int k = 0; k < NW; ++k)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) win[0][k][q] = (f32x2)(0.f);      // row -1
-    load_row(0, raw);
-    fill(0, raw, win[1]);
-    load_row(1, raw);
+        for (int q = 0; q < NQ; ++q) win[0][k][q] = DwWin<IN2>::zero();      // row -1
+    load_row(0, raw, raw2);
+    fill(0, raw, raw2, win[1]);
+    load_row(1, raw, raw2);
+    if (EPI) load_ep(0, eraw);
     f32x2 s2[NQ], q2[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) s2[q] = q2[q] = (f32x2)(0.f);
     bf16* yb = y + img + (int64_t)x0 * C + c0;
 #define GG_DWM_STEP(RA, RB, RC, yy)                                                                                        \
     {                                                                                                                      \
-        fill((yy) + 1, raw, win[RC]);                                                                                      \
-        load_row((yy) + 2, raw);                                                                                           \
+        fill((yy) + 1, raw, raw2, win[RC]);                                                                                \
+        load_row((yy) + 2, raw, raw2);                                                                                     \
+        Raw ecur[NCOL];                                                                                                    \
+        if (EPI) {                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < NCOL; ++j) ecur[j] = eraw[j];                                            \
+            load_ep((yy) + 1, eraw);                                                                                       \
+        }                                                                                                                  \
         _Pragma("unroll") for (int j = 0; j < NCOL; ++j) {                                                                 \
             const bool live = (yy) < H && x0 + j < W;                                                                      \
             Raw o;                                                                                                         \
@@ -499,11 +536,18 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_s1_multi_kernel(const bf16* 
                 f32x2 a = (f32x2)(0.f);                                                                                    \
                 _Pragma("unroll") for (int t = 0; t < 9; ++t) {                                                            \
                     const int rsl = t < 3 ? RA : (t < 6 ? RB : RC);                                                        \
-                    a = win[rsl][j + t % 3][q] * tap[t][q] + a;                                                            \
+                    a = DwWin<IN2>::get(win[rsl][j + t % 3][q]) * tap[t][q] + a;                                           \
                 }                                                                                                          \
-                o[q] = dw_pack2(a);                                                                                        \
-                const f32x2 r = live ? dw_unpack2(o[q]) : (f32x2)(0.f);                                                    \
-                s2[q] += r; q2[q] += r * r;                                                                                \
+                if (EPI) {                                                                                                 \
+                    const f32x2 yv = dw_unpack2(ecur[j][q]);                                                               \
+                    o[q] = dw_pack2(a * gg_act_grad_v2(yv * esc[q] + esh[q], ep_gelu));                                    \
+                    const f32x2 r = live ? dw_unpack2(o[q]) : (f32x2)(0.f);                                                \
+                    s2[q] += r; q2[q] += r * (yv * ers[q] + emr[q]);                                                       \
+                } else {                                                                                                   \
+                    o[q] = dw_pack2(a);                                                                                    \
+                    const f32x2 r = live ? dw_unpack2(o[q]) : (f32x2)(0.f);                                                \
+                    s2[q] += r; q2[q] += r * r;                                                                            \
+                }                                                                                                          \
             }                                                                                                              \
             if (live) *reinterpret_cast<Raw*>(yb + ((int64_t)(yy) * W + j) * C) = o;                                       \
         }                                                                                                                  \
@@ -1314,11 +1358,13 @@ static bool dw_walk_fused4(int C) { return (C / 4) <= 256; }       // both fusio
 static const int kDwMultiCols = 4;
 static bool dw_multi_ok(int C) {
     const int CG = C / 4, PX = std::max(1, 256 / std::max(CG, 1));
-    return (C & 3) == 0 && CG <= 256 && ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float) <= 64 * 1024 && getenv("GG_DW_TILED") == nullptr &&
+    return (C & 3) == 0 && CG <= 256 && (size_t)PX * 2 * C * sizeof(float) <= 64 * 1024 && getenv("GG_DW_TILED") == nullptr &&
            getenv("GG_DW_NO_MULTI") == nullptr;
 }
 static bool dw_multi_plain(int C) { return getenv("GG_DW_NO_MULTI_PLAIN") == nullptr && dw_multi_ok(C); }      // the plain stride-1 forward too: half the loads per result (-8..15 % on 14x14 / 28x28 maps)
-static int dw_multi_nbx(int W, int C) { return (int)gg_cdiv(W, std::max(1, 256 / (C / 4)) * kDwMultiCols); }
+static bool dw_multi_bwd(int C) { return getenv("GG_DW_NO_MULTI_BWD") == nullptr && dw_multi_ok(C); }          // stride-1 data gradients (plain and fused)
+static const int kDwMultiColsEpi = 2;       // variants with the act'(BN) epilogue: 2 columns per thread (4 spill at 256 registers)
+static int dw_multi_nbx(int W, int C, int ncol = kDwMultiCols) { return (int)gg_cdiv(W, std::max(1, 256 / (C / 4)) * ncol); }
 // stride-2 forward: the walking kernel when its per-thread state fits (8 channels per thread, <= 256 channel groups) and the image fits the
 // 30-bit offsets; GG_DW_TILED keeps the LDS-tiled kernel
 static bool dw_s2_walk_ok(int C) { return (C / 8) <= 256 && (C & 7) == 0 && getenv("GG_DW_TILED") == nullptr && getenv("GG_DW_S2_TILED") == nullptr; }
@@ -1352,6 +1398,7 @@ extern "C" int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride) {
 extern "C" int gg_dwconv_tiled_stat_rows(int B, int Ho) { return B * (int)gg_cdiv(Ho, 8); }
 /* rows written by gg_dwconv3x3_bwd_data_fused with an output-side fusion */
 extern "C" int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_input_fusion) {
+    if (dw_multi_bwd(C)) return B * dw_multi_nbx(W, C, kDwMultiColsEpi);
     if (!dw_walk_ok(C, 1)) return B * (int)gg_cdiv(H, 8);
     (void)with_input_fusion;
     const int nc = dw_walk_fused4(C) ? 4 : 8;
@@ -1364,16 +1411,24 @@ extern "C" int gg_dwconv_fwd_fused_stat_rows(int B, int H, int W, int C, int str
     if (dw_multi_ok(C)) return B * dw_multi_nbx(W, C);
     return gg_dwconv_fused_stat_rows(B, H, W, C, 1);
 }
-static int dwconv_multi_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, float* colstats, void* stream, const DwWalkFuse& f) {
+static int dwconv_multi_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, int flip, float* colstats, void* stream,
+                               const DwWalkFuse& f) {
     GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");
     GG_CHECK(((uintptr_t)wt & 7) == 0 && ((uintptr_t)x & 7) == 0 && ((uintptr_t)y & 7) == 0, "dwconv: operands must be 8-byte aligned");
-    const int CG = C / 4, PX = std::max(1, 256 / CG), nbx = dw_multi_nbx(W, C);
-    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 4.0 * B * C * (double)H * W, stream);
-    const size_t lds = ((size_t)PX * 2 * C + 2 * (size_t)C) * sizeof(float);
-    if (f.in_stat) hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<kDwMultiCols, true>), dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream,
-                                      (const bf16*)x, wt, (bf16*)y, H, W, C, CG, PX, nbx, colstats, f);
-    else hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<kDwMultiCols, false>), dim3((unsigned)(B * nbx)), dim3(CG * PX), lds, (hipStream_t)stream,
-                            (const bf16*)x, wt, (bf16*)y, H, W, C, CG, PX, nbx, colstats, f);
+    const bool in1 = f.in_stat != nullptr, in2 = f.in_coef != nullptr, epi = f.ep_y != nullptr;
+    GG_CHECK(!(in1 && (in2 || epi)), "dwconv: producer fusion excludes the backward fusions");
+    const int CG = C / 4, PX = std::max(1, 256 / CG), nbx = dw_multi_nbx(W, C, epi ? kDwMultiColsEpi : kDwMultiCols);
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 2.0 * B * C * (double)H * W * (2 + in2 + epi), stream);
+    const size_t lds = (size_t)PX * 2 * C * sizeof(float);
+    const dim3 grid((unsigned)(B * nbx)), block(CG * PX);
+#define GG_DWM(N_, I_, E_) hipLaunchKernelGGL((dwconv3x3_s1_multi_kernel<N_, I_, E_>), grid, block, lds, (hipStream_t)stream, (const bf16*)x, wt, \
+                                              (bf16*)y, H, W, C, CG, PX, nbx, flip, colstats, f)
+    if (in1) GG_DWM(kDwMultiCols, 1, false);
+    else if (in2 && epi) GG_DWM(kDwMultiColsEpi, 2, true);
+    else if (in2) GG_DWM(kDwMultiCols, 2, false);
+    else if (epi) GG_DWM(kDwMultiColsEpi, 0, true);
+    else GG_DWM(kDwMultiCols, 0, false);
+#undef GG_DWM
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -1472,7 +1527,7 @@ static int dwconv_tiled_launch(const void* x, const float* wt, void* y, int B, i
 extern "C" int gg_dwconv3x3_fwd(const void* x, const float* wt, void* y, int B, int H, int W, int C, int stride, float* colstats,
                                 void* stream) {
     GG_CHECK(x && wt && y && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd: bad args");
-    if (stride == 1 && dw_multi_plain(C)) { DwWalkFuse wf; memset(&wf, 0, sizeof(wf)); return dwconv_multi_launch(x, wt, y, B, H, W, C, colstats, stream, wf); }
+    if (stride == 1 && dw_multi_plain(C)) { DwWalkFuse wf; memset(&wf, 0, sizeof(wf)); return dwconv_multi_launch(x, wt, y, B, H, W, C, 0, colstats, stream, wf); }
     if (dw_walk_ok(C, stride)) return dwconv_walk_launch(x, wt, y, B, H, W, C, 0, colstats, stream);
     if (stride == 2 && dw_s2_walk_ok(C)) return dwconv_s2_walk_launch(x, wt, y, B, H, W, C, colstats, stream, nullptr);
     return dwconv_tiled_launch(x, wt, y, B, H, W, C, stride, 0, nullptr, nullptr, nullptr, 0, colstats, stream);
@@ -1486,7 +1541,7 @@ extern "C" int gg_dwconv3x3_fwd_fused(const void* x, const float* in_stat, const
         DwWalkFuse wf;
         memset(&wf, 0, sizeof(wf));
         wf.in_stat = in_stat; wf.in_gamma = in_gamma; wf.in_beta = in_beta; wf.in_act = in_act;
-        return dwconv_multi_launch(x, wt, y, B, H, W, C, colstats, stream, wf);
+        return dwconv_multi_launch(x, wt, y, B, H, W, C, 0, colstats, stream, wf);
     }
     if (dw_walk_ok(C, stride)) {
         DwWalkFuse wf;
@@ -1511,6 +1566,13 @@ extern "C" int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, 
     GG_CHECK(dz_in && wt && out && B > 0 && (C & 7) == 0, "gg_dwconv3x3_bwd_data_fused: bad args");
     GG_CHECK(!in_coef || y_in, "gg_dwconv3x3_bwd_data_fused: in_coef needs y_in");
     GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_part), "gg_dwconv3x3_bwd_data_fused: epilogue needs stat/gamma/beta/partials");
+    if (dw_multi_bwd(C)) {
+        DwWalkFuse wf;
+        memset(&wf, 0, sizeof(wf));
+        wf.in2 = in_coef ? (const bf16*)y_in : nullptr; wf.in_coef = in_coef;
+        wf.ep_y = (const bf16*)ep_y; wf.ep_stat = ep_stat; wf.ep_gamma = ep_gamma; wf.ep_beta = ep_beta; wf.ep_act = ep_act;
+        return dwconv_multi_launch(dz_in, wt, out, B, H, W, C, 1, ep_y ? ep_part : nullptr, stream, wf);
+    }
     if (dw_walk_ok(C, 1)) {
         DwWalkFuse wf;
         memset(&wf, 0, sizeof(wf));
@@ -1526,6 +1588,7 @@ extern "C" int gg_dwconv3x3_bwd_data_fused(const void* dz_in, const void* y_in, 
 extern "C" int gg_dwconv3x3_bwd_data(const void* dy, const float* wt, void* dx, int B, int H, int W, int C, int stride, void* stream) {
     GG_CHECK(dy && wt && dx && B > 0 && (C & 7) == 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_data: bad args");
     GG_CHECK((int64_t)B * H * W * (C / 8) < ((int64_t)1 << 32), "gg_dwconv3x3_bwd_data: tensor too large for 32-bit indexing");
+    if (stride == 1 && dw_multi_bwd(C)) { DwWalkFuse wf; memset(&wf, 0, sizeof(wf)); return dwconv_multi_launch(dy, wt, dx, B, H, W, C, 1, nullptr, stream, wf); }
     if (dw_walk_ok(C, stride)) return dwconv_walk_launch(dy, wt, dx, B, H, W, C, 1, nullptr, stream);
     if (stride == 1)     // data gradient of a stride-1 depthwise conv == the same conv with flipped taps
         return dwconv_tiled_launch(dy, wt, dx, B, H, W, C, 1, 1, nullptr, nullptr, nullptr, 0, nullptr, stream);
