@@ -736,7 +736,8 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
                                 int accumulate, void* stream) {
     GG_CHECK(dout && x && mean && rstd && gamma && dx && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_bwd: bad args");
     GG_CHECK(!dgamma || (scratch && dbeta), "gg_layernorm_bwd: parameter grads need scratch + dbeta");
-    const int nb = ln_blocks(M);
+    // with parameter gradients every block ends in a 2*C-column reduction + partial row: fewer, longer-running blocks amortise it
+    const int nb = dgamma ? std::min(ln_blocks(M), 512) : ln_blocks(M);
     GG_PROF(GG_CAT_NORM, 0, (dres ? 8.0 : 6.0) * M * C, stream);
     float* part = dgamma ? scratch : nullptr;
     size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
