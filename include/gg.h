@@ -93,7 +93,7 @@ int gg_col2im_nhwc_bnbwd_bf16(const void* dcol, const void* y, const float* stat
 int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride);   /* partial-statistics rows gg_dwconv3x3_fwd writes */
 int gg_dwconv_tiled_stat_rows(int B, int Ho);                          /* ... the producer-fused forward variant (LDS-tiled kernel) */
 int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_input_fusion);   /* ... the fused data gradient with ep_y */
-int gg_dwconv_fwd_fused_stat_rows(int B, int H, int W, int C, int stride);   /* ... gg_dwconv3x3_fwd_fused (H, W = input size) */
+int gg_dwconv_fwd_fused_stat_rows(int B, int H, int W, int C, int stride);   /* ... the fused forward; H, W = input size */
 int gg_dwconv3x3_fwd(const void* x, const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
 int gg_dwconv3x3_fwd_fused(const void* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act,
                            const float* taps, void* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
