@@ -22,6 +22,7 @@ def L():
 
 def test_header_symbols_exported_and_bound(L):
     hdr = open(os.path.join(ROOT, "include", "gg.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)          # declarations only: comments may mention entry points by name
     declared = set(re.findall(r"\b(gg_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(L.SYMBOLS)
     lib = L.lib()
