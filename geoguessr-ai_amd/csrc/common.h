@@ -49,14 +49,14 @@ static inline int64_t gg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t gg_align(int64_t a, int64_t b) { return gg_cdiv(a, b) * b; }
 
 // ---- device math ---------------------------------------------------------------
-// erf(x/sqrt2) as an odd polynomial u*P(u^2), u = min(|x|/sqrt2, 3) (least-squares Chebyshev fit, degree 17): no
+// erf(x/sqrt2) as an odd polynomial u*P(u^2), u = |x|/sqrt2, fitted on [0, 3] and clamped to 1 on the way out (least-squares Chebyshev fit, degree 17): no
 // transcendental, and the FMAs pair up into v_pk_fma_f32.  |erf error| <= 2.1e-5 (1 - erf(3) = 2.2e-5 is the clamp),
 // i.e. |GELU error| <= 4.4e-5 absolute, 100x below the bf16 resolution every GELU result is stored with.  libm erff
 // and the Abramowitz-Stegun form (rcp + exp) cost 5x / 2.5x more VALU and made the GELU epilogues, not HBM or MFMA,
 // the limiter of the fc1 GEMMs and the BatchNorm+GELU kernels (19 G evaluations per 1024-image step).
 __device__ __forceinline__ float gg_erf_sqrt2(float x) {
-    const float u = fminf(fabsf(x) * 0.70710678118654752f, 3.0f);
-    const float t = u * u;
+    const float u = fabsf(x) * 0.70710678118654752f;      // no clamp on the way in: beyond the fit range the polynomial rises monotonically
+    const float t = u * u;                                // (>= 0.99999 for every u >= 3, +inf on overflow) and the clamp on the way out saturates it
     float p = 3.912539981e-08f;
     p = fmaf(p, t, -1.883036475e-06f);
     p = fmaf(p, t, 4.008835822e-05f);
@@ -87,7 +87,7 @@ __device__ __forceinline__ f32x2 gg_clamp2(f32x2 x, float a) {
     return (f32x2){__builtin_amdgcn_fmed3f(x.x, -a, a), __builtin_amdgcn_fmed3f(x.y, -a, a)};
 }
 __device__ __forceinline__ f32x2 gg_erf_sqrt2_v2(f32x2 x) {
-    const f32x2 u = gg_clamp2(x * 0.70710678118654752f, 3.0f);
+    const f32x2 u = x * 0.70710678118654752f;             // (input clamp dropped: see gg_erf_sqrt2)
     const f32x2 t = u * u;
     f32x2 p = (f32x2)(3.912539981e-08f);
     p = p * t + (f32x2)(-1.883036475e-06f);
