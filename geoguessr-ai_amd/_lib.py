@@ -34,7 +34,7 @@ class AttnArgs(C.Structure):
                 ("tokens_per_window", C.c_int), ("window_size", C.c_int), ("map_h", C.c_int), ("map_w", C.c_int),
                 ("bias", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("dout", C.c_void_p), ("lddo", C.c_int64), ("dqkv", C.c_void_p), ("dbias", C.c_void_p), ("dbias_scratch", C.c_void_p),
-                ("lse", C.c_void_p)]
+                ("lse", C.c_void_p), ("bias_table", C.c_void_p)]
 
 
 class GeoHeadArgs(C.Structure):
@@ -42,7 +42,7 @@ class GeoHeadArgs(C.Structure):
                 ("centroids", C.c_void_p), ("labels_clf", C.c_void_p), ("mode", C.c_int), ("smoothing_km", C.c_float),
                 ("grad_scale", C.c_float), ("loss_rows", C.c_void_p), ("loss", C.c_void_p), ("dlogits", C.c_void_p),
                 ("ldd", C.c_int64), ("preds", C.c_void_p), ("llh", C.c_void_p), ("topk_vals", C.c_void_p),
-                ("topk_idx", C.c_void_p), ("num_candidates", C.c_int), ("nearest", C.c_void_p)]
+                ("topk_idx", C.c_void_p), ("num_candidates", C.c_int), ("nearest", C.c_void_p), ("dlogits_f32", C.c_int)]
 
 
 class ProtoRefineArgs(C.Structure):
@@ -57,13 +57,15 @@ class TinyVitCfg(C.Structure):
     _fields_ = [("img_size", C.c_int), ("in_chans", C.c_int), ("embed_dims", C.c_int * 4), ("depths", C.c_int * 4),
                 ("num_heads", C.c_int * 4), ("window_sizes", C.c_int * 4), ("mlp_ratio", C.c_float),
                 ("mbconv_expand_ratio", C.c_float), ("bn_eps", C.c_float), ("ln_eps", C.c_float),
-                ("bn_momentum", C.c_float)]
+                ("bn_momentum", C.c_float), ("act_dtype", C.c_int), ("features_only", C.c_int)]
 
 
 class ClipCfg(C.Structure):
     _fields_ = [("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int),
                 ("image_size", C.c_int), ("patch_size", C.c_int), ("ln_eps", C.c_float)]
 
+
+STAGE_DONE_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)      # GgStageDoneFn (host callback of gg_tinyvit_backward)
 
 # every exported symbol of include/gg.h: name -> (restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -122,10 +124,31 @@ SIGNATURES = {
     "gg_attention_expand_bias": (_I, [_P, _I, _I, _F, _P, _P]),
     "gg_attention_fwd": (_I, [C.POINTER(AttnArgs), _P]),
     "gg_attention_bwd": (_I, [C.POINTER(AttnArgs), _P]),
+    "gg_attention_flash_fwd": (_I, [C.POINTER(AttnArgs), _I, _P]),
+    "gg_attention_flash_bwd": (_I, [C.POINTER(AttnArgs), _I, _P]),
+    "gg_attention_flash_dbias_rows": (_L, [_I, _I]),
+    "gg_gemm_nt_f32": (_I, [C.POINTER(GemmArgs), _P]),
+    "gg_gemm_tn_f32_splits": (_I, [_I, _I, _I]),
+    "gg_gemm_tn_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),
+    "gg_colsum_f32": (_I, [_P, _L, _I, _I, _P, _I, _P, _P, _I, _P]),
+    "gg_im2col_nchw3_f32_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "gg_im2col_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "gg_col2im_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "gg_dwconv_f32_stat_rows": (_I, [_I, _I, _I, _I]),
+    "gg_dwconv3x3_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "gg_dwconv3x3_bwd_data_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "gg_dwconv_f32_wgrad_scratch_floats": (_L, [_I, _I, _I, _I, _I]),
+    "gg_dwconv3x3_bwd_weight_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "gg_bn_apply_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P]),
+    "gg_bn_bwd_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "gg_token_mean_fwd_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gg_token_mean_bwd_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gg_view_mean_fwd_f32": (_I, [_P, _P, _L, _I, _I, _I, _P]),
+    "gg_view_mean_bwd_f32": (_I, [_P, _L, _P, _I, _I, _I, _P]),
     "gg_geo_head": (_I, [C.POINTER(GeoHeadArgs), _P]),
     "gg_haversine_matrix": (_I, [_P, _P, _P, _I, _I, _P]),
     "gg_proto_refine": (_I, [C.POINTER(ProtoRefineArgs), _P]),
-    "gg_geoguessr_score": (_I, [_P, _P, _I, _P, _P, _P]),
+    "gg_geoguessr_score": (_I, [_P, _P, _I, _P, _P, _P]),      # (pred, truth, N, double* dist_km, int32* score, stream)
     "gg_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P]),
     "gg_fill_f32": (_I, [_P, _L, _F, _P]),
     "gg_prof_enable": (_I, [_I]),
@@ -146,7 +169,7 @@ SIGNATURES = {
     "gg_preprocess_bilinear": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "gg_segment_mean": (_I, [_P, _L, _P, _P, _I, _I, _P, _P]),
     "gg_tinyvit_forward": (_I, [C.POINTER(TinyVitCfg), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
-    "gg_tinyvit_backward": (_I, [C.POINTER(TinyVitCfg), _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
+    "gg_tinyvit_backward": (_I, [C.POINTER(TinyVitCfg), _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P, STAGE_DONE_FN, _P]),
     "gg_tinyvit_activation_info": (_I, [C.POINTER(TinyVitCfg), _I, C.c_char_p, C.POINTER(_L), C.POINTER(_L)]),
     "gg_clip_num_tensors": (_I, [C.POINTER(ClipCfg)]),
     "gg_clip_tensor_info": (_I, [C.POINTER(ClipCfg), _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I),

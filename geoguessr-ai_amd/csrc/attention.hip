@@ -906,7 +906,14 @@ extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int w
     return 0;
 }
 
+// beyond 256 tokens per window (tiny_vit_21m_384 / _512 stage 2, CLIP ViT-L/14-336) a score row no longer fits a wave's registers:
+// those shapes run on the online-softmax kernels of attention_flash.hip (bias from the compact f32 table)
+static bool attn_use_flash(const GgAttnArgs* a) { return a && (a->tokens_per_window > 256 || a->window_size > 16); }
 extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
+    if (attn_use_flash(a)) {
+        GG_CHECK(!a->bias || a->bias_table, "gg_attention_fwd: windows of more than 256 tokens take the bias as bias_table (compact f32)");
+        return gg_attention_flash_fwd(a, 0, stream);
+    }
     AttnParams p;
     GG_TRY(attn_fill(p, a, "gg_attention_fwd"));
     GG_CHECK(a->out && (a->ldo & 3) == 0, "gg_attention_fwd: bad out");
@@ -933,6 +940,10 @@ extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
     return 0;
 }
 extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
+    if (attn_use_flash(a)) {
+        GG_CHECK(!a->bias || a->bias_table, "gg_attention_bwd: windows of more than 256 tokens take the bias as bias_table (compact f32)");
+        return gg_attention_flash_bwd(a, 0, stream);
+    }
     AttnParams p;
     GG_TRY(attn_fill(p, a, "gg_attention_bwd"));
     GG_CHECK(a->dout && a->dqkv && (a->lddo & 7) == 0, "gg_attention_bwd: bad dout/dqkv");

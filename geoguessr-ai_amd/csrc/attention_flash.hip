@@ -1,0 +1,508 @@
+// Flash (online-softmax) attention, forward and backward, for ANY window / sequence length, with f32 arithmetic on
+// v_mfma_f32_16x16x4_f32 (gfx950).  Two users:
+//   * the reference-precision (fp32) mode: every attention of TinyViT (timm Attention.forward reached through models/tinyvit.py:135)
+//     on f32 activations;
+//   * the reference's own default shapes, which the register-resident kernels of attention.hip (<= 256 tokens) cannot hold:
+//     tiny_vit_21m_512 (32x32 = 1024-token windows, config.py:9), tiny_vit_21m_384 (24x24), CLIP ViT-L/14-336 (577 tokens,
+//     config.py:6) -- on bf16 activations (operands are widened to f32 on their way into LDS).
+//
+// Work decomposition: one 256-thread workgroup per (window, head, 64-query tile) [forward, dQ pass] or per (window, head, 64-key
+// tile) [dK/dV pass]; a wave owns 16 of those rows.  K/V (resp. Q/dO) tiles of 64 tokens are staged in LDS as f32 rows of D + 4
+// floats.  Scores are computed "swapped" (S^T = K Q^T in the forward / dQ pass, S = Q K^T in the dK/dV pass) so that the row a lane
+// owns -- its query resp. its key -- is the MFMA column index (lane & 15): running max / sum / log-sum-exp / delta are lane-local,
+// a tile's softmax reduction is two shuffles, and the exponentiated tile is directly the B operand of the next product.
+// MFMA operands are one f32 per lane: row-contiguous fragments come out of LDS as ds_read_b128 (4 consecutive k feed 4 successive
+// MFMA steps, the k permutation is the same on both operands), "k-major" fragments as ds_read_b32 of 16 consecutive floats per row.
+// The relative-position bias is looked up in the compact f32 table attention_biases[h][|dy|*ws+|dx|] (LDS copy), its gradient is
+// summed per workgroup in LDS.  The backward pass runs in two passes (dQ; dK,dV): no atomics on dq/dk/dv, deterministic.
+#include "common.h"
+#include "../../include/gg.h"
+
+namespace {
+
+struct FlashParams {
+    const void* qkv; int64_t ld;
+    int q_off, k_off, v_off, head_stride;
+    void* out; int64_t ldo;
+    const float* bias_table;          // [nh][ws*ws] f32 or null
+    int ws, nWx, nWy, H, W;
+    int N, nh;
+    float scale;
+    const void* dout; int64_t lddo;
+    void* dqkv;
+    float* dbias; float* dbias_part;  // [nh][ws*ws] accumulated into (atomics) / per-workgroup partial rows [rows][nh][ws*ws]
+    float* lse;                       // [tokens][nh]
+    int ntile;                        // ceil(N / 64)
+};
+
+template <typename T> struct Ld4;
+template <> struct Ld4<float> {
+    static __device__ __forceinline__ f32x4 load(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void store(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Ld4<bf16> {
+    static __device__ __forceinline__ f32x4 load(const bf16* p) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+        *reinterpret_cast<bf16x4*>(p) = (bf16x4){(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    }
+};
+
+__device__ __forceinline__ int64_t fl_origin(const FlashParams& p, int w) {
+    if (p.ws == 0) return (int64_t)w * p.N;
+    const int per_img = p.nWx * p.nWy;
+    const int b = w / per_img, r = w % per_img;
+    const int wy = r / p.nWx, wx = r % p.nWx;
+    return ((int64_t)b * p.H + wy * p.ws) * p.W + wx * p.ws;
+}
+__device__ __forceinline__ int64_t fl_token(const FlashParams& p, int64_t origin, int t) {      // t < N
+    if (p.ws == 0) return origin + t;
+    const int i = t / p.ws, j = t - i * p.ws;
+    return origin + (int64_t)i * p.W + j;
+}
+
+// stage rows [t0, t0+64) x D of one head's column block into X[64][D+4] (f32; zero rows beyond N)
+template <typename T, int D>
+__device__ __forceinline__ void fl_stage(const FlashParams& p, const T* base, int64_t ld, int col, int64_t origin, int t0, float* X) {
+    constexpr int CH = D / 4, RS = D + 4;
+#pragma unroll
+    for (int i = 0; i < 64 * CH / 256; ++i) {
+        const int id = threadIdx.x + i * 256;
+        const int row = id / CH, ch = id % CH;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + row < p.N) v = Ld4<T>::load(base + fl_token(p, origin, t0 + row) * ld + col + ch * 4);
+        *reinterpret_cast<f32x4*>(X + row * RS + ch * 4) = v;
+    }
+}
+// window coordinates of tokens [t0, t0+64) -> cy/cx (bias lookups)
+__device__ __forceinline__ void fl_stage_coords(const FlashParams& p, int t0, int* cy, int* cx) {
+    if (threadIdx.x < 64) {
+        const int t = min(t0 + (int)threadIdx.x, p.N - 1);
+        const int i = p.ws ? t / p.ws : 0;
+        cy[threadIdx.x] = i; cx[threadIdx.x] = p.ws ? t - i * p.ws : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- forward
+template <typename T, int D>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
+    constexpr int RS = D + 4, DC = D / 16;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * RS];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * RS];
+    __shared__ float btab[1024];
+    __shared__ int kcy[64], kcx[64];
+    const int qt = blockIdx.x % p.ntile;
+    const int wh = blockIdx.x / p.ntile;
+    const int h = wh % p.nh, w = wh / p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int64_t origin = fl_origin(p, w);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const int hc = h * p.head_stride;
+    const bool has_bias = p.bias_table != nullptr;
+    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += 256) btab[i] = p.bias_table[h * p.ws * p.ws + i];
+
+    const int qi = qt * 64 + wave * 16 + lr;
+    const bool qok = qi < p.N;
+    const bool wave_on = qt * 64 + wave * 16 < p.N;                 // wave-uniform
+    const int64_t qtok = fl_token(p, origin, min(qi, p.N - 1));
+    f32x4 qf[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        qf[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (qok) qf[c] = Ld4<T>::load(qkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg);
+    }
+    const int qq = min(qi, p.N - 1);
+    const int qcy = p.ws ? qq / p.ws : 0, qcx = p.ws ? qq - qcy * p.ws : 0;
+    float m = -1e30f, l = 0.f;
+    f32x4 oacc[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
+        const int t0 = kt0 * 64;
+        __syncthreads();
+        fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
+        fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
+        if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
+        __syncthreads();
+        if (!wave_on) continue;
+        const int nsub = min(4, (p.N - t0 + 15) / 16);
+        f32x4 st[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (kt < nsub) {
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + lr) * RS + 16 * c + 4 * lg);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[c][s], st[kt], 0, 0, 0);
+                }
+            }
+        }
+        // lane holds S^T[key = t0 + 16kt + 4lg + r][q = lr]
+        float tmax = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kl = 16 * kt + 4 * lg + r;
+                float s = st[kt][r] * p.scale;
+                if (has_bias) s += btab[abs(qcy - kcy[kl]) * p.ws + abs(qcx - kcx[kl])];
+                s = (kt < nsub && t0 + kl < p.N) ? s : -INFINITY;
+                st[kt][r] = s;
+                tmax = fmaxf(tmax, s);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __expf(m - mn);
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __expf(st[kt][r] - mn); st[kt][r] = e; ls += e; }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l = l * alpha + ls;
+        m = mn;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) oacc[c] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < nsub) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int c = 0; c < DC; ++c) {
+                        const float vf = Vs[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+                        oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, st[kt][r], oacc[c], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (qok) {
+        const float inv = 1.0f / l;
+        T* out = reinterpret_cast<T*>(p.out);
+#pragma unroll
+        for (int c = 0; c < DC; ++c) Ld4<T>::store(out + qtok * p.ldo + h * D + 16 * c + 4 * lg, oacc[c] * inv);
+        if (p.lse && lg == 0) p.lse[qtok * p.nh + h] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward, pass A: dQ
+template <typename T, int D>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
+    constexpr int RS = D + 4, DC = D / 16;
+    __shared__ __attribute__((aligned(16))) float Ks[64 * RS];
+    __shared__ __attribute__((aligned(16))) float Vs[64 * RS];
+    __shared__ float btab[1024];
+    __shared__ int kcy[64], kcx[64];
+    const int qt = blockIdx.x % p.ntile;
+    const int wh = blockIdx.x / p.ntile;
+    const int h = wh % p.nh, w = wh / p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int64_t origin = fl_origin(p, w);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    const T* outp = reinterpret_cast<const T*>(p.out);
+    const int hc = h * p.head_stride;
+    const bool has_bias = p.bias_table != nullptr;
+    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += 256) btab[i] = p.bias_table[h * p.ws * p.ws + i];
+
+    const int qi = qt * 64 + wave * 16 + lr;
+    const bool qok = qi < p.N;
+    const bool wave_on = qt * 64 + wave * 16 < p.N;
+    const int64_t qtok = fl_token(p, origin, min(qi, p.N - 1));
+    f32x4 qf[DC], dof[DC];
+    float delta = 0.f;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        qf[c] = dof[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (qok) {
+            qf[c] = Ld4<T>::load(qkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg);
+            dof[c] = Ld4<T>::load(dout + qtok * p.lddo + h * D + 16 * c + 4 * lg);
+            const f32x4 o = Ld4<T>::load(outp + qtok * p.ldo + h * D + 16 * c + 4 * lg);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) delta = fmaf(dof[c][s], o[s], delta);
+        }
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    const float lse = qok ? p.lse[qtok * p.nh + h] : 0.f;
+    const int qq = min(qi, p.N - 1);
+    const int qcy = p.ws ? qq / p.ws : 0, qcx = p.ws ? qq - qcy * p.ws : 0;
+    f32x4 dq[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
+        const int t0 = kt0 * 64;
+        __syncthreads();
+        fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
+        fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
+        if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
+        __syncthreads();
+        if (!wave_on) continue;
+        const int nsub = min(4, (p.N - t0 + 15) / 16);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nsub) continue;
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + lr) * RS + 16 * c + 4 * lg);
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (16 * kt + lr) * RS + 16 * c + 4 * lg);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[c][s], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], dof[c][s], dp, 0, 0, 0);
+                }
+            }
+            // lane holds S^T / dP^T [key = t0 + 16kt + 4lg + r][q = lr]
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kl = 16 * kt + 4 * lg + r;
+                float s = st[r] * p.scale;
+                if (has_bias) s += btab[abs(qcy - kcy[kl]) * p.ws + abs(qcx - kcx[kl])];
+                const float pr = (t0 + kl < p.N && qok) ? __expf(s - lse) : 0.f;
+                ds[r] = pr * (dp[r] - delta) * p.scale;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const float kf = Ks[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+                    dq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, ds[r], dq[c], 0, 0, 0);
+                }
+        }
+    }
+    if (qok) {
+        T* dqkv = reinterpret_cast<T*>(p.dqkv);
+#pragma unroll
+        for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward, pass B: dK, dV (+ dbias)
+template <typename T, int D, bool DBIAS>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
+    constexpr int RS = D + 4, DC = D / 16;
+    __shared__ __attribute__((aligned(16))) float Qs[64 * RS];
+    __shared__ __attribute__((aligned(16))) float Os[64 * RS];     // dO tile
+    __shared__ float btab[1024];
+    __shared__ float dbt[DBIAS ? 1024 : 1];
+    __shared__ int qcy[64], qcx[64];
+    __shared__ float lse_s[64], del_s[64];
+    const int kvt = blockIdx.x % p.ntile;
+    const int wh = blockIdx.x / p.ntile;
+    const int h = wh % p.nh, w = wh / p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int64_t origin = fl_origin(p, w);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    const T* outp = reinterpret_cast<const T*>(p.out);
+    const int hc = h * p.head_stride;
+    const bool has_bias = p.bias_table != nullptr;
+    const int nb = p.ws * p.ws;
+    if (has_bias) for (int i = threadIdx.x; i < nb; i += 256) btab[i] = p.bias_table[h * nb + i];
+    if (DBIAS) for (int i = threadIdx.x; i < nb; i += 256) dbt[i] = 0.f;
+
+    const int ki = kvt * 64 + wave * 16 + lr;
+    const bool kok = ki < p.N;
+    const bool wave_on = kvt * 64 + wave * 16 < p.N;
+    const int64_t ktok = fl_token(p, origin, min(ki, p.N - 1));
+    f32x4 kf[DC], vf[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        kf[c] = vf[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (kok) {
+            kf[c] = Ld4<T>::load(qkv + ktok * p.ld + p.k_off + hc + 16 * c + 4 * lg);
+            vf[c] = Ld4<T>::load(qkv + ktok * p.ld + p.v_off + hc + 16 * c + 4 * lg);
+        }
+    }
+    const int kk = min(ki, p.N - 1);
+    const int kcy = p.ws ? kk / p.ws : 0, kcx = p.ws ? kk - kcy * p.ws : 0;
+    f32x4 dk[DC], dv[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int qt0 = 0; qt0 < p.ntile; ++qt0) {
+        const int t0 = qt0 * 64;
+        __syncthreads();
+        fl_stage<T, D>(p, qkv, p.ld, p.q_off + hc, origin, t0, Qs);
+        fl_stage<T, D>(p, dout, p.lddo, h * D, origin, t0, Os);
+        if (has_bias) fl_stage_coords(p, t0, qcy, qcx);
+        {   // delta[q] = sum_d dO[q][d] O[q][d], lse[q]: 4 lanes per row
+            const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+            float dsum = 0.f;
+            const bool ok = t0 + row < p.N;
+            const int64_t tok = fl_token(p, origin, min(t0 + row, p.N - 1));
+            if (ok) {
+#pragma unroll
+                for (int c = 0; c < D / 16; ++c) {
+                    const f32x4 a = Ld4<T>::load(dout + tok * p.lddo + h * D + part * (D / 4) + 4 * c);
+                    const f32x4 b = Ld4<T>::load(outp + tok * p.ldo + h * D + part * (D / 4) + 4 * c);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) dsum = fmaf(a[s], b[s], dsum);
+                }
+            }
+            dsum += __shfl_xor(dsum, 1, 64);
+            dsum += __shfl_xor(dsum, 2, 64);
+            if (part == 0) { del_s[row] = dsum; lse_s[row] = ok ? p.lse[tok * p.nh + h] : INFINITY; }
+        }
+        __syncthreads();
+        if (!wave_on) continue;
+        const int nsub = min(4, (p.N - t0 + 15) / 16);
+#pragma unroll
+        for (int qs = 0; qs < 4; ++qs) {
+            if (qs >= nsub) continue;
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(Qs + (16 * qs + lr) * RS + 16 * c + 4 * lg);
+                const f32x4 oa = *reinterpret_cast<const f32x4*>(Os + (16 * qs + lr) * RS + 16 * c + 4 * lg);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    st = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kf[c][s], st, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(oa[s], vf[c][s], dp, 0, 0, 0);
+                }
+            }
+            // lane holds S / dP [q = t0 + 16qs + 4lg + r][key = lr]
+            f32x4 pr, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ql = 16 * qs + 4 * lg + r;
+                float s = st[r] * p.scale;
+                int bidx = 0;
+                if (has_bias) { bidx = abs(qcy[ql] - kcy) * p.ws + abs(qcx[ql] - kcx); s += btab[bidx]; }
+                const float e = kok ? __expf(s - lse_s[ql]) : 0.f;        // lse_s = +inf for padded queries -> 0
+                const float g = e * (dp[r] - del_s[ql]);
+                pr[r] = e;
+                ds[r] = g * p.scale;
+                if (DBIAS && kok && t0 + ql < p.N) atomicAdd(&dbt[bidx], g);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const float of = Os[(16 * qs + 4 * lg + r) * RS + 16 * c + lr];
+                    const float qf = Qs[(16 * qs + 4 * lg + r) * RS + 16 * c + lr];
+                    dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(of, pr[r], dv[c], 0, 0, 0);
+                    dk[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf, ds[r], dk[c], 0, 0, 0);
+                }
+        }
+    }
+    if (kok) {
+        T* dqkv = reinterpret_cast<T*>(p.dqkv);
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            Ld4<T>::store(dqkv + ktok * p.ld + p.k_off + hc + 16 * c + 4 * lg, dk[c]);
+            Ld4<T>::store(dqkv + ktok * p.ld + p.v_off + hc + 16 * c + 4 * lg, dv[c]);
+        }
+    }
+    if (DBIAS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            if (p.dbias_part) p.dbias_part[((int64_t)(w * p.ntile + kvt) * p.nh + h) * nb + i] = dbt[i];
+            else atomicAdd(&p.dbias[h * nb + i], dbt[i]);
+        }
+    }
+}
+
+__global__ void flash_dbias_final_kernel(const float* __restrict__ rows, int nrows, int W, float* __restrict__ dbias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W) return;
+    double s = 0.0;
+    for (int r = 0; r < nrows; ++r) s += (double)rows[(int64_t)r * W + i];
+    dbias[i] += (float)s;
+}
+
+int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) {
+    GG_CHECK(a && a->qkv, "%s: null qkv", who);
+    GG_CHECK(dtype == 0 || dtype == 1, "%s: dtype must be 0 (bf16) or 1 (f32)", who);
+    GG_CHECK(a->head_dim == 32 || a->head_dim == 64, "%s: head_dim must be 32 or 64 (got %d)", who, a->head_dim);
+    GG_CHECK(a->tokens_per_window > 0 && a->num_windows > 0 && a->num_heads > 0, "%s: bad window/head/token count", who);
+    GG_CHECK((a->ld & 3) == 0 && (a->q_off & 3) == 0 && (a->k_off & 3) == 0 && (a->v_off & 3) == 0 && (a->head_stride & 3) == 0,
+             "%s: qkv offsets/strides must be multiples of 4 elements", who);
+    GG_CHECK(((uintptr_t)a->qkv & 15) == 0, "%s: qkv must be 16-byte aligned", who);
+    if (a->window_size > 0) {
+        GG_CHECK(a->window_size * a->window_size == a->tokens_per_window, "%s: window_size^2 != tokens_per_window", who);
+        GG_CHECK(a->map_h % a->window_size == 0 && a->map_w % a->window_size == 0, "%s: map not divisible by window", who);
+        GG_CHECK(a->num_windows % ((a->map_h / a->window_size) * (a->map_w / a->window_size)) == 0, "%s: window count", who);
+        GG_CHECK(a->window_size <= 32, "%s: window_size > 32 unsupported (bias table of at most 1024 entries)", who);
+    }
+    if (a->bias_table || a->dbias) GG_CHECK(a->window_size > 0, "%s: the relative-position bias needs a window geometry", who);
+    GG_CHECK(!a->dbias || a->bias_table, "%s: dbias without bias_table", who);
+    GG_CHECK((int64_t)a->num_windows * a->num_heads * gg_cdiv(a->tokens_per_window, 64) < ((int64_t)1 << 31), "%s: grid too large", who);
+    p.qkv = a->qkv; p.ld = a->ld; p.q_off = a->q_off; p.k_off = a->k_off; p.v_off = a->v_off; p.head_stride = a->head_stride;
+    p.out = a->out; p.ldo = a->ldo; p.bias_table = a->bias_table;
+    p.ws = a->window_size; p.H = a->map_h; p.W = a->map_w;
+    p.nWx = a->window_size ? a->map_w / a->window_size : 1;
+    p.nWy = a->window_size ? a->map_h / a->window_size : 1;
+    p.N = a->tokens_per_window; p.nh = a->num_heads; p.scale = a->scale;
+    p.dout = a->dout; p.lddo = a->lddo; p.dqkv = a->dqkv; p.dbias = a->dbias; p.dbias_part = a->dbias ? a->dbias_scratch : nullptr; p.lse = a->lse;
+    p.ntile = (int)gg_cdiv(a->tokens_per_window, 64);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stream) {
+    FlashParams p;
+    GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_fwd"));
+    GG_CHECK(a->out && (a->ldo & 3) == 0 && ((uintptr_t)a->out & 15) == 0, "gg_attention_flash_fwd: bad out");
+    const dim3 grid((unsigned)(a->num_windows * a->num_heads * p.ntile)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const double es = dtype ? 4.0 : 2.0;
+    GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
+            4.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
+    if (dtype == 1) {
+        if (a->head_dim == 32) hipLaunchKernelGGL((flash_fwd_kernel<float, 32>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_fwd_kernel<float, 64>), grid, block, 0, s, p);
+    } else {
+        if (a->head_dim == 32) hipLaunchKernelGGL((flash_fwd_kernel<bf16, 32>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((flash_fwd_kernel<bf16, 64>), grid, block, 0, s, p);
+    }
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per_window) {
+    return (int64_t)num_windows * gg_cdiv(tokens_per_window, 64) + GG_REDUCE_SLICES;
+}
+extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stream) {
+    FlashParams p;
+    GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_bwd"));
+    GG_CHECK(a->dout && a->dqkv && (a->lddo & 3) == 0 && ((uintptr_t)a->dout & 15) == 0 && ((uintptr_t)a->dqkv & 15) == 0,
+             "gg_attention_flash_bwd: bad dout/dqkv");
+    GG_CHECK(a->lse && a->out && (a->ldo & 3) == 0, "gg_attention_flash_bwd: needs the forward's lse and out");
+    const dim3 grid((unsigned)(a->num_windows * a->num_heads * p.ntile)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const double es = dtype ? 4.0 : 2.0;
+    GG_PROF(GG_CAT_ATTN, 14.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
+            8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
+#define GG_FL_BWD(T_, D_)                                                                                     \
+    do {                                                                                                      \
+        hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_>), grid, block, 0, s, p);                              \
+        if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true>), grid, block, 0, s, p);          \
+        else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false>), grid, block, 0, s, p);                 \
+    } while (0)
+    if (dtype == 1) { if (a->head_dim == 32) GG_FL_BWD(float, 32); else GG_FL_BWD(float, 64); }
+    else { if (a->head_dim == 32) GG_FL_BWD(bf16, 32); else GG_FL_BWD(bf16, 64); }
+#undef GG_FL_BWD
+    if (p.dbias && p.dbias_part) {
+        const int Wd = p.nh * p.ws * p.ws;
+        const float* rows; int nrows;
+        gg_reduce_rows(p.dbias_part, a->num_windows * p.ntile, Wd, s, &rows, &nrows);
+        hipLaunchKernelGGL(flash_dbias_final_kernel, dim3((unsigned)gg_cdiv(Wd, 256)), dim3(256), 0, s, rows, nrows, Wd, p.dbias);
+    }
+    GG_LAUNCH_CHECK();
+    return 0;
+}

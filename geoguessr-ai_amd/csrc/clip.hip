@@ -20,7 +20,7 @@ struct CModel {
     int cls, patch_w, pos, pre_g, pre_b, post_g, post_b;
     int64_t wpatch;
     std::vector<LayerP> layers;
-    int T, G, Kpatch;
+    int T, G, Kpatch, Kraw;
 };
 static int addt(CModel& m, const std::string& n, std::initializer_list<int64_t> shape) {
     TInfo t; t.name = n; t.ndim = (int)shape.size(); t.numel = 1;
@@ -38,9 +38,10 @@ static int build(const GgClipCfg* c, CModel& m) {
     m.cfg = *c;
     const int D = c->hidden_size, I = c->intermediate_size, P = c->patch_size;
     GG_CHECK(D > 0 && D % 64 == 0 && c->num_heads > 0 && D / c->num_heads == 64, "clip: head_dim must be 64 (hidden %d, heads %d)", D, c->num_heads);
-    GG_CHECK(P > 0 && c->image_size % P == 0 && (3 * P * P) % 8 == 0 && I % 8 == 0, "clip: bad patch/image/intermediate size");
-    m.G = c->image_size / P; m.T = m.G * m.G + 1; m.Kpatch = 3 * P * P;
-    GG_CHECK(m.T <= 256, "clip: %d tokens per image unsupported (attention kernel holds <= 256; ViT-L/14-336 needs the online-softmax variant)", m.T);
+    GG_CHECK(P > 0 && c->image_size % P == 0 && I % 8 == 0, "clip: bad patch/image/intermediate size");
+    // patch-embedding contraction 3*P*P is padded to a multiple of 8 (ViT-L/14: 588 -> 592 zero columns); sequences beyond 256 tokens
+    // (ViT-L/14-336: 577, the reference's CLIP_MODEL, config.py:6) run on the online-softmax attention kernels
+    m.G = c->image_size / P; m.T = m.G * m.G + 1; m.Kraw = 3 * P * P; m.Kpatch = (int)gg_align(m.Kraw, 8);
     m.cls = addt(m, "embeddings.class_embedding", {D});
     m.patch_w = addt(m, "embeddings.patch_embedding.weight", {D, 3, P, P});
     m.pos = addt(m, "embeddings.position_embedding.weight", {m.T, D});
@@ -69,8 +70,8 @@ static int build(const GgClipCfg* c, CModel& m) {
 }
 
 // x f32 NCHW (B,3,S,S) -> col bf16 [B*G*G, 3*P*P], k = (c, py, px)  (== Conv2d(kernel=stride=P) weight flatten)
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, bf16* __restrict__ col, int B, int S, int P, int G) {
-    const int K = 3 * P * P;
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, bf16* __restrict__ col, int B, int S, int P, int G, int K) {
+    const int Kraw = 3 * P * P;         // K = Kraw padded to a multiple of 8 (zero columns)
     const int64_t total = (int64_t)B * G * G * (K / 8);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int kc = (int)(i % (K / 8)) * 8;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         for (int j = 0; j < 8; ++j) {
             const int k = kc + j;
             const int c = k / (P * P), py = (k / P) % P, px = k % P;
-            o[j] = (bf16)x[(((int64_t)b * 3 + c) * S + gy * P + py) * S + gx * P + px];
+            o[j] = k < Kraw ? (bf16)x[(((int64_t)b * 3 + c) * S + gy * P + py) * S + gx * P + px] : (bf16)0.f;
         }
         *reinterpret_cast<bf16x8*>(col + p * K + kc) = o;
     }
@@ -96,6 +97,14 @@ __global__ void assemble_tokens_kernel(const bf16* __restrict__ patches, const f
         const int64_t b = i / ((int64_t)D * T);
         const float v = t == 0 ? cls[dd] : (float)patches[(b * (T - 1) + (t - 1)) * D + dd];
         tokens[i] = (bf16)(v + pos[(int64_t)t * D + dd]);
+    }
+}
+// f32 [R][K] -> bf16 [R][Kp] with zero padding columns
+__global__ void cast_pad_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int K, int Kp) {
+    const int64_t n = (int64_t)R * Kp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        dst[i] = k < K ? (bf16)src[(i / Kp) * K + k] : (bf16)0.f;
     }
 }
 __global__ void cast_rows_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n) {
@@ -149,7 +158,8 @@ extern "C" int gg_clip_refresh_weights(const GgClipCfg* cfg, const float* params
     hipStream_t st = (hipStream_t)stream;
     const int64_t D = m.cfg.hidden_size, I = m.cfg.intermediate_size;
     auto P = [&](int t) { return params + m.t[t].offset; };
-    GG_TRY(cast_w(P(m.patch_w), (bf16*)(wc + m.wpatch), D * m.Kpatch, st));
+    hipLaunchKernelGGL(cast_pad_rows_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(D * m.Kpatch, 256), 8192)), dim3(256), 0, st, P(m.patch_w),
+                       (bf16*)(wc + m.wpatch), (int)D, m.Kraw, m.Kpatch);
     for (auto& l : m.layers) {
         bf16* wq = (bf16*)(wc + l.wqkv);
         GG_TRY(cast_w(P(l.q_w), wq, D * D, st));
@@ -187,7 +197,7 @@ extern "C" int gg_clip_forward(const GgClipCfg* cfg, int batch, const float* par
         return gg_gemm_nt(&g, st);
     };
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(Mp * (m.Kpatch / 8), 256), 32768)), dim3(256), 0, st, x,
-                       A(L.col), B, m.cfg.image_size, m.cfg.patch_size, m.G);
+                       A(L.col), B, m.cfg.image_size, m.cfg.patch_size, m.G, m.Kpatch);
     GG_TRY(gemm(A(L.col), m.Kpatch, (const bf16*)(wc + m.wpatch), m.Kpatch, A(L.patches), D, Mp, D, m.Kpatch, nullptr, 0, nullptr));
     hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(M * D, 256), 32768)), dim3(256), 0, st, A(L.patches),
                        P(m.cls), P(m.pos), A(L.a), B, T, D);

@@ -1,0 +1,356 @@
+// Spatial (3x3) kernels of the reference-precision (fp32) mode: NHWC f32 activations, 16 bytes (4 channels) per lane.
+// Same operations as conv.hip (timm ConvNorm convs of PatchEmbed / MBConv / PatchMerging / local_conv, models/tinyvit.py:135), f32
+// storage and arithmetic; HBM-bound byte movers, so the structure that matters is the same: lanes run over channels first, every wave
+// access is a contiguous run of an NHWC row, and the depthwise kernels walk down the image with the 3x3 input window in registers
+// (each input element is fetched from HBM once; the left / right neighbours come out of L1).
+#include "common.h"
+#include "../../include/gg.h"
+
+namespace {
+
+__device__ __forceinline__ float act_exact(float x, int act) {
+    if (act == GG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
+    return x;
+}
+
+// ---------------------------------------------------------------- im2col (dense 3x3, pad 1)
+// x f32 NCHW (B,3,H,W) -> col f32 [B*Ho*Wo, 32]; k = (ky*3+kx)*3 + ci for k < 27, zeros above.  thread = (pixel, 16-byte eighth)
+__global__ __launch_bounds__(256) void im2col_nchw3_f32_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int H, int W,
+                                                               int Ho, int Wo, int stride) {
+    const int64_t total = (int64_t)B * Ho * Wo * 8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned pu = (unsigned)(i >> 3);
+        const int q = (int)(i & 7);
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
+        const float* xb = x + (int64_t)b * 3 * H * W;
+        f32x4 t;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = q * 4 + j;
+            const int tap = (k * 11) >> 5, ci = k - tap * 3;          // k / 3, k % 3 for k < 32
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;
+            const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+            const bool ok = k < 27 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            t[j] = ok ? xb[((int64_t)ci * H + iy) * W + ix] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(col + (int64_t)pu * 32 + q * 4) = t;
+    }
+}
+
+// x f32 NHWC (B,H,W,C) -> col f32 [B*Ho*Wo, 9*C]; k = (ky*3+kx)*C + c.  BN: x is a saved pre-BatchNorm conv output and
+// act(gamma*(x-mean)*rstd+beta) is applied to every gathered chunk (padding taps stay zero); scale / shift from an LDS table (C <= 512)
+template <bool BN>
+__global__ __launch_bounds__(256) void im2col_nhwc_f32_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                              float* __restrict__ col, int B, int H, int W, int C, int Ho, int Wo, int stride) {
+    __shared__ __attribute__((aligned(16))) float tab[BN ? 2 * 512 : 4];
+    if (BN) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float sc = stat[C + c] * gamma[c];
+            tab[c] = sc;
+            tab[512 + c] = beta[c] - stat[c] * sc;
+        }
+        __syncthreads();
+    }
+    const int cg = C >> 2;
+    const int per_pix = 9 * cg;
+    const int64_t total = (int64_t)B * Ho * Wo * per_pix;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % per_pix);
+        const int64_t p = i / per_pix;
+        const int tap = ch / cg, g = ch % cg;
+        const int ky = tap / 3, kx = tap % 3;
+        const unsigned pu = (unsigned)p;
+        const int ox = (int)(pu % (unsigned)Wo);
+        const int oy = (int)((pu / (unsigned)Wo) % (unsigned)Ho);
+        const int b = (int)(pu / ((unsigned)Wo * (unsigned)Ho));
+        const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            v = *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 4);
+            if (BN) {
+                const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + g * 4), sh = *reinterpret_cast<const f32x4*>(tab + 512 + g * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_exact(fmaf(v[j], sc[j], sh[j]), act);
+            }
+        }
+        *reinterpret_cast<f32x4*>(col + p * (9 * C) + tap * C + g * 4) = v;
+    }
+}
+
+// transpose of im2col_nhwc: dcol f32 [B*Ho*Wo, 9*C] -> dx f32 NHWC (gather form, no atomics)
+__global__ __launch_bounds__(256) void col2im_nhwc_f32_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W,
+                                                              int C, int Ho, int Wo, int stride) {
+    const int cg = C >> 2;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t p = i / cg;
+        const unsigned pu = (unsigned)p;
+        const int ix = (int)(pu % (unsigned)W);
+        const int iy = (int)((pu / (unsigned)W) % (unsigned)H);
+        const int b = (int)(pu / ((unsigned)W * (unsigned)H));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty % stride) != 0) continue;
+            const int oy = ty / stride;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx % stride) != 0) continue;
+                const int ox = tx / stride;
+                if (ox >= Wo) continue;
+                acc += *reinterpret_cast<const f32x4*>(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * (9 * C) + (ky * 3 + kx) * C + g * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + p * C + g * 4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------- column-walking depthwise 3x3
+// Thread = (4 channels, one output column); a block covers PX adjacent output columns x all C channels of one image and walks down a
+// strip of output rows.  MODE 0: y = conv(x, taps) (+ per-block partial BatchNorm statistics of y); MODE 1: the same with flipped taps
+// (stride-1 data gradient); MODE 2: weight gradient -- acc[tap] += window[tap] * dy, one partial row [9][C] per block.
+enum { DWM_FWD = 0, DWM_FLIP = 1, DWM_WGRAD = 2 };
+template <int S, int MODE>
+__global__ __launch_bounds__(256) void dw3x3_walk_f32_kernel(const float* __restrict__ x, const float* __restrict__ taps,
+                                                             float* __restrict__ y, const float* __restrict__ dy, int H, int W, int C,
+                                                             int Ho, int Wo, int PX, int rows_per_strip, float* __restrict__ part) {
+    extern __shared__ float sred[];
+    const int CG = C >> 2;
+    const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
+    const int ox = blockIdx.x * PX + px;
+    const int b = blockIdx.y;
+    const int oy0 = blockIdx.z * rows_per_strip, oy1 = min(Ho, oy0 + rows_per_strip);
+    const bool live = px < PX && ox < Wo;
+    const float* xb = x + (int64_t)b * H * W * C + cg * 4;
+    f32x4 w[9];
+    if (MODE != DWM_WGRAD) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const f32x4*>(taps + (MODE == DWM_FLIP ? 8 - k : k) * C + cg * 4);
+    }
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[9];                    // MODE 2: the 9 tap gradients;  MODE 0: acc[0], acc[1] = sum / sum of squares of y
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = zero;
+    const int ix0 = ox * S - 1;
+    const bool c0 = ix0 >= 0, c2 = ix0 + 2 < W;           // ix0 + 1 < W always holds for a live column
+    auto row = [&](int iy, f32x4 (&r)[3]) {
+        if (live && iy >= 0 && iy < H) {
+            const float* p = xb + ((int64_t)iy * W + ix0) * C;
+            r[0] = c0 ? *reinterpret_cast<const f32x4*>(p) : zero;
+            r[1] = *reinterpret_cast<const f32x4*>(p + C);
+            r[2] = c2 ? *reinterpret_cast<const f32x4*>(p + 2 * C) : zero;
+        } else { r[0] = r[1] = r[2] = zero; }
+    };
+    f32x4 r0[3], r1[3], r2[3];
+    if (S == 1) { row(oy0 - 1, r0); row(oy0, r1); }
+    else row(2 * oy0 - 1, r0);
+    for (int oy = oy0; oy < oy1; ++oy) {
+        if (S == 1) row(oy + 1, r2);
+        else { row(2 * oy, r1); row(2 * oy + 1, r2); }
+        if (MODE == DWM_WGRAD) {
+            f32x4 g = zero;
+            if (live) g = *reinterpret_cast<const f32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + cg * 4);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { acc[k] += r0[k] * g; acc[3 + k] += r1[k] * g; acc[6 + k] += r2[k] * g; }
+        } else {
+            f32x4 o = r0[0] * w[0];
+            o += r0[1] * w[1]; o += r0[2] * w[2];
+            o += r1[0] * w[3]; o += r1[1] * w[4]; o += r1[2] * w[5];
+            o += r2[0] * w[6]; o += r2[1] * w[7]; o += r2[2] * w[8];
+            if (live) {
+                *reinterpret_cast<f32x4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * C + cg * 4) = o;
+                if (part) { acc[0] += o; acc[1] += o * o; }
+            }
+        }
+        if (S == 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r0[k] = r2[k];
+        }
+    }
+    if (!part) return;
+    // fold the block's PX columns: sred[px][NR][C] -> part[block][NR][C]
+    constexpr int NR = MODE == DWM_WGRAD ? 9 : 2;
+    const int nslots = blockDim.x / CG;
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sred[(px * NR + k) * C + cg * 4 + j] = acc[k][j];
+    __syncthreads();
+    const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (int i = threadIdx.x; i < NR * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < nslots; ++k) t += sred[k * NR * C + i];
+        part[blk * NR * C + i] = t;
+    }
+}
+
+// stride-2 data gradient, gather form: dx[iy][ix] = sum over the taps (ky,kx) with (iy+1-ky, ix+1-kx) both even of
+// w[ky][kx] * dy[(iy+1-ky)/2][(ix+1-kx)/2]   (at most 4 taps per input pixel)
+__global__ __launch_bounds__(256) void dw3x3_s2_bwd_data_f32_kernel(const float* __restrict__ dy, const float* __restrict__ taps,
+                                                                    float* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+    const int cg = C >> 2;
+    const int64_t total = (int64_t)B * H * W * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int64_t p = i / cg;
+        const unsigned pu = (unsigned)p;
+        const int ix = (int)(pu % (unsigned)W);
+        const int iy = (int)((pu / (unsigned)W) % (unsigned)H);
+        const int b = (int)(pu / ((unsigned)W * (unsigned)H));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oy = ty >> 1;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ox = tx >> 1;
+                if (ox >= Wo) continue;
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(taps + (ky * 3 + kx) * C + g * 4);
+                acc += wv * *reinterpret_cast<const f32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + g * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + p * C + g * 4) = acc;
+    }
+}
+
+// part [nparts][9][C] -> grad (C,1,3,3) (+)=
+__global__ void dw_wgrad_final_f32_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ grad, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // over 9*C, part layout [k][c]
+    if (i >= 9 * C) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)part[(int64_t)p * 9 * C + i];
+    const int k = i / C, c = i % C;
+    grad[c * 9 + k] = accumulate ? grad[c * 9 + k] + (float)s : (float)s;
+}
+
+struct WalkGeom { int PX, threads, nbx, strips, rows_per_strip; };
+WalkGeom walk_geom(int B, int Ho, int Wo, int C) {
+    WalkGeom g;
+    const int CG = C / 4;
+    g.PX = std::max(1, std::min(256 / CG, Wo));
+    g.threads = CG * g.PX;
+    g.nbx = (int)gg_cdiv(Wo, g.PX);
+    // enough blocks to fill the chip (>= ~2048), strips of >= 4 rows so the 2-row window warm-up stays cheap
+    int strips = (int)gg_cdiv(2048, (int64_t)g.nbx * B);
+    strips = std::max(1, std::min(strips, (int)gg_cdiv(Ho, 4)));
+    g.rows_per_strip = (int)gg_cdiv(Ho, strips);
+    g.strips = (int)gg_cdiv(Ho, g.rows_per_strip);
+    return g;
+}
+int grid_for(int64_t n, int cap = 16384) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(n, 256), cap)); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- host
+extern "C" int gg_im2col_nchw3_f32_f32(const float* x, float* col, int B, int H, int W, int stride, void* stream) {
+    GG_CHECK(x && col && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gg_im2col_nchw3_f32_f32: bad args");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 4.0 * B * 3.0 * H * W + 128.0 * B * Ho * Wo, stream);
+    hipLaunchKernelGGL(im2col_nchw3_f32_kernel, dim3(grid_for((int64_t)B * Ho * Wo * 8, 65536)), dim3(256), 0, (hipStream_t)stream, x, col, B, H, W,
+                       Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_im2col_nhwc_f32(const float* x, const float* stat, const float* gamma, const float* beta, int act, float* col, int B, int H,
+                                  int W, int C, int stride, void* stream) {
+    GG_CHECK(x && col && B > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "gg_im2col_nhwc_f32: bad args (C %% 4)");
+    GG_CHECK(!stat || (gamma && beta && C <= 512), "gg_im2col_nhwc_f32: the BatchNorm form needs gamma, beta and C <= 512");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 4.0 * B * (double)H * W * C + 36.0 * B * Ho * Wo * C, stream);
+    const dim3 grid(grid_for((int64_t)B * Ho * Wo * 9 * (C / 4), 65536));
+    if (stat) hipLaunchKernelGGL(im2col_nhwc_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, stat, gamma, beta, act, col, B, H, W, C, Ho, Wo, stride);
+    else hipLaunchKernelGGL(im2col_nhwc_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, stat, gamma, beta, act, col, B, H, W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_col2im_nhwc_f32(const float* dcol, float* dx, int B, int H, int W, int C, int stride, void* stream) {
+    GG_CHECK(dcol && dx && B > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "gg_col2im_nhwc_f32: bad args");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_MOVE, 0, 4.0 * B * (double)H * W * C + 36.0 * B * Ho * Wo * C, stream);
+    hipLaunchKernelGGL(col2im_nhwc_f32_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4), 65536)), dim3(256), 0, (hipStream_t)stream, dcol, dx, B, H,
+                       W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gg_dwconv_f32_stat_rows(int B, int Ho, int Wo, int C) {
+    const WalkGeom g = walk_geom(B, Ho, Wo, C);
+    return g.nbx * B * g.strips;
+}
+static int dw_walk_launch(int mode, const float* x, const float* taps, float* y, const float* dy, int B, int H, int W, int C, int stride,
+                          float* part, void* stream) {
+    GG_CHECK((C & 3) == 0 && C >= 4 && C <= 1024, "gg_dwconv3x3 f32: C must be a multiple of 4, <= 1024 (got %d)", C);
+    GG_CHECK(B <= 65535, "gg_dwconv3x3 f32: batch too large for one launch");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const WalkGeom g = walk_geom(B, Ho, Wo, C);
+    const dim3 grid(g.nbx, B, g.strips), block(g.threads);
+    const int NR = mode == DWM_WGRAD ? 9 : 2;
+    const size_t lds = part ? (size_t)g.PX * NR * C * sizeof(float) : 0;
+    GG_CHECK(lds <= 64 * 1024, "gg_dwconv3x3 f32: reduction tile too large");
+    hipStream_t st = (hipStream_t)stream;
+#define GG_DW_LAUNCH(S_, M_) hipLaunchKernelGGL((dw3x3_walk_f32_kernel<S_, M_>), grid, block, lds, st, x, taps, y, dy, H, W, C, Ho, Wo, g.PX, g.rows_per_strip, part)
+    if (stride == 1) {
+        if (mode == DWM_FWD) GG_DW_LAUNCH(1, DWM_FWD);
+        else if (mode == DWM_FLIP) GG_DW_LAUNCH(1, DWM_FLIP);
+        else GG_DW_LAUNCH(1, DWM_WGRAD);
+    } else {
+        if (mode == DWM_FWD) GG_DW_LAUNCH(2, DWM_FWD);
+        else if (mode == DWM_WGRAD) GG_DW_LAUNCH(2, DWM_WGRAD);
+        else { gg_set_error("gg_dwconv3x3 f32: flipped stride-2 walk does not exist"); return -1; }
+    }
+#undef GG_DW_LAUNCH
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// y = depthwise conv3x3(x, taps [9][C]) pad 1; colstats: gg_dwconv_f32_stat_rows(B, Ho, Wo, C) partial rows [2][C] (sum y, sum y^2) or NULL
+extern "C" int gg_dwconv3x3_fwd_f32(const float* x, const float* taps, float* y, int B, int H, int W, int C, int stride, float* colstats,
+                                    void* stream) {
+    GG_CHECK(x && taps && y && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd_f32: bad args");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 4.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    return dw_walk_launch(DWM_FWD, x, taps, y, nullptr, B, H, W, C, stride, colstats, stream);
+}
+// dx = gradient of the conv w.r.t. its input; (H, W) = the conv INPUT map
+extern "C" int gg_dwconv3x3_bwd_data_f32(const float* dy, const float* taps, float* dx, int B, int H, int W, int C, int stride, void* stream) {
+    GG_CHECK(dy && taps && dx && B > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2) && (C & 3) == 0, "gg_dwconv3x3_bwd_data_f32: bad args");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 4.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    if (stride == 1) return dw_walk_launch(DWM_FLIP, dy, taps, dx, nullptr, B, H, W, C, 1, nullptr, stream);
+    hipLaunchKernelGGL(dw3x3_s2_bwd_data_f32_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4), 65536)), dim3(256), 0, (hipStream_t)stream, dy, taps,
+                       dx, B, H, W, C, Ho, Wo);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t gg_dwconv_f32_wgrad_scratch_floats(int B, int H, int W, int C, int stride) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    return ((int64_t)gg_dwconv_f32_stat_rows(B, Ho, Wo, C) + GG_REDUCE_SLICES) * 9 * C;
+}
+// grad (C,1,3,3) (+)= sum_{b,y,x} x[b, y*s+ky-1, x*s+kx-1, c] * dy[b, y, x, c]
+extern "C" int gg_dwconv3x3_bwd_weight_f32(const float* x, const float* dy, int B, int H, int W, int C, int stride, float* scratch, float* grad,
+                                           int accumulate, void* stream) {
+    GG_CHECK(x && dy && scratch && grad && B > 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_bwd_weight_f32: bad args");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 4.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    GG_TRY(dw_walk_launch(DWM_WGRAD, x, nullptr, nullptr, dy, B, H, W, C, stride, scratch, stream));
+    const float* rows; int nrows;
+    gg_reduce_rows(scratch, gg_dwconv_f32_stat_rows(B, Ho, Wo, C), 9 * C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(dw_wgrad_final_f32_kernel, dim3((unsigned)gg_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, grad, accumulate);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,464 @@
+// fp32 MFMA GEMMs of the reference-precision mode (gfx950):  C[M,N] = epi(A[M,K] . B[N,K]^T)  and the weight-gradient form
+// dW[N,K] = dY[M,N]^T . X[M,K], all operands and results f32, arithmetic on v_mfma_f32_16x16x4_f32 (exact f32 products, f32
+// accumulation: bit-for-bit a k-ordered fmaf chain -- the precision of the reference's own torch fp32 matmuls).
+//
+// The reference runs TinyViT / the geocell head in fp32 end to end; this file is the contraction kernel of the mode
+// that does the same.  At 64 FLOP/clk/SIMD the f32 MFMA is 1/16 of the bf16 rate, so unlike the bf16 kernel of gemm.hip every shape
+// of the model is MFMA-bound here (ridge point 157 TFLOP/s / 8 TB/s = 20 flop/B, the model's leanest GEMM has 2K = 192 flop per
+// 12 B): the kernel keeps the matrix pipe fed and otherwise stays simple -- results leave straight from the accumulator fragments.
+//
+// NT tile 128 x BN x 32 (BN = 128: 2x2 waves, 64x64 per wave; BN = 64: 4x1 waves, 32x64 per wave), 256 threads.  An operand tile is
+// R rows x 32 floats = R x 128 bytes, the same byte image as the bf16 kernel's R x 64 tile, so it uses the same 16-byte XOR swizzle
+// (conflict-free ds_write_b128 staging and ds_read_b128 fragment reads).  One ds_read_b128 hands a lane 4 consecutive k of its row:
+// they feed 4 successive MFMA k-steps (lane (r, g) owns k = 4g + s in step s for BOTH operands, so every k is summed exactly once).
+#include "common.h"
+#include <stdlib.h>
+#include "../../include/gg.h"
+
+#define FBK 32   // floats per k-tile
+
+namespace {
+
+struct F32GemmParams {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    int M, N, K;
+    const float* bias;
+    float* preact;
+    const float* rowscale; int rows_per_scale;
+    const float* residual; int64_t ldr;
+    const float* dact_preact;
+    float* colstats;              // [tilesM][2][N]
+    int tilesM, tilesN;
+};
+
+__device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float offset of 16-byte chunk kc (0..7) of a tile row
+    return row * FBK + ((kc ^ ((row & 2) | ((row >> 1) & 4))) << 2);
+}
+
+// exact-erf GELU family: the f32 GEMMs are MFMA-bound, the epilogue's libm calls ride under the next tile's matrix work
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_exact(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4 };
+
+template <int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32GemmParams p) {
+    constexpr int BM = 128;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;           // 16-byte chunks per thread per k-tile
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * FBK];
+    float* As = smem;
+    float* Bs = smem + BM * FBK;
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    const int tm = bid / p.tilesN, tn = bid % p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int srow = threadIdx.x >> 3, skc = threadIdx.x & 7;
+    const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 4u;
+    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
+    unsigned voa[LA], vob[LB];
+    int lds_a[LA], lds_b[LB];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        voa[i] = (unsigned)(srow + 32 * i) * (unsigned)p.lda * 4u + skc * 16u;
+        lds_a[i] = f32_chunk_off(srow + 32 * i, skc);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        vob[i] = (unsigned)(srow + 32 * i) * (unsigned)p.ldb * 4u + skc * 16u;
+        lds_b[i] = f32_chunk_off(srow + 32 * i, skc);
+    }
+    const int sw = (lr & 2) | ((lr >> 1) & 4);
+    const int a_base = (wm * (BM / WM) + lr) * FBK, b_base = (wn * (BN / WN) + lr) * FBK;
+    const int kc0 = ((0 + lg) ^ sw) << 2, kc1 = ((4 + lg) ^ sw) << 2;
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[LA], rb[LB];
+    const int nk = (p.K + FBK - 1) / FBK;
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * FBK;
+        const bool kin = (k0 + skc * 4) < p.K;                    // K % 4 == 0: a chunk is entirely in or out
+        const int so = k0 * 4;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voa[i] : 0xFFFFFFF0u), so, 0);
+#pragma unroll
+        for (int i = 0; i < LB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kin ? vob[i] : 0xFFFFFFF0u), so, 0);
+    };
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(As + lds_a[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<u32x4*>(Bs + lds_b[i]) = rb[i];
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const int rounds = (p.K - kt * FBK) > 16 ? 2 : 1;            // skip the all-zero upper half of a K tail
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks < rounds) {
+                const int kc = ks ? kc1 : kc0;
+                f32x4 xf[TM], wf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(As + a_base + i * 16 * FBK + kc);
+#pragma unroll
+                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Bs + b_base + i * 16 * FBK + kc);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < TM; ++mt)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], xf[mt][s], acc[nt][mt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    const bool vec_c = (p.ldc & 3) == 0;
+    float cs[TN][4], cq[TN][4];
+    if (EPI == FE_PLAIN) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[nt][r] = cq[nt][r] = 0.f;
+    }
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (EPI != FE_PLAIN && EPI != FE_DGELU && p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = p.bias[min(n + r, p.N - 1)];
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m0 + wm * WROWS + mt * 16 + lr;
+            f32x4 v = acc[nt][mt];
+            const bool ok = m < p.M && n < p.N;
+            const bool full = ok && vec_c && n + 3 < p.N;
+            if (EPI == FE_PLAIN) {
+                if (p.colstats) {      // rows beyond M and columns beyond N hold exact zeros (range-checked operand loads)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { cs[nt][r] += v[r]; cq[nt][r] = fmaf(v[r], v[r], cq[nt][r]); }
+                }
+            } else if (ok) {
+                const float rs = ((EPI == FE_LINEAR || EPI == FE_DGELU) && p.rowscale) ? p.rowscale[m / p.rows_per_scale] : 1.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += b4[r];
+                if (EPI == FE_GELU) {
+                    if (p.preact) {
+                        float* g = p.preact + (int64_t)m * p.ldc + n;
+                        if (full) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
+                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+                }
+                if (EPI == FE_QGELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
+                }
+                if (EPI == FE_DGELU) {
+                    const float* g = p.dact_preact + (int64_t)m * p.ldc + n;
+                    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                    if (full) h = *reinterpret_cast<const f32x4*>(g);
+                    else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
+                }
+                if (EPI == FE_LINEAR) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] *= rs;
+                    if (p.residual) {
+                        const float* g = p.residual + (int64_t)m * p.ldr + n;
+                        if (full && (p.ldr & 3) == 0) { const f32x4 h = *reinterpret_cast<const f32x4*>(g); v += h; }
+                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += g[r]; }
+                    }
+                }
+            }
+            if (ok) {
+                float* g = p.C + (int64_t)m * p.ldc + n;
+                if (full) *reinterpret_cast<f32x4*>(g) = v;
+                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
+            }
+        }
+    }
+    if (EPI == FE_PLAIN && p.colstats) {
+        // column sums over this tile's rows: the 16 row-lanes of a wave first, then the WM waves that share columns through LDS
+        float* red = smem;                                    // [WM][2][BN]  (the k-loop's last barrier has passed)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = cs[nt][r], b = cq[nt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (lr == 0) {
+                    const int col = wn * WCOLS + nt * 16 + lg * 4 + r;
+                    red[(wm * 2 + 0) * BN + col] = a;
+                    red[(wm * 2 + 1) * BN + col] = b;
+                }
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+            const int which = i / BN, col = i % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
+            if (n0 + col < p.N) p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- TN (weight gradients)
+// part[split][N][K] = sum over the split's rows m of dY[m][n] * X[m][k].  Both operands are row-major over the reduction index, and the
+// f32 MFMA takes ONE float per lane per operand (A[i = n][k = m], B[k = m][j = k]), so fragments are plain ds_read_b32 of the
+// row-major LDS tiles: lane (lr, lg) reads T[4*step + lg][col + lr] -- no transposed copies, no transposing reads.  Row stride
+// 128 + 16 floats: the two m-rows a 32-lane half touches land on disjoint bank halves.
+struct F32TnParams {
+    const float* dY; int64_t ldy; const float* X; int64_t ldx;
+    int M, N, K;
+    const float* rowscale; int rows_per_scale;
+    float* part;
+    int tilesN, tilesK, m_per_split;
+};
+__global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
+    constexpr int TB = 128, MS = 32, RS = TB + 16;
+    constexpr int LS = MS * (TB / 4) / 256;                 // 16-byte chunks per thread per operand per step (= 4)
+    __shared__ __attribute__((aligned(16))) float Ys[MS * RS];
+    __shared__ __attribute__((aligned(16))) float Xs[MS * RS];
+    const int ntile = p.tilesN * p.tilesK;
+    const int lb = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int split_id = lb / ntile, tile_id = lb - split_id * ntile;
+    const int tn = tile_id / p.tilesK, tk = tile_id % p.tilesK;
+    const int n0 = tn * TB, k0 = tk * TB;
+    const int mbeg = split_id * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int srow = threadIdx.x >> 5, sch = threadIdx.x & 31;          // 8 rows x 32 chunks per pass, LS passes
+    const bool yok = (n0 + sch * 4) < p.N, xok = (k0 + sch * 4) < p.K;
+    const int nrows = max(mend - mbeg, 0);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + (int64_t)mbeg * p.ldy), 0, (int)((unsigned)nrows * (unsigned)p.ldy * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (int64_t)mbeg * p.ldx), 0, (int)((unsigned)nrows * (unsigned)p.ldx * 4u), 0x00020000);
+    unsigned voy[LS], vox[LS];
+#pragma unroll
+    for (int i = 0; i < LS; ++i) {
+        voy[i] = ((unsigned)(srow + 8 * i) * (unsigned)p.ldy + (unsigned)(n0 + sch * 4)) * 4u;
+        vox[i] = ((unsigned)(srow + 8 * i) * (unsigned)p.ldx + (unsigned)(k0 + sch * 4)) * 4u;
+    }
+    const unsigned stepY = (unsigned)MS * (unsigned)p.ldy * 4u, stepX = (unsigned)MS * (unsigned)p.ldx * 4u;
+    f32x4 ry[LS], rx[LS];
+    float rsc[LS];
+    auto load_step = [&](int m0) {
+        const unsigned st = (unsigned)(m0 - mbeg) / MS;
+#pragma unroll
+        for (int i = 0; i < LS; ++i) {
+            ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
+            rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(xok ? vox[i] + st * stepX : 0xFFFFFFF0u), 0, 0));
+        }
+        if (p.rowscale) {
+#pragma unroll
+            for (int i = 0; i < LS; ++i) rsc[i] = p.rowscale[min(m0 + srow + 8 * i, p.M - 1) / p.rows_per_scale];
+        }
+    };
+    f32x4 acc[4][4];     // [k tile][n tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (mbeg < mend) load_step(mbeg);
+    for (int m0 = mbeg; m0 < mend; m0 += MS) {
+        if (p.rowscale) {
+#pragma unroll
+            for (int i = 0; i < LS; ++i) ry[i] *= rsc[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LS; ++i) {
+            *reinterpret_cast<f32x4*>(Ys + (srow + 8 * i) * RS + sch * 4) = ry[i];
+            *reinterpret_cast<f32x4*>(Xs + (srow + 8 * i) * RS + sch * 4) = rx[i];
+        }
+        __syncthreads();
+        if (m0 + MS < mend) load_step(m0 + MS);
+        const int steps = min(MS, mend - m0 + 3) / 4;              // rows beyond mend are zero anyway; skip whole empty steps
+#pragma unroll 2
+        for (int ss = 0; ss < steps; ++ss) {
+            float yf[4], xf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                yf[i] = Ys[(4 * ss + lg) * RS + wn * 64 + i * 16 + lr];
+                xf[i] = Xs[(4 * ss + lg) * RS + wk * 64 + i * 16 + lr];
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
+        }
+        __syncthreads();
+    }
+    // lane holds D[n = .. + nt*16 + 4lg + r][k = .. + kt*16 + lr]
+    float* out = p.part + (int64_t)split_id * p.N * p.K;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + wk * 64 + kt * 16 + lr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + nt * 16 + lg * 4 + r;
+                if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[kt][nt][r];
+            }
+        }
+}
+
+// column sums of an f32 [M, C] matrix (bias gradients): thread = (4-column group of 64, row lane of 4)
+__global__ __launch_bounds__(256) void colsum_partial_f32_kernel(const float* __restrict__ x, int64_t ld, int M, int C,
+                                                                 const float* rowscale, int rows_per_scale, float* __restrict__ part,
+                                                                 int rows_per_block) {
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, pp = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 256 + cg * 4;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+#pragma unroll 4
+        for (int r = r0 + pp; r < r1; r += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (int64_t)r * ld + c0);
+            const float rs = rowscale ? rowscale[r / rows_per_scale] : 1.f;
+            s += v * rs;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[pp][cg * 4 + j] = s[j];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) part[(int64_t)blockIdx.y * C + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void colsum_final_f32_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int i = 0; i < nparts; ++i) s += (double)part[(int64_t)i * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------- host
+extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
+    GG_CHECK(a && a->A && a->B && a->C, "gg_gemm_nt_f32: null operand");
+    GG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_f32: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+    GG_CHECK((a->K & 3) == 0 && (a->lda & 3) == 0 && (a->ldb & 3) == 0,
+             "gg_gemm_nt_f32: K, lda, ldb must be multiples of 4 (16-byte rows): K=%d lda=%lld ldb=%lld", a->K, (long long)a->lda, (long long)a->ldb);
+    GG_CHECK(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0 && ((uintptr_t)a->C & 15) == 0, "gg_gemm_nt_f32: A/B/C must be 16-byte aligned");
+    GG_CHECK(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "gg_gemm_nt_f32: leading dimension too small");
+    GG_CHECK(a->lda * 512 < 0xFFFFFF00LL && a->ldb * 512 < 0xFFFFFF00LL && (int64_t)a->K * 4 < 0x7FFFFFFFLL,
+             "gg_gemm_nt_f32: leading dimension too large for 32-bit tile offsets (ld < 8.3M elements)");
+    GG_CHECK(a->split_k <= 1 && !a->A2 && !a->bn_y && !a->a_bn_stat, "gg_gemm_nt_f32: split-K / two-source / BatchNorm-fused forms are bf16-only");
+    if (a->rowscale) GG_CHECK(a->rows_per_scale > 0, "gg_gemm_nt_f32: rows_per_scale must be > 0");
+    GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU, "gg_gemm_nt_f32: only the GELU derivative epilogue is built");
+    GG_CHECK(!(a->dact_preact && (a->bias || a->act || a->residual || a->preact)), "gg_gemm_nt_f32: dact excludes bias/act/residual/preact");
+    GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt_f32: an activation epilogue excludes rowscale/residual");
+    GG_CHECK(!a->preact || a->act == GG_ACT_GELU, "gg_gemm_nt_f32: preact is only available with the GELU epilogue");
+    GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact), "gg_gemm_nt_f32: colstats needs the plain epilogue");
+    GG_CHECK(!a->preact || ((uintptr_t)a->preact & 15) == 0, "gg_gemm_nt_f32: preact must be 16-byte aligned");
+    GG_CHECK(!a->residual || ((uintptr_t)a->residual & 15) == 0, "gg_gemm_nt_f32: residual must be 16-byte aligned");
+    GG_CHECK(!a->dact_preact || ((uintptr_t)a->dact_preact & 15) == 0, "gg_gemm_nt_f32: dact_preact must be 16-byte aligned");
+    F32GemmParams p;
+    p.A = (const float*)a->A; p.lda = a->lda; p.B = (const float*)a->B; p.ldb = a->ldb; p.C = (float*)a->C; p.ldc = a->ldc;
+    p.M = a->M; p.N = a->N; p.K = a->K; p.bias = a->bias; p.preact = (float*)a->preact;
+    p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = (const float*)a->residual; p.ldr = a->ldr;
+    p.dact_preact = (const float*)a->dact_preact; p.colstats = a->colstats;
+    const int rem = a->N % 128;
+    const bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
+    const int bn = narrow ? 64 : 128;
+    p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
+    const double mn = (double)a->M * a->N;
+    GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
+            4.0 * ((double)a->M * a->K + (double)a->N * a->K + mn) + 4.0 * mn * ((a->preact != nullptr) + (a->residual != nullptr) + (a->dact_preact != nullptr)),
+            stream);
+    int epi;
+    if (a->dact_preact) epi = FE_DGELU;
+    else if (a->act == GG_ACT_GELU) epi = FE_GELU;
+    else if (a->act == GG_ACT_QUICK_GELU) epi = FE_QGELU;
+    else if (a->bias || a->rowscale || a->residual) epi = FE_LINEAR;
+    else epi = FE_PLAIN;
+    dim3 grid(p.tilesM * p.tilesN);
+    hipStream_t st = (hipStream_t)stream;
+#define GG_LAUNCH_F32(E)                                                                                  \
+    do {                                                                                                  \
+        if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);     \
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);           \
+    } while (0)
+    switch (epi) {
+        case FE_PLAIN: GG_LAUNCH_F32(FE_PLAIN); break;
+        case FE_LINEAR: GG_LAUNCH_F32(FE_LINEAR); break;
+        case FE_GELU: GG_LAUNCH_F32(FE_GELU); break;
+        case FE_QGELU: GG_LAUNCH_F32(FE_QGELU); break;
+        default: GG_LAUNCH_F32(FE_DGELU); break;
+    }
+#undef GG_LAUNCH_F32
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale,
+                              int rows_per_scale, float* partials, int splits, void* stream) {
+    GG_CHECK(dY && X && partials && M > 0 && N > 0 && K > 0 && splits > 0, "gg_gemm_tn_f32: bad args");
+    GG_CHECK((N & 3) == 0 && (K & 3) == 0 && (ldy & 3) == 0 && (ldx & 3) == 0, "gg_gemm_tn_f32: N, K, ldy, ldx must be multiples of 4");
+    GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gg_gemm_tn_f32: operands must be 16-byte aligned");
+    GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn_f32: rows_per_scale");
+    F32TnParams p;
+    p.dY = (const float*)dY; p.ldy = ldy; p.X = (const float*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
+    p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
+    p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
+    p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 32);
+    GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 32), "gg_gemm_tn_f32: a split's rows must span < 4 GiB per operand (use more splits)");
+    GG_CHECK((int64_t)p.tilesN * p.tilesK * splits < ((int64_t)1 << 31), "gg_gemm_tn_f32: grid too large");
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(256), 0, (hipStream_t)stream, p);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_gemm_tn_f32_splits(int M, int N, int K) {
+    const int64_t tiles = gg_cdiv(N, 128) * gg_cdiv(K, 128);
+    int64_t s = std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(1024, tiles), gg_cdiv(M, 512)));
+    const int64_t cap = ((int64_t)64 << 20) / ((int64_t)N * K * 4);        // 64 MiB of slabs at most
+    return (int)std::max<int64_t>(1, std::min<int64_t>(s, cap));
+}
+
+extern "C" int gg_colsum_f32(const float* x, int64_t ld, int M, int C, const float* rowscale, int rows_per_scale, float* scratch,
+                             float* out, int accumulate, void* stream) {
+    GG_CHECK(x && scratch && out && M > 0 && C > 0 && (C & 3) == 0 && (ld & 3) == 0 && ((uintptr_t)x & 15) == 0, "gg_colsum_f32: bad args (C, ld %% 4)");
+    GG_PROF(GG_CAT_NORM, 0, 4.0 * M * C, stream);
+    const int rpb = 512;
+    const int nparts = (int)gg_cdiv(M, rpb);
+    GG_CHECK(nparts <= 65535, "gg_colsum_f32: M too large");
+    hipLaunchKernelGGL(colsum_partial_f32_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream, x, ld, M, C,
+                       rowscale, rows_per_scale, scratch, rpb);
+    const float* rows; int nrows;
+    gg_reduce_rows(scratch, nparts, C, (hipStream_t)stream, &rows, &nrows);
+    hipLaunchKernelGGL(colsum_final_f32_kernel, dim3((unsigned)gg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, out, accumulate);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

@@ -52,10 +52,15 @@ struct GeoParams {
     float smoothing_km;
     float grad_scale;          // dlogits = d(mean loss)/dlogits * grad_scale  (1/N folded in)
     float* loss_rows;
-    bf16* dlogits; int64_t ldd;
+    void* dlogits; int64_t ldd; int dlogits_f32;
     int64_t* preds; float* llh; float* topk_vals; int64_t* topk_idx; int num_candidates;
     int64_t* nearest;
 };
+
+__device__ __forceinline__ void geo_store_dlogit(const GeoParams& p, int64_t i, float v) {
+    if (p.dlogits_f32) reinterpret_cast<float*>(p.dlogits)[i] = v;
+    else reinterpret_cast<bf16*>(p.dlogits)[i] = (bf16)v;
+}
 
 template <int E>
 __global__ __launch_bounds__(GEO_NT) void geo_head_kernel(GeoParams p) {
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(GEO_NT) void geo_head_kernel(GeoParams p) {
                 if (k < p.K) {
                     const float t = d[e] * inv;
                     lr -= t * (z[e] - lse);
-                    if (p.dlogits) p.dlogits[(int64_t)n * p.ldd + k] = (bf16)((__expf(z[e] - lse) * tsum - t) * p.grad_scale);
+                    if (p.dlogits) geo_store_dlogit(p, (int64_t)n * p.ldd + k, (__expf(z[e] - lse) * tsum - t) * p.grad_scale);
                 }
             }
             lr = gg_block_sum<GEO_NT>(lr, red);
@@ -127,18 +132,24 @@ __global__ __launch_bounds__(GEO_NT) void geo_head_kernel(GeoParams p) {
         }
     }
     if (p.mode == 2) {
-        const int lab = (int)p.labels_clf[n];
+        const int64_t lab64 = p.labels_clf[n];
+        const bool lab_ok = lab64 >= 0 && lab64 < p.K;
+        const int lab = lab_ok ? (int)lab64 : -1;
+        // torch.nn.CrossEntropyLoss raises on a class index outside [0, K) (models/super_guessr.py:383); a kernel cannot raise, so the
+        // row's loss -- and with it the batch mean -- is NaN and its gradient row is NaN: loud, never uninitialised memory
+        if (!lab_ok && tid == 0 && p.loss_rows) p.loss_rows[n] = __builtin_nanf("");
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int k = e * GEO_NT + tid;
             if (k < p.K) {
                 if (k == lab && p.loss_rows) p.loss_rows[n] = -(z[e] - lse);
-                if (p.dlogits) p.dlogits[(int64_t)n * p.ldd + k] = (bf16)((__expf(z[e] - lse) - (k == lab ? 1.f : 0.f)) * p.grad_scale);
+                if (p.dlogits)
+                    geo_store_dlogit(p, (int64_t)n * p.ldd + k, lab_ok ? (__expf(z[e] - lse) - (k == lab ? 1.f : 0.f)) * p.grad_scale : __builtin_nanf(""));
             }
         }
     }
     if (p.dlogits && p.mode != 0)
-        for (int k = p.K + tid; k < p.ldd; k += GEO_NT) p.dlogits[(int64_t)n * p.ldd + k] = (bf16)0.f;
+        for (int k = p.K + tid; k < p.ldd; k += GEO_NT) geo_store_dlogit(p, (int64_t)n * p.ldd + k, 0.f);
 
     // predictions: top-`num_candidates` of softmax == of logits (destroys z)
     if (p.preds || p.topk_idx) {
@@ -247,19 +258,25 @@ __global__ __launch_bounds__(64) void proto_refine_kernel(const float* __restric
     }
 }
 
-// ---------------------------------------------------------------------------- scoring (run_benchmark.py:28-65), fp64
-__global__ void score_kernel(const float* __restrict__ pred, const float* __restrict__ truth, int N, float* __restrict__ dist_km,
-                             float* __restrict__ score) {
+// ---------------------------------------------------------------------------- scoring (run_benchmark.py:25-65), fp64 + int32
+// haversine_np: numpy float64 on (lon, lat) degrees, R = 6 371 000 m (quirk C5: not the loss's 6 378 137 m).
+// geoguessr_score_from_distance: int(round(clamp(5000*exp(-d/1492.7), 0, 5000))); Python round() = half-to-even = rint().
+__global__ void score_kernel(const float* __restrict__ pred, const float* __restrict__ truth, int N, double* __restrict__ dist_km,
+                             int32_t* __restrict__ score) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    const double d2r = 0.017453292519943295769;
-    const double lon1 = pred[2 * i] * d2r, lat1 = pred[2 * i + 1] * d2r, lon2 = truth[2 * i] * d2r, lat2 = truth[2 * i + 1] * d2r;
-    const double sa = sin((lat2 - lat1) * 0.5), sb = sin((lon2 - lon1) * 0.5);
-    double a = sa * sa + cos(lat1) * cos(lat2) * sb * sb;
-    a = fmin(a, 1.0);
-    const double km = 6371000.0 * 2.0 * asin(sqrt(a)) / 1000.0;
-    dist_km[i] = (float)km;
-    score[i] = (float)(5000.0 * exp(-km / 1492.7));
+    const double d2r = 0.017453292519943295769;          // numpy.radians multiplies by pi/180
+    const double lon1 = (double)pred[2 * i] * d2r, lat1 = (double)pred[2 * i + 1] * d2r;
+    const double lon2 = (double)truth[2 * i] * d2r, lat2 = (double)truth[2 * i + 1] * d2r;
+    const double sa = sin((lat2 - lat1) / 2.0), sb = sin((lon2 - lon1) / 2.0);
+    const double a = sa * sa + cos(lat1) * cos(lat2) * (sb * sb);
+    const double c = 2.0 * asin(sqrt(a));
+    double km = (6371000.0 * c) / 1000.0;
+    if (dist_km) dist_km[i] = km;
+    if (km < 0.0) km = 0.0;
+    double pts = 5000.0 * exp(-(km / 1492.7));
+    pts = fmax(0.0, fmin(5000.0, pts));
+    score[i] = (int32_t)rint(pts);
 }
 
 // ------------------------------------------------------------------------------------------- host
@@ -276,7 +293,7 @@ extern "C" int gg_geo_head(const GgGeoHeadArgs* a, void* stream) {
     p.labels = a->labels; p.centroids = a->centroids; p.labels_clf = a->labels_clf; p.mode = a->mode;
     p.smoothing_km = a->smoothing_km > 0 ? a->smoothing_km : 65.0f;
     p.grad_scale = a->grad_scale;
-    p.loss_rows = a->loss_rows; p.dlogits = (bf16*)a->dlogits; p.ldd = a->ldd;
+    p.loss_rows = a->loss_rows; p.dlogits = a->dlogits; p.ldd = a->ldd; p.dlogits_f32 = a->dlogits_f32;
     p.preds = a->preds; p.llh = a->llh; p.topk_vals = a->topk_vals; p.topk_idx = a->topk_idx;
     p.num_candidates = a->num_candidates > 0 ? a->num_candidates : 1;
     p.nearest = a->nearest;
@@ -312,8 +329,8 @@ extern "C" int gg_proto_refine(const GgProtoRefineArgs* a, void* stream) {
     GG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, float* dist_km, float* score, void* stream) {
-    GG_CHECK(pred_llh && true_llh && dist_km && score && N > 0, "gg_geoguessr_score: bad args");
+extern "C" int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, double* dist_km, int32_t* score, void* stream) {
+    GG_CHECK(pred_llh && true_llh && score && N > 0, "gg_geoguessr_score: bad args");
     hipLaunchKernelGGL(score_kernel, dim3((unsigned)gg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred_llh, true_llh, N, dist_km, score);
     GG_LAUNCH_CHECK();
     return 0;

@@ -7,6 +7,47 @@
 #include "common.h"
 #include "../../include/gg.h"
 
+// storage-type helpers: 8 consecutive elements per lane (16 bytes of bf16, 32 bytes of f32)
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&f)[8]) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&f)[8]) {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
+        *reinterpret_cast<bf16x8*>(p) = v;
+    }
+};
+template <> struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&f)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&f)[8]) {
+        *reinterpret_cast<f32x4*>(p) = (f32x4){f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = (f32x4){f[4], f[5], f[6], f[7]};
+    }
+};
+
+// activation at the precision of the storage type: the bf16 path's polynomial erf (|err| 2e-5) is far below bf16 resolution; the f32
+// (reference-precision) path calls libm's erff / expf
+template <typename T> __device__ __forceinline__ float act_t(float x, int act) {
+    if (sizeof(T) == 2) return gg_act(x, act);
+    if (act == GG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+    if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
+    return x;
+}
+template <typename T> __device__ __forceinline__ float act_grad_t(float x, int act) {
+    if (sizeof(T) == 2) return gg_act_grad(x, act);
+    if (act == GG_ACT_GELU) return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    if (act == GG_ACT_QUICK_GELU) { const float sg = 1.0f / (1.0f + expf(-1.702f * x)); return sg + 1.702f * x * sg * (1.0f - sg); }
+    return 1.0f;
+}
+
 // ------------------------------------------------------------------------------ BN statistics
 // part [nparts][2][C] -> stat [2][C] = (mean, rstd); running stats updated with unbiased variance.
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, float eps, float momentum,
@@ -39,9 +80,10 @@ __global__ void bn_eval_stat_kernel(const float* __restrict__ rm, const float* _
 // out = act( [residual + rs *] (gamma * (y - mean) * rstd + beta) )
 // Thread = (row-lane pp, channel group g): g is fixed per thread, so the folded per-channel scale / shift live in
 // registers and the row loop issues only the 16-byte streaming accesses.
-__global__ void bn_apply_kernel(const bf16* __restrict__ y, const float* __restrict__ stat, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, int64_t M, int C, int act, const bf16* __restrict__ residual,
-                                const float* __restrict__ rowscale, int rows_per_scale, bf16* __restrict__ out, int CG, int PP,
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ stat, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int64_t M, int C, int act, const T* __restrict__ residual,
+                                const float* __restrict__ rowscale, int rows_per_scale, T* __restrict__ out, int CG, int PP,
                                 int rows_per_block) {
     const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
     const int c0 = g * 8;
@@ -54,18 +96,19 @@ __global__ void bn_apply_kernel(const bf16* __restrict__ y, const float* __restr
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
     for (int64_t m = r0 + pp; m < r1; m += PP) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
-        bf16x8 o;
+        float v[8], o[8];
+        Vec8<T>::load(y + m * C + c0, v);
         if (residual) {
-            const bf16x8 r = *reinterpret_cast<const bf16x8*>(residual + m * C + c0);
+            float r[8];
+            Vec8<T>::load(residual + m * C + c0, r);
             const float rs = rowscale ? rowscale[m / rows_per_scale] : 1.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16)gg_act((float)r[j] + rs * ((float)v[j] * sc[j] + sh[j]), act);
+            for (int j = 0; j < 8; ++j) o[j] = act_t<T>(r[j] + rs * (v[j] * sc[j] + sh[j]), act);
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16)gg_act((float)v[j] * sc[j] + sh[j], act);
+            for (int j = 0; j < 8; ++j) o[j] = act_t<T>(v[j] * sc[j] + sh[j], act);
         }
-        *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+        Vec8<T>::store(out + m * C + c0, o);
     }
 }
 
@@ -73,10 +116,11 @@ __global__ void bn_apply_kernel(const bf16* __restrict__ y, const float* __restr
 //   z    = gamma*xhat + beta ; pre = residual ? residual + rs*z : z
 //   dpre = dout * act'(pre)            -> written to dz (it is also the skip-path gradient of an MBConv)
 //   g    = residual ? rs*dpre : dpre   -> partial sums  sum g, sum g*xhat   [gridDim.x][2][C]
-__global__ void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ y, const float* __restrict__ stat,
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ y, const float* __restrict__ stat,
                                      const float* __restrict__ gamma, const float* __restrict__ beta, int64_t M, int C, int act,
-                                     const bf16* __restrict__ residual, const float* __restrict__ rowscale, int rows_per_scale,
-                                     bf16* __restrict__ dz, float* __restrict__ part, int CG, int PP, int rows_per_block) {
+                                     const T* __restrict__ residual, const float* __restrict__ rowscale, int rows_per_scale,
+                                     T* __restrict__ dz, float* __restrict__ part, int CG, int PP, int rows_per_block) {
     extern __shared__ float sred[];   // [PP][2][C]
     const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
     const int c0 = g * 8;
@@ -89,27 +133,26 @@ __global__ void bn_bwd_reduce_kernel(const bf16* __restrict__ dout, const bf16* 
         s[j] = q[j] = 0.f;
     }
     for (int64_t m = r0 + pp; m < r1; m += PP) {
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dout + m * C + c0);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
-        bf16x8 r;
+        float d[8], v[8], r[8], o[8];
+        Vec8<T>::load(dout + m * C + c0, d);
+        Vec8<T>::load(y + m * C + c0, v);
         float rs = 1.f;
         if (residual) {
-            r = *reinterpret_cast<const bf16x8*>(residual + m * C + c0);
+            Vec8<T>::load(residual + m * C + c0, r);
             if (rowscale) rs = rowscale[m / rows_per_scale];
         }
-        bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float xh = ((float)v[j] - mu[j]) * rstd[j];
+            const float xh = (v[j] - mu[j]) * rstd[j];
             float pre = ga[j] * xh + be[j];
-            if (residual) pre = (float)r[j] + rs * pre;
-            const float dpre = (float)d[j] * gg_act_grad(pre, act);
-            o[j] = (bf16)dpre;
+            if (residual) pre = r[j] + rs * pre;
+            const float dpre = d[j] * act_grad_t<T>(pre, act);
+            o[j] = dpre;
             const float gg = residual ? rs * dpre : dpre;
             s[j] += gg;
             q[j] += gg * xh;
         }
-        if (dz) *reinterpret_cast<bf16x8*>(dz + m * C + c0) = o;
+        if (dz) Vec8<T>::store(dz + m * C + c0, o);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -146,8 +189,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int npart
     }
 }
 // dy = coef0*(rs*dz) + coef1*y + coef2     (same thread geometry as bn_apply)
-__global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __restrict__ y, const float* __restrict__ coef, int64_t M,
-                                    int C, const float* __restrict__ rowscale, int rows_per_scale, bf16* __restrict__ dy, int CG, int PP,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ coef, int64_t M,
+                                    int C, const float* __restrict__ rowscale, int rows_per_scale, T* __restrict__ dy, int CG, int PP,
                                     int rows_per_block) {
     const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
     const int c0 = g * 8;
@@ -157,13 +201,13 @@ __global__ void bn_bwd_apply_kernel(const bf16* __restrict__ dz, const bf16* __r
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
     for (int64_t m = r0 + pp; m < r1; m += PP) {
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(dz + m * C + c0);
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(y + m * C + c0);
+        float d[8], v[8], o[8];
+        Vec8<T>::load(dz + m * C + c0, d);
+        Vec8<T>::load(y + m * C + c0, v);
         const float rs = rowscale ? rowscale[m / rows_per_scale] : 1.f;
-        bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(ca[j] * rs, (float)d[j], fmaf(cb[j], (float)v[j], cc[j]));
-        *reinterpret_cast<bf16x8*>(dy + m * C + c0) = o;
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(ca[j] * rs, d[j], fmaf(cb[j], v[j], cc[j]));
+        Vec8<T>::store(dy + m * C + c0, o);
     }
 }
 
@@ -193,31 +237,6 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------ LayerNorm
 // One wave per row, 8-element chunks: lane takes chunks lane, lane+64 (C <= 1024).
-template <typename T> struct Vec8;
-template <> struct Vec8<bf16> {
-    static __device__ __forceinline__ void load(const bf16* p, float (&f)[8]) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
-    }
-    static __device__ __forceinline__ void store(bf16* p, const float (&f)[8]) {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (bf16)f[j];
-        *reinterpret_cast<bf16x8*>(p) = v;
-    }
-};
-template <> struct Vec8<float> {
-    static __device__ __forceinline__ void load(const float* p, float (&f)[8]) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-        f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
-    }
-    static __device__ __forceinline__ void store(float* p, const float (&f)[8]) {
-        *reinterpret_cast<f32x4*>(p) = (f32x4){f[0], f[1], f[2], f[3]};
-        *reinterpret_cast<f32x4*>(p + 4) = (f32x4){f[4], f[5], f[6], f[7]};
-    }
-};
-
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int64_t M, int C, float eps,
@@ -534,7 +553,8 @@ __global__ void ln_param_final_kernel(const float* __restrict__ part, int nparts
 
 // ------------------------------------------------------------------------------ pooling / means
 // x bf16 [B*T, C] -> out f32 [B, C] = mean over T tokens
-__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const bf16* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
+template <typename TT>
+__global__ __launch_bounds__(256) void token_mean_fwd_kernel(const TT* __restrict__ x, float* __restrict__ out, int B, int T, int C) {
     const int cg = C >> 3;
     const int64_t total = (int64_t)B * cg;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -542,9 +562,10 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const bf16* __restr
         const int64_t b = i / cg;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int t = 0; t < T; ++t) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (b * T + t) * C + g * 8);
+            float v[8];
+            Vec8<TT>::load(x + (b * T + t) * C + g * 8, v);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
         }
         const float inv = 1.f / (float)T;
 #pragma unroll
@@ -552,7 +573,8 @@ __global__ __launch_bounds__(256) void token_mean_fwd_kernel(const bf16* __restr
     }
 }
 // dout f32 [B, C] -> dx bf16 [B*T, C] = dout / T
-__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, bf16* __restrict__ dx, int B, int T, int C) {
+template <typename TT>
+__global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __restrict__ dout, TT* __restrict__ dx, int B, int T, int C) {
     const int cg = C >> 3;
     const int64_t total = (int64_t)B * T * cg;
     const float inv = 1.f / (float)T;
@@ -560,25 +582,27 @@ __global__ __launch_bounds__(256) void token_mean_bwd_kernel(const float* __rest
         const int g = (int)(i % cg);
         const int64_t bt = i / cg;
         const int64_t b = bt / T;
-        bf16x8 o;
+        float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)(dout[b * C + g * 8 + j] * inv);
-        *reinterpret_cast<bf16x8*>(dx + bt * C + g * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = dout[b * C + g * 8 + j] * inv;
+        Vec8<TT>::store(dx + bt * C + g * 8, o);
     }
 }
 // emb f32 [N, V, C] -> out bf16 [N, ldo] (mean over V views; SuperGuessr panorama combine)
-__global__ void view_mean_fwd_kernel(const float* __restrict__ emb, bf16* __restrict__ out, int64_t ldo, int N, int V, int C) {
+template <typename TT>
+__global__ void view_mean_fwd_kernel(const float* __restrict__ emb, TT* __restrict__ out, int64_t ldo, int N, int V, int C) {
     const int64_t total = (int64_t)N * C;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const int64_t n = i / C;
         float s = 0.f;
         for (int v = 0; v < V; ++v) s += emb[(n * V + v) * C + c];
-        out[n * ldo + c] = (bf16)(s / (float)V);
+        out[n * ldo + c] = (TT)(s / (float)V);
     }
 }
 // dmean bf16 [N, ld] -> demb f32 [N, V, C] = dmean / V
-__global__ void view_mean_bwd_kernel(const bf16* __restrict__ dmean, int64_t ld, float* __restrict__ demb, int N, int V, int C) {
+template <typename TT>
+__global__ void view_mean_bwd_kernel(const TT* __restrict__ dmean, int64_t ld, float* __restrict__ demb, int N, int V, int C) {
     const int64_t total = (int64_t)N * V * C;
     const float inv = 1.f / (float)V;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -620,33 +644,47 @@ extern "C" int gg_bn_eval_stat(const float* running_mean, const float* running_v
     GG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gg_bn_apply(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
-                           const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream) {
+template <typename T>
+static int bn_apply_t(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                      const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream) {
     GG_CHECK(y && stat && gamma && beta && out && M > 0 && (C & 7) == 0, "gg_bn_apply: bad args");
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_bn_apply: rows_per_scale");
-    GG_PROF(GG_CAT_NORM, 0, (residual ? 6.0 : 4.0) * M * C, stream);
+    GG_PROF(GG_CAT_NORM, 0, (residual ? 3.0 : 2.0) * sizeof(T) * M * C, stream);
     GG_CHECK(C <= 2048, "gg_bn_apply: C too large");
     RowGeom g = row_geom(M, C);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)y, stat, gamma, beta, M, C,
-                       act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)out, g.CG, g.PP, g.rows_per_block);
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const T*)y, stat, gamma, beta, M, C,
+                       act, (const T*)residual, rowscale, rows_per_scale, (T*)out, g.CG, g.PP, g.rows_per_block);
     GG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gg_bn_apply(const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                           const void* residual, const float* rowscale, int rows_per_scale, void* out, void* stream) {
+    return bn_apply_t<bf16>(y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, out, stream);
+}
+extern "C" int gg_bn_apply_f32(const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                               const float* residual, const float* rowscale, int rows_per_scale, float* out, void* stream) {
+    return bn_apply_t<float>(y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, out, stream);
 }
 extern "C" int64_t gg_bn_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)row_geom(M, C).nblocks + GG_REDUCE_SLICES) * 2 * C + 3 * C; }
 extern "C" int gg_bn_bwd_rows(int64_t M, int C) { return row_geom(M, C).nblocks; }
 // part: [gg_stat_rows_capacity(gg_bn_bwd_rows(M,C))][2][C]; dz may be NULL (no activation / no residual: dz == dout)
-extern "C" int gg_bn_bwd_reduce(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
-                                int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, float* part, void* stream) {
+template <typename T>
+static int bn_bwd_reduce_t(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                           int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, float* part, void* stream) {
     GG_CHECK(dout && y && stat && gamma && beta && part && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd_reduce: bad args");
     RowGeom g = row_geom(M, C);
     GG_CHECK(g.threads <= 1024, "gg_bn_bwd_reduce: C too large");
-    GG_PROF(GG_CAT_NORM, 0, (residual ? 8.0 : (dz ? 6.0 : 4.0)) * M * C, stream);
+    GG_PROF(GG_CAT_NORM, 0, (residual ? 4.0 : (dz ? 3.0 : 2.0)) * sizeof(T) * M * C, stream);
     size_t lds = (size_t)g.PP * 2 * C * sizeof(float);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const bf16*)dout,
-                       (const bf16*)y, stat, gamma, beta, M, C, act, (const bf16*)residual, rowscale, rows_per_scale, (bf16*)dz, part,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(g.nblocks), dim3(g.threads), lds, (hipStream_t)stream, (const T*)dout,
+                       (const T*)y, stat, gamma, beta, M, C, act, (const T*)residual, rowscale, rows_per_scale, (T*)dz, part,
                        g.CG, g.PP, g.rows_per_block);
     GG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gg_bn_bwd_reduce(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                                int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, float* part, void* stream) {
+    return bn_bwd_reduce_t<bf16>(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, part, stream);
 }
 // part rows -> coef [3][C] (dy = coef0*g + coef1*y + coef2) and the parameter gradients
 extern "C" int gg_bn_bwd_finalize(float* part, int nparts, int C, int64_t count, const float* stat, const float* gamma, float* coef,
@@ -659,15 +697,20 @@ extern "C" int gg_bn_bwd_finalize(float* part, int nparts, int C, int64_t count,
     GG_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int gg_bn_bwd_apply(const void* dz, const void* y, const float* coef, int64_t M, int C, const float* rowscale,
-                               int rows_per_scale, void* dy, void* stream) {
+template <typename T>
+static int bn_bwd_apply_t(const void* dz, const void* y, const float* coef, int64_t M, int C, const float* rowscale,
+                          int rows_per_scale, void* dy, void* stream) {
     GG_CHECK(dz && y && coef && dy && M > 0 && (C & 7) == 0 && C <= 2048, "gg_bn_bwd_apply: bad args");
     RowGeom g = row_geom(M, C);
-    GG_PROF(GG_CAT_NORM, 0, 6.0 * M * C, stream);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const bf16*)dz, (const bf16*)y, coef,
-                       M, C, rowscale, rows_per_scale, (bf16*)dy, g.CG, g.PP, g.rows_per_block);
+    GG_PROF(GG_CAT_NORM, 0, 3.0 * sizeof(T) * M * C, stream);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(g.nblocks), dim3(g.threads), 0, (hipStream_t)stream, (const T*)dz, (const T*)y, coef,
+                       M, C, rowscale, rows_per_scale, (T*)dy, g.CG, g.PP, g.rows_per_block);
     GG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gg_bn_bwd_apply(const void* dz, const void* y, const float* coef, int64_t M, int C, const float* rowscale,
+                               int rows_per_scale, void* dy, void* stream) {
+    return bn_bwd_apply_t<bf16>(dz, y, coef, M, C, rowscale, rows_per_scale, dy, stream);
 }
 extern "C" int gg_bn_bwd_fold_weights(const float* W, const float* coef, const float* stat, int Cout, int Cin, void* Bf, float* bias,
                                       void* stream) {
@@ -677,16 +720,28 @@ extern "C" int gg_bn_bwd_fold_weights(const float* W, const float* coef, const f
     return 0;
 }
 // scratch: [nblocks + slices][2][C] partial rows followed by coef [3][C]
-extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
-                         int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
-                         float* dgamma, float* dbeta, int accumulate, void* stream) {
+template <typename T>
+static int bn_bwd_t(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                    int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
+                    float* dgamma, float* dbeta, int accumulate, void* stream) {
     GG_CHECK(dz && dy && scratch, "gg_bn_bwd: bad args");
     const int nb = row_geom(M, C).nblocks;
     float* part = scratch;
     float* coef = scratch + ((int64_t)nb + GG_REDUCE_SLICES) * 2 * C;
-    GG_TRY(gg_bn_bwd_reduce(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, part, stream));
+    GG_TRY(bn_bwd_reduce_t<T>(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, part, stream));
     GG_TRY(gg_bn_bwd_finalize(part, nb, C, M, stat, gamma, coef, dgamma, dbeta, accumulate, stream));
-    return gg_bn_bwd_apply(dz, y, coef, M, C, residual ? rowscale : nullptr, rows_per_scale, dy, stream);
+    return bn_bwd_apply_t<T>(dz, y, coef, M, C, residual ? rowscale : nullptr, rows_per_scale, dy, stream);
+}
+extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                         int act, const void* residual, const float* rowscale, int rows_per_scale, void* dz, void* dy, float* scratch,
+                         float* dgamma, float* dbeta, int accumulate, void* stream) {
+    return bn_bwd_t<bf16>(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, dy, scratch, dgamma, dbeta, accumulate, stream);
+}
+/* f32 storage (reference-precision mode): same three passes, exact erf in the activation derivative */
+extern "C" int gg_bn_bwd_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                             int act, const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* dy, float* scratch,
+                             float* dgamma, float* dbeta, int accumulate, void* stream) {
+    return bn_bwd_t<float>(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, dy, scratch, dgamma, dbeta, accumulate, stream);
 }
 
 static int ln_blocks(int64_t M) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(M, 4), 2048)); }
@@ -769,25 +824,49 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
 }
 extern "C" int gg_token_mean_fwd(const void* x, float* out, int B, int T, int C, void* stream) {
     GG_CHECK(x && out && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_fwd: bad args");
-    hipLaunchKernelGGL(token_mean_fwd_kernel, dim3(grid_for((int64_t)B * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, B, T, C);
+    hipLaunchKernelGGL(token_mean_fwd_kernel<bf16>, dim3(grid_for((int64_t)B * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, out, B, T, C);
     GG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int gg_token_mean_bwd(const float* dout, void* dx, int B, int T, int C, void* stream) {
     GG_CHECK(dout && dx && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_bwd: bad args");
-    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(grid_for((int64_t)B * T * (C / 8))), dim3(256), 0, (hipStream_t)stream, dout, (bf16*)dx, B, T, C);
+    hipLaunchKernelGGL(token_mean_bwd_kernel<bf16>, dim3(grid_for((int64_t)B * T * (C / 8))), dim3(256), 0, (hipStream_t)stream, dout, (bf16*)dx, B, T, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_token_mean_fwd_f32(const float* x, float* out, int B, int T, int C, void* stream) {
+    GG_CHECK(x && out && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_fwd_f32: bad args");
+    hipLaunchKernelGGL(token_mean_fwd_kernel<float>, dim3(grid_for((int64_t)B * (C / 8))), dim3(256), 0, (hipStream_t)stream, x, out, B, T, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_token_mean_bwd_f32(const float* dout, float* dx, int B, int T, int C, void* stream) {
+    GG_CHECK(dout && dx && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_bwd_f32: bad args");
+    hipLaunchKernelGGL(token_mean_bwd_kernel<float>, dim3(grid_for((int64_t)B * T * (C / 8))), dim3(256), 0, (hipStream_t)stream, dout, dx, B, T, C);
     GG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int gg_view_mean_fwd(const float* emb, void* out, int64_t ldo, int N, int V, int C, void* stream) {
     GG_CHECK(emb && out && N > 0 && V > 0 && C > 0 && ldo >= C, "gg_view_mean_fwd: bad args");
-    hipLaunchKernelGGL(view_mean_fwd_kernel, dim3(grid_for((int64_t)N * C)), dim3(256), 0, (hipStream_t)stream, emb, (bf16*)out, ldo, N, V, C);
+    hipLaunchKernelGGL(view_mean_fwd_kernel<bf16>, dim3(grid_for((int64_t)N * C)), dim3(256), 0, (hipStream_t)stream, emb, (bf16*)out, ldo, N, V, C);
     GG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int gg_view_mean_bwd(const void* dmean, int64_t ld, float* demb, int N, int V, int C, void* stream) {
     GG_CHECK(dmean && demb && N > 0 && V > 0 && C > 0 && ld >= C, "gg_view_mean_bwd: bad args");
-    hipLaunchKernelGGL(view_mean_bwd_kernel, dim3(grid_for((int64_t)N * V * C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dmean, ld, demb, N, V, C);
+    hipLaunchKernelGGL(view_mean_bwd_kernel<bf16>, dim3(grid_for((int64_t)N * V * C)), dim3(256), 0, (hipStream_t)stream, (const bf16*)dmean, ld, demb, N, V, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_view_mean_fwd_f32(const float* emb, float* out, int64_t ldo, int N, int V, int C, void* stream) {
+    GG_CHECK(emb && out && N > 0 && V > 0 && C > 0 && ldo >= C, "gg_view_mean_fwd_f32: bad args");
+    hipLaunchKernelGGL(view_mean_fwd_kernel<float>, dim3(grid_for((int64_t)N * C)), dim3(256), 0, (hipStream_t)stream, emb, out, ldo, N, V, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_view_mean_bwd_f32(const float* dmean, int64_t ld, float* demb, int N, int V, int C, void* stream) {
+    GG_CHECK(dmean && demb && N > 0 && V > 0 && C > 0 && ld >= C, "gg_view_mean_bwd_f32: bad args");
+    hipLaunchKernelGGL(view_mean_bwd_kernel<float>, dim3(grid_for((int64_t)N * V * C)), dim3(256), 0, (hipStream_t)stream, dmean, ld, demb, N, V, C);
     GG_LAUNCH_CHECK();
     return 0;
 }

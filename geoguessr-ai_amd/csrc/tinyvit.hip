@@ -30,6 +30,8 @@ struct StageL { MergeL merge; std::vector<BlockL> blocks; int C, heads, ws, res;
 
 struct Model {
     GgTinyVitCfg cfg;
+    int es = 2;             // bytes per activation / cached-weight element: 2 (bf16) or 4 (f32, reference-precision mode)
+    bool f32 = false;
     std::vector<TensorInfo> tensors;
     int64_t param_floats = 0, buffer_floats = 0, wcache_bytes = 0;
     int num_counters = 0;
@@ -62,8 +64,8 @@ static void make_dense(Model& m, DenseW& w, const std::string& wname, int N, int
     if (conv) { const int ks = taps == 9 ? 3 : 1; w.t_w = add_tensor(m, wname, {N, cin, ks, ks}, GG_KIND_PARAM); }
     else w.t_w = add_tensor(m, wname, {N, cin}, GG_KIND_PARAM);
     if (bname) w.t_b = add_tensor(m, *bname, {N}, GG_KIND_PARAM);
-    w.wn = wc_alloc(m, (int64_t)N * w.Kp * 2);
-    w.wt = wc_alloc(m, (int64_t)w.Kp * w.Np * 2);
+    w.wn = wc_alloc(m, (int64_t)N * w.Kp * m.es);
+    w.wt = wc_alloc(m, (int64_t)w.Kp * w.Np * m.es);
 }
 static void make_bn(Model& m, BNP& bn, const std::string& prefix, int C) {
     bn.C = C;
@@ -92,6 +94,8 @@ static void make_ln(Model& m, LNP& l, const std::string& prefix, int C) {
 static int build_model(const GgTinyVitCfg* cfg, Model& m) {
     GG_CHECK(cfg, "tinyvit: null config");
     m.cfg = *cfg;
+    GG_CHECK(cfg->act_dtype == 0 || cfg->act_dtype == 1, "tinyvit: act_dtype must be 0 (bf16) or 1 (f32)");
+    m.f32 = cfg->act_dtype == 1; m.es = m.f32 ? 4 : 2;
     const int* d = cfg->embed_dims;
     GG_CHECK(cfg->img_size > 0 && cfg->img_size % 32 == 0, "tinyvit: img_size must be a multiple of 32");
     GG_CHECK(cfg->in_chans == 3, "tinyvit: in_chans must be 3");
@@ -119,7 +123,7 @@ static int build_model(const GgTinyVitCfg* cfg, Model& m) {
         res /= 2;
         st.C = C; st.heads = nh; st.ws = ws; st.res = res;
         GG_CHECK(res % ws == 0, "tinyvit: stage %d map %d not divisible by window %d (padding path not built)", s, res, ws);
-        GG_CHECK(ws * ws <= 256 && ws <= 16, "tinyvit: window %d unsupported (max 16x16 tokens)", ws);
+        GG_CHECK(ws <= 32, "tinyvit: window %d unsupported (max 32x32 tokens)", ws);
         const std::string pm = "stages." + std::to_string(s) + ".downsample";
         make_convbn_dense(m, st.merge.c1, pm + ".conv1", d[s - 1], C, 1);
         make_convbn_dw(m, st.merge.c2, pm + ".conv2", C);
@@ -130,10 +134,10 @@ static int build_model(const GgTinyVitCfg* cfg, Model& m) {
             BlockL& b = st.blocks[i];
             const std::string p = "stages." + std::to_string(s) + ".blocks." + std::to_string(i);
             b.t_ab = add_tensor(m, p + ".attn.attention_biases", {nh, ws * ws}, GG_KIND_PARAM);
-            {
+            if (!m.f32 && ws <= 16) {     // expanded bf16 table of the register-resident kernels; the flash kernels read the compact parameter
                 const int np_ = gg_attention_padded_tokens(ws * ws);
                 b.bias_full = wc_alloc(m, (int64_t)nh * np_ * np_ * 2);
-            }
+            } else b.bias_full = -1;
             make_ln(m, b.ln1, p + ".attn.norm", C);
             std::string bn = p + ".attn.qkv.bias";
             make_dense(m, b.qkv, p + ".attn.qkv.weight", 3 * C, C, 1, &bn, false);
@@ -212,21 +216,23 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
     const int H1 = c.img_size / 2, H0 = m.res0;
     const int64_t M1 = (int64_t)B * H1 * H1, M0 = (int64_t)B * H0 * H0;
     int64_t gmax = 0, statmax = 0, bnsmax = 0, lnsmax = 0, csmax = 0;
-    auto track = [&](int64_t elems) { gmax = std::max(gmax, elems * 2); };
+    const int64_t es = m.es;
+    auto track = [&](int64_t elems) { gmax = std::max(gmax, elems * es); };
     auto bnreg = [&](const std::string& n, Act& a, int64_t M, int C, bool dw, int Bn, int Ho, int Wo) {
-        a.y = p.alloc(n + ".y", M * C * 2);
+        a.y = p.alloc(n + ".y", M * C * es);
         a.stat = p.alloc(n + ".stat", 2 * C * 4, false);
         statmax = std::max(statmax, bn_part_floats(M, C, Bn, Ho, Wo, dw) * 4);
+        if (dw) statmax = std::max(statmax, (int64_t)gg_stat_rows_capacity(gg_dwconv_f32_stat_rows(Bn, Ho, Wo, C)) * 2 * C * 4);
         statmax = std::max(statmax, (int64_t)gg_stat_rows_capacity(4096) * 2 * C * 4);      // stride-2 fused data gradient partials
         bnsmax = std::max(bnsmax, gg_bn_bwd_scratch_floats(M, C) * 4);
         track(M * C);
     };
-    L.col1 = p.alloc("patch_embed.col1", M1 * 32 * 2);
+    L.col1 = p.alloc("patch_embed.col1", M1 * 32 * es);
     bnreg("patch_embed.conv1", L.pe1, M1, d[0] / 2, false, B, H1, H1);
-    L.col2 = p.alloc("patch_embed.col2", M0 * m.pe2.w.Kp * 2);
+    L.col2 = p.alloc("patch_embed.col2", M0 * m.pe2.w.Kp * es);
     track(M0 * m.pe2.w.Kp); track(M1 * 32);
     bnreg("patch_embed.conv2", L.pe2, M0, d[0], false, B, H0, H0);
-    L.x_pe = p.alloc("patch_embed.out", M0 * d[0] * 2);
+    L.x_pe = p.alloc("patch_embed.out", M0 * d[0] * es);
     const int mid = (int)(d[0] * c.mbconv_expand_ratio);
     L.mb.resize(m.mb.size());
     int64_t prev = L.x_pe;
@@ -235,11 +241,11 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         MBAct& a = L.mb[i];
         a.x = prev;
         bnreg(n + ".conv1", a.c1, M0, mid, false, B, H0, H0);
-        a.a1 = p.alloc(n + ".act1", M0 * mid * 2);
+        a.a1 = p.alloc(n + ".act1", M0 * mid * es);
         bnreg(n + ".conv2", a.c2, M0, mid, true, B, H0, H0);
-        a.a2 = p.alloc(n + ".act2", M0 * mid * 2);
+        a.a2 = p.alloc(n + ".act2", M0 * mid * es);
         bnreg(n + ".conv3", a.c3, M0, d[0], false, B, H0, H0);
-        a.out = p.alloc(n + ".out", M0 * d[0] * 2);
+        a.out = p.alloc(n + ".out", M0 * d[0] * es);
         prev = a.out;
     }
     int res = H0;
@@ -251,11 +257,11 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         const std::string n = "stages." + std::to_string(s + 1) + ".downsample";
         MergeAct& ma = L.merge[s];
         bnreg(n + ".conv1", ma.c1, Mprev, C, false, B, res, res);
-        ma.a1 = p.alloc(n + ".act1", Mprev * C * 2);
+        ma.a1 = p.alloc(n + ".act1", Mprev * C * es);
         bnreg(n + ".conv2", ma.c2, M, C, true, B, st.res, st.res);
-        ma.a2 = p.alloc(n + ".act2", M * C * 2);
+        ma.a2 = p.alloc(n + ".act2", M * C * es);
         bnreg(n + ".conv3", ma.c3, M, C, false, B, st.res, st.res);
-        ma.out = p.alloc(n + ".out", M * C * 2);
+        ma.out = p.alloc(n + ".out", M * C * es);
         prev = ma.out;
         const int hid = (int)(C * c.mlp_ratio);
         L.blocks[s].resize(st.blocks.size());
@@ -263,21 +269,21 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
             const std::string bn = "stages." + std::to_string(s + 1) + ".blocks." + std::to_string(i);
             BlockAct& a = L.blocks[s][i];
             a.x0 = prev;
-            a.a = p.alloc(bn + ".ln1", M * C * 2);
+            a.a = p.alloc(bn + ".ln1", M * C * es);
             a.mean1 = p.alloc(bn + ".mean1", M * 4);
             a.rstd1 = p.alloc(bn + ".rstd1", M * 4);
-            a.qkv = p.alloc(bn + ".qkv", M * 3 * C * 2);
-            a.o = p.alloc(bn + ".attn.out", M * C * 2);
+            a.qkv = p.alloc(bn + ".qkv", M * 3 * C * es);
+            a.o = p.alloc(bn + ".attn.out", M * C * es);
             a.lse = p.alloc(bn + ".attn.lse", M * st.heads * 4);
-            a.x1 = p.alloc(bn + ".x1", M * C * 2);
+            a.x1 = p.alloc(bn + ".x1", M * C * es);
             bnreg(bn + ".local_conv", a.local, M, C, true, B, st.res, st.res);
-            a.x2 = p.alloc(bn + ".x2", M * C * 2);
-            a.b = p.alloc(bn + ".ln2", M * C * 2);
+            a.x2 = p.alloc(bn + ".x2", M * C * es);
+            a.b = p.alloc(bn + ".ln2", M * C * es);
             a.mean2 = p.alloc(bn + ".mean2", M * 4);
             a.rstd2 = p.alloc(bn + ".rstd2", M * 4);
-            a.hpre = p.alloc(bn + ".fc1.pre", M * hid * 2);
-            a.h = p.alloc(bn + ".fc1.act", M * hid * 2);
-            a.x3 = p.alloc(bn + ".out", M * C * 2);
+            a.hpre = p.alloc(bn + ".fc1.pre", M * hid * es);
+            a.h = p.alloc(bn + ".fc1.act", M * hid * es);
+            a.x3 = p.alloc(bn + ".out", M * C * es);
             prev = a.x3;
             track(M * hid); track(M * 3 * C);
             lnsmax = std::max(lnsmax, gg_layernorm_bwd_scratch_floats(M, C) * 4);
@@ -296,10 +302,13 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         // dw wgrad scratch may exceed the BN scratch
         int64_t dwmax = 0;
         dwmax = std::max(dwmax, gg_dwconv_wgrad_scratch_floats(B, H0, H0, mid, 1) * 4);
+        dwmax = std::max(dwmax, gg_dwconv_f32_wgrad_scratch_floats(B, H0, H0, mid, 1) * 4);
         for (int s = 0; s < 3; ++s) {
             const int rin = s == 0 ? H0 : m.stages[s - 1].res;
             dwmax = std::max(dwmax, gg_dwconv_wgrad_scratch_floats(B, rin, rin, m.stages[s].C, 2) * 4);
             dwmax = std::max(dwmax, gg_dwconv_wgrad_scratch_floats(B, m.stages[s].res, m.stages[s].res, m.stages[s].C, 1) * 4);
+            dwmax = std::max(dwmax, gg_dwconv_f32_wgrad_scratch_floats(B, rin, rin, m.stages[s].C, 2) * 4);
+            dwmax = std::max(dwmax, gg_dwconv_f32_wgrad_scratch_floats(B, m.stages[s].res, m.stages[s].res, m.stages[s].C, 1) * 4);
         }
         L.bnscratch = p.alloc("scratch.bn", std::max(bnsmax, dwmax), false);
         L.lnscratch = p.alloc("scratch.ln", lnsmax, false);
@@ -307,7 +316,7 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         L.splitk = p.alloc("scratch.splitk", (int64_t)64 << 20, false);
         int64_t fold = (int64_t)d[0] * 2 * mid;
         for (int s = 0; s < 3; ++s) fold = std::max(fold, (int64_t)(s == 0 ? d[0] : m.stages[s - 1].C) * 2 * m.stages[s].C);
-        L.foldw = p.alloc("scratch.foldw", fold * 2, false);
+        L.foldw = p.alloc("scratch.foldw", fold * es, false);
         L.foldb = p.alloc("scratch.foldb", 4096 * 4, false);
         L.gbytes = gg_align(gmax, 256);
         for (int i = 0; i < 5; ++i) L.G[i] = p.alloc("scratch.G" + std::to_string(i), L.gbytes, false);
@@ -329,6 +338,7 @@ static void plan_make(const Model& m, int B, bool training, Plan& p, Layout& L) 
 }
 
 // ------------------------------------------------------------------------------------------- execution context
+typedef char act_t;        // an activation / cached-weight element of the model's storage type (bf16 or f32): only ever passed on
 struct Exec {
     const Model* m; const Layout* L;
     int B; bool training;
@@ -336,9 +346,12 @@ struct Exec {
     const char* wc; char* ws; hipStream_t st;
     const float* drop;   // [slots][B] or null
     float* grads; const uint8_t* trainable;
+    GgStageDoneFn stage_done = nullptr; void* stage_user = nullptr;     // host callback: the gradient of a stage is fully enqueued
+    void done(int stage) const { if (stage_done) stage_done(stage, stage_user); }
     // Fusing BatchNorm+GELU of the producer into the depthwise conv's input load removes one [M,C] write+read, but each input is
     // loaded (and transformed) by its three neighbouring columns: the erf work triples and the conv turns VALU-bound
     // (measured at 1024 images: +4.7 ms conv vs -2.7 ms elementwise) -> off by default.
+    bool f32 = false;       // reference-precision mode: f32 activations / cached weights, f32 MFMA, every fusion below off (set by exec_init)
     bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
     // the stride-2 depthwise conv of PatchMerging stages its input tile in LDS: BatchNorm1 + GELU are applied once per staged element
     // (17x17 inputs per 8x8 outputs = 1.13x), the apply pass and the activation tensor disappear
@@ -358,17 +371,21 @@ struct Exec {
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
-    bf16* A(int64_t off) const { return reinterpret_cast<bf16*>(ws + off); }
+    void exec_init() {
+        f32 = m->f32;
+        if (f32) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = false;
+    }
+    act_t* A(int64_t off) const { return reinterpret_cast<act_t*>(ws + off); }
     float* F(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
-    const bf16* Wn(const DenseW& w) const { return reinterpret_cast<const bf16*>(wc + w.wn); }
-    const bf16* Wt(const DenseW& w) const { return reinterpret_cast<const bf16*>(wc + w.wt); }
+    const act_t* Wn(const DenseW& w) const { return reinterpret_cast<const act_t*>(wc + w.wn); }
+    const act_t* Wt(const DenseW& w) const { return reinterpret_cast<const act_t*>(wc + w.wt); }
     const float* Taps(const DwW& w) const { return reinterpret_cast<const float*>(wc + w.taps); }
     const float* dropv(int slot) const { return drop ? drop + (int64_t)slot * B : nullptr; }
 };
 
 // conv dgrad with the BatchNorm-backward reduce of the ConvNorm it feeds as epilogue: dz = (dY . W) * act'(BN(y)), partial
 // column sums -> statpart
-static int gemm_bnbwd(const Exec& e, const bf16* dY, int64_t ldy, const bf16* Wt, int64_t ldw, bf16* dz, int64_t M, int N, int K,
+static int gemm_bnbwd(const Exec& e, const act_t* dY, int64_t ldy, const act_t* Wt, int64_t ldw, act_t* dz, int64_t M, int N, int K,
                       const BNP& bn, const Act& a, int act) {
     GgGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -378,8 +395,8 @@ static int gemm_bnbwd(const Exec& e, const bf16* dY, int64_t ldy, const bf16* Wt
     return gg_gemm_nt(&g, e.st);
 }
 // 1x1-conv dgrad straight from (dz, y): BatchNorm backward's apply step is folded into the weights (gg_bn_bwd_fold_weights)
-static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const bf16* dz, const bf16* y, const float* coef, const float* stat,
-                             bf16* dx, int64_t M, const bf16* residual) {
+static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const act_t* dz, const act_t* y, const float* coef, const float* stat,
+                             act_t* dx, int64_t M, const act_t* residual) {
     const int Cout = w.N, Cin = w.K;
     GG_TRY(gg_bn_bwd_fold_weights(e.P(w.t_w), coef, stat, Cout, Cin, e.A(e.L->foldw), e.F(e.L->foldb), e.st));
     GgGemmArgs g;
@@ -388,15 +405,15 @@ static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const bf16* dz, con
     g.M = (int)M; g.N = Cin; g.K = 2 * Cout; g.bias = e.F(e.L->foldb); g.residual = residual; g.ldr = Cin;
     return gg_gemm_nt(&g, e.st);
 }
-static int gemm(const Exec& e, const bf16* A, int64_t lda, const bf16* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
+static int gemm(const Exec& e, const act_t* A, int64_t lda, const act_t* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
                 const float* bias = nullptr, int act = 0, void* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
-                const bf16* residual = nullptr, float* colstats = nullptr, const bf16* dact_pre = nullptr, int dact = 0) {
+                const act_t* residual = nullptr, float* colstats = nullptr, const act_t* dact_pre = nullptr, int dact = 0) {
     GgGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.preact = preact; g.rowscale = rowscale; g.rows_per_scale = rps;
     g.residual = residual; g.ldr = ldc; g.colstats = colstats; g.dact_preact = dact_pre; g.dact = dact;
-    return gg_gemm_nt(&g, e.st);
+    return e.f32 ? gg_gemm_nt_f32(&g, e.st) : gg_gemm_nt(&g, e.st);
 }
 
 // BatchNorm statistics for a ConvNorm whose producer wrote `nparts` partial rows into statpart
@@ -410,7 +427,7 @@ static int bn_stats(const Exec& e, const BNP& bn, const Act& a, int nparts, int6
     return 0;
 }
 // dense ConvNorm: y = A . Wn^T (+ partial stats) ; stat
-static int conv_dense_fwd(const Exec& e, const ConvBNDense& c, const Act& a, const bf16* A, int64_t lda, int64_t M) {
+static int conv_dense_fwd(const Exec& e, const ConvBNDense& c, const Act& a, const act_t* A, int64_t lda, int64_t M) {
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     GG_TRY(gemm(e, A, lda, e.Wn(c.w), c.w.Kp, e.A(a.y), c.w.N, M, c.w.N, c.w.Kp, nullptr, 0, nullptr, nullptr, 0, nullptr, part));
     return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
@@ -426,9 +443,13 @@ static int conv_dense_fwd_pro(const Exec& e, const ConvBNDense& c, const Act& a,
     GG_TRY(gg_gemm_nt(&g, e.st));
     return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
 }
-static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const bf16* x, int B, int H, int W, int stride) {
+static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const act_t* x, int B, int H, int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
+    if (e.f32) {
+        GG_TRY(gg_dwconv3x3_fwd_f32((const float*)x, e.Taps(c.w), (float*)e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
+        return bn_stats(e, c.bn, a, gg_dwconv_f32_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+    }
     GG_TRY(gg_dwconv3x3_fwd(x, e.Taps(c.w), e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
     return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C, stride), (int64_t)B * Ho * Wo);
 }
@@ -441,9 +462,24 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
                                   c.w.C, stride, part, e.st));
     return bn_stats(e, c.bn, a, gg_dwconv_fwd_fused_stat_rows(B, H, W, c.w.C, stride), (int64_t)B * Ho * Wo);
 }
-static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, bf16* out, const bf16* residual = nullptr,
+static int bn_apply(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, act_t* out, const act_t* residual = nullptr,
                     const float* rowscale = nullptr, int rps = 0) {
+    if (e.f32) return gg_bn_apply_f32((const float*)e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, (const float*)residual,
+                                      rowscale, rps, (float*)out, e.st);
     return gg_bn_apply(e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, residual, rowscale, rps, out, e.st);
+}
+// window attention arguments of one TinyVitBlock (forward fields; the caller adds the backward ones)
+static void attn_args(const Exec& e, const StageL& st, const BlockL& l, const BlockAct& a, int B, GgAttnArgs& at) {
+    const int C = st.C;
+    memset(&at, 0, sizeof(at));
+    at.qkv = e.A(a.qkv); at.ld = 3 * C; at.q_off = 0; at.k_off = 32; at.v_off = 64; at.head_stride = 96; at.head_dim = 32;
+    at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
+    at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
+    at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
+    at.bias = l.bias_full >= 0 ? e.wc + l.bias_full : nullptr;      // expanded bf16 table (register-resident kernels)
+    at.bias_table = e.P(l.t_ab);                                     // compact f32 parameter (online-softmax kernels)
+    at.scale = kAttnScale;
+    at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
 }
 
 // ------------------------------------------------------------------------------------------- forward
@@ -456,12 +492,15 @@ static int forward_impl(Exec& e, const float* x, float* out) {
     // (num_batches_tracked counters are bumped by the host shim: they are int64 bookkeeping, not arithmetic)
 
     // PatchEmbed: conv3x3 s2 + BN + GELU, conv3x3 s2 + BN
-    GG_TRY(gg_im2col_nchw3_f32(x, e.A(L.col1), B, H, H, 2, e.st));
+    if (e.f32) GG_TRY(gg_im2col_nchw3_f32_f32(x, (float*)e.A(L.col1), B, H, H, 2, e.st));
+    else GG_TRY(gg_im2col_nchw3_f32(x, e.A(L.col1), B, H, H, 2, e.st));
     GG_TRY(conv_dense_fwd(e, m.pe1, L.pe1, e.A(L.col1), 32, M1));
     GG_CHECK(m.pe2.w.Kp == m.pe2.w.K, "tinyvit: patch_embed.conv2 K=%d must be a multiple of 8", m.pe2.w.K);
     // BN1 + GELU ride on conv2's im2col gather: the activation tensor (M1 x 48, the largest of the model) is never written
-    GG_TRY(gg_im2col_nhwc_bn_bf16(e.A(L.pe1.y), e.F(L.pe1.stat), e.P(m.pe1.bn.t_g), e.P(m.pe1.bn.t_b), GG_ACT_GELU, e.A(L.col2), B, H1, H1,
-                                  d[0] / 2, 2, e.st));
+    if (e.f32) GG_TRY(gg_im2col_nhwc_f32((const float*)e.A(L.pe1.y), e.F(L.pe1.stat), e.P(m.pe1.bn.t_g), e.P(m.pe1.bn.t_b), GG_ACT_GELU,
+                                         (float*)e.A(L.col2), B, H1, H1, d[0] / 2, 2, e.st));
+    else GG_TRY(gg_im2col_nhwc_bn_bf16(e.A(L.pe1.y), e.F(L.pe1.stat), e.P(m.pe1.bn.t_g), e.P(m.pe1.bn.t_b), GG_ACT_GELU, e.A(L.col2), B, H1, H1,
+                                       d[0] / 2, 2, e.st));
     GG_TRY(conv_dense_fwd(e, m.pe2, L.pe2, e.A(L.col2), m.pe2.w.Kp, M0));
     GG_TRY(bn_apply(e, m.pe2.bn, L.pe2, M0, GG_ACT_NONE, e.A(L.x_pe)));
 
@@ -514,25 +553,19 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             const float* s1 = e.training ? e.dropv(slot) : nullptr;
             const float* s2 = e.training ? e.dropv(slot + 1) : nullptr;
             slot += 2;
-            GG_TRY(gg_layernorm_fwd(e.A(a.x0), 0, e.P(l.ln1.t_g), e.P(l.ln1.t_b), M, C, c.ln_eps, e.A(a.a), 0, e.F(a.mean1), e.F(a.rstd1), e.st));
+            GG_TRY(gg_layernorm_fwd(e.A(a.x0), e.f32, e.P(l.ln1.t_g), e.P(l.ln1.t_b), M, C, c.ln_eps, e.A(a.a), e.f32, e.F(a.mean1), e.F(a.rstd1), e.st));
             GG_TRY(gemm(e, e.A(a.a), C, e.Wn(l.qkv), l.qkv.Kp, e.A(a.qkv), 3 * C, M, 3 * C, l.qkv.Kp, e.P(l.qkv.t_b)));
             GgAttnArgs at;
-            memset(&at, 0, sizeof(at));
-            at.qkv = e.A(a.qkv); at.ld = 3 * C; at.q_off = 0; at.k_off = 32; at.v_off = 64; at.head_stride = 96; at.head_dim = 32;
-            at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
-            at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
-            at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = e.wc + l.bias_full; at.scale = kAttnScale;
-            at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
-            GG_TRY(gg_attention_fwd(&at, e.st));
+            attn_args(e, st, l, a, B, at);
+            GG_TRY(e.f32 ? gg_attention_flash_fwd(&at, 1, e.st) : gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
             GG_TRY(conv_dw_fwd(e, l.local, a.local, e.A(a.x1), B, st.res, st.res, 1));
-            if (C <= 640) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
+            if (C <= 640 && !e.f32) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
                 GG_TRY(gg_layernorm_fwd_bn(e.A(a.local.y), e.F(a.local.stat), e.P(l.local.bn.t_g), e.P(l.local.bn.t_b), e.A(a.x2), e.P(l.ln2.t_g),
                                            e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), e.F(a.mean2), e.F(a.rstd2), e.st));
             } else {
                 GG_TRY(bn_apply(e, l.local.bn, a.local, M, GG_ACT_NONE, e.A(a.x2)));
-                GG_TRY(gg_layernorm_fwd(e.A(a.x2), 0, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), 0, e.F(a.mean2), e.F(a.rstd2), e.st));
+                GG_TRY(gg_layernorm_fwd(e.A(a.x2), e.f32, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), e.f32, e.F(a.mean2), e.F(a.rstd2), e.st));
             }
             GG_TRY(gemm(e, e.A(a.b), C, e.Wn(l.fc1), l.fc1.Kp, e.A(a.h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU,
                         e.training ? (void*)e.A(a.hpre) : nullptr));
@@ -544,14 +577,19 @@ static int forward_impl(Exec& e, const float* x, float* out) {
     }
     // head: global average pool -> LayerNorm
     const int T = res * res, C3 = d[3];
-    GG_TRY(gg_token_mean_fwd(e.A(prev), e.F(L.pooled), B, T, C3, e.st));
+    if (e.f32) GG_TRY(gg_token_mean_fwd_f32((const float*)e.A(prev), e.F(L.pooled), B, T, C3, e.st));
+    else GG_TRY(gg_token_mean_fwd(e.A(prev), e.F(L.pooled), B, T, C3, e.st));
+    if (c.features_only) {     // models/tinyvit.py:139-143: the pooled last feature map, no head.norm
+        GG_HIP(hipMemcpyAsync(out, e.F(L.pooled), (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, e.st));
+        return 0;
+    }
     GG_TRY(gg_layernorm_fwd(e.F(L.pooled), 1, e.P(m.head.t_g), e.P(m.head.t_b), B, C3, c.ln_eps, out, 1, e.F(L.mean_h), e.F(L.rstd_h), e.st));
     return 0;
 }
 
 // BatchNorm-backward pieces on the shared scratch: partial rows at the start of `bnscratch`, coef [3][C] right behind them
 static float* bn_coef(const Exec& e, int64_t M, int C) { return e.F(e.L->bnscratch) + ((int64_t)gg_bn_bwd_rows(M, C) + 64) * 2 * C; }
-static int bn_bwd_reduce_fin(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz) {
+static int bn_bwd_reduce_fin(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const act_t* dout, act_t* dz) {
     const bool tr = e.tr(bn.t_g);
     GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz,
                             e.F(e.L->bnscratch), e.st));
@@ -581,12 +619,13 @@ static int conv_wgrad_scatter(const float* src, int N, int Kp, int cin, int taps
 
 // ------------------------------------------------------------------------------------------- backward helpers
 // wgrad of a dense weight: dW[N,K] (+)= dY^T[N,M] . X[M,K]   (transposes into scratch, split-K over M)
-static int dense_wgrad(const Exec& e, const DenseW& w, const bf16* X, int64_t ldx, const bf16* dY, int64_t ldy, int64_t M,
-                       const float* rowscale, int rps, bf16* T0, bf16* T1, bool conv_reorder) {
+static int dense_wgrad(const Exec& e, const DenseW& w, const act_t* X, int64_t ldx, const act_t* dY, int64_t ldy, int64_t M,
+                       const float* rowscale, int rps, act_t* T0, act_t* T1, bool conv_reorder) {
     (void)T0; (void)T1;
     const int K = conv_reorder ? w.Kp : w.K;   // im2col'd operand has Kp columns
-    const int split = gg_gemm_tn_splits((int)M, w.N, K);
-    GG_TRY(gg_gemm_tn(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
+    const int split = e.f32 ? gg_gemm_tn_f32_splits((int)M, w.N, K) : gg_gemm_tn_splits((int)M, w.N, K);
+    if (e.f32) GG_TRY(gg_gemm_tn_f32(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
+    else GG_TRY(gg_gemm_tn(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
     float* gw = e.Gd(w.t_w);
     if (!conv_reorder) {
         GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), gw, (int64_t)w.N * K, split, 1, 1.0f, e.st));
@@ -600,8 +639,8 @@ static int dense_wgrad(const Exec& e, const DenseW& w, const bf16* X, int64_t ld
 // weight gradient of a ConvNorm whose dy feeds nothing else (the first conv of the network): BatchNorm backward stops after
 // reduce + finalize, and the TN GEMM forms dy = c0*dz + c1*y + c2 from (dz, y) while loading -- no apply pass, no dy tensor
 // (dcol != null: dout does not exist yet -- the reduce rides on the col2im that would have produced it from dcol [B, H, W] stride 2)
-static int convnorm_wgrad_from_dz(const Exec& e, const ConvBNDense& c, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz,
-                                  const bf16* X, int64_t ldx, const bf16* dcol = nullptr, int B = 0, int H = 0, int W = 0) {
+static int convnorm_wgrad_from_dz(const Exec& e, const ConvBNDense& c, const Act& a, int64_t M, int act, const act_t* dout, act_t* dz,
+                                  const act_t* X, int64_t ldx, const act_t* dcol = nullptr, int B = 0, int H = 0, int W = 0) {
     const BNP& bn = c.bn;
     const bool tr = e.tr(bn.t_g);
     float* part = e.F(e.L->bnscratch);
@@ -618,15 +657,28 @@ static int convnorm_wgrad_from_dz(const Exec& e, const ConvBNDense& c, const Act
     GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), e.F(e.L->splitk), (int64_t)w.N * K, split, 0, 1.0f, e.st));
     return conv_wgrad_scatter(e.F(e.L->splitk), w.N, K, w.cin, w.taps, e.Gd(w.t_w), e.st);
 }
-static int bias_grad(const Exec& e, int t_b, const bf16* dY, int64_t ld, int64_t M, int N, const float* rowscale, int rps) {
+static int bias_grad(const Exec& e, int t_b, const act_t* dY, int64_t ld, int64_t M, int N, const float* rowscale, int rps) {
+    if (e.f32) return gg_colsum_f32((const float*)dY, ld, (int)M, N, rowscale, rps, e.F(e.L->colsum), e.Gd(t_b), 1, e.st);
     return gg_colsum_bf16(dY, ld, (int)M, N, rowscale, rps, e.F(e.L->colsum), e.Gd(t_b), 1, e.st);
 }
 // BatchNorm backward of one ConvNorm: dout (grad wrt post-activation output) -> dy (grad wrt the conv output)
-static int bn_bwd(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const bf16* dout, bf16* dz, bf16* dy,
-                  const bf16* residual = nullptr, const float* rowscale = nullptr, int rps = 0) {
+static int bn_bwd(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const act_t* dout, act_t* dz, act_t* dy,
+                  const act_t* residual = nullptr, const float* rowscale = nullptr, int rps = 0) {
     const bool tr = e.tr(bn.t_g);
+    if (e.f32) return gg_bn_bwd_f32((const float*)dout, (const float*)e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act,
+                                    (const float*)residual, rowscale, rps, (float*)dz, (float*)dy, e.F(e.L->bnscratch),
+                                    tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
     return gg_bn_bwd(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, residual, rowscale, rps, dz, dy,
                      e.F(e.L->bnscratch), tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
+}
+
+static int dw_bwd_data(const Exec& e, const DwW& w, const act_t* dy, act_t* dx, int B, int H, int W, int stride) {
+    if (e.f32) return gg_dwconv3x3_bwd_data_f32((const float*)dy, e.Taps(w), (float*)dx, B, H, W, w.C, stride, e.st);
+    return gg_dwconv3x3_bwd_data(dy, e.Taps(w), dx, B, H, W, w.C, stride, e.st);
+}
+static int dw_bwd_weight(const Exec& e, const DwW& w, const act_t* x, const act_t* dy, int B, int H, int W, int stride) {
+    if (e.f32) return gg_dwconv3x3_bwd_weight_f32((const float*)x, (const float*)dy, B, H, W, w.C, stride, e.F(e.L->bnscratch), e.Gd(w.t_w), 1, e.st);
+    return gg_dwconv3x3_bwd_weight(x, dy, B, H, W, w.C, stride, e.F(e.L->bnscratch), e.Gd(w.t_w), 1, e.st);
 }
 
 static int backward_impl(Exec& e, const float* d_out) {
@@ -635,7 +687,7 @@ static int backward_impl(Exec& e, const float* d_out) {
     const int* d = c.embed_dims;
     const int H = c.img_size, H1 = H / 2, H0 = m.res0;
     const int64_t M1 = (int64_t)B * H1 * H1, M0 = (int64_t)B * H0 * H0;
-    bf16* G0 = e.A(L.G[0]); bf16* G1 = e.A(L.G[1]); bf16* G2 = e.A(L.G[2]); bf16* G3 = e.A(L.G[3]); bf16* G4 = e.A(L.G[4]);
+    act_t* G0 = e.A(L.G[0]); act_t* G1 = e.A(L.G[1]); act_t* G2 = e.A(L.G[2]); act_t* G3 = e.A(L.G[3]); act_t* G4 = e.A(L.G[4]);
 
     // drop-path slot bookkeeping mirrors forward
     int nslots = (int)m.mb.size();
@@ -647,13 +699,16 @@ static int backward_impl(Exec& e, const float* d_out) {
     {
         const bool tr = e.tr(m.head.t_g);
         float* dpool = reinterpret_cast<float*>(G1);
-        GG_TRY(gg_layernorm_bwd(d_out, e.F(L.pooled), 1, e.F(L.mean_h), e.F(L.rstd_h), e.P(m.head.t_g), B, C3, nullptr, dpool,
-                                e.F(L.lnscratch), tr ? e.Gd(m.head.t_g) : nullptr, tr ? e.Gd(m.head.t_b) : nullptr, 1, e.st));
-        GG_TRY(gg_token_mean_bwd(dpool, G0, B, T, C3, e.st));
+        if (c.features_only) GG_HIP(hipMemcpyAsync(dpool, d_out, (size_t)B * C3 * sizeof(float), hipMemcpyDeviceToDevice, e.st));
+        else GG_TRY(gg_layernorm_bwd(d_out, e.F(L.pooled), 1, e.F(L.mean_h), e.F(L.rstd_h), e.P(m.head.t_g), B, C3, nullptr, dpool,
+                                     e.F(L.lnscratch), tr ? e.Gd(m.head.t_g) : nullptr, tr ? e.Gd(m.head.t_b) : nullptr, 1, e.st));
+        if (e.f32) GG_TRY(gg_token_mean_bwd_f32(dpool, (float*)G0, B, T, C3, e.st));
+        else GG_TRY(gg_token_mean_bwd(dpool, G0, B, T, C3, e.st));
     }
-    bf16* dx = G0;      // gradient w.r.t. the current activation (block output), bf16 [M, C]
+    act_t* dx = G0;      // gradient w.r.t. the current activation (block output), bf16 [M, C]
     // free buffers for the block-level temporaries
     for (int s = 2; s >= 0; --s) {
+        if (s < 2) e.done(s + 2);          // model stage s+2 (blocks + PatchMerging) is enqueued: its parameter gradients are final
         const StageL& st = m.stages[s];
         const int C = st.C;
         const int64_t M = (int64_t)B * st.res * st.res;
@@ -668,8 +723,8 @@ static int backward_impl(Exec& e, const float* d_out) {
             const float* s1 = e.dropv(slot);
             const float* s2 = e.dropv(slot + 1);
             // dx == d(x3).  MLP branch: x3 = x2 + s2*(fc2(gelu(fc1(ln2(x2)))))
-            bf16* t_a = (dx == G0) ? G1 : G0;    // scratch distinct from dx
-            bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+            act_t* t_a = (dx == G0) ? G1 : G0;    // scratch distinct from dx
+            act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
             // dh = (s2*dx) . W2  * gelu'(hpre)                      [M, hid]
             GG_TRY(gemm(e, dx, C, e.Wt(l.fc2), l.fc2.Np, t_b, hid, M, hid, C, nullptr, 0, nullptr, s2, rps, nullptr, nullptr, e.A(a.hpre), GG_ACT_GELU));
             if (e.tr(l.fc2.t_w)) {
@@ -685,22 +740,22 @@ static int backward_impl(Exec& e, const float* d_out) {
             // dx2 = LN2bwd(db) + dx                                   -> t_b
             {
                 const bool tr = e.tr(l.ln2.t_g);
-                GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x2), 0, e.F(a.mean2), e.F(a.rstd2), e.P(l.ln2.t_g), M, C, dx, t_b, e.F(L.lnscratch),
+                GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x2), e.f32, e.F(a.mean2), e.F(a.rstd2), e.P(l.ln2.t_g), M, C, dx, t_b, e.F(L.lnscratch),
                                         tr ? e.Gd(l.ln2.t_g) : nullptr, tr ? e.Gd(l.ln2.t_b) : nullptr, 1, e.st));
             }
             // local_conv: x2 = BN(dw(x1)).  dy -> t_a (dz scratch t_c), dx1 = dwT(dy) -> t_c
             if (e.tr(l.local.w.t_w) || !e.fuse_bnbwd) {
                 GG_TRY(bn_bwd(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, t_c, t_a));
                 if (e.tr(l.local.w.t_w))
-                    GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.x1), t_a, B, st.res, st.res, C, 1, e.F(L.bnscratch), e.Gd(l.local.w.t_w), 1, e.st));
-                GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.local.w), t_c, B, st.res, st.res, C, 1, e.st));
+                    GG_TRY(dw_bwd_weight(e, l.local.w, e.A(a.x1), t_a, B, st.res, st.res, 1));
+                GG_TRY(dw_bwd_data(e, l.local.w, t_a, t_c, B, st.res, st.res, 1));
             } else {
                 // frozen taps: BN-backward apply is folded into the conv's staging (no dz / dy tensors at all)
                 GG_TRY(bn_bwd_reduce_fin(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, nullptr));
                 GG_TRY(gg_dwconv3x3_bwd_data_fused(t_b, e.A(a.local.y), bn_coef(e, M, C), e.Taps(l.local.w), t_c, B, st.res, st.res, C,
                                                    nullptr, nullptr, nullptr, nullptr, 0, nullptr, e.st));
             }
-            bf16* dx1 = t_c;
+            act_t* dx1 = t_c;
             // attention branch: x1 = x0 + s1*(proj(o)+b)
             // do = (s1*dx1) . Wproj                                   -> t_a  [M, C]
             GG_TRY(gemm(e, dx1, C, e.Wt(l.proj), l.proj.Np, t_a, C, M, C, C, nullptr, 0, nullptr, s1, rps));
@@ -710,36 +765,33 @@ static int backward_impl(Exec& e, const float* d_out) {
             }
             // dqkv                                                     -> t_b  [M, 3C]
             GgAttnArgs at;
-            memset(&at, 0, sizeof(at));
-            at.qkv = e.A(a.qkv); at.ld = 3 * C; at.q_off = 0; at.k_off = 32; at.v_off = 64; at.head_stride = 96; at.head_dim = 32;
-            at.num_heads = st.heads; at.tokens_per_window = st.ws * st.ws;
-            at.num_windows = B * (st.res / st.ws) * (st.res / st.ws);
-            at.window_size = st.ws; at.map_h = st.res; at.map_w = st.res;
-            at.bias = e.wc + l.bias_full; at.scale = kAttnScale;
-            at.dout = t_a; at.lddo = C; at.dqkv = t_b; at.out = e.A(a.o); at.ldo = C; at.lse = e.F(a.lse);
+            attn_args(e, st, l, a, B, at);
+            at.dout = t_a; at.lddo = C; at.dqkv = t_b;
             at.dbias = e.tr(l.t_ab) ? e.Gd(l.t_ab) : nullptr;
-            if (at.dbias && (int64_t)(at.num_windows + 64) * st.heads * st.ws * st.ws * 4 <= ((int64_t)64 << 20))
-                at.dbias_scratch = e.F(L.splitk);      // per-window partials -> deterministic second stage
-            GG_TRY(gg_attention_bwd(&at, e.st));
+            const bool flash = e.f32 || at.tokens_per_window > 256 || st.ws > 16;
+            const int64_t prow = flash ? gg_attention_flash_dbias_rows(at.num_windows, at.tokens_per_window) : (int64_t)at.num_windows + 64;
+            if (at.dbias && prow * st.heads * st.ws * st.ws * 4 <= ((int64_t)64 << 20))
+                at.dbias_scratch = e.F(L.splitk);      // per-workgroup partials -> deterministic second stage
+            GG_TRY(e.f32 ? gg_attention_flash_bwd(&at, 1, e.st) : gg_attention_bwd(&at, e.st));
             // da = dqkv . Wqkv                                         -> t_a  [M, C]
             GG_TRY(gemm(e, t_b, 3 * C, e.Wt(l.qkv), l.qkv.Np, t_a, C, M, C, 3 * C));
             if (e.tr(l.qkv.t_w)) {
-                bf16* t_e = dx;   // the old block-output gradient is dead by now
+                act_t* t_e = dx;   // the old block-output gradient is dead by now
                 GG_TRY(dense_wgrad(e, l.qkv, e.A(a.a), C, t_b, 3 * C, M, nullptr, 0, t_e, t_d, false));
                 GG_TRY(bias_grad(e, l.qkv.t_b, t_b, 3 * C, M, 3 * C, nullptr, 0));
             }
             // dx0 = LN1bwd(da) + dx1                                   -> old dx buffer
             {
                 const bool tr = e.tr(l.ln1.t_g);
-                GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x0), 0, e.F(a.mean1), e.F(a.rstd1), e.P(l.ln1.t_g), M, C, dx1, dx, e.F(L.lnscratch),
+                GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x0), e.f32, e.F(a.mean1), e.F(a.rstd1), e.P(l.ln1.t_g), M, C, dx1, dx, e.F(L.lnscratch),
                                         tr ? e.Gd(l.ln1.t_g) : nullptr, tr ? e.Gd(l.ln1.t_b) : nullptr, 1, e.st));
             }
             (void)hid;
         }
         // ---- PatchMerging backward: out = BN3(conv3(a2)); a2 = gelu(BN2(dw s2(a1))); a1 = gelu(BN1(conv1(x))) ----
         const MergeAct& ma = L.merge[s];
-        bf16* t_a = (dx == G0) ? G1 : G0;
-        bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+        act_t* t_a = (dx == G0) ? G1 : G0;
+        act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
         const int64_t xin = s == 0 ? (L.mb.empty() ? L.x_pe : L.mb.back().out)
                                    : (L.blocks[s - 1].empty() ? L.merge[s - 1].out : L.blocks[s - 1].back().x3);
         GG_TRY(bn_bwd(e, st.merge.c3.bn, ma.c3, M, GG_ACT_NONE, dx, t_b, t_a));                         // dy3 -> t_a
@@ -760,7 +812,7 @@ static int backward_impl(Exec& e, const float* d_out) {
                 continue;
             }
             GG_TRY(gg_bn_bwd_apply(t_d, e.A(ma.c2.y), bn_coef(e, M, C), M, C, nullptr, 0, t_a, e.st));       // dy2 -> t_a
-            GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(st.merge.c2.w), t_b, B, rin, rin, C, 2, e.st));         // da1 -> t_b [Min, C]
+            GG_TRY(dw_bwd_data(e, st.merge.c2.w, t_a, t_b, B, rin, rin, 2));         // da1 -> t_b [Min, C]
             GG_TRY(bn_bwd_reduce_fin(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, t_b, t_d));                 // dz1 -> t_d
             GG_TRY(gemm_folded_dgrad(e, st.merge.c1.w, t_d, e.A(ma.c1.y), bn_coef(e, Min, C), e.F(ma.c1.stat), dx, Min, nullptr));
             continue;
@@ -769,13 +821,14 @@ static int backward_impl(Exec& e, const float* d_out) {
         GG_TRY(bn_bwd(e, st.merge.c2.bn, ma.c2, M, GG_ACT_GELU, t_b, t_c, t_a));                          // dy2 -> t_a
         if (e.tr(st.merge.c2.w.t_w)) {
             if (e.fuse_dw || e.fuse_dw_s2) GG_TRY(bn_apply(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, e.A(ma.a1)));      // act1 was fused away in forward
-            GG_TRY(gg_dwconv3x3_bwd_weight(e.A(ma.a1), t_a, B, rin, rin, C, 2, e.F(L.bnscratch), e.Gd(st.merge.c2.w.t_w), 1, e.st));
+            GG_TRY(dw_bwd_weight(e, st.merge.c2.w, e.A(ma.a1), t_a, B, rin, rin, 2));
         }
-        GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(st.merge.c2.w), t_b, B, rin, rin, C, 2, e.st));        // da1 -> t_b [Min, C]
+        GG_TRY(dw_bwd_data(e, st.merge.c2.w, t_a, t_b, B, rin, rin, 2));        // da1 -> t_b [Min, C]
         GG_TRY(bn_bwd(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, t_b, t_c, t_a));                        // dy1 -> t_a
         if (e.tr(st.merge.c1.w.t_w)) GG_TRY(dense_wgrad(e, st.merge.c1.w, e.A(xin), Cin, t_a, C, Min, nullptr, 0, t_b, t_c, false));
         GG_TRY(gemm(e, t_a, C, e.Wt(st.merge.c1.w), st.merge.c1.w.Np, dx, Cin, Min, Cin, C));             // dx_in -> dx
     }
+    e.done(1);
     // ---- stage 0: MBConv backward ----
     const int mid = (int)(d[0] * c.mbconv_expand_ratio);
     const int rps0 = H0 * H0;
@@ -783,8 +836,8 @@ static int backward_impl(Exec& e, const float* d_out) {
         const MBConvL& l = m.mb[i]; const MBAct& a = L.mb[i];
         slot -= 1;
         const float* s0 = e.dropv(slot);
-        bf16* t_a = (dx == G0) ? G1 : G0;
-        bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+        act_t* t_a = (dx == G0) ? G1 : G0;
+        act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
         // out = gelu(x + s*BN3(y3)):  dz(=dpre, also the skip gradient) -> t_b, dy3 -> t_a
         GG_TRY(bn_bwd(e, l.c3.bn, a.c3, M0, GG_ACT_GELU, dx, t_b, t_a, e.A(a.x), s0, rps0));
         // (a2 exists: the forward only skips it when its `trainable` mask freezes conv3 -- the two calls must get the same mask)
@@ -792,7 +845,7 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (e.fuse_bngemm && !e.tr(l.c1.w.t_w) && !e.tr(l.c2.w.t_w) && mid % 64 == 0) {
             GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));                   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
-            bf16* dz1;
+            act_t* dz1;
             if (e.fuse_bnbwd && e.fuse_bnbwd_epi) {
                 GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
                                                    e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
@@ -806,7 +859,7 @@ static int backward_impl(Exec& e, const float* d_out) {
                                                        nullptr, nullptr, nullptr, 0, nullptr, e.st));
                 } else {
                     GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));   // dy2 -> t_a
-                    GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));             // da1 -> t_c
+                    GG_TRY(dw_bwd_data(e, l.c2.w, t_a, t_c, B, H0, H0, 1));             // da1 -> t_c
                 }
                 GG_TRY(bn_bwd_reduce_fin(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d));                        // dz1 -> t_d
                 dz1 = t_d;
@@ -822,7 +875,7 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                // dy2 -> t_a
             if (e.tr(l.c2.w.t_w)) {
                 if (e.fuse_dw || e.fuse_dw_s1) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
-                GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+                GG_TRY(dw_bwd_weight(e, l.c2.w, e.A(a.a1), t_a, B, H0, H0, 1));
             }
             GG_TRY(gg_dwconv3x3_bwd_data_fused(t_a, nullptr, nullptr, e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y), e.F(a.c1.stat),
                                                e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
@@ -839,9 +892,9 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(bn_bwd(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy2 -> t_a
             if (e.tr(l.c2.w.t_w)) {
                 if (e.fuse_dw || e.fuse_dw_s1) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));             // act1 was fused away in forward
-                GG_TRY(gg_dwconv3x3_bwd_weight(e.A(a.a1), t_a, B, H0, H0, mid, 1, e.F(L.bnscratch), e.Gd(l.c2.w.t_w), 1, e.st));
+                GG_TRY(dw_bwd_weight(e, l.c2.w, e.A(a.a1), t_a, B, H0, H0, 1));
             }
-            GG_TRY(gg_dwconv3x3_bwd_data(t_a, e.Taps(l.c2.w), t_c, B, H0, H0, mid, 1, e.st));           // da1 -> t_c
+            GG_TRY(dw_bwd_data(e, l.c2.w, t_a, t_c, B, H0, H0, 1));           // da1 -> t_c
             GG_TRY(bn_bwd(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d, t_a));                              // dy1 -> t_a
         } else {
             // frozen taps: 3 streaming passes instead of 5.  reduce(c2) -> dz2; the depthwise data gradient forms dy2 from
@@ -858,10 +911,11 @@ static int backward_impl(Exec& e, const float* d_out) {
         // dx_in = dy1 . W1 + dpre
         GG_TRY(gemm(e, t_a, mid, e.Wt(l.c1.w), l.c1.w.Np, dx, d[0], M0, d[0], mid, nullptr, 0, nullptr, nullptr, 0, t_b));
     }
+    e.done(0);
     // ---- PatchEmbed backward (dgrad only to conv1's output; the image needs no gradient) ----
     {
-        bf16* t_a = (dx == G0) ? G1 : G0;
-        bf16* t_b = G2; bf16* t_c = G3; bf16* t_d = G4;
+        act_t* t_a = (dx == G0) ? G1 : G0;
+        act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
         const bool need1 = e.tr(m.pe1.w.t_w) || e.tr(m.pe1.bn.t_g);
         const bool need2 = e.tr(m.pe2.w.t_w) || e.tr(m.pe2.bn.t_g) || need1;
         if (need2) {
@@ -874,23 +928,26 @@ static int backward_impl(Exec& e, const float* d_out) {
                 // col2im + BN1-backward reduce in one pass (dz1 -> t_d; da1 and dy1 are never formed), weight gradient from (dz1, y1, coef)
                 GG_TRY(convnorm_wgrad_from_dz(e, m.pe1, L.pe1, M1, GG_ACT_GELU, nullptr, t_d, e.A(L.col1), 32, t_b, B, H1, H1));
             } else {
-                GG_TRY(gg_col2im_nhwc_bf16(t_b, t_c, B, H1, H1, d[0] / 2, 2, e.st));                       // da1 -> t_c [M1, C0/2]
+                if (e.f32) GG_TRY(gg_col2im_nhwc_f32((const float*)t_b, (float*)t_c, B, H1, H1, d[0] / 2, 2, e.st));
+                else GG_TRY(gg_col2im_nhwc_bf16(t_b, t_c, B, H1, H1, d[0] / 2, 2, e.st));                  // da1 -> t_c [M1, C0/2]
                 GG_TRY(bn_bwd(e, m.pe1.bn, L.pe1, M1, GG_ACT_GELU, t_c, t_d, t_a));                         // dy1 -> t_a
                 if (e.tr(m.pe1.w.t_w)) GG_TRY(dense_wgrad(e, m.pe1.w, e.A(L.col1), 32, t_a, d[0] / 2, M1, nullptr, 0, t_b, t_c, true));
             }
         }
     }
+    e.done(-1);
     return 0;
 }
 
-__global__ void repack_weight_kernel(const float* __restrict__ src, int N, int cin, int taps, bf16* __restrict__ Wn, int ldn,
-                                     bf16* __restrict__ Wt, int ldt) {
+template <typename T>
+__global__ void repack_weight_kernel(const float* __restrict__ src, int N, int cin, int taps, T* __restrict__ Wn, int ldn,
+                                     T* __restrict__ Wt, int ldt) {
     const int K = cin * taps;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * K) return;
     const int co = i / K, k = i % K;
     const int tap = k / cin, ci = k % cin;
-    const bf16 v = (bf16)src[((int64_t)co * cin + ci) * taps + tap];
+    const T v = (T)src[((int64_t)co * cin + ci) * taps + tap];
     Wn[(int64_t)co * ldn + k] = v;
     Wt[(int64_t)k * ldt + co] = v;
 }
@@ -902,8 +959,12 @@ __global__ void repack_taps_kernel(const float* __restrict__ src, int C, float* 
 }
 static int repack_dense(const DenseW& w, const float* params, const Model& m, char* wc, hipStream_t st) {
     const int n = w.N * w.K;
-    hipLaunchKernelGGL(repack_weight_kernel, dim3((unsigned)gg_cdiv(n, 256)), dim3(256), 0, st, params + m.tensors[w.t_w].offset, w.N,
-                       w.cin, w.taps, reinterpret_cast<bf16*>(wc + w.wn), w.Kp, reinterpret_cast<bf16*>(wc + w.wt), w.Np);
+    if (m.f32)
+        hipLaunchKernelGGL(repack_weight_kernel<float>, dim3((unsigned)gg_cdiv(n, 256)), dim3(256), 0, st, params + m.tensors[w.t_w].offset, w.N,
+                           w.cin, w.taps, reinterpret_cast<float*>(wc + w.wn), w.Kp, reinterpret_cast<float*>(wc + w.wt), w.Np);
+    else
+        hipLaunchKernelGGL(repack_weight_kernel<bf16>, dim3((unsigned)gg_cdiv(n, 256)), dim3(256), 0, st, params + m.tensors[w.t_w].offset, w.N,
+                           w.cin, w.taps, reinterpret_cast<bf16*>(wc + w.wn), w.Kp, reinterpret_cast<bf16*>(wc + w.wt), w.Np);
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -989,8 +1050,9 @@ extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* 
             GG_TRY(repack_dense(b.fc1, params, m, wc, st));
             GG_TRY(repack_dense(b.fc2, params, m, wc, st));
             GG_TRY(repack_dw(b.local.w, params, m, wc, st));
-            GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws, kAttnScale,
-                                            wc + b.bias_full, stream));
+            if (b.bias_full >= 0)
+                GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws, kAttnScale,
+                                                wc + b.bias_full, stream));
         }
     }
     return 0;
@@ -1008,10 +1070,12 @@ extern "C" int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int traini
     e.m = &m; e.L = &L; e.B = batch; e.training = training != 0; e.params = params; e.buffers = buffers; e.counters = counters;
     e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = nullptr;
     e.trainable = trainable;       // NULL: keep every activation a weight gradient could need
+    e.exec_init();
     return forward_impl(e, x, out);
 }
 extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,
-                                   void* workspace, const float* d_out, float* grads, const uint8_t* trainable, void* stream) {
+                                   void* workspace, const float* d_out, float* grads, const uint8_t* trainable, void* stream,
+                                   GgStageDoneFn stage_done, void* stage_user) {
     Model m;
     GG_TRY(build_model(cfg, m));
     GG_CHECK(batch > 0 && params && wcache && workspace && d_out && grads, "gg_tinyvit_backward: null pointer / bad batch");
@@ -1020,6 +1084,7 @@ extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const flo
     Exec e;
     e.m = &m; e.L = &L; e.B = batch; e.training = true; e.params = params; e.buffers = nullptr; e.counters = nullptr;
     e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = grads;
-    e.trainable = trainable;
+    e.trainable = trainable; e.stage_done = stage_done; e.stage_user = stage_user;
+    e.exec_init();
     return backward_impl(e, d_out);
 }

@@ -124,3 +124,44 @@ def build_prototypes(panorama_embeddings: torch.Tensor, cluster_of_panorama: Seq
     dev = emb.device
     protos = ops.segment_mean(emb.contiguous(), torch.from_numpy(ptr).to(dev), torch.from_numpy(order.astype(np.int64)).to(dev))
     return protos, torch.from_numpy(counts)
+
+
+def build_prototypes_from_members(panorama_embeddings: torch.Tensor, ptr, member, latlon_by_index=None) -> torch.Tensor:
+    """``Embeddings.generate_embeddings`` (models/proto_refiner.py:461-517) for every cluster of a CSR member list, on the GPU:
+    members outside [0, P) or whose (lat, lon) row is not finite are skipped (:469-474), each member's (V, D) embedding is
+    averaged over its views (:483-485, ``gg_view_mean_fwd``), a cluster's vectors are summed in LIST order in fp32 and divided
+    by the number of valid members, an empty cluster is the zero vector (``gg_segment_mean``).  Bit-exact against the reference's
+    running CPU sum (tests/golden/proto_mean.npz).  Returns (num_clusters, D) float32 on the GPU."""
+    emb = panorama_embeddings.to(torch.float32).contiguous()
+    if emb.dim() == 3:
+        emb = ops.view_mean_f32(emb)
+    P = emb.shape[0]
+    ptr = np.asarray(ptr, np.int64); member = np.asarray(member, np.int64)
+    ok = (member >= 0) & (member < P)
+    if latlon_by_index is not None:
+        ll = np.asarray(latlon_by_index, np.float64)
+        ok &= member < len(ll)
+        fin = np.zeros(member.shape, bool)
+        fin[ok] = np.isfinite(ll[member[ok]]).all(axis=1)
+        ok &= fin
+    seg = np.repeat(np.arange(len(ptr) - 1), np.diff(ptr))
+    counts = np.bincount(seg[ok], minlength=len(ptr) - 1)
+    ptr2 = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    dev = emb.device
+    return ops.segment_mean(emb, torch.from_numpy(ptr2).to(dev), torch.from_numpy(member[ok]).to(dev))
+
+
+def read_panorama_embeddings(db_path: str):
+    """Embedding database -> ((P, V, D) float32 array, (P, 2) (lat, lon)): panorama i = the i-th distinct ``location_id`` in key
+    order, its views ordered by heading (every location must have the same number of views)."""
+    recs, emb = read_embeddings(db_path)
+    if not recs:
+        raise ValueError(f"no embeddings in {db_path}")
+    locs: List[str] = []
+    for r in recs:
+        if not locs or locs[-1] != r["location_id"]:
+            locs.append(r["location_id"])
+    V = len(recs) // len(locs)
+    assert V * len(locs) == len(recs), "every location needs the same number of heading views"
+    latlon = np.asarray([[recs[i * V]["lat"], recs[i * V]["lon"]] for i in range(len(locs))], np.float64)
+    return emb.reshape(len(locs), V, -1), latlon

@@ -3,10 +3,10 @@
 candidate_probs) -> (loss, preds_LLH, preds_geocell)`` contract, executed as ONE HIP launch over the whole batch
 (``gg_proto_refine``) instead of the reference's Python double loop with a ``.item()`` sync per candidate.
 
-The prototype store is a CSR table on the device (``cell_ptr``, ``proto_emb``, ``proto_lnglat``) built from whatever the
-caller has: a ``proto_df``-like table + per-cluster mean embeddings (``from_clusters``), i.e. the data the reference
-keeps as one HF ``Dataset`` per geocell (:104-113).  Building prototypes by embedding the training set (:271-345,
-:409-517) is the offline job of SURVEY.md row f2 and is out of scope here.
+The prototype store is a CSR table on the device (``cell_ptr``, ``proto_emb``, ``proto_lnglat``) holding what the reference
+keeps as one HF ``Dataset`` per geocell (:104-113).  The constructor builds it the reference's way -- ``proto_path`` CSV ->
+``ProtoDataManager`` -> per-cluster mean embeddings (built on the GPU by ``gg_segment_mean`` or loaded from
+``data/geocells/protos/proto_{i}``) -- or from a ready table (``from_clusters``).
 
 Within-cluster refinement (:239-269) uses the cluster centroid -- the only branch that can execute in the reference as
 shipped (``self.dataset`` is undefined at :254).
@@ -24,25 +24,120 @@ from torch.nn.parameter import Parameter
 from .. import _lib as L
 
 
+PROTO_PATH = "data/geocells/proto_df.csv"            # models/proto_refiner.py:25
+PROTOS_DIR = "data/geocells/protos"                   # models/proto_refiner.py:101,107 (proto_{i} HF datasets)
+
+
 class ProtoRefiner(nn.Module):
-    def __init__(self, topk: int = 5, max_refinement: int = 1000, temperature: float = 1.6, proto_path: str = None,
-                 protos=None, verbose: bool = False, clip_db_path: str = None, tinyvit_db_path: str = None,
-                 backend: str = "clip", cell_ptr=None, proto_emb=None, proto_lnglat=None):
+    """Constructor = the reference's (:33-118): ``proto_path`` is read into a ``ProtoDataManager``; ``protos=None`` BUILDS the
+    prototypes (per-cluster mean embedding of the member panoramas, :271-345,461-517) and saves them under ``protos_dir`` as one
+    HF dataset per geocell, any other ``protos`` LOADS them from there (:104-113) -- or takes a ready list of per-cell tables.
+    The per-panorama embeddings the build needs come from ``embeddings=`` ((P, V, D) / (P, D), row = the sample index the
+    ``indices`` column refers to) or from the backend's embedding database (``clip_db_path`` / ``tinyvit_db_path``, the
+    reference's precomputed-embedding SQLite layout; panorama i = i-th location in key order); the reference instead re-embeds
+    the images on the fly (``Embeddings``, :409-459), which needs its image database.
+    Extra keyword-only ways in: ``cell_ptr/proto_emb/proto_lnglat`` (a ready CSR table) and ``from_clusters``."""
+
+    def __init__(self, topk: int = 5, max_refinement: int = 1000, temperature: float = 1.6, proto_path: str = PROTO_PATH,
+                 protos=None, verbose: bool = False, clip_db_path: str = "data/sqlite/clip/dataset.sqlite",
+                 tinyvit_db_path: str = "data/sqlite/tinyvit/dataset.sqlite", backend: str = "clip", cell_ptr=None, proto_emb=None,
+                 proto_lnglat=None, embeddings=None, latlon_by_index=None, protos_dir: str = PROTOS_DIR, save_protos: bool = True):
         super().__init__()
         self.topk = topk
         self.max_refinement = max_refinement
         self.verbose = verbose
+        backend = (backend or "clip").lower()
+        if backend not in ("clip", "tinyvit"):
+            raise ValueError("backend must be 'clip' or 'tinyvit'")          # :413-414
         self.backend = backend
         self.temperature = Parameter(torch.tensor(float(temperature)), requires_grad=False)
         self.geo_scaling = Parameter(torch.tensor(20.0), requires_grad=False)
         if cell_ptr is None:
-            raise L.GgError("ProtoRefiner needs a prototype table: pass cell_ptr/proto_emb/proto_lnglat or use "
-                            "ProtoRefiner.from_clusters(...) (building prototypes from the image database is offline work)")
+            import pandas as pd
+            from .utils import ProtoDataManager
+            self.proto_df = pd.read_csv(proto_path)                           # FileNotFoundError like the reference (:79)
+            self.proto_manager = ProtoDataManager(self.proto_df)
+            self.proto_df["geocell_index"] = self.proto_df["geocell_index"].astype(int)
+            num_geocells = int(self.proto_df["geocell_index"].max()) + 1
+            if protos is None:
+                tab = self._build_prototypes(embeddings, latlon_by_index, clip_db_path if backend == "clip" else tinyvit_db_path)
+                if save_protos and protos_dir:
+                    self._save_protos(tab, num_geocells, protos_dir)
+            elif isinstance(protos, (list, tuple)):
+                if len(protos) != num_geocells:
+                    raise ValueError("Number of loaded prototypes does not match number of geocells.")      # :92-95
+                tab = self._table_from_cells(list(protos))
+            else:
+                tab = self._table_from_cells(self._load_protos(num_geocells, protos_dir))
+                if verbose:
+                    print("Loaded prototypes from disk.")
+            gi = tab["geocell_index"]
+            order = np.argsort(gi, kind="stable")
+            cell_ptr = np.concatenate([[0], np.cumsum(np.bincount(gi, minlength=num_geocells))]).astype(np.int64)
+            proto_emb = np.asarray(tab["embedding"], np.float32)[order]
+            proto_lnglat = np.stack([tab["centroid_lng"], tab["centroid_lat"]], 1).astype(np.float32)[order]
         self.register_buffer("cell_ptr", torch.as_tensor(np.asarray(cell_ptr), dtype=torch.int64).contiguous())
         self.register_buffer("proto_emb", torch.as_tensor(np.asarray(proto_emb), dtype=torch.float32).contiguous())
         self.register_buffer("proto_lnglat", torch.as_tensor(np.asarray(proto_lnglat), dtype=torch.float32).contiguous())
         self.num_geocells = self.cell_ptr.numel() - 1
         assert self.proto_emb.shape[0] == self.proto_lnglat.shape[0] == int(self.cell_ptr[-1])
+
+    # ---- prototype build / load (models/proto_refiner.py:271-345) ---------------------------------------------------------
+    def _build_prototypes(self, embeddings, latlon_by_index, db_path):
+        from ..embedding_store import build_prototypes_from_members, read_panorama_embeddings
+        L.require_gpu()
+        if embeddings is None:
+            import os
+            if not os.path.exists(db_path):
+                raise FileNotFoundError(f"ProtoRefiner(protos=None) builds prototypes from per-panorama embeddings: pass embeddings= or "
+                                        f"provide the {self.backend} embedding database at '{db_path}'")
+            embeddings, latlon_by_index = read_panorama_embeddings(db_path)
+        tab = self.proto_manager.cluster_table()
+        emb = torch.as_tensor(np.asarray(embeddings) if not torch.is_tensor(embeddings) else embeddings).to("cuda", torch.float32)
+        protos = build_prototypes_from_members(emb, tab["ptr"], tab["member"], latlon_by_index)
+        tab["embedding"] = protos.cpu().numpy()
+        return tab
+
+    @staticmethod
+    def _table_from_cells(cells):
+        """cells[i]: None or a table (HF Dataset / dict of columns) with ``embedding`` (P_i, D), ``centroid_lng``, ``centroid_lat``."""
+        gi, emb, lng, lat = [], [], [], []
+        for i, c in enumerate(cells):
+            if c is None:
+                continue
+            e = np.asarray(c["embedding"], np.float32)
+            e = e.reshape(len(c["centroid_lng"]), -1)
+            gi += [i] * e.shape[0]; emb.append(e)
+            lng += [float(v) for v in c["centroid_lng"]]; lat += [float(v) for v in c["centroid_lat"]]
+        return dict(geocell_index=np.asarray(gi, np.int64), embedding=np.concatenate(emb, 0) if emb else np.zeros((0, 1), np.float32),
+                    centroid_lng=np.asarray(lng, np.float32), centroid_lat=np.asarray(lat, np.float32))
+
+    @staticmethod
+    def _load_protos(num_geocells: int, protos_dir: str):
+        from datasets import Dataset
+        cells = [None] * num_geocells
+        for i in range(num_geocells):
+            try:
+                cells[i] = Dataset.load_from_disk(f"{protos_dir}/proto_{i}").with_format("numpy")
+            except FileNotFoundError:
+                cells[i] = None
+        return cells
+
+    @staticmethod
+    def _save_protos(tab, num_geocells: int, protos_dir: str):
+        """One HF dataset per geocell with the proto_df columns + ``embedding`` (:97-101)."""
+        from datasets import Dataset
+        import os
+        os.makedirs(protos_dir, exist_ok=True)
+        gi = tab["geocell_index"]
+        for i in range(num_geocells):
+            rows = np.nonzero(gi == i)[0]
+            if rows.size == 0:
+                continue
+            Dataset.from_dict(dict(geocell_index=[int(i)] * rows.size, count=[int(v) for v in tab["count"][rows]],
+                                   centroid_lat=[float(v) for v in tab["centroid_lat"][rows]],
+                                   centroid_lng=[float(v) for v in tab["centroid_lng"][rows]],
+                                   embedding=[tab["embedding"][r].tolist() for r in rows])).save_to_disk(f"{protos_dir}/proto_{i}")
 
     @classmethod
     def from_clusters(cls, geocell_index: Sequence[int], embeddings, centroid_lng, centroid_lat, num_geocells: int, **kw):

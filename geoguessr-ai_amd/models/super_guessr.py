@@ -47,16 +47,21 @@ class _HeadFn(torch.autograd.Function):
         K = weight.shape[0]
         Kp = (K + 7) // 8 * 8
         dev = emb.device
-        xm = torch.empty((N, Cc), dtype=torch.bfloat16, device=dev)
-        L.check(L.lib().gg_view_mean_fwd(L.ptr(emb), L.ptr(xm), Cc, N, V, Cc, L.stream()), "gg_view_mean_fwd")
-        wn, wt = model._weight_cache()
+        f32 = model.precision == "fp32"
+        if f32:      # reference precision: f32 view mean, f32 MFMA logits, f32 dlogits (models/super_guessr.py:347,354 are fp32)
+            xm = ops.view_mean_f32(emb.view(N, V, Cc))
+            wn, wt = weight.detach(), None
+        else:
+            xm = torch.empty((N, Cc), dtype=torch.bfloat16, device=dev)
+            L.check(L.lib().gg_view_mean_fwd(L.ptr(emb), L.ptr(xm), Cc, N, V, Cc, L.stream()), "gg_view_mean_fwd")
+            wn, wt = model._weight_cache()
         logits = torch.empty((N, Kp), dtype=torch.float32, device=dev)
         ops.gemm_nt(xm, wn, bias=bias.detach(), out_f32=True, out=logits, N=K, ldc=Kp)
         need_grad = mode != 0 and any(ctx.needs_input_grad)      # grad mode is off inside Function.forward
         r = ops.geo_head(logits, model.geocell_centroid_coords.data, labels=labels, labels_clf=labels_clf, mode=mode,
                          smoothing_km=float(LABEL_SMOOTHING_CONSTANT), want_dlogits=need_grad,
-                         num_candidates=model.num_candidates, K=K)
-        ctx.model, ctx.dims, ctx.need = model, (N, V, Cc, K, Kp, embedding.dim()), need_grad
+                         num_candidates=model.num_candidates, K=K, dlogits_f32=f32)
+        ctx.model, ctx.dims, ctx.need, ctx.f32 = model, (N, V, Cc, K, Kp, embedding.dim()), need_grad, f32
         if need_grad:
             ctx.save_for_backward(xm, r["dlogits"])
         outs = (r["loss"].view(()), r["preds"], r["llh"], r["topk_vals"], r["topk_idx"])
@@ -71,19 +76,27 @@ class _HeadFn(torch.autograd.Function):
         xm, dlogits = ctx.saved_tensors
         model = ctx.model
         g = g_loss.to(torch.float32).reshape(1).contiguous()      # upstream scalar, applied as a per-row scale on device
-        wn, wt = model._weight_cache()
-        dxm = ops.gemm_nt(dlogits, wt, rowscale=g, rows_per_scale=N, K=Kp)            # (N, C) bf16
         demb = torch.empty((N, V, Cc), dtype=torch.float32, device=xm.device)
-        L.check(L.lib().gg_view_mean_bwd(L.ptr(dxm), Cc, L.ptr(demb), N, V, Cc, L.stream()), "gg_view_mean_bwd")
+        dW = db = None
+        if ctx.f32:
+            wt = model._weight_t_f32()                                                  # (C, Kp) f32
+            dxm = ops.gemm_nt(dlogits, wt, rowscale=g, rows_per_scale=N, K=Kp)            # (N, C) f32
+            L.check(L.lib().gg_view_mean_bwd_f32(L.ptr(dxm), Cc, L.ptr(demb), N, V, Cc, L.stream()), "gg_view_mean_bwd_f32")
+            if model.cell_layer.weight.requires_grad:
+                dW = ops.gemm_tn(dlogits, xm, rowscale=g, rows_per_scale=N)[:K]          # (K, C) f32: dlogits^T . xm, no transposed copies
+                db = ops.colsum_bf16(dlogits, rowscale=g, rows_per_scale=N)[:K]
+        else:
+            wn, wt = model._weight_cache()
+            dxm = ops.gemm_nt(dlogits, wt, rowscale=g, rows_per_scale=N, K=Kp)            # (N, C) bf16
+            L.check(L.lib().gg_view_mean_bwd(L.ptr(dxm), Cc, L.ptr(demb), N, V, Cc, L.stream()), "gg_view_mean_bwd")
+            if model.cell_layer.weight.requires_grad:
+                dl = dlogits[:, :K]
+                dlT = ops.transpose_bf16(dl, rowscale=g, rows_per_scale=N)                  # (K, Np)
+                xT = ops.transpose_bf16(xm)                                                 # (C, Np)
+                dW = ops.gemm_nt(dlT, xT, out_f32=True)                                      # (K, C) f32
+                db = ops.colsum_bf16(dl, rowscale=g, rows_per_scale=N)
         if edim == 2:
             demb = demb.view(N, Cc)
-        dW = db = None
-        if model.cell_layer.weight.requires_grad:
-            dl = dlogits[:, :K]
-            dlT = ops.transpose_bf16(dl, rowscale=g, rows_per_scale=N)                  # (K, Np)
-            xT = ops.transpose_bf16(xm)                                                 # (C, Np)
-            dW = ops.gemm_nt(dlT, xT, out_f32=True)                                      # (K, C) f32
-            db = ops.colsum_bf16(dl, rowscale=g, rows_per_scale=N)
         return None, demb, dW, db, None, None, None
 
 
@@ -101,8 +114,16 @@ class _CellLayer(nn.Module):
 class SuperGuessr(nn.Module):
     def __init__(self, base_model: Optional[nn.Module], panorama: bool = False, hierarchical: bool = False,
                  should_smooth_labels: bool = False, serving: bool = False, freeze_base: bool = False,
-                 num_candidates: int = 5, embed_dim: int = CLIP_EMBED_DIM, centroids=None, **kwargs):
+                 num_candidates: int = 5, embed_dim: int = CLIP_EMBED_DIM, centroids=None, precision: Optional[str] = None, **kwargs):
+        """``centroids`` / ``precision`` are not in the reference: the geocell centroid table as data (C7/C8) and the arithmetic of
+        the head ("bf16" | "fp32"; default: the base model's, else ``$GG_PRECISION``, else bf16)."""
         super().__init__()
+        from .tinyvit import PRECISIONS, default_precision
+        bb_prec = getattr(getattr(base_model, "backbone", None), "precision", None)
+        self.precision = precision or bb_prec or default_precision()
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision='{self.precision}' (known: bf16, fp32)")
+        self.precision = "fp32" if PRECISIONS[self.precision] == 1 else "bf16"
         if len(kwargs) > 0:
             print(f"Not using keyword arguments: {list(kwargs.keys())}")
         if hierarchical:
@@ -189,6 +210,19 @@ class SuperGuessr(nn.Module):
                                                   L.ptr(self._wc[1]), Kp, L.stream()), "gg_cast_transpose_f32")
             self._wc_version, self._wc_dirty = ver, False
         return self._wc
+
+    def _weight_t_f32(self):
+        """(C, Kpad) f32 transpose of the head weight for the f32 dgrad (dlogits . W as an NT GEMM)."""
+        w = self.cell_layer.weight
+        ver = (w._version, w.data_ptr())
+        if getattr(self, "_wt32", None) is None or self._wt32_version != ver or getattr(self, "_wc_dirty", False) or self._wt32.device != w.device:
+            K, Cc = w.shape
+            Kp = (K + 7) // 8 * 8
+            if getattr(self, "_wt32", None) is None or self._wt32.device != w.device:
+                self._wt32 = torch.zeros((Cc, Kp), dtype=torch.float32, device=w.device)
+            self._wt32[:, :K].copy_(w.detach().t())         # device-side strided copy (data movement only)
+            self._wt32_version, self._wc_dirty = ver, False
+        return self._wt32
 
     def mark_params_dirty(self):
         self._wc_dirty = True

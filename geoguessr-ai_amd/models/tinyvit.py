@@ -37,6 +37,18 @@ VARIANTS = {
 DEPTHS = (2, 2, 6, 2)
 
 
+PRECISIONS = {"bf16": 0, "bfloat16": 0, "fp32": 1, "f32": 1, "float32": 1}
+
+
+def default_precision() -> str:
+    """``GG_PRECISION`` = "bf16" (default: bf16 activations / MFMA operands, fp32 accumulation and master weights) or "fp32" (the
+    reference's own arithmetic: f32 activations, f32 MFMA, exact erf -- SURVEY.md 0.3)."""
+    p = os.environ.get("GG_PRECISION", "bf16").lower()
+    if p not in PRECISIONS:
+        raise ValueError(f"GG_PRECISION='{p}' (known: bf16, fp32)")
+    return p
+
+
 def make_cfg(model_name: str, **overrides) -> tuple:
     base = model_name.split(".")[0]
     if base not in VARIANTS:
@@ -52,6 +64,11 @@ def make_cfg(model_name: str, **overrides) -> tuple:
     c.window_sizes = (C.c_int * 4)(*v["window_sizes"])
     c.mlp_ratio, c.mbconv_expand_ratio = 4.0, 4.0
     c.bn_eps, c.ln_eps, c.bn_momentum = 1e-5, 1e-5, 0.1
+    prec = v.get("precision") or default_precision()
+    if prec not in PRECISIONS:
+        raise ValueError(f"precision='{prec}' (known: bf16, fp32)")
+    c.act_dtype = PRECISIONS[prec]
+    c.features_only = int(bool(v.get("features_only", False)))
     return c, v, depths
 
 
@@ -111,6 +128,7 @@ class TinyVitBackbone(_Tree):
         super().__init__()
         self.cfg, self.variant, self.depths = make_cfg(model_name, **overrides)
         self.model_name = model_name.split(".")[0]
+        self.precision = "fp32" if self.cfg.act_dtype == 1 else "bf16"
         self.table = _tensor_table(self.cfg)
         lib = L.lib()
         self.num_features = int(self.variant["embed_dims"][-1])
@@ -148,6 +166,8 @@ class TinyVitBackbone(_Tree):
         self._wcache_version = -1
         self._ws: Dict[bool, torch.Tensor] = {}
         self._last = None
+        self._gen = 0                    # generation of the training workspace contents (one per training forward)
+        self._grad_ready_hook = None     # set by optim.AdamW.overlap_allreduce: fn(lo, hi) over flat gradient floats
 
     # -- module tree helpers ---------------------------------------------------------------------------
     def _walk(self, name: str):
@@ -192,9 +212,6 @@ class TinyVitBackbone(_Tree):
                 parent._buffers[leaf] = cnt[t["offset"]]
         self._flat, self._flat_buf, self._counters, self._flat_grad = flat, buf, cnt, grad
         self._wcache, self._wcache_version, self._ws = None, -1, {}
-
-    def _load_from_state_dict(self, *a, **k):
-        super()._load_from_state_dict(*a, **k)
 
     # -- flat views used by the optimizer / all-reduce ---------------------------------------------------
     @property
@@ -244,6 +261,12 @@ class TinyVitBackbone(_Tree):
     def mark_params_dirty(self):
         self._wcache_version = -1
 
+    def _param_version(self):
+        """Changes whenever any parameter is written through torch (``torch.optim`` steps, ``load_state_dict``, ``p.copy_``):
+        after ``_reflatten`` every Parameter is its own view with its own version counter, so the flat buffer's counter alone
+        misses those writes.  Raw-pointer writers (the fused AdamW kernel) call ``mark_params_dirty`` instead."""
+        return (self._flat._version, sum(p._version for p in self._params.values()), self._flat.data_ptr())
+
     # -- HIP calls ------------------------------------------------------------------------------------------
     def _ensure_weights(self):
         lib = L.lib()
@@ -251,10 +274,11 @@ class TinyVitBackbone(_Tree):
             nbytes = lib.gg_tinyvit_wcache_bytes(C.byref(self.cfg))
             self._wcache = torch.zeros(nbytes, dtype=torch.uint8, device=self._flat.device)
             self._wcache_version = -1
-        if self._wcache_version != self._flat._version:
+        ver = self._param_version()
+        if self._wcache_version != ver:
             L.check(lib.gg_tinyvit_refresh_weights(C.byref(self.cfg), L.ptr(self._flat, torch.float32, "params"),
                                                    L.ptr(self._wcache), L.stream()), "gg_tinyvit_refresh_weights")
-            self._wcache_version = self._flat._version
+            self._wcache_version = ver
 
     def _workspace(self, batch: int, training: bool) -> torch.Tensor:
         need = L.lib().gg_tinyvit_workspace_bytes(C.byref(self.cfg), batch, int(training))
@@ -299,11 +323,35 @@ class TinyVitBackbone(_Tree):
         if training:
             self._counters += 1          # num_batches_tracked (int64 bookkeeping)
             self._flat_buf_dirty = True
-        self._last = (B, drop_scales)
+            self._gen += 1
+            self._last = (B, drop_scales, self._gen)
         return out
 
-    def backward_hip(self, d_out: torch.Tensor):
-        B, drop = self._last
+    def _stage_ranges(self):
+        """Flat float range of each backward stage id: 3, 2, 1 (TinyVitStages), 0 (MBConv stage), -1 (patch_embed); the range of
+        stage 3 also holds head.norm (final before the stage loop starts)."""
+        if getattr(self, "_stage_rng", None) is None:
+            first = {}
+            for t in self.table:
+                if t["kind"] != 0:
+                    continue
+                key = -1 if t["name"].startswith("patch_embed.") else (int(t["name"].split(".")[1]) if t["name"].startswith("stages.") else 4)
+                first.setdefault(key, t["offset"])
+            order = [-1, 0, 1, 2, 3]
+            ends = {k: (first[order[i + 1]] if i + 1 < len(order) else self.param_floats) for i, k in enumerate(order)}
+            self._stage_rng = {k: (first[k], ends[k]) for k in order}
+        return self._stage_rng
+
+    def backward_hip(self, d_out: torch.Tensor, gen: Optional[int] = None):
+        if self._last is None:
+            raise L.GgError("TinyViT backward without a training forward")
+        B, drop, last_gen = self._last
+        if gen is not None and gen != last_gen:
+            raise L.GgError(f"TinyViT backward for training forward #{gen}, but the workspace now holds the activations of forward "
+                            f"#{last_gen}: saved activations live in ONE workspace per backbone, so every training forward must be "
+                            "followed by its backward before the next training forward")
+        if d_out.shape[0] != B:
+            raise L.GgError(f"TinyViT backward: gradient batch {d_out.shape[0]} != forward batch {B}")
         fg = self.attach_grads()
         ws = self._ws[True]
         mask = self.trainable_mask()
@@ -312,8 +360,13 @@ class TinyVitBackbone(_Tree):
             if extra:
                 raise L.GgError("requires_grad was switched on between forward and backward for " + ", ".join(extra[:4]) +
                                 " ...: the training forward fused away activations their weight gradients need; run the forward again")
+        hook = self._grad_ready_hook
+        cb = L.STAGE_DONE_FN(0)
+        if hook is not None:
+            rng = self._stage_ranges()
+            cb = L.STAGE_DONE_FN(lambda stage, _user: hook(*rng[stage]))
         L.check(L.lib().gg_tinyvit_backward(C.byref(self.cfg), B, L.ptr(self._flat), L.ptr(self._wcache), L.ptr(drop), L.ptr(ws),
-                                            L.ptr(d_out.contiguous(), torch.float32, "d_out"), L.ptr(fg), mask, L.stream()),
+                                            L.ptr(d_out.contiguous(), torch.float32, "d_out"), L.ptr(fg), mask, L.stream(), cb, None),
                 "gg_tinyvit_backward")
 
     def activation(self, name: str, batch: int) -> torch.Tensor:
@@ -348,6 +401,7 @@ class _EncoderFn(torch.autograd.Function):
         out = bb.forward_hip(x, training, drop)
         ctx.bb = bb
         ctx.valid = training and need_grad
+        ctx.gen = bb._gen
         return out
 
     @staticmethod
@@ -355,7 +409,7 @@ class _EncoderFn(torch.autograd.Function):
         if not ctx.valid:
             raise L.GgError("backward through a TinyViT forward that ran in eval mode (running-stat BatchNorm keeps no "
                             "activations); call .train() before the forward pass")
-        ctx.bb.backward_hip(d_out)
+        ctx.bb.backward_hip(d_out, ctx.gen)
         return None, None, torch.zeros((), device=d_out.device)
 
 
@@ -366,11 +420,15 @@ class TinyViTAdapter(nn.Module):
 
     def __init__(self, model_name: str = "tiny_vit_21m_512.dist_in22k_ft_in1k", pretrained: bool = True,
                  global_pool: str = "avg", features_only: bool = False, **overrides):
+        """``overrides`` (not in the reference): ``precision="bf16"|"fp32"`` (default ``$GG_PRECISION`` or bf16), ``seed``,
+        ``drop_path_rate``, ``img_size`` ... (timm ``create_model`` kwargs)."""
         super().__init__()
         if global_pool != "avg":
             raise NotImplementedError("only global_pool='avg' (the reference's setting) is built")
-        self.features_only = features_only   # pooled last feature map == num_classes=0 output before head.norm; see forward
-        self.backbone = TinyVitBackbone(model_name, **overrides)
+        # features_only=True (models/tinyvit.py:38-46): timm returns the stage feature maps and the adapter's forward pools the last
+        # one (:139-143) -- i.e. the encoder output WITHOUT head.norm; the runtime writes exactly that vector
+        self.features_only = features_only
+        self.backbone = TinyVitBackbone(model_name, features_only=features_only, **overrides)
         hidden = self.backbone.num_features
         self.config = SimpleNamespace(hidden_size=hidden, hidden_sizes=[hidden], _name_or_path=model_name)
         stages = self.backbone._modules["stages"]
@@ -384,8 +442,6 @@ class TinyViTAdapter(nn.Module):
             else:
                 warnings.warn(f"pretrained weights for {model_name} not available offline (set GG_PRETRAINED_DIR); "
                               "using the timm initialisation")
-        if features_only:
-            raise NotImplementedError("features_only=True (list of feature maps) is not on the reference's hot path")
 
     def build_transform(self):
         raise RuntimeError("timm data transforms not available in this environment.")   # models/tinyvit.py:83-86

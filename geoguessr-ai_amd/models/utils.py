@@ -1,12 +1,15 @@
 """Drop-in for the reference's ``models/utils.py``: ``ModelOutput`` (:12-17), ``smooth_labels`` (:20-32),
-``haversine_matrix`` (:39-57), tolerant ``load_state_dict`` (:74-95).  The two geo functions run as HIP kernels
+``haversine_matrix`` (:39-57), ``predict`` (:60-71), tolerant ``load_state_dict`` (:74-95), ``ProtoDataManager`` (:98-181).  The two geo functions run as HIP kernels
 (``csrc/geo.hip``); inside the training step they are not called at all -- the fused head kernel computes
 distances, argmin, soft targets and the loss in one pass."""
 from __future__ import annotations
 
+import ast
 from collections import namedtuple
-from typing import Dict
+from typing import Any, Dict, List, Tuple
 
+import numpy as np
+import pandas as pd
 import torch
 from torch import Tensor
 from torch.nn.parameter import Parameter
@@ -42,3 +45,105 @@ def load_state_dict(self, state_dict: Dict, embedder: bool = False):
         if isinstance(param, Parameter):
             param = param.data
         own_state[name].copy_(param)
+
+
+PredictionOutput = namedtuple("PredictionOutput", "predictions label_ids metrics")
+
+
+def predict(model: Any, dataset, batch_size: int = 8) -> Tuple:
+    """models/utils.py:60-71 (``Trainer(model=model).predict(dataset)``) without the HF Trainer: the model is run in eval mode over
+    the dataset in order (Trainer's default eval batch size is 8) and the per-batch outputs are concatenated.  Returns
+    ``PredictionOutput(predictions, label_ids, metrics)`` like ``Trainer.predict``: ``predictions`` = the model output fields after
+    the loss as numpy arrays (Trainer drops the loss entry when labels are given), ``label_ids`` = (labels, labels_clf) where
+    present, ``metrics`` = {"test_loss": row-weighted mean loss} when the model returned one."""
+    from ..training.train_eval_loop import MODEL_KEYS, _num_rows, _take
+    was_training = model.training
+    model.eval()
+    cols, loss_sum, n_seen = None, 0.0, 0
+    n = _num_rows(dataset)
+    with torch.no_grad():
+        for s0 in range(0, n, batch_size):
+            data = _take(dataset, torch.arange(s0, min(n, s0 + batch_size)))
+            out = model(**{k: v for k, v in data.items() if k in MODEL_KEYS})
+            if isinstance(out, tuple) and not hasattr(out, "_fields"):           # serving tuple (pred_LLH, topk, embedding)
+                fields = [out[0], out[1].values, out[1].indices, out[2]]
+            else:
+                if out.loss is not None:
+                    loss_sum += float(out.loss) * _num_rows(data); n_seen += _num_rows(data)
+                fields = [out.loss_clf if out.loss_clf is None else out.loss_clf.reshape(1), out.preds_LLH, out.preds_geocell,
+                          out.top5_geocells.values, out.top5_geocells.indices, out.embedding][1:]
+            arrs = [f.detach().cpu().numpy() for f in fields]
+            cols = [[a] for a in arrs] if cols is None else [c + [a] for c, a in zip(cols, arrs)]
+    model.train(was_training)
+    preds = tuple(np.concatenate(c, 0) for c in cols) if cols else ()
+    labels = tuple(np.asarray(dataset[k]) if isinstance(dataset, dict) and k in dataset else None for k in ("labels", "labels_clf"))
+    labels = tuple(l for l in labels if l is not None) or None
+    return PredictionOutput(preds, labels, {"test_loss": loss_sum / n_seen} if n_seen else {})
+
+
+class ProtoDataManager:
+    """Manages prototype data for geocell prototypes: the rows of ``proto_df.csv`` (``geocell_index, indices, count, centroid_lat,
+    centroid_lng``), grouped per geocell, with the ``indices`` column parsed into lists of ints (models/utils.py:98-181; same
+    attributes ``proto_df`` / ``geocell_indices`` and the same tolerant parsing, pinned by tests/golden/proto_manager.json)."""
+
+    def __init__(self, proto_data: pd.DataFrame):
+        self.proto_df = proto_data.copy()
+        if "geocell_index" in self.proto_df.columns:
+            self.proto_df["geocell_index"] = self.proto_df["geocell_index"].astype(int)
+        if "indices" in self.proto_df.columns:
+            self.proto_df["indices"] = self.proto_df["indices"].apply(self._parse_indices_value)
+        self.geocell_indices = self._make_geocell_indices_list()
+
+    @staticmethod
+    def _parse_indices_value(indices_val) -> List[int]:
+        """list / tuple, NaN, "", "[1, 2]", "(1, 2)", "1, 2", "7" or a bare number -> list[int]; entries that are not integers are
+        dropped (:118-154)."""
+        if isinstance(indices_val, (list, tuple)):
+            cand = list(indices_val)
+        elif not isinstance(indices_val, str) and pd.isna(indices_val):
+            cand = []
+        elif isinstance(indices_val, str):
+            text = indices_val.strip()
+            if text == "":
+                cand = []
+            else:
+                try:
+                    obj = ast.literal_eval(text)
+                except Exception:
+                    obj = [part for part in text.strip("[](){}").split(",") if part != ""]
+                cand = list(obj) if isinstance(obj, (list, tuple)) else [obj]
+        else:
+            cand = [indices_val]
+        out: List[int] = []
+        for x in cand:
+            try:
+                out.append(int(x))
+            except Exception:
+                try:
+                    out.append(int(str(x).strip()))
+                except Exception:
+                    continue
+        return out
+
+    def _make_geocell_indices_list(self) -> Dict[int, pd.DataFrame]:
+        if "geocell_index" not in self.proto_df.columns:
+            return {}
+        return {int(cell): grp.reset_index(drop=True) for cell, grp in self.proto_df.groupby("geocell_index")}
+
+    def get_indices_for_cell(self, cell_id: int) -> pd.DataFrame:
+        df = self.geocell_indices.get(cell_id, None)
+        if df is None:
+            return pd.DataFrame(columns=list(self.proto_df.columns))
+        return df
+
+    # ---- flat views for the device-side prototype table (not in the reference) -------------------------------------------
+    def cluster_table(self):
+        """Clusters in (geocell_index, file order): -> dict(geocell_index (R,), centroid_lng (R,), centroid_lat (R,), count (R,),
+        ptr (R+1,), member (sum,)) -- the CSR member lists ``gg_segment_mean`` consumes."""
+        df = self.proto_df.sort_values("geocell_index", kind="stable")
+        lists = list(df["indices"]) if "indices" in df.columns else [[] for _ in range(len(df))]
+        ptr = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int64)
+        member = np.asarray([i for l in lists for i in l], np.int64)
+        col = lambda name, dt: np.asarray(df[name], dt) if name in df.columns else np.zeros(len(df), dt)
+        return dict(geocell_index=col("geocell_index", np.int64), centroid_lng=col("centroid_lng", np.float32),
+                    centroid_lat=col("centroid_lat", np.float32), count=col("count", np.int64), ptr=ptr, member=member)

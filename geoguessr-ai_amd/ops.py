@@ -42,27 +42,33 @@ def gemm_nt(A, B, *, bias=None, act=None, preact=False, rowscale=None, rows_per_
     lda = A.stride(0) if lda is None else lda
     ldb = B.stride(0) if ldb is None else ldb
     dev = A.device
+    DT = A.dtype                     # BF16: bf16 MFMA kernels; F32: the reference-precision twins (gg_gemm_nt_f32)
+    if DT not in (BF16, F32):
+        raise L.GgError(f"gemm_nt: operands must be bf16 or f32, got {DT}")
     if out is None:
-        out = torch.empty((M, N), dtype=F32 if out_f32 else BF16, device=dev)
+        out = torch.empty((M, N), dtype=F32 if (out_f32 or DT == F32) else BF16, device=dev)
     ldc = out.stride(0) if ldc is None else ldc
-    pre = torch.empty((M, N), dtype=BF16, device=dev) if preact else None
+    pre = torch.empty((M, N), dtype=DT, device=dev) if preact else None
     stats = None
     if colstats:
         rows = L.lib().gg_gemm_colstats_rows(M)
         stats_buf = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), dtype=F32, device=dev)
         stats = stats_buf[:rows]
     a = L.GemmArgs()
-    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(A, BF16, "A"), lda, _pr(B, BF16, "B"), ldb, _pr(out), ldc
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(A, DT, "A"), lda, _pr(B, DT, "B"), ldb, _pr(out), ldc
     a.M, a.N, a.K = M, N, K
     a.bias = _p(bias, F32, "bias")
     a.act = ACT[act]
     a.preact = _p(pre)
     a.rowscale, a.rows_per_scale = _p(rowscale, F32, "rowscale"), rows_per_scale
-    a.residual, a.ldr = _p(residual, BF16, "residual"), (residual.stride(0) if residual is not None else 0)
-    a.dact_preact, a.dact = _p(dact_preact, BF16, "dact_preact"), ACT[dact]
+    a.residual, a.ldr = _p(residual, DT, "residual"), (residual.stride(0) if residual is not None else 0)
+    a.dact_preact, a.dact = _p(dact_preact, DT, "dact_preact"), ACT[dact]
     a.colstats = _p(stats)
     a.out_f32, a.split_k = int(out_f32), 1
-    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    if DT == F32:
+        L.check(L.lib().gg_gemm_nt_f32(C.byref(a), L.stream()), "gg_gemm_nt_f32")
+    else:
+        L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
     res = [out]
     if preact:
         res.append(pre)
@@ -89,10 +95,16 @@ def gemm_tn(dY, X, rowscale=None, rows_per_scale=0, accumulate_into=None):
     """f32 dW[N,K] = dY[M,N]^T @ X[M,K] (weight-gradient form, reduction over rows split across workgroups)."""
     M, N = dY.shape
     K = X.shape[1]
-    splits = L.lib().gg_gemm_tn_splits(M, N, K)
-    part = torch.empty((splits, N, K), dtype=F32, device=dY.device)
-    L.check(L.lib().gg_gemm_tn(_pr(dY, BF16, "dY"), dY.stride(0), _pr(X, BF16, "X"), X.stride(0), M, N, K, _p(rowscale, F32), rows_per_scale,
-                               _p(part), splits, L.stream()), "gg_gemm_tn")
+    if dY.dtype == F32:
+        splits = L.lib().gg_gemm_tn_f32_splits(M, N, K)
+        part = torch.empty((splits, N, K), dtype=F32, device=dY.device)
+        L.check(L.lib().gg_gemm_tn_f32(_pr(dY, F32, "dY"), dY.stride(0), _pr(X, F32, "X"), X.stride(0), M, N, K, _p(rowscale, F32),
+                                       rows_per_scale, _p(part), splits, L.stream()), "gg_gemm_tn_f32")
+    else:
+        splits = L.lib().gg_gemm_tn_splits(M, N, K)
+        part = torch.empty((splits, N, K), dtype=F32, device=dY.device)
+        L.check(L.lib().gg_gemm_tn(_pr(dY, BF16, "dY"), dY.stride(0), _pr(X, BF16, "X"), X.stride(0), M, N, K, _p(rowscale, F32), rows_per_scale,
+                                   _p(part), splits, L.stream()), "gg_gemm_tn")
     out = accumulate_into if accumulate_into is not None else torch.empty((N, K), dtype=F32, device=dY.device)
     L.check(L.lib().gg_splitk_reduce(_p(part), _p(out, F32), N * K, splits, int(accumulate_into is not None), 1.0, L.stream()),
             "gg_splitk_reduce")
@@ -138,25 +150,35 @@ def colsum_bf16(x, rowscale=None, rows_per_scale=0, out=None):
     acc = out is not None
     if out is None:
         out = torch.empty((Cc,), dtype=F32, device=x.device)
-    L.check(L.lib().gg_colsum_bf16(_pr(x, BF16), x.stride(0), M, Cc, _p(rowscale, F32), rows_per_scale, _p(scratch),
-                                   _p(out, F32), int(acc), L.stream()), "gg_colsum_bf16")
+    if x.dtype == F32:
+        L.check(L.lib().gg_colsum_f32(_pr(x, F32), x.stride(0), M, Cc, _p(rowscale, F32), rows_per_scale, _p(scratch),
+                                      _p(out, F32), int(acc), L.stream()), "gg_colsum_f32")
+    else:
+        L.check(L.lib().gg_colsum_bf16(_pr(x, BF16), x.stride(0), M, Cc, _p(rowscale, F32), rows_per_scale, _p(scratch),
+                                       _p(out, F32), int(acc), L.stream()), "gg_colsum_bf16")
     return out
 
 
-def im2col_nchw3(x, stride=2):
+def im2col_nchw3(x, stride=2, out_dtype=BF16):
     B, Cc, H, W = x.shape
     assert Cc == 3
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    col = torch.empty((B * Ho * Wo, 32), dtype=BF16, device=x.device)
-    L.check(L.lib().gg_im2col_nchw3_f32(_p(x, F32), _p(col), B, H, W, stride, L.stream()), "gg_im2col_nchw3_f32")
+    col = torch.empty((B * Ho * Wo, 32), dtype=out_dtype, device=x.device)
+    if out_dtype == F32:
+        L.check(L.lib().gg_im2col_nchw3_f32_f32(_p(x, F32), _p(col), B, H, W, stride, L.stream()), "gg_im2col_nchw3_f32_f32")
+    else:
+        L.check(L.lib().gg_im2col_nchw3_f32(_p(x, F32), _p(col), B, H, W, stride, L.stream()), "gg_im2col_nchw3_f32")
     return col
 
 
 def im2col_nhwc(x, stride=2):
     B, H, W, Cc = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    col = torch.empty((B * Ho * Wo, 9 * Cc), dtype=BF16, device=x.device)
-    L.check(L.lib().gg_im2col_nhwc_bf16(_p(x, BF16), _p(col), B, H, W, Cc, stride, L.stream()), "gg_im2col_nhwc_bf16")
+    col = torch.empty((B * Ho * Wo, 9 * Cc), dtype=x.dtype, device=x.device)
+    if x.dtype == F32:
+        L.check(L.lib().gg_im2col_nhwc_f32(_p(x, F32), None, None, None, 0, _p(col), B, H, W, Cc, stride, L.stream()), "gg_im2col_nhwc_f32")
+    else:
+        L.check(L.lib().gg_im2col_nhwc_bf16(_p(x, BF16), _p(col), B, H, W, Cc, stride, L.stream()), "gg_im2col_nhwc_bf16")
     return col
 
 
@@ -164,28 +186,40 @@ def im2col_nhwc_bn(y, stat, gamma, beta, act="gelu", stride=2):
     """im2col of act(BatchNorm(y)) for a saved pre-BatchNorm conv output y (B,H,W,C); the activation tensor is never stored."""
     B, H, W, Cc = y.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    col = torch.empty((B * Ho * Wo, 9 * Cc), dtype=BF16, device=y.device)
-    L.check(L.lib().gg_im2col_nhwc_bn_bf16(_p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(col), B, H, W, Cc,
-                                           stride, L.stream()), "gg_im2col_nhwc_bn_bf16")
+    col = torch.empty((B * Ho * Wo, 9 * Cc), dtype=y.dtype, device=y.device)
+    if y.dtype == F32:
+        L.check(L.lib().gg_im2col_nhwc_f32(_p(y, F32), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(col), B, H, W, Cc,
+                                           stride, L.stream()), "gg_im2col_nhwc_f32")
+    else:
+        L.check(L.lib().gg_im2col_nhwc_bn_bf16(_p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(col), B, H, W, Cc,
+                                               stride, L.stream()), "gg_im2col_nhwc_bn_bf16")
     return col
 
 
 def col2im_nhwc(dcol, B, H, W, Cc, stride=2):
-    dx = torch.empty((B, H, W, Cc), dtype=BF16, device=dcol.device)
-    L.check(L.lib().gg_col2im_nhwc_bf16(_p(dcol, BF16), _p(dx), B, H, W, Cc, stride, L.stream()), "gg_col2im_nhwc_bf16")
+    dx = torch.empty((B, H, W, Cc), dtype=dcol.dtype, device=dcol.device)
+    if dcol.dtype == F32:
+        L.check(L.lib().gg_col2im_nhwc_f32(_p(dcol, F32), _p(dx), B, H, W, Cc, stride, L.stream()), "gg_col2im_nhwc_f32")
+    else:
+        L.check(L.lib().gg_col2im_nhwc_bf16(_p(dcol, BF16), _p(dx), B, H, W, Cc, stride, L.stream()), "gg_col2im_nhwc_bf16")
     return dx
 
 
 def dwconv3x3_fwd(x, taps, stride=1, colstats=False):
     B, H, W, Cc = x.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=x.device)
+    y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
     stats = None
+    f32 = x.dtype == F32
     if colstats:
-        rows = L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, stride)
+        rows = L.lib().gg_dwconv_f32_stat_rows(B, Ho, Wo, Cc) if f32 else L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, stride)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=x.device)[:rows]
-    L.check(L.lib().gg_dwconv3x3_fwd(_p(x, BF16), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
-            "gg_dwconv3x3_fwd")
+    if f32:
+        L.check(L.lib().gg_dwconv3x3_fwd_f32(_p(x, F32), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
+                "gg_dwconv3x3_fwd_f32")
+    else:
+        L.check(L.lib().gg_dwconv3x3_fwd(_p(x, BF16), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
+                "gg_dwconv3x3_fwd")
     return (y, stats) if colstats else y
 
 
@@ -204,20 +238,30 @@ def dwconv3x3_fwd_fused(y_in, stat, gamma, beta, taps, act="gelu", stride=2, col
 
 
 def dwconv3x3_bwd_data(dy, taps, B, H, W, Cc, stride=1):
-    dx = torch.empty((B, H, W, Cc), dtype=BF16, device=dy.device)
-    L.check(L.lib().gg_dwconv3x3_bwd_data(_p(dy, BF16), _p(taps, F32), _p(dx), B, H, W, Cc, stride, L.stream()),
-            "gg_dwconv3x3_bwd_data")
+    dx = torch.empty((B, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    if dy.dtype == F32:
+        L.check(L.lib().gg_dwconv3x3_bwd_data_f32(_p(dy, F32), _p(taps, F32), _p(dx), B, H, W, Cc, stride, L.stream()),
+                "gg_dwconv3x3_bwd_data_f32")
+    else:
+        L.check(L.lib().gg_dwconv3x3_bwd_data(_p(dy, BF16), _p(taps, F32), _p(dx), B, H, W, Cc, stride, L.stream()),
+                "gg_dwconv3x3_bwd_data")
     return dx
 
 
 def dwconv3x3_bwd_weight(x, dy, stride=1, grad=None):
     B, H, W, Cc = x.shape
-    scratch = torch.empty((L.lib().gg_dwconv_wgrad_scratch_floats(B, H, W, Cc, stride),), dtype=F32, device=x.device)
+    f32 = x.dtype == F32
+    nscr = L.lib().gg_dwconv_f32_wgrad_scratch_floats(B, H, W, Cc, stride) if f32 else L.lib().gg_dwconv_wgrad_scratch_floats(B, H, W, Cc, stride)
+    scratch = torch.empty((nscr,), dtype=F32, device=x.device)
     acc = grad is not None
     if grad is None:
         grad = torch.empty((Cc, 1, 3, 3), dtype=F32, device=x.device)
-    L.check(L.lib().gg_dwconv3x3_bwd_weight(_p(x, BF16), _p(dy, BF16), B, H, W, Cc, stride, _p(scratch), _p(grad, F32),
-                                            int(acc), L.stream()), "gg_dwconv3x3_bwd_weight")
+    if f32:
+        L.check(L.lib().gg_dwconv3x3_bwd_weight_f32(_p(x, F32), _p(dy, F32), B, H, W, Cc, stride, _p(scratch), _p(grad, F32),
+                                                    int(acc), L.stream()), "gg_dwconv3x3_bwd_weight_f32")
+    else:
+        L.check(L.lib().gg_dwconv3x3_bwd_weight(_p(x, BF16), _p(dy, BF16), B, H, W, Cc, stride, _p(scratch), _p(grad, F32),
+                                                int(acc), L.stream()), "gg_dwconv3x3_bwd_weight")
     return grad
 
 
@@ -243,8 +287,9 @@ def bn_eval_stat(running_mean, running_var, eps=1e-5):
 def bn_apply(y, stat, gamma, beta, act=None, residual=None, rowscale=None, rows_per_scale=0):
     M, Cc = y.shape
     out = torch.empty_like(y)
-    L.check(L.lib().gg_bn_apply(_p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), M, Cc, ACT[act],
-                                _p(residual, BF16), _p(rowscale, F32), rows_per_scale, _p(out), L.stream()), "gg_bn_apply")
+    fn = L.lib().gg_bn_apply_f32 if y.dtype == F32 else L.lib().gg_bn_apply
+    L.check(fn(_p(y, y.dtype), _p(stat, F32), _p(gamma, F32), _p(beta, F32), M, Cc, ACT[act],
+               _p(residual, y.dtype), _p(rowscale, F32), rows_per_scale, _p(out), L.stream()), "gg_bn_apply")
     return out
 
 
@@ -255,9 +300,10 @@ def bn_bwd(dout, y, stat, gamma, beta, act=None, residual=None, rowscale=None, r
     scratch = torch.empty((L.lib().gg_bn_bwd_scratch_floats(M, Cc),), dtype=F32, device=dev)
     dg = torch.zeros((Cc,), dtype=F32, device=dev) if want_param_grads else None
     db = torch.zeros((Cc,), dtype=F32, device=dev) if want_param_grads else None
-    L.check(L.lib().gg_bn_bwd(_p(dout, BF16), _p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), M, Cc, ACT[act],
-                              _p(residual, BF16), _p(rowscale, F32), rows_per_scale, _p(dz), _p(dy), _p(scratch), _p(dg),
-                              _p(db), 1, L.stream()), "gg_bn_bwd")
+    fn = L.lib().gg_bn_bwd_f32 if y.dtype == F32 else L.lib().gg_bn_bwd
+    L.check(fn(_p(dout, y.dtype), _p(y), _p(stat, F32), _p(gamma, F32), _p(beta, F32), M, Cc, ACT[act],
+               _p(residual, y.dtype), _p(rowscale, F32), rows_per_scale, _p(dz), _p(dy), _p(scratch), _p(dg),
+               _p(db), 1, L.stream()), "gg_bn_bwd")
     return dz, dy, dg, db
 
 
@@ -372,15 +418,62 @@ def layernorm_bwd(dout, x, mean, rstd, gamma, dres=None, want_param_grads=True):
 def token_mean_fwd(x, B, T):
     Cc = x.shape[-1]
     out = torch.empty((B, Cc), dtype=F32, device=x.device)
-    L.check(L.lib().gg_token_mean_fwd(_p(x, BF16), _p(out), B, T, Cc, L.stream()), "gg_token_mean_fwd")
+    fn = L.lib().gg_token_mean_fwd_f32 if x.dtype == F32 else L.lib().gg_token_mean_fwd
+    L.check(fn(_p(x), _p(out), B, T, Cc, L.stream()), "gg_token_mean_fwd")
     return out
 
 
-def token_mean_bwd(dout, T):
+def token_mean_bwd(dout, T, out_dtype=BF16):
     B, Cc = dout.shape
-    dx = torch.empty((B * T, Cc), dtype=BF16, device=dout.device)
-    L.check(L.lib().gg_token_mean_bwd(_p(dout, F32), _p(dx), B, T, Cc, L.stream()), "gg_token_mean_bwd")
+    dx = torch.empty((B * T, Cc), dtype=out_dtype, device=dout.device)
+    fn = L.lib().gg_token_mean_bwd_f32 if out_dtype == F32 else L.lib().gg_token_mean_bwd
+    L.check(fn(_p(dout, F32), _p(dx), B, T, Cc, L.stream()), "gg_token_mean_bwd")
     return dx
+
+
+def view_mean_f32(emb):
+    """(N, V, C) f32 -> (N, C) f32 mean over the V views, summed in view order (models/super_guessr.py:347; prototype building)."""
+    L.require_gpu()
+    N, V, Cc = emb.shape
+    out = torch.empty((N, Cc), dtype=F32, device=emb.device)
+    L.check(L.lib().gg_view_mean_fwd_f32(_p(emb, F32, "emb"), _p(out), Cc, N, V, Cc, L.stream()), "gg_view_mean_fwd_f32")
+    return out
+
+
+def attention_flash(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off, k_off, v_off, head_stride,
+                    window_size=0, map_h=0, map_w=0, bias_table=None, scale=None, dout=None, want_dbias=False, out=None, lse=None,
+                    want_lse=False, deterministic_dbias=True):
+    """Online-softmax attention (any tokens_per_window; bf16 or f32 storage by ``qkv.dtype``).  Forward when ``dout`` is None
+    (returns out, or (out, lse)); else backward given the forward's ``out`` and ``lse`` -> (dqkv, dbias)."""
+    L.require_gpu()
+    DT = qkv.dtype
+    a = L.AttnArgs()
+    a.qkv, a.ld = _p(qkv, DT, "qkv"), qkv.stride(0)
+    a.q_off, a.k_off, a.v_off, a.head_stride, a.head_dim = q_off, k_off, v_off, head_stride, head_dim
+    a.num_heads, a.num_windows, a.tokens_per_window = num_heads, num_windows, tokens_per_window
+    a.window_size, a.map_h, a.map_w = window_size, map_h, map_w
+    a.scale = head_dim ** -0.5 if scale is None else scale
+    a.bias_table = _p(bias_table, F32, "bias_table")
+    tokens = qkv.shape[0]
+    dt = int(DT == F32)
+    if dout is None:
+        out = torch.empty((tokens, num_heads * head_dim), dtype=DT, device=qkv.device)
+        a.out, a.ldo = _p(out), out.stride(0)
+        lse_t = torch.empty((tokens, num_heads), dtype=F32, device=qkv.device) if want_lse else None
+        a.lse = _p(lse_t)
+        L.check(L.lib().gg_attention_flash_fwd(C.byref(a), dt, L.stream()), "gg_attention_flash_fwd")
+        return (out, lse_t) if want_lse else out
+    dqkv = torch.zeros_like(qkv)
+    dbias = torch.zeros_like(bias_table) if (want_dbias and bias_table is not None) else None
+    a.dout, a.lddo, a.dqkv, a.dbias = _p(dout, DT, "dout"), dout.stride(0), _p(dqkv), _p(dbias)
+    scratch = None
+    if dbias is not None and deterministic_dbias:
+        rows = L.lib().gg_attention_flash_dbias_rows(num_windows, tokens_per_window)
+        scratch = torch.empty((rows * num_heads * window_size * window_size,), dtype=F32, device=qkv.device)
+        a.dbias_scratch = _p(scratch)
+    a.out, a.ldo, a.lse = _p(out, DT, "out"), out.stride(0), _p(lse, F32, "lse")
+    L.check(L.lib().gg_attention_flash_bwd(C.byref(a), dt, L.stream()), "gg_attention_flash_bwd")
+    return dqkv, dbias
 
 
 def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off, k_off, v_off, head_stride,
@@ -423,7 +516,7 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
 
 
 def geo_head(logits, centroids, *, labels=None, labels_clf=None, mode=0, smoothing_km=65.0, grad_scale=None,
-             want_dlogits=False, num_candidates=5, want_nearest=False, K=None):
+             want_dlogits=False, num_candidates=5, want_nearest=False, K=None, dlogits_f32=False):
     """Fused SuperGuessr head epilogue.  Returns a dict of device tensors."""
     N = logits.shape[0]
     K = logits.shape[1] if K is None else K
@@ -434,7 +527,7 @@ def geo_head(logits, centroids, *, labels=None, labels_clf=None, mode=0, smoothi
              topk_idx=torch.empty((N, num_candidates), dtype=I64, device=dev))
     if want_dlogits:
         ldd = (K + 7) // 8 * 8
-        r["dlogits"] = torch.empty((N, ldd), dtype=BF16, device=dev)
+        r["dlogits"] = torch.empty((N, ldd), dtype=F32 if dlogits_f32 else BF16, device=dev)
     if want_nearest:
         r["nearest"] = torch.empty((N,), dtype=I64, device=dev)
     a = L.GeoHeadArgs()
@@ -444,7 +537,7 @@ def geo_head(logits, centroids, *, labels=None, labels_clf=None, mode=0, smoothi
     a.grad_scale = (1.0 / N) if grad_scale is None else grad_scale
     a.loss_rows, a.loss = _p(r["loss_rows"]), _p(r["loss"])
     if want_dlogits:
-        a.dlogits, a.ldd = _p(r["dlogits"]), r["dlogits"].stride(0)
+        a.dlogits, a.ldd, a.dlogits_f32 = _p(r["dlogits"]), r["dlogits"].stride(0), int(dlogits_f32)
     a.preds, a.llh, a.topk_vals, a.topk_idx, a.num_candidates = _p(r["preds"]), _p(r["llh"]), _p(r["topk_vals"]), _p(r["topk_idx"]), num_candidates
     a.nearest = _p(r.get("nearest"))
     L.check(L.lib().gg_geo_head(C.byref(a), L.stream()), "gg_geo_head")
@@ -465,10 +558,12 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
 
 
 def geoguessr_score(pred_llh, true_llh):
+    """run_benchmark.py:25-65 for a batch: (distance_km float64 (N,), score int32 (N,)) -- haversine_np + geoguessr_score_from_distance."""
     N = pred_llh.shape[0]
-    d = torch.empty((N,), dtype=F32, device=pred_llh.device)
-    s = torch.empty((N,), dtype=F32, device=pred_llh.device)
-    L.check(L.lib().gg_geoguessr_score(_p(pred_llh, F32), _p(true_llh, F32), N, _p(d), _p(s), L.stream()), "gg_geoguessr_score")
+    d = torch.empty((N,), dtype=torch.float64, device=pred_llh.device)
+    s = torch.empty((N,), dtype=torch.int32, device=pred_llh.device)
+    L.check(L.lib().gg_geoguessr_score(_p(pred_llh.contiguous(), F32), _p(true_llh.contiguous(), F32), N, _p(d), _p(s), L.stream()),
+            "gg_geoguessr_score")
     return d, s
 
 

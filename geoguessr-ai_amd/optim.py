@@ -8,6 +8,7 @@ sum all-reduce over RCCL -- gradients are the only thing exchanged (SURVEY.md 8e
 from __future__ import annotations
 
 import math
+import contextlib
 from typing import List, Optional
 
 import torch
@@ -42,8 +43,10 @@ class AdamW:
         flat_ids = set()
         for bb in self.backbones:
             flat_ids.update(id(p) for p in bb._params.values())
+        self._flat_ids = flat_ids
         self.loose: List[torch.nn.Parameter] = [p for p in model.parameters() if p.requires_grad and id(p) not in flat_ids]
         self.state = {}
+        self._inflight, self._covered = {}, {}
 
     def _st(self, key, like):
         if key not in self.state or self.state[key][0].device != like.device:
@@ -59,10 +62,100 @@ class AdamW:
         out += [p.grad for p in self.loose if p.grad is not None]
         return out
 
+    # ---- data-parallel exchange (the reference gets all of it from Accelerate -> DistributedDataParallel,
+    #      training/train_eval_loop.py:184-187,200-202,234) ------------------------------------------------------------
+    @staticmethod
+    def _world() -> int:
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def broadcast_params(self, src: int = 0):
+        """DDP construction semantics: every rank starts from rank ``src``'s parameters and buffers."""
+        if self._world() == 1:
+            return
+        for bb in self.backbones:
+            dist.broadcast(bb.flat_params, src)
+            bb.mark_params_dirty()
+        for p in self.model.parameters():
+            if id(p) not in self._flat_ids:
+                dist.broadcast(p.data, src)
+        self.broadcast_buffers(src)
+        if hasattr(self.model, "mark_params_dirty"):
+            self.model.mark_params_dirty()
+
+    def broadcast_buffers(self, src: int = 0):
+        """``DistributedDataParallel(broadcast_buffers=True)`` (the default the reference runs with): BatchNorm running
+        statistics and ``num_batches_tracked`` of rank ``src`` overwrite every other rank's before a training forward."""
+        if self._world() == 1:
+            return
+        for bb in self.backbones:
+            dist.broadcast(bb._flat_buf, src)
+            dist.broadcast(bb._counters, src)
+
+    def _launch(self, key, tensor):
+        if key in self._inflight or tensor is None or tensor.numel() == 0:
+            return
+        self._inflight[key] = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _bucket_ready(self, bb_index: int, lo: int, hi: int):
+        """Called (through the backward pass's stage callback) when flat gradient floats [lo, hi) of a backbone are final."""
+        bb = self.backbones[bb_index]
+        fg = bb.flat_grads()
+        for s, e in bb.trainable_ranges():
+            a, b = max(s, lo), min(e, hi)
+            if a < b:
+                self._launch(("bb", bb_index, a, b), fg[a:b])
+                self._covered.setdefault(bb_index, []).append((a, b))
+
+    @contextlib.contextmanager
+    def overlap_allreduce(self, enabled: bool = True):
+        """Inside this context, gradient buckets are all-reduced (async, on RCCL's own stream) as soon as the backward pass
+        has finished them: the geocell head's weight/bias right after the head's backward, the encoder's last stage while
+        the earlier stages are still running.  ``allreduce_grads()`` afterwards sends what is left and waits for all of it."""
+        if not enabled or self._world() == 1:
+            yield
+            return
+        handles = []
+        for p in self.loose:
+            handles.append(p.register_post_accumulate_grad_hook(lambda q: self._launch(("loose", id(q)), q.grad)))
+        for i, bb in enumerate(self.backbones):
+            bb._grad_ready_hook = (lambda lo, hi, i=i: self._bucket_ready(i, lo, hi))
+        try:
+            yield
+        finally:
+            for h in handles:
+                h.remove()
+            for bb in self.backbones:
+                bb._grad_ready_hook = None
+
     def allreduce_grads(self, async_op: bool = False):
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        """Sum every trainable gradient over the ranks (RCCL over xGMI under backend "nccl"; gloo in the CPU tests).  Buckets
+        already launched by ``overlap_allreduce`` are not sent twice; returns after the current stream is ordered behind
+        every reduction (``async_op=True``: returns the work handles instead)."""
+        if self._world() == 1:
             return []
-        return [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=async_op) for g in self.grad_buffers()]
+        for i, bb in enumerate(self.backbones):
+            fg = bb.flat_grads()
+            done = sorted(self._covered.get(i, []))
+            for s, e in bb.trainable_ranges():
+                cur = s
+                for a, b in done:
+                    if b <= cur or a >= e:
+                        continue
+                    if a > cur:
+                        self._launch(("bb", i, cur, a), fg[cur:a])
+                    cur = max(cur, b)
+                if cur < e:
+                    self._launch(("bb", i, cur, e), fg[cur:e])
+        for p in self.loose:
+            if p.grad is not None:
+                self._launch(("loose", id(p)), p.grad)
+        works = list(self._inflight.values())
+        self._inflight, self._covered = {}, {}
+        if async_op:
+            return works
+        for w in works:
+            w.wait()
+        return []
 
     def step(self, grad_scale: Optional[float] = None):
         g = self.param_groups[0]

@@ -56,11 +56,29 @@ def _take(ds, idx) -> Dict[str, torch.Tensor]:
     return {k: torch.stack([torch.as_tensor(r[k]) for r in rows]) for k in rows[0]}
 
 
-def _batches(ds, batch_size: int, shuffle: bool, seed: int, rank: int, world: int):
-    n = _num_rows(ds)
+def _shard(n: int, shuffle: bool, seed: int, rank: int, world: int) -> torch.Tensor:
+    """Row indices of this rank.  Same contract as ``torch.utils.data.DistributedSampler`` (what Accelerate wraps the
+    reference's DataLoader in, training/train_eval_loop.py:200-202): the order is padded by wrapping around to a multiple of
+    ``world`` and dealt out strided, so EVERY rank gets exactly ceil(n / world) rows -- equal batch counts, hence equal
+    numbers of gradient all-reduces (a short rank would deadlock the collective)."""
     order = torch.randperm(n, generator=torch.Generator().manual_seed(seed)) if shuffle else torch.arange(n)
+    if world <= 1:
+        return order
     per = (n + world - 1) // world
-    mine = order[rank * per:(rank + 1) * per] if world > 1 else order
+    total = per * world
+    if total > n:
+        reps = (total + n - 1) // n
+        order = order.repeat(reps)[:total]
+    return order[rank:total:world]
+
+
+def _num_batches(n: int, batch_size: int, world: int) -> int:
+    per = (n + world - 1) // world if world > 1 else n
+    return (per + batch_size - 1) // batch_size
+
+
+def _batches(ds, batch_size: int, shuffle: bool, seed: int, rank: int, world: int):
+    mine = _shard(_num_rows(ds), shuffle, seed, rank, world)
     for i in range(0, len(mine), batch_size):
         yield _take(ds, mine[i:i + batch_size])
 
@@ -68,20 +86,38 @@ def _batches(ds, batch_size: int, shuffle: bool, seed: int, rank: int, world: in
 MODEL_KEYS = ("pixel_values", "embedding", "labels", "labels_clf", "index")
 
 
+def _gather_rows(arrays, rank: int, world: int):
+    """Concatenate per-rank result lists in rank order (each rank evaluated one contiguous slice of the dataset)."""
+    if world <= 1:
+        return arrays
+    box = [None] * world
+    dist.all_gather_object(box, arrays)
+    return [np.concatenate([b[i] for b in box], 0) for i in range(len(arrays))]
+
+
 def evaluate_model(model, dataset, metrics: Callable, train_args, refiner=None, writer=None, step: int = 0) -> float:
+    """Reference contract (:37-155): returns ``-metrics(results)["Geocell_accuracy"]`` with
+    ``results = (preds_LLH, preds_geocell, top5_geocells, labels_lla, labels_cell)`` over the WHOLE validation set in dataset
+    order.  Under data parallelism each rank evaluates one contiguous slice and the slices are all-gathered (the reference
+    has every rank evaluate everything, :62-68 -- same numbers, world times the work)."""
     logger.warning("Starting evaluation ...")
     rank, world = _rank_world()
     model.eval()
     if refiner is not None:
         refiner.eval()
+    n = _num_rows(dataset)
+    per = (n + world - 1) // world
+    lo, hi = min(n, rank * per), min(n, (rank + 1) * per)
+    ebs = train_args.per_device_eval_batch_size
     preds, cells, top5c, top5p, lab_lla, lab_cell = [], [], [], [], [], []
     loss_sum, n_seen = 0.0, 0
     with torch.no_grad():
-        for data in _batches(dataset, train_args.per_device_eval_batch_size, False, 0, 0, 1):
+        for s0 in range(lo, hi, ebs):
+            data = _take(dataset, torch.arange(s0, min(hi, s0 + ebs)))
             outputs = model(**{k: v for k, v in data.items() if k in MODEL_KEYS})
             bs = _num_rows(data)
             if outputs.loss is not None:
-                loss_sum += float(outputs.loss) * bs
+                loss_sum += float(outputs.loss) * bs          # weighted by rows (the reference uses len(dict), C11)
             n_seen += bs
             if refiner is not None:
                 _, p_llh, _ = refiner(outputs.embedding, initial_preds=outputs.preds_LLH,
@@ -94,28 +130,38 @@ def evaluate_model(model, dataset, metrics: Callable, train_args, refiner=None, 
             top5p.append(outputs.top5_geocells.values.cpu().numpy())
             lab_lla.append(np.asarray(data["labels"].cpu()) if "labels" in data else np.zeros((bs, 2), np.float32))
             lab_cell.append(np.asarray(data["labels_clf"].cpu()) if "labels_clf" in data else np.zeros((bs,), np.int64))
-    results = (np.concatenate(preds, 0), np.concatenate(cells, 0), np.concatenate(top5c, 0), np.concatenate(lab_lla, 0),
-               np.concatenate(lab_cell, 0))
+    cat = lambda xs, shape, dt: np.concatenate(xs, 0) if xs else np.zeros(shape, dt)
+    k = int(getattr(model, "num_candidates", 5))
+    local = [cat(preds, (0, 2), np.float32), cat(cells, (0,), np.int64), cat(top5c, (0, k), np.int64),
+             cat(lab_lla, (0, 2), np.float32), cat(lab_cell, (0,), np.int64), np.asarray([loss_sum, n_seen], np.float64)[None]]
+    full = _gather_rows(local, rank, world)
+    results = tuple(full[:5])
     eval_dict = metrics(results)
-    if writer is not None and n_seen:
-        writer("Loss/val", loss_sum / n_seen, step)
-        for k, v in eval_dict.items():
-            writer(k, v, step)
+    tot = full[5].sum(0)
+    if writer is not None and tot[1] > 0:
+        writer("Loss/val", float(tot[0] / tot[1]), step)
+        for key, v in eval_dict.items():
+            writer(key, v, step)
     model.train()
     logger.warning("Back to training ...")
     return -eval_dict["Geocell_accuracy"]
 
 
 def train_model(loaded_model: Any, dataset, on_embeddings: bool, train_args, metrics: Callable, patience: int = None,
-                should_profile: bool = False, refiner=None, log_fn: Optional[Callable] = None, save_path: str = CURRENT_SAVE_PATH):
+                should_profile: bool = False, refiner=None, log_fn: Optional[Callable] = None, save_path: str = CURRENT_SAVE_PATH,
+                broadcast_buffers: bool = True):
+    """Reference contract (:158-274).  DDP start-up semantics of ``accelerator.prepare`` (:200-202) are kept: parameters and
+    buffers are broadcast from rank 0 once, BatchNorm running statistics are re-broadcast from rank 0 before every training
+    forward (``DistributedDataParallel(broadcast_buffers=True)``, the default), gradients are summed over ranks before each
+    optimizer step (overlapped with the encoder's backward pass) and averaged inside the AdamW kernel."""
     rank, world = _rank_world()
     model = loaded_model
     optimizer = AdamW(model, lr=train_args.learning_rate)         # torch defaults: betas (.9,.999), eps 1e-8, wd 1e-2
+    optimizer.broadcast_params()                                  # no-op for world == 1
     grad_acc_steps = getattr(train_args, "gradient_accumulation_steps", None) or 1
     logging_steps = getattr(train_args, "logging_steps", 0) or 0
     bs = train_args.per_device_train_batch_size
-    n_local = (_num_rows(dataset["train"]) + world - 1) // world
-    steps = (n_local + bs - 1) // bs
+    steps = _num_batches(_num_rows(dataset["train"]), bs, world)  # == len(train_data) after accelerator.prepare: identical on every rank
     prior_eval_loss, current_patience = None, 0
     unwrapped_model = model
     prof = generate_profiler() if should_profile else None
@@ -127,9 +173,13 @@ def train_model(loaded_model: Any, dataset, on_embeddings: bool, train_args, met
         optimizer.zero_grad()
         for epoch in range(int(train_args.num_train_epochs)):
             for i, data in enumerate(_batches(dataset["train"], bs, True, getattr(train_args, "seed", 0) + epoch, rank, world)):
-                output = model(**{k: v for k, v in data.items() if k in MODEL_KEYS})
-                output.loss.backward()
-                if i % grad_acc_steps == (grad_acc_steps - 1) or (i + 1) == steps:
+                last = i % grad_acc_steps == (grad_acc_steps - 1) or (i + 1) == steps
+                if broadcast_buffers:
+                    optimizer.broadcast_buffers()
+                with optimizer.overlap_allreduce(enabled=last):      # gradient buckets leave as the backward pass completes them
+                    output = model(**{k: v for k, v in data.items() if k in MODEL_KEYS})
+                    output.loss.backward()
+                if last:
                     optimizer.allreduce_grads()
                     optimizer.step()
                     optimizer.zero_grad()

@@ -167,6 +167,9 @@ typedef struct GgAttnArgs {
                                              second deterministic stage; NULL: float atomics */
     float* lse;                           /* f32 [tokens][num_heads] row log-sum-exp: forward writes (may be NULL), backward reads;
                                              backward also reads `out` (the forward result) */
+    const float* bias_table;              /* COMPACT attention_biases f32 [num_heads][ws*ws] (index |dy|*ws+|dx|, timm's first-seen order)
+                                             or NULL: what the online-softmax kernels read (gg_attention_flash_*, and gg_attention_fwd/bwd
+                                             beyond 256 tokens per window, where `bias` is ignored) */
 } GgAttnArgs;
 int gg_attention_padded_tokens(int tokens_per_window);
 /* full[h][q][k] = bf16(table[h][|dy|*ws+|dx|] / scale) (-inf for padded keys): the kernels start their score accumulators from it,
@@ -174,6 +177,44 @@ int gg_attention_padded_tokens(int tokens_per_window);
 int gg_attention_expand_bias(const float* table /* [num_heads][ws*ws] */, int num_heads, int window_size, float scale, void* full /* bf16 */, void* stream);
 int gg_attention_fwd(const GgAttnArgs* args, void* stream);
 int gg_attention_bwd(const GgAttnArgs* args, void* stream);
+/* Online-softmax (flash) form for ANY tokens_per_window (1024-token windows of the reference's default tiny_vit_21m_512, config.py:9;
+ * 577 tokens of CLIP ViT-L/14-336, config.py:6) and for the reference-precision mode: dtype 0 = bf16, 1 = f32 storage of
+ * qkv / out / dout / dqkv; arithmetic is f32 MFMA either way.  window_size <= 32.  dbias_scratch (optional): f32
+ * [gg_attention_flash_dbias_rows(num_windows, tokens_per_window)][num_heads][ws*ws]. */
+int gg_attention_flash_fwd(const GgAttnArgs* args, int dtype, void* stream);
+int gg_attention_flash_bwd(const GgAttnArgs* args, int dtype, void* stream);
+int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per_window);
+
+/* ---------------------------------------------------------------- reference-precision (fp32) mode
+ * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins
+ * of the kernels above: f32 activations [tokens, channels], f32 MFMA (v_mfma_f32_16x16x4_f32 -- exact f32 products, f32
+ * accumulation), exact erf GELU.  GgTinyVitCfg.act_dtype = 1 runs the whole encoder on them. */
+int gg_gemm_nt_f32(const GgGemmArgs* args, void* stream);   /* all matrices f32; K, lda, ldb multiples of 4; no split-K / A2 / BatchNorm-fused forms */
+int gg_gemm_tn_f32_splits(int M, int N, int K);
+int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale,
+                   float* partials, int splits, void* stream);
+int gg_colsum_f32(const float* x, int64_t ld, int M, int C, const float* rowscale, int rows_per_scale, float* scratch /* gg_colsum_scratch_floats */,
+                  float* out, int accumulate, void* stream);
+int gg_im2col_nchw3_f32_f32(const float* x, float* col, int B, int H, int W, int stride, void* stream);      /* -> f32 [B*Ho*Wo, 32] */
+/* stat != NULL: x is a saved pre-BatchNorm conv output, act(BatchNorm(x)) is gathered (C <= 512) */
+int gg_im2col_nhwc_f32(const float* x, const float* stat, const float* gamma, const float* beta, int act, float* col, int B, int H, int W, int C,
+                       int stride, void* stream);
+int gg_col2im_nhwc_f32(const float* dcol, float* dx, int B, int H, int W, int C, int stride, void* stream);
+int gg_dwconv_f32_stat_rows(int B, int Ho, int Wo, int C);      /* partial rows written by gg_dwconv3x3_fwd_f32.colstats */
+int gg_dwconv3x3_fwd_f32(const float* x, const float* taps, float* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
+int gg_dwconv3x3_bwd_data_f32(const float* dy, const float* taps, float* dx, int B, int H, int W, int C, int stride, void* stream);
+int64_t gg_dwconv_f32_wgrad_scratch_floats(int B, int H, int W, int C, int stride);
+int gg_dwconv3x3_bwd_weight_f32(const float* x, const float* dy, int B, int H, int W, int C, int stride, float* scratch, float* grad, int accumulate,
+                                void* stream);
+int gg_bn_apply_f32(const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act, const float* residual,
+                    const float* rowscale, int rows_per_scale, float* out, void* stream);
+int gg_bn_bwd_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                  const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* dy, float* scratch /* gg_bn_bwd_scratch_floats */,
+                  float* dgamma, float* dbeta, int accumulate, void* stream);
+int gg_token_mean_fwd_f32(const float* x, float* out, int B, int T, int C, void* stream);
+int gg_token_mean_bwd_f32(const float* dout, float* dx, int B, int T, int C, void* stream);
+int gg_view_mean_fwd_f32(const float* emb, float* out, int64_t ldo, int N, int V, int C, void* stream);
+int gg_view_mean_bwd_f32(const float* dmean, int64_t ld, float* demb, int N, int V, int C, void* stream);
 
 /* ---------------------------------------------------------------- SuperGuessr head + loss (models/super_guessr.py:355-383,
  * models/utils.py:20-57, main_coordinator_idun_s3.py:390-391) fused per row over the (N,K) logits. */
@@ -188,11 +229,14 @@ typedef struct GgGeoHeadArgs {
     float grad_scale;                     /* dlogits = dloss_row/dlogits * grad_scale (pass upstream_grad / N) */
     float* loss_rows;                     /* f32 (N,) or NULL */
     float* loss;                          /* f32 scalar = mean(loss_rows) or NULL */
-    void* dlogits; int64_t ldd;           /* bf16 [N, ldd] (columns K..ldd zeroed) or NULL */
+    void* dlogits; int64_t ldd;           /* bf16 (f32 if dlogits_f32) [N, ldd] (columns K..ldd zeroed) or NULL */
     int64_t* preds; float* llh;           /* argmax geocell (N,), its centroid (N,2) */
     float* topk_vals; int64_t* topk_idx; int num_candidates;   /* (N,num_candidates) softmax probabilities / indices */
     int64_t* nearest;                     /* (N,) argmin_k haversine(labels, centroids) or NULL */
+    int dlogits_f32;                      /* reference-precision mode: dlogits is f32 */
 } GgGeoHeadArgs;
+/* mode 2 with labels_clf[n] outside [0,K): torch's CrossEntropyLoss raises (models/super_guessr.py:383); here loss_rows[n], the mean
+ * loss and row n of dlogits come out NaN. */
 int gg_geo_head(const GgGeoHeadArgs* args, void* stream);
 int gg_haversine_matrix(const float* x, const float* centroids, float* out, int N, int K, void* stream);   /* models/utils.py:39 */
 
@@ -210,7 +254,9 @@ typedef struct GgProtoRefineArgs {
     float* out_llh; int64_t* out_cell; int64_t* out_idx;
 } GgProtoRefineArgs;
 int gg_proto_refine(const GgProtoRefineArgs* args, void* stream);
-int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, float* dist_km, float* score, void* stream); /* run_benchmark.py:28-65 */
+/* run_benchmark.py:25-65: dist_km[i] = haversine_np (fp64, R = 6371 km; may be NULL), score[i] = geoguessr_score_from_distance =
+ * int(round(clamp(5000*exp(-d/1492.7), 0, 5000))) with Python's round-half-to-even: integer output, bit-exact vs the reference */
+int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, double* dist_km, int32_t* score, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (main_coordinator_idun_s3.py:286-291) */
 int gg_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
@@ -235,6 +281,11 @@ typedef struct GgTinyVitCfg {
     int embed_dims[4], depths[4], num_heads[4], window_sizes[4];
     float mlp_ratio, mbconv_expand_ratio;
     float bn_eps, ln_eps, bn_momentum;
+    int act_dtype;       /* 0: bf16 activations + bf16 MFMA operands (fp32 accumulate / statistics / master weights);
+                            1: reference-precision mode -- f32 activations, f32 MFMA (v_mfma_f32_16x16x4_f32), exact erf: the
+                               arithmetic of the reference's own torch fp32 forward / backward */
+    int features_only;   /* 1: models/tinyvit.py:38-46,139-143 (timm features_only=True): the output is the global-average-pooled
+                               last feature map, head.norm is not applied (its parameters stay in the table, unused) */
 } GgTinyVitCfg;
 enum { GG_KIND_PARAM = 0, GG_KIND_BUFFER = 1, GG_KIND_COUNTER = 2 };
 int gg_tinyvit_num_tensors(const GgTinyVitCfg* cfg);
@@ -257,8 +308,15 @@ int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int training, const f
                        const uint8_t* trainable /* host */, void* stream);
 /* d_out: f32 (batch, C).  grads: flat f32 like params, ACCUMULATED into.  trainable: host uint8[num_tensors]
  * (wgrad computed only where 1; dgrad always flows to patch_embed -- SURVEY.md C1). */
+/* stage_done (may be NULL): HOST callback, called on the calling thread as soon as every kernel that writes the parameter gradients
+ * of a stage has been enqueued on `stream` -- stage ids 3, 2, 1 (TinyVitStage incl. its PatchMerging; 3 also covers head.norm),
+ * 0 (the MBConv stage), -1 (patch_embed), in that order.  The data-parallel host uses it to start the RCCL all-reduce of that
+ * stage's gradient bucket behind an event on `stream` while the earlier stages are still running (the overlap the reference gets
+ * from DistributedDataParallel's bucketed reducer, training/train_eval_loop.py:184-187,234). */
+typedef void (*GgStageDoneFn)(int stage, void* user);
 int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,
-                        void* workspace, const float* d_out, float* grads, const uint8_t* trainable /* host */, void* stream);
+                        void* workspace, const float* d_out, float* grads, const uint8_t* trainable /* host */, void* stream,
+                        GgStageDoneFn stage_done, void* stage_user);
 /* debug / parity: byte offset of a named saved activation inside the workspace (host) */
 int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes);
 

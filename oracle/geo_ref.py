@@ -103,8 +103,19 @@ def haversine_np_score(lat1, lon1, lat2, lon2) -> np.ndarray:
 
 
 def geoguessr_score(d_km) -> np.ndarray:
-    """run_benchmark.py:50-65."""
-    return 5000.0 * np.exp(-np.asarray(d_km, np.float64) / DECAY_CONSTANT)
+    """run_benchmark.py:50-65: negative distances count as 0, 5000*exp(-d/1492.7) clamped to [0, 5000], ``int(round(.))`` --
+    Python's round() on a float is round-half-to-even = np.rint.  int32 result.  PINNED by tests/golden/score.npz."""
+    d = np.maximum(np.asarray(d_km, np.float64), 0.0)
+    pts = np.minimum(np.maximum(5000.0 * np.exp(-(d / DECAY_CONSTANT)), 0.0), 5000.0)
+    return np.rint(pts).astype(np.int32)
+
+
+def score_summary(distance_km, score, top1_prob) -> dict:
+    """run_benchmark.py:67-117 (``_compute_summary_from_data``) on arrays; ``top1_prob`` < 0 marks a sample without top-5 list."""
+    d = np.asarray(distance_km, np.float64); s = np.asarray(score, np.float64); p = np.asarray(top1_prob, np.float64)
+    n = len(d)
+    return dict(num_samples=n, avg_distance_km=float(np.sum(d) / n), median_distance_km=float(np.median(d)),
+                avg_top1_prob=float(np.sum(np.where(p < 0, 0.0, p)) / n), avg_score=float(np.sum(s) / n))
 
 
 # ---------------------------------------------------------------------------- optimizer / schedule

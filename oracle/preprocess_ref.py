@@ -57,3 +57,26 @@ def cluster_mean(embeddings: np.ndarray, ptr: np.ndarray, member: np.ndarray) ->
         if ptr[k + 1] > ptr[k]:
             out[k] = s / np.float32(ptr[k + 1] - ptr[k])
     return out
+
+
+def prototype_means(table: np.ndarray, latlon: np.ndarray, ptr: np.ndarray, member: np.ndarray) -> np.ndarray:
+    """``Embeddings.generate_embeddings`` (models/proto_refiner.py:461-517) for every cluster of a CSR member list: members outside
+    [0, len(latlon)) or with a non-finite (lat, lon) row are skipped (:469-474), each member's (V, D) embedding is averaged over
+    its views (:483-485), clusters keep a running fp32 sum in list order divided by the number of VALID members (:492-515), a
+    cluster without valid members is the zero vector (:500-512).  PINNED by tests/golden/proto_mean.npz."""
+    table = np.asarray(table, np.float32)
+    views = np.zeros(table.shape[:1] + table.shape[2:], np.float32)
+    for v in range(table.shape[1]):                     # torch's mean over dim 0 of a (V, D) tensor: sequential row sum, / V
+        views = (views + table[:, v]).astype(np.float32)
+    views = (views / np.float32(table.shape[1])).astype(np.float32)
+    out = np.zeros((len(ptr) - 1, table.shape[-1]), np.float32)
+    for k in range(len(ptr) - 1):
+        s, cnt = np.zeros(table.shape[-1], np.float32), 0
+        for m in member[ptr[k]:ptr[k + 1]]:
+            if m < 0 or m >= len(latlon) or not np.isfinite(latlon[m]).all():
+                continue
+            s = (s + views[m]).astype(np.float32)
+            cnt += 1
+        if cnt:
+            out[k] = s / np.float32(cnt)
+    return out

@@ -308,6 +308,7 @@ def forward(cfg: TinyVitConfig, st: Dict[str, torch.Tensor], x: torch.Tensor, *,
     c.tap("stages.0", x)
     for s in range(1, len(cfg.embed_dims)):
         x = _patch_merging(c, x, f"stages.{s}.downsample")
+        c.tap(f"stages.{s}.downsample.out", x)
         x = x.permute(0, 2, 3, 1)
         for i in range(cfg.depths[s]):
             x = _tinyvit_block_m(c, x, f"stages.{s}.blocks.{i}", cfg.num_heads[s], cfg.window_sizes[s], masks, blk)
@@ -348,7 +349,9 @@ def _mbconv_m(c, x, p, masks, blk):
     s = masks.scale(blk, 0) if masks is not None else None
     if s is not None:
         x = x * s[:, None, None, None]
-    return c.q(F.gelu(sc + x))
+    x = c.q(F.gelu(sc + x))
+    c.tap(f"{p}.out", x)
+    return x
 
 
 def _tinyvit_block_m(c, x, p, nh, ws, masks, blk):
@@ -381,6 +384,7 @@ def _tinyvit_block_m(c, x, p, nh, ws, masks, blk):
     if s2 is not None:
         h = h * s2[:, None, None]
     x = c.q(x + h)
+    c.tap(f"{p}.out", x)
     return x.view(B, H, W, C)
 
 

@@ -64,10 +64,19 @@ def test_tinyvit_table_matches_oracle_spec(L):
         ws_train = L.lib().gg_tinyvit_workspace_bytes(C.byref(cfg), 8, 1)
         ws_eval = L.lib().gg_tinyvit_workspace_bytes(C.byref(cfg), 8, 0)
         assert 0 < ws_eval < ws_train
-    # the 512 variant needs 32x32-token windows: refused loudly, not silently mis-computed
-    cfg, _, _ = make_cfg("tiny_vit_21m_512")
-    assert L.lib().gg_tinyvit_num_tensors(C.byref(cfg)) < 0
-    assert b"window" in L.lib().gg_last_error()
+    # the reference's own default (config.py:9) and the 384 variant: 32x32 / 24x24-token windows run on the online-softmax kernels
+    for name, ws2 in (("tiny_vit_21m_512", 1024), ("tiny_vit_21m_384", 576)):
+        for prec in ("bf16", "fp32"):
+            cfg, _, _ = make_cfg(name, precision=prec)
+            assert L.lib().gg_tinyvit_num_tensors(C.byref(cfg)) == 294
+            t = [t for t in _tensor_table(cfg) if t["name"] == "stages.2.blocks.0.attn.attention_biases"][0]
+            assert t["shape"] == (12, ws2)
+            assert L.lib().gg_tinyvit_workspace_bytes(C.byref(cfg), 2, 1) > 0
+    # fp32 activations double the workspace and the weight cache
+    c16, _, _ = make_cfg("tiny_vit_21m_224", precision="bf16"); c32, _, _ = make_cfg("tiny_vit_21m_224", precision="fp32")
+    assert L.lib().gg_tinyvit_workspace_bytes(C.byref(c32), 8, 1) > 1.8 * L.lib().gg_tinyvit_workspace_bytes(C.byref(c16), 8, 1)
+    bad, _, _ = make_cfg("tiny_vit_21m_224"); bad.act_dtype = 7
+    assert L.lib().gg_tinyvit_num_tensors(C.byref(bad)) < 0 and b"act_dtype" in L.lib().gg_last_error()
 
 
 def test_adapter_call_surface_on_cpu(L):
@@ -114,7 +123,17 @@ def test_lr_schedule_and_loop_helpers():
     from oracle import geo_ref as G
     for ep in range(0, 80):
         assert abs(cosine_warm_restarts_lr(ep, 5e-5) - G.cosine_warm_restarts_lr(ep, 5e-5)) < 1e-15
-    from geoguessr_ai_amd.training.train_eval_loop import _batches
+    from geoguessr_ai_amd.training.train_eval_loop import _batches, _shard, _num_batches
     ds = dict(a=torch.arange(10), b=torch.arange(10) * 2)
     seen = torch.cat([b["a"] for r in range(2) for b in _batches(ds, 2, True, 0, r, 2)])
     assert sorted(seen.tolist()) == list(range(10))                           # the two ranks partition the epoch
+    # every rank gets the same number of rows / batches for ANY (n, world, batch) -- a short rank would deadlock the all-reduce
+    from torch.utils.data import DistributedSampler
+    for n, world, bs in [(10, 4, 1), (13, 2, 3), (9, 4, 2), (5, 8, 2), (64, 8, 8), (1, 2, 1)]:
+        shards = [_shard(n, False, 0, r, world) for r in range(world)]
+        assert len({len(sh) for sh in shards}) == 1 and len(shards[0]) == -(-n // world)
+        assert set(torch.cat(shards).tolist()) == set(range(n))
+        for r in range(world):        # the exact index lists of torch's DistributedSampler (what Accelerate gives the reference)
+            assert shards[r].tolist() == list(DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=False))
+        counts = [sum(1 for _ in _batches(dict(a=torch.arange(n)), bs, True, 3, r, world)) for r in range(world)]
+        assert counts == [_num_batches(n, bs, world)] * world

@@ -552,15 +552,16 @@ def test_proto_refine_matches_oracle():
     np.testing.assert_array_equal(ref.last_guess_index.cpu().numpy(), o_idx)
 
 
-def test_scoring(ops):
+def test_scoring_matches_reference_golden(ops, golden_dir):
+    """gg_geoguessr_score against run_benchmark.py:25-65 executed by tests/golden/make_golden_r2.py: fp64 distances, INTEGER scores
+    (clamp + round-half-even) bit-exact."""
+    g = np.load(os.path.join(golden_dir, "score.npz"))
+    d, s = ops.geoguessr_score(dev(torch.from_numpy(g["pred"])), dev(torch.from_numpy(g["true"])))
+    assert d.dtype == torch.float64 and s.dtype == torch.int32
+    np.testing.assert_allclose(d.cpu().numpy(), g["dist_km"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(s.cpu().numpy(), g["score"])
     from oracle import geo_ref as G
-    rng = np.random.default_rng(2)
-    a = np.stack([rng.uniform(-180, 180, 50), rng.uniform(-90, 90, 50)], 1).astype(np.float32)
-    b = np.stack([rng.uniform(-180, 180, 50), rng.uniform(-90, 90, 50)], 1).astype(np.float32)
-    d, s = ops.geoguessr_score(dev(torch.from_numpy(a)), dev(torch.from_numpy(b)))
-    dref = G.haversine_np_score(a[:, 1], a[:, 0], b[:, 1], b[:, 0])
-    np.testing.assert_allclose(d.cpu().numpy(), dref, rtol=1e-5)
-    np.testing.assert_allclose(s.cpu().numpy(), G.geoguessr_score(dref), rtol=1e-4)
+    np.testing.assert_array_equal(s.cpu().numpy(), G.geoguessr_score(d.cpu().numpy()))
 
 
 def test_preprocess_bilinear_matches_reference_golden(ops, golden_dir):

@@ -1,0 +1,364 @@
+"""Round-2 coverage of the call surface on the GPU: the loop (train_model / evaluate_model, config c1), the refiner at c5 size and
+through its reference constructor, prototype building vs the reference's running mean, serving values, the reference's own default
+shapes (tiny_vit_21m_512, CLIP ViT-L/14-336), robustness fixes (weight-cache invalidation, workspace generations, label range)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.flatten().double(), b.flatten().double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _randomize(bb, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in bb.named_parameters():
+            if name.endswith(("bn.weight", "norm.weight")):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith(".bias") and p.dim() == 1:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif name.endswith("attention_biases"):
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+            elif name.endswith(".weight") and p.dim() == 2:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+
+# ------------------------------------------------------------------------------------------- a14 / config c1: the loop
+def test_train_model_and_evaluate_model_c1(centroids, tmp_path):
+    """BASELINE config c1 through the reference's loop contract (training/train_eval_loop.py:158-274): TinyViT-5M-224, single images
+    (panorama=False), hard CE, batch 8, gradient accumulation 2, a `metrics` callable and a refiner.  Asserts the loss decreases,
+    save-best writes a loadable state dict, early stopping fires, and evaluate_model hands `metrics` the whole validation set in order."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    from geoguessr_ai_amd.training.train_eval_loop import train_model, evaluate_model
+    torch.manual_seed(0)
+    K = 16
+    cent = centroids[:K].copy()
+    base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.0)
+    model = SuperGuessr(base, panorama=False, should_smooth_labels=False, centroids=cent).cuda()
+    g = torch.Generator().manual_seed(1)
+    tmpl = torch.randn(K, 3, 1, 1, generator=g).expand(K, 3, 224, 224)           # class templates: one constant colour per geocell
+
+    def make(n, seed):
+        gg = torch.Generator().manual_seed(seed)
+        y = torch.randint(0, K, (n,), generator=gg)
+        x = tmpl[y] + 0.3 * torch.randn(n, 3, 224, 224, generator=gg)
+        return dict(pixel_values=x, labels=torch.from_numpy(cent[y.numpy()]), labels_clf=y)
+    data = dict(train=make(44, 2), val=make(20, 3))                              # 44 = 5 batches of 8 + a tail of 4
+    seen = []
+
+    def metrics(results):
+        preds, cells, top5, lab_lla, lab_cell = results
+        assert preds.shape == (20, 2) and cells.shape == (20,) and top5.shape == (20, 5) and lab_lla.shape == (20, 2)
+        np.testing.assert_array_equal(lab_cell, data["val"]["labels_clf"].numpy())       # dataset order
+        acc = float((cells == lab_cell).mean())
+        seen.append(acc)
+        return {"Geocell_accuracy": acc if len(seen) < 3 else seen[1] - 1.0}                # collapses from epoch 2 on -> patience
+    rng = np.random.default_rng(0)
+    refiner = ProtoRefiner.from_clusters(np.arange(K), rng.standard_normal((K, 320)).astype(np.float32), cent[:, 0], cent[:, 1], K, topk=5).cuda()
+    args = types.SimpleNamespace(learning_rate=2e-3, per_device_train_batch_size=8, per_device_eval_batch_size=8, num_train_epochs=6,
+                                 gradient_accumulation_steps=2, logging_steps=1, seed=0)
+    logs = []
+    save = str(tmp_path / "best.model")
+    w_before = model.cell_layer.weight.detach().clone()
+    best = train_model(model, data, False, args, metrics, patience=2, refiner=refiner, log_fn=lambda tag, v, step: logs.append((tag, float(v), step)),
+                       save_path=save)
+    assert best is model
+    train_losses = [v for t, v, _ in logs if t == "Loss/train"]
+    val_losses = [v for t, v, _ in logs if t == "Loss/val"]
+    print(f"\n[c1] train loss first/last {train_losses[0]:.3f}/{train_losses[-1]:.3f}, val loss {[round(v, 3) for v in val_losses]}, accuracy {seen}")
+    assert len(train_losses) > 4 and np.mean(train_losses[-3:]) < 0.7 * np.mean(train_losses[:3])      # it learns
+    assert len(seen) == 4                                                        # epochs 0,1 improve; 2,3 do not -> stop after 4 evaluations
+    assert seen[1] > 1.5 / K
+    assert not torch.equal(w_before, model.cell_layer.weight.detach())
+    sd = torch.load(save, map_location="cpu")                                    # save-best (epoch 1's weights, the last improvement)
+    assert set(sd) == set(model.state_dict())
+    assert not torch.equal(sd["cell_layer.weight"], model.cell_layer.weight.detach().cpu())     # later epochs moved on
+    # evaluate_model alone: returns -Geocell_accuracy and leaves the model in train mode
+    r = evaluate_model(model, data["val"], lambda res: {"Geocell_accuracy": 0.25}, args, refiner=None)
+    assert r == -0.25 and model.training
+
+
+# ------------------------------------------------------------------------------------------- a17/a18: refiner
+def test_proto_refiner_reference_constructor_and_c5_size(golden_dir, tmp_path):
+    """ProtoRefiner(topk, max_refinement, temperature, proto_path=..., protos=...) as the reference builds it: CSV -> ProtoDataManager ->
+    prototypes built on the GPU from per-panorama embeddings (then re-loaded from the saved HF datasets), no cell_ptr argument."""
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    from geoguessr_ai_amd.models.utils import ProtoDataManager
+    from oracle import preprocess_ref as PR, proto_ref as P
+    import pandas as pd
+    csv = os.path.join(golden_dir, "proto_df_small.csv")
+    gold = json.load(open(os.path.join(golden_dir, "proto_manager.json")))
+    mgr = ProtoDataManager(pd.read_csv(csv))
+    for cid, v in gold["cells"].items():
+        sub = mgr.get_indices_for_cell(int(cid))
+        assert ([list(map(int, x)) for x in sub["indices"].tolist()] if len(sub) else []) == v["indices"]
+    D, V = 64, 4
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(30, V, D, generator=g)
+    pdir = str(tmp_path / "protos")
+    ref = ProtoRefiner(topk=5, max_refinement=1000, temperature=1.6, proto_path=csv, protos=None, embeddings=emb, protos_dir=pdir).cuda().eval()
+    assert ref.num_geocells == 8 and int(ref.cell_ptr[-1]) == 9
+    tab = mgr.cluster_table()
+    want = PR.prototype_means(emb.numpy(), np.zeros((30, 2)), tab["ptr"], tab["member"])
+    np.testing.assert_array_equal(ref.proto_emb.cpu().numpy(), want)               # same fp32 additions in the same order as the reference
+    again = ProtoRefiner(proto_path=csv, protos="load", protos_dir=pdir).cuda().eval()      # any non-None `protos` loads from disk (:104-113)
+    np.testing.assert_array_equal(again.proto_emb.cpu().numpy(), want)
+    np.testing.assert_array_equal(again.cell_ptr.cpu().numpy(), ref.cell_ptr.cpu().numpy())
+    with pytest.raises(FileNotFoundError):
+        ProtoRefiner(proto_path=str(tmp_path / "missing.csv"))
+    # forward against the oracle on this table
+    B = 17
+    q = torch.randn(B, V, D, generator=g)
+    cands = torch.stack([torch.randperm(8, generator=g)[:5] for _ in range(B)])
+    probs = torch.softmax(torch.randn(B, 5, generator=g), -1).sort(-1, descending=True).values
+    init = torch.stack([torch.rand(B, generator=g) * 360 - 180, torch.rand(B, generator=g) * 180 - 90], 1)
+    loss, llh, cell = ref(q, init, cands, probs)
+    o_llh, o_cell, o_idx = P.refine(q.numpy(), init.numpy(), cands.numpy(), probs.numpy(), ref.cell_ptr.cpu().numpy(), ref.proto_emb.cpu().numpy(),
+                                    ref.proto_lnglat.cpu().numpy())
+    np.testing.assert_array_equal(cell.cpu().numpy(), o_cell)
+    np.testing.assert_allclose(llh.cpu().numpy(), o_llh)
+
+
+def test_proto_refiner_c5_size(centroids):
+    """BASELINE config c5 shapes: B = 4096 queries, D = 576, ~50 k prototypes over 12 647 cells (1 + Poisson(3) per cell): a 512-row
+    slice against the oracle, and the per-sample property that a row's result does not depend on the batch it sits in."""
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    from oracle import proto_ref as P
+    rng = np.random.default_rng(7)
+    K, D, B = 12647, 576, 4096
+    counts = 1 + rng.poisson(3.0, K)
+    counts[rng.integers(0, K, 200)] = 0                                            # some cells without prototypes
+    gi = np.repeat(np.arange(K), counts)
+    Pn = int(counts.sum())
+    emb = rng.standard_normal((Pn, D), dtype=np.float32)
+    lng = (centroids[gi, 0] + rng.normal(0, 0.5, Pn)).astype(np.float32); lat = np.clip(centroids[gi, 1] + rng.normal(0, 0.5, Pn), -90, 90).astype(np.float32)
+    ref = ProtoRefiner.from_clusters(gi, emb, lng, lat, K, topk=5).cuda().eval()
+    q = rng.standard_normal((B, 4, D), dtype=np.float32)
+    cands = rng.integers(0, K, (B, 5)).astype(np.int64)
+    probs = np.sort(rng.dirichlet(np.ones(5), B).astype(np.float32), 1)[:, ::-1].copy()
+    init = centroids[cands[:, 0]].astype(np.float32)
+    _, llh, cell = ref(torch.from_numpy(q), torch.from_numpy(init), torch.from_numpy(cands), torch.from_numpy(probs))
+    idx = ref.last_guess_index.cpu().numpy()
+    sl = slice(1000, 1512)
+    o_llh, o_cell, o_idx = P.refine(q[sl], init[sl], cands[sl], probs[sl], ref.cell_ptr.cpu().numpy(), emb[np.argsort(gi, kind="stable")],
+                                    ref.proto_lnglat.cpu().numpy())
+    assert (idx[sl] == o_idx).mean() > 0.995                                       # fp32 distance ties aside
+    same = idx[sl] == o_idx
+    np.testing.assert_array_equal(cell.cpu().numpy()[sl][same], o_cell[same])
+    np.testing.assert_allclose(llh.cpu().numpy()[sl][same], o_llh[same])
+    _, llh2, cell2 = ref(torch.from_numpy(q[sl]), torch.from_numpy(init[sl]), torch.from_numpy(cands[sl]), torch.from_numpy(probs[sl]))
+    np.testing.assert_array_equal(cell2.cpu().numpy(), cell.cpu().numpy()[sl])
+    np.testing.assert_array_equal(llh2.cpu().numpy(), llh.cpu().numpy()[sl])
+    assert 0.02 < float((idx != 0).mean()) < 0.98                                  # the refiner does change some guesses and keeps others
+
+
+def test_prototype_means_match_reference_golden(golden_dir):
+    """build_prototypes_from_members == Embeddings.generate_embeddings of the reference (tests/golden/proto_mean.npz), bit for bit:
+    invalid members skipped, view mean, running fp32 sum in list order, zero vector for an empty cluster."""
+    from geoguessr_ai_amd.embedding_store import build_prototypes_from_members
+    g = np.load(os.path.join(golden_dir, "proto_mean.npz"))
+    got = build_prototypes_from_members(torch.from_numpy(g["table"]).cuda(), g["ptr"], g["member"], g["latlon"])
+    np.testing.assert_array_equal(got.cpu().numpy(), g["out"])
+
+
+# ------------------------------------------------------------------------------------------- a10: serving values, load_state, predict
+def test_serving_tuple_values_and_load_state(golden_dir, tmp_path):
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.models.utils import predict
+    g = np.load(os.path.join(golden_dir, "head.npz"))
+    rng = np.random.default_rng(int(g["seed"]))
+    W = rng.standard_normal((12647, 576), dtype=np.float32) * np.float32(0.05)
+    b = rng.standard_normal((12647,), dtype=np.float32) * np.float32(0.1)
+    emb = rng.standard_normal((32, 4, 576), dtype=np.float32)
+    src = SuperGuessr(base_model=None, panorama=True, should_smooth_labels=True, embed_dim=576, precision="fp32")
+    with torch.no_grad():
+        src.cell_layer.weight.copy_(torch.from_numpy(W)); src.cell_layer.bias.copy_(torch.from_numpy(b))
+    path = str(tmp_path / "head.model")
+    torch.save(src.state_dict(), path)
+    model = SuperGuessr(base_model=None, panorama=True, embed_dim=576, serving=True, precision="fp32").cuda().eval()
+    model.load_state(path)                                                        # models/super_guessr.py:208-225
+    assert torch.equal(model.cell_layer.weight.detach().cpu(), torch.from_numpy(W))
+    llh, topk, embedding = model(embedding=torch.from_numpy(emb).cuda(), labels_clf=None)
+    # fp32 head vs the REAL reference's outputs: identical predictions, probabilities to 1e-5
+    np.testing.assert_array_equal(topk.indices[:, 0].cpu().numpy(), g["preds_geocell"])
+    np.testing.assert_array_equal(topk.indices.cpu().numpy(), g["top5_idx"])
+    np.testing.assert_allclose(topk.values.cpu().numpy(), g["top5_vals"], rtol=2e-4, atol=1e-7)
+    np.testing.assert_array_equal(llh.cpu().numpy(), g["preds_LLH"])
+    np.testing.assert_array_equal(embedding.cpu().numpy(), emb)
+    # training-mode outputs of the fp32 head against the same golden (loss 1e-5 rel)
+    model.serving = False; model.should_smooth_labels = True; model.train()
+    e = torch.from_numpy(emb).cuda().requires_grad_(True)
+    out = model(embedding=e, labels=torch.from_numpy(g["labels"]).cuda(), labels_clf=torch.from_numpy(g["labels_clf"]).cuda())
+    out.loss.backward()
+    assert abs(float(out.loss) - float(g["loss"])) / float(g["loss"]) < 1e-5
+    rel = float((e.grad.cpu() - torch.from_numpy(g["demb"])).norm() / torch.from_numpy(g["demb"]).norm())
+    assert rel < 1e-4, rel
+    dW = model.cell_layer.weight.grad.cpu().numpy()
+    np.testing.assert_allclose(dW[g["labels_clf"][:8]], g["dW_rows"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(np.abs(dW).astype(np.float64).sum(), float(g["dW_abs_sum"]), rtol=1e-4)
+    # predict(): Trainer.predict-shaped output
+    model.eval()
+    po = predict(model, dict(embedding=torch.from_numpy(emb), labels=torch.from_numpy(g["labels"]), labels_clf=torch.from_numpy(g["labels_clf"])), batch_size=8)
+    np.testing.assert_array_equal(po.predictions[1], g["preds_geocell"])
+    assert po.predictions[0].shape == (32, 2) and abs(po.metrics["test_loss"] - float(g["loss"])) / float(g["loss"]) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------- reference default shapes
+def test_default_tinyvit_adapter_is_the_512_model():
+    """TinyViTAdapter() with the reference's default arguments (tiny_vit_21m_512, config.py:9): constructs, runs 32x32-token windows on the
+    online-softmax kernels, matches the oracle at batch 2 (eval) and trains (backward finite, stage-3 gradients present)."""
+    import warnings
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from oracle import tinyvit_ref as R
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = TinyViTAdapter()
+    assert m.config._name_or_path == "tiny_vit_21m_512.dist_in22k_ft_in1k" and m.config.hidden_size == 576
+    _randomize(m.backbone, 2)
+    m = m.cuda().eval()
+    cfg = R.config_for("tiny_vit_21m_512")
+    st = {k: v.detach().cpu().clone() for k, v in m.backbone.state_dict().items()}
+    x = torch.randn(2, 3, 512, 512, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        got = m(pixel_values=x.cuda()).pooler_output.cpu()
+        emu = R.forward(cfg, st, x, training=False, emulate_bf16=True)
+    rel = float((got - emu).norm() / emu.norm())
+    print(f"\n[tiny_vit_21m_512 bf16] embedding rel-L2 vs bf16-emulating oracle {rel:.3e}, max|err| {float((got - emu).abs().max()):.3e}")
+    assert rel < 2e-2
+    m.train()
+    m.freeze_all_but_last_stage()
+    out = m(pixel_values=x.cuda()).pooler_output
+    out.square().mean().backward()
+    gsum = m.backbone._params["stages.3.blocks.1.mlp.fc2.weight"].grad
+    assert gsum is not None and torch.isfinite(gsum).all() and float(gsum.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("name", ["tiny_vit_21m_384"])
+def test_fp32_mode_large_windows_train_step(name, centroids):
+    """24x24 = 576-token windows, fp32 mode, full train step vs the fp32 oracle incl. the attention-bias gradient of stage 3."""
+    try:
+        from test_gpu_precision import _train_step_case, _grad_table, relerr
+    except ImportError:
+        from tests.test_gpu_precision import _train_step_case, _grad_table, relerr
+    case = _train_step_case(name, "fp32", 1, centroids, False, seed=31)
+    emb = case["out"].embedding.detach().cpu()
+    assert relerr(emb, case["emb_o"]) < 1e-4
+    _grad_table(case, 2e-3, f"fp32 {name}")
+
+
+def test_clip_large_patch14_336_tower():
+    """CLIPVisionTower("openai/clip-vit-large-patch14-336") -- the reference's CLIP_MODEL (config.py:6): 577 tokens, patch 14 (contraction
+    588 -> padded 592), 24 layers; batch 2 against the CPU oracle with the same random weights."""
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower, CLIPEmbedding
+    from oracle import clip_ref as CR
+    tower = CLIPVisionTower("openai/clip-vit-large-patch14-336", seed=3)
+    assert tower.config.hidden_size == 1024
+    st = {k: v.clone() for k, v in tower.named_views().items()}
+    tower = tower.cuda()
+    x = torch.randn(2, 3, 336, 336, generator=torch.Generator().manual_seed(4))
+    out = tower(pixel_values=x.cuda())
+    assert out.last_hidden_state.shape == (2, 577, 1024)
+    cfg = CR.ClipVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336, patch_size=14)
+    with torch.no_grad():
+        ref = CR.forward(cfg, st, x, emulate_bf16=True)
+    got = out.pooled_mean.cpu()
+    rel = float((got - ref).norm() / ref.norm())
+    print(f"\n[CLIP L/14-336] pooled embedding rel-L2 vs bf16-emulating oracle {rel:.3e}")
+    assert rel < 2e-2
+    # the reference's wrapper class (pretrain/clip_embedder.py:10-101): panorama kwargs stack on dim 1
+    e = CLIPEmbedding("openai/clip-vit-base-patch32", device="cuda", panorama=True)
+    xs = [torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(10 + i)) for i in range(4)]
+    pano = e(xs[0].cuda(), image_2=xs[1].cuda(), image_3=xs[2].cuda(), image_4=xs[3].cuda())
+    assert pano.shape == (2, 4, 768)
+    single = e(xs[2].cuda())
+    assert torch.allclose(single, pano[:, 2], atol=1e-6)
+
+
+def test_features_only_adapter_and_tinyvit_embedding():
+    """features_only=True (models/tinyvit.py:38-46,139-143): pooled last feature map without head.norm; TinyViTEmbedding wrapper."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.pretrain.tinyvit_embedder import TinyViTEmbedding
+    from oracle import tinyvit_ref as R
+    torch.manual_seed(0)
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, features_only=True, precision="fp32")
+    _randomize(m.backbone, 4)
+    m = m.cuda().eval()
+    cfg = R.config_for("tiny_vit_5m_224")
+    st = {k: v.detach().cpu().clone() for k, v in m.backbone.state_dict().items()}
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    taps = {}
+    with torch.no_grad():
+        got = m(pixel_values=x.cuda()).pooler_output.cpu()
+        R.forward(cfg, st, x, training=False, taps=taps)
+    want = taps["stages.3"].mean(dim=(-2, -1))
+    assert float((got - want).norm() / want.norm()) < 1e-4
+    emb = TinyViTEmbedding(model_name="tiny_vit_5m_224", device="cuda", load_checkpoint=False, panorama=False)
+    v = emb(x.cuda())
+    assert v.shape == (2, 320) and torch.isfinite(v).all()
+
+
+# ------------------------------------------------------------------------------------------- robustness
+def test_weight_cache_follows_torch_optim_and_load_state_dict():
+    """The bf16 weight cache must notice parameter writes that go through torch (torch.optim steps, load_state_dict, p.copy_), not only
+    the fused AdamW kernel: the reference coordinator trains with torch.optim.AdamW."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    torch.manual_seed(0)
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.0).cuda().train()
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-2)
+    y0 = m(pixel_values=x).pooler_output
+    y0.square().mean().backward()
+    opt.step(); opt.zero_grad()
+    m.eval()
+    with torch.no_grad():
+        y1 = m(pixel_values=x).pooler_output.clone()
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        y1b = m(pixel_values=x).pooler_output.clone()
+    assert torch.equal(y1, y1b)
+    with torch.no_grad():
+        for k in sd:
+            if k.endswith("mlp.fc2.weight"):
+                sd[k] = sd[k] * 0.5
+        m.load_state_dict(sd)
+        y2 = m(pixel_values=x).pooler_output.clone()
+        m.backbone._params["head.norm.bias"].copy_(torch.full((320,), 3.0, device="cuda"))
+        y3 = m(pixel_values=x).pooler_output.clone()
+    assert float((y1 - y0.detach()).abs().max()) > 1e-3          # the optimizer step reached the forward
+    assert float((y2 - y1).abs().max()) > 1e-3                   # so did load_state_dict
+    assert float((y3 - y2).abs().max()) > 1.0                    # and a direct p.copy_
+
+
+def test_backward_of_a_stale_forward_is_refused():
+    from geoguessr_ai_amd import _lib as L
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    torch.manual_seed(0)
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.0).cuda().train()
+    xa, xb = torch.randn(2, 3, 224, 224, device="cuda"), torch.randn(3, 3, 224, 224, device="cuda")
+    ya = m(pixel_values=xa).pooler_output
+    yb = m(pixel_values=xb).pooler_output                       # overwrites the saved activations of forward A
+    with pytest.raises(L.GgError, match="workspace now holds"):
+        ya.sum().backward()
+    yb.sum().backward()                                          # the most recent forward is fine
+
+
+def test_hard_ce_label_out_of_range_is_loud(centroids):
+    from geoguessr_ai_amd import ops
+    logits = torch.randn(4, 12648, device="cuda")
+    lab = torch.tensor([3, 12647, 5, -1], device="cuda")
+    r = ops.geo_head(logits, torch.from_numpy(centroids).cuda(), labels_clf=lab, mode=2, want_dlogits=True, K=12647)
+    rows = r["loss_rows"].cpu()
+    assert torch.isfinite(rows[[0, 2]]).all() and torch.isnan(rows[[1, 3]]).all() and torch.isnan(r["loss"]).all()
+    d = r["dlogits"].float().cpu()
+    assert torch.isfinite(d[0]).all() and torch.isnan(d[1, :12647]).all()
