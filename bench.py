@@ -6,21 +6,29 @@ geocells, reference freeze policy ``freeze_all_but_last_stage``, DropPath 0.2, b
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One process per GPU; ranks shard the global batch (weak scaling: 256 panoramas per GPU) and exchange only gradients
-(sum all-reduce over RCCL, average folded into the AdamW kernel).  Inputs are synthetic and resident in HBM before the
-timed region.  Rank 0 prints ONE JSON line.
+One process per GPU; ranks shard the global batch (weak scaling: 256 panoramas per GPU), start from rank 0's parameters (broadcast) and
+exchange only gradients (sum all-reduce over RCCL, launched bucket by bucket while the backward pass is still running; the average
+is folded into the AdamW kernel).  Inputs are synthetic and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-``roofline``: the dominant kernel is the bf16 MFMA GEMM (``gemm_nt_kernel``, every Linear / 1x1 conv / im2col'd conv and
-their dgrad / wgrad).  Its launches are timed with HIP events recorded on the launch stream inside libgg (``gg_prof_*``)
-over an instrumented replay of the timed steps; each launch declares its algorithmic FLOPs (2MNK) and algorithmic bytes
-(A, B, C once each plus every second tensor its epilogue reads or writes).  The average launch's intensity
-(~120 flop/B, K <= 384 for most of TinyViT) is below the ridge point 2.5 PFLOP/s / 8 TB/s = 312 flop/B, so the binding
-roof is HBM: achieved = algorithmic bytes / duration against 8 TB/s; the MFMA-side numbers ride along as
-``mfma_achieved_tflops`` / ``mfma_frac``.  ``traffic`` = measured HBM bytes per launch (PMC, profiles/).
-``cpu_baseline``: the CPU oracle's identical step (torch fp32, all host cores) on a bounded sample, rank 0 / N=1 only.
+PRECISION.  The reference computes this path in fp32 (torch defaults), so the headline ``value`` / ``dtype`` of the line
+are measured in the fp32 reference-precision mode (f32 activations, ``v_mfma_f32_16x16x4_f32``, exact erf).  The bf16 mode (bf16
+activations / MFMA operands, fp32 accumulation and master weights -- the mode a production run would use) is measured in the same
+invocation with the same protocol (W warm-up steps, exactly K timed steps between barrier + synchronize) and reported under
+``"bf16"``.  ``--precision fp32|bf16`` runs one mode only (then ``value`` is that mode's).
+
+``roofline`` (dominant kernel class = the MFMA GEMMs: every Linear / 1x1 conv / im2col'd conv and their dgrad / wgrad).  Every launch is
+timed with HIP events recorded on the launch stream inside libgg (``gg_prof_*``) over an instrumented replay of the timed steps and
+declares its algorithmic FLOPs (2MNK) and algorithmic bytes (A, B, C once each plus every second tensor its epilogue reads or writes).
+fp32: 157.3 TFLOP/s / 8 TB/s = 20 flop/B ridge, every GEMM of the model is above it -> bound "mfma", achieved = sum flops / sum time
+against 157.3 TFLOP/s.  bf16: ridge 312 flop/B, the average launch sits near 136 flop/B -> bound "hbm", achieved = algorithmic bytes /
+time against 8 TB/s (the MFMA-side numbers ride along).  ``per_launch_frac`` = sum_i max(flops_i / peak_flops, bytes_i / 8 TB/s) /
+sum_i t_i: the roofline evaluated per launch instead of on the aggregate (the per-shape table is committed under profiles/).
+``traffic`` = measured HBM bytes per GEMM launch (rocprofv3 PMC passes of this command, profiles/).
+``cpu_baseline``: the CPU oracle's identical step (torch fp32, host cores) on a bounded sample, rank 0 / N=1 only.
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -32,6 +40,8 @@ if ROOT not in sys.path:
 
 CATS = ["gemm", "attention", "dwconv", "norm_elementwise", "head_loss", "optimizer", "data_movement"]
 GFLOP_PER_IMAGE = 18.2          # fwd 8.50 + dgrad 8.50 + wgrad(patch_embed + stage 3) 1.20
+MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense f32 / bf16 matrix peaks
+HBM_PEAK_GBS = 8000.0
 
 
 def cpu_baseline(seconds_budget: float = 20.0):
@@ -62,30 +72,21 @@ def cpu_baseline(seconds_budget: float = 20.0):
                 sample=f"{steps} oracle train steps (fwd+bwd, torch fp32) of {n} panoramas = {n * 4} images, TinyViT-21M-224 + 12647-cell head, {dt:.1f} s")
 
 
-def pmc_traffic(kernel_class):
-    """HBM bytes per launch of a kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-    separate runs of this same command; profiles/r01_hbm_traffic_pmc.json).  PMC collection cannot run inside the timed
-    process, so this is the offline measurement of the same workload; None when the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["per_kernel_class"][kernel_class]["traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+def pmc_traffic(precision):
+    """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
+    runs; tools/profile_round.sh + tools/pmc_traffic.py).  PMC collection cannot run inside the timed process, so this is the offline
+    measurement of the same workload; None when no file for this precision is committed."""
+    for name in (f"r02_hbm_traffic_pmc_{precision}.json",) + (("r01_hbm_traffic_pmc.json",) if precision == "bf16" else ()):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["per_kernel_class"]["gemm_nt"]["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--panoramas", type=int, default=256, help="panoramas per GPU per step (BASELINE: 256)")
-    ap.add_argument("--model", default="tiny_vit_21m_224")
-    ap.add_argument("--unfrozen", action="store_true", help="train every parameter instead of the reference freeze policy")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-roofline", action="store_true")
-    args = ap.parse_args()
-
+def run_mode(precision, args, rank, world, dev, x, lab):
+    """W warm-up steps, exactly K timed steps (barrier + synchronize on both sides, max over ranks), then an instrumented replay."""
     import torch
     import torch.distributed as dist
     from geoguessr_ai_amd import _lib as L
@@ -93,31 +94,19 @@ def main():
     from geoguessr_ai_amd.models.super_guessr import SuperGuessr
     from geoguessr_ai_amd.optim import AdamW
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    L.require_gpu()
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-
-    torch.manual_seed(0)                                  # identical initial weights on every rank
-    base = TinyViTAdapter(args.model, pretrained=False)
+    torch.manual_seed(0)
+    base = TinyViTAdapter(args.model, pretrained=False, precision=precision)
     model = SuperGuessr(base, panorama=True, should_smooth_labels=True, serving=False).to(dev).train()
     if args.unfrozen:
         base.unfreeze_all()
     opt = AdamW(model, lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)    # main_coordinator_idun_s3.py:246-248
-    N = args.panoramas
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)              # SURVEY.md 8(d) synthetic inputs
-    x = torch.randn(N, 4, 3, 224, 224, device=dev, generator=g)
-    lab = torch.stack([torch.rand(N, device=dev, generator=g) * 360 - 180, torch.rand(N, device=dev, generator=g) * 180 - 90], 1)
+    opt.broadcast_params()                                                # DDP start-up: every rank begins with rank 0's weights
+    N = x.shape[0]
 
     def step():
-        out = model(pixel_values=x, labels=lab)            # nearest-centroid labels + soft targets fused in the head kernel
-        out.loss.backward()
+        with opt.overlap_allreduce():                    # gradient buckets leave while the backward pass is still running
+            out = model(pixel_values=x, labels=lab)      # nearest-centroid labels + soft targets fused in the head kernel
+            out.loss.backward()
         opt.allreduce_grads()
         opt.step()
         opt.zero_grad()
@@ -140,11 +129,10 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(out.loss)
+    loss = float(out.loss.detach())
     images = args.steps * N * 4 * world
-    value = images / dt
+    res = dict(value=round(images / dt, 2), ms_per_step=round(1e3 * dt / args.steps, 3), loss=round(loss, 5))
 
-    roof, breakdown = None, None
     if not args.no_roofline:
         lib = L.lib()
         lib.gg_prof_reset(); lib.gg_prof_enable(1)
@@ -155,45 +143,103 @@ def main():
         sync()
         dt_prof = time.perf_counter() - t1
         lib.gg_prof_enable(0)
+        peak_tf = MFMA_PEAK_TF[precision]
+        tot = {c: [0.0, 0, 0.0, 0.0] for c in range(len(CATS))}        # ms, launches, flops, bytes
+        ideal_ms, mfma_bound_ms = 0.0, 0.0
+        cat, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        for i in range(lib.gg_prof_count()):
+            L.check(lib.gg_prof_record(i, C.byref(cat), C.byref(ms), C.byref(fl), C.byref(by)), "gg_prof_record")
+            t = tot[cat.value]
+            t[0] += ms.value; t[1] += 1; t[2] += fl.value; t[3] += by.value
+            if cat.value == 0:
+                tf, tb = fl.value / (peak_tf * 1e9), by.value / (HBM_PEAK_GBS * 1e6)       # ms at the MFMA / HBM roof
+                ideal_ms += max(tf, tb)
+                mfma_bound_ms += ms.value if tf >= tb else 0.0
         breakdown = {}
         for c, name in enumerate(CATS):
-            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
-            L.check(lib.gg_prof_read(c, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "gg_prof_read")
-            breakdown[name] = dict(ms_per_step=round(ms.value / args.steps, 3), launches_per_step=n.value // args.steps,
-                                   tflops=round(fl.value / max(ms.value, 1e-9) / 1e9, 2) if fl.value else None,
-                                   gbps=round(by.value / max(ms.value, 1e-9) / 1e6, 1) if by.value else None)
-            if name == "gemm":
-                # arithmetic intensity of the average launch (flops / algorithmic bytes) against the ridge point 2500 TF / 8 TB/s
-                # = 312 flop/B decides which roof binds; TinyViT's K <= 384 projections sit near 110-130 flop/B: HBM
-                ach_tf = fl.value / max(ms.value, 1e-9) / 1e9
-                ach_gb = by.value / max(ms.value, 1e-9) / 1e6
-                intensity = fl.value / max(by.value, 1.0)
-                common = dict(kernel="gemm_nt_kernel (+ gemm_tn_kernel weight gradients)", traffic=pmc_traffic("gemm_nt"), launches=n.value // args.steps,
-                              avg_launch_us=round(1e3 * ms.value / max(n.value, 1), 2), gemm_ms_per_step=round(ms.value / args.steps, 3),
-                              algorithmic_gflop_per_launch=round(fl.value / max(n.value, 1) / 1e9, 3),
-                              algorithmic_bytes_per_launch=int(by.value / max(n.value, 1)), flop_per_byte=round(intensity, 1),
-                              mfma_achieved_tflops=round(ach_tf, 2), mfma_frac=round(ach_tf / 2500.0, 4),
-                              hbm_achieved_gbps=round(ach_gb, 1), hbm_frac=round(ach_gb / 8000.0, 4))
-                if intensity < 2500.0 / 8.0:
-                    roof = dict(bound="hbm", achieved=round(ach_gb, 1), peak=8000.0, unit="GB/s", frac=round(ach_gb / 8000.0, 4), **common)
-                else:
-                    roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=2500.0, unit="TFLOP/s", frac=round(ach_tf / 2500.0, 4), **common)
+            ms_, n_, fl_, by_ = tot[c]
+            breakdown[name] = dict(ms_per_step=round(ms_ / args.steps, 3), launches_per_step=n_ // args.steps,
+                                   tflops=round(fl_ / max(ms_, 1e-9) / 1e9, 2) if fl_ else None,
+                                   gbps=round(by_ / max(ms_, 1e-9) / 1e6, 1) if by_ else None)
+        ms_, n_, fl_, by_ = tot[0]
+        ach_tf, ach_gb = fl_ / max(ms_, 1e-9) / 1e9, by_ / max(ms_, 1e-9) / 1e6
+        intensity = fl_ / max(by_, 1.0)
+        kern = "gemm_nt_f32_kernel (+ gemm_tn_f32_kernel weight gradients)" if precision == "fp32" else "gemm_nt_kernel (+ gemm_tn_kernel weight gradients)"
+        common = dict(kernel=kern, traffic=pmc_traffic(precision), launches=n_ // args.steps, avg_launch_us=round(1e3 * ms_ / max(n_, 1), 2),
+                      gemm_ms_per_step=round(ms_ / args.steps, 3), algorithmic_gflop_per_launch=round(fl_ / max(n_, 1) / 1e9, 3),
+                      algorithmic_bytes_per_launch=int(by_ / max(n_, 1)), flop_per_byte=round(intensity, 1),
+                      mfma_achieved_tflops=round(ach_tf, 2), mfma_frac=round(ach_tf / peak_tf, 4),
+                      hbm_achieved_gbps=round(ach_gb, 1), hbm_frac=round(ach_gb / HBM_PEAK_GBS, 4),
+                      per_launch_frac=round(ideal_ms / max(ms_, 1e-9), 4), mfma_bound_time_share=round(mfma_bound_ms / max(ms_, 1e-9), 3))
+        if intensity < peak_tf * 1e3 / HBM_PEAK_GBS:
+            roof = dict(bound="hbm", achieved=round(ach_gb, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gb / HBM_PEAK_GBS, 4), **common)
+        else:
+            roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach_tf / peak_tf, 4), **common)
         lib.gg_prof_reset()
         breakdown["instrumented_ms_per_step"] = round(1e3 * dt_prof / args.steps, 3)
+        res.update(roofline=roof, kernel_breakdown=breakdown)
+    res["step_tflops"] = round(res["value"] * GFLOP_PER_IMAGE / 1e3, 2)
+    res["step_frac_of_mfma_peak"] = round(res["value"] * GFLOP_PER_IMAGE / 1e3 / MFMA_PEAK_TF[precision] / world, 4)
+    del opt, model, base, out
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--panoramas", type=int, default=256, help="panoramas per GPU per step (BASELINE: 256)")
+    ap.add_argument("--model", default="tiny_vit_21m_224")
+    ap.add_argument("--precision", default="both", choices=["both", "fp32", "bf16"],
+                    help="both: fp32 (headline, the reference's arithmetic) and bf16 (reported under 'bf16')")
+    ap.add_argument("--unfrozen", action="store_true", help="train every parameter instead of the reference freeze policy")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from geoguessr_ai_amd import _lib as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    L.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    N = args.panoramas
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)              # SURVEY.md 8(d) synthetic inputs
+    x = torch.randn(N, 4, 3, 224, 224, device=dev, generator=g)
+    lab = torch.stack([torch.rand(N, device=dev, generator=g) * 360 - 180, torch.rand(N, device=dev, generator=g) * 180 - 90], 1)
+
+    modes = ["fp32", "bf16"] if args.precision == "both" else [args.precision]
+    results = {m: run_mode(m, args, rank, world, dev, x, lab) for m in modes}
+    head = results[modes[0]]
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
     if rank == 0:
-        line = dict(metric="images/sec TinyViT-21M-224 train, 4-heading batch", value=round(value, 2), unit="images/s",
-                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", data="synthetic",
+        line = dict(metric="images/sec TinyViT-21M-224 train, 4-heading batch", value=head["value"], unit="images/s",
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head["ms_per_step"],
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=modes[0], data="synthetic",
                     config=dict(workload=f"{args.model} 4x224x224 panoramas, fwd+bwd+AdamW, soft-CE over 12647 geocells, "
                                          f"{'all params' if args.unfrozen else 'freeze_all_but_last_stage'}, DropPath, train-mode BN",
-                                panoramas_per_gpu=N, images_per_gpu=N * 4, global_batch_panoramas=N * world, parallelism=f"dp{world}"),
-                    step_tflops=round(value * GFLOP_PER_IMAGE / 1e3, 2), step_frac_of_mfma_peak=round(value * GFLOP_PER_IMAGE / 1e3 / 2500.0 / world, 4),
-                    loss=round(loss, 5), roofline=roof, cpu_baseline=cpu, kernel_breakdown=breakdown)
+                                panoramas_per_gpu=N, images_per_gpu=N * 4, global_batch_panoramas=N * world, parallelism=f"dp{world}",
+                                precision=modes[0]),
+                    step_tflops=head["step_tflops"], step_frac_of_mfma_peak=head["step_frac_of_mfma_peak"], loss=head["loss"],
+                    roofline=head.get("roofline"), cpu_baseline=cpu, kernel_breakdown=head.get("kernel_breakdown"))
+        for m in modes[1:]:
+            line[m] = dict(dtype=m, **results[m])
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
