@@ -147,6 +147,9 @@ SIGNATURES = {
     "gg_view_mean_bwd_f32": (_I, [_P, _L, _P, _I, _I, _I, _P]),
     "gg_geo_head": (_I, [C.POINTER(GeoHeadArgs), _P]),
     "gg_haversine_matrix": (_I, [_P, _P, _P, _I, _I, _P]),
+    "gg_pe_add_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "gg_mha_q0_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "gg_mha_q0_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "gg_proto_refine": (_I, [C.POINTER(ProtoRefineArgs), _P]),
     "gg_geoguessr_score": (_I, [_P, _P, _I, _P, _P, _P]),      # (pred, truth, N, double* dist_km, int32* score, stream)
     "gg_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P]),

@@ -8,3 +8,4 @@ CURRENT_SAVE_PATH = "saved_models/WorldCLIP_head_landmarks.model"   # config.py:
 CLIP_PRETRAINED_HEAD = "saved_models/New_Base_smooth_avg_MT_Geo_SV.model"   # config.py:60
 EMBED_BATCH_SIZE_PER_GPU = 512                        # config.py:63
 NUM_GEOCELLS = 12647                                  # shipped geocell pickles
+NUM_ATTENTION_HEADS = 16                              # config.py (hierarchical SuperGuessr, models/super_guessr.py:91-97)

@@ -31,6 +31,7 @@ struct F32GemmParams {
     const float* dact_preact;
     float* colstats;              // [tilesM][2][N]
     int tilesM, tilesN;
+    int debug;                    // timing experiments only (GG_GEMM_F32_DEBUG): 1 no operand loads, 2 no result stores, 4 no LDS staging / barriers
 };
 
 __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float offset of 16-byte chunk kc (0..7) of a tile row
@@ -45,28 +46,119 @@ __device__ __forceinline__ float gelu_grad_exact(float x) {
 
 enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4 };
 
+// Epilogue shared by both NT kernels: lane holds C[m = m0 + wm*WROWS + mt*16 + lr][n = n0 + wn*WCOLS + nt*16 + lg*4 + r]; results leave straight
+// from the accumulator fragments (16-byte stores, 64-byte runs per row).  `smem`: at least 2*WM*BN floats, no longer read by anyone.
+template <int BM, int BN, int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
+                                                  int tm, int wm, int wn, int lr, int lg) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    const bool vec_c = (p.ldc & 3) == 0;
+        float* red = smem;                                    // [WM][2][BN] column partials (the k-loop's last barrier has passed)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+            if (EPI != FE_PLAIN && EPI != FE_DGELU && p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[r] = p.bias[min(n + r, p.N - 1)];
+            }
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int m = m0 + wm * WROWS + mt * 16 + lr;
+                f32x4 v = acc[nt][mt];
+                const bool ok = m < p.M && n < p.N;
+                const bool full = ok && vec_c && n + 3 < p.N;
+                if (EPI == FE_PLAIN) {
+                    if (p.colstats) { cs += v; cq += v * v; }   // rows beyond M / columns beyond N hold exact zeros (range-checked operand loads)
+                } else if (ok) {
+                    const float rs = ((EPI == FE_LINEAR || EPI == FE_DGELU) && p.rowscale) ? p.rowscale[m / p.rows_per_scale] : 1.f;
+                    v += b4;
+                    if (EPI == FE_GELU) {
+                        if (p.preact) {
+                            float* g = p.preact + (int64_t)m * p.ldc + n;
+                            if (full) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
+                            else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+                    }
+                    if (EPI == FE_QGELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
+                    }
+                    if (EPI == FE_DGELU) {
+                        const float* g = p.dact_preact + (int64_t)m * p.ldc + n;
+                        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                        if (full) h = *reinterpret_cast<const f32x4*>(g);
+                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
+                    }
+                    if (EPI == FE_LINEAR) {
+                        v *= rs;
+                        if (p.residual) {
+                            const float* g = p.residual + (int64_t)m * p.ldr + n;
+                            if (full && (p.ldr & 3) == 0) { const f32x4 h = *reinterpret_cast<const f32x4*>(g); v += h; }
+                            else { for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += g[r]; }
+                        }
+                    }
+                }
+                if (ok && !((p.debug & 2) && v[0] != 12345.678f)) {
+                    float* g = p.C + (int64_t)m * p.ldc + n;
+                    if (full) *reinterpret_cast<f32x4*>(g) = v;
+                    else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
+                }
+            }
+            if (EPI == FE_PLAIN && p.colstats) {
+                // column sums over this wave's 64 / 32 rows: the 16 row-lanes first, then the WM waves that share columns through LDS
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float a = cs[r], b = cq[r];
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                    if (lr == 0) {
+                        const int col = wn * WCOLS + nt * 16 + lg * 4 + r;
+                        red[(wm * 2 + 0) * BN + col] = a;
+                        red[(wm * 2 + 1) * BN + col] = b;
+                    }
+                }
+            }
+        }
+        if (EPI == FE_PLAIN && p.colstats) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+                const int which = i / BN, col = i % BN;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
+                if (n0 + col < p.N) p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = s;
+            }
+            __syncthreads();                                  // the next tile's operand staging reuses this LDS
+        }
+}
+
+// PERSISTENT workgroups: the grid is min(tiles, resident workgroups) and a workgroup walks tiles t, t + grid, ...  The operand
+// registers that prefetch the next k-tile are idle during a tile's last k-iteration, so they fetch the NEXT tile's first k-tile
+// there: a tile's prologue (first-load latency, ~10 % of a K = 384 tile, ~25 % of a K = 96 tile when measured by ablation) and its
+// epilogue stores overlap with matrix work instead of adding to it.  Result-independent of the grid size.
 template <int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32GemmParams p) {
     constexpr int BM = 128;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;           // 16-byte chunks per thread per k-tile
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * FBK];
     float* As = smem;
     float* Bs = smem + BM * FBK;
     const int tiles = p.tilesM * p.tilesN;
-    const int bid = gg_xcd_remap(blockIdx.x, tiles);
-    const int tm = bid / p.tilesN, tn = bid % p.tilesN;
-    const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int srow = threadIdx.x >> 3, skc = threadIdx.x & 7;
-    const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 4u;
-    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 4u;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
     unsigned voa[LA], vob[LB];
     int lds_a[LA], lds_b[LB];
 #pragma unroll
@@ -82,16 +174,19 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32
     const int sw = (lr & 2) | ((lr >> 1) & 4);
     const int a_base = (wm * (BM / WM) + lr) * FBK, b_base = (wn * (BN / WN) + lr) * FBK;
     const int kc0 = ((0 + lg) ^ sw) << 2, kc1 = ((4 + lg) ^ sw) << 2;
-
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + FBK - 1) / FBK;
+    const bool vec_c = (p.ldc & 3) == 0;
 
     u32x4 ra[LA], rb[LB];
-    const int nk = (p.K + FBK - 1) / FBK;
-    auto load_tile = [&](int kt) {
+    // operand loads of k-tile kt of the tile at (tm, tn): raw buffer loads, descriptor = the valid rows of that tile (rows beyond M / N
+    // read as zeros through the hardware range check), k offset in the scalar soffset, chunks beyond K pushed out of range
+    auto load_tile = [&](int tm_, int tn_, int kt) {
+        if (p.debug & 1) return;
+        const int m0_ = tm_ * BM, n0_ = tn_ * BN;
+        const unsigned bytesA = (unsigned)min(p.M - m0_, BM) * (unsigned)p.lda * 4u;
+        const unsigned bytesB = (unsigned)min(p.N - n0_, BN) * (unsigned)p.ldb * 4u;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0_ * p.lda), 0, (int)bytesA, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0_ * p.ldb), 0, (int)bytesB, 0x00020000);
         const int k0 = kt * FBK;
         const bool kin = (k0 + skc * 4) < p.K;                    // K % 4 == 0: a chunk is entirely in or out
         const int so = k0 * 4;
@@ -100,132 +195,160 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32
 #pragma unroll
         for (int i = 0; i < LB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kin ? vob[i] : 0xFFFFFFF0u), so, 0);
     };
-    load_tile(0);
-    for (int kt = 0; kt < nk; ++kt) {
+    if (p.debug & 1) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(As + lds_a[i]) = ra[i];
+        for (int i = 0; i < LA; ++i) ra[i] = (u32x4){1, 2, 3, 4};
 #pragma unroll
-        for (int i = 0; i < LB; ++i) *reinterpret_cast<u32x4*>(Bs + lds_b[i]) = rb[i];
-        __syncthreads();
-        if (kt + 1 < nk) load_tile(kt + 1);
-        const int rounds = (p.K - kt * FBK) > 16 ? 2 : 1;            // skip the all-zero upper half of a K tail
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks < rounds) {
-                const int kc = ks ? kc1 : kc0;
-                f32x4 xf[TM], wf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(As + a_base + i * 16 * FBK + kc);
-#pragma unroll
-                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Bs + b_base + i * 16 * FBK + kc);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < TM; ++mt)
-                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], xf[mt][s], acc[nt][mt], 0, 0, 0);
-            }
-        }
-        __syncthreads();
+        for (int i = 0; i < LB; ++i) rb[i] = (u32x4){1, 2, 3, 4};
     }
+    int t = blockIdx.x;
+    int bid = gg_xcd_remap(t, tiles);
+    int tm = bid / p.tilesN, tn = bid % p.tilesN;
+    load_tile(tm, tn, 0);
+    while (true) {
+        const int t_next = t + (int)gridDim.x;
+        const bool has_next = t_next < tiles;
+        const int bid_n = gg_xcd_remap(has_next ? t_next : t, tiles);
+        const int tm_n = bid_n / p.tilesN, tn_n = bid_n % p.tilesN;
+        const int m0 = tm * BM, n0 = tn * BN;
+        f32x4 acc[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            if (!(p.debug & 4)) {
+#pragma unroll
+                for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(As + lds_a[i]) = ra[i];
+#pragma unroll
+                for (int i = 0; i < LB; ++i) *reinterpret_cast<u32x4*>(Bs + lds_b[i]) = rb[i];
+                __syncthreads();
+            }
+            if (kt + 1 < nk) load_tile(tm, tn, kt + 1);
+            else if (has_next) load_tile(tm_n, tn_n, 0);              // the next tile's first operands travel under this tile's last MFMAs + epilogue
+            const int rounds = (p.K - kt * FBK) > 16 ? 2 : 1;            // skip the all-zero upper half of a K tail
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks < rounds) {
+                    const int kc = ks ? kc1 : kc0;
+                    f32x4 xf[TM], wf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(As + a_base + i * 16 * FBK + kc);
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(Bs + b_base + i * 16 * FBK + kc);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < TM; ++mt)
+                                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][s], xf[mt][s], acc[nt][mt], 0, 0, 0);
+                }
+            }
+            if (!(p.debug & 4)) __syncthreads();
+        }
 
-    // ---------------- epilogue: lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
-    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
-    const bool vec_c = (p.ldc & 3) == 0;
-    float cs[TN][4], cq[TN][4];
-    if (EPI == FE_PLAIN) {
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[nt][r] = cq[nt][r] = 0.f;
+        gemm_f32_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+        if (!has_next) break;
+        t = t_next; tm = tm_n; tn = tn_n;
     }
+}
+
+// ---------------------------------------------------------------------------------------------- NT, LDS-DMA ring (default)
+// Measured on the register-staged kernel above (GG_GEMM_F32_DEBUG ablations, M = 200 704, N = 1152, K = 384): 119 TFLOP/s as is, 131
+// without operand loads, 132 without stores, 136 without either, 144 without LDS staging / barriers, against 154 sustained by the
+// bare MFMA loop -- its one-k-tile prefetch distance (1.7 us) is shorter than a loaded HBM miss, and every k-tile pays two barriers
+// plus an exposed ds_read.  This kernel removes both: operands travel global -> LDS by LDS-DMA (`buffer_load ... lds`: no
+// staging registers, hardware range check = zero fill) into a ring of 4 stages of 16 k (16 KB each), 3 stages ahead of the matrix
+// work (counted vmcnt, one raw s_barrier per stage); the fragments of stage s+1 are read while the 64 MFMAs of stage s issue
+// (two fragment register sets), so a wave's MFMA stream has no memory wait inside the k-loop.  64 KB LDS -> 2 workgroups per CU.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int IPW> __device__ __forceinline__ void wait_stages_outstanding(int n) {      // at most n later stages (IPW DMAs each) in flight
+    if (n >= 3) wait_vmcnt<3 * IPW>();
+    else if (n == 2) wait_vmcnt<2 * IPW>();
+    else if (n == 1) wait_vmcnt<IPW>();
+    else wait_vmcnt<0>();
+}
+template <int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
+    constexpr int BM = 128, SK = 16, NST = 4;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int WCOLS = BN / WN;
+    constexpr int ROWS = BM + BN, STAGE = ROWS * SK;            // floats per stage
+    constexpr int IPW = ROWS / 16 / 4;                            // 1-KiB DMA instructions per wave per stage (16 rows x 64 B each)
+    constexpr int JA = BM / 64;                                   // the first JA of a wave's blocks are A rows, the rest B rows
+    __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    const int tm = bid / p.tilesN, tn = bid % p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+    const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 4u;
+    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
+    // DMA geometry: block blk = wave + 4 j covers tile rows 16 blk .. 16 blk + 15 (A rows first, then B rows) x 16 k: lane -> (row lane/4, 16-byte chunk lane%4)
+    const int drow = lane >> 2, dch = lane & 3;
+    unsigned voff[IPW];
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (EPI != FE_PLAIN && EPI != FE_DGELU && p.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b4[r] = p.bias[min(n + r, p.N - 1)];
-        }
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int m = m0 + wm * WROWS + mt * 16 + lr;
-            f32x4 v = acc[nt][mt];
-            const bool ok = m < p.M && n < p.N;
-            const bool full = ok && vec_c && n + 3 < p.N;
-            if (EPI == FE_PLAIN) {
-                if (p.colstats) {      // rows beyond M and columns beyond N hold exact zeros (range-checked operand loads)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { cs[nt][r] += v[r]; cq[nt][r] = fmaf(v[r], v[r], cq[nt][r]); }
-                }
-            } else if (ok) {
-                const float rs = ((EPI == FE_LINEAR || EPI == FE_DGELU) && p.rowscale) ? p.rowscale[m / p.rows_per_scale] : 1.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += b4[r];
-                if (EPI == FE_GELU) {
-                    if (p.preact) {
-                        float* g = p.preact + (int64_t)m * p.ldc + n;
-                        if (full) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
-                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
-                }
-                if (EPI == FE_QGELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
-                }
-                if (EPI == FE_DGELU) {
-                    const float* g = p.dact_preact + (int64_t)m * p.ldc + n;
-                    f32x4 h = {0.f, 0.f, 0.f, 0.f};
-                    if (full) h = *reinterpret_cast<const f32x4*>(g);
-                    else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
-                }
-                if (EPI == FE_LINEAR) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] *= rs;
-                    if (p.residual) {
-                        const float* g = p.residual + (int64_t)m * p.ldr + n;
-                        if (full && (p.ldr & 3) == 0) { const f32x4 h = *reinterpret_cast<const f32x4*>(g); v += h; }
-                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += g[r]; }
-                    }
-                }
-            }
-            if (ok) {
-                float* g = p.C + (int64_t)m * p.ldc + n;
-                if (full) *reinterpret_cast<f32x4*>(g) = v;
-                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
-            }
-        }
+    for (int j = 0; j < IPW; ++j) {
+        const int blk = wave + 4 * j;
+        const int row = (j < JA ? blk : blk - BM / 16) * 16 + drow;
+        voff[j] = (unsigned)row * (unsigned)(j < JA ? p.lda : p.ldb) * 4u + dch * 16u;
     }
-    if (EPI == FE_PLAIN && p.colstats) {
-        // column sums over this tile's rows: the 16 row-lanes of a wave first, then the WM waves that share columns through LDS
-        float* red = smem;                                    // [WM][2][BN]  (the k-loop's last barrier has passed)
+    auto issue_stage = [&](int st) {
+        const int k0 = st * SK;
+        const bool kin = (k0 + dch * 4) < p.K;                    // K % 4 == 0: a chunk is entirely in or out
+        float* base = smem + (st & (NST - 1)) * STAGE;
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt)
+        for (int j = 0; j < IPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : rsB, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
+                                                     (int)(kin ? voff[j] : 0xFFFFFFF0u), k0 * 4, 0, 0);
+    };
+    const int a_off = (wm * (BM / WM) + lr) * SK + lg * 4, b_off = BM * SK + (wn * WCOLS + lr) * SK + lg * 4;
+    auto frag_read = [&](int st, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
+        const float* base = smem + (st & (NST - 1)) * STAGE;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float a = cs[nt][r], b = cq[nt][r];
+        for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(base + a_off + i * 16 * SK);
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-                if (lr == 0) {
-                    const int col = wn * WCOLS + nt * 16 + lg * 4 + r;
-                    red[(wm * 2 + 0) * BN + col] = a;
-                    red[(wm * 2 + 1) * BN + col] = b;
-                }
-            }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * BN; i += 256) {
-            const int which = i / BN, col = i % BN;
-            float s = 0.f;
+        for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(base + b_off + i * 16 * SK);
+    };
+    f32x4 acc[TN][TM];
 #pragma unroll
-            for (int w = 0; w < WM; ++w) s += red[(w * 2 + which) * BN + col];
-            if (n0 + col < p.N) p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = s;
-        }
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + SK - 1) / SK;
+#pragma unroll
+    for (int st = 0; st < NST; ++st)
+        if (st < nk) issue_stage(st);
+    wait_stages_outstanding<IPW>(min(nk, NST) - 1);             // stage 0 has landed (this wave's part) ...
+    __builtin_amdgcn_s_barrier();                                 // ... and everybody else's
+    f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
+    frag_read(0, xa, wa);
+    auto step = [&](int s, f32x4 (&xc)[TM], f32x4 (&wc)[TN], f32x4 (&xn)[TM], f32x4 (&wn_)[TN]) {
+        const bool more = s + 1 < nk;
+        if (more) wait_stages_outstanding<IPW>(min(nk - 1, s + NST - 1) - (s + 1));     // this wave's DMAs of stage s+1 have landed
+        __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): ... and its fragment reads of stage s (whose buffer is refilled below)
+        __builtin_amdgcn_s_barrier();
+        if (s + NST < nk) issue_stage(s + NST);                   // into the buffer stage s occupied
+        if (more) frag_read(s + 1, xn, wn_);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[nt][q], xc[mt][q], acc[nt][mt], 0, 0, 0);
+    };
+    for (int s = 0; s < nk; s += 2) {
+        step(s, xa, wa, xb, wb);
+        if (s + 1 < nk) step(s + 1, xb, wb, xa, wa);
     }
+    __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring: the epilogue may reuse it
+    gemm_f32_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
 }
 
 // ------------------------------------------------------------------------------------------- TN (weight gradients)
@@ -393,6 +516,8 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     const bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
     const int bn = narrow ? 64 : 128;
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
+    static const char* dbg = getenv("GG_GEMM_F32_DEBUG");
+    p.debug = dbg ? atoi(dbg) : 0;
     const double mn = (double)a->M * a->N;
     GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
             4.0 * ((double)a->M * a->K + (double)a->N * a->K + mn) + 4.0 * mn * ((a->preact != nullptr) + (a->residual != nullptr) + (a->dact_preact != nullptr)),
@@ -403,12 +528,20 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     else if (a->act == GG_ACT_QUICK_GELU) epi = FE_QGELU;
     else if (a->bias || a->rowscale || a->residual) epi = FE_LINEAR;
     else epi = FE_PLAIN;
-    dim3 grid(p.tilesM * p.tilesN);
+    // default: the LDS-DMA ring kernel, one workgroup per tile.  GG_GEMM_F32_RING=0: the register-staged kernel with persistent
+    // workgroups (at most the resident count, each walks tiles t, t + grid, ...) -- kept for A/B timing and the DEBUG ablations
+    static const char* ring_env = getenv("GG_GEMM_F32_RING");
+    static const char* np_env = getenv("GG_GEMM_F32_NO_PERSIST");
+    const bool ring = !(ring_env && ring_env[0] == '0') && p.debug == 0;
+    const int resident = 256 * (narrow ? 4 : 3);
+    dim3 grid((ring || np_env || p.tilesM * p.tilesN <= resident) ? p.tilesM * p.tilesN : resident);
     hipStream_t st = (hipStream_t)stream;
-#define GG_LAUNCH_F32(E)                                                                                  \
-    do {                                                                                                  \
-        if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);     \
-        else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);           \
+#define GG_LAUNCH_F32(E)                                                                                          \
+    do {                                                                                                          \
+        if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);    \
+        else if (ring) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);       \
+        else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);           \
+        else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);                      \
     } while (0)
     switch (epi) {
         case FE_PLAIN: GG_LAUNCH_F32(FE_PLAIN); break;

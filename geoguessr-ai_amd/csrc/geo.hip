@@ -279,6 +279,94 @@ __global__ void score_kernel(const float* __restrict__ pred, const float* __rest
     score[i] = (int32_t)rint(pts);
 }
 
+// ---------------------------------------------------------------------------- hierarchical combine (models/super_guessr.py:89-99,340-345)
+// SuperGuessr(hierarchical=True): x (N,4,C) -> PositionalEncoder (pos_encoding[:N] is (N,1,C): the position is the BATCH index, the same
+// vector for the 4 views -- quirk C3, models/layers/positional_encoder.py:44) -> dropout -> nn.MultiheadAttention(C, 16 heads,
+// batch_first)(x, x, x)[0][:, 0].  Only query token 0 reaches the output, so attention is one score row per (sample, head):
+//   s_j = q0 . k_j / sqrt(hd),  p = softmax(s) (* dropout mask),  o = sum_j p_j v_j          (j over the V = 4 views)
+// The in/out projections are gg_gemm_nt_f32; these kernels are the elementwise / tiny-reduction parts.  fp32 in both modes.
+__global__ void pe_add_kernel(const float* __restrict__ x, const float* __restrict__ pe, const float* __restrict__ mask, float* __restrict__ out,
+                              int N, int V, int C) {
+    const int64_t total = (int64_t)N * V * C;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t n = i / ((int64_t)V * C);
+        const float v = pe ? x[i] + pe[n * C + c] : x[i];
+        out[i] = mask ? v * mask[i] : v;
+    }
+}
+// qkv f32 [N*V, 3C] = [q | k | v], head h at columns h*hd; one 16-lane group per (sample, head), lanes stride over hd.
+// o0 [N, C] = attention output of query token 0; probs [N, H, V] = post-softmax (pre-dropout) row (saved for the backward pass)
+__global__ __launch_bounds__(256) void mha_q0_fwd_kernel(const float* __restrict__ qkv, const float* __restrict__ pmask, float* __restrict__ o0,
+                                                         float* __restrict__ probs, int N, int V, int C, int H, float scale) {
+    const int hd = C / H;
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    if (g >= N * H) return;
+    const int n = g / H, h = g % H;
+    const float* q = qkv + (int64_t)n * V * 3 * C + h * hd;                  // token 0 of sample n
+    float s[8];
+    float mx = -INFINITY;
+    for (int j = 0; j < V; ++j) {
+        const float* k = qkv + ((int64_t)n * V + j) * 3 * C + C + h * hd;
+        float a = 0.f;
+        for (int d = l; d < hd; d += 16) a = fmaf(q[d], k[d], a);
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+        s[j] = a * scale;
+        mx = fmaxf(mx, s[j]);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < V; ++j) { s[j] = expf(s[j] - mx); sum += s[j]; }
+    for (int j = 0; j < V; ++j) {
+        s[j] /= sum;
+        if (l == 0) probs[((int64_t)n * H + h) * V + j] = s[j];
+        if (pmask) s[j] *= pmask[((int64_t)n * H + h) * V + j];
+    }
+    for (int d = l; d < hd; d += 16) {
+        float a = 0.f;
+        for (int j = 0; j < V; ++j) a = fmaf(s[j], qkv[((int64_t)n * V + j) * 3 * C + 2 * C + h * hd + d], a);
+        o0[(int64_t)n * C + h * hd + d] = a;
+    }
+}
+// do0 [N, C] -> dqkv [N*V, 3C] (every element written: the q rows of tokens 1..V-1 are zero)
+__global__ __launch_bounds__(256) void mha_q0_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ probs, const float* __restrict__ pmask,
+                                                         const float* __restrict__ do0, float* __restrict__ dqkv, int N, int V, int C, int H, float scale) {
+    const int hd = C / H;
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 4, l = threadIdx.x & 15;
+    if (g >= N * H) return;
+    const int n = g / H, h = g % H;
+    const float* q = qkv + (int64_t)n * V * 3 * C + h * hd;
+    const float* go = do0 + (int64_t)n * C + h * hd;
+    float p[8], dp[8];
+    float dot = 0.f;
+    for (int j = 0; j < V; ++j) {
+        const float* v = qkv + ((int64_t)n * V + j) * 3 * C + 2 * C + h * hd;
+        float a = 0.f;
+        for (int d = l; d < hd; d += 16) a = fmaf(go[d], v[d], a);
+        a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+        const float m = pmask ? pmask[((int64_t)n * H + h) * V + j] : 1.f;
+        p[j] = probs[((int64_t)n * H + h) * V + j];
+        dp[j] = a * m;                      // gradient w.r.t. the pre-dropout probability
+        dot = fmaf(p[j], dp[j], dot);
+    }
+    for (int j = 0; j < V; ++j) {
+        const float ds = p[j] * (dp[j] - dot) * scale;
+        const float pm = p[j] * (pmask ? pmask[((int64_t)n * H + h) * V + j] : 1.f);
+        float* row = dqkv + ((int64_t)n * V + j) * 3 * C;
+        const float* k = qkv + ((int64_t)n * V + j) * 3 * C + C + h * hd;
+        for (int d = l; d < hd; d += 16) {
+            row[C + h * hd + d] = ds * q[d];                 // dk_j
+            row[2 * C + h * hd + d] = pm * go[d];            // dv_j
+            if (j > 0) row[h * hd + d] = 0.f;                // dq of the unused query tokens
+        }
+        dp[j] = ds;
+    }
+    for (int d = l; d < hd; d += 16) {
+        float a = 0.f;
+        for (int j = 0; j < V; ++j) a = fmaf(dp[j], qkv[((int64_t)n * V + j) * 3 * C + C + h * hd + d], a);
+        dqkv[(int64_t)n * V * 3 * C + h * hd + d] = a;       // dq0
+    }
+}
+
 // ------------------------------------------------------------------------------------------- host
 extern "C" int gg_geo_head(const GgGeoHeadArgs* a, void* stream) {
     GG_CHECK(a && a->logits && a->centroids, "gg_geo_head: null logits/centroids");
@@ -332,6 +420,29 @@ extern "C" int gg_proto_refine(const GgProtoRefineArgs* a, void* stream) {
 extern "C" int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, double* dist_km, int32_t* score, void* stream) {
     GG_CHECK(pred_llh && true_llh && score && N > 0, "gg_geoguessr_score: bad args");
     hipLaunchKernelGGL(score_kernel, dim3((unsigned)gg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred_llh, true_llh, N, dist_km, score);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gg_pe_add_f32(const float* x, const float* pe, const float* mask, float* out, int N, int V, int C, void* stream) {
+    GG_CHECK(x && out && N > 0 && V > 0 && C > 0, "gg_pe_add_f32: bad args");      // pe == NULL: out = x * mask (the dropout's backward)
+    const int64_t total = (int64_t)N * V * C;
+    hipLaunchKernelGGL(pe_add_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(total, 256), 16384)), dim3(256), 0, (hipStream_t)stream, x, pe, mask, out, N, V, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_mha_q0_fwd(const float* qkv, const float* pmask, float* o0, float* probs, int N, int V, int C, int H, void* stream) {
+    GG_CHECK(qkv && o0 && probs && N > 0 && V > 0 && V <= 8 && H > 0 && C % H == 0, "gg_mha_q0_fwd: bad args (V <= 8, C %% H == 0)");
+    hipLaunchKernelGGL(mha_q0_fwd_kernel, dim3((unsigned)gg_cdiv((int64_t)N * H * 16, 256)), dim3(256), 0, (hipStream_t)stream, qkv, pmask, o0, probs, N, V,
+                       C, H, 1.0f / sqrtf((float)(C / H)));
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_mha_q0_bwd(const float* qkv, const float* probs, const float* pmask, const float* do0, float* dqkv, int N, int V, int C, int H,
+                             void* stream) {
+    GG_CHECK(qkv && probs && do0 && dqkv && N > 0 && V > 0 && V <= 8 && H > 0 && C % H == 0, "gg_mha_q0_bwd: bad args");
+    hipLaunchKernelGGL(mha_q0_bwd_kernel, dim3((unsigned)gg_cdiv((int64_t)N * H * 16, 256)), dim3(256), 0, (hipStream_t)stream, qkv, probs, pmask, do0, dqkv,
+                       N, V, C, H, 1.0f / sqrtf((float)(C / H)));
     GG_LAUNCH_CHECK();
     return 0;
 }

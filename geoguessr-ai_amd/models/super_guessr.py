@@ -7,11 +7,12 @@ top-k (:355-365), haversine-smoothed soft cross-entropy or hard CE (:372-383) an
 launches: view-mean, one MFMA GEMM, and the fused per-row head kernel (``csrc/geo.hip``).
 
 Divergences from the reference, on purpose: the centroid table is data shipped with the package or
-passed in (C7/C8: no 29 s unpickling, explicit ordering); ``labels_clf=None`` is accepted (C6); the hierarchical
-(MultiheadAttention) combine -- off in every caller -- is not built.
+passed in (C7/C8: no 29 s unpickling, explicit ordering); ``labels_clf=None`` is accepted (C6).  The hierarchical combine
+(``hierarchical=True``: PositionalEncoder + MultiheadAttention, token 0) runs as HIP launches too (``_HierFn``).
 """
 from __future__ import annotations
 
+import math
 import os
 from typing import Optional
 
@@ -22,7 +23,7 @@ from torch.nn.parameter import Parameter
 
 from .. import _lib as L
 from .. import ops
-from ..config import CLIP_EMBED_DIM, CLIP_PRETRAINED_HEAD, LABEL_SMOOTHING_CONSTANT
+from ..config import CLIP_EMBED_DIM, CLIP_PRETRAINED_HEAD, LABEL_SMOOTHING_CONSTANT, NUM_ATTENTION_HEADS
 from .utils import ModelOutput, TopK
 
 _DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
@@ -100,6 +101,84 @@ class _HeadFn(torch.autograd.Function):
         return None, demb, dW, db, None, None, None
 
 
+class _HierFn(torch.autograd.Function):
+    """The hierarchical combine (models/super_guessr.py:340-345): ``self_attn(pos_encoder(x), ...)[0][:, 0]`` as HIP launches -- PE add (+dropout),
+    in_proj (f32 MFMA GEMM), one softmax row per (sample, head) for query token 0 (the only one that reaches the output), out_proj on the
+    token-0 rows.  fp32 in both precision modes."""
+
+    @staticmethod
+    def forward(ctx, model: "SuperGuessr", emb: Tensor, in_w: Tensor, in_b: Tensor, out_w: Tensor, out_b: Tensor):
+        L.require_gpu()
+        x = emb.to(torch.float32).contiguous()
+        N, V, Cc = x.shape
+        H = model.self_attn.num_heads
+        if N > model.pos_encoder.pos_encoding.shape[0]:
+            raise L.GgError(f"hierarchical SuperGuessr: batch {N} exceeds PositionalEncoder max_len {model.pos_encoder.pos_encoding.shape[0]} "
+                            "(the reference indexes the encoding by BATCH position, models/layers/positional_encoder.py:44)")
+        dev = x.device
+        pe = model.pos_encoder.pos_encoding.detach()[:N, 0, :].contiguous()
+        mask = pmask = None
+        if model.training:          # nn.Dropout(0.1) of the encoder and of the attention weights (scale_by_keep)
+            p1, p2 = model.pos_encoder.dropout_p, model.self_attn.dropout
+            if p1 > 0:
+                mask = ((torch.rand((N, V, Cc), device=dev) >= p1).to(torch.float32) / (1.0 - p1)).contiguous()
+            if p2 > 0:
+                pmask = ((torch.rand((N, H, V), device=dev) >= p2).to(torch.float32) / (1.0 - p2)).contiguous()
+        mask = getattr(model, "_hier_masks", (mask, pmask))[0] if hasattr(model, "_hier_masks") else mask          # tests inject masks
+        pmask = model._hier_masks[1] if hasattr(model, "_hier_masks") else pmask
+        lib = L.lib()
+        xin = torch.empty((N * V, Cc), dtype=torch.float32, device=dev)
+        L.check(lib.gg_pe_add_f32(L.ptr(x), L.ptr(pe), L.ptr(mask), L.ptr(xin), N, V, Cc, L.stream()), "gg_pe_add_f32")
+        qkv = ops.gemm_nt(xin, in_w.detach().contiguous(), bias=in_b.detach())
+        o0 = torch.empty((N, Cc), dtype=torch.float32, device=dev)
+        probs = torch.empty((N, H, V), dtype=torch.float32, device=dev)
+        L.check(lib.gg_mha_q0_fwd(L.ptr(qkv), L.ptr(pmask), L.ptr(o0), L.ptr(probs), N, V, Cc, H, L.stream()), "gg_mha_q0_fwd")
+        out = ops.gemm_nt(o0, out_w.detach().contiguous(), bias=out_b.detach())
+        ctx.save_for_backward(xin, qkv, probs, o0, in_w, out_w)
+        ctx.masks, ctx.dims = (mask, pmask), (N, V, Cc, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, qkv, probs, o0, in_w, out_w = ctx.saved_tensors
+        mask, pmask = ctx.masks
+        N, V, Cc, H = ctx.dims
+        lib = L.lib()
+        dout = dout.to(torch.float32).contiguous()
+        do0 = ops.gemm_nt(dout, out_w.detach().t().contiguous())                      # (N, C): dout . W_out
+        d_out_w = ops.gemm_tn(dout, o0) if ctx.needs_input_grad[4] else None
+        d_out_b = ops.colsum_bf16(dout) if ctx.needs_input_grad[5] else None
+        dqkv = torch.empty_like(qkv)
+        L.check(lib.gg_mha_q0_bwd(L.ptr(qkv), L.ptr(probs), L.ptr(pmask), L.ptr(do0), L.ptr(dqkv), N, V, Cc, H, L.stream()), "gg_mha_q0_bwd")
+        d_in_w = ops.gemm_tn(dqkv, xin) if ctx.needs_input_grad[2] else None
+        d_in_b = ops.colsum_bf16(dqkv) if ctx.needs_input_grad[3] else None
+        demb = None
+        if ctx.needs_input_grad[1]:
+            dxin = ops.gemm_nt(dqkv, in_w.detach().t().contiguous())                  # (N*V, C): dqkv . W_in
+            if mask is not None:
+                demb = torch.empty_like(dxin)
+                L.check(lib.gg_pe_add_f32(L.ptr(dxin), None, L.ptr(mask), L.ptr(demb), N, V, Cc, L.stream()), "gg_pe_add_f32")
+            else:
+                demb = dxin
+            demb = demb.view(N, V, Cc)
+        return None, demb, d_in_w, d_in_b, d_out_w, d_out_b
+
+
+class _PositionalEncoder(nn.Module):
+    """Parameter holder of the reference's ``PositionalEncoder`` (models/layers/positional_encoder.py:5-44): the sinusoidal table
+    ``pos_encoding`` (max_len, 1, C) as a frozen parameter (state-dict key ``pos_encoder.pos_encoding``), dropout 0.1."""
+
+    def __init__(self, dim_model: int, dropout_p: float = 0.1, max_len: int = 1000):
+        super().__init__()
+        self.dropout_p = dropout_p
+        pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+        freq = torch.exp(torch.arange(0, dim_model, 2, dtype=torch.float32) * (-math.log(10000.0) / dim_model))
+        table = torch.zeros(max_len, dim_model)
+        table[:, 0::2] = torch.sin(pos * freq)
+        table[:, 1::2] = torch.cos(pos * freq)
+        self.register_parameter("pos_encoding", nn.Parameter(table.unsqueeze(1).contiguous(), requires_grad=False))
+
+
 class _CellLayer(nn.Module):
     """Parameter holder with nn.Linear's state-dict keys (``cell_layer.weight`` (K,C), ``cell_layer.bias`` (K,))."""
 
@@ -126,9 +205,6 @@ class SuperGuessr(nn.Module):
         self.precision = "fp32" if PRECISIONS[self.precision] == 1 else "bf16"
         if len(kwargs) > 0:
             print(f"Not using keyword arguments: {list(kwargs.keys())}")
-        if hierarchical:
-            raise NotImplementedError("hierarchical=True (positional encoding + MultiheadAttention combine, "
-                                      "models/super_guessr.py:89-99) is off in every reference caller and is not built")
         self.base_model = base_model
         self.panorama = panorama
         self.hidden_size = embed_dim
@@ -143,6 +219,14 @@ class SuperGuessr(nn.Module):
         self.geocell_centroid_coords = nn.Parameter(cent.contiguous(), requires_grad=False)
         self.num_cells = cent.size(0)
         self.input_dim = self.hidden_size
+        if self.hierarchical:                                   # models/super_guessr.py:89-99
+            print("Number of attention heads:", NUM_ATTENTION_HEADS)
+            self.heading_pad = 0
+            self.pos_encoder = _PositionalEncoder(self.input_dim + self.heading_pad)
+            # parameter container with nn.MultiheadAttention's init and state-dict keys (in_proj_weight, in_proj_bias, out_proj.*); its
+            # torch forward is never called -- the arithmetic is _HierFn
+            self.self_attn = nn.MultiheadAttention(self.input_dim + self.heading_pad, NUM_ATTENTION_HEADS, dropout=0.1, batch_first=True)
+            self.relu = nn.ReLU()
         self.cell_layer = _CellLayer(self.input_dim, self.num_cells)
         self._wc = None
         self._wc_version = None
@@ -272,6 +356,10 @@ class SuperGuessr(nn.Module):
         if not self.training and self.serving:
             mode = 0
         head_in = embedding if (self.panorama or embedding.dim() == 2) else embedding
+        if self.panorama and self.hierarchical:                 # (N, 4, C) -> self_attn(pos_encoder(x))[:, 0]  (:340-345)
+            assert embedding.dim() == 3, "hierarchical=True expects (N, 4, C) embeddings"
+            a = self.self_attn
+            head_in = _HierFn.apply(self, embedding, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)
         loss, preds, llh, tv, ti = _HeadFn.apply(self, head_in, self.cell_layer.weight, self.cell_layer.bias,
                                                  labels.contiguous() if labels is not None else None,
                                                  labels_clf.contiguous() if labels_clf is not None else None, mode)

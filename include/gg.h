@@ -240,6 +240,17 @@ typedef struct GgGeoHeadArgs {
 int gg_geo_head(const GgGeoHeadArgs* args, void* stream);
 int gg_haversine_matrix(const float* x, const float* centroids, float* out, int N, int K, void* stream);   /* models/utils.py:39 */
 
+/* ---------------------------------------------------------------- hierarchical combine (models/super_guessr.py:89-99,340-345)
+ * SuperGuessr(hierarchical=True): PositionalEncoder (position = batch index, models/layers/positional_encoder.py:44) ->
+ * nn.MultiheadAttention(C, NUM_ATTENTION_HEADS = 16)(x, x, x)[0][:, 0].  The projections are gg_gemm_nt_f32; these are the rest.
+ * fp32.  mask / pmask: optional dropout scales (keep / (1-p)); NULL in eval mode. */
+int gg_pe_add_f32(const float* x /* (N,V,C) */, const float* pe /* (>=N, C) */, const float* mask /* (N,V,C) or NULL */, float* out, int N, int V, int C,
+                  void* stream);
+/* qkv f32 [N*V, 3C] = in_proj output [q | k | v]; o0 (N, C) = attention output of query token 0; probs (N, H, V) saved softmax row */
+int gg_mha_q0_fwd(const float* qkv, const float* pmask /* (N,H,V) or NULL */, float* o0, float* probs, int N, int V, int C, int H, void* stream);
+int gg_mha_q0_bwd(const float* qkv, const float* probs, const float* pmask, const float* do0 /* (N, C) */, float* dqkv /* [N*V, 3C], fully written */,
+                  int N, int V, int C, int H, void* stream);
+
 /* ---------------------------------------------------------------- ProtoRefiner.forward (models/proto_refiner.py:129-237) */
 typedef struct GgProtoRefineArgs {
     const float* embedding; int B, V, D;  /* f32 (B,V,D); V views are averaged (:150-151); V=1 for (B,D) */

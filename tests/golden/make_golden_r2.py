@@ -140,12 +140,54 @@ def make_proto_manager():
     print("proto_manager.json:", {k: len(v["indices"]) for k, v in cells.items()})
 
 
+def make_hier():
+    """SuperGuessr(hierarchical=True) of the reference in eval mode (dropouts off): forward + backward on embeddings."""
+    import torch
+    from models.super_guessr import SuperGuessr
+    from models.utils import haversine_matrix
+    torch.manual_seed(0)
+    m = SuperGuessr(base_model=None, panorama=True, hierarchical=True, should_smooth_labels=True, embed_dim=576).eval()
+    K, C = m.num_cells, 576
+    rng = np.random.default_rng(99)
+    W = rng.standard_normal((K, C), dtype=np.float32) * np.float32(0.05)
+    b = rng.standard_normal((K,), dtype=np.float32) * np.float32(0.1)
+    in_w = rng.standard_normal((3 * C, C), dtype=np.float32) * np.float32(0.04)
+    in_b = rng.standard_normal((3 * C,), dtype=np.float32) * np.float32(0.1)
+    out_w = rng.standard_normal((C, C), dtype=np.float32) * np.float32(0.04)
+    out_b = rng.standard_normal((C,), dtype=np.float32) * np.float32(0.1)
+    emb = rng.standard_normal((24, 4, C), dtype=np.float32)
+    lab = np.stack([rng.uniform(-180, 180, 24), rng.uniform(-90, 90, 24)], 1).astype(np.float32)
+    with torch.no_grad():
+        m.cell_layer.weight.copy_(torch.from_numpy(W)); m.cell_layer.bias.copy_(torch.from_numpy(b))
+        m.self_attn.in_proj_weight.copy_(torch.from_numpy(in_w)); m.self_attn.in_proj_bias.copy_(torch.from_numpy(in_b))
+        m.self_attn.out_proj.weight.copy_(torch.from_numpy(out_w)); m.self_attn.out_proj.bias.copy_(torch.from_numpy(out_b))
+    lab_t = torch.from_numpy(lab)
+    clf = torch.argmin(haversine_matrix(lab_t, m.geocell_centroid_coords.data.t()), dim=-1)
+    e = torch.from_numpy(emb).requires_grad_(True)
+    out = m(embedding=e, labels=lab_t, labels_clf=clf)
+    out.loss.backward()
+    a = m.self_attn
+    np.savez_compressed(os.path.join(HERE, "hier.npz"), seed=99, heads=a.num_heads, labels=lab, labels_clf=clf.numpy(),
+                        checks=np.asarray([W.astype(np.float64).sum(), in_w.astype(np.float64).sum(), emb.astype(np.float64).sum()]),
+                        loss=np.float32(out.loss.item()), preds_geocell=out.preds_geocell.numpy(), top5_idx=out.top5_geocells.indices.numpy(),
+                        top5_vals=out.top5_geocells.values.detach().numpy(), demb=e.grad.numpy(),
+                        d_in_w_abs=np.float64(a.in_proj_weight.grad.abs().double().sum().item()), d_in_w_rows=a.in_proj_weight.grad.numpy()[[0, 577, 1200]],
+                        d_in_b=a.in_proj_bias.grad.numpy(), d_out_w_rows=a.out_proj.weight.grad.numpy()[[0, 100, 575]], d_out_b=a.out_proj.bias.grad.numpy(),
+                        pe_rows=m.pos_encoder.pos_encoding.detach().numpy()[[0, 1, 7, 999], 0, :8],
+                        state_keys=np.asarray(sorted(k for k in m.state_dict() if k.startswith(("pos_encoder", "self_attn")))))
+    print("hier.npz: loss", out.loss.item())
+
+
 def main():
     _import_reference()
+    if "--hier-only" in sys.argv:
+        make_hier()
+        return
     make_score()
     make_proto_manager()
     make_proto_mean()
-    for f in ("score.npz", "proto_mean.npz", "proto_df_small.csv", "proto_manager.json"):
+    make_hier()
+    for f in ("score.npz", "proto_mean.npz", "proto_df_small.csv", "proto_manager.json", "hier.npz"):
         print(f"  {f:30s} {os.path.getsize(os.path.join(HERE, f)) / 1024:.1f} KB")
 
 

@@ -362,3 +362,75 @@ def test_hard_ce_label_out_of_range_is_loud(centroids):
     assert torch.isfinite(rows[[0, 2]]).all() and torch.isnan(rows[[1, 3]]).all() and torch.isnan(r["loss"]).all()
     d = r["dlogits"].float().cpu()
     assert torch.isfinite(d[0]).all() and torch.isnan(d[1, :12647]).all()
+
+
+# ------------------------------------------------------------------------------------------- a11: hierarchical combine
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_hierarchical_superguessr_matches_reference_golden(golden_dir, precision):
+    """SuperGuessr(hierarchical=True) -- PositionalEncoder by batch index + MultiheadAttention(16 heads) + token 0 (models/super_guessr.py:
+    89-99,340-345) -- against the REAL reference's eval-mode outputs and gradients (tests/golden/hier.npz)."""
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    g = np.load(os.path.join(golden_dir, "hier.npz"))
+    K, C = 12647, 576
+    rng = np.random.default_rng(int(g["seed"]))
+    W = rng.standard_normal((K, C), dtype=np.float32) * np.float32(0.05)
+    b = rng.standard_normal((K,), dtype=np.float32) * np.float32(0.1)
+    in_w = rng.standard_normal((3 * C, C), dtype=np.float32) * np.float32(0.04)
+    in_b = rng.standard_normal((3 * C,), dtype=np.float32) * np.float32(0.1)
+    out_w = rng.standard_normal((C, C), dtype=np.float32) * np.float32(0.04)
+    out_b = rng.standard_normal((C,), dtype=np.float32) * np.float32(0.1)
+    emb = rng.standard_normal((24, 4, C), dtype=np.float32)
+    np.testing.assert_allclose([W.astype(np.float64).sum(), in_w.astype(np.float64).sum(), emb.astype(np.float64).sum()], g["checks"], rtol=1e-12)
+    m = SuperGuessr(base_model=None, panorama=True, hierarchical=True, should_smooth_labels=True, embed_dim=576, precision=precision).cuda().eval()
+    assert sorted(k for k in m.state_dict() if k.startswith(("pos_encoder", "self_attn"))) == [str(k) for k in g["state_keys"]]
+    np.testing.assert_allclose(m.pos_encoder.pos_encoding.detach().cpu().numpy()[[0, 1, 7, 999], 0, :8], g["pe_rows"], rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        m.cell_layer.weight.copy_(torch.from_numpy(W)); m.cell_layer.bias.copy_(torch.from_numpy(b))
+        m.self_attn.in_proj_weight.copy_(torch.from_numpy(in_w)); m.self_attn.in_proj_bias.copy_(torch.from_numpy(in_b))
+        m.self_attn.out_proj.weight.copy_(torch.from_numpy(out_w)); m.self_attn.out_proj.bias.copy_(torch.from_numpy(out_b))
+    e = torch.from_numpy(emb).cuda().requires_grad_(True)
+    out = m(embedding=e, labels=torch.from_numpy(g["labels"]).cuda(), labels_clf=torch.from_numpy(g["labels_clf"]).cuda())
+    out.loss.backward()
+    f32 = precision == "fp32"
+    assert abs(float(out.loss) - float(g["loss"])) / float(g["loss"]) < (1e-5 if f32 else 2e-3)
+    a = m.self_attn
+    rel = lambda x, y: float(np.linalg.norm(np.asarray(x, np.float64) - y) / (np.linalg.norm(y) + 1e-30))
+    tol = 2e-4 if f32 else 3e-2
+    assert rel(e.grad.cpu().numpy(), g["demb"]) < tol
+    assert rel(a.in_proj_weight.grad.cpu().numpy()[[0, 577, 1200]], g["d_in_w_rows"]) < tol
+    assert rel(a.in_proj_bias.grad.cpu().numpy(), g["d_in_b"]) < tol
+    assert rel(a.out_proj.weight.grad.cpu().numpy()[[0, 100, 575]], g["d_out_w_rows"]) < tol
+    assert rel(a.out_proj.bias.grad.cpu().numpy(), g["d_out_b"]) < tol
+    assert abs(float(a.in_proj_weight.grad.abs().double().sum()) - float(g["d_in_w_abs"])) / float(g["d_in_w_abs"]) < tol
+    if f32:
+        np.testing.assert_array_equal(out.preds_geocell.cpu().numpy(), g["preds_geocell"])
+        np.testing.assert_array_equal(out.top5_geocells.indices.cpu().numpy(), g["top5_idx"])
+        np.testing.assert_allclose(out.top5_geocells.values.detach().cpu().numpy(), g["top5_vals"], rtol=5e-4, atol=1e-7)
+    else:
+        assert (out.preds_geocell.cpu().numpy() == g["preds_geocell"]).mean() >= 0.9
+    # train mode: dropout masks as inputs, checked against autograd on the same masked computation
+    m.train()
+    N, V, H = 5, 4, 16
+    gen = torch.Generator().manual_seed(3)
+    mask = ((torch.rand(N, V, C, generator=gen) >= 0.1).float() / 0.9).cuda()
+    pmask = ((torch.rand(N, H, V, generator=gen) >= 0.1).float() / 0.9).cuda()
+    m._hier_masks = (mask, pmask)
+    x = torch.from_numpy(emb[:N]).cuda().requires_grad_(True)
+    from geoguessr_ai_amd.models.super_guessr import _HierFn
+    y = _HierFn.apply(m, x, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias)
+    dy = torch.randn(N, C, generator=gen).cuda()
+    m.zero_grad()
+    y.backward(dy)
+    xd = torch.from_numpy(emb[:N]).double().requires_grad_(True)
+    pe = m.pos_encoder.pos_encoding.detach().cpu().double()[:N]
+    xin = (xd + pe) * mask.cpu().double()
+    qkv = xin @ torch.from_numpy(in_w).double().t() + torch.from_numpy(in_b).double()
+    q, k, v = qkv.split(C, dim=-1)
+    hd = C // H
+    q0 = q[:, 0].view(N, H, 1, hd); kk = k.view(N, V, H, hd).transpose(1, 2); vv = v.view(N, V, H, hd).transpose(1, 2)
+    p = torch.softmax(q0 @ kk.transpose(-1, -2) / hd ** 0.5, -1) * pmask.cpu().double().unsqueeze(2)
+    yr = (p @ vv).reshape(N, C) @ torch.from_numpy(out_w).double().t() + torch.from_numpy(out_b).double()
+    yr.backward(dy.cpu().double())
+    assert rel(y.detach().cpu().numpy(), yr.detach().numpy()) < 1e-5
+    assert rel(x.grad.cpu().numpy(), xd.grad.numpy()) < 1e-5
+    del m._hier_masks

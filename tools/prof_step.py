@@ -12,7 +12,9 @@ from geoguessr_ai_amd.optim import AdamW
 CATS = ["gemm", "attention", "dwconv", "norm", "head", "optim", "move"]
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-base = TinyViTAdapter("tiny_vit_21m_224", pretrained=False)
+PREC = "fp32" if "--fp32" in sys.argv else "bf16"
+PEAK = 157.3e9 if PREC == "fp32" else 2.5e12      # flop / ms
+base = TinyViTAdapter("tiny_vit_21m_224", pretrained=False, precision=PREC)
 model = SuperGuessr(base, panorama=True, should_smooth_labels=True, serving=False).to(dev).train()
 if "--unfrozen" in sys.argv: base.unfreeze_all()
 opt = AdamW(model, lr=5e-5)
@@ -37,9 +39,12 @@ for i in range(lib.gg_prof_count()):
     g = groups.setdefault((c.value, fl.value, by.value), [0, 0.0, i])
     g[0] += 1; g[1] += ms.value
 tot = sum(g[1] for g in groups.values()) / K
-print(f"total {tot:.2f} ms/step")
+print(f"precision {PREC}: total {tot:.2f} ms/step of instrumented kernels")
+ideal = sum(n * max(fl / PEAK, by / 8e9) for (c, fl, by), (n, ms, first) in groups.items() if c == 0) / K
+gemm = sum(ms for (c, fl, by), (n, ms, first) in groups.items() if c == 0) / K
+print(f"GEMM per-launch roofline: sum max(flops/peak, bytes/8TB/s) = {ideal:.2f} ms vs measured {gemm:.2f} ms -> {ideal / gemm:.3f}")
 for (c, fl, by), (n, ms, first) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
     per = ms / n
     if ms / K < 0.15: continue
     print(f"{CATS[c]:9s} first#{first:4d} n/step={n/K:5.1f} {ms/K:7.3f} ms/step  {per*1e3:8.1f} us/launch  {fl/per/1e9 if fl else 0:7.1f} TF/s  {by/per/1e6:7.1f} GB/s  "
-          f"gflop={fl/1e9:8.2f} MB={by/1e6:8.1f}  hbm-floor {by/8e6:7.1f} us  mfma-floor {fl/2.5e9:7.1f} us")
+          f"gflop={fl/1e9:8.2f} MB={by/1e6:8.1f}  hbm-floor {by/8e6:7.1f} us  mfma-floor {fl/PEAK*1e3:7.1f} us")
