@@ -154,6 +154,14 @@ SIGNATURES = {
     "gg_geoguessr_score": (_I, [_P, _P, _I, _P, _P, _P]),      # (pred, truth, N, double* dist_km, int32* score, stream)
     "gg_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P]),
     "gg_fill_f32": (_I, [_P, _L, _F, _P]),
+    "gg_comm_unique_id": (_I, [_P]),
+    "gg_comm_create": (_I, [C.POINTER(_P), _P, _I, _I, _I]),
+    "gg_comm_destroy": (_I, [_P]),
+    "gg_comm_rank": (_I, [_P]),
+    "gg_comm_world": (_I, [_P]),
+    "gg_comm_allreduce_sum_f32": (_I, [_P, _P, _L, _P]),
+    "gg_comm_broadcast": (_I, [_P, _P, _L, _I, _P]),
+    "gg_comm_barrier": (_I, [_P, _P, _I]),
     "gg_prof_enable": (_I, [_I]),
     "gg_prof_reset": (_I, []),
     "gg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

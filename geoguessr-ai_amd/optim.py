@@ -68,16 +68,33 @@ class AdamW:
     def _world() -> int:
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
+    def _native(self):
+        """The gg_comm (RCCL behind the C-ABI) communicator when GG_NATIVE_COMM=1 and the tensors live on the GPU; else None
+        (torch.distributed carries the same collectives)."""
+        from . import comm as _comm
+        if not _comm.enabled() or not any(bb.flat_params.is_cuda for bb in self.backbones) and not any(p.is_cuda for p in self.loose):
+            return None
+        if getattr(self, "_ncomm", None) is None:
+            self._ncomm = _comm.NativeComm()
+        return self._ncomm
+
+    def _bcast(self, t: torch.Tensor, src: int):
+        nc = self._native()
+        if nc is not None and t.is_cuda:
+            nc.broadcast_(t, src)
+        else:
+            dist.broadcast(t, src)
+
     def broadcast_params(self, src: int = 0):
         """DDP construction semantics: every rank starts from rank ``src``'s parameters and buffers."""
         if self._world() == 1:
             return
         for bb in self.backbones:
-            dist.broadcast(bb.flat_params, src)
+            self._bcast(bb.flat_params, src)
             bb.mark_params_dirty()
         for p in self.model.parameters():
             if id(p) not in self._flat_ids:
-                dist.broadcast(p.data, src)
+                self._bcast(p.data, src)
         self.broadcast_buffers(src)
         if hasattr(self.model, "mark_params_dirty"):
             self.model.mark_params_dirty()
@@ -88,13 +105,21 @@ class AdamW:
         if self._world() == 1:
             return
         for bb in self.backbones:
-            dist.broadcast(bb._flat_buf, src)
-            dist.broadcast(bb._counters, src)
+            self._bcast(bb._flat_buf, src)
+            self._bcast(bb._counters, src)
+        nc = self._native()
+        if nc is not None:
+            nc.wait()
 
     def _launch(self, key, tensor):
         if key in self._inflight or tensor is None or tensor.numel() == 0:
             return
-        self._inflight[key] = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
+        nc = self._native()
+        if nc is not None and tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous():
+            nc.allreduce_sum_(tensor)                   # on the communicator's own stream, behind an event on the compute stream
+            self._inflight[key] = None
+        else:
+            self._inflight[key] = dist.all_reduce(tensor, op=dist.ReduceOp.SUM, async_op=True)
 
     def _bucket_ready(self, bb_index: int, lo: int, hi: int):
         """Called (through the backward pass's stage callback) when flat gradient floats [lo, hi) of a backbone are final."""
@@ -149,12 +174,15 @@ class AdamW:
         for p in self.loose:
             if p.grad is not None:
                 self._launch(("loose", id(p)), p.grad)
-        works = list(self._inflight.values())
+        works = [w for w in self._inflight.values() if w is not None]
         self._inflight, self._covered = {}, {}
         if async_op:
             return works
         for w in works:
             w.wait()
+        nc = self._native()
+        if nc is not None:
+            nc.wait()                                   # the compute stream is ordered behind the native collectives
         return []
 
     def step(self, grad_scale: Optional[float] = None):

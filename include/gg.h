@@ -274,6 +274,23 @@ int gg_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 int gg_fill_f32(float* p, int64_t n, float value, void* stream);
 
+/* ---------------------------------------------------------------- data-parallel exchange
+ * One opaque communicator per process / GPU over RCCL (xGMI inside a node): the only collectives of the path.  Replaces Accelerate ->
+ * DistributedDataParallel -> NCCL of training/train_eval_loop.py:184-187,200-202,234 (gradient all-reduce at :234, parameter broadcast
+ * at construction, BatchNorm-buffer broadcast before each training forward).  The unique id (128 bytes, host) is created on one rank
+ * and handed to the others by the launcher's own channel (the Python host uses torch.distributed's store).  Everything is enqueued
+ * on `stream`.  The Python host runs the same three collectives through torch.distributed (backend "nccl" = this same RCCL) by
+ * default and through these entry points with GG_NATIVE_COMM=1 (geoguessr_ai_amd/comm.py). */
+typedef struct gg_comm gg_comm;
+int gg_comm_unique_id(void* out128 /* host, 128 bytes */);
+int gg_comm_create(gg_comm** out, const void* unique_id128 /* host */, int rank, int world, int device);
+int gg_comm_destroy(gg_comm* comm);
+int gg_comm_rank(const gg_comm* comm);
+int gg_comm_world(const gg_comm* comm);
+int gg_comm_allreduce_sum_f32(gg_comm* comm, float* buf /* in place */, int64_t n, void* stream);
+int gg_comm_broadcast(gg_comm* comm, void* buf, int64_t bytes, int root, void* stream);
+int gg_comm_barrier(gg_comm* comm, void* stream, int sync /* != 0: also wait on the host */);
+
 /* ---------------------------------------------------------------- optional kernel timing (HIP events on the launch stream)
  * categories: 0 gemm, 1 attention, 2 dwconv, 3 norm/elementwise, 4 head-loss, 5 optimizer, 6 data movement */
 int gg_prof_enable(int on);

@@ -434,3 +434,24 @@ def test_hierarchical_superguessr_matches_reference_golden(golden_dir, precision
     assert rel(y.detach().cpu().numpy(), yr.detach().numpy()) < 1e-5
     assert rel(x.grad.cpu().numpy(), xd.grad.numpy()) < 1e-5
     del m._hier_masks
+
+
+# ------------------------------------------------------------------------------------------- (b) boundary: native RCCL exchange
+def test_native_comm_single_rank():
+    """gg_comm_* (RCCL behind the C-ABI, csrc/comm.cpp) on the one GPU a test box has: communicator creation from a unique id, the three
+    collectives of the path on its own stream with event ordering against the compute stream (a 1-rank all-reduce / broadcast is the
+    identity; multi-rank correctness is RCCL's, the host-side bucket logic is covered on CPU by tests/test_distributed_cpu.py)."""
+    from geoguessr_ai_amd.comm import NativeComm
+    c = NativeComm()
+    assert (c.rank, c.world) == (0, 1)
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    y = x * 2 + 1                      # produced on the compute stream right before the collective
+    ref = y.clone()
+    c.allreduce_sum_(y)
+    c.broadcast_(y, 0)
+    c.wait()
+    z = y + 1                          # consumer on the compute stream
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref) and torch.equal(z, ref + 1)
+    c.barrier(sync=True)
+    c.close()

@@ -7,13 +7,13 @@ usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.c
 """
 import csv, json, sys, collections
 
-CLASSES = [("gemm_nt", "gemm_nt_kernel"), ("gemm_tn", "gemm_tn_kernel"), ("attn", "attn_"), ("dwconv", "dwconv"), ("im2col", "im2col"),
-           ("col2im", "col2im"), ("bn", "bn_"), ("ln", "layernorm")]
+CLASSES = [("gemm_nt", ("gemm_nt_",)), ("gemm_tn", ("gemm_tn_",)), ("attn", ("attn_", "flash_")), ("dwconv", ("dwconv", "dw3x3")),
+           ("im2col", ("im2col",)), ("col2im", ("col2im",)), ("bn", ("bn_",)), ("ln", ("layernorm",))]
 
 
 def klass(name):
-    for k, pat in CLASSES:
-        if pat in name:
+    for k, pats in CLASSES:
+        if any(p in name for p in pats):
             return k
     return "other"
 
@@ -34,7 +34,8 @@ def main():
     f, nf = load(fpath, "FETCH_SIZE")
     w, nw = load(wpath, "WRITE_SIZE")
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) on bench.py --steps 2 --warmup 1 "
-                     "--panoramas 256; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section), KB units",
+                     "--panoramas 256 --precision <fp32|bf16>; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section), KB units; "
+                     "launches of the warm-up step are included in steps_profiled",
            "steps_profiled": steps, "per_kernel_class": {}}
     for k in sorted(set(f) | set(w), key=lambda k: -(2 * f[k] + w[k])):
         fetch, write, launches = 2.0 * f[k] * 1024, w[k] * 1024, max(nf[k], 1)

@@ -1,11 +1,19 @@
+# Round profile: rocprofv3 kernel-trace summary + the two PMC passes (FETCH_SIZE, WRITE_SIZE: separate runs, no trace domains) of bench.py,
+# once per precision.  Run on the GPU box:  bash tools/profile_round.sh <fp32|bf16> <tag>   -> gpurun_out/<tag>_*
 set -x
+P=${1:-fp32}
+TAG=${2:-r02_$P}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd $R
-rm -rf gpurun_out/prof_v8 gpurun_out/pmc_fetch gpurun_out/pmc_write
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_v8 -o v8 --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/prof_v8.log 2>&1
-tail -1 gpurun_out/prof_v8.log | cut -c1-200
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/pmc_write.log 2>&1
-find gpurun_out/prof_v8 gpurun_out/pmc_fetch gpurun_out/pmc_write -type f | head -20
-du -sh gpurun_out/prof_v8 gpurun_out/pmc_fetch gpurun_out/pmc_write
+rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_trace -o t --output-format csv -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --precision $P > gpurun_out/${TAG}_trace.log 2>&1
+tail -1 gpurun_out/${TAG}_trace.log | cut -c1-300
+rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --precision $P > gpurun_out/${TAG}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${TAG}_write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --precision $P > gpurun_out/${TAG}_write.log 2>&1
+F=$(find gpurun_out/${TAG}_fetch -name "*counter_collection.csv" | head -1); W=$(find gpurun_out/${TAG}_write -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_traffic.py $F $W 3 gpurun_out/${TAG}_hbm_traffic_pmc.json
+S=$(find gpurun_out/${TAG}_trace -name "*kernel_stats.csv" | head -1); cp $S gpurun_out/${TAG}_kernel_stats.csv
+# keep the merge-back small: drop the raw per-dispatch tables
+rm -rf gpurun_out/${TAG}_trace gpurun_out/${TAG}_fetch gpurun_out/${TAG}_write
+ls -la gpurun_out | grep ${TAG}
