@@ -5,6 +5,7 @@
 // (each input element is fetched from HBM once; the left / right neighbours come out of L1).
 #include "common.h"
 #include "../../include/gg.h"
+#include <string.h>
 
 namespace {
 
@@ -12,6 +13,11 @@ __device__ __forceinline__ float act_exact(float x, int act) {
     if (act == GG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
     if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
     return x;
+}
+__device__ __forceinline__ float act_grad_exact(float x, int act) {
+    if (act == GG_ACT_GELU) return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+    if (act == GG_ACT_QUICK_GELU) { const float sg = 1.0f / (1.0f + expf(-1.702f * x)); return sg + 1.702f * x * sg * (1.0f - sg); }
+    return 1.0f;
 }
 
 // ---------------------------------------------------------------- im2col (dense 3x3, pad 1)
@@ -117,11 +123,22 @@ __global__ __launch_bounds__(256) void col2im_nhwc_f32_kernel(const float* __res
 // Thread = (4 channels, one output column); a block covers PX adjacent output columns x all C channels of one image and walks down a
 // strip of output rows.  MODE 0: y = conv(x, taps) (+ per-block partial BatchNorm statistics of y); MODE 1: the same with flipped taps
 // (stride-1 data gradient); MODE 2: weight gradient -- acc[tap] += window[tap] * dy, one partial row [9][C] per block.
+// Fusions (the BatchNorm passes either side of a frozen depthwise ConvNorm ride on its loads / stores; bn_apply / bn_bwd passes and the
+// tensors between them disappear -- the f32 twins of gg_dwconv3x3_fwd_fused / gg_dwconv3x3_bwd_data_fused):
+//   IN 1: x is the producer ConvNorm's saved PRE-BatchNorm output; act(sc*x + sh) is applied to every in-image load (padding stays 0)
+//   IN 2: x = dz, x2 = y of the ConvNorm whose BatchNorm-backward apply step dy = c0*dz + c1*y + c2 is formed on load
+//   EPI : (MODE 1) o *= act'(BN(ep_y)) at the output position and the partial rows hold (sum dz, sum dz*xhat) for gg_bn_bwd_finalize
 enum { DWM_FWD = 0, DWM_FLIP = 1, DWM_WGRAD = 2 };
-template <int S, int MODE>
+struct DwFuse {
+    const float* x2;                         // IN 2: second input tensor
+    const float* in_a; const float* in_b; const float* in_c;   // IN 1: stat [2][C], gamma, beta;  IN 2: coef [3][C] in in_a
+    int in_act;
+    const float* ep_y; const float* ep_stat; const float* ep_gamma; const float* ep_beta; int ep_act;
+};
+template <int S, int MODE, int IN = 0, bool EPI = false>
 __global__ __launch_bounds__(256) void dw3x3_walk_f32_kernel(const float* __restrict__ x, const float* __restrict__ taps,
                                                              float* __restrict__ y, const float* __restrict__ dy, int H, int W, int C,
-                                                             int Ho, int Wo, int PX, int rows_per_strip, float* __restrict__ part) {
+                                                             int Ho, int Wo, int PX, int rows_per_strip, float* __restrict__ part, DwFuse fz) {
     extern __shared__ float sred[];
     const int CG = C >> 2;
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
@@ -141,12 +158,43 @@ __global__ __launch_bounds__(256) void dw3x3_walk_f32_kernel(const float* __rest
     for (int k = 0; k < 9; ++k) acc[k] = zero;
     const int ix0 = ox * S - 1;
     const bool c0 = ix0 >= 0, c2 = ix0 + 2 < W;           // ix0 + 1 < W always holds for a live column
+    // per-channel coefficients of the fused passes (this thread's 4 channels are fixed)
+    f32x4 ia = zero, ib = zero, ic = zero;
+    if (IN == 1) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(fz.in_a + cg * 4), rs = *reinterpret_cast<const f32x4*>(fz.in_a + C + cg * 4);
+        ia = rs * *reinterpret_cast<const f32x4*>(fz.in_b + cg * 4);
+        ib = *reinterpret_cast<const f32x4*>(fz.in_c + cg * 4) - mu * ia;
+    }
+    if (IN == 2) {
+        ia = *reinterpret_cast<const f32x4*>(fz.in_a + cg * 4); ib = *reinterpret_cast<const f32x4*>(fz.in_a + C + cg * 4);
+        ic = *reinterpret_cast<const f32x4*>(fz.in_a + 2 * C + cg * 4);
+    }
+    f32x4 esc = zero, esh = zero, ers = zero, enm = zero;
+    if (EPI) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(fz.ep_stat + cg * 4);
+        ers = *reinterpret_cast<const f32x4*>(fz.ep_stat + C + cg * 4);
+        esc = ers * *reinterpret_cast<const f32x4*>(fz.ep_gamma + cg * 4);
+        esh = *reinterpret_cast<const f32x4*>(fz.ep_beta + cg * 4) - mu * esc;
+        enm = -mu * ers;
+    }
+    const float* x2b = IN == 2 ? fz.x2 + (int64_t)b * H * W * C + cg * 4 : nullptr;
+    auto ld = [&](const float* p, const float* p2) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        if (IN == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_exact(fmaf(v[j], ia[j], ib[j]), fz.in_act);
+        }
+        if (IN == 2) v = ia * v + (ib * *reinterpret_cast<const f32x4*>(p2) + ic);
+        return v;
+    };
     auto row = [&](int iy, f32x4 (&r)[3]) {
         if (live && iy >= 0 && iy < H) {
-            const float* p = xb + ((int64_t)iy * W + ix0) * C;
-            r[0] = c0 ? *reinterpret_cast<const f32x4*>(p) : zero;
-            r[1] = *reinterpret_cast<const f32x4*>(p + C);
-            r[2] = c2 ? *reinterpret_cast<const f32x4*>(p + 2 * C) : zero;
+            const int64_t o = ((int64_t)iy * W + ix0) * C;
+            const float* p = xb + o;
+            const float* p2 = IN == 2 ? x2b + o : nullptr;
+            r[0] = c0 ? ld(p, p2) : zero;
+            r[1] = ld(p + C, IN == 2 ? p2 + C : nullptr);
+            r[2] = c2 ? ld(p + 2 * C, IN == 2 ? p2 + 2 * C : nullptr) : zero;
         } else { r[0] = r[1] = r[2] = zero; }
     };
     f32x4 r0[3], r1[3], r2[3];
@@ -166,8 +214,14 @@ __global__ __launch_bounds__(256) void dw3x3_walk_f32_kernel(const float* __rest
             o += r1[0] * w[3]; o += r1[1] * w[4]; o += r1[2] * w[5];
             o += r2[0] * w[6]; o += r2[1] * w[7]; o += r2[2] * w[8];
             if (live) {
-                *reinterpret_cast<f32x4*>(y + (((int64_t)b * Ho + oy) * Wo + ox) * C + cg * 4) = o;
-                if (part) { acc[0] += o; acc[1] += o * o; }
+                const int64_t oo = (((int64_t)b * Ho + oy) * Wo + ox) * C + cg * 4;
+                if (EPI) {      // dz = da * act'(gamma*xhat + beta); sums of dz and dz*xhat
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(fz.ep_y + oo);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] *= act_grad_exact(fmaf(yv[j], esc[j], esh[j]), fz.ep_act);
+                    acc[0] += o; acc[1] += o * (yv * ers + enm);
+                } else if (part) { acc[0] += o; acc[1] += o * o; }
+                *reinterpret_cast<f32x4*>(y + oo) = o;
             }
         }
         if (S == 1) {
@@ -294,7 +348,7 @@ extern "C" int gg_dwconv_f32_stat_rows(int B, int Ho, int Wo, int C) {
     return g.nbx * B * g.strips;
 }
 static int dw_walk_launch(int mode, const float* x, const float* taps, float* y, const float* dy, int B, int H, int W, int C, int stride,
-                          float* part, void* stream) {
+                          float* part, void* stream, const DwFuse* fuse = nullptr, int in_mode = 0, bool epi = false) {
     GG_CHECK((C & 3) == 0 && C >= 4 && C <= 1024, "gg_dwconv3x3 f32: C must be a multiple of 4, <= 1024 (got %d)", C);
     GG_CHECK(B <= 65535, "gg_dwconv3x3 f32: batch too large for one launch");
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -304,7 +358,20 @@ static int dw_walk_launch(int mode, const float* x, const float* taps, float* y,
     const size_t lds = part ? (size_t)g.PX * NR * C * sizeof(float) : 0;
     GG_CHECK(lds <= 64 * 1024, "gg_dwconv3x3 f32: reduction tile too large");
     hipStream_t st = (hipStream_t)stream;
-#define GG_DW_LAUNCH(S_, M_) hipLaunchKernelGGL((dw3x3_walk_f32_kernel<S_, M_>), grid, block, lds, st, x, taps, y, dy, H, W, C, Ho, Wo, g.PX, g.rows_per_strip, part)
+    DwFuse fz;
+    memset(&fz, 0, sizeof(fz));
+    if (fuse) fz = *fuse;
+#define GG_DW_LAUNCHF(S_, M_, I_, E_) hipLaunchKernelGGL((dw3x3_walk_f32_kernel<S_, M_, I_, E_>), grid, block, lds, st, x, taps, y, dy, H, W, C, Ho, Wo, g.PX, g.rows_per_strip, part, fz)
+#define GG_DW_LAUNCH(S_, M_) GG_DW_LAUNCHF(S_, M_, 0, false)
+    if (in_mode != 0 || epi) {
+        if (mode == DWM_FWD && in_mode == 1 && !epi) { if (stride == 1) GG_DW_LAUNCHF(1, DWM_FWD, 1, false); else GG_DW_LAUNCHF(2, DWM_FWD, 1, false); }
+        else if (mode == DWM_FLIP && stride == 1 && in_mode == 2 && epi) GG_DW_LAUNCHF(1, DWM_FLIP, 2, true);
+        else if (mode == DWM_FLIP && stride == 1 && in_mode == 2 && !epi) GG_DW_LAUNCHF(1, DWM_FLIP, 2, false);
+        else if (mode == DWM_FLIP && stride == 1 && in_mode == 0 && epi) GG_DW_LAUNCHF(1, DWM_FLIP, 0, true);
+        else { gg_set_error("gg_dwconv3x3 f32: fused variant (mode %d, stride %d, in %d, epi %d) is not built", mode, stride, in_mode, (int)epi); return -1; }
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     if (stride == 1) {
         if (mode == DWM_FWD) GG_DW_LAUNCH(1, DWM_FWD);
         else if (mode == DWM_FLIP) GG_DW_LAUNCH(1, DWM_FLIP);
@@ -315,6 +382,7 @@ static int dw_walk_launch(int mode, const float* x, const float* taps, float* y,
         else { gg_set_error("gg_dwconv3x3 f32: flipped stride-2 walk does not exist"); return -1; }
     }
 #undef GG_DW_LAUNCH
+#undef GG_DW_LAUNCHF
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -353,4 +421,32 @@ extern "C" int gg_dwconv3x3_bwd_weight_f32(const float* x, const float* dy, int 
     hipLaunchKernelGGL(dw_wgrad_final_f32_kernel, dim3((unsigned)gg_cdiv(9 * C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, grad, accumulate);
     GG_LAUNCH_CHECK();
     return 0;
+}
+
+// depthwise ConvNorm whose input is act(BatchNorm(x_prebn)) of the ConvNorm in front, formed while loading (timm MBConv.conv2 /
+// PatchMerging.conv2): replaces gg_bn_apply_f32 + gg_dwconv3x3_fwd_f32, the activation tensor is never stored.  in_stat = [mean | rstd][C]
+extern "C" int gg_dwconv3x3_fwd_fused_f32(const float* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act,
+                                          const float* taps, float* y, int B, int H, int W, int C, int stride, float* colstats, void* stream) {
+    GG_CHECK(x_prebn && in_stat && in_gamma && in_beta && taps && y && B > 0 && (stride == 1 || stride == 2), "gg_dwconv3x3_fwd_fused_f32: bad args");
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 4.0 * B * C * ((double)H * W + (double)Ho * Wo), stream);
+    DwFuse f;
+    memset(&f, 0, sizeof(f));
+    f.in_a = in_stat; f.in_b = in_gamma; f.in_c = in_beta; f.in_act = in_act;
+    return dw_walk_launch(DWM_FWD, x_prebn, taps, y, nullptr, B, H, W, C, stride, colstats, stream, &f, 1, false);
+}
+// stride-1 data gradient with the BatchNorm-backward passes of the ConvNorms on both sides riding on it:
+//   input : in_coef != NULL -> dy = coef0*dz_in + coef1*y_in + coef2 formed on load (apply step of the ConvNorm this conv belongs to)
+//   output: ep_y != NULL    -> out = dz = da * ep_act'(BN(ep_y)), ep_partials <- gg_dwconv_f32_stat_rows(B,H,W,C) rows of (sum dz, sum dz*xhat)
+extern "C" int gg_dwconv3x3_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H,
+                                               int W, int C, const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta,
+                                               int ep_act, float* ep_partials, void* stream) {
+    GG_CHECK(dz_in && taps && out && B > 0, "gg_dwconv3x3_bwd_data_fused_f32: bad args");
+    GG_CHECK(!in_coef || y_in, "gg_dwconv3x3_bwd_data_fused_f32: in_coef needs y_in");
+    GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_partials), "gg_dwconv3x3_bwd_data_fused_f32: the epilogue needs stat, gamma, beta and partials");
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * H * W * C, 4.0 * B * C * (double)H * W * (2.0 + (in_coef != nullptr) + (ep_y != nullptr)), stream);
+    DwFuse f;
+    memset(&f, 0, sizeof(f));
+    f.x2 = y_in; f.in_a = in_coef; f.ep_y = ep_y; f.ep_stat = ep_stat; f.ep_gamma = ep_gamma; f.ep_beta = ep_beta; f.ep_act = ep_act;
+    return dw_walk_launch(DWM_FLIP, dz_in, taps, out, nullptr, B, H, W, C, 1, ep_y ? ep_partials : nullptr, stream, &f, in_coef ? 2 : 0, ep_y != nullptr);
 }

@@ -32,6 +32,11 @@ struct F32GemmParams {
     float* colstats;              // [tilesM][2][N]
     int tilesM, tilesN;
     int debug;                    // timing experiments only (GG_GEMM_F32_DEBUG): 1 no operand loads, 2 no result stores, 4 no LDS staging / barriers
+    // BatchNorm-backward epilogue (FE_BNBWD): C = dz = acc * act'(BN(bn_y)), colstats <- column sums of (dz, dz*xhat)
+    const float* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;
+    // A-operand prologues of the register-staged kernel: PRO 1: A := a_act(BN(A)) (a_stat = [mean | rstd][K], gamma, beta);
+    // PRO 2: A := coef0*A + coef1*A2 + coef2 (a_stat = coef [3][K]: BatchNorm backward's apply step formed while staging)
+    const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
 };
 
 __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float offset of 16-byte chunk kc (0..7) of a tile row
@@ -44,7 +49,17 @@ __device__ __forceinline__ float gelu_grad_exact(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
-enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4 };
+enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4, FE_BNBWD = 5 };
+__device__ __forceinline__ float act_grad_exact_f(float x, int act) {
+    if (act == GG_ACT_GELU) return gelu_grad_exact(x);
+    if (act == GG_ACT_QUICK_GELU) { const float sg = 1.0f / (1.0f + expf(-1.702f * x)); return sg + 1.702f * x * sg * (1.0f - sg); }
+    return 1.0f;
+}
+__device__ __forceinline__ float act_exact_f(float x, int act) {
+    if (act == GG_ACT_GELU) return gelu_exact(x);
+    if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
+    return x;
+}
 
 // Epilogue shared by both NT kernels: lane holds C[m = m0 + wm*WROWS + mt*16 + lr][n = n0 + wn*WCOLS + nt*16 + lg*4 + r]; results leave straight
 // from the accumulator fragments (16-byte stores, 64-byte runs per row).  `smem`: at least 2*WM*BN floats, no longer read by anyone.
@@ -64,6 +79,15 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 for (int r = 0; r < 4; ++r) b4[r] = p.bias[min(n + r, p.N - 1)];
             }
             f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bsc = cs, bsh = cs, brs = cs, bnm = cs;
+            if (EPI == FE_BNBWD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = min(n + r, p.N - 1);
+                    const float mu = p.bn_stat[c], rstd = p.bn_stat[p.N + c];
+                    bsc[r] = p.bn_gamma[c] * rstd; bsh[r] = p.bn_beta[c] - mu * bsc[r]; brs[r] = rstd; bnm[r] = -mu * rstd;
+                }
+            }
 #pragma unroll
             for (int mt = 0; mt < TM; ++mt) {
                 const int m = m0 + wm * WROWS + mt * 16 + lr;
@@ -72,6 +96,16 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 const bool full = ok && vec_c && n + 3 < p.N;
                 if (EPI == FE_PLAIN) {
                     if (p.colstats) { cs += v; cq += v * v; }   // rows beyond M / columns beyond N hold exact zeros (range-checked operand loads)
+                } else if (EPI == FE_BNBWD) {
+                    if (ok) {       // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat
+                        const float* g = p.bn_y + (int64_t)m * p.ldc + n;
+                        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
+                        if (full) yv = *reinterpret_cast<const f32x4*>(g);
+                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) yv[r] = g[r]; }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] *= act_grad_exact_f(fmaf(yv[r], bsc[r], bsh[r]), p.bn_act);
+                        cs += v; cq += v * (yv * brs + bnm);
+                    }
                 } else if (ok) {
                     const float rs = ((EPI == FE_LINEAR || EPI == FE_DGELU) && p.rowscale) ? p.rowscale[m / p.rows_per_scale] : 1.f;
                     v += b4;
@@ -111,7 +145,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
                 }
             }
-            if (EPI == FE_PLAIN && p.colstats) {
+            if ((EPI == FE_PLAIN || EPI == FE_BNBWD) && p.colstats) {
                 // column sums over this wave's 64 / 32 rows: the 16 row-lanes first, then the WM waves that share columns through LDS
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -126,7 +160,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 }
             }
         }
-        if (EPI == FE_PLAIN && p.colstats) {
+        if ((EPI == FE_PLAIN || EPI == FE_BNBWD) && p.colstats) {
             __syncthreads();
             for (int i = threadIdx.x; i < 2 * BN; i += 256) {
                 const int which = i / BN, col = i % BN;
@@ -143,19 +177,31 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
 // registers that prefetch the next k-tile are idle during a tile's last k-iteration, so they fetch the NEXT tile's first k-tile
 // there: a tile's prologue (first-load latency, ~10 % of a K = 384 tile, ~25 % of a K = 96 tile when measured by ablation) and its
 // epilogue stores overlap with matrix work instead of adding to it.  Result-independent of the grid size.
-template <int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32GemmParams p) {
+template <int BN, int WM, int WN, int EPI, int PRO = 0>
+__global__ __launch_bounds__(256, PRO != 0 ? 2 : (BN == 128 ? 3 : 4)) void gemm_nt_f32_kernel(F32GemmParams p) {
     constexpr int BM = 128;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;           // 16-byte chunks per thread per k-tile
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * FBK];
+    __shared__ __attribute__((aligned(16))) float ptab[PRO ? 3 * 1024 : 4];      // PRO: per-k coefficients [3][K], K <= 1024
     float* As = smem;
     float* Bs = smem + BM * FBK;
     const int tiles = p.tilesM * p.tilesN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
+    if (PRO == 1) {
+        for (int k = threadIdx.x; k < p.K; k += 256) {
+            const float sc = p.a_gamma[k] * p.a_stat[p.K + k];
+            ptab[k] = sc; ptab[1024 + k] = p.a_beta[k] - p.a_stat[k] * sc;
+        }
+        __syncthreads();
+    }
+    if (PRO == 2) {
+        for (int k = threadIdx.x; k < p.K; k += 256) { ptab[k] = p.a_stat[k]; ptab[1024 + k] = p.a_stat[p.K + k]; ptab[2048 + k] = p.a_stat[2 * p.K + k]; }
+        __syncthreads();
+    }
 
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int srow = threadIdx.x >> 3, skc = threadIdx.x & 7;
@@ -177,7 +223,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32
     const int nk = (p.K + FBK - 1) / FBK;
     const bool vec_c = (p.ldc & 3) == 0;
 
-    u32x4 ra[LA], rb[LB];
+    u32x4 ra[LA], rb[LB], ra2[PRO == 2 ? LA : 1];
     // operand loads of k-tile kt of the tile at (tm, tn): raw buffer loads, descriptor = the valid rows of that tile (rows beyond M / N
     // read as zeros through the hardware range check), k offset in the scalar soffset, chunks beyond K pushed out of range
     auto load_tile = [&](int tm_, int tn_, int kt) {
@@ -192,6 +238,11 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32
         const int so = k0 * 4;
 #pragma unroll
         for (int i = 0; i < LA; ++i) ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voa[i] : 0xFFFFFFF0u), so, 0);
+        if (PRO == 2) {
+            const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 + (int64_t)m0_ * p.lda), 0, (int)bytesA, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < LA; ++i) ra2[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, (int)(kin ? voa[i] : 0xFFFFFFF0u), so, 0);
+        }
 #pragma unroll
         for (int i = 0; i < LB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(kin ? vob[i] : 0xFFFFFFF0u), so, 0);
     };
@@ -217,6 +268,28 @@ __global__ __launch_bounds__(256, BN == 128 ? 3 : 4) void gemm_nt_f32_kernel(F32
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) {
+            if (PRO) {
+                // this thread's chunk covers contraction columns k0 + 4 skc .. + 3 of every staged A row; rows beyond M and chunks beyond K stay
+                // zero (they feed the column statistics / must not add the affine's constant term)
+                const int kq = kt * FBK + skc * 4;
+                const bool kin = kq < p.K;
+                const int kc = min(kq, p.K - 4);
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(ptab + kc), t1 = *reinterpret_cast<const f32x4*>(ptab + 1024 + kc);
+                const f32x4 t2 = PRO == 2 ? *reinterpret_cast<const f32x4*>(ptab + 2048 + kc) : t0;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) {
+                    const bool rok = kin && (m0 + srow + 32 * i < p.M);
+                    f32x4 v = __builtin_bit_cast(f32x4, ra[i]);
+                    if (PRO == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = act_exact_f(fmaf(v[j], t0[j], t1[j]), p.a_act);
+                    } else {
+                        v = t0 * v + (t1 * __builtin_bit_cast(f32x4, ra2[i]) + t2);
+                    }
+                    if (!rok) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    ra[i] = __builtin_bit_cast(u32x4, v);
+                }
+            }
             if (!(p.debug & 4)) {
 #pragma unroll
                 for (int i = 0; i < LA; ++i) *reinterpret_cast<u32x4*>(As + lds_a[i]) = ra[i];
@@ -497,13 +570,24 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     GG_CHECK(a->lda >= a->K && a->ldb >= a->K && a->ldc >= a->N, "gg_gemm_nt_f32: leading dimension too small");
     GG_CHECK(a->lda * 512 < 0xFFFFFF00LL && a->ldb * 512 < 0xFFFFFF00LL && (int64_t)a->K * 4 < 0x7FFFFFFFLL,
              "gg_gemm_nt_f32: leading dimension too large for 32-bit tile offsets (ld < 8.3M elements)");
-    GG_CHECK(a->split_k <= 1 && !a->A2 && !a->bn_y && !a->a_bn_stat, "gg_gemm_nt_f32: split-K / two-source / BatchNorm-fused forms are bf16-only");
+    GG_CHECK(a->split_k <= 1, "gg_gemm_nt_f32: no split-K form");
+    if (a->bn_y) {
+        GG_CHECK(a->bn_stat && a->bn_gamma && a->bn_beta && a->colstats && ((uintptr_t)a->bn_y & 15) == 0,
+                 "gg_gemm_nt_f32: the BatchNorm-backward epilogue needs stat, gamma, beta, colstats");
+        GG_CHECK(!(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact), "gg_gemm_nt_f32: the BatchNorm-backward epilogue excludes every other epilogue option");
+    }
+    if (a->a_bn_stat) {        // A prologues (register-staged kernel): BN+act of one source, or the affine of two sources (A2 != NULL)
+        GG_CHECK(a->K <= 1024 && (a->A2 || (a->a_bn_gamma && a->a_bn_beta)), "gg_gemm_nt_f32: the A prologue needs K <= 1024 and gamma/beta (or A2 + coef)");
+        GG_CHECK(!a->A2 || ((uintptr_t)a->A2 & 15) == 0, "gg_gemm_nt_f32: A2 must be 16-byte aligned");
+        if (a->A2) GG_CHECK(!(a->act || a->dact_preact || a->preact || a->colstats || a->bn_y), "gg_gemm_nt_f32: the two-source prologue is built with the linear epilogue");
+        else GG_CHECK(!(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->bn_y), "gg_gemm_nt_f32: the BatchNorm prologue is built with the plain (+ column statistics) epilogue");
+    } else GG_CHECK(!a->A2, "gg_gemm_nt_f32: A2 without coefficients");
     if (a->rowscale) GG_CHECK(a->rows_per_scale > 0, "gg_gemm_nt_f32: rows_per_scale must be > 0");
     GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU, "gg_gemm_nt_f32: only the GELU derivative epilogue is built");
     GG_CHECK(!(a->dact_preact && (a->bias || a->act || a->residual || a->preact)), "gg_gemm_nt_f32: dact excludes bias/act/residual/preact");
     GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt_f32: an activation epilogue excludes rowscale/residual");
     GG_CHECK(!a->preact || a->act == GG_ACT_GELU, "gg_gemm_nt_f32: preact is only available with the GELU epilogue");
-    GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact), "gg_gemm_nt_f32: colstats needs the plain epilogue");
+    GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact), "gg_gemm_nt_f32: colstats needs the plain or BatchNorm-backward epilogue");
     GG_CHECK(!a->preact || ((uintptr_t)a->preact & 15) == 0, "gg_gemm_nt_f32: preact must be 16-byte aligned");
     GG_CHECK(!a->residual || ((uintptr_t)a->residual & 15) == 0, "gg_gemm_nt_f32: residual must be 16-byte aligned");
     GG_CHECK(!a->dact_preact || ((uintptr_t)a->dact_preact & 15) == 0, "gg_gemm_nt_f32: dact_preact must be 16-byte aligned");
@@ -512,6 +596,8 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.M = a->M; p.N = a->N; p.K = a->K; p.bias = a->bias; p.preact = (float*)a->preact;
     p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = (const float*)a->residual; p.ldr = a->ldr;
     p.dact_preact = (const float*)a->dact_preact; p.colstats = a->colstats;
+    p.bn_y = (const float*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
+    p.A2 = (const float*)a->A2; p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     const int rem = a->N % 128;
     const bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
     const int bn = narrow ? 64 : 128;
@@ -520,10 +606,12 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.debug = dbg ? atoi(dbg) : 0;
     const double mn = (double)a->M * a->N;
     GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
-            4.0 * ((double)a->M * a->K + (double)a->N * a->K + mn) + 4.0 * mn * ((a->preact != nullptr) + (a->residual != nullptr) + (a->dact_preact != nullptr)),
+            4.0 * ((double)a->M * a->K * (a->A2 ? 2 : 1) + (double)a->N * a->K + mn) +
+                4.0 * mn * ((a->preact != nullptr) + (a->residual != nullptr) + (a->dact_preact != nullptr) + (a->bn_y != nullptr)),
             stream);
     int epi;
-    if (a->dact_preact) epi = FE_DGELU;
+    if (a->bn_y) epi = FE_BNBWD;
+    else if (a->dact_preact) epi = FE_DGELU;
     else if (a->act == GG_ACT_GELU) epi = FE_GELU;
     else if (a->act == GG_ACT_QUICK_GELU) epi = FE_QGELU;
     else if (a->bias || a->rowscale || a->residual) epi = FE_LINEAR;
@@ -532,7 +620,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     // workgroups (at most the resident count, each walks tiles t, t + grid, ...) -- kept for A/B timing and the DEBUG ablations
     static const char* ring_env = getenv("GG_GEMM_F32_RING");
     static const char* np_env = getenv("GG_GEMM_F32_NO_PERSIST");
-    const bool ring = !(ring_env && ring_env[0] == '0') && p.debug == 0;
+    const bool ring = !(ring_env && ring_env[0] == '0') && p.debug == 0 && !a->a_bn_stat;
     const int resident = 256 * (narrow ? 4 : 3);
     dim3 grid((ring || np_env || p.tilesM * p.tilesN <= resident) ? p.tilesM * p.tilesN : resident);
     hipStream_t st = (hipStream_t)stream;
@@ -543,7 +631,19 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);           \
         else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);                      \
     } while (0)
+    if (a->a_bn_stat) {       // prologue kernels: (PRO 1, plain epilogue) / (PRO 2, linear epilogue)
+        if (a->A2) {
+            if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, FE_LINEAR, 2>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_LINEAR, 2>), grid, dim3(256), 0, st, p);
+        } else {
+            if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, FE_PLAIN, 1>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_PLAIN, 1>), grid, dim3(256), 0, st, p);
+        }
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     switch (epi) {
+        case FE_BNBWD: GG_LAUNCH_F32(FE_BNBWD); break;
         case FE_PLAIN: GG_LAUNCH_F32(FE_PLAIN); break;
         case FE_LINEAR: GG_LAUNCH_F32(FE_LINEAR); break;
         case FE_GELU: GG_LAUNCH_F32(FE_GELU); break;

@@ -738,6 +738,14 @@ extern "C" int gg_bn_bwd(const void* dout, const void* y, const float* stat, con
     return bn_bwd_t<bf16>(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, dy, scratch, dgamma, dbeta, accumulate, stream);
 }
 /* f32 storage (reference-precision mode): same three passes, exact erf in the activation derivative */
+extern "C" int gg_bn_bwd_reduce_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
+                                    int act, const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* part, void* stream) {
+    return bn_bwd_reduce_t<float>(dout, y, stat, gamma, beta, M, C, act, residual, rowscale, rows_per_scale, dz, part, stream);
+}
+extern "C" int gg_bn_bwd_apply_f32(const float* dz, const float* y, const float* coef, int64_t M, int C, const float* rowscale, int rows_per_scale,
+                                   float* dy, void* stream) {
+    return bn_bwd_apply_t<float>(dz, y, coef, M, C, rowscale, rows_per_scale, dy, stream);
+}
 extern "C" int gg_bn_bwd_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C,
                              int act, const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* dy, float* scratch,
                              float* dgamma, float* dbeta, int accumulate, void* stream) {

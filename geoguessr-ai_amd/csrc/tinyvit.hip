@@ -373,7 +373,10 @@ struct Exec {
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
     void exec_init() {
         f32 = m->f32;
-        if (f32) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = false;
+        // reference-precision mode: the same fusions where an f32 twin exists (MBConv / PatchMerging forward, the stride-1 data gradients, the
+        // GEMM-side BatchNorm epilogue / prologues); GG_F32_NO_FUSE=1 runs every BatchNorm pass on its own (the schedule the fusions are tested against)
+        if (f32 && getenv("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = false;
+        if (f32) fuse_dw = false;
     }
     act_t* A(int64_t off) const { return reinterpret_cast<act_t*>(ws + off); }
     float* F(int64_t off) const { return reinterpret_cast<float*>(ws + off); }
@@ -392,12 +395,21 @@ static int gemm_bnbwd(const Exec& e, const act_t* dY, int64_t ldy, const act_t* 
     g.A = dY; g.lda = ldy; g.B = Wt; g.ldb = ldw; g.C = dz; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;
     g.bn_y = e.A(a.y); g.bn_stat = e.F(a.stat); g.bn_gamma = e.P(bn.t_g); g.bn_beta = e.P(bn.t_b); g.bn_act = act;
     g.colstats = e.F(e.L->statpart);
-    return gg_gemm_nt(&g, e.st);
+    return e.f32 ? gg_gemm_nt_f32(&g, e.st) : gg_gemm_nt(&g, e.st);
 }
 // 1x1-conv dgrad straight from (dz, y): BatchNorm backward's apply step is folded into the weights (gg_bn_bwd_fold_weights)
 static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const act_t* dz, const act_t* y, const float* coef, const float* stat,
                              act_t* dx, int64_t M, const act_t* residual) {
     const int Cout = w.N, Cin = w.K;
+    if (e.f32) {
+        // f32: a doubled contraction would cost real MFMA time (1/16 of the bf16 rate); instead the apply step dy = c0*dz + c1*y + c2 is formed
+        // from the two sources while the register-staged GEMM stages its A tile (GgGemmArgs.A2 + a_bn_stat = coef)
+        GgGemmArgs g;
+        memset(&g, 0, sizeof(g));
+        g.A = dz; g.lda = Cout; g.A2 = y; g.a_bn_stat = coef; g.B = e.Wt(w); g.ldb = w.Np; g.C = dx; g.ldc = Cin;
+        g.M = (int)M; g.N = Cin; g.K = Cout; g.residual = residual; g.ldr = Cin;
+        return gg_gemm_nt_f32(&g, e.st);
+    }
     GG_TRY(gg_bn_bwd_fold_weights(e.P(w.t_w), coef, stat, Cout, Cin, e.A(e.L->foldw), e.F(e.L->foldb), e.st));
     GgGemmArgs g;
     memset(&g, 0, sizeof(g));
@@ -440,7 +452,7 @@ static int conv_dense_fwd_pro(const Exec& e, const ConvBNDense& c, const Act& a,
     g.M = (int)M; g.N = c.w.N; g.K = c.w.Kp;
     g.colstats = e.training ? e.F(e.L->statpart) : nullptr;
     g.a_bn_stat = e.F(prev.stat); g.a_bn_gamma = e.P(prev_bn.t_g); g.a_bn_beta = e.P(prev_bn.t_b); g.a_bn_act = in_act;
-    GG_TRY(gg_gemm_nt(&g, e.st));
+    GG_TRY(e.f32 ? gg_gemm_nt_f32(&g, e.st) : gg_gemm_nt(&g, e.st));
     return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
 }
 static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const act_t* x, int B, int H, int W, int stride) {
@@ -458,6 +470,11 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
                              int W, int stride) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
+    if (e.f32) {
+        GG_TRY(gg_dwconv3x3_fwd_fused_f32((const float*)e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w),
+                                          (float*)e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
+        return bn_stats(e, c.bn, a, gg_dwconv_f32_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+    }
     GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
                                   c.w.C, stride, part, e.st));
     return bn_stats(e, c.bn, a, gg_dwconv_fwd_fused_stat_rows(B, H, W, c.w.C, stride), (int64_t)B * Ho * Wo);
@@ -591,7 +608,9 @@ static int forward_impl(Exec& e, const float* x, float* out) {
 static float* bn_coef(const Exec& e, int64_t M, int C) { return e.F(e.L->bnscratch) + ((int64_t)gg_bn_bwd_rows(M, C) + 64) * 2 * C; }
 static int bn_bwd_reduce_fin(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act, const act_t* dout, act_t* dz) {
     const bool tr = e.tr(bn.t_g);
-    GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz,
+    if (e.f32) GG_TRY(gg_bn_bwd_reduce_f32((const float*)dout, (const float*)e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr,
+                                           nullptr, 0, (float*)dz, e.F(e.L->bnscratch), e.st));
+    else GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz,
                             e.F(e.L->bnscratch), e.st));
     return gg_bn_bwd_finalize(e.F(e.L->bnscratch), gg_bn_bwd_rows(M, bn.C), bn.C, M, e.F(a.stat), e.P(bn.t_g), bn_coef(e, M, bn.C),
                               tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
@@ -672,6 +691,20 @@ static int bn_bwd(const Exec& e, const BNP& bn, const Act& a, int64_t M, int act
                      e.F(e.L->bnscratch), tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st);
 }
 
+static int bn_bwd_apply_only(const Exec& e, const act_t* dz, const act_t* y, const float* coef, int64_t M, int C, act_t* dy) {
+    if (e.f32) return gg_bn_bwd_apply_f32((const float*)dz, (const float*)y, coef, M, C, nullptr, 0, (float*)dy, e.st);
+    return gg_bn_bwd_apply(dz, y, coef, M, C, nullptr, 0, dy, e.st);
+}
+// stride-1 depthwise data gradient with the BatchNorm-backward fusions on its input (apply) and output (reduce) sides
+static int dw_bwd_data_fused(const Exec& e, const act_t* dz_in, const act_t* y_in, const float* in_coef, const DwW& w, act_t* out, int B, int H, int W,
+                             const act_t* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act, float* ep_part) {
+    if (e.f32) return gg_dwconv3x3_bwd_data_fused_f32((const float*)dz_in, (const float*)y_in, in_coef, e.Taps(w), (float*)out, B, H, W, w.C,
+                                                      (const float*)ep_y, ep_stat, ep_gamma, ep_beta, ep_act, ep_part, e.st);
+    return gg_dwconv3x3_bwd_data_fused(dz_in, y_in, in_coef, e.Taps(w), out, B, H, W, w.C, ep_y, ep_stat, ep_gamma, ep_beta, ep_act, ep_part, e.st);
+}
+static int dw_fused_rows(const Exec& e, int B, int H, int W, int C, int with_input_fusion) {
+    return e.f32 ? gg_dwconv_f32_stat_rows(B, H, W, C) : gg_dwconv_fused_stat_rows(B, H, W, C, with_input_fusion);
+}
 static int dw_bwd_data(const Exec& e, const DwW& w, const act_t* dy, act_t* dx, int B, int H, int W, int stride) {
     if (e.f32) return gg_dwconv3x3_bwd_data_f32((const float*)dy, e.Taps(w), (float*)dx, B, H, W, w.C, stride, e.st);
     return gg_dwconv3x3_bwd_data(dy, e.Taps(w), dx, B, H, W, w.C, stride, e.st);
@@ -752,8 +785,8 @@ static int backward_impl(Exec& e, const float* d_out) {
             } else {
                 // frozen taps: BN-backward apply is folded into the conv's staging (no dz / dy tensors at all)
                 GG_TRY(bn_bwd_reduce_fin(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, nullptr));
-                GG_TRY(gg_dwconv3x3_bwd_data_fused(t_b, e.A(a.local.y), bn_coef(e, M, C), e.Taps(l.local.w), t_c, B, st.res, st.res, C,
-                                                   nullptr, nullptr, nullptr, nullptr, 0, nullptr, e.st));
+                GG_TRY(dw_bwd_data_fused(e, t_b, e.A(a.local.y), bn_coef(e, M, C), l.local.w, t_c, B, st.res, st.res,
+                                                   nullptr, nullptr, nullptr, nullptr, 0, nullptr));
             }
             act_t* dx1 = t_c;
             // attention branch: x1 = x0 + s1*(proj(o)+b)
@@ -799,7 +832,7 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (e.fuse_bngemm && !e.tr(st.merge.c1.w.t_w) && !e.tr(st.merge.c2.w.t_w) && C % 64 == 0) {
             GG_TRY(gemm_bnbwd(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_d, M, C, C, st.merge.c2.bn, ma.c2, GG_ACT_GELU));   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, st.merge.c2.bn, ma.c2, M));
-            if (e.fuse_bnbwd && e.fuse_bnbwd_epi) {
+            if (e.fuse_bnbwd && e.fuse_bnbwd_epi && !e.f32) {
                 // the stride-2 data gradient forms dy2 from (dz2, y2) at its taps and emits dz1 = da1*GELU'(BN1(y1)) + BN1's sums
                 GG_TRY(gg_dwconv3x3_s2_bwd_data_fused(t_d, e.A(ma.c2.y), bn_coef(e, M, C), e.Taps(st.merge.c2.w), t_b, B, rin, rin, C,
                                                       e.A(ma.c1.y), e.F(ma.c1.stat), e.P(st.merge.c1.bn.t_g), e.P(st.merge.c1.bn.t_b),
@@ -811,7 +844,7 @@ static int backward_impl(Exec& e, const float* d_out) {
                 GG_TRY(gemm_folded_dgrad(e, st.merge.c1.w, t_b, e.A(ma.c1.y), bn_coef(e, Min, C), e.F(ma.c1.stat), dx, Min, nullptr));
                 continue;
             }
-            GG_TRY(gg_bn_bwd_apply(t_d, e.A(ma.c2.y), bn_coef(e, M, C), M, C, nullptr, 0, t_a, e.st));       // dy2 -> t_a
+            GG_TRY(bn_bwd_apply_only(e, t_d, e.A(ma.c2.y), bn_coef(e, M, C), M, C, t_a));       // dy2 -> t_a
             GG_TRY(dw_bwd_data(e, st.merge.c2.w, t_a, t_b, B, rin, rin, 2));         // da1 -> t_b [Min, C]
             GG_TRY(bn_bwd_reduce_fin(e, st.merge.c1.bn, ma.c1, Min, GG_ACT_GELU, t_b, t_d));                 // dz1 -> t_d
             GG_TRY(gemm_folded_dgrad(e, st.merge.c1.w, t_d, e.A(ma.c1.y), bn_coef(e, Min, C), e.F(ma.c1.stat), dx, Min, nullptr));
@@ -847,18 +880,18 @@ static int backward_impl(Exec& e, const float* d_out) {
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
             act_t* dz1;
             if (e.fuse_bnbwd && e.fuse_bnbwd_epi) {
-                GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
-                                                   e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
+                GG_TRY(dw_bwd_data_fused(e, t_d, e.A(a.c2.y), bn_coef(e, M0, mid), l.c2.w, t_c, B, H0, H0, e.A(a.c1.y),
+                                                   e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart)));   // dz1 -> t_c
                 const bool tr1 = e.tr(l.c1.bn.t_g);
-                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_fused_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), dw_fused_rows(e, B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                           bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
                 dz1 = t_c;
             } else {
                 if (e.fuse_bnbwd) {      // dy2 is formed from (dz2, y2) inside the conv; da1 -> t_c
-                    GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, nullptr,
-                                                       nullptr, nullptr, nullptr, 0, nullptr, e.st));
+                    GG_TRY(dw_bwd_data_fused(e, t_d, e.A(a.c2.y), bn_coef(e, M0, mid), l.c2.w, t_c, B, H0, H0, nullptr,
+                                                       nullptr, nullptr, nullptr, 0, nullptr));
                 } else {
-                    GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));   // dy2 -> t_a
+                    GG_TRY(bn_bwd_apply_only(e, t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, t_a));   // dy2 -> t_a
                     GG_TRY(dw_bwd_data(e, l.c2.w, t_a, t_c, B, H0, H0, 1));             // da1 -> t_c
                 }
                 GG_TRY(bn_bwd_reduce_fin(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, t_c, t_d));                        // dz1 -> t_d
@@ -872,17 +905,17 @@ static int backward_impl(Exec& e, const float* d_out) {
             // ride on the kernels that produce their inputs (conv3's dgrad epilogue, the depthwise data gradient's epilogue)
             GG_TRY(gemm_bnbwd(e, t_a, d[0], e.Wt(l.c3.w), l.c3.w.Np, t_d, M0, mid, d[0], l.c2.bn, a.c2, GG_ACT_GELU));   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, l.c2.bn, a.c2, M0));
-            GG_TRY(gg_bn_bwd_apply(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                // dy2 -> t_a
+            GG_TRY(bn_bwd_apply_only(e, t_d, e.A(a.c2.y), bn_coef(e, M0, mid), M0, mid, t_a));                // dy2 -> t_a
             if (e.tr(l.c2.w.t_w)) {
                 if (e.fuse_dw || e.fuse_dw_s1) GG_TRY(bn_apply(e, l.c1.bn, a.c1, M0, GG_ACT_GELU, e.A(a.a1)));
                 GG_TRY(dw_bwd_weight(e, l.c2.w, e.A(a.a1), t_a, B, H0, H0, 1));
             }
-            GG_TRY(gg_dwconv3x3_bwd_data_fused(t_a, nullptr, nullptr, e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y), e.F(a.c1.stat),
-                                               e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
+            GG_TRY(dw_bwd_data_fused(e, t_a, nullptr, nullptr, l.c2.w, t_c, B, H0, H0, e.A(a.c1.y), e.F(a.c1.stat),
+                                               e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart)));   // dz1 -> t_c
             const bool tr1 = e.tr(l.c1.bn.t_g);
-            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_fused_stat_rows(B, H0, H0, mid, 0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), dw_fused_rows(e, B, H0, H0, mid, 0), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                       bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
-            GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                // dy1 -> t_a
+            GG_TRY(bn_bwd_apply_only(e, t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, t_a));                // dy1 -> t_a
             if (e.tr(l.c1.w.t_w)) GG_TRY(dense_wgrad(e, l.c1.w, e.A(a.x), d[0], t_a, mid, M0, nullptr, 0, t_c, t_d, false));
             GG_TRY(gemm(e, t_a, mid, e.Wt(l.c1.w), l.c1.w.Np, dx, d[0], M0, d[0], mid, nullptr, 0, nullptr, nullptr, 0, t_b));
             continue;
@@ -900,12 +933,12 @@ static int backward_impl(Exec& e, const float* d_out) {
             // frozen taps: 3 streaming passes instead of 5.  reduce(c2) -> dz2; the depthwise data gradient forms dy2 from
             // (dz2, y2) while staging and emits dz1 = da1*GELU'(BN1(y1)) + BN1's backward statistics; apply(c1) -> dy1.
             GG_TRY(bn_bwd_reduce_fin(e, l.c2.bn, a.c2, M0, GG_ACT_GELU, t_c, t_d));                        // dz2 -> t_d
-            GG_TRY(gg_dwconv3x3_bwd_data_fused(t_d, e.A(a.c2.y), bn_coef(e, M0, mid), e.Taps(l.c2.w), t_c, B, H0, H0, mid, e.A(a.c1.y),
-                                               e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));   // dz1 -> t_c
+            GG_TRY(dw_bwd_data_fused(e, t_d, e.A(a.c2.y), bn_coef(e, M0, mid), l.c2.w, t_c, B, H0, H0, e.A(a.c1.y),
+                                               e.F(a.c1.stat), e.P(l.c1.bn.t_g), e.P(l.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart)));   // dz1 -> t_c
             const bool tr1 = e.tr(l.c1.bn.t_g);
-            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_fused_stat_rows(B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
+            GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), dw_fused_rows(e, B, H0, H0, mid, 1), mid, M0, e.F(a.c1.stat), e.P(l.c1.bn.t_g),
                                       bn_coef(e, M0, mid), tr1 ? e.Gd(l.c1.bn.t_g) : nullptr, tr1 ? e.Gd(l.c1.bn.t_b) : nullptr, 1, e.st));
-            GG_TRY(gg_bn_bwd_apply(t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, nullptr, 0, t_a, e.st));                              // dy1 -> t_a
+            GG_TRY(bn_bwd_apply_only(e, t_c, e.A(a.c1.y), bn_coef(e, M0, mid), M0, mid, t_a));                              // dy1 -> t_a
         }
         if (e.tr(l.c1.w.t_w)) GG_TRY(dense_wgrad(e, l.c1.w, e.A(a.x), d[0], t_a, mid, M0, nullptr, 0, t_c, t_d, false));
         // dx_in = dy1 . W1 + dpre
@@ -924,7 +957,7 @@ static int backward_impl(Exec& e, const float* d_out) {
         }
         if (need1) {
             GG_TRY(gemm(e, t_a, d[0], e.Wt(m.pe2.w), m.pe2.w.Np, t_b, m.pe2.w.Kp, M0, m.pe2.w.Kp, d[0])); // dcol2 -> t_b
-            if (e.fuse_bnbwd && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & 7) == 0) {
+            if (e.fuse_bnbwd && !e.f32 && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & 7) == 0) {
                 // col2im + BN1-backward reduce in one pass (dz1 -> t_d; da1 and dy1 are never formed), weight gradient from (dz1, y1, coef)
                 GG_TRY(convnorm_wgrad_from_dz(e, m.pe1, L.pe1, M1, GG_ACT_GELU, nullptr, t_d, e.A(L.col1), 32, t_b, B, H1, H1));
             } else {

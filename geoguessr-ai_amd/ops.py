@@ -227,14 +227,35 @@ def dwconv3x3_fwd_fused(y_in, stat, gamma, beta, taps, act="gelu", stride=2, col
     """depthwise conv over act(BatchNorm(y_in)) formed while loading (y_in = saved pre-BatchNorm output of the ConvNorm in front)."""
     B, H, W, Cc = y_in.shape
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
-    y = torch.empty((B, Ho, Wo, Cc), dtype=BF16, device=y_in.device)
+    f32 = y_in.dtype == F32
+    y = torch.empty((B, Ho, Wo, Cc), dtype=y_in.dtype, device=y_in.device)
     stats = None
     if colstats:
-        rows = L.lib().gg_dwconv_fwd_fused_stat_rows(B, H, W, Cc, stride)
+        rows = L.lib().gg_dwconv_f32_stat_rows(B, Ho, Wo, Cc) if f32 else L.lib().gg_dwconv_fwd_fused_stat_rows(B, H, W, Cc, stride)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=y_in.device)[:rows]
-    L.check(L.lib().gg_dwconv3x3_fwd_fused(_p(y_in, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(taps, F32), _p(y), B, H, W,
-                                           Cc, stride, _p(stats), L.stream()), "gg_dwconv3x3_fwd_fused")
+    fn = L.lib().gg_dwconv3x3_fwd_fused_f32 if f32 else L.lib().gg_dwconv3x3_fwd_fused
+    L.check(fn(_p(y_in, y_in.dtype), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(taps, F32), _p(y), B, H, W,
+               Cc, stride, _p(stats), L.stream()), "gg_dwconv3x3_fwd_fused")
     return (y, stats) if colstats else y
+
+
+def dwconv3x3_bwd_data_fused(dz_in, y_in, in_coef, taps, ep_y=None, ep_stat=None, ep_gamma=None, ep_beta=None, ep_act=None):
+    """Stride-1 depthwise data gradient; the BatchNorm-backward apply of the ConvNorm behind it rides on the loads (dy = c0*dz + c1*y + c2
+    when y_in is given) and act'(BN(ep_y)) * . plus BatchNorm backward's column sums of the ConvNorm in front ride on the stores.
+    Returns (out, partial rows [rows, 2, C] or None)."""
+    L.require_gpu()
+    B, H, W, Cc = dz_in.shape
+    dt = dz_in.dtype
+    f32 = dt == F32
+    out = torch.empty((B, H, W, Cc), dtype=dt, device=dz_in.device)
+    part, rows = None, 0
+    if ep_y is not None:
+        rows = L.lib().gg_dwconv_f32_stat_rows(B, H, W, Cc) if f32 else L.lib().gg_dwconv_fused_stat_rows(B, H, W, Cc, int(y_in is not None))
+        part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=dz_in.device)
+    fn = L.lib().gg_dwconv3x3_bwd_data_fused_f32 if f32 else L.lib().gg_dwconv3x3_bwd_data_fused
+    L.check(fn(_p(dz_in, dt), _p(y_in, dt), _p(in_coef, F32), _p(taps, F32), _p(out), B, H, W, Cc, _p(ep_y, dt), _p(ep_stat, F32),
+               _p(ep_gamma, F32), _p(ep_beta, F32), ACT[ep_act], _p(part), L.stream()), "gg_dwconv3x3_bwd_data_fused")
+    return out, (part[:rows] if part is not None else None)
 
 
 def dwconv3x3_bwd_data(dy, taps, B, H, W, Cc, stride=1):
@@ -307,48 +328,53 @@ def bn_bwd(dout, y, stat, gamma, beta, act=None, residual=None, rowscale=None, r
     return dz, dy, dg, db
 
 
+def _gemm_nt_any(a, dtype):
+    fn = L.lib().gg_gemm_nt_f32 if dtype == F32 else L.lib().gg_gemm_nt
+    L.check(fn(C.byref(a), L.stream()), "gg_gemm_nt")
+
+
 def conv_bn_prologue(y_prev, stat, gamma, beta, W, act=None, colstats=False):
     """C = act(BN(y_prev)) @ W^T with the BatchNorm + activation applied while the GEMM stages its A tile.
 
-    y_prev [M,K] bf16 is the previous ConvNorm's saved pre-BatchNorm output, stat = [mean[K], rstd[K]]."""
+    y_prev [M,K] (bf16 or f32) is the previous ConvNorm's saved pre-BatchNorm output, stat = [mean[K], rstd[K]]."""
     L.require_gpu()
     M, K = y_prev.shape
     N = W.shape[0]
-    dev = y_prev.device
-    out = torch.empty((M, N), dtype=BF16, device=dev)
+    dev, dt = y_prev.device, y_prev.dtype
+    out = torch.empty((M, N), dtype=dt, device=dev)
     stats = None
     if colstats:
         rows = L.lib().gg_gemm_colstats_rows(M)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), dtype=F32, device=dev)[:rows]
     a = L.GemmArgs()
-    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(y_prev, BF16, "y_prev"), y_prev.stride(0), _pr(W, BF16, "W"), W.stride(0), _p(out), N
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(y_prev, dt, "y_prev"), y_prev.stride(0), _pr(W, dt, "W"), W.stride(0), _p(out), N
     a.M, a.N, a.K = M, N, K
     a.a_bn_stat, a.a_bn_gamma, a.a_bn_beta, a.a_bn_act = _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act]
     a.colstats = _p(stats)
     a.split_k = 1
-    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    _gemm_nt_any(a, dt)
     return (out, stats) if colstats else out
 
 
 def conv_dgrad_bn_bwd(dY, Wt, y, stat, gamma, beta, act=None, want_param_grads=True):
     """dz = (dY @ Wt^T) * act'(BN(y)) with BatchNorm backward's column sums taken in the GEMM epilogue, then finalize.
 
-    dY [M,K] bf16, Wt [N,K] bf16 (the conv weight transposed), y [M,N] bf16 (the ConvNorm's saved conv output).
+    dY [M,K], Wt [N,K] (the conv weight transposed), y [M,N] (the ConvNorm's saved conv output); all bf16 or all f32.
     Returns (dz, coef [3,N], dgamma, dbeta) with dy = coef0*dz + coef1*y + coef2."""
     L.require_gpu()
     M, K = dY.shape
     N = Wt.shape[0]
-    dev = dY.device
-    dz = torch.empty((M, N), dtype=BF16, device=dev)
+    dev, dt = dY.device, dY.dtype
+    dz = torch.empty((M, N), dtype=dt, device=dev)
     rows = L.lib().gg_gemm_colstats_rows(M)
     part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, N), dtype=F32, device=dev)
     a = L.GemmArgs()
-    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(dY, BF16, "dY"), dY.stride(0), _pr(Wt, BF16, "Wt"), Wt.stride(0), _pr(dz), N
+    a.A, a.lda, a.B, a.ldb, a.C, a.ldc = _pr(dY, dt, "dY"), dY.stride(0), _pr(Wt, dt, "Wt"), Wt.stride(0), _pr(dz), N
     a.M, a.N, a.K = M, N, K
-    a.bn_y, a.bn_stat, a.bn_gamma, a.bn_beta, a.bn_act = _p(y, BF16, "y"), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act]
+    a.bn_y, a.bn_stat, a.bn_gamma, a.bn_beta, a.bn_act = _p(y, dt, "y"), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act]
     a.colstats = _p(part)
     a.split_k = 1
-    L.check(L.lib().gg_gemm_nt(C.byref(a), L.stream()), "gg_gemm_nt")
+    _gemm_nt_any(a, dt)
     coef = torch.empty((3, N), dtype=F32, device=dev)
     dg = torch.zeros((N,), dtype=F32, device=dev) if want_param_grads else None
     db = torch.zeros((N,), dtype=F32, device=dev) if want_param_grads else None
@@ -358,11 +384,24 @@ def conv_dgrad_bn_bwd(dY, Wt, y, stat, gamma, beta, act=None, want_param_grads=T
 
 
 def folded_dgrad(dz, y, W, coef, stat, residual=None):
-    """dx = BNbwd_apply(dz, y, coef) @ W  for a 1x1 conv W [Cout, Cin] f32, without forming dy: [dz | y] @ Bf^T + bias."""
+    """dx = BNbwd_apply(dz, y, coef) @ W  for a 1x1 conv W [Cout, Cin] f32, without forming dy.
+    bf16: [dz | y] @ Bf^T + bias with the apply folded into the weights; f32: dy = c0*dz + c1*y + c2 formed from the two sources while the
+    GEMM stages its A tile (a doubled contraction would cost real f32 MFMA time)."""
     L.require_gpu()
     M, Cout = dz.shape
     Cin = W.shape[1]
     dev = dz.device
+    if dz.dtype == F32:
+        Wt = W.t().contiguous()                                    # [Cin, Cout]
+        dx = torch.empty((M, Cin), dtype=F32, device=dev)
+        a = L.GemmArgs()
+        a.A, a.lda, a.A2, a.a_bn_stat = _pr(dz, F32, "dz"), dz.stride(0), _pr(y, F32, "y"), _p(coef, F32)
+        a.B, a.ldb, a.C, a.ldc = _p(Wt), Cout, _p(dx), Cin
+        a.M, a.N, a.K = M, Cin, Cout
+        a.residual, a.ldr = _p(residual, F32, "residual"), Cin
+        a.split_k = 1
+        _gemm_nt_any(a, F32)
+        return dx
     Bf = torch.empty((Cin, 2 * Cout), dtype=BF16, device=dev)
     bias = torch.empty((Cin,), dtype=F32, device=dev)
     L.check(L.lib().gg_bn_bwd_fold_weights(_p(W, F32, "W"), _p(coef, F32), _p(stat, F32), Cout, Cin, _p(Bf), _p(bias),

@@ -211,6 +211,18 @@ int gg_bn_apply_f32(const float* y, const float* stat, const float* gamma, const
 int gg_bn_bwd_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
                   const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* dy, float* scratch /* gg_bn_bwd_scratch_floats */,
                   float* dgamma, float* dbeta, int accumulate, void* stream);
+int gg_bn_bwd_reduce_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
+                         const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* partials, void* stream);
+int gg_bn_bwd_apply_f32(const float* dz, const float* y, const float* coef, int64_t M, int C, const float* rowscale, int rows_per_scale, float* dy,
+                        void* stream);
+/* f32 twins of the fused depthwise kernels (BatchNorm passes of the ConvNorms either side ride on the loads / stores; stride 1 for the data
+ * gradient).  gg_gemm_nt_f32 takes the matching GEMM-side fusions through GgGemmArgs: bn_y.. (BatchNorm-backward epilogue), a_bn_stat..
+ * (A := act(BN(A)) while staging) and A2 + a_bn_stat = coef [3][K] (A := coef0*A + coef1*A2 + coef2: BatchNorm backward's apply step). */
+int gg_dwconv3x3_fwd_fused_f32(const float* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act, const float* taps,
+                               float* y, int B, int H, int W, int C, int stride, float* colstats /* gg_dwconv_f32_stat_rows(B,Ho,Wo,C) rows */, void* stream);
+int gg_dwconv3x3_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H, int W, int C,
+                                    const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
+                                    float* ep_partials /* gg_dwconv_f32_stat_rows(B,H,W,C) rows */, void* stream);
 int gg_token_mean_fwd_f32(const float* x, float* out, int B, int T, int C, void* stream);
 int gg_token_mean_bwd_f32(const float* dout, float* dx, int B, int T, int C, void* stream);
 int gg_view_mean_fwd_f32(const float* emb, float* out, int64_t ldo, int N, int V, int C, void* stream);

@@ -205,6 +205,110 @@ def _attn_ref(qkv, nh, D, N, nw, ws, map_hw, table, q_off, k_off, v_off, hs, dou
     return out.detach(), qkv.grad, None if tab is None else tab.grad
 
 
+# ------------------------------------------------------------------------------------------- f32 BatchNorm fusions
+@pytest.mark.parametrize("C,H,act,stride", [(192, 28, "gelu", 2), (48, 15, "gelu", 2), (384, 14, "gelu", 1), (16, 13, "gelu", 1), (40, 7, None, 1),
+                                            (256, 56, "gelu", 1)])
+def test_f32_dwconv_with_batchnorm_gelu_on_load(ops, C, H, act, stride):
+    """gg_dwconv3x3_fwd_fused_f32 == gg_bn_apply_f32 then gg_dwconv3x3_fwd_f32 (MBConv.conv2 / PatchMerging.conv2 in fp32 mode), incl. the
+    BatchNorm partial statistics of the result, and == torch conv2d over fp32 BatchNorm + exact GELU."""
+    B = 3
+    y1 = rnd(B, H, H, C, seed=50, scale=1.5)
+    mean, var = rnd(C, seed=51, scale=0.4), rnd(C, seed=52).abs() + 0.5
+    stat = torch.stack([mean, (var + 1e-5).rsqrt()])
+    gamma, beta = rnd(C, seed=53) + 1.0, rnd(C, seed=54, scale=0.3)
+    taps = rnd(9, C, seed=55, scale=0.4)
+    a1 = ops.bn_apply(y1.cuda().view(-1, C), stat.cuda(), gamma.cuda(), beta.cuda(), act=act).view(B, H, H, C)
+    want, wstats = ops.dwconv3x3_fwd(a1, taps.cuda(), stride=stride, colstats=True)
+    got, gstats = ops.dwconv3x3_fwd_fused(y1.cuda(), stat.cuda(), gamma.cuda(), beta.cuda(), taps.cuda(), act=act, stride=stride, colstats=True)
+    assert got.dtype == F32
+    close(got, want, 1e-5, 1e-5, "fused f32 dwconv vs apply + conv")
+    close(gstats.sum(0), wstats.sum(0), 1e-4, 1e-2, "fused f32 dwconv statistics")
+    z = (y1 - mean) * stat[1] * gamma + beta
+    ref = F.conv2d((F.gelu(z) if act else z).permute(0, 3, 1, 2), taps.t().reshape(C, 1, 3, 3), None, stride, 1, 1, C)
+    close(got.permute(0, 3, 1, 2), ref, 1e-4, 1e-4, "fused f32 dwconv vs conv2d")
+
+
+@pytest.mark.parametrize("C,H", [(384, 14), (40, 7), (256, 56), (16, 13)])
+def test_f32_dwconv_data_gradient_with_batchnorm_fusions(ops, C, H):
+    """gg_dwconv3x3_bwd_data_fused_f32: BatchNorm-backward apply on the loads (dy2 = c0*dz2 + c1*y2 + c2), stride-1 data gradient,
+    * GELU'(BN1(y1)) and BatchNorm backward's two column sums on the stores -- each fusion alone and both together, vs fp32 torch."""
+    B = 2
+    dz = rnd(B, H, H, C, seed=90); y2 = rnd(B, H, H, C, seed=91)
+    coef = torch.stack([1 + 0.2 * rnd(C, seed=92), 0.3 * rnd(C, seed=93), 0.1 * rnd(C, seed=94)])
+    w = rnd(C, 1, 3, 3, seed=95, scale=0.4); taps = w.view(C, 9).t().contiguous()
+    y1 = rnd(B, H, H, C, seed=96) + 0.3
+    gamma, beta = 1 + 0.2 * rnd(C, seed=97), 0.2 * rnd(C, seed=98)
+    mean, var = y1.mean((0, 1, 2)), y1.var((0, 1, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    dy = coef[0] * dz + coef[1] * y2 + coef[2]
+    xr = torch.zeros(B, C, H, H, requires_grad=True)
+    F.conv2d(xr, w, None, 1, 1, 1, C).backward(dy.permute(0, 3, 1, 2))
+    da = xr.grad.permute(0, 2, 3, 1)
+    z = ((y1 - mean) * rstd * gamma + beta).requires_grad_(True)
+    F.gelu(z).sum().backward()
+    ref = da * z.grad
+    c = lambda t: t.cuda()
+    ep = dict(ep_y=c(y1), ep_stat=c(torch.stack([mean, rstd])), ep_gamma=c(gamma), ep_beta=c(beta), ep_act="gelu")
+    out, part = ops.dwconv3x3_bwd_data_fused(c(dz), c(y2), c(coef), c(taps), **ep)
+    close(out, ref, 1e-4, 1e-5, "f32 fused dgrad (both)")
+    s = part.cpu().sum(0)
+    close(s[0], ref.sum((0, 1, 2)), 1e-4, 1e-3, "f32 fused sum dz")
+    close(s[1], (ref * ((y1 - mean) * rstd)).sum((0, 1, 2)), 1e-4, 2e-3, "f32 fused sum dz*xhat")
+    out, part = ops.dwconv3x3_bwd_data_fused(c(dy), None, None, c(taps), **ep)
+    close(out, ref, 1e-4, 1e-5, "f32 fused dgrad (epilogue only)")
+    close(part.cpu().sum(0)[0], ref.sum((0, 1, 2)), 1e-4, 1e-3, "f32 fused sum dz (epilogue only)")
+    out, part = ops.dwconv3x3_bwd_data_fused(c(dz), c(y2), c(coef), c(taps))
+    assert part is None
+    close(out, da, 1e-4, 1e-5, "f32 fused dgrad (load only)")
+
+
+@pytest.mark.parametrize("act", [None, "gelu"])
+@pytest.mark.parametrize("M,K,N", [(3000, 256, 64), (1111, 384, 96), (130, 128, 128)])
+def test_f32_gemm_batchnorm_prologue(ops, M, K, N, act):
+    """MBConv.conv3 in fp32 mode: C = act(BN(y_prev)) @ W^T with the BatchNorm + exact GELU formed while the GEMM stages its A tile."""
+    y = rnd(M, K, seed=80) + 0.5
+    W = rnd(N, K, seed=81) / K ** 0.5
+    gamma, beta = 1 + 0.2 * rnd(K, seed=82), 0.3 * rnd(K, seed=83)
+    mean, var = y.mean(0), y.var(0, unbiased=False)
+    stat = torch.stack([mean, torch.rsqrt(var + 1e-5)])
+    z = F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5)
+    ref = (F.gelu(z) if act else z) @ W.T
+    out, stats = ops.conv_bn_prologue(y.cuda(), stat.cuda(), gamma.cuda(), beta.cuda(), W.cuda(), act=act, colstats=True)
+    assert out.dtype == F32
+    close(out, ref, 1e-4, 1e-4, "f32 prologue gemm")
+    s = stats.cpu().sum(0)
+    close(s[0], ref.sum(0), 1e-4, 2e-3, "f32 prologue colsum")
+    close(s[1], (ref * ref).sum(0), 1e-4, 2e-3, "f32 prologue colsumsq")
+
+
+@pytest.mark.parametrize("M,Cin,Cmid,Cout", [(3000, 64, 256, 64), (1111, 64, 128, 192), (200, 96, 384, 96)])
+def test_f32_convnorm_chain_backward_fused_into_gemms(ops, M, Cin, Cmid, Cout):
+    """x -conv1-> y1 -BN(train)+GELU-> a1 -conv3-> y3 in f32: conv3's dgrad carries BatchNorm backward's reduce in its epilogue, conv1's
+    dgrad forms dy1 = c0*dz1 + c1*y1 + c2 from the two sources while staging A (+ residual).  Checked against fp32 autograd."""
+    x = rnd(M, Cin, seed=70)
+    W1 = rnd(Cmid, Cin, seed=71) / Cin ** 0.5
+    W3 = rnd(Cout, Cmid, seed=72) / Cmid ** 0.5
+    gamma, beta = 1 + 0.2 * rnd(Cmid, seed=73), 0.3 * rnd(Cmid, seed=74)
+    G = rnd(M, Cout, seed=75)
+    skip = rnd(M, Cin, seed=76)
+    y1 = x @ W1.T + 1.5
+    yr = y1.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a1 = F.gelu(F.batch_norm(yr, None, None, g_, b_, True, 0.1, 1e-5))
+    (a1 @ W3.T).backward(G)
+    dx_ref = yr.grad @ W1 + skip
+    mean, var = y1.mean(0), y1.var(0, unbiased=False)
+    stat = torch.stack([mean, torch.rsqrt(var + 1e-5)]).cuda()
+    dz, coef, dg, db = ops.conv_dgrad_bn_bwd(G.cuda(), W3.T.contiguous().cuda(), y1.cuda(), stat, gamma.cuda(), beta.cuda(), act="gelu")
+    assert dz.dtype == F32
+    dy = coef[0] * dz + coef[1] * y1.cuda() + coef[2]
+    close(dy, yr.grad, 2e-4, 2e-5, "f32 dy from gemm-epilogue dz + coef")
+    close(dg, g_.grad, 2e-4, 2e-3, "f32 dgamma")
+    close(db, b_.grad, 2e-4, 2e-3, "f32 dbeta")
+    dx = ops.folded_dgrad(dz, y1.cuda(), W1.cuda(), coef, stat, residual=skip.cuda())
+    close(dx, dx_ref, 2e-4, 5e-5, "f32 two-source dgrad")
+
+
 @pytest.mark.parametrize("dtype", [F32, BF])
 @pytest.mark.parametrize("nh,D,ws,map_hw,batch,linearN", [(3, 32, 7, 14, 2, 0), (2, 32, 14, 14, 2, 0), (2, 32, 32, 32, 1, 0), (2, 32, 24, 24, 1, 0),
                                                           (2, 64, 0, 0, 2, 577), (3, 64, 0, 0, 3, 50)])
