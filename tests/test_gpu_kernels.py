@@ -564,6 +564,27 @@ def test_scoring_matches_reference_golden(ops, golden_dir):
     np.testing.assert_array_equal(s.cpu().numpy(), G.geoguessr_score(d.cpu().numpy()))
 
 
+def test_scoring_summary_and_metrics_callable(golden_dir):
+    """scoring.compute_summary == run_benchmark.py:67-117 (golden from the reference function itself) on GPU-computed distances / scores of
+    the same 200 samples; scoring.geocell_metrics honours the metrics-callable contract of evaluate_model."""
+    from geoguessr_ai_amd import scoring
+    g = np.load(os.path.join(golden_dir, "score.npz"))
+    d, s = scoring.score_batch(dev(torch.from_numpy(g["pred"][:200])), dev(torch.from_numpy(g["true"][:200])))
+    summ = scoring.compute_summary(d, s, g["sample_top1"])
+    want = dict(zip([str(k) for k in g["summary_keys"]], g["summary_vals"]))
+    assert set(summ) == set(want)
+    assert summ["num_samples"] == 200 and summ["avg_score"] == want["avg_score"]           # integer scores: exact
+    for k in ("avg_distance_km", "median_distance_km", "avg_top1_prob"):
+        np.testing.assert_allclose(summ[k], want[k], rtol=1e-9)
+    with pytest.raises(ValueError):
+        scoring.compute_summary([], [])
+    cells = np.arange(200) % 7
+    top5 = np.stack([(cells + k) % 7 for k in (1, 0, 2, 3, 4)], 1)
+    m = scoring.geocell_metrics((g["pred"][:200], cells, top5, g["true"][:200], np.where(np.arange(200) % 4 == 0, cells, (cells + 5) % 7)))
+    assert m["Geocell_accuracy"] == 0.25 and m["Geocell_top5_accuracy"] == 0.25
+    np.testing.assert_allclose(m["Mean_score"], want["avg_score"]); np.testing.assert_allclose(m["Median_distance_km"], want["median_distance_km"], rtol=1e-9)
+
+
 def test_preprocess_bilinear_matches_reference_golden(ops, golden_dir):
     g = np.load(os.path.join(golden_dir, "preprocess.npz"))
     mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
