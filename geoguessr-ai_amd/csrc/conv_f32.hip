@@ -9,16 +9,8 @@
 
 namespace {
 
-__device__ __forceinline__ float act_exact(float x, int act) {
-    if (act == GG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
-    return x;
-}
-__device__ __forceinline__ float act_grad_exact(float x, int act) {
-    if (act == GG_ACT_GELU) return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-    if (act == GG_ACT_QUICK_GELU) { const float sg = 1.0f / (1.0f + expf(-1.702f * x)); return sg + 1.702f * x * sg * (1.0f - sg); }
-    return 1.0f;
-}
+__device__ __forceinline__ float act_exact(float x, int act) { return gg_act_f32(x, act); }
+__device__ __forceinline__ float act_grad_exact(float x, int act) { return gg_act_grad_f32(x, act); }
 
 // ---------------------------------------------------------------- im2col (dense 3x3, pad 1)
 // x f32 NCHW (B,3,H,W) -> col f32 [B*Ho*Wo, 32]; k = (ky*3+kx)*3 + ci for k < 27, zeros above.  thread = (pixel, 16-byte eighth)

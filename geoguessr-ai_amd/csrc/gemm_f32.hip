@@ -43,23 +43,13 @@ __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float of
     return row * FBK + ((kc ^ ((row & 2) | ((row >> 1) & 4))) << 2);
 }
 
-// exact-erf GELU family: the f32 GEMMs are MFMA-bound, the epilogue's libm calls ride under the next tile's matrix work
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_exact(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-}
+// fp32 GELU family (common.h gg_erff: fp32-accurate, branch-free)
+__device__ __forceinline__ float gelu_exact(float x) { return gg_gelu_f32(x); }
+__device__ __forceinline__ float gelu_grad_exact(float x) { return gg_gelu_grad_f32(x); }
 
 enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4, FE_BNBWD = 5 };
-__device__ __forceinline__ float act_grad_exact_f(float x, int act) {
-    if (act == GG_ACT_GELU) return gelu_grad_exact(x);
-    if (act == GG_ACT_QUICK_GELU) { const float sg = 1.0f / (1.0f + expf(-1.702f * x)); return sg + 1.702f * x * sg * (1.0f - sg); }
-    return 1.0f;
-}
-__device__ __forceinline__ float act_exact_f(float x, int act) {
-    if (act == GG_ACT_GELU) return gelu_exact(x);
-    if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
-    return x;
-}
+__device__ __forceinline__ float act_grad_exact_f(float x, int act) { return gg_act_grad_f32(x, act); }
+__device__ __forceinline__ float act_exact_f(float x, int act) { return gg_act_f32(x, act); }
 
 // Epilogue shared by both NT kernels: lane holds C[m = m0 + wm*WROWS + mt*16 + lr][n = n0 + wn*WCOLS + nt*16 + lg*4 + r]; results leave straight
 // from the accumulator fragments (16-byte stores, 64-byte runs per row).  `smem`: at least 2*WM*BN floats, no longer read by anyone.
@@ -70,8 +60,37 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     const bool vec_c = (p.ldc & 3) == 0;
         float* red = smem;                                    // [WM][2][BN] column partials (the k-loop's last barrier has passed)
+    // the epilogue's second tensor (BatchNorm-backward: saved conv output; GELU': saved pre-activation; linear: residual) for the whole
+    // tile, all 16 loads in flight at once -- fetched inside the loop below they were 16 serialised memory round trips per tile
+    constexpr bool AUX = EPI == FE_BNBWD || EPI == FE_DGELU || EPI == FE_LINEAR;
+    constexpr int GN = (TN * TM > 8) ? 2 : TN;               // n-tiles per prefetch group: at most 8 x 16 bytes per lane in flight (32 registers)
+    const float* aux_src = EPI == FE_BNBWD ? p.bn_y : (EPI == FE_DGELU ? p.dact_preact : (EPI == FE_LINEAR ? p.residual : nullptr));
+    const int64_t aux_ld = EPI == FE_LINEAR ? p.ldr : p.ldc;
+    const bool aux_vec = (aux_ld & 3) == 0;
+    f32x4 aux[AUX ? GN : 1][AUX ? TM : 1];
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
+    for (int g0 = 0; g0 < TN; g0 += GN) {
+        if (AUX) {
+#pragma unroll
+            for (int gi = 0; gi < GN; ++gi) {
+                const int n = n0 + wn * WCOLS + (g0 + gi) * 16 + lg * 4;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const int m = m0 + wm * WROWS + mt * 16 + lr;
+                    f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                    if (g0 + gi < TN && aux_src && m < p.M && n < p.N) {
+                        const float* g = aux_src + (int64_t)m * aux_ld + n;
+                        if (aux_vec && n + 3 < p.N) h = *reinterpret_cast<const f32x4*>(g);
+                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
+                    }
+                    aux[AUX ? gi : 0][AUX ? mt : 0] = h;
+                }
+            }
+        }
+#pragma unroll
+        for (int gi = 0; gi < GN; ++gi) {
+            const int nt = g0 + gi;
+            if (nt >= TN) break;
             const int n = n0 + wn * WCOLS + nt * 16 + lg * 4;
             f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
             if (EPI != FE_PLAIN && EPI != FE_DGELU && p.bias) {
@@ -98,10 +117,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     if (p.colstats) { cs += v; cq += v * v; }   // rows beyond M / columns beyond N hold exact zeros (range-checked operand loads)
                 } else if (EPI == FE_BNBWD) {
                     if (ok) {       // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat
-                        const float* g = p.bn_y + (int64_t)m * p.ldc + n;
-                        f32x4 yv = {0.f, 0.f, 0.f, 0.f};
-                        if (full) yv = *reinterpret_cast<const f32x4*>(g);
-                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) yv[r] = g[r]; }
+                        const f32x4 yv = aux[AUX ? gi : 0][AUX ? mt : 0];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] *= act_grad_exact_f(fmaf(yv[r], bsc[r], bsh[r]), p.bn_act);
                         cs += v; cq += v * (yv * brs + bnm);
@@ -123,20 +139,13 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                         for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
                     }
                     if (EPI == FE_DGELU) {
-                        const float* g = p.dact_preact + (int64_t)m * p.ldc + n;
-                        f32x4 h = {0.f, 0.f, 0.f, 0.f};
-                        if (full) h = *reinterpret_cast<const f32x4*>(g);
-                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
+                        const f32x4 h = aux[AUX ? gi : 0][AUX ? mt : 0];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
                     }
                     if (EPI == FE_LINEAR) {
                         v *= rs;
-                        if (p.residual) {
-                            const float* g = p.residual + (int64_t)m * p.ldr + n;
-                            if (full && (p.ldr & 3) == 0) { const f32x4 h = *reinterpret_cast<const f32x4*>(g); v += h; }
-                            else { for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += g[r]; }
-                        }
+                        v += aux[AUX ? gi : 0][AUX ? mt : 0];            // zeros without a residual
                     }
                 }
                 if (ok && !((p.debug & 2) && v[0] != 12345.678f)) {
@@ -160,6 +169,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 }
             }
         }
+    }
         if ((EPI == FE_PLAIN || EPI == FE_BNBWD) && p.colstats) {
             __syncthreads();
             for (int i = threadIdx.x; i < 2 * BN; i += 256) {
@@ -342,11 +352,13 @@ template <int IPW> __device__ __forceinline__ void wait_stages_outstanding(int n
     else if (n == 1) wait_vmcnt<IPW>();
     else wait_vmcnt<0>();
 }
-template <int BN, int WM, int WN, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
-    constexpr int BM = 128, SK = 16, NST = 4;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int WCOLS = BN / WN;
+// BNC < BN: the tile computes BNC columns (N = 96 / 576 ...: no MFMA work on padding) while the LDS image and the DMA pattern stay those of
+// the BN-row B panel -- rows >= BNC are outside the buffer resource's range and arrive as zeros without touching memory.
+template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
+    constexpr int BM = 128, SK = 16;
+    constexpr int TM = BM / WM / 16, TN = BNC / WN / 16;
+    constexpr int WCOLS = BNC / WN;
     constexpr int ROWS = BM + BN, STAGE = ROWS * SK;            // floats per stage
     constexpr int IPW = ROWS / 16 / 4;                            // 1-KiB DMA instructions per wave per stage (16 rows x 64 B each)
     constexpr int JA = BM / 64;                                   // the first JA of a wave's blocks are A rows, the rest B rows
@@ -354,12 +366,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_ring_kernel(F32GemmParams 
     const int tiles = p.tilesM * p.tilesN;
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
     const int tm = bid / p.tilesN, tn = bid % p.tilesN;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BNC;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
     const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 4u;
-    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 4u;
+    const unsigned bytesB = (unsigned)min(p.N - n0, BNC) * (unsigned)p.ldb * 4u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
     // DMA geometry: block blk = wave + 4 j covers tile rows 16 blk .. 16 blk + 15 (A rows first, then B rows) x 16 k: lane -> (row lane/4, 16-byte chunk lane%4)
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_ring_kernel(F32GemmParams 
     auto issue_stage = [&](int st) {
         const int k0 = st * SK;
         const bool kin = (k0 + dch * 4) < p.K;                    // K % 4 == 0: a chunk is entirely in or out
-        float* base = smem + (st & (NST - 1)) * STAGE;
+        float* base = smem + (st % NST) * STAGE;
 #pragma unroll
         for (int j = 0; j < IPW; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : rsB, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
@@ -382,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_ring_kernel(F32GemmParams 
     };
     const int a_off = (wm * (BM / WM) + lr) * SK + lg * 4, b_off = BM * SK + (wn * WCOLS + lr) * SK + lg * 4;
     auto frag_read = [&](int st, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
-        const float* base = smem + (st & (NST - 1)) * STAGE;
+        const float* base = smem + (st % NST) * STAGE;
 #pragma unroll
         for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(base + a_off + i * 16 * SK);
 #pragma unroll
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_ring_kernel(F32GemmParams 
         if (s + 1 < nk) step(s + 1, xb, wb, xa, wa);
     }
     __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring: the epilogue may reuse it
-    gemm_f32_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+    gemm_f32_epilogue<BM, BNC, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
 }
 
 // ------------------------------------------------------------------------------------------- TN (weight gradients)
@@ -599,8 +611,14 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.bn_y = (const float*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
     p.A2 = (const float*)a->A2; p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     const int rem = a->N % 128;
-    const bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
-    const int bn = narrow ? 64 : 128;
+    bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
+    // 96-column tiles (ring kernel only) when they cover N with less padding than both 128 and 64 would (N = 96, 288, ...: +14 % at N = 96;
+    // at equal padding the 64-wide tile's 3 workgroups per CU win, N = 576: 126 vs 118 TFLOP/s)
+    static const char* w96_env = getenv("GG_GEMM_F32_NO_W96");
+    const int64_t pad96 = gg_cdiv(a->N, 96) * 96, pad128 = gg_cdiv(a->N, 128) * 128, pad64 = gg_cdiv(a->N, 64) * 64;
+    const bool wide96 = !w96_env && !a->a_bn_stat && a->N > 64 && pad96 < pad128 && pad96 < pad64;
+    if (wide96) narrow = false;
+    const int bn = wide96 ? 96 : (narrow ? 64 : 128);
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
     static const char* dbg = getenv("GG_GEMM_F32_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
@@ -620,14 +638,21 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     // workgroups (at most the resident count, each walks tiles t, t + grid, ...) -- kept for A/B timing and the DEBUG ablations
     static const char* ring_env = getenv("GG_GEMM_F32_RING");
     static const char* np_env = getenv("GG_GEMM_F32_NO_PERSIST");
-    const bool ring = !(ring_env && ring_env[0] == '0') && p.debug == 0 && !a->a_bn_stat;
+    const bool ring = (!(ring_env && ring_env[0] == '0') && p.debug == 0 && !a->a_bn_stat) || wide96;
+    const bool ring4 = ring && ring_env && ring_env[0] == '4';      // A/B: the 4-stage ring at 2 workgroups per CU
+    static const char* ringn_env = getenv("GG_GEMM_F32_RINGN");     // A/B for the 128x64 tile: "43" = 4 stages, 3 WG/CU; "34" = 3 stages, 4 WG/CU
+    const int ringn = ringn_env ? atoi(ringn_env) : 0;
     const int resident = 256 * (narrow ? 4 : 3);
     dim3 grid((ring || np_env || p.tilesM * p.tilesN <= resident) ? p.tilesM * p.tilesN : resident);
     hipStream_t st = (hipStream_t)stream;
 #define GG_LAUNCH_F32(E)                                                                                          \
     do {                                                                                                          \
-        if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);    \
-        else if (ring) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);       \
+        if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
+        else if (ring4 && !narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 4, 2>), grid, dim3(256), 0, st, p); \
+        else if (ring && narrow && ringn == 43) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 3>), grid, dim3(256), 0, st, p); \
+        else if (ring && narrow && ringn == 34) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 3, 4>), grid, dim3(256), 0, st, p); \
+        else if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 2>), grid, dim3(256), 0, st, p);    \
+        else if (ring) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3>), grid, dim3(256), 0, st, p);       \
         else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);           \
         else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);                      \
     } while (0)

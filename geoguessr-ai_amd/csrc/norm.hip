@@ -34,19 +34,9 @@ template <> struct Vec8<float> {
 };
 
 // activation at the precision of the storage type: the bf16 path's polynomial erf (|err| 2e-5) is far below bf16 resolution; the f32
-// (reference-precision) path calls libm's erff / expf
-template <typename T> __device__ __forceinline__ float act_t(float x, int act) {
-    if (sizeof(T) == 2) return gg_act(x, act);
-    if (act == GG_ACT_GELU) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
-    if (act == GG_ACT_QUICK_GELU) return x / (1.0f + expf(-1.702f * x));
-    return x;
-}
-template <typename T> __device__ __forceinline__ float act_grad_t(float x, int act) {
-    if (sizeof(T) == 2) return gg_act_grad(x, act);
-    if (act == GG_ACT_GELU) return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-    if (act == GG_ACT_QUICK_GELU) { const float sg = 1.0f / (1.0f + expf(-1.702f * x)); return sg + 1.702f * x * sg * (1.0f - sg); }
-    return 1.0f;
-}
+// (reference-precision) path uses the fp32-accurate forms of common.h (gg_erff: 1.4 ulp)
+template <typename T> __device__ __forceinline__ float act_t(float x, int act) { return sizeof(T) == 2 ? gg_act(x, act) : gg_act_f32(x, act); }
+template <typename T> __device__ __forceinline__ float act_grad_t(float x, int act) { return sizeof(T) == 2 ? gg_act_grad(x, act) : gg_act_grad_f32(x, act); }
 
 // ------------------------------------------------------------------------------ BN statistics
 // part [nparts][2][C] -> stat [2][C] = (mean, rstd); running stats updated with unbiased variance.

@@ -56,7 +56,7 @@ def test_f32_mfma_fragment_layout(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (300, 200, 100), (1000, 48, 32), (4099, 384, 96), (96, 576, 2304), (64, 12647, 576),
-                                   (257, 96, 432), (130, 72, 20)])
+                                   (257, 96, 432), (130, 72, 20), (515, 192, 64), (300, 576, 192), (129, 288, 48), (1000, 100, 36)])
 def test_f32_gemm_plain_and_stats(ops, M, N, K):
     A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1)
     ref = A.double() @ B.double().t()
