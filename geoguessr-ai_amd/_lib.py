@@ -134,7 +134,7 @@ SIGNATURES = {
     "gg_im2col_nchw3_f32_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "gg_im2col_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "gg_col2im_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "gg_dwconv_f32_stat_rows": (_I, [_I, _I, _I, _I]),
+    "gg_dwconv_f32_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv3x3_fwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_f32_wgrad_scratch_floats": (_L, [_I, _I, _I, _I, _I]),

@@ -187,12 +187,12 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
 // registers that prefetch the next k-tile are idle during a tile's last k-iteration, so they fetch the NEXT tile's first k-tile
 // there: a tile's prologue (first-load latency, ~10 % of a K = 384 tile, ~25 % of a K = 96 tile when measured by ablation) and its
 // epilogue stores overlap with matrix work instead of adding to it.  Result-independent of the grid size.
-template <int BN, int WM, int WN, int EPI, int PRO = 0>
+template <int BN, int WM, int WN, int EPI, int PRO = 0, int BNC = BN>      // BNC < BN: compute BNC columns of a BN-row B panel (see the ring kernel)
 __global__ __launch_bounds__(256, PRO != 0 ? 2 : (BN == 128 ? 3 : 4)) void gemm_nt_f32_kernel(F32GemmParams p) {
     constexpr int BM = 128;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int TM = BM / WM / 16, TN = BNC / WN / 16;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;           // 16-byte chunks per thread per k-tile
-    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    constexpr int WROWS = BM / WM, WCOLS = BNC / WN;
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * FBK];
     __shared__ __attribute__((aligned(16))) float ptab[PRO ? 3 * 1024 : 4];      // PRO: per-k coefficients [3][K], K <= 1024
     float* As = smem;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, PRO != 0 ? 2 : (BN == 128 ? 3 : 4)) void gemm_
         lds_b[i] = f32_chunk_off(srow + 32 * i, skc);
     }
     const int sw = (lr & 2) | ((lr >> 1) & 4);
-    const int a_base = (wm * (BM / WM) + lr) * FBK, b_base = (wn * (BN / WN) + lr) * FBK;
+    const int a_base = (wm * (BM / WM) + lr) * FBK, b_base = (wn * WCOLS + lr) * FBK;
     const int kc0 = ((0 + lg) ^ sw) << 2, kc1 = ((4 + lg) ^ sw) << 2;
     const int nk = (p.K + FBK - 1) / FBK;
     const bool vec_c = (p.ldc & 3) == 0;
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(256, PRO != 0 ? 2 : (BN == 128 ? 3 : 4)) void gemm_
     // read as zeros through the hardware range check), k offset in the scalar soffset, chunks beyond K pushed out of range
     auto load_tile = [&](int tm_, int tn_, int kt) {
         if (p.debug & 1) return;
-        const int m0_ = tm_ * BM, n0_ = tn_ * BN;
+        const int m0_ = tm_ * BM, n0_ = tn_ * BNC;
         const unsigned bytesA = (unsigned)min(p.M - m0_, BM) * (unsigned)p.lda * 4u;
-        const unsigned bytesB = (unsigned)min(p.N - n0_, BN) * (unsigned)p.ldb * 4u;
+        const unsigned bytesB = (unsigned)min(p.N - n0_, BNC) * (unsigned)p.ldb * 4u;
         const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0_ * p.lda), 0, (int)bytesA, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0_ * p.ldb), 0, (int)bytesB, 0x00020000);
         const int k0 = kt * FBK;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, PRO != 0 ? 2 : (BN == 128 ? 3 : 4)) void gemm_
         const bool has_next = t_next < tiles;
         const int bid_n = gg_xcd_remap(has_next ? t_next : t, tiles);
         const int tm_n = bid_n / p.tilesN, tn_n = bid_n % p.tilesN;
-        const int m0 = tm * BM, n0 = tn * BN;
+        const int m0 = tm * BM, n0 = tn * BNC;
         f32x4 acc[TN][TM];
 #pragma unroll
         for (int i = 0; i < TN; ++i)
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256, PRO != 0 ? 2 : (BN == 128 ? 3 : 4)) void gemm_
             if (!(p.debug & 4)) __syncthreads();
         }
 
-        gemm_f32_epilogue<BM, BN, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+        gemm_f32_epilogue<BM, BNC, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
         if (!has_next) break;
         t = t_next; tm = tm_n; tn = tn_n;
     }
@@ -448,6 +448,10 @@ struct F32TnParams {
     float* part;
     int tilesN, tilesK, m_per_split;
 };
+// SMALL (N <= 64 and K <= 64, e.g. patch_embed.conv1: 48 x 32 over 12.8 M rows): one 16x16-fragment block covers the whole result, so the four
+// waves split the ROWS of every 32-row step instead of the (n, k) plane and each writes its own slab (slab = 4 * block + wave; the
+// caller's slab reduce sums them like any other split).  Fragments entirely beyond N / K are skipped in both forms.
+template <bool SMALL>
 __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
     constexpr int TB = 128, MS = 32, RS = TB + 16;
     constexpr int LS = MS * (TB / 4) / 256;                 // 16-byte chunks per thread per operand per step (= 4)
@@ -460,9 +464,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
     const int n0 = tn * TB, k0 = tk * TB;
     const int mbeg = split_id * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = SMALL ? 0 : wave >> 1, wk = SMALL ? 0 : wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int nt_lim = min(4, max(0, (p.N - n0 - wn * 64 + 15) >> 4)), kt_lim = min(4, max(0, (p.K - k0 - wk * 64 + 15) >> 4));   // wave-uniform
     const int srow = threadIdx.x >> 5, sch = threadIdx.x & 31;          // 8 rows x 32 chunks per pass, LS passes
     const bool yok = (n0 + sch * 4) < p.N, xok = (k0 + sch * 4) < p.K;
     const int nrows = max(mend - mbeg, 0);
@@ -508,8 +512,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
         __syncthreads();
         if (m0 + MS < mend) load_step(m0 + MS);
         const int steps = min(MS, mend - m0 + 3) / 4;              // rows beyond mend are zero anyway; skip whole empty steps
+        const int ss0 = SMALL ? 2 * wave : 0, ss1 = SMALL ? min(steps, 2 * wave + 2) : steps;
 #pragma unroll 2
-        for (int ss = 0; ss < steps; ++ss) {
+        for (int ss = ss0; ss < ss1; ++ss) {
             float yf[4], xf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -520,12 +525,13 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
+                    if (kt < kt_lim && nt < nt_lim)
+                        acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
         }
         __syncthreads();
     }
     // lane holds D[n = .. + nt*16 + 4lg + r][k = .. + kt*16 + lr]
-    float* out = p.part + (int64_t)split_id * p.N * p.K;
+    float* out = p.part + (int64_t)(SMALL ? split_id * 4 + wave : split_id) * p.N * p.K;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -616,7 +622,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     // at equal padding the 64-wide tile's 3 workgroups per CU win, N = 576: 126 vs 118 TFLOP/s)
     static const char* w96_env = getenv("GG_GEMM_F32_NO_W96");
     const int64_t pad96 = gg_cdiv(a->N, 96) * 96, pad128 = gg_cdiv(a->N, 128) * 128, pad64 = gg_cdiv(a->N, 64) * 64;
-    const bool wide96 = !w96_env && !a->a_bn_stat && a->N > 64 && pad96 < pad128 && pad96 < pad64;
+    const bool wide96 = !w96_env && a->N > 64 && pad96 < pad128 && pad96 < pad64;
     if (wide96) narrow = false;
     const int bn = wide96 ? 96 : (narrow ? 64 : 128);
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
@@ -638,11 +644,11 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     // workgroups (at most the resident count, each walks tiles t, t + grid, ...) -- kept for A/B timing and the DEBUG ablations
     static const char* ring_env = getenv("GG_GEMM_F32_RING");
     static const char* np_env = getenv("GG_GEMM_F32_NO_PERSIST");
-    const bool ring = (!(ring_env && ring_env[0] == '0') && p.debug == 0 && !a->a_bn_stat) || wide96;
+    const bool ring = ((!(ring_env && ring_env[0] == '0') && p.debug == 0) || wide96) && !a->a_bn_stat;
     const bool ring4 = ring && ring_env && ring_env[0] == '4';      // A/B: the 4-stage ring at 2 workgroups per CU
     static const char* ringn_env = getenv("GG_GEMM_F32_RINGN");     // A/B for the 128x64 tile: "43" = 4 stages, 3 WG/CU; "34" = 3 stages, 4 WG/CU
     const int ringn = ringn_env ? atoi(ringn_env) : 0;
-    const int resident = 256 * (narrow ? 4 : 3);
+    const int resident = 256 * (a->a_bn_stat ? 2 : (narrow ? 4 : 3));      // workgroups the persistent variants keep resident (launch bounds)
     dim3 grid((ring || np_env || p.tilesM * p.tilesN <= resident) ? p.tilesM * p.tilesN : resident);
     hipStream_t st = (hipStream_t)stream;
 #define GG_LAUNCH_F32(E)                                                                                          \
@@ -658,10 +664,12 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     } while (0)
     if (a->a_bn_stat) {       // prologue kernels: (PRO 1, plain epilogue) / (PRO 2, linear epilogue)
         if (a->A2) {
-            if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, FE_LINEAR, 2>), grid, dim3(256), 0, st, p);
+            if (wide96) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_LINEAR, 2, 96>), grid, dim3(256), 0, st, p);
+            else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, FE_LINEAR, 2>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_LINEAR, 2>), grid, dim3(256), 0, st, p);
         } else {
-            if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, FE_PLAIN, 1>), grid, dim3(256), 0, st, p);
+            if (wide96) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_PLAIN, 1, 96>), grid, dim3(256), 0, st, p);
+            else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, FE_PLAIN, 1>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_PLAIN, 1>), grid, dim3(256), 0, st, p);
         }
         GG_LAUNCH_CHECK();
@@ -690,11 +698,14 @@ extern "C" int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_
     p.dY = (const float*)dY; p.ldy = ldy; p.X = (const float*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
     p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
     p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
-    p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 32);
+    const bool small = N <= 64 && K <= 64 && (splits & 3) == 0;      // gg_gemm_tn_f32_splits returns a multiple of 4 for these shapes
+    const int blocks = small ? splits / 4 : splits;
+    p.m_per_split = (int)gg_align(gg_cdiv(M, blocks), 32);
     GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 32), "gg_gemm_tn_f32: a split's rows must span < 4 GiB per operand (use more splits)");
-    GG_CHECK((int64_t)p.tilesN * p.tilesK * splits < ((int64_t)1 << 31), "gg_gemm_tn_f32: grid too large");
+    GG_CHECK((int64_t)p.tilesN * p.tilesK * blocks < ((int64_t)1 << 31), "gg_gemm_tn_f32: grid too large");
     GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
-    hipLaunchKernelGGL(gemm_tn_f32_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(256), 0, (hipStream_t)stream, p);
+    if (small) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, dim3((unsigned)(p.tilesN * p.tilesK * blocks)), dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -702,7 +713,9 @@ extern "C" int gg_gemm_tn_f32_splits(int M, int N, int K) {
     const int64_t tiles = gg_cdiv(N, 128) * gg_cdiv(K, 128);
     int64_t s = std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(1024, tiles), gg_cdiv(M, 512)));
     const int64_t cap = ((int64_t)64 << 20) / ((int64_t)N * K * 4);        // 64 MiB of slabs at most
-    return (int)std::max<int64_t>(1, std::min<int64_t>(s, cap));
+    s = std::max<int64_t>(1, std::min<int64_t>(s, cap));
+    if (N <= 64 && K <= 64 && M >= 4096) s = 4 * std::max<int64_t>(1, std::min<int64_t>(s, cap / 4));   // row-split form: 4 slabs (one per wave) per block
+    return (int)s;
 }
 
 extern "C" int gg_colsum_f32(const float* x, int64_t ld, int M, int C, const float* rowscale, int rows_per_scale, float* scratch,

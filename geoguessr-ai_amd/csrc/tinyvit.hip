@@ -222,7 +222,7 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         a.y = p.alloc(n + ".y", M * C * es);
         a.stat = p.alloc(n + ".stat", 2 * C * 4, false);
         statmax = std::max(statmax, bn_part_floats(M, C, Bn, Ho, Wo, dw) * 4);
-        if (dw) statmax = std::max(statmax, (int64_t)gg_stat_rows_capacity(gg_dwconv_f32_stat_rows(Bn, Ho, Wo, C)) * 2 * C * 4);
+        if (dw) statmax = std::max(statmax, (int64_t)gg_stat_rows_capacity(std::max(gg_dwconv_f32_stat_rows(Bn, Ho, Wo, C, 1), gg_dwconv_f32_stat_rows(Bn, Ho, Wo, C, 2))) * 2 * C * 4);
         statmax = std::max(statmax, (int64_t)gg_stat_rows_capacity(4096) * 2 * C * 4);      // stride-2 fused data gradient partials
         bnsmax = std::max(bnsmax, gg_bn_bwd_scratch_floats(M, C) * 4);
         track(M * C);
@@ -460,7 +460,7 @@ static int conv_dw_fwd(const Exec& e, const ConvBNDw& c, const Act& a, const act
     float* part = e.training ? e.F(e.L->statpart) : nullptr;
     if (e.f32) {
         GG_TRY(gg_dwconv3x3_fwd_f32((const float*)x, e.Taps(c.w), (float*)e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
-        return bn_stats(e, c.bn, a, gg_dwconv_f32_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+        return bn_stats(e, c.bn, a, gg_dwconv_f32_stat_rows(B, Ho, Wo, c.w.C, stride), (int64_t)B * Ho * Wo);
     }
     GG_TRY(gg_dwconv3x3_fwd(x, e.Taps(c.w), e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
     return bn_stats(e, c.bn, a, gg_dwconv_stat_rows(B, Ho, Wo, c.w.C, stride), (int64_t)B * Ho * Wo);
@@ -473,7 +473,7 @@ static int conv_dw_fwd_fused(const Exec& e, const ConvBNDw& c, const Act& a, con
     if (e.f32) {
         GG_TRY(gg_dwconv3x3_fwd_fused_f32((const float*)e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w),
                                           (float*)e.A(a.y), B, H, W, c.w.C, stride, part, e.st));
-        return bn_stats(e, c.bn, a, gg_dwconv_f32_stat_rows(B, Ho, Wo, c.w.C), (int64_t)B * Ho * Wo);
+        return bn_stats(e, c.bn, a, gg_dwconv_f32_stat_rows(B, Ho, Wo, c.w.C, stride), (int64_t)B * Ho * Wo);
     }
     GG_TRY(gg_dwconv3x3_fwd_fused(e.A(prev.y), e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act, e.Taps(c.w), e.A(a.y), B, H, W,
                                   c.w.C, stride, part, e.st));
@@ -703,7 +703,7 @@ static int dw_bwd_data_fused(const Exec& e, const act_t* dz_in, const act_t* y_i
     return gg_dwconv3x3_bwd_data_fused(dz_in, y_in, in_coef, e.Taps(w), out, B, H, W, w.C, ep_y, ep_stat, ep_gamma, ep_beta, ep_act, ep_part, e.st);
 }
 static int dw_fused_rows(const Exec& e, int B, int H, int W, int C, int with_input_fusion) {
-    return e.f32 ? gg_dwconv_f32_stat_rows(B, H, W, C) : gg_dwconv_fused_stat_rows(B, H, W, C, with_input_fusion);
+    return e.f32 ? gg_dwconv_f32_stat_rows(B, H, W, C, 1) : gg_dwconv_fused_stat_rows(B, H, W, C, with_input_fusion);
 }
 static int dw_bwd_data(const Exec& e, const DwW& w, const act_t* dy, act_t* dx, int B, int H, int W, int stride) {
     if (e.f32) return gg_dwconv3x3_bwd_data_f32((const float*)dy, e.Taps(w), (float*)dx, B, H, W, w.C, stride, e.st);

@@ -212,7 +212,7 @@ def dwconv3x3_fwd(x, taps, stride=1, colstats=False):
     stats = None
     f32 = x.dtype == F32
     if colstats:
-        rows = L.lib().gg_dwconv_f32_stat_rows(B, Ho, Wo, Cc) if f32 else L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, stride)
+        rows = L.lib().gg_dwconv_f32_stat_rows(B, Ho, Wo, Cc, stride) if f32 else L.lib().gg_dwconv_stat_rows(B, Ho, Wo, Cc, stride)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=x.device)[:rows]
     if f32:
         L.check(L.lib().gg_dwconv3x3_fwd_f32(_p(x, F32), _p(taps, F32), _p(y), B, H, W, Cc, stride, _p(stats), L.stream()),
@@ -231,7 +231,7 @@ def dwconv3x3_fwd_fused(y_in, stat, gamma, beta, taps, act="gelu", stride=2, col
     y = torch.empty((B, Ho, Wo, Cc), dtype=y_in.dtype, device=y_in.device)
     stats = None
     if colstats:
-        rows = L.lib().gg_dwconv_f32_stat_rows(B, Ho, Wo, Cc) if f32 else L.lib().gg_dwconv_fwd_fused_stat_rows(B, H, W, Cc, stride)
+        rows = L.lib().gg_dwconv_f32_stat_rows(B, Ho, Wo, Cc, stride) if f32 else L.lib().gg_dwconv_fwd_fused_stat_rows(B, H, W, Cc, stride)
         stats = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=y_in.device)[:rows]
     fn = L.lib().gg_dwconv3x3_fwd_fused_f32 if f32 else L.lib().gg_dwconv3x3_fwd_fused
     L.check(fn(_p(y_in, y_in.dtype), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(taps, F32), _p(y), B, H, W,
@@ -250,7 +250,7 @@ def dwconv3x3_bwd_data_fused(dz_in, y_in, in_coef, taps, ep_y=None, ep_stat=None
     out = torch.empty((B, H, W, Cc), dtype=dt, device=dz_in.device)
     part, rows = None, 0
     if ep_y is not None:
-        rows = L.lib().gg_dwconv_f32_stat_rows(B, H, W, Cc) if f32 else L.lib().gg_dwconv_fused_stat_rows(B, H, W, Cc, int(y_in is not None))
+        rows = L.lib().gg_dwconv_f32_stat_rows(B, H, W, Cc, 1) if f32 else L.lib().gg_dwconv_fused_stat_rows(B, H, W, Cc, int(y_in is not None))
         part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=dz_in.device)
     fn = L.lib().gg_dwconv3x3_bwd_data_fused_f32 if f32 else L.lib().gg_dwconv3x3_bwd_data_fused
     L.check(fn(_p(dz_in, dt), _p(y_in, dt), _p(in_coef, F32), _p(taps, F32), _p(out), B, H, W, Cc, _p(ep_y, dt), _p(ep_stat, F32),

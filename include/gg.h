@@ -200,7 +200,7 @@ int gg_im2col_nchw3_f32_f32(const float* x, float* col, int B, int H, int W, int
 int gg_im2col_nhwc_f32(const float* x, const float* stat, const float* gamma, const float* beta, int act, float* col, int B, int H, int W, int C,
                        int stride, void* stream);
 int gg_col2im_nhwc_f32(const float* dcol, float* dx, int B, int H, int W, int C, int stride, void* stream);
-int gg_dwconv_f32_stat_rows(int B, int Ho, int Wo, int C);      /* partial rows written by gg_dwconv3x3_fwd_f32.colstats */
+int gg_dwconv_f32_stat_rows(int B, int Ho, int Wo, int C, int stride);      /* partial rows written by gg_dwconv3x3_fwd_f32.colstats (Ho, Wo = output map) */
 int gg_dwconv3x3_fwd_f32(const float* x, const float* taps, float* y, int B, int H, int W, int C, int stride, float* colstats, void* stream);
 int gg_dwconv3x3_bwd_data_f32(const float* dy, const float* taps, float* dx, int B, int H, int W, int C, int stride, void* stream);
 int64_t gg_dwconv_f32_wgrad_scratch_floats(int B, int H, int W, int C, int stride);
@@ -219,10 +219,10 @@ int gg_bn_bwd_apply_f32(const float* dz, const float* y, const float* coef, int6
  * gradient).  gg_gemm_nt_f32 takes the matching GEMM-side fusions through GgGemmArgs: bn_y.. (BatchNorm-backward epilogue), a_bn_stat..
  * (A := act(BN(A)) while staging) and A2 + a_bn_stat = coef [3][K] (A := coef0*A + coef1*A2 + coef2: BatchNorm backward's apply step). */
 int gg_dwconv3x3_fwd_fused_f32(const float* x_prebn, const float* in_stat, const float* in_gamma, const float* in_beta, int in_act, const float* taps,
-                               float* y, int B, int H, int W, int C, int stride, float* colstats /* gg_dwconv_f32_stat_rows(B,Ho,Wo,C) rows */, void* stream);
+                               float* y, int B, int H, int W, int C, int stride, float* colstats /* gg_dwconv_f32_stat_rows(B,Ho,Wo,C,stride) rows */, void* stream);
 int gg_dwconv3x3_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H, int W, int C,
                                     const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
-                                    float* ep_partials /* gg_dwconv_f32_stat_rows(B,H,W,C) rows */, void* stream);
+                                    float* ep_partials /* gg_dwconv_f32_stat_rows(B,H,W,C,1) rows */, void* stream);
 int gg_token_mean_fwd_f32(const float* x, float* out, int B, int T, int C, void* stream);
 int gg_token_mean_bwd_f32(const float* dout, float* dx, int B, int T, int C, void* stream);
 int gg_view_mean_fwd_f32(const float* emb, float* out, int64_t ldo, int N, int V, int C, void* stream);

@@ -87,7 +87,8 @@ def test_f32_gemm_epilogues(ops):
     close(out, z * torch.sigmoid(1.702 * z), 1e-5, 1e-5, "f32 quick_gelu")
 
 
-@pytest.mark.parametrize("M,N,K,T", [(777, 96, 432, 0), (4100, 576, 576, 1025), (300, 12648, 576, 300), (50, 48, 32, 0)])
+@pytest.mark.parametrize("M,N,K,T", [(777, 96, 432, 0), (4100, 576, 576, 1025), (300, 12648, 576, 300), (50, 48, 32, 0), (100003, 48, 32, 0), (20001, 64, 64, 77),
+                                     (9999, 40, 20, 0)])
 def test_f32_gemm_tn_weight_gradient(ops, M, N, K, T):
     dY, X = rnd(M, N, seed=8, scale=0.1), rnd(M, K, seed=9)
     rs = None

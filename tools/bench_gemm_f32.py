@@ -43,3 +43,12 @@ for name, M, N, K, kw in shapes:
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"{name:18s} M={M:8d} N={N:5d} K={K:5d}  {dt*1e6:9.1f} us  {2.0*M*N*K/dt/1e12:7.1f} TF/s  {4.0*(M*K+N*K+M*N)/dt/1e9:8.1f} GB/s(A+B+C)")
     del A, B, out, kw, fn
+
+for name, M, N, K in [("pe1 wgrad", 12845056, 48, 32), ("pe2 wgrad", 3211264, 96, 432), ("s3.fc1 wgrad", 50176, 2304, 576)]:
+    dY = torch.randn(M, N, device="cuda"); X = torch.randn(M, K, device="cuda")
+    for _ in range(2): ops.gemm_tn(dY, X)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): ops.gemm_tn(dY, X)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f"{name:18s} M={M:8d} N={N:5d} K={K:5d}  {dt*1e6:9.1f} us  {2.0*M*N*K/dt/1e12:7.1f} TF/s  {4.0*M*(N+K)/dt/1e9:8.1f} GB/s")
+    del dY, X
