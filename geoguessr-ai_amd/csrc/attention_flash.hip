@@ -33,6 +33,7 @@ struct FlashParams {
     float* dbias; float* dbias_part;  // [nh][ws*ws] accumulated into (atomics) / per-workgroup partial rows [rows][nh][ws*ws]
     float* lse;                       // [tokens][nh]
     int ntile;                        // ceil(N / 64)
+    int npad, nbpad;                  // tokens rounded up to 16 (rows of a resident LDS image); floats reserved for a bias table
 };
 
 template <typename T> struct Ld4;
@@ -63,9 +64,9 @@ __device__ __forceinline__ int64_t fl_token(const FlashParams& p, int64_t origin
     return origin + (int64_t)i * p.W + j;
 }
 
-// stage rows [t0, t0+64) x D of one head's column block into X[64][D+4] (f32; zero rows beyond N)
+// stage rows [t0, t0+64) x D of one head's column block into X[.][D+4] (f32; zero rows beyond N; rows >= rlim are not written)
 template <typename T, int D>
-__device__ __forceinline__ void fl_stage(const FlashParams& p, const T* base, int64_t ld, int col, int64_t origin, int t0, float* X) {
+__device__ __forceinline__ void fl_stage(const FlashParams& p, const T* base, int64_t ld, int col, int64_t origin, int t0, float* X, int rlim = 64) {
     constexpr int CH = D / 4, RS = D + 4;
 #pragma unroll
     for (int i = 0; i < 64 * CH / 256; ++i) {
@@ -73,28 +74,48 @@ __device__ __forceinline__ void fl_stage(const FlashParams& p, const T* base, in
         const int row = id / CH, ch = id % CH;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (t0 + row < p.N) v = Ld4<T>::load(base + fl_token(p, origin, t0 + row) * ld + col + ch * 4);
+        if (row < rlim) *reinterpret_cast<f32x4*>(X + row * RS + ch * 4) = v;
+    }
+}
+// resident form: all p.npad rows of one head's column block (zero rows beyond N), any block size
+template <typename T, int D>
+__device__ __forceinline__ void fl_stage_all(const FlashParams& p, const T* base, int64_t ld, int col, int64_t origin, float* X) {
+    constexpr int CH = D / 4, RS = D + 4;
+    for (int id = threadIdx.x; id < p.npad * CH; id += blockDim.x) {
+        const int row = id / CH, ch = id % CH;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < p.N) v = Ld4<T>::load(base + fl_token(p, origin, row) * ld + col + ch * 4);
         *reinterpret_cast<f32x4*>(X + row * RS + ch * 4) = v;
     }
 }
-// window coordinates of tokens [t0, t0+64) -> cy/cx (bias lookups)
-__device__ __forceinline__ void fl_stage_coords(const FlashParams& p, int t0, int* cy, int* cx) {
-    if (threadIdx.x < 64) {
-        const int t = min(t0 + (int)threadIdx.x, p.N - 1);
-        const int i = p.ws ? t / p.ws : 0;
-        cy[threadIdx.x] = i; cx[threadIdx.x] = p.ws ? t - i * p.ws : 0;
+// window coordinates of tokens [t0, t0+n) -> cy/cx (bias lookups)
+__device__ __forceinline__ void fl_stage_coords(const FlashParams& p, int t0, int* cy, int* cx, int n = 64) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int t = min(t0 + i, p.N - 1);
+        const int r = p.ws ? t / p.ws : 0;
+        cy[i] = r; cx[i] = p.ws ? t - r * p.ws : 0;
     }
 }
 
+// RES (resident) variants: windows whose K/V (resp. Q/dO) fit in LDS next to a second workgroup (p.npad rows = tokens rounded up to 16, e.g. the
+// 14x14 windows of TinyViT stage 2) are staged ONCE by one workgroup per (window, head); its four waves then walk the 16-row strips
+// (strip = wave, wave + 4, ...) with no barrier inside.  The streaming form re-staged every K/V tile for each 64-query tile (4x for 196
+// tokens) behind two barriers per tile.  Same arithmetic in the same order per row: results are bit-identical between the two forms.
+// LDS carve-up (dynamic): [R][RS] x 2 operand images, the bias table (p.nbpad floats), coordinates and per-row scalars; R = RES ? npad : 64.
+
 // ------------------------------------------------------------------------------------------- forward
-template <typename T, int D>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
+template <typename T, int D, bool RES>
+__global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams p) {
     constexpr int RS = D + 4, DC = D / 16;
-    __shared__ __attribute__((aligned(16))) float Ks[64 * RS];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * RS];
-    __shared__ float btab[1024];
-    __shared__ int kcy[64], kcx[64];
-    const int qt = blockIdx.x % p.ntile;
-    const int wh = blockIdx.x / p.ntile;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int R = RES ? p.npad : 64;
+    float* Ks = fsm;
+    float* Vs = Ks + R * RS;
+    float* btab = Vs + R * RS;
+    int* kcy = reinterpret_cast<int*>(btab + p.nbpad);
+    int* kcx = kcy + R;
+    const int qt = RES ? 0 : blockIdx.x % p.ntile;
+    const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
     const int h = wh % p.nh, w = wh / p.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
@@ -102,11 +123,18 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
     const T* qkv = reinterpret_cast<const T*>(p.qkv);
     const int hc = h * p.head_stride;
     const bool has_bias = p.bias_table != nullptr;
-    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += 256) btab[i] = p.bias_table[h * p.ws * p.ws + i];
-
-    const int qi = qt * 64 + wave * 16 + lr;
+    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += blockDim.x) btab[i] = p.bias_table[h * p.ws * p.ws + i];
+    if (RES) {
+        fl_stage_all<T, D>(p, qkv, p.ld, p.k_off + hc, origin, Ks);
+        fl_stage_all<T, D>(p, qkv, p.ld, p.v_off + hc, origin, Vs);
+        if (has_bias) fl_stage_coords(p, 0, kcy, kcx, p.npad);
+        __syncthreads();
+    }
+    const int nstrips = (p.N + 15) >> 4;
+    for (int strip = RES ? wave : qt * 4 + wave; !RES || strip < nstrips; strip += (int)(blockDim.x >> 6)) {
+    const int qi = strip * 16 + lr;
     const bool qok = qi < p.N;
-    const bool wave_on = qt * 64 + wave * 16 < p.N;                 // wave-uniform
+    const bool wave_on = strip * 16 < p.N;                          // wave-uniform
     const int64_t qtok = fl_token(p, origin, min(qi, p.N - 1));
     f32x4 qf[DC];
 #pragma unroll
@@ -123,12 +151,18 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
 
     for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
         const int t0 = kt0 * 64;
-        __syncthreads();
-        fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
-        fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
-        if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
-        __syncthreads();
-        if (!wave_on) continue;
+        if (!RES) {
+            __syncthreads();
+            fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
+            fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
+            if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
+            __syncthreads();
+            if (!wave_on) continue;
+        }
+        const float* Kt = Ks + (RES ? t0 * RS : 0);
+        const float* Vt = Vs + (RES ? t0 * RS : 0);
+        const int* cyt = kcy + (RES ? t0 : 0);
+        const int* cxt = kcx + (RES ? t0 : 0);
         const int nsub = min(4, (p.N - t0 + 15) / 16);
         f32x4 st[4];
 #pragma unroll
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
             if (kt < nsub) {
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
-                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + lr) * RS + 16 * c + 4 * lg);
+                    const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
 #pragma unroll
                     for (int s = 0; s < 4; ++s) st[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[c][s], st[kt], 0, 0, 0);
                 }
@@ -151,7 +185,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int kl = 16 * kt + 4 * lg + r;
                 float s = st[kt][r] * p.scale;
-                if (has_bias) s += btab[abs(qcy - kcy[kl]) * p.ws + abs(qcx - kcx[kl])];
+                if (has_bias && kt < nsub) s += btab[abs(qcy - cyt[kl]) * p.ws + abs(qcx - cxt[kl])];
                 s = (kt < nsub && t0 + kl < p.N) ? s : -INFINITY;
                 st[kt][r] = s;
                 tmax = fmaxf(tmax, s);
@@ -178,7 +212,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
                     for (int c = 0; c < DC; ++c) {
-                        const float vf = Vs[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+                        const float vf = Vt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
                         oacc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, st[kt][r], oacc[c], 0, 0, 0);
                     }
                 }
@@ -192,18 +226,23 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FlashParams p) {
         for (int c = 0; c < DC; ++c) Ld4<T>::store(out + qtok * p.ldo + h * D + 16 * c + 4 * lg, oacc[c] * inv);
         if (p.lse && lg == 0) p.lse[qtok * p.nh + h] = m + __logf(l);
     }
+    if (!RES) break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- backward, pass A: dQ
-template <typename T, int D>
-__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
+template <typename T, int D, bool RES>
+__global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashParams p) {
     constexpr int RS = D + 4, DC = D / 16;
-    __shared__ __attribute__((aligned(16))) float Ks[64 * RS];
-    __shared__ __attribute__((aligned(16))) float Vs[64 * RS];
-    __shared__ float btab[1024];
-    __shared__ int kcy[64], kcx[64];
-    const int qt = blockIdx.x % p.ntile;
-    const int wh = blockIdx.x / p.ntile;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int R = RES ? p.npad : 64;
+    float* Ks = fsm;
+    float* Vs = Ks + R * RS;
+    float* btab = Vs + R * RS;
+    int* kcy = reinterpret_cast<int*>(btab + p.nbpad);
+    int* kcx = kcy + R;
+    const int qt = RES ? 0 : blockIdx.x % p.ntile;
+    const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
     const int h = wh % p.nh, w = wh / p.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
@@ -213,11 +252,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
     const T* outp = reinterpret_cast<const T*>(p.out);
     const int hc = h * p.head_stride;
     const bool has_bias = p.bias_table != nullptr;
-    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += 256) btab[i] = p.bias_table[h * p.ws * p.ws + i];
-
-    const int qi = qt * 64 + wave * 16 + lr;
+    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += blockDim.x) btab[i] = p.bias_table[h * p.ws * p.ws + i];
+    if (RES) {
+        fl_stage_all<T, D>(p, qkv, p.ld, p.k_off + hc, origin, Ks);
+        fl_stage_all<T, D>(p, qkv, p.ld, p.v_off + hc, origin, Vs);
+        if (has_bias) fl_stage_coords(p, 0, kcy, kcx, p.npad);
+        __syncthreads();
+    }
+    const int nstrips = (p.N + 15) >> 4;
+    for (int strip = RES ? wave : qt * 4 + wave; !RES || strip < nstrips; strip += (int)(blockDim.x >> 6)) {
+    const int qi = strip * 16 + lr;
     const bool qok = qi < p.N;
-    const bool wave_on = qt * 64 + wave * 16 < p.N;
+    const bool wave_on = strip * 16 < p.N;
     const int64_t qtok = fl_token(p, origin, min(qi, p.N - 1));
     f32x4 qf[DC], dof[DC];
     float delta = 0.f;
@@ -243,12 +289,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
 
     for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
         const int t0 = kt0 * 64;
-        __syncthreads();
-        fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
-        fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
-        if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
-        __syncthreads();
-        if (!wave_on) continue;
+        if (!RES) {
+            __syncthreads();
+            fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
+            fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
+            if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
+            __syncthreads();
+            if (!wave_on) continue;
+        }
+        const float* Kt = Ks + (RES ? t0 * RS : 0);
+        const float* Vt = Vs + (RES ? t0 * RS : 0);
+        const int* cyt = kcy + (RES ? t0 : 0);
+        const int* cxt = kcx + (RES ? t0 : 0);
         const int nsub = min(4, (p.N - t0 + 15) / 16);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -256,8 +308,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + lr) * RS + 16 * c + 4 * lg);
-                const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (16 * kt + lr) * RS + 16 * c + 4 * lg);
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
+                const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[c][s], st, 0, 0, 0);
@@ -270,7 +322,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int kl = 16 * kt + 4 * lg + r;
                 float s = st[r] * p.scale;
-                if (has_bias) s += btab[abs(qcy - kcy[kl]) * p.ws + abs(qcx - kcx[kl])];
+                if (has_bias) s += btab[abs(qcy - cyt[kl]) * p.ws + abs(qcx - cxt[kl])];
                 const float pr = (t0 + kl < p.N && qok) ? __expf(s - lse) : 0.f;
                 ds[r] = pr * (dp[r] - delta) * p.scale;
             }
@@ -278,7 +330,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
-                    const float kf = Ks[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+                    const float kf = Kt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
                     dq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, ds[r], dq[c], 0, 0, 0);
                 }
         }
@@ -288,20 +340,49 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(FlashParams p) {
 #pragma unroll
         for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[c]);
     }
+    if (!RES) break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- backward, pass B: dK, dV (+ dbias)
-template <typename T, int D, bool DBIAS>
-__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
+// delta[q] = sum_d dO[q][d] O[q][d] and lse[q] of rows [t0, t0+n) into LDS: 4 lanes per row
+template <typename T, int D>
+__device__ __forceinline__ void fl_stage_rowstats(const FlashParams& p, const T* dout, const T* outp, int64_t origin, int h, int t0, int n,
+                                                  float* lse_s, float* del_s) {
+    for (int base = 0; base < n; base += blockDim.x >> 2) {
+        const int row = base + (threadIdx.x >> 2), part = threadIdx.x & 3;
+        float dsum = 0.f;
+        const bool ok = t0 + row < p.N;
+        const int64_t tok = fl_token(p, origin, min(t0 + row, p.N - 1));
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < D / 16; ++c) {
+                const f32x4 a = Ld4<T>::load(dout + tok * p.lddo + h * D + part * (D / 4) + 4 * c);
+                const f32x4 b = Ld4<T>::load(outp + tok * p.ldo + h * D + part * (D / 4) + 4 * c);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dsum = fmaf(a[s], b[s], dsum);
+            }
+        }
+        dsum += __shfl_xor(dsum, 1, 64);
+        dsum += __shfl_xor(dsum, 2, 64);
+        if (part == 0 && row < n) { del_s[row] = dsum; lse_s[row] = ok ? p.lse[tok * p.nh + h] : INFINITY; }
+    }
+}
+template <typename T, int D, bool DBIAS, bool RES>
+__global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashParams p) {
     constexpr int RS = D + 4, DC = D / 16;
-    __shared__ __attribute__((aligned(16))) float Qs[64 * RS];
-    __shared__ __attribute__((aligned(16))) float Os[64 * RS];     // dO tile
-    __shared__ float btab[1024];
-    __shared__ float dbt[DBIAS ? 1024 : 1];
-    __shared__ int qcy[64], qcx[64];
-    __shared__ float lse_s[64], del_s[64];
-    const int kvt = blockIdx.x % p.ntile;
-    const int wh = blockIdx.x / p.ntile;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    const int R = RES ? p.npad : 64;
+    float* Qs = fsm;
+    float* Os = Qs + R * RS;                                       // dO image
+    float* btab = Os + R * RS;
+    float* dbt = btab + p.nbpad;
+    float* lse_s = dbt + (DBIAS ? p.nbpad : 0);
+    float* del_s = lse_s + R;
+    int* qcy = reinterpret_cast<int*>(del_s + R);
+    int* qcx = qcy + R;
+    const int kvt = RES ? 0 : blockIdx.x % p.ntile;
+    const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
     const int h = wh % p.nh, w = wh / p.nh;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lr = lane & 15, lg = lane >> 4;
@@ -312,12 +393,20 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
     const int hc = h * p.head_stride;
     const bool has_bias = p.bias_table != nullptr;
     const int nb = p.ws * p.ws;
-    if (has_bias) for (int i = threadIdx.x; i < nb; i += 256) btab[i] = p.bias_table[h * nb + i];
-    if (DBIAS) for (int i = threadIdx.x; i < nb; i += 256) dbt[i] = 0.f;
-
-    const int ki = kvt * 64 + wave * 16 + lr;
+    if (has_bias) for (int i = threadIdx.x; i < nb; i += blockDim.x) btab[i] = p.bias_table[h * nb + i];
+    if (DBIAS) for (int i = threadIdx.x; i < nb; i += blockDim.x) dbt[i] = 0.f;
+    if (RES) {
+        fl_stage_all<T, D>(p, qkv, p.ld, p.q_off + hc, origin, Qs);
+        fl_stage_all<T, D>(p, dout, p.lddo, h * D, origin, Os);
+        if (has_bias) fl_stage_coords(p, 0, qcy, qcx, p.npad);
+        fl_stage_rowstats<T, D>(p, dout, outp, origin, h, 0, p.npad, lse_s, del_s);
+        __syncthreads();
+    }
+    const int nstrips = (p.N + 15) >> 4;
+    for (int strip = RES ? wave : kvt * 4 + wave; !RES || strip < nstrips; strip += (int)(blockDim.x >> 6)) {
+    const int ki = strip * 16 + lr;
     const bool kok = ki < p.N;
-    const bool wave_on = kvt * 64 + wave * 16 < p.N;
+    const bool wave_on = strip * 16 < p.N;
     const int64_t ktok = fl_token(p, origin, min(ki, p.N - 1));
     f32x4 kf[DC], vf[DC];
 #pragma unroll
@@ -336,30 +425,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
 
     for (int qt0 = 0; qt0 < p.ntile; ++qt0) {
         const int t0 = qt0 * 64;
-        __syncthreads();
-        fl_stage<T, D>(p, qkv, p.ld, p.q_off + hc, origin, t0, Qs);
-        fl_stage<T, D>(p, dout, p.lddo, h * D, origin, t0, Os);
-        if (has_bias) fl_stage_coords(p, t0, qcy, qcx);
-        {   // delta[q] = sum_d dO[q][d] O[q][d], lse[q]: 4 lanes per row
-            const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
-            float dsum = 0.f;
-            const bool ok = t0 + row < p.N;
-            const int64_t tok = fl_token(p, origin, min(t0 + row, p.N - 1));
-            if (ok) {
-#pragma unroll
-                for (int c = 0; c < D / 16; ++c) {
-                    const f32x4 a = Ld4<T>::load(dout + tok * p.lddo + h * D + part * (D / 4) + 4 * c);
-                    const f32x4 b = Ld4<T>::load(outp + tok * p.ldo + h * D + part * (D / 4) + 4 * c);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) dsum = fmaf(a[s], b[s], dsum);
-                }
-            }
-            dsum += __shfl_xor(dsum, 1, 64);
-            dsum += __shfl_xor(dsum, 2, 64);
-            if (part == 0) { del_s[row] = dsum; lse_s[row] = ok ? p.lse[tok * p.nh + h] : INFINITY; }
+        if (!RES) {
+            __syncthreads();
+            fl_stage<T, D>(p, qkv, p.ld, p.q_off + hc, origin, t0, Qs);
+            fl_stage<T, D>(p, dout, p.lddo, h * D, origin, t0, Os);
+            if (has_bias) fl_stage_coords(p, t0, qcy, qcx);
+            fl_stage_rowstats<T, D>(p, dout, outp, origin, h, t0, 64, lse_s, del_s);
+            __syncthreads();
+            if (!wave_on) continue;
         }
-        __syncthreads();
-        if (!wave_on) continue;
+        const float* Qt = Qs + (RES ? t0 * RS : 0);
+        const float* Ot = Os + (RES ? t0 * RS : 0);
+        const int ro = RES ? t0 : 0;
         const int nsub = min(4, (p.N - t0 + 15) / 16);
 #pragma unroll
         for (int qs = 0; qs < 4; ++qs) {
@@ -367,8 +444,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
-                const f32x4 qa = *reinterpret_cast<const f32x4*>(Qs + (16 * qs + lr) * RS + 16 * c + 4 * lg);
-                const f32x4 oa = *reinterpret_cast<const f32x4*>(Os + (16 * qs + lr) * RS + 16 * c + 4 * lg);
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(Qt + (16 * qs + lr) * RS + 16 * c + 4 * lg);
+                const f32x4 oa = *reinterpret_cast<const f32x4*>(Ot + (16 * qs + lr) * RS + 16 * c + 4 * lg);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     st = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s], kf[c][s], st, 0, 0, 0);
@@ -382,9 +459,9 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
                 const int ql = 16 * qs + 4 * lg + r;
                 float s = st[r] * p.scale;
                 int bidx = 0;
-                if (has_bias) { bidx = abs(qcy[ql] - kcy) * p.ws + abs(qcx[ql] - kcx); s += btab[bidx]; }
-                const float e = kok ? __expf(s - lse_s[ql]) : 0.f;        // lse_s = +inf for padded queries -> 0
-                const float g = e * (dp[r] - del_s[ql]);
+                if (has_bias) { bidx = abs(qcy[ro + ql] - kcy) * p.ws + abs(qcx[ro + ql] - kcx); s += btab[bidx]; }
+                const float e = kok ? __expf(s - lse_s[ro + ql]) : 0.f;        // lse_s = +inf for padded queries -> 0
+                const float g = e * (dp[r] - del_s[ro + ql]);
                 pr[r] = e;
                 ds[r] = g * p.scale;
                 if (DBIAS && kok && t0 + ql < p.N) atomicAdd(&dbt[bidx], g);
@@ -393,8 +470,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
-                    const float of = Os[(16 * qs + 4 * lg + r) * RS + 16 * c + lr];
-                    const float qf = Qs[(16 * qs + 4 * lg + r) * RS + 16 * c + lr];
+                    const float of = Ot[(16 * qs + 4 * lg + r) * RS + 16 * c + lr];
+                    const float qf = Qt[(16 * qs + 4 * lg + r) * RS + 16 * c + lr];
                     dv[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(of, pr[r], dv[c], 0, 0, 0);
                     dk[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf, ds[r], dk[c], 0, 0, 0);
                 }
@@ -408,10 +485,13 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(FlashParams p) {
             Ld4<T>::store(dqkv + ktok * p.ld + p.v_off + hc + 16 * c + 4 * lg, dv[c]);
         }
     }
+    if (!RES) break;
+    }
     if (DBIAS) {
         __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += 256) {
-            if (p.dbias_part) p.dbias_part[((int64_t)(w * p.ntile + kvt) * p.nh + h) * nb + i] = dbt[i];
+        const int prow = RES ? w : w * p.ntile + kvt;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+            if (p.dbias_part) p.dbias_part[((int64_t)prow * p.nh + h) * nb + i] = dbt[i];
             else atomicAdd(&p.dbias[h * nb + i], dbt[i]);
         }
     }
@@ -450,7 +530,18 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.N = a->tokens_per_window; p.nh = a->num_heads; p.scale = a->scale;
     p.dout = a->dout; p.lddo = a->lddo; p.dqkv = a->dqkv; p.dbias = a->dbias; p.dbias_part = a->dbias ? a->dbias_scratch : nullptr; p.lse = a->lse;
     p.ntile = (int)gg_cdiv(a->tokens_per_window, 64);
+    p.npad = (int)gg_align(a->tokens_per_window, 16);
+    p.nbpad = (int)gg_align(std::max(4, a->window_size * a->window_size), 4);
     return 0;
+}
+// dynamic LDS of the forward / dQ kernels (two operand images, bias table, coordinates) and of the dK/dV kernel (+ bias-gradient bins,
+// lse, delta) for R staged rows
+size_t flash_lds_fwd(const FlashParams& p, int D, int R) { return ((size_t)2 * R * (D + 4) + p.nbpad + 2 * R) * 4; }
+size_t flash_lds_dkv(const FlashParams& p, int D, int R, bool dbias) { return ((size_t)2 * R * (D + 4) + p.nbpad * (dbias ? 2 : 1) + 4 * R) * 4; }
+// resident form: more than one 64-row tile (a single tile is already staged once) and two workgroups still fit a CU's 160 KB
+bool flash_resident(const FlashParams& p, int D, bool dbias) {
+    static const bool off = getenv("GG_ATTN_FLASH_NO_RES") != nullptr;
+    return !off && p.ntile > 1 && flash_lds_dkv(p, D, p.npad, dbias) <= 64 * 1024;
 }
 
 }  // namespace
@@ -459,18 +550,21 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
     FlashParams p;
     GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_fwd"));
     GG_CHECK(a->out && (a->ldo & 3) == 0 && ((uintptr_t)a->out & 15) == 0, "gg_attention_flash_fwd: bad out");
-    const dim3 grid((unsigned)(a->num_windows * a->num_heads * p.ntile)), block(256);
+    const bool res = flash_resident(p, a->head_dim, false);
+    const dim3 grid((unsigned)(a->num_windows * a->num_heads * (res ? 1 : p.ntile))), block(res ? 64 * std::min(16, p.npad / 16) : 256);
+    const size_t lds = flash_lds_fwd(p, a->head_dim, res ? p.npad : 64);
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype ? 4.0 : 2.0;
     GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
             4.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
-    if (dtype == 1) {
-        if (a->head_dim == 32) hipLaunchKernelGGL((flash_fwd_kernel<float, 32>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_fwd_kernel<float, 64>), grid, block, 0, s, p);
-    } else {
-        if (a->head_dim == 32) hipLaunchKernelGGL((flash_fwd_kernel<bf16, 32>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((flash_fwd_kernel<bf16, 64>), grid, block, 0, s, p);
-    }
+#define GG_FL_FWD(T_, D_)                                                                                     \
+    do {                                                                                                      \
+        if (res) hipLaunchKernelGGL((flash_fwd_kernel<T_, D_, true>), grid, block, lds, s, p);                \
+        else hipLaunchKernelGGL((flash_fwd_kernel<T_, D_, false>), grid, block, lds, s, p);                   \
+    } while (0)
+    if (dtype == 1) { if (a->head_dim == 32) GG_FL_FWD(float, 32); else GG_FL_FWD(float, 64); }
+    else { if (a->head_dim == 32) GG_FL_FWD(bf16, 32); else GG_FL_FWD(bf16, 64); }
+#undef GG_FL_FWD
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -483,24 +577,29 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     GG_CHECK(a->dout && a->dqkv && (a->lddo & 3) == 0 && ((uintptr_t)a->dout & 15) == 0 && ((uintptr_t)a->dqkv & 15) == 0,
              "gg_attention_flash_bwd: bad dout/dqkv");
     GG_CHECK(a->lse && a->out && (a->ldo & 3) == 0, "gg_attention_flash_bwd: needs the forward's lse and out");
-    const dim3 grid((unsigned)(a->num_windows * a->num_heads * p.ntile)), block(256);
+    const bool res = flash_resident(p, a->head_dim, p.dbias != nullptr);
+    const dim3 grid((unsigned)(a->num_windows * a->num_heads * (res ? 1 : p.ntile))), block(res ? 64 * std::min(16, p.npad / 16) : 256);
+    const int R = res ? p.npad : 64;
+    const size_t lds_q = flash_lds_fwd(p, a->head_dim, R), lds_kv = flash_lds_dkv(p, a->head_dim, R, p.dbias != nullptr);
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype ? 4.0 : 2.0;
     GG_PROF(GG_CAT_ATTN, 14.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
             8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
-#define GG_FL_BWD(T_, D_)                                                                                     \
+#define GG_FL_BWD2(T_, D_, R_)                                                                                \
     do {                                                                                                      \
-        hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_>), grid, block, 0, s, p);                              \
-        if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true>), grid, block, 0, s, p);          \
-        else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false>), grid, block, 0, s, p);                 \
+        hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_>), grid, block, lds_q, s, p);                      \
+        if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true, R_>), grid, block, lds_kv, s, p); \
+        else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false, R_>), grid, block, lds_kv, s, p);        \
     } while (0)
+#define GG_FL_BWD(T_, D_) do { if (res) GG_FL_BWD2(T_, D_, true); else GG_FL_BWD2(T_, D_, false); } while (0)
     if (dtype == 1) { if (a->head_dim == 32) GG_FL_BWD(float, 32); else GG_FL_BWD(float, 64); }
     else { if (a->head_dim == 32) GG_FL_BWD(bf16, 32); else GG_FL_BWD(bf16, 64); }
 #undef GG_FL_BWD
+#undef GG_FL_BWD2
     if (p.dbias && p.dbias_part) {
         const int Wd = p.nh * p.ws * p.ws;
         const float* rows; int nrows;
-        gg_reduce_rows(p.dbias_part, a->num_windows * p.ntile, Wd, s, &rows, &nrows);
+        gg_reduce_rows(p.dbias_part, a->num_windows * (res ? 1 : p.ntile), Wd, s, &rows, &nrows);
         hipLaunchKernelGGL(flash_dbias_final_kernel, dim3((unsigned)gg_cdiv(Wd, 256)), dim3(256), 0, s, rows, nrows, Wd, p.dbias);
     }
     GG_LAUNCH_CHECK();

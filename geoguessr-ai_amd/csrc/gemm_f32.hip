@@ -37,6 +37,7 @@ struct F32GemmParams {
     // A-operand prologues of the register-staged kernel: PRO 1: A := a_act(BN(A)) (a_stat = [mean | rstd][K], gamma, beta);
     // PRO 2: A := coef0*A + coef1*A2 + coef2 (a_stat = coef [3][K]: BatchNorm backward's apply step formed while staging)
     const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
+    int stagger;        // experiment (GG_GEMM_F32_STAGGER): first-round workgroups start hash(blockIdx) * stagger * 0.45 us late
 };
 
 __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float offset of 16-byte chunk kc (0..7) of a tile row
@@ -50,6 +51,14 @@ __device__ __forceinline__ float gelu_grad_exact(float x) { return gg_gelu_grad_
 enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4, FE_BNBWD = 5 };
 __device__ __forceinline__ float act_grad_exact_f(float x, int act) { return gg_act_grad_f32(x, act); }
 __device__ __forceinline__ float act_exact_f(float x, int act) { return gg_act_f32(x, act); }
+
+__device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 lanes of a DPP row, result in every lane of the row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));   // row_ror:1
+    return v;
+}
 
 // Epilogue shared by both NT kernels: lane holds C[m = m0 + wm*WROWS + mt*16 + lr][n = n0 + wn*WCOLS + nt*16 + lg*4 + r]; results leave straight
 // from the accumulator fragments (16-byte stores, 64-byte runs per row).  `smem`: at least 2*WM*BN floats, no longer read by anyone.
@@ -158,9 +167,8 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 // column sums over this wave's 64 / 32 rows: the 16 row-lanes first, then the WM waves that share columns through LDS
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float a = cs[r], b = cq[r];
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                    // the 16 row-lanes of a column are one DPP row: rotate-and-add inside the VALU (row_ror 8/4/2/1) instead of 8 ds_bpermute round trips
+                    const float a = row16_sum(cs[r]), b = row16_sum(cq[r]);
                     if (lr == 0) {
                         const int col = wn * WCOLS + nt * 16 + lg * 4 + r;
                         red[(wm * 2 + 0) * BN + col] = a;
@@ -364,6 +372,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     constexpr int JA = BM / 64;                                   // the first JA of a wave's blocks are A rows, the rest B rows
     __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];
     const int tiles = p.tilesM * p.tilesN;
+    if (p.stagger > 0 && blockIdx.x < 256 * OCC) {
+        const int d = (int)((blockIdx.x * 2654435761u) >> 28) * p.stagger;
+        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
     const int tm = bid / p.tilesN, tn = bid % p.tilesN;
     const int m0 = tm * BM, n0 = tn * BNC;
@@ -628,6 +640,8 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
     static const char* dbg = getenv("GG_GEMM_F32_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
+    static const char* stg = getenv("GG_GEMM_F32_STAGGER");
+    p.stagger = stg ? atoi(stg) : 0;
     const double mn = (double)a->M * a->N;
     GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
             4.0 * ((double)a->M * a->K * (a->A2 ? 2 : 1) + (double)a->N * a->K + mn) +
