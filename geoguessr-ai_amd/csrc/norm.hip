@@ -284,13 +284,14 @@ __device__ __forceinline__ float gg_group16_sum(float v) {
 // BNIN: x is the saved pre-BatchNorm output of the ConvNorm in front (TinyViT local_conv); the BatchNorm apply runs on the way in
 // (bf16-rounded exactly as the separate apply pass stores it) and the applied tensor -- the residual stream -- is written to xout, so
 // the apply pass and one read of the stream disappear.
-template <int NCH, bool BNIN = false>
-__global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+template <typename T> __device__ __forceinline__ float ln_round(float v) { return sizeof(T) == 2 ? (float)(bf16)v : v; }   // storage rounding of T
+template <typename T, int NCH, bool BNIN = false>
+__global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int64_t M, int C, float eps,
-                                                                bf16* __restrict__ out, float* __restrict__ mean_out,
+                                                                T* __restrict__ out, float* __restrict__ mean_out,
                                                                 float* __restrict__ rstd_out, const float* __restrict__ bn_stat = nullptr,
                                                                 const float* __restrict__ bn_gamma = nullptr,
-                                                                const float* __restrict__ bn_beta = nullptr, bf16* __restrict__ xout = nullptr) {
+                                                                const float* __restrict__ bn_beta = nullptr, T* __restrict__ xout = nullptr) {
     const int l16 = threadIdx.x & 15;
     const int nch = C >> 3;
     float g[NCH][8], b[NCH][8];
@@ -311,28 +312,31 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __re
     }
     const float invC = 1.f / (float)C;
     for (int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (int64_t)gridDim.x * 16) {
-        bf16x8 raw[NCH];
+        float v[NCH][8];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = l16 + 16 * k;
-            raw[k] = ch < nch ? *reinterpret_cast<const bf16x8*>(x + m * C + ch * 8) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (ch < nch) Vec8<T>::load(x + m * C + ch * 8, v[k]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+            }
             if (BNIN && ch < nch) {
                 const f32x4 s0 = *reinterpret_cast<const f32x4*>(bn_tab + ch * 8), s1 = *reinterpret_cast<const f32x4*>(bn_tab + ch * 8 + 4);
                 const f32x4 h0 = *reinterpret_cast<const f32x4*>(bn_tab + 640 + ch * 8), h1 = *reinterpret_cast<const f32x4*>(bn_tab + 640 + ch * 8 + 4);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    raw[k][j] = (bf16)((float)raw[k][j] * s0[j] + h0[j]);
-                    raw[k][j + 4] = (bf16)((float)raw[k][j + 4] * s1[j] + h1[j]);
+                    v[k][j] = ln_round<T>(v[k][j] * s0[j] + h0[j]);
+                    v[k][j + 4] = ln_round<T>(v[k][j + 4] * s1[j] + h1[j]);
                 }
-                *reinterpret_cast<bf16x8*>(xout + m * C + ch * 8) = raw[k];
+                Vec8<T>::store(xout + m * C + ch * 8, v[k]);
             }
         }
-        float v[NCH][8];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[k][j] = (float)raw[k][j]; s += v[k][j]; }
+            for (int j = 0; j < 8; ++j) s += v[k][j];
         const float mean = gg_group16_sum(s) * invC;
         float q = 0.f;
 #pragma unroll
@@ -346,21 +350,21 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const bf16* __re
         for (int k = 0; k < NCH; ++k) {
             const int ch = l16 + 16 * k;
             if (ch < nch) {
-                bf16x8 o;
+                float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaf(v[k][j] * rstd, g[k][j], b[k][j]);
-                *reinterpret_cast<bf16x8*>(out + m * C + ch * 8) = o;
+                for (int j = 0; j < 8; ++j) o[j] = fmaf(v[k][j] * rstd, g[k][j], b[k][j]);
+                Vec8<T>::store(out + m * C + ch * 8, o);
             }
         }
         if (mean_out && l16 == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
     }
 }
 // backward, same geometry.  PARAMS: accumulate (sum dout*xhat, sum dout) per channel -> part [gridDim.x][2][C]
-template <int NCH, bool PARAMS>
-__global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ x,
+template <typename T, int NCH, bool PARAMS>
+__global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const T* __restrict__ dout, const T* __restrict__ x,
                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                                 const float* __restrict__ gamma, int64_t M, int C,
-                                                                const bf16* __restrict__ dres, bf16* __restrict__ dx,
+                                                                const T* __restrict__ dres, T* __restrict__ dx,
                                                                 float* __restrict__ part) {
     extern __shared__ float sred[];   // [4 waves][2][C] when PARAMS
     const int l16 = threadIdx.x & 15;
@@ -380,27 +384,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const bf16* __re
             for (int j = 0; j < 8; ++j) dg[k][j] = db[k][j] = 0.f;
     }
     const float invC = 1.f / (float)C;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); m < M; m += (int64_t)gridDim.x * 16) {
-        bf16x8 xr[NCH], dr[NCH], rr[NCH];
+        float xh[NCH][8], dxh[NCH][8], rr[NCH][8];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = l16 + 16 * k;
             const bool ok = ch < nch;
-            xr[k] = ok ? *reinterpret_cast<const bf16x8*>(x + m * C + ch * 8) : zero8;
-            dr[k] = ok ? *reinterpret_cast<const bf16x8*>(dout + m * C + ch * 8) : zero8;
-            if (dres) rr[k] = ok ? *reinterpret_cast<const bf16x8*>(dres + m * C + ch * 8) : zero8;
+            if (ok) {
+                Vec8<T>::load(x + m * C + ch * 8, xh[k]);
+                Vec8<T>::load(dout + m * C + ch * 8, dxh[k]);
+                if (dres) Vec8<T>::load(dres + m * C + ch * 8, rr[k]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xh[k][j] = dxh[k][j] = rr[k][j] = 0.f;
+            }
         }
         const float mean = mean_in[m], rstd = rstd_in[m];
-        float xh[NCH][8], dxh[NCH][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const bool ok = l16 + 16 * k < nch;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float dv = (float)dr[k][j];
-                xh[k][j] = ok ? ((float)xr[k][j] - mean) * rstd : 0.f;
+                const float dv = dxh[k][j];
+                xh[k][j] = ok ? (xh[k][j] - mean) * rstd : 0.f;
                 dxh[k][j] = dv * g[k][j];
                 s1 += dxh[k][j];
                 s2 = fmaf(dxh[k][j], xh[k][j], s2);
@@ -413,14 +420,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const bf16* __re
         for (int k = 0; k < NCH; ++k) {
             const int ch = l16 + 16 * k;
             if (ch < nch) {
-                bf16x8 o;
+                float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float r = rstd * (dxh[k][j] - s1 - xh[k][j] * s2);
-                    if (dres) r += (float)rr[k][j];
-                    o[j] = (bf16)r;
+                    if (dres) r += rr[k][j];
+                    o[j] = r;
                 }
-                *reinterpret_cast<bf16x8*>(dx + m * C + ch * 8) = o;
+                Vec8<T>::store(dx + m * C + ch * 8, o);
             }
         }
     }
@@ -747,12 +754,16 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
                                 int out_f32, float* mean, float* rstd, void* stream) {
     GG_CHECK(x && gamma && beta && out && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_fwd: bad args (C %% 8, C <= 1024)");
     dim3 grid(ln_blocks(M)), block(256);
-    GG_PROF(GG_CAT_NORM, 0, 4.0 * M * C, stream);
+    GG_PROF(GG_CAT_NORM, 0, ((x_f32 ? 4.0 : 2.0) + (out_f32 ? 4.0 : 2.0)) * M * C, stream);
     hipStream_t s = (hipStream_t)stream;
-    const int nchl = (C / 8 + 15) / 16;          // 16-byte chunks per lane in the 16-lanes-per-row kernels
-    if (!x_f32 && !out_f32 && nchl <= 5) {
+    const int nchl = (C / 8 + 15) / 16;          // 8-element chunks per lane in the 16-lanes-per-row kernels
+    if (x_f32 == out_f32 && nchl <= 5) {
         const dim3 g16((unsigned)std::min<int64_t>(gg_cdiv(M, 16), 8192));
-#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<N_>), g16, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd)
+#define GG_LN_FWD(N_)                                                                                                                          \
+    do {                                                                                                                                       \
+        if (x_f32) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<float, N_>), g16, block, 0, s, (const float*)x, gamma, beta, M, C, eps, (float*)out, mean, rstd); \
+        else hipLaunchKernelGGL((layernorm_fwd_g16_kernel<bf16, N_>), g16, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);         \
+    } while (0)
         switch (nchl) { case 1: GG_LN_FWD(1); break; case 2: GG_LN_FWD(2); break; case 3: GG_LN_FWD(3); break; case 4: GG_LN_FWD(4); break; default: GG_LN_FWD(5); }
 #undef GG_LN_FWD
     } else if (!x_f32 && !out_f32)
@@ -766,21 +777,32 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
     GG_LAUNCH_CHECK();
     return 0;
 }
-// LayerNorm of BatchNorm(y) for a saved pre-BatchNorm conv output y: xout = bf16(BN(y)) (the residual stream), out = LN(xout)
-extern "C" int gg_layernorm_fwd_bn(const void* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, void* xout,
-                                   const float* gamma, const float* beta, int64_t M, int C, float eps, void* out, float* mean, float* rstd,
-                                   void* stream) {
+// LayerNorm of BatchNorm(y) for a saved pre-BatchNorm conv output y: xout = BN(y) in the storage type (the residual stream), out = LN(xout)
+template <typename T>
+static int layernorm_fwd_bn_t(const void* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, void* xout,
+                              const float* gamma, const float* beta, int64_t M, int C, float eps, void* out, float* mean, float* rstd,
+                              void* stream) {
     GG_CHECK(y && bn_stat && bn_gamma && bn_beta && xout && gamma && beta && out && M > 0 && (C & 7) == 0, "gg_layernorm_fwd_bn: bad args");
     const int nchl = (C / 8 + 15) / 16;
     GG_CHECK(nchl <= 5, "gg_layernorm_fwd_bn: C <= 640");
-    GG_PROF(GG_CAT_NORM, 0, 6.0 * M * C, stream);
+    GG_PROF(GG_CAT_NORM, 0, 3.0 * sizeof(T) * M * C, stream);
     const dim3 g16((unsigned)std::min<int64_t>(gg_cdiv(M, 16), 8192)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<N_, true>), g16, block, 0, s, (const bf16*)y, gamma, beta, M, C, eps, (bf16*)out, mean, rstd, bn_stat, bn_gamma, bn_beta, (bf16*)xout)
+#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<T, N_, true>), g16, block, 0, s, (const T*)y, gamma, beta, M, C, eps, (T*)out, mean, rstd, bn_stat, bn_gamma, bn_beta, (T*)xout)
     switch (nchl) { case 1: GG_LN_FWD(1); break; case 2: GG_LN_FWD(2); break; case 3: GG_LN_FWD(3); break; case 4: GG_LN_FWD(4); break; default: GG_LN_FWD(5); }
 #undef GG_LN_FWD
     GG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int gg_layernorm_fwd_bn(const void* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, void* xout,
+                                   const float* gamma, const float* beta, int64_t M, int C, float eps, void* out, float* mean, float* rstd,
+                                   void* stream) {
+    return layernorm_fwd_bn_t<bf16>(y, bn_stat, bn_gamma, bn_beta, xout, gamma, beta, M, C, eps, out, mean, rstd, stream);
+}
+extern "C" int gg_layernorm_fwd_bn_f32(const float* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, float* xout,
+                                       const float* gamma, const float* beta, int64_t M, int C, float eps, float* out, float* mean, float* rstd,
+                                       void* stream) {
+    return layernorm_fwd_bn_t<float>(y, bn_stat, bn_gamma, bn_beta, xout, gamma, beta, M, C, eps, out, mean, rstd, stream);
 }
 extern "C" int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C) { return ((int64_t)ln_blocks(M) + GG_REDUCE_SLICES) * 2 * C; }
 // f32 != 0: x, dout, dres, dx are all f32 (head norm); else all bf16
@@ -791,25 +813,27 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
     GG_CHECK(!dgamma || (scratch && dbeta), "gg_layernorm_bwd: parameter grads need scratch + dbeta");
     // with parameter gradients every block ends in a 2*C-column reduction + partial row: fewer, longer-running blocks amortise it
     const int nb = dgamma ? std::min(ln_blocks(M), 512) : ln_blocks(M);
-    GG_PROF(GG_CAT_NORM, 0, (dres ? 8.0 : 6.0) * M * C, stream);
+    GG_PROF(GG_CAT_NORM, 0, (dres ? 4.0 : 3.0) * (f32 ? 4.0 : 2.0) * M * C, stream);
     float* part = dgamma ? scratch : nullptr;
     size_t lds = dgamma ? (size_t)4 * 2 * C * sizeof(float) : 0;
     hipStream_t s = (hipStream_t)stream;
     const int nchl = (C / 8 + 15) / 16;
-    if (f32)
-        hipLaunchKernelGGL((layernorm_bwd_kernel<float, float>), dim3(nb), dim3(256), lds, s, (const float*)dout, (const float*)x, mean, rstd,
-                           gamma, M, C, (const float*)dres, (float*)dx, part);
-    else if (nchl <= 5) {
-#define GG_LN_BWD(N_)                                                                                                                  \
+    if (nchl <= 5) {
+#define GG_LN_BWD2(T_, N_)                                                                                                             \
     do {                                                                                                                               \
-        if (part) hipLaunchKernelGGL((layernorm_bwd_g16_kernel<N_, true>), dim3(nb), dim3(256), lds, s, (const bf16*)dout, (const bf16*)x, \
-                                     mean, rstd, gamma, M, C, (const bf16*)dres, (bf16*)dx, part);                                      \
-        else hipLaunchKernelGGL((layernorm_bwd_g16_kernel<N_, false>), dim3(nb), dim3(256), 0, s, (const bf16*)dout, (const bf16*)x,   \
-                                mean, rstd, gamma, M, C, (const bf16*)dres, (bf16*)dx, part);                                           \
+        if (part) hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, true>), dim3(nb), dim3(256), lds, s, (const T_*)dout, (const T_*)x, \
+                                     mean, rstd, gamma, M, C, (const T_*)dres, (T_*)dx, part);                                          \
+        else hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, false>), dim3(nb), dim3(256), 0, s, (const T_*)dout, (const T_*)x,   \
+                                mean, rstd, gamma, M, C, (const T_*)dres, (T_*)dx, part);                                               \
     } while (0)
+#define GG_LN_BWD(N_) do { if (f32) GG_LN_BWD2(float, N_); else GG_LN_BWD2(bf16, N_); } while (0)
         switch (nchl) { case 1: GG_LN_BWD(1); break; case 2: GG_LN_BWD(2); break; case 3: GG_LN_BWD(3); break; case 4: GG_LN_BWD(4); break; default: GG_LN_BWD(5); }
 #undef GG_LN_BWD
-    } else
+#undef GG_LN_BWD2
+    } else if (f32)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<float, float>), dim3(nb), dim3(256), lds, s, (const float*)dout, (const float*)x, mean, rstd,
+                           gamma, M, C, (const float*)dres, (float*)dx, part);
+    else
         hipLaunchKernelGGL((layernorm_bwd_kernel<bf16, bf16>), dim3(nb), dim3(256), lds, s, (const bf16*)dout, (const bf16*)x, mean, rstd,
                            gamma, M, C, (const bf16*)dres, (bf16*)dx, part);
     if (dgamma) {

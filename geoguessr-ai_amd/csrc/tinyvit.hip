@@ -368,6 +368,7 @@ struct Exec {
     bool fuse_bngemm = getenv("GG_NO_BNGEMM") == nullptr;
     // MBConv conv3 applies BatchNorm2 + GELU in its A prologue (one N tile: each element is transformed once)
     bool fuse_pro = getenv("GG_NO_PRO") == nullptr;
+    bool fuse_lnbn = true;           // fp32: local_conv's BatchNorm apply inside norm2 (off with GG_F32_NO_FUSE)
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
@@ -375,7 +376,7 @@ struct Exec {
         f32 = m->f32;
         // reference-precision mode: the same fusions where an f32 twin exists (MBConv / PatchMerging forward, the stride-1 data gradients, the
         // GEMM-side BatchNorm epilogue / prologues); GG_F32_NO_FUSE=1 runs every BatchNorm pass on its own (the schedule the fusions are tested against)
-        if (f32 && getenv("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = false;
+        if (f32 && getenv("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = fuse_lnbn = false;
         if (f32) fuse_dw = false;
     }
     act_t* A(int64_t off) const { return reinterpret_cast<act_t*>(ws + off); }
@@ -577,7 +578,10 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             GG_TRY(e.f32 ? gg_attention_flash_fwd(&at, 1, e.st) : gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
             GG_TRY(conv_dw_fwd(e, l.local, a.local, e.A(a.x1), B, st.res, st.res, 1));
-            if (C <= 640 && !e.f32) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
+            if (C <= 640 && e.f32 && e.fuse_lnbn) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
+                GG_TRY(gg_layernorm_fwd_bn_f32((const float*)e.A(a.local.y), e.F(a.local.stat), e.P(l.local.bn.t_g), e.P(l.local.bn.t_b), (float*)e.A(a.x2),
+                                               e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, (float*)e.A(a.b), e.F(a.mean2), e.F(a.rstd2), e.st));
+            } else if (C <= 640 && !e.f32) {
                 GG_TRY(gg_layernorm_fwd_bn(e.A(a.local.y), e.F(a.local.stat), e.P(l.local.bn.t_g), e.P(l.local.bn.t_b), e.A(a.x2), e.P(l.ln2.t_g),
                                            e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), e.F(a.mean2), e.F(a.rstd2), e.st));
             } else {

@@ -431,14 +431,15 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, out_f32=None, save_stats=True):
 
 
 def layernorm_fwd_bn(y, bn_stat, bn_gamma, bn_beta, gamma, beta, eps=1e-5):
-    """(x, LN(x), mean, rstd) with x = bf16(BatchNorm(y)) formed on the way in (TinyViT local_conv -> norm2)."""
+    """(x, LN(x), mean, rstd) with x = BatchNorm(y) (in y's storage type) formed on the way in (TinyViT local_conv -> norm2)."""
     M, Cc = y.shape
     x = torch.empty_like(y)
     out = torch.empty_like(y)
     mean = torch.empty((M,), dtype=F32, device=y.device)
     rstd = torch.empty((M,), dtype=F32, device=y.device)
-    L.check(L.lib().gg_layernorm_fwd_bn(_p(y, BF16), _p(bn_stat, F32), _p(bn_gamma, F32), _p(bn_beta, F32), _p(x), _p(gamma, F32), _p(beta, F32),
-                                        M, Cc, eps, _p(out), _p(mean), _p(rstd), L.stream()), "gg_layernorm_fwd_bn")
+    fn = L.lib().gg_layernorm_fwd_bn_f32 if y.dtype == F32 else L.lib().gg_layernorm_fwd_bn
+    L.check(fn(_p(y, y.dtype), _p(bn_stat, F32), _p(bn_gamma, F32), _p(bn_beta, F32), _p(x), _p(gamma, F32), _p(beta, F32),
+               M, Cc, eps, _p(out), _p(mean), _p(rstd), L.stream()), "gg_layernorm_fwd_bn")
     return x, out, mean, rstd
 
 

@@ -362,7 +362,8 @@ def test_batchnorm_train(ops, act, with_res):
         close(dz, zz.grad, what="bn dz (skip grad)")
 
 
-@pytest.mark.parametrize("C,f32", [(192, False), (576, False), (160, False), (768, False), (576, True), (1024, False)])
+@pytest.mark.parametrize("C,f32", [(192, False), (576, False), (160, False), (768, False), (576, True), (1024, False), (384, True), (192, True), (1024, True),
+                                   (160, True)])
 def test_layernorm(ops, C, f32):
     M = 301
     x = (rnd(M, C, seed=40, scale=1.5) + 0.3).to(BF).float()
@@ -406,6 +407,25 @@ def test_layernorm_with_batchnorm_apply_on_load(ops, M, C):
     x32 = x.float().cpu()
     close(o, F.layer_norm(x32, (C,), g.cpu(), b.cpu(), 1e-5), rtol=1e-2, atol=1e-2, what="ln vs torch on the written stream")
     close(m, x32.mean(1), rtol=1e-4, atol=1e-4, what="ln mean")
+
+
+@pytest.mark.parametrize("M,C", [(1000, 384), (333, 192), (77, 576), (50, 40)])
+def test_f32_layernorm_with_batchnorm_apply_on_load(ops, M, C):
+    """fp32 twin: gg_layernorm_fwd_bn_f32 == gg_bn_apply_f32 then gg_layernorm_fwd on f32 storage, and == torch."""
+    y = rnd(M, C, seed=70, scale=2.0)
+    mean, var = rnd(C, seed=71, scale=0.5), rnd(C, seed=72).abs() + 0.5
+    stat = torch.stack([mean, (var + 1e-5).rsqrt()])
+    bg, bb = rnd(C, seed=73) + 1.0, rnd(C, seed=74, scale=0.3)
+    g, b = rnd(C, seed=75) + 1.0, rnd(C, seed=76, scale=0.2)
+    x_ref = ops.bn_apply(dev(y), dev(stat), dev(bg), dev(bb))
+    o_ref, m_ref, r_ref = ops.layernorm_fwd(x_ref, dev(g), dev(b))
+    x, o, m, r = ops.layernorm_fwd_bn(dev(y), dev(stat), dev(bg), dev(bb), dev(g), dev(b))
+    assert x.dtype == torch.float32 and o.dtype == torch.float32
+    close(x, x_ref, rtol=1e-6, atol=1e-6, what="f32 bn-applied stream")
+    close(o, o_ref, rtol=1e-5, atol=1e-5, what="f32 ln of bn")
+    xt = (y - mean) * stat[1] * bg + bb
+    close(o, F.layer_norm(xt, (C,), g, b, 1e-5), rtol=1e-4, atol=1e-4, what="f32 ln of bn vs torch")
+    close(m, xt.mean(1), rtol=1e-5, atol=1e-5, what="f32 ln mean")
 
 
 # ------------------------------------------------------------------------------------------- attention
