@@ -72,6 +72,31 @@ def cpu_baseline(seconds_budget: float = 20.0):
                 sample=f"{steps} oracle train steps (fwd+bwd, torch fp32) of {n} panoramas = {n * 4} images, TinyViT-21M-224 + 12647-cell head, {dt:.1f} s")
 
 
+def clock_under_gemm_load(dev):
+    """Shader clock while the fp32 GEMM runs: a traced launch of the model's qkv shape (gg_gemm_f32_set_trace: every workgroup records
+    s_memtime, which ticks at the shader clock, and the constant 100 MHz wall clock over its life).  MI355X lowers its clock under sustained
+    fp32 MFMA load, so the matrix peak that can be reached is 157.3 TFLOP/s x (this clock / 2.4 GHz)."""
+    import numpy as np
+    import torch
+    from geoguessr_ai_amd import ops, _lib as L
+    M, N, K = 200704, 1152, 384
+    A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev) * 0.05; out = torch.empty(M, N, device=dev)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    buf = torch.zeros(tiles, 8, dtype=torch.int64, device=dev)
+    for _ in range(3):
+        ops.gemm_nt(A, B, out=out)
+    L.lib().gg_gemm_f32_set_trace(buf.data_ptr())
+    try:
+        ops.gemm_nt(A, B, out=out)
+        torch.cuda.synchronize(dev)
+    finally:
+        L.lib().gg_gemm_f32_set_trace(None)
+    t = buf.cpu().numpy().astype("float64")
+    life_us = (t[:, 5] - t[:, 2]) * 0.01
+    ok = life_us > 1.0
+    return float(np.median(t[ok, 1] / life_us[ok])) if ok.any() else None
+
+
 def pmc_traffic(precision):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     runs; tools/profile_round.sh + tools/pmc_traffic.py).  PMC collection cannot run inside the timed process, so this is the offline
@@ -175,6 +200,11 @@ def run_mode(precision, args, rank, world, dev, x, lab):
             roof = dict(bound="hbm", achieved=round(ach_gb, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gb / HBM_PEAK_GBS, 4), **common)
         else:
             roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach_tf / peak_tf, 4), **common)
+        if precision == "fp32" and roof["bound"] == "mfma":
+            mhz = clock_under_gemm_load(dev)
+            if mhz:
+                pk = peak_tf * mhz / 2400.0
+                roof.update(shader_clock_mhz_under_load=round(mhz, 0), peak_at_measured_clock=round(pk, 1), frac_at_measured_clock=round(ach_tf / pk, 4))
         lib.gg_prof_reset()
         breakdown["instrumented_ms_per_step"] = round(1e3 * dt_prof / args.steps, 3)
         res.update(roofline=roof, kernel_breakdown=breakdown)

@@ -114,6 +114,7 @@ SIGNATURES = {
     "gg_bn_bwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P]),
     "gg_layernorm_fwd": (_I, [_P, _I, _P, _P, _L, _I, _F, _P, _I, _P, _P, _P]),
     "gg_layernorm_fwd_bn": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
+    "gg_gemm_f32_set_trace": (_I, [_P]),
     "gg_layernorm_fwd_bn_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gg_layernorm_bwd_scratch_floats": (_L, [_L, _I]),
     "gg_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P]),

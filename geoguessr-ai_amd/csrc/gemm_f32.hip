@@ -37,6 +37,7 @@ struct F32GemmParams {
     // A-operand prologues of the register-staged kernel: PRO 1: A := a_act(BN(A)) (a_stat = [mean | rstd][K], gamma, beta);
     // PRO 2: A := coef0*A + coef1*A2 + coef2 (a_stat = coef [3][K]: BatchNorm backward's apply step formed while staging)
     const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
+    unsigned long long* trace;      // dev (gg_gemm_f32_set_trace): per-workgroup [hw_id, xcc_id, t_start, t_first_data, t_loop_end, t_epilogue_end, tile, 0] (100 MHz ticks)
     int stagger;        // experiment (GG_GEMM_F32_STAGGER): first-round workgroups start hash(blockIdx) * stagger * 0.45 us late
 };
 
@@ -159,7 +160,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 }
                 if (ok && !((p.debug & 2) && v[0] != 12345.678f)) {
                     float* g = p.C + (int64_t)m * p.ldc + n;
-                    if (full) *reinterpret_cast<f32x4*>(g) = v;
+                    if (full) { if (p.debug & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g)); else *reinterpret_cast<f32x4*>(g) = v; }
                     else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
                 }
             }
@@ -372,6 +373,9 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     constexpr int JA = BM / 64;                                   // the first JA of a wave's blocks are A rows, the rest B rows
     __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];
     const int tiles = p.tilesM * p.tilesN;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    unsigned long long mt0 = 0;
+    if (p.trace) { tr0 = wall_clock64(); mt0 = __builtin_readcyclecounter(); }
     if (p.stagger > 0 && blockIdx.x < 256 * OCC) {
         const int d = (int)((blockIdx.x * 2654435761u) >> 28) * p.stagger;
         for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
@@ -424,12 +428,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     wait_stages_outstanding<IPW>(min(nk, NST) - 1);             // stage 0 has landed (this wave's part) ...
     __builtin_amdgcn_s_barrier();                                 // ... and everybody else's
     f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
+    if (p.trace) tr1 = wall_clock64();
     frag_read(0, xa, wa);
+    unsigned long long tw_dma = 0, tw_bar = 0;                    // dev trace: cycles this wave spent waiting for its DMAs / at the stage barrier
     auto step = [&](int s, f32x4 (&xc)[TM], f32x4 (&wc)[TN], f32x4 (&xn)[TM], f32x4 (&wn_)[TN]) {
         const bool more = s + 1 < nk;
+        unsigned long long c0 = 0, c1 = 0;
+        if (p.trace) c0 = __builtin_readcyclecounter();
         if (more) wait_stages_outstanding<IPW>(min(nk - 1, s + NST - 1) - (s + 1));     // this wave's DMAs of stage s+1 have landed
+        if (p.trace) c1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_waitcnt(0xC07F);                       // lgkmcnt(0): ... and its fragment reads of stage s (whose buffer is refilled below)
         __builtin_amdgcn_s_barrier();
+        if (p.trace) { tw_dma += c1 - c0; tw_bar += __builtin_readcyclecounter() - c1; }
         if (s + NST < nk) issue_stage(s + NST);                   // into the buffer stage s occupied
         if (more) frag_read(s + 1, xn, wn_);
 #pragma unroll
@@ -445,7 +455,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         if (s + 1 < nk) step(s + 1, xb, wb, xa, wa);
     }
     __builtin_amdgcn_s_barrier();                                 // every wave is done with the ring: the epilogue may reuse it
+    if (p.trace) tr2 = wall_clock64();
     gemm_f32_epilogue<BM, BNC, WM, WN, EPI>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+    if (p.trace && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the epilogue's stores have been acknowledged
+        unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+        t[0] = hw | ((unsigned long long)(xcc & 0xF) << 32); t[1] = __builtin_readcyclecounter() - mt0; t[2] = tr0; t[3] = tr1; t[4] = tr2; t[5] = wall_clock64(); t[6] = tw_dma; t[7] = tw_bar;
+    }
 }
 
 // ------------------------------------------------------------------------------------------- TN (weight gradients)
@@ -591,6 +610,9 @@ __global__ void colsum_final_f32_kernel(const float* __restrict__ part, int npar
 }  // namespace
 
 // ------------------------------------------------------------------------------------------- host
+static unsigned long long* g_f32_trace = nullptr;
+// dev: per-workgroup timeline of the ring kernel (tools/trace_gemm_f32.py); buf = 8 x uint64 per tile or NULL to switch it off
+extern "C" int gg_gemm_f32_set_trace(void* buf) { g_f32_trace = (unsigned long long*)buf; return 0; }
 extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     GG_CHECK(a && a->A && a->B && a->C, "gg_gemm_nt_f32: null operand");
     GG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_f32: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -640,6 +662,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
     static const char* dbg = getenv("GG_GEMM_F32_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
+    p.trace = g_f32_trace;
     static const char* stg = getenv("GG_GEMM_F32_STAGGER");
     p.stagger = stg ? atoi(stg) : 0;
     const double mn = (double)a->M * a->N;
@@ -658,7 +681,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     // workgroups (at most the resident count, each walks tiles t, t + grid, ...) -- kept for A/B timing and the DEBUG ablations
     static const char* ring_env = getenv("GG_GEMM_F32_RING");
     static const char* np_env = getenv("GG_GEMM_F32_NO_PERSIST");
-    const bool ring = ((!(ring_env && ring_env[0] == '0') && p.debug == 0) || wide96) && !a->a_bn_stat;
+    const bool ring = ((!(ring_env && ring_env[0] == '0') && (p.debug & 5) == 0) || wide96) && !a->a_bn_stat;
     const bool ring4 = ring && ring_env && ring_env[0] == '4';      // A/B: the 4-stage ring at 2 workgroups per CU
     static const char* ringn_env = getenv("GG_GEMM_F32_RINGN");     // A/B for the 128x64 tile: "43" = 4 stages, 3 WG/CU; "34" = 3 stages, 4 WG/CU
     const int ringn = ringn_env ? atoi(ringn_env) : 0;

@@ -211,6 +211,7 @@ int gg_bn_apply_f32(const float* y, const float* stat, const float* gamma, const
 int gg_bn_bwd_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,
                   const float* residual, const float* rowscale, int rows_per_scale, float* dz, float* dy, float* scratch /* gg_bn_bwd_scratch_floats */,
                   float* dgamma, float* dbeta, int accumulate, void* stream);
+int gg_gemm_f32_set_trace(void* buf);   /* dev: per-workgroup timeline of gg_gemm_nt_f32's ring kernel, 8 x uint64 per tile; NULL = off */
 int gg_layernorm_fwd_bn_f32(const float* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, float* xout, const float* gamma,
                             const float* beta, int64_t M, int C, float eps, float* out, float* mean, float* rstd, void* stream);   /* f32 twin of gg_layernorm_fwd_bn */
 int gg_bn_bwd_reduce_f32(const float* dout, const float* y, const float* stat, const float* gamma, const float* beta, int64_t M, int C, int act,

@@ -309,6 +309,42 @@ def test_features_only_adapter_and_tinyvit_embedding():
     assert v.shape == (2, 320) and torch.isfinite(v).all()
 
 
+def test_embed_and_store_writes_reference_layout(tmp_path):
+    """f2 end to end: embed_and_store(TinyViTEmbedding, batches) writes one float32 little-endian BLOB row per image in the reference's
+    `samples` layout (backend/s3bucket.py:846-861,910-957); reading the file back gives bit-identical embeddings in primary-key order,
+    re-embedding a key replaces its row, and the panorama reader groups the 4 headings of a location."""
+    from geoguessr_ai_amd.pretrain.tinyvit_embedder import TinyViTEmbedding
+    from geoguessr_ai_amd.embedding_store import embed_and_store, read_embeddings, read_panorama_embeddings
+    torch.manual_seed(3)
+    emb = TinyViTEmbedding(model_name="tiny_vit_5m_224", device="cuda", load_checkpoint=False, panorama=False)
+    g = torch.Generator().manual_seed(9)
+    locs = [f"loc{i:03d}" for i in range(5)]
+    recs = [dict(location_id=l, lat=10.0 + i, lon=-20.0 - i, heading=h, capture_date="2024-05", pano_id=f"p{i}", batch_date="2024-06-01")
+            for i, l in enumerate(locs) for h in (0, 90, 180, 270)]
+    x = torch.randn(len(recs), 3, 224, 224, generator=g)
+    order = torch.randperm(len(recs), generator=g).tolist()                   # written in shuffled order, in ragged batches
+    batches = [([recs[j] for j in order[a:b]], x[order[a:b]].cuda()) for a, b in ((0, 7), (7, 8), (8, 20))]
+    db = str(tmp_path / "tinyvit_embeddings.sqlite")
+    assert embed_and_store(emb, batches, db) == 20
+    got_recs, got = read_embeddings(db)
+    assert [(r["location_id"], r["heading"]) for r in got_recs] == [(r["location_id"], r["heading"]) for r in recs]
+    want_by_key = {(recs[j]["location_id"], recs[j]["heading"]): None for j in range(20)}
+    with torch.no_grad():
+        for (rs, xv) in batches:
+            e = emb(xv).float().cpu().numpy()
+            for r, v in zip(rs, e):
+                want_by_key[(r["location_id"], r["heading"])] = v
+    for r, v in zip(got_recs, got):
+        np.testing.assert_array_equal(v, want_by_key[(r["location_id"], r["heading"])])        # the stored bytes ARE the fp32 embedding
+    assert got.dtype == np.float32 and got.shape == (20, 320) and got_recs[0]["lat"] == 10.0 and got_recs[0]["pano_id"] == "p0"
+    # INSERT OR REPLACE on (location_id, heading)
+    assert embed_and_store(emb, [([recs[3]], torch.zeros(1, 3, 224, 224).cuda())], db) == 1
+    recs2, got2 = read_embeddings(db)
+    assert len(recs2) == 20 and not np.array_equal(got2[3], got[3]) and np.array_equal(got2[4], got[4])
+    pano, latlon = read_panorama_embeddings(db)
+    assert tuple(pano.shape) == (5, 4, 320) and tuple(latlon.shape) == (5, 2) and latlon[2, 0] == 12.0
+
+
 # ------------------------------------------------------------------------------------------- robustness (ADVICE round 1)
 def test_weight_cache_follows_torch_optim_and_load_state_dict():
     """The bf16 weight cache must notice parameter writes that go through torch (torch.optim steps, load_state_dict, p.copy_), not only
