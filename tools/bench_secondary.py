@@ -17,7 +17,8 @@ from geoguessr_ai_amd.optim import AdamW
 
 L.require_gpu()
 dev = torch.device("cuda", 0)
-cases = sys.argv[1:] or ["c1", "c2u", "c4", "c5"]
+cases = [a for a in sys.argv[1:] if not a.startswith("--")] or ["c1", "c2u", "c4", "c5"]
+precisions = ["fp32", "bf16"] if "--both" in sys.argv or not any(a.startswith("--") for a in sys.argv[1:]) else [a[2:] for a in sys.argv[1:] if a in ("--fp32", "--bf16")]
 
 
 def timed(fn, steps, warmup):
@@ -29,9 +30,9 @@ def timed(fn, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
-def train_case(name, model_name, n, panorama, unfrozen, smooth, steps, warmup):
+def train_case(name, model_name, n, panorama, unfrozen, smooth, steps, warmup, precision):
     torch.manual_seed(0)
-    base = TinyViTAdapter(model_name, pretrained=False)
+    base = TinyViTAdapter(model_name, pretrained=False, precision=precision)
     model = SuperGuessr(base, panorama=panorama, should_smooth_labels=smooth, serving=False).to(dev).train()
     if unfrozen: base.unfreeze_all()
     opt = AdamW(model, lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
@@ -44,15 +45,17 @@ def train_case(name, model_name, n, panorama, unfrozen, smooth, steps, warmup):
         out.loss.backward(); opt.step(); opt.zero_grad()
     dt = timed(step, steps, warmup)
     imgs = n * (4 if panorama else 1)
-    print(json.dumps(dict(case=name, model=model_name, images_per_step=imgs, ms_per_step=round(dt * 1e3, 3), images_per_s=round(imgs / dt, 1),
+    print(json.dumps(dict(case=name, precision=precision, model=model_name, images_per_step=imgs, ms_per_step=round(dt * 1e3, 3), images_per_s=round(imgs / dt, 1),
                           trainable="all" if unfrozen else "freeze_all_but_last_stage")))
     del model, base, opt, x
+    import gc; gc.collect(); torch.cuda.empty_cache()
 
 
-if "c1" in cases:
-    train_case("c1", "tiny_vit_5m_224", 8, False, False, False, 20, 5)
-if "c2u" in cases:
-    train_case("c2-unfrozen", "tiny_vit_21m_224", 256, True, True, True, 5, 2)
+for prec in precisions:
+    if "c1" in cases:
+        train_case("c1", "tiny_vit_5m_224", 8, False, False, False, 20, 5, prec)
+    if "c2u" in cases:
+        train_case("c2-unfrozen", "tiny_vit_21m_224", 256, True, True, True, 5, 2, prec)
 if "c4" in cases:
     from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
     tower = CLIPVisionTower("openai/clip-vit-base-patch32").to(dev).eval()
@@ -65,7 +68,7 @@ if "c4" in cases:
 if "c5" in cases:
     torch.manual_seed(0)
     Bq, D, K = 4096, 576, 12647
-    head = SuperGuessr(None, panorama=True, serving=True, embed_dim=D).to(dev).eval()
+    head = SuperGuessr(None, panorama=True, serving=True, embed_dim=D, precision="fp32").to(dev).eval()
     rng = np.random.default_rng(0)
     counts = rng.poisson(4.0, K)
     gi = np.repeat(np.arange(K), counts)
