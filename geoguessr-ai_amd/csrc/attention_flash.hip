@@ -20,6 +20,8 @@
 
 namespace {
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 struct FlashParams {
     const void* qkv; int64_t ld;
     int q_off, k_off, v_off, head_stride;
@@ -88,13 +90,24 @@ __device__ __forceinline__ void fl_stage_all(const FlashParams& p, const T* base
         *reinterpret_cast<f32x4*>(X + row * RS + ch * 4) = v;
     }
 }
-// window coordinates of tokens [t0, t0+n) -> cy/cx (bias lookups)
-__device__ __forceinline__ void fl_stage_coords(const FlashParams& p, int t0, int* cy, int* cx, int n = 64) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int t = min(t0 + i, p.N - 1);
-        const int r = p.ws ? t / p.ws : 0;
-        cy[i] = r; cx[i] = p.ws ? t - r * p.ws : 0;
+// Relative-position bias without per-element index arithmetic: the compact table attention_biases[h][|dy|*ws+|dx|] is expanded in LDS to
+// E[(dy + ws-1) * (2ws-1) + (dx + ws-1)] (pre-multiplied by log2 e: the softmax runs in the exp2 domain), so that the entry for a
+// (query, key) pair sits at byte offset qlin4 - klin4[key] with  lin4(t) = 4 * (cy(t) * (2ws-1) + cx(t)),  qlin4 = lin4(q) + 4*(ws-1)*2ws:
+// one subtraction and one LDS read per score (it was two coordinate reads, two abs-differences, a multiply-add and the table read).
+__device__ __forceinline__ void fl_stage_bias(const FlashParams& p, int h, float* E) {
+    const int w2 = 2 * p.ws - 1;
+    for (int i = threadIdx.x; i < w2 * w2; i += blockDim.x) {
+        const int dy = i / w2 - (p.ws - 1), dx = i % w2 - (p.ws - 1);
+        E[i] = p.bias_table[h * p.ws * p.ws + abs(dy) * p.ws + abs(dx)] * 1.4426950408889634f;
     }
+}
+__device__ __forceinline__ int fl_lin4(const FlashParams& p, int t) {       // t < N
+    const int r = t / p.ws;
+    return 4 * (r * (2 * p.ws - 1) + (t - r * p.ws));
+}
+// klin4 of tokens [t0, t0+n)
+__device__ __forceinline__ void fl_stage_coords(const FlashParams& p, int t0, int* klin, int n = 64) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) klin[i] = fl_lin4(p, min(t0 + i, p.N - 1));
 }
 
 // RES (resident) variants: windows whose K/V (resp. Q/dO) fit in LDS next to a second workgroup (p.npad rows = tokens rounded up to 16, e.g. the
@@ -112,8 +125,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
     float* Ks = fsm;
     float* Vs = Ks + R * RS;
     float* btab = Vs + R * RS;
-    int* kcy = reinterpret_cast<int*>(btab + p.nbpad);
-    int* kcx = kcy + R;
+    int* klin = reinterpret_cast<int*>(btab + p.nbpad);            // byte-scaled linear window coordinate of every staged key
     const int qt = RES ? 0 : blockIdx.x % p.ntile;
     const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
     const int h = wh % p.nh, w = wh / p.nh;
@@ -123,11 +135,11 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
     const T* qkv = reinterpret_cast<const T*>(p.qkv);
     const int hc = h * p.head_stride;
     const bool has_bias = p.bias_table != nullptr;
-    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += blockDim.x) btab[i] = p.bias_table[h * p.ws * p.ws + i];
+    if (has_bias) fl_stage_bias(p, h, btab);
     if (RES) {
         fl_stage_all<T, D>(p, qkv, p.ld, p.k_off + hc, origin, Ks);
         fl_stage_all<T, D>(p, qkv, p.ld, p.v_off + hc, origin, Vs);
-        if (has_bias) fl_stage_coords(p, 0, kcy, kcx, p.npad);
+        if (has_bias) fl_stage_coords(p, 0, klin, p.npad);
         __syncthreads();
     }
     const int nstrips = (p.N + 15) >> 4;
@@ -143,8 +155,9 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
         if (qok) qf[c] = Ld4<T>::load(qkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg);
     }
     const int qq = min(qi, p.N - 1);
-    const int qcy = p.ws ? qq / p.ws : 0, qcx = p.ws ? qq - qcy * p.ws : 0;
+    const int qlin = has_bias ? fl_lin4(p, qq) + 4 * (p.ws - 1) * 2 * p.ws : 0;       // + the table's centre (dy = dx = 0)
     float m = -1e30f, l = 0.f;
+    const float sc2 = p.scale * 1.4426950408889634f;
     f32x4 oacc[DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) oacc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -155,14 +168,13 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
             __syncthreads();
             fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
             fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
-            if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
+            if (has_bias) fl_stage_coords(p, t0, klin);
             __syncthreads();
             if (!wave_on) continue;
         }
         const float* Kt = Ks + (RES ? t0 * RS : 0);
         const float* Vt = Vs + (RES ? t0 * RS : 0);
-        const int* cyt = kcy + (RES ? t0 : 0);
-        const int* cxt = kcx + (RES ? t0 : 0);
+        const int* klt = klin + (RES ? t0 : 0);
         const int nsub = min(4, (p.N - t0 + 15) / 16);
         f32x4 st[4];
 #pragma unroll
@@ -179,13 +191,22 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
         }
         // lane holds S^T[key = t0 + 16kt + 4lg + r][q = lr]
         float tmax = -1e30f;
+        f32x4 bia[4];                               // the 16 bias entries of this lane, all LDS reads in flight together
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            bia[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (has_bias && kt < nsub) {
+                const i32x4 kl4 = *reinterpret_cast<const i32x4*>(klt + 16 * kt + 4 * lg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bia[kt][r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(btab) + (qlin - kl4[r]));
+            }
+        }
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 4; ++r) {          // scores in the exp2 domain: s * scale * log2 e + bias * log2 e
                 const int kl = 16 * kt + 4 * lg + r;
-                float s = st[kt][r] * p.scale;
-                if (has_bias && kt < nsub) s += btab[abs(qcy - cyt[kl]) * p.ws + abs(qcx - cxt[kl])];
+                float s = fmaf(st[kt][r], sc2, bia[kt][r]);
                 s = (kt < nsub && t0 + kl < p.N) ? s : -INFINITY;
                 st[kt][r] = s;
                 tmax = fmaxf(tmax, s);
@@ -193,12 +214,12 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
         tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float mn = fmaxf(m, tmax);
-        const float alpha = __expf(m - mn);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = __expf(st[kt][r] - mn); st[kt][r] = e; ls += e; }
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(st[kt][r] - mn); st[kt][r] = e; ls += e; }
         ls += __shfl_xor(ls, 16, 64);
         ls += __shfl_xor(ls, 32, 64);
         l = l * alpha + ls;
@@ -224,7 +245,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
         T* out = reinterpret_cast<T*>(p.out);
 #pragma unroll
         for (int c = 0; c < DC; ++c) Ld4<T>::store(out + qtok * p.ldo + h * D + 16 * c + 4 * lg, oacc[c] * inv);
-        if (p.lse && lg == 0) p.lse[qtok * p.nh + h] = m + __logf(l);
+        if (p.lse && lg == 0) p.lse[qtok * p.nh + h] = m * 0.6931471805599453f + __logf(l);       // natural-log lse (m is a base-2 exponent)
     }
     if (!RES) break;
     }
@@ -239,8 +260,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
     float* Ks = fsm;
     float* Vs = Ks + R * RS;
     float* btab = Vs + R * RS;
-    int* kcy = reinterpret_cast<int*>(btab + p.nbpad);
-    int* kcx = kcy + R;
+    int* klin = reinterpret_cast<int*>(btab + p.nbpad);            // byte-scaled linear window coordinate of every staged key
     const int qt = RES ? 0 : blockIdx.x % p.ntile;
     const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
     const int h = wh % p.nh, w = wh / p.nh;
@@ -252,11 +272,11 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
     const T* outp = reinterpret_cast<const T*>(p.out);
     const int hc = h * p.head_stride;
     const bool has_bias = p.bias_table != nullptr;
-    if (has_bias) for (int i = threadIdx.x; i < p.ws * p.ws; i += blockDim.x) btab[i] = p.bias_table[h * p.ws * p.ws + i];
+    if (has_bias) fl_stage_bias(p, h, btab);
     if (RES) {
         fl_stage_all<T, D>(p, qkv, p.ld, p.k_off + hc, origin, Ks);
         fl_stage_all<T, D>(p, qkv, p.ld, p.v_off + hc, origin, Vs);
-        if (has_bias) fl_stage_coords(p, 0, kcy, kcx, p.npad);
+        if (has_bias) fl_stage_coords(p, 0, klin, p.npad);
         __syncthreads();
     }
     const int nstrips = (p.N + 15) >> 4;
@@ -280,9 +300,10 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
-    const float lse = qok ? p.lse[qtok * p.nh + h] : 0.f;
+    const float lse2 = (qok ? p.lse[qtok * p.nh + h] : 0.f) * 1.4426950408889634f;
+    const float sc2 = p.scale * 1.4426950408889634f;
     const int qq = min(qi, p.N - 1);
-    const int qcy = p.ws ? qq / p.ws : 0, qcx = p.ws ? qq - qcy * p.ws : 0;
+    const int qlin = has_bias ? fl_lin4(p, qq) + 4 * (p.ws - 1) * 2 * p.ws : 0;       // + the table's centre (dy = dx = 0)
     f32x4 dq[DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -293,14 +314,13 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             __syncthreads();
             fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
             fl_stage<T, D>(p, qkv, p.ld, p.v_off + hc, origin, t0, Vs);
-            if (has_bias) fl_stage_coords(p, t0, kcy, kcx);
+            if (has_bias) fl_stage_coords(p, t0, klin);
             __syncthreads();
             if (!wave_on) continue;
         }
         const float* Kt = Ks + (RES ? t0 * RS : 0);
         const float* Vt = Vs + (RES ? t0 * RS : 0);
-        const int* cyt = kcy + (RES ? t0 : 0);
-        const int* cxt = kcx + (RES ? t0 : 0);
+        const int* klt = klin + (RES ? t0 : 0);
         const int nsub = min(4, (p.N - t0 + 15) / 16);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -318,13 +338,20 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             }
             // lane holds S^T / dP^T [key = t0 + 16kt + 4lg + r][q = lr]
             f32x4 ds;
+            const bool tail = t0 + 16 * kt + 15 >= p.N;        // wave-uniform: only the window's last sub-tile holds padded keys
+            f32x4 bia = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) {
+                const i32x4 kl4 = *reinterpret_cast<const i32x4*>(klt + 16 * kt + 4 * lg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bia[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(btab) + (qlin - kl4[r]));
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int kl = 16 * kt + 4 * lg + r;
-                float s = st[r] * p.scale;
-                if (has_bias) s += btab[abs(qcy - cyt[kl]) * p.ws + abs(qcx - cxt[kl])];
-                const float pr = (t0 + kl < p.N && qok) ? __expf(s - lse) : 0.f;
-                ds[r] = pr * (dp[r] - delta) * p.scale;
+                const float s = fmaf(st[r], sc2, bia[r]);
+                float pr = __builtin_amdgcn_exp2f(s - lse2);          // rows beyond N are never stored: no query mask needed in this pass
+                if (tail && t0 + kl >= p.N) pr = 0.f;
+                ds[r] = pr * (dp[r] - delta);                         // the softmax scale is applied once, to dQ
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -338,7 +365,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
     if (qok) {
         T* dqkv = reinterpret_cast<T*>(p.dqkv);
 #pragma unroll
-        for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[c]);
+        for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[c] * p.scale);
     }
     if (!RES) break;
     }
@@ -365,7 +392,7 @@ __device__ __forceinline__ void fl_stage_rowstats(const FlashParams& p, const T*
         }
         dsum += __shfl_xor(dsum, 1, 64);
         dsum += __shfl_xor(dsum, 2, 64);
-        if (part == 0 && row < n) { del_s[row] = dsum; lse_s[row] = ok ? p.lse[tok * p.nh + h] : INFINITY; }
+        if (part == 0 && row < n) { del_s[row] = dsum; lse_s[row] = ok ? p.lse[tok * p.nh + h] * 1.4426950408889634f : INFINITY; }   // base-2 lse
     }
 }
 template <typename T, int D, bool DBIAS, bool RES>
@@ -379,8 +406,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
     float* dbt = btab + p.nbpad;
     float* lse_s = dbt + (DBIAS ? p.nbpad : 0);
     float* del_s = lse_s + R;
-    int* qcy = reinterpret_cast<int*>(del_s + R);
-    int* qcx = qcy + R;
+    int* qlin = reinterpret_cast<int*>(del_s + R);                 // per staged query: byte-scaled linear coordinate + the table's centre
     const int kvt = RES ? 0 : blockIdx.x % p.ntile;
     const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
     const int h = wh % p.nh, w = wh / p.nh;
@@ -393,12 +419,13 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
     const int hc = h * p.head_stride;
     const bool has_bias = p.bias_table != nullptr;
     const int nb = p.ws * p.ws;
-    if (has_bias) for (int i = threadIdx.x; i < nb; i += blockDim.x) btab[i] = p.bias_table[h * nb + i];
-    if (DBIAS) for (int i = threadIdx.x; i < nb; i += blockDim.x) dbt[i] = 0.f;
+    const int w2 = 2 * p.ws - 1;
+    if (has_bias) fl_stage_bias(p, h, btab);
+    if (DBIAS) for (int i = threadIdx.x; i < w2 * w2; i += blockDim.x) dbt[i] = 0.f;      // bins in the expanded (signed-offset) index space
     if (RES) {
         fl_stage_all<T, D>(p, qkv, p.ld, p.q_off + hc, origin, Qs);
         fl_stage_all<T, D>(p, dout, p.lddo, h * D, origin, Os);
-        if (has_bias) fl_stage_coords(p, 0, qcy, qcx, p.npad);
+        if (has_bias) fl_stage_coords(p, 0, qlin, p.npad);
         fl_stage_rowstats<T, D>(p, dout, outp, origin, h, 0, p.npad, lse_s, del_s);
         __syncthreads();
     }
@@ -418,7 +445,8 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
         }
     }
     const int kk = min(ki, p.N - 1);
-    const int kcy = p.ws ? kk / p.ws : 0, kcx = p.ws ? kk - kcy * p.ws : 0;
+    const int klin = has_bias ? fl_lin4(p, kk) - 4 * (p.ws - 1) * 2 * p.ws : 0;       // minus the table's centre: offset = qlin[q] - klin
+    const float sc2 = p.scale * 1.4426950408889634f;
     f32x4 dk[DC], dv[DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) dk[c] = dv[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -429,7 +457,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
             __syncthreads();
             fl_stage<T, D>(p, qkv, p.ld, p.q_off + hc, origin, t0, Qs);
             fl_stage<T, D>(p, dout, p.lddo, h * D, origin, t0, Os);
-            if (has_bias) fl_stage_coords(p, t0, qcy, qcx);
+            if (has_bias) fl_stage_coords(p, t0, qlin);
             fl_stage_rowstats<T, D>(p, dout, outp, origin, h, t0, 64, lse_s, del_s);
             __syncthreads();
             if (!wave_on) continue;
@@ -454,17 +482,25 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
             }
             // lane holds S / dP [q = t0 + 16qs + 4lg + r][key = lr]
             f32x4 pr, ds;
+            const int q4 = ro + 16 * qs + 4 * lg;                              // this lane's 4 consecutive queries: one 16-byte read per array
+            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q4), del4 = *reinterpret_cast<const f32x4*>(del_s + q4);
+            i32x4 boff4 = {0, 0, 0, 0};
+            f32x4 bia = {0.f, 0.f, 0.f, 0.f};
+            if (has_bias) {
+                boff4 = *reinterpret_cast<const i32x4*>(qlin + q4) - klin;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bia[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(btab) + boff4[r]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ql = 16 * qs + 4 * lg + r;
-                float s = st[r] * p.scale;
-                int bidx = 0;
-                if (has_bias) { bidx = abs(qcy[ro + ql] - kcy) * p.ws + abs(qcx[ro + ql] - kcx); s += btab[bidx]; }
-                const float e = kok ? __expf(s - lse_s[ro + ql]) : 0.f;        // lse_s = +inf for padded queries -> 0
-                const float g = e * (dp[r] - del_s[ro + ql]);
+                const int boff = boff4[r];
+                const float s = fmaf(st[r], sc2, bia[r]);
+                const float e = __builtin_amdgcn_exp2f(s - lse4[r]);           // lse_s = +inf for padded queries -> 0; a padded key's column is never stored
+                const float g = e * (dp[r] - del4[r]);
                 pr[r] = e;
-                ds[r] = g * p.scale;
-                if (DBIAS && kok && t0 + ql < p.N) atomicAdd(&dbt[bidx], g);
+                ds[r] = g;                                                     // the softmax scale is applied once, to dK
+                if (DBIAS && kok && t0 + ql < p.N) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dbt) + boff), g);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -481,7 +517,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
         T* dqkv = reinterpret_cast<T*>(p.dqkv);
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
-            Ld4<T>::store(dqkv + ktok * p.ld + p.k_off + hc + 16 * c + 4 * lg, dk[c]);
+            Ld4<T>::store(dqkv + ktok * p.ld + p.k_off + hc + 16 * c + 4 * lg, dk[c] * p.scale);
             Ld4<T>::store(dqkv + ktok * p.ld + p.v_off + hc + 16 * c + 4 * lg, dv[c]);
         }
     }
@@ -490,9 +526,14 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
     if (DBIAS) {
         __syncthreads();
         const int prow = RES ? w : w * p.ntile + kvt;
-        for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-            if (p.dbias_part) p.dbias_part[((int64_t)prow * p.nh + h) * nb + i] = dbt[i];
-            else atomicAdd(&p.dbias[h * nb + i], dbt[i]);
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) {      // fold the signed offsets back onto attention_biases[|dy| * ws + |dx|]
+            const int ady = i / p.ws, adx = i - ady * p.ws, c0 = (p.ws - 1) * w2 + (p.ws - 1);
+            float t = dbt[c0 + ady * w2 + adx];
+            if (ady) t += dbt[c0 - ady * w2 + adx];
+            if (adx) t += dbt[c0 + ady * w2 - adx];
+            if (ady && adx) t += dbt[c0 - ady * w2 - adx];
+            if (p.dbias_part) p.dbias_part[((int64_t)prow * p.nh + h) * nb + i] = t;
+            else atomicAdd(&p.dbias[h * nb + i], t);
         }
     }
 }
@@ -531,13 +572,13 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.dout = a->dout; p.lddo = a->lddo; p.dqkv = a->dqkv; p.dbias = a->dbias; p.dbias_part = a->dbias ? a->dbias_scratch : nullptr; p.lse = a->lse;
     p.ntile = (int)gg_cdiv(a->tokens_per_window, 64);
     p.npad = (int)gg_align(a->tokens_per_window, 16);
-    p.nbpad = (int)gg_align(std::max(4, a->window_size * a->window_size), 4);
+    p.nbpad = (int)gg_align(std::max(4, (2 * a->window_size - 1) * (2 * a->window_size - 1)), 4);      // expanded (signed-offset) bias table
     return 0;
 }
 // dynamic LDS of the forward / dQ kernels (two operand images, bias table, coordinates) and of the dK/dV kernel (+ bias-gradient bins,
 // lse, delta) for R staged rows
-size_t flash_lds_fwd(const FlashParams& p, int D, int R) { return ((size_t)2 * R * (D + 4) + p.nbpad + 2 * R) * 4; }
-size_t flash_lds_dkv(const FlashParams& p, int D, int R, bool dbias) { return ((size_t)2 * R * (D + 4) + p.nbpad * (dbias ? 2 : 1) + 4 * R) * 4; }
+size_t flash_lds_fwd(const FlashParams& p, int D, int R) { return ((size_t)2 * R * (D + 4) + p.nbpad + R) * 4; }
+size_t flash_lds_dkv(const FlashParams& p, int D, int R, bool dbias) { return ((size_t)2 * R * (D + 4) + p.nbpad * (dbias ? 2 : 1) + 3 * R) * 4; }
 // resident form: more than one 64-row tile (a single tile is already staged once) and two workgroups still fit a CU's 160 KB
 bool flash_resident(const FlashParams& p, int D, bool dbias) {
     static const bool off = getenv("GG_ATTN_FLASH_NO_RES") != nullptr;
