@@ -345,6 +345,26 @@ def test_embed_and_store_writes_reference_layout(tmp_path):
     assert tuple(pano.shape) == (5, 4, 320) and tuple(latlon.shape) == (5, 2) and latlon[2, 0] == 12.0
 
 
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) rehearsed with two ranks sharing this box's one GPU over gloo:
+    parameter broadcast, gradient buckets leaving from the backward pass's stage callback, the remainder after backward, AdamW with the
+    1/world average -- the same Python/C path the RCCL run takes, only the transport differs.  One JSON line, finite loss, global batch."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = __import__("socket").socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, GG_DIST_BACKEND="gloo", GG_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--panoramas", "8", "--no-cpu-baseline", "--no-roofline",
+           "--precision", "fp32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch_panoramas"] == 16 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["dtype"] == "fp32" and np.isfinite(d["loss"]) and d["value"] > 0
+
+
 # ------------------------------------------------------------------------------------------- robustness (ADVICE round 1)
 def test_weight_cache_follows_torch_optim_and_load_state_dict():
     """The bf16 weight cache must notice parameter writes that go through torch (torch.optim steps, load_state_dict, p.copy_), not only
