@@ -69,35 +69,28 @@ __device__ __forceinline__ float gg_erf_sqrt2(float x) {
     return copysignf(fminf(p * u, 1.0f), x);
 }
 // ---- fp32 (reference-precision) activations ---------------------------------------------------------------------------------
-// erf to fp32 accuracy without libm: two branches, both evaluated, one select (tools/fit_erf.py: Chebyshev fits, every step rounded to
-// fp32 in the check).  |x| <= 0.92: x + x*P(x^2);  above: 1 - exp(-t*R(t)), t = min(|x|, 4) (erfc(4) = 1.5e-8 < half an ulp of 1).
-// Max error vs erf in double: 8.2e-8 absolute (1.4 ulp of 1), 9.9e-8 relative -- the same class as libm's erff, at 20 VALU
-// instructions and no divergent branch (libm erff + expf made the fp32 GELU' epilogues ~95 instructions per element).
-__device__ __forceinline__ float gg_erff(float x) {
-    const float t = fabsf(x), s = x * x;
-    float r = 8.33473605e-05f;
-    r = fmaf(r, s, -0.000813482853f);
-    r = fmaf(r, s, 0.00520039117f);
-    r = fmaf(r, s, -0.0268591661f);
-    r = fmaf(r, s, 0.11283692f);
-    r = fmaf(r, s, -0.376126349f);
-    r = fmaf(r, s, 0.128379166f);
-    const float lo = fmaf(r, x, x);
-    const float tt = fminf(t, 4.0f);
-    float q = -9.59732574e-07f;
-    q = fmaf(q, tt, 3.28280694e-05f);
-    q = fmaf(q, tt, -0.000487119221f);
-    q = fmaf(q, tt, 0.00425670343f);
-    q = fmaf(q, tt, -0.0250302516f);
-    q = fmaf(q, tt, 0.107709751f);
-    q = fmaf(q, tt, 0.634251595f);
-    q = fmaf(q, tt, 1.12887287f);
-    const float hi = copysignf(1.0f - __builtin_amdgcn_exp2f(q * tt * -1.4426950408889634f), x);
-    return t > 0.92f ? hi : lo;
+// GELU needs Phi(x) = 0.5 erfc(-x / sqrt2), not erf: h(t) = 0.5 erfc(t) = exp2(P(t)) for t = |x| / sqrt2 (clamped to 4.2: h(4.2) = 1.4e-9),
+// P a degree-9 polynomial fitted with weight h (tools/fit_phi.py; every step rounded to fp32 in the check), and Phi = x < 0 ? h : 1 - h.
+// One branch-free path, 9 FMAs + one v_exp_f32: max |error of Phi| 7.3e-8 (1.2 ulp of 1), and no cancellation on the negative side
+// (relative error of GELU 4e-6 where |GELU| > 1e-3; 0.5 (1 + erf) loses it there).  libm erff + expf cost ~95 instructions per GELU'.
+__device__ __forceinline__ float gg_phi_f32(float x) {
+    const float t = fminf(fabsf(x) * 0.70710678118654752f, 4.2f);
+    float p = 1.15539833e-05f;
+    p = fmaf(p, t, -0.000152371736f);
+    p = fmaf(p, t, 0.000845456321f);
+    p = fmaf(p, t, -0.00226795045f);
+    p = fmaf(p, t, 7.51803382e-05f);
+    p = fmaf(p, t, 0.0277323835f);
+    p = fmaf(p, t, -0.1483116f);
+    p = fmaf(p, t, -0.918442011f);
+    p = fmaf(p, t, -1.6279074f);
+    p = fmaf(p, t, -1.0f);
+    const float h = __builtin_amdgcn_exp2f(p);
+    return x < 0.f ? h : 1.0f - h;
 }
-__device__ __forceinline__ float gg_gelu_f32(float x) { return 0.5f * x * (1.0f + gg_erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gg_gelu_f32(float x) { return x * gg_phi_f32(x); }
 __device__ __forceinline__ float gg_gelu_grad_f32(float x) {       // Phi(x) + x * phi(x)
-    return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f), 0.5f * (1.0f + gg_erff(x * 0.70710678118654752f)));
+    return fmaf(x * 0.3989422804014327f, __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f), gg_phi_f32(x));
 }
 __device__ __forceinline__ float gg_act_f32(float x, int act) {
     if (act == 1 /* GG_ACT_GELU */) return gg_gelu_f32(x);

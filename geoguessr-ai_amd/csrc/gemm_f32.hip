@@ -45,7 +45,7 @@ __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float of
     return row * FBK + ((kc ^ ((row & 2) | ((row >> 1) & 4))) << 2);
 }
 
-// fp32 GELU family (common.h gg_erff: fp32-accurate, branch-free)
+// fp32 GELU family (common.h gg_phi_f32: fp32-accurate, branch-free)
 __device__ __forceinline__ float gelu_exact(float x) { return gg_gelu_f32(x); }
 __device__ __forceinline__ float gelu_grad_exact(float x) { return gg_gelu_grad_f32(x); }
 
