@@ -195,7 +195,7 @@ class SuperGuessr(nn.Module):
                  should_smooth_labels: bool = False, serving: bool = False, freeze_base: bool = False,
                  num_candidates: int = 5, embed_dim: int = CLIP_EMBED_DIM, centroids=None, precision: Optional[str] = None, **kwargs):
         """``centroids`` / ``precision`` are not in the reference: the geocell centroid table as data (C7/C8) and the arithmetic of
-        the head ("bf16" | "fp32"; default: the base model's, else ``$GG_PRECISION``, else bf16)."""
+        the head ("bf16" | "fp32"; default: the base model's, else ``$GG_PRECISION``, else fp32)."""
         super().__init__()
         from .tinyvit import PRECISIONS, default_precision
         bb_prec = getattr(getattr(base_model, "backbone", None), "precision", None)

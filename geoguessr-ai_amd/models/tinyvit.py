@@ -41,9 +41,9 @@ PRECISIONS = {"bf16": 0, "bfloat16": 0, "fp32": 1, "f32": 1, "float32": 1}
 
 
 def default_precision() -> str:
-    """``GG_PRECISION`` = "bf16" (default: bf16 activations / MFMA operands, fp32 accumulation and master weights) or "fp32" (the
-    reference's own arithmetic: f32 activations, f32 MFMA, exact erf -- SURVEY.md 0.3)."""
-    p = os.environ.get("GG_PRECISION", "bf16").lower()
+    """``GG_PRECISION`` = "fp32" (default: the reference's own arithmetic -- f32 activations, f32 MFMA, fp32-accurate GELU)
+    or "bf16" (bf16 activations / MFMA operands, fp32 accumulation and master weights: 3.4x the throughput, bf16-level parity)."""
+    p = os.environ.get("GG_PRECISION", "fp32").lower()
     if p not in PRECISIONS:
         raise ValueError(f"GG_PRECISION='{p}' (known: bf16, fp32)")
     return p
@@ -420,7 +420,7 @@ class TinyViTAdapter(nn.Module):
 
     def __init__(self, model_name: str = "tiny_vit_21m_512.dist_in22k_ft_in1k", pretrained: bool = True,
                  global_pool: str = "avg", features_only: bool = False, **overrides):
-        """``overrides`` (not in the reference): ``precision="bf16"|"fp32"`` (default ``$GG_PRECISION`` or bf16), ``seed``,
+        """``overrides`` (not in the reference): ``precision="bf16"|"fp32"`` (default ``$GG_PRECISION`` or fp32), ``seed``,
         ``drop_path_rate``, ``img_size`` ... (timm ``create_model`` kwargs)."""
         super().__init__()
         if global_pool != "avg":

@@ -13,6 +13,15 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["fp32", "bf16"])
+def _precision_mode(request, monkeypatch):
+    """Every model-level test of this file runs in both arithmetic modes (the modules read $GG_PRECISION when no precision= is given);
+    the tolerances written below are the bf16 ones, the fp32 mode meets them with orders of magnitude to spare (its own tight bounds:
+    tests/test_gpu_precision.py)."""
+    monkeypatch.setenv("GG_PRECISION", request.param)
+    yield request.param
+
+
 def _state_from(bb):
     return {k: v.detach().cpu().clone() for k, v in bb.state_dict().items()}
 
@@ -37,13 +46,23 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-@pytest.fixture(scope="module")
-def adapter5m():
+_ADAPTERS = {}
+
+
+@pytest.fixture
+def adapter5m(_precision_mode):
+    """One TinyViT-5M per arithmetic mode, shared by the tests of that mode (gradients of an earlier test are cleared)."""
     from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
-    torch.manual_seed(0)
-    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.1)
-    _randomize(m.backbone, 1)
-    return m.cuda()
+    if _precision_mode not in _ADAPTERS:
+        torch.manual_seed(0)
+        m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.1, precision=_precision_mode)
+        _randomize(m.backbone, 1)
+        _ADAPTERS[_precision_mode] = m.cuda()
+    m = _ADAPTERS[_precision_mode]
+    assert m.backbone.precision == _precision_mode
+    m.zero_grad(set_to_none=True)
+    m.backbone.flat_grads().zero_()
+    return m
 
 
 def test_state_dict_keys_match_timm_table(adapter5m):
