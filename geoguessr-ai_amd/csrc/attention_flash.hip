@@ -252,7 +252,9 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
 }
 
 // ------------------------------------------------------------------------------------------- backward, pass A: dQ
-template <typename T, int D, bool RES>
+// QS = query strips a wave works on at once: every K / V fragment read from LDS then feeds QS independent score / dP / dQ chains (QS = 2
+// in the resident form: half the LDS reads per MFMA and twice the independent MFMA work per wave).
+template <typename T, int D, bool RES, int QS = 1>
 __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashParams p) {
     constexpr int RS = D + 4, DC = D / 16;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
@@ -280,33 +282,38 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
         __syncthreads();
     }
     const int nstrips = (p.N + 15) >> 4;
-    for (int strip = RES ? wave : qt * 4 + wave; !RES || strip < nstrips; strip += (int)(blockDim.x >> 6)) {
-    const int qi = strip * 16 + lr;
-    const bool qok = qi < p.N;
-    const bool wave_on = strip * 16 < p.N;
-    const int64_t qtok = fl_token(p, origin, min(qi, p.N - 1));
-    f32x4 qf[DC], dof[DC];
-    float delta = 0.f;
-#pragma unroll
-    for (int c = 0; c < DC; ++c) {
-        qf[c] = dof[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (qok) {
-            qf[c] = Ld4<T>::load(qkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg);
-            dof[c] = Ld4<T>::load(dout + qtok * p.lddo + h * D + 16 * c + 4 * lg);
-            const f32x4 o = Ld4<T>::load(outp + qtok * p.ldo + h * D + 16 * c + 4 * lg);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) delta = fmaf(dof[c][s], o[s], delta);
-        }
-    }
-    delta += __shfl_xor(delta, 16, 64);
-    delta += __shfl_xor(delta, 32, 64);
-    const float lse2 = (qok ? p.lse[qtok * p.nh + h] : 0.f) * 1.4426950408889634f;
+    const int nwaves = (int)(blockDim.x >> 6);
     const float sc2 = p.scale * 1.4426950408889634f;
-    const int qq = min(qi, p.N - 1);
-    const int qlin = has_bias ? fl_lin4(p, qq) + 4 * (p.ws - 1) * 2 * p.ws : 0;       // + the table's centre (dy = dx = 0)
-    f32x4 dq[DC];
+    for (int strip0 = RES ? wave * QS : qt * 4 + wave; !RES || strip0 < nstrips; strip0 += nwaves * QS) {
+    bool qok[QS];
+    int64_t qtok[QS];
+    f32x4 qf[QS][DC], dof[QS][DC], dq[QS][DC];
+    float delta[QS], lse2[QS];
+    int qlin[QS];
 #pragma unroll
-    for (int c = 0; c < DC; ++c) dq[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < QS; ++u) {
+        const int qi = (strip0 + u) * 16 + lr;
+        qok[u] = qi < p.N;
+        qtok[u] = fl_token(p, origin, min(qi, p.N - 1));
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+            qf[u][c] = dof[u][c] = dq[u][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (qok[u]) {
+                qf[u][c] = Ld4<T>::load(qkv + qtok[u] * p.ld + p.q_off + hc + 16 * c + 4 * lg);
+                dof[u][c] = Ld4<T>::load(dout + qtok[u] * p.lddo + h * D + 16 * c + 4 * lg);
+                const f32x4 o = Ld4<T>::load(outp + qtok[u] * p.ldo + h * D + 16 * c + 4 * lg);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) d = fmaf(dof[u][c][s], o[s], d);
+            }
+        }
+        d += __shfl_xor(d, 16, 64);
+        d += __shfl_xor(d, 32, 64);
+        delta[u] = d;
+        lse2[u] = (qok[u] ? p.lse[qtok[u] * p.nh + h] : 0.f) * 1.4426950408889634f;
+        qlin[u] = has_bias ? fl_lin4(p, min(qi, p.N - 1)) + 4 * (p.ws - 1) * 2 * p.ws : 0;       // + the table's centre (dy = dx = 0)
+    }
+    const bool wave_on = strip0 * 16 < p.N;
 
     for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
         const int t0 = kt0 * 64;
@@ -325,48 +332,60 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             if (kt >= nsub) continue;
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st[QS], dp[QS];
+#pragma unroll
+            for (int u = 0; u < QS; ++u) st[u] = dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
                 const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[c][s], st, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], dof[c][s], dp, 0, 0, 0);
-                }
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int u = 0; u < QS; ++u) {
+                        st[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[u][c][s], st[u], 0, 0, 0);
+                        dp[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], dof[u][c][s], dp[u], 0, 0, 0);
+                    }
             }
-            // lane holds S^T / dP^T [key = t0 + 16kt + 4lg + r][q = lr]
-            f32x4 ds;
+            // lane holds S^T / dP^T [key = t0 + 16kt + 4lg + r][q = lr] of each strip
             const bool tail = t0 + 16 * kt + 15 >= p.N;        // wave-uniform: only the window's last sub-tile holds padded keys
-            f32x4 bia = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bia[QS];
+#pragma unroll
+            for (int u = 0; u < QS; ++u) bia[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (has_bias) {
                 const i32x4 kl4 = *reinterpret_cast<const i32x4*>(klt + 16 * kt + 4 * lg);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) bia[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(btab) + (qlin - kl4[r]));
+                for (int u = 0; u < QS; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bia[u][r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(btab) + (qlin[u] - kl4[r]));
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kl = 16 * kt + 4 * lg + r;
-                const float s = fmaf(st[r], sc2, bia[r]);
-                float pr = __builtin_amdgcn_exp2f(s - lse2);          // rows beyond N are never stored: no query mask needed in this pass
-                if (tail && t0 + kl >= p.N) pr = 0.f;
-                ds[r] = pr * (dp[r] - delta);                         // the softmax scale is applied once, to dQ
-            }
+            for (int u = 0; u < QS; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kl = 16 * kt + 4 * lg + r;
+                    const float s = fmaf(st[u][r], sc2, bia[u][r]);
+                    float pr = __builtin_amdgcn_exp2f(s - lse2[u]);      // rows beyond N are never stored: no query mask needed in this pass
+                    if (tail && t0 + kl >= p.N) pr = 0.f;
+                    st[u][r] = pr * (dp[u][r] - delta[u]);               // dS^T; the softmax scale is applied once, to dQ
+                }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
-                    const float kf = Kt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
-                    dq[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, ds[r], dq[c], 0, 0, 0);
+                    const float kfs = Kt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+#pragma unroll
+                    for (int u = 0; u < QS; ++u) dq[u][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfs, st[u][r], dq[u][c], 0, 0, 0);
                 }
         }
     }
-    if (qok) {
-        T* dqkv = reinterpret_cast<T*>(p.dqkv);
 #pragma unroll
-        for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[c] * p.scale);
-    }
+    for (int u = 0; u < QS; ++u)
+        if (qok[u]) {
+            T* dqkv = reinterpret_cast<T*>(p.dqkv);
+#pragma unroll
+            for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok[u] * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[u][c] * p.scale);
+        }
     if (!RES) break;
     }
 }
@@ -628,7 +647,8 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
             8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
 #define GG_FL_BWD2(T_, D_, R_)                                                                                \
     do {                                                                                                      \
-        hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_>), grid, block, lds_q, s, p);                      \
+        if (R_ && D_ == 32 && !getenv("GG_ATTN_DQ_QS1")) hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_, 2>), grid, dim3(64 * ((p.npad / 16 + 1) / 2)), lds_q, s, p); \
+        else hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_>), grid, block, lds_q, s, p);                 \
         if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true, R_>), grid, block, lds_kv, s, p); \
         else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false, R_>), grid, block, lds_kv, s, p);        \
     } while (0)
