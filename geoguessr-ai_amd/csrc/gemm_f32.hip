@@ -748,9 +748,16 @@ extern "C" int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_
 }
 extern "C" int gg_gemm_tn_f32_splits(int M, int N, int K) {
     const int64_t tiles = gg_cdiv(N, 128) * gg_cdiv(K, 128);
-    int64_t s = std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(1024, tiles), gg_cdiv(M, 512)));
-    const int64_t cap = ((int64_t)64 << 20) / ((int64_t)N * K * 4);        // 64 MiB of slabs at most
-    s = std::max<int64_t>(1, std::min<int64_t>(s, cap));
+    const int64_t cap = std::max<int64_t>(1, ((int64_t)128 << 20) / ((int64_t)N * K * 4));        // 128 MiB of slabs at most (scratch.splitk)
+    const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(cap, gg_cdiv(M, 512)));              // at least 512 rows per split
+    // fill whole rounds of the 768 resident workgroups (3 per CU): tiles * splits just below a multiple of 768 -- 90 tiles x 12 splits ran
+    // 1080 workgroups = 1.4 rounds (70 % of the second round idle); x 17 = 1530 = 1.99 rounds
+    int64_t s = 1;
+    double best = 0.0;
+    for (int64_t c = 1; c <= smax && c * tiles <= 4 * 768; ++c) {
+        const double eff = (double)(c * tiles) / (768.0 * (double)gg_cdiv(c * tiles, 768));
+        if (eff > best + 0.02) { best = eff; s = c; }
+    }
     if (N <= 64 && K <= 64 && M >= 4096) s = 4 * std::max<int64_t>(1, std::min<int64_t>(s, cap / 4));   // row-split form: 4 slabs (one per wave) per block
     return (int)s;
 }

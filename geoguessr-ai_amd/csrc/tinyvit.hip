@@ -313,7 +313,7 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         L.bnscratch = p.alloc("scratch.bn", std::max(bnsmax, dwmax), false);
         L.lnscratch = p.alloc("scratch.ln", lnsmax, false);
         L.colsum = p.alloc("scratch.colsum", std::max<int64_t>(csmax, 1024), false);
-        L.splitk = p.alloc("scratch.splitk", (int64_t)64 << 20, false);
+        L.splitk = p.alloc("scratch.splitk", (int64_t)128 << 20, false);      // gg_gemm_tn_f32_splits sizes its slabs against this
         int64_t fold = (int64_t)d[0] * 2 * mid;
         for (int s = 0; s < 3; ++s) fold = std::max(fold, (int64_t)(s == 0 ? d[0] : m.stages[s - 1].C) * 2 * m.stages[s].C);
         L.foldw = p.alloc("scratch.foldw", fold * es, false);
