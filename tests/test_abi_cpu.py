@@ -74,7 +74,7 @@ def test_tinyvit_table_matches_oracle_spec(L):
             assert L.lib().gg_tinyvit_workspace_bytes(C.byref(cfg), 2, 1) > 0
     # fp32 activations double the workspace and the weight cache
     c16, _, _ = make_cfg("tiny_vit_21m_224", precision="bf16"); c32, _, _ = make_cfg("tiny_vit_21m_224", precision="fp32")
-    assert L.lib().gg_tinyvit_workspace_bytes(C.byref(c32), 8, 1) > 1.8 * L.lib().gg_tinyvit_workspace_bytes(C.byref(c16), 8, 1)
+    assert L.lib().gg_tinyvit_workspace_bytes(C.byref(c32), 256, 1) > 1.9 * L.lib().gg_tinyvit_workspace_bytes(C.byref(c16), 256, 1)     # activation-dominated size
     bad, _, _ = make_cfg("tiny_vit_21m_224"); bad.act_dtype = 7
     assert L.lib().gg_tinyvit_num_tensors(C.byref(bad)) < 0 and b"act_dtype" in L.lib().gg_last_error()
 
