@@ -5,13 +5,15 @@ geocells, reference freeze policy ``freeze_all_but_last_stage``, DropPath 0.2, b
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...        (no launcher: starts the line above as a child process and relays its JSON line; exits non-zero
+                                         when the machine has fewer than N GPUs -- it never reports an N-GPU number from fewer ranks)
 
 One process per GPU; ranks shard the global batch (weak scaling: 256 panoramas per GPU), start from rank 0's parameters (broadcast) and
 exchange only gradients (sum all-reduce over RCCL, launched bucket by bucket while the backward pass is still running; the average
 is folded into the AdamW kernel).  Inputs are synthetic and resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 PRECISION.  The reference computes this path in fp32 (torch defaults), so the headline ``value`` / ``dtype`` of the line
-are measured in the fp32 reference-precision mode (f32 activations, ``v_mfma_f32_16x16x4_f32``, exact erf).  The bf16 mode (bf16
+are measured in the fp32 reference-precision mode (f32 activations, ``v_mfma_f32_16x16x4_f32``, erf GELU through a 1.2-ulp fp32 Phi).  The bf16 mode (bf16
 activations / MFMA operands, fp32 accumulation and master weights -- the mode a production run would use) is measured in the same
 invocation with the same protocol (W warm-up steps, exactly K timed steps between barrier + synchronize) and reported under
 ``"bf16"``.  ``--precision fp32|bf16`` runs one mode only (then ``value`` is that mode's).
@@ -110,6 +112,66 @@ def pmc_traffic(precision):
     return None
 
 
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` (N > 1) without a launcher in front: start the driver's own launch line
+    (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``) as a CHILD
+    process, relay rank 0's JSON line and return the child's exit code.  This process never initialises the GPU (counting devices does not),
+    and it is a fork + wait, not an exec.  Fails loudly when the box has fewer than N GPUs -- an N-GPU number must come from N devices."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus and not os.environ.get("GG_BENCH_ONE_DEVICE"):
+        print(f"bench.py: --gpus {args.gpus} requested but this machine exposes {have} GPU(s); refusing to report an {args.gpus}-GPU number "
+              f"from fewer devices (GG_BENCH_ONE_DEVICE=1 GG_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    lines = 0
+    for line in proc.stdout:                 # rank 0 prints exactly one JSON line; anything else on stdout goes to our stderr
+        if line.startswith("{") and '"metric"' in line:
+            sys.stdout.write(line); sys.stdout.flush(); lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the {args.gpus}-rank run printed {lines} result lines instead of 1", file=sys.stderr)
+        return 3
+    return rc
+
+
+def allreduce_cost(opt, dev, world, reps=5):
+    """What the step's gradient exchange costs when nothing hides it: the same buckets (flat trainable ranges + the head's weight / bias),
+    summed in place ``reps`` times between device synchronisations on scratch copies.  In the timed step these all-reduces ride under the
+    backward pass (bucket launch from the stage callback), so this is an upper bound of their exposed share."""
+    import torch
+    import torch.distributed as dist
+    bufs = [torch.zeros_like(t) for t in opt.grad_buffers()]
+    nbytes = sum(b.numel() * b.element_size() for b in bufs)
+    for b in bufs:
+        dist.all_reduce(b)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for b in bufs:
+            dist.all_reduce(b)
+    torch.cuda.synchronize(dev)
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    t = torch.tensor([ms], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    # ring all-reduce moves 2 (n-1)/n of the payload per rank
+    return dict(allreduce_ms_per_step=round(ms, 3), allreduce_bytes_per_step=nbytes, allreduce_buckets=len(bufs),
+                allreduce_busbw_gbps=round(2 * (world - 1) / world * nbytes / max(ms, 1e-9) / 1e6, 1))
+
+
 def run_mode(precision, args, rank, world, dev, x, lab):
     """W warm-up steps, exactly K timed steps (barrier + synchronize on both sides, max over ranks), then an instrumented replay."""
     import torch
@@ -157,6 +219,8 @@ def run_mode(precision, args, rank, world, dev, x, lab):
     loss = float(out.loss.detach())
     images = args.steps * N * 4 * world
     res = dict(value=round(images / dt, 2), ms_per_step=round(1e3 * dt / args.steps, 3), loss=round(loss, 5))
+    if world > 1:
+        res.update(allreduce_cost(opt, dev, world))
 
     if not args.no_roofline:
         lib = L.lib()
@@ -230,6 +294,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # `python bench.py --gpus N`: become the launcher, BEFORE anything here touches the GPU
+
     import torch
     import torch.distributed as dist
     from geoguessr_ai_amd import _lib as L
@@ -237,6 +304,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; launch with "
+                 f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}` "
+                 f"(or run `python bench.py --gpus {args.gpus}` and let it start the ranks itself)")
     L.require_gpu()
     backend = os.environ.get("GG_DIST_BACKEND", "nccl")          # "gloo" + GG_BENCH_ONE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box
     if os.environ.get("GG_BENCH_ONE_DEVICE"):
@@ -249,7 +320,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rccl_ranks = 1
+    if world > 1:      # prove the transport before timing anything: every rank contributes 1 to a sum all-reduce on the device
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
+        if rccl_ranks != args.gpus:
+            sys.exit(f"bench.py: the all-reduce summed {rccl_ranks} ranks, --gpus says {args.gpus}")
 
     N = args.panoramas
     g = torch.Generator(device=dev).manual_seed(1234 + rank)              # SURVEY.md 8(d) synthetic inputs
@@ -272,6 +349,9 @@ def main():
                                          f"{'all params' if args.unfrozen else 'freeze_all_but_last_stage'}, DropPath, train-mode BN",
                                 panoramas_per_gpu=N, images_per_gpu=N * 4, global_batch_panoramas=N * world, parallelism=f"dp{world}",
                                 precision=modes[0]),
+                    rccl_ranks=rccl_ranks, comm_backend=(backend if world > 1 else None),
+                    allreduce_ms_per_step=head.get("allreduce_ms_per_step"), allreduce_bytes_per_step=head.get("allreduce_bytes_per_step"),
+                    allreduce_busbw_gbps=head.get("allreduce_busbw_gbps"),
                     step_tflops=head["step_tflops"], step_frac_of_mfma_peak=head["step_frac_of_mfma_peak"], loss=head["loss"],
                     roofline=head.get("roofline"), cpu_baseline=cpu, kernel_breakdown=head.get("kernel_breakdown"))
         for m in modes[1:]:

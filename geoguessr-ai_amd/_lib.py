@@ -158,6 +158,7 @@ SIGNATURES = {
     "gg_mha_q0_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "gg_proto_refine": (_I, [C.POINTER(ProtoRefineArgs), _P]),
     "gg_geoguessr_score": (_I, [_P, _P, _I, _P, _P, _P]),      # (pred, truth, N, double* dist_km, int32* score, stream)
+    "gg_geoguessr_score_f64": (_I, [_P, _P, _I, _P, _P, _P]),  # same with double* coordinates
     "gg_adamw_step": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _F, _F, _P]),
     "gg_fill_f32": (_I, [_P, _L, _F, _P]),
     "gg_comm_unique_id": (_I, [_P]),
@@ -180,6 +181,8 @@ SIGNATURES = {
     "gg_tinyvit_buffer_floats": (_L, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_num_counters": (_I, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_num_drop_slots": (_I, [C.POINTER(TinyVitCfg)]),
+    "gg_drop_path_scales": (_I, [_P, _I, _I, C.c_uint64, C.c_uint64, _P, _P]),
+    "gg_transpose_f32": (_I, [_P, _I, _I, _P, _L, _P]),
     "gg_tinyvit_wcache_bytes": (_L, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_workspace_bytes": (_L, [C.POINTER(TinyVitCfg), _I, _I]),
     "gg_tinyvit_refresh_weights": (_I, [C.POINTER(TinyVitCfg), _P, _P, _P]),

@@ -37,6 +37,13 @@ int load_api() {
     GG_SYM(GetUniqueId, "ncclGetUniqueId") GG_SYM(CommInitRank, "ncclCommInitRank") GG_SYM(CommDestroy, "ncclCommDestroy")
     GG_SYM(AllReduce, "ncclAllReduce") GG_SYM(Broadcast, "ncclBroadcast") GG_SYM(GetErrorString, "ncclGetErrorString")
 #undef GG_SYM
+    // the enum values above are those of the NCCL 2.x ABI (ncclFloat = 7 since 2.0; RCCL keeps NCCL's numbering): refuse anything else
+    int (*get_version)(int*) = reinterpret_cast<int (*)(int*)>(dlsym(h, "ncclGetVersion"));
+    int ver = 0;
+    if (!get_version || get_version(&ver) != 0 || ver < 2000 || ver >= 30000) {
+        gg_set_error("gg_comm: RCCL reports NCCL API version %d; this binding is written against the 2.x ABI", ver);
+        return -1;
+    }
     g_api.ok = true;
     return 0;
 }
@@ -67,7 +74,9 @@ extern "C" int gg_comm_create(gg_comm** out, const void* unique_id128, int rank,
     gg_comm* c = new gg_comm{nullptr, rank, world, device, nullptr};
     int r = g_api.CommInitRank(&c->comm, world, id, rank);
     if (r != 0) { gg_set_error("ncclCommInitRank failed: %s", g_api.GetErrorString(r)); delete c; return -4; }
-    if (hipMalloc(reinterpret_cast<void**>(&c->scratch), 256) != hipSuccess) { gg_set_error("gg_comm_create: hipMalloc failed"); g_api.CommDestroy(c->comm); delete c; return -2; }
+    if (hipMalloc(reinterpret_cast<void**>(&c->scratch), 256) != hipSuccess || hipMemset(c->scratch, 0, 256) != hipSuccess) {   // the barrier sums this word: zeros, not garbage
+        gg_set_error("gg_comm_create: hipMalloc / hipMemset failed"); g_api.CommDestroy(c->comm); delete c; return -2;
+    }
     *out = c;
     return 0;
 }

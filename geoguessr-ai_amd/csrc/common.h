@@ -69,12 +69,13 @@ __device__ __forceinline__ float gg_erf_sqrt2(float x) {
     return copysignf(fminf(p * u, 1.0f), x);
 }
 // ---- fp32 (reference-precision) activations ---------------------------------------------------------------------------------
-// GELU needs Phi(x) = 0.5 erfc(-x / sqrt2), not erf: h(t) = 0.5 erfc(t) = exp2(P(t)) for t = |x| / sqrt2 (clamped to 4.2: h(4.2) = 1.4e-9),
+// GELU needs Phi(x) = 0.5 erfc(-x / sqrt2), not erf: h(t) = 0.5 erfc(t) = exp2(P(t)) for t = |x| / sqrt2 <= 4.2 (h(4.2) = 1.4e-9; continued linearly in the exponent beyond),
 // P a degree-9 polynomial fitted with weight h (tools/fit_phi.py; every step rounded to fp32 in the check), and Phi = x < 0 ? h : 1 - h.
 // One branch-free path, 9 FMAs + one v_exp_f32: max |error of Phi| 7.3e-8 (1.2 ulp of 1), and no cancellation on the negative side
 // (relative error of GELU 4e-6 where |GELU| > 1e-3; 0.5 (1 + erf) loses it there).  libm erff + expf cost ~95 instructions per GELU'.
 __device__ __forceinline__ float gg_phi_f32(float x) {
-    const float t = fminf(fabsf(x) * 0.70710678118654752f, 4.2f);
+    const float tu = fabsf(x) * 0.70710678118654752f;
+    const float t = fminf(tu, 4.2f);
     float p = 1.15539833e-05f;
     p = fmaf(p, t, -0.000152371736f);
     p = fmaf(p, t, 0.000845456321f);
@@ -85,6 +86,7 @@ __device__ __forceinline__ float gg_phi_f32(float x) {
     p = fmaf(p, t, -0.918442011f);
     p = fmaf(p, t, -1.6279074f);
     p = fmaf(p, t, -1.0f);
+    p = fmaf(tu - t, -12.2f, p);          // beyond the fit range: keep falling at the slope log2 h has at 4.2, so Phi(x) -> 0 (and x Phi(x) -> 0) for x -> -inf
     const float h = __builtin_amdgcn_exp2f(p);
     return x < 0.f ? h : 1.0f - h;
 }

@@ -899,6 +899,30 @@ extern "C" int gg_cast_transpose_f32(const float* in, int R, int C, void* out, i
     GG_LAUNCH_CHECK();
     return 0;
 }
+// f32 [R, C] -> f32 [C, ldt] (ldt >= R; columns R..ldt-1 of the output are left as they are): the f32 head weight's transposed copy
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ outT, int64_t ldt) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? in[(int64_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) outT[(int64_t)c * ldt + r] = tile[tx][i];
+    }
+}
+extern "C" int gg_transpose_f32(const float* in, int R, int C, float* outT, int64_t ldt, void* stream) {
+    GG_CHECK(in && outT && R > 0 && C > 0 && ldt >= R, "gg_transpose_f32: bad args");
+    GG_PROF(GG_CAT_MOVE, 0, 8.0 * R * C, stream);
+    dim3 grid((unsigned)gg_cdiv(C, 64), (unsigned)gg_cdiv(R, 64));
+    GG_CHECK(grid.y <= 65535u, "gg_transpose_f32: too many rows");
+    hipLaunchKernelGGL(transpose_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, R, C, outT, ldt);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gg_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
     GG_CHECK(in && out && n > 0, "gg_cast_f32_to_bf16: bad args");
     int blocks = (int)std::min<int64_t>(gg_cdiv(n, 256), 8192);

@@ -261,7 +261,11 @@ __global__ __launch_bounds__(64) void proto_refine_kernel(const float* __restric
 // ---------------------------------------------------------------------------- scoring (run_benchmark.py:25-65), fp64 + int32
 // haversine_np: numpy float64 on (lon, lat) degrees, R = 6 371 000 m (quirk C5: not the loss's 6 378 137 m).
 // geoguessr_score_from_distance: int(round(clamp(5000*exp(-d/1492.7), 0, 5000))); Python round() = half-to-even = rint().
-__global__ void score_kernel(const float* __restrict__ pred, const float* __restrict__ truth, int N, double* __restrict__ dist_km,
+// Coordinates arrive as f32 or f64 (T): the reference's arrays are float64, and a metre can flip a rounded score, so f64 inputs are NOT
+// narrowed.  Near-exact antipodes can round a above 1 (asin -> NaN, on which the reference's int(round()) raises): a is clamped to 1;
+// a non-finite distance (NaN / inf coordinates) gives the sentinel score -1 instead of an undefined float -> int conversion.
+template <typename T>
+__global__ void score_kernel(const T* __restrict__ pred, const T* __restrict__ truth, int N, double* __restrict__ dist_km,
                              int32_t* __restrict__ score) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
@@ -269,10 +273,11 @@ __global__ void score_kernel(const float* __restrict__ pred, const float* __rest
     const double lon1 = (double)pred[2 * i] * d2r, lat1 = (double)pred[2 * i + 1] * d2r;
     const double lon2 = (double)truth[2 * i] * d2r, lat2 = (double)truth[2 * i + 1] * d2r;
     const double sa = sin((lat2 - lat1) / 2.0), sb = sin((lon2 - lon1) / 2.0);
-    const double a = sa * sa + cos(lat1) * cos(lat2) * (sb * sb);
+    const double a = fmin(sa * sa + cos(lat1) * cos(lat2) * (sb * sb), 1.0);
     const double c = 2.0 * asin(sqrt(a));
     double km = (6371000.0 * c) / 1000.0;
     if (dist_km) dist_km[i] = km;
+    if (!(fabs(km) <= 1.0e300)) { score[i] = -1; return; }
     if (km < 0.0) km = 0.0;
     double pts = 5000.0 * exp(-(km / 1492.7));
     pts = fmax(0.0, fmin(5000.0, pts));
@@ -419,7 +424,13 @@ extern "C" int gg_proto_refine(const GgProtoRefineArgs* a, void* stream) {
 }
 extern "C" int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, double* dist_km, int32_t* score, void* stream) {
     GG_CHECK(pred_llh && true_llh && score && N > 0, "gg_geoguessr_score: bad args");
-    hipLaunchKernelGGL(score_kernel, dim3((unsigned)gg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred_llh, true_llh, N, dist_km, score);
+    hipLaunchKernelGGL(score_kernel<float>, dim3((unsigned)gg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred_llh, true_llh, N, dist_km, score);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_geoguessr_score_f64(const double* pred_llh, const double* true_llh, int N, double* dist_km, int32_t* score, void* stream) {
+    GG_CHECK(pred_llh && true_llh && score && N > 0, "gg_geoguessr_score_f64: bad args");
+    hipLaunchKernelGGL(score_kernel<double>, dim3((unsigned)gg_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, pred_llh, true_llh, N, dist_km, score);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -892,3 +892,29 @@ extern "C" int gg_view_mean_bwd_f32(const float* dmean, int64_t ld, float* demb,
     GG_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------- DropPath keep/scale rows (timm DropPath, scale_by_keep)
+// out[s][b] = Bernoulli(1 - rate[s]) / (1 - rate[s]) per (slot, sample): what timm's drop_path draws with x.new_empty(...).bernoulli_(keep)
+// / keep (models/tinyvit.py:135 is the call site).  Counter-based generator (two rounds of the splitmix64 finaliser over
+// (seed, call counter, element index)): any launch shape gives the same stream, nothing is kept on the device between calls.
+__device__ __forceinline__ uint64_t gg_mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void drop_path_scales_kernel(const float* __restrict__ rates, int slots, int batch, uint64_t seed, uint64_t counter,
+                                        float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots * batch) return;
+    const float keep = 1.0f - rates[i / batch];
+    const uint64_t r = gg_mix64(gg_mix64(seed + 0x9E3779B97F4A7C15ull * (counter + 1)) ^ (uint64_t)i * 0xD1342543DE82EF95ull);
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);          // 24 uniform bits in [0, 1)
+    out[i] = (keep >= 1.0f) ? 1.0f : (u < keep ? 1.0f / keep : 0.0f);
+}
+extern "C" int gg_drop_path_scales(const float* rates, int slots, int batch, uint64_t seed, uint64_t counter, float* out, void* stream) {
+    GG_CHECK(rates && out && slots > 0 && batch > 0, "gg_drop_path_scales: bad args");
+    hipLaunchKernelGGL(drop_path_scales_kernel, dim3((unsigned)gg_cdiv((int64_t)slots * batch, 256)), dim3(256), 0, (hipStream_t)stream, rates,
+                       slots, batch, seed, counter, out);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

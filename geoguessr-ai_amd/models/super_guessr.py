@@ -233,52 +233,55 @@ class SuperGuessr(nn.Module):
         self._freeze_params()
         print(f"Initialized SuperGuessr classification model with {self.num_cells} geocells.")
 
-    # ---- reference helpers -----------------------------------------------------------------------------
+    # ---- reference helpers (behaviour of models/super_guessr.py:113-150,240-245,385-395; own text) -------------------------
     def _set_hidden_size(self):
-        if self.base_model is not None:
-            try:
-                self.hidden_size = self.base_model.config.hidden_size
-                self.mode = "transformer"
-            except AttributeError:
-                self.hidden_size = self.base_model.config.hidden_sizes[-1]
-                self.mode = "convnext"
-
-    def _freeze_params(self):
+        """Embedding width and ``mode`` from the base model's config: ``config.hidden_size`` -> "transformer" (CLIP, TinyViT adapter), else
+        the last entry of ``config.hidden_sizes`` -> "convnext".  No base model: ``embed_dim`` stands."""
+        cfg = getattr(self.base_model, "config", None)
         if self.base_model is None:
             return
-        name = getattr(self.base_model.config, "_name_or_path", "")
+        if hasattr(cfg, "hidden_size"):
+            self.hidden_size, self.mode = cfg.hidden_size, "transformer"
+        else:
+            self.hidden_size, self.mode = cfg.hidden_sizes[-1], "convnext"       # AttributeError here = not a usable base model (as upstream)
+
+    def _freeze_params(self):
+        """Training policy by base-model family: ``freeze_base`` freezes the whole encoder; a CLIP tower that is not serving loads the
+        pretrained head when the file exists and then trains only its LAST encoder layer (without the file: warning, nothing frozen); a TinyViT
+        that is not serving keeps patch_embed + last stage + head trainable (``freeze_all_but_last_stage``)."""
+        base = self.base_model
+        if base is None:
+            return
+        family = getattr(base.config, "_name_or_path", "")
         if self.freeze_base:
-            for p in self.base_model.parameters():
+            for p in base.parameters():
                 p.requires_grad = False
-        elif "clip-vit" in name and not self.serving:
-            head = CLIP_PRETRAINED_HEAD
-            if os.path.exists(head):
-                self.load_state(head)
-                print(f"Initialized model parameters from model: {head}")
-                for m in self.base_model.vision_model.encoder.layers[:-1]:
-                    for p in m.parameters():
-                        p.requires_grad = False
-            else:
-                print(f"Warning: pretrained head not found at '{head}'. Proceeding without loading and without freezing base layers.")
-        elif "tiny" in name and not self.serving:
-            self.base_model.freeze_all_but_last_stage()
+            return
+        if self.serving:
+            return
+        if "clip-vit" in family:
+            if not os.path.exists(CLIP_PRETRAINED_HEAD):
+                print(f"Warning: pretrained head not found at '{CLIP_PRETRAINED_HEAD}'. Proceeding without loading and without freezing base layers.")
+                return
+            self.load_state(CLIP_PRETRAINED_HEAD)
+            print(f"Initialized model parameters from model: {CLIP_PRETRAINED_HEAD}")
+            for layer in list(base.vision_model.encoder.layers)[:-1]:
+                for p in layer.parameters():
+                    p.requires_grad = False
+        elif "tiny" in family:
+            base.freeze_all_but_last_stage()
 
     def load_state(self, path: str):
-        own_state = self.state_dict()
-        state_dict = torch.load(path, map_location="cuda" if torch.cuda.is_available() else "cpu")
-        for name, param in state_dict.items():
-            if name not in own_state:
-                print(f"Parameter {name} not in model's state.")
-                continue
-            if isinstance(param, Parameter):
-                param = param.data
-            own_state[name].copy_(param)
+        """Copy every tensor of the checkpoint at ``path`` whose name this model has; the others are reported and skipped (the tolerant loader
+        of models/utils.py, on the device the model will run on)."""
+        from .utils import load_state_dict
+        load_state_dict(self, torch.load(path, map_location="cuda" if torch.cuda.is_available() else "cpu"))
 
     def _assert_requirements(self, pixel_values=None, embedding=None):
-        if self.base_model is not None:
-            assert pixel_values is not None, 'Parameter "pixel_values" must be supplied if model has a base model.'
-        else:
-            assert embedding is not None, 'Parameter "embedding" must be supplied if model does not have a base model.'
+        have_base = self.base_model is not None
+        given, name = (pixel_values, "pixel_values") if have_base else (embedding, "embedding")
+        assert given is not None, (f'Parameter "{name}" must be supplied if model has a base model.' if have_base else
+                                   f'Parameter "{name}" must be supplied if model does not have a base model.')
 
     # ---- bf16 copies of the head weight: Wn (K, C) for the forward GEMM, Wt (C, Kpad) for dgrad --------------
     def _weight_cache(self):
@@ -304,7 +307,8 @@ class SuperGuessr(nn.Module):
             Kp = (K + 7) // 8 * 8
             if getattr(self, "_wt32", None) is None or self._wt32.device != w.device:
                 self._wt32 = torch.zeros((Cc, Kp), dtype=torch.float32, device=w.device)
-            self._wt32[:, :K].copy_(w.detach().t())         # device-side strided copy (data movement only)
+            L.check(L.lib().gg_transpose_f32(L.ptr(w.detach(), torch.float32, "cell_layer.weight"), K, Cc, L.ptr(self._wt32), Kp, L.stream()),
+                    "gg_transpose_f32")                       # pad columns K..Kp-1 stay zero
             self._wt32_version, self._wc_dirty = ver, False
         return self._wt32
 
@@ -371,15 +375,9 @@ class SuperGuessr(nn.Module):
         return ModelOutput(loss, loss, llh, preds, topk, embedding)
 
     def __str__(self):
-        rep = "SuperGuessr(\n"
-        rep += f"\tbase_model\t= {self.base_model is not None}\n"
-        rep += f"\tpanorama\t= {self.panorama}\n"
-        rep += f"\thierarchical\t= {self.hierarchical}\n"
-        rep += f"\tembedding_size\t= {self.hidden_size}\n"
-        rep += f"\tinput_dim\t= {self.input_dim}\n"
-        rep += f"\tnum_geocells\t= {self.num_cells}\n"
-        rep += f"\tlabel_smoothing\t= {self.should_smooth_labels}\n"
-        rep += f"\tfreeze_base\t= {self.freeze_base}\n"
-        rep += f"\tserving\t\t= {self.serving}\n"
-        rep += ")"
-        return rep
+        rows = [("base_model", self.base_model is not None), ("panorama", self.panorama), ("hierarchical", self.hierarchical),
+                ("embedding_size", self.hidden_size), ("input_dim", self.input_dim), ("num_geocells", self.num_cells),
+                ("label_smoothing", self.should_smooth_labels), ("freeze_base", self.freeze_base), ("serving", self.serving)]
+        # one tab after the name, two after the one name shorter than a tab stop (the reference's layout)
+        body = "".join(f"\t{k}{chr(9) * (2 if len(k) < 8 else 1)}= {v}\n" for k, v in rows)
+        return f"SuperGuessr(\n{body})"

@@ -292,14 +292,25 @@ class TinyVitBackbone(_Tree):
         return ws
 
     def make_drop_scales(self, batch: int, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
-        """timm DropPath (scale_by_keep): per-sample Bernoulli(1-p)/(1-p), one row per slot."""
+        """timm DropPath (scale_by_keep): per-sample Bernoulli(1-p)/(1-p), one row per slot, drawn by ``gg_drop_path_scales`` (a counter-based
+        generator on the device).  The seed comes from torch's RNG once per backbone (so ``torch.manual_seed`` makes runs repeatable), the counter
+        advances with every call; ``generator`` re-seeds from that generator instead."""
         if max(self.drop_rates) <= 0:
             return None
-        keep = getattr(self, "_keep_dev", None)
-        if keep is None or keep.device != self._flat.device:          # cached on the device: no host-to-device copy per step (graph-capturable)
-            keep = self._keep_dev = 1.0 - torch.tensor(self.drop_rates, device=self._flat.device).unsqueeze(1)
-        u = torch.rand((self.num_drop_slots, batch), device=self._flat.device, generator=generator)
-        return ((u < keep).to(torch.float32) / keep).contiguous()
+        dev = self._flat.device
+        rates = getattr(self, "_rates_dev", None)
+        if rates is None or rates.device != dev:          # cached on the device: no host-to-device copy per step (graph-capturable)
+            rates = self._rates_dev = torch.tensor(self.drop_rates, dtype=torch.float32, device=dev)
+        if generator is not None:
+            seed, counter = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item()), 0
+        else:
+            if getattr(self, "_drop_seed", None) is None:
+                self._drop_seed, self._drop_counter = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+            seed, counter = self._drop_seed, self._drop_counter
+            self._drop_counter += 1
+        out = torch.empty((self.num_drop_slots, batch), dtype=torch.float32, device=dev)
+        L.check(L.lib().gg_drop_path_scales(L.ptr(rates), self.num_drop_slots, batch, seed, counter, L.ptr(out), L.stream()), "gg_drop_path_scales")
+        return out
 
     def forward_hip(self, x: torch.Tensor, training: bool, drop_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
         L.require_gpu()
@@ -362,12 +373,27 @@ class TinyVitBackbone(_Tree):
                                 " ...: the training forward fused away activations their weight gradients need; run the forward again")
         hook = self._grad_ready_hook
         cb = L.STAGE_DONE_FN(0)
+        failed = []
         if hook is not None:
             rng = self._stage_ranges()
-            cb = L.STAGE_DONE_FN(lambda stage, _user: hook(*rng[stage]))
+
+            def _stage_done(stage, _user):
+                # ctypes swallows an exception raised inside a callback (it only prints "Exception ignored ..."), and a rank that skips one
+                # bucket would then launch its collectives in another order than its peers: keep the first failure, send nothing further
+                # from inside this backward (allreduce_grads() sends whatever is left in one fixed order) and re-raise below
+                if failed:
+                    return
+                try:
+                    hook(*rng[stage])
+                except BaseException as exc:      # noqa: BLE001 -- must not escape into the C caller
+                    failed.append(exc)
+            cb = L.STAGE_DONE_FN(_stage_done)
         L.check(L.lib().gg_tinyvit_backward(C.byref(self.cfg), B, L.ptr(self._flat), L.ptr(self._wcache), L.ptr(drop), L.ptr(ws),
                                             L.ptr(d_out.contiguous(), torch.float32, "d_out"), L.ptr(fg), mask, L.stream(), cb, None),
                 "gg_tinyvit_backward")
+        if failed:
+            raise L.GgError(f"TinyViT backward: the gradient-ready hook failed ({type(failed[0]).__name__}: {failed[0]}); the gradients are "
+                            "complete, but no further bucket was sent from inside this backward pass") from failed[0]
 
     def activation(self, name: str, batch: int) -> torch.Tensor:
         """Raw bytes of a saved activation of the last training forward (parity tests)."""

@@ -34,17 +34,18 @@ def smooth_labels(distances: Tensor) -> Tensor:
 
 
 def load_state_dict(self, state_dict: Dict, embedder: bool = False):
-    """Loads parameters wherever names match (models/utils.py:74-95)."""
-    own_state = self.state_dict()
-    for name, param in state_dict.items():
-        if embedder and "base_model" in name:
-            name = ".".join(name.split(".")[1:])
-        if name not in own_state:
-            print(f"Parameter {name} not in model's state.")
-            continue
-        if isinstance(param, Parameter):
-            param = param.data
-        own_state[name].copy_(param)
+    """Tolerant loader with the behaviour of models/utils.py:74-95: every entry whose name exists in ``self.state_dict()`` is copied in place
+    (a serialized ``Parameter`` contributes its ``.data``), every other entry is reported with the reference's message and skipped.  With
+    ``embedder=True`` names containing ``base_model`` lose their first dotted component before the lookup."""
+    targets = self.state_dict()
+    for key, value in state_dict.items():
+        if embedder and "base_model" in key:
+            key = key.partition(".")[2]
+        dst = targets.get(key)
+        if dst is None:
+            print(f"Parameter {key} not in model's state.")
+        else:
+            dst.copy_(value.data if isinstance(value, Parameter) else value)
 
 
 PredictionOutput = namedtuple("PredictionOutput", "predictions label_ids metrics")
@@ -95,46 +96,51 @@ class ProtoDataManager:
         self.geocell_indices = self._make_geocell_indices_list()
 
     @staticmethod
-    def _parse_indices_value(indices_val) -> List[int]:
-        """list / tuple, NaN, "", "[1, 2]", "(1, 2)", "1, 2", "7" or a bare number -> list[int]; entries that are not integers are
-        dropped (:118-154)."""
+    def _as_int(item):
+        """int(item), retried on the stripped text form; None when neither converts (such entries are dropped, :146-153)."""
+        for form in (item, str(item).strip()):
+            try:
+                return int(form)
+            except Exception:
+                pass
+        return None
+
+    @classmethod
+    def _parse_indices_value(cls, indices_val) -> List[int]:
+        """One cell of the ``indices`` column -> list[int] (behaviour of models/utils.py:118-154, pinned by tests/golden/proto_manager.json):
+        sequences are taken item by item; NaN / None / "" give []; text is read as a Python literal ("[1, 2]", "(1, 2)", "7") and, when that
+        fails ("1, 2", "[3, x, 4]"), split on commas inside its outermost brackets; any other scalar is a one-item list."""
         if isinstance(indices_val, (list, tuple)):
-            cand = list(indices_val)
-        elif not isinstance(indices_val, str) and pd.isna(indices_val):
-            cand = []
+            items = indices_val
         elif isinstance(indices_val, str):
             text = indices_val.strip()
-            if text == "":
-                cand = []
+            if not text:
+                items = ()
             else:
                 try:
-                    obj = ast.literal_eval(text)
+                    literal = ast.literal_eval(text)
+                    items = literal if isinstance(literal, (list, tuple)) else (literal,)
                 except Exception:
-                    obj = [part for part in text.strip("[](){}").split(",") if part != ""]
-                cand = list(obj) if isinstance(obj, (list, tuple)) else [obj]
+                    items = [tok for tok in text.strip("[](){}").split(",") if tok]
+        elif pd.isna(indices_val):
+            items = ()
         else:
-            cand = [indices_val]
-        out: List[int] = []
-        for x in cand:
-            try:
-                out.append(int(x))
-            except Exception:
-                try:
-                    out.append(int(str(x).strip()))
-                except Exception:
-                    continue
-        return out
+            items = (indices_val,)
+        return [v for v in map(cls._as_int, items) if v is not None]
 
     def _make_geocell_indices_list(self) -> Dict[int, pd.DataFrame]:
-        if "geocell_index" not in self.proto_df.columns:
+        """geocell id -> its rows of ``proto_df`` (re-indexed from 0), {} when the table has no ``geocell_index`` column (:156-168)."""
+        if "geocell_index" not in self.proto_df:
             return {}
-        return {int(cell): grp.reset_index(drop=True) for cell, grp in self.proto_df.groupby("geocell_index")}
+        groups = self.proto_df.groupby("geocell_index").groups          # id -> row labels, in file order
+        return {int(cell): self.proto_df.loc[rows].reset_index(drop=True) for cell, rows in groups.items()}
 
     def get_indices_for_cell(self, cell_id: int) -> pd.DataFrame:
-        df = self.geocell_indices.get(cell_id, None)
-        if df is None:
+        """Rows of one geocell; an empty frame with the table's columns for an unknown id (:170-181)."""
+        try:
+            return self.geocell_indices[cell_id]
+        except KeyError:
             return pd.DataFrame(columns=list(self.proto_df.columns))
-        return df
 
     # ---- flat views for the device-side prototype table (not in the reference) -------------------------------------------
     def cluster_table(self):

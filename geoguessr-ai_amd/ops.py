@@ -598,12 +598,18 @@ def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_de
 
 
 def geoguessr_score(pred_llh, true_llh):
-    """run_benchmark.py:25-65 for a batch: (distance_km float64 (N,), score int32 (N,)) -- haversine_np + geoguessr_score_from_distance."""
+    """run_benchmark.py:25-65 for a batch: (distance_km float64 (N,), score int32 (N,)) -- haversine_np + geoguessr_score_from_distance.
+    float64 coordinates (the reference's arrays) go through the double entry point un-narrowed; anything else is read as float32."""
     N = pred_llh.shape[0]
     d = torch.empty((N,), dtype=torch.float64, device=pred_llh.device)
     s = torch.empty((N,), dtype=torch.int32, device=pred_llh.device)
-    L.check(L.lib().gg_geoguessr_score(_p(pred_llh.contiguous(), F32), _p(true_llh.contiguous(), F32), N, _p(d), _p(s), L.stream()),
-            "gg_geoguessr_score")
+    if pred_llh.dtype == torch.float64 or true_llh.dtype == torch.float64:
+        F64 = torch.float64
+        L.check(L.lib().gg_geoguessr_score_f64(_p(pred_llh.to(F64).contiguous(), F64), _p(true_llh.to(F64).contiguous(), F64), N, _p(d), _p(s),
+                                               L.stream()), "gg_geoguessr_score_f64")
+    else:
+        L.check(L.lib().gg_geoguessr_score(_p(pred_llh.float().contiguous(), F32), _p(true_llh.float().contiguous(), F32), N, _p(d), _p(s),
+                                           L.stream()), "gg_geoguessr_score")
     return d, s
 
 

@@ -31,6 +31,21 @@ def cosine_warm_restarts_lr(epoch: float, base_lr: float, T_0: int = 10, T_mult:
     return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / t_i)) / 2
 
 
+class _NativeWork:
+    """Work handle of the buckets sent through the C-ABI communicator (``async_op=True``): ``wait()`` orders the current compute stream
+    behind the communicator's stream, the same contract as a ``torch.distributed`` work object on the GPU."""
+
+    def __init__(self, nc):
+        self._nc = nc
+
+    def wait(self):
+        self._nc.wait()
+        return True
+
+    def is_completed(self):
+        return not self._nc._pending
+
+
 class AdamW:
     """``torch.optim.AdamW(model.parameters(), lr, betas, weight_decay)`` semantics (decoupled decay on every trainable
     parameter, bias-corrected) for a SuperGuessr / TinyViTAdapter built on flat storage."""
@@ -175,12 +190,15 @@ class AdamW:
             if p.grad is not None:
                 self._launch(("loose", id(p)), p.grad)
         works = [w for w in self._inflight.values() if w is not None]
+        native_pending = any(w is None for w in self._inflight.values())
         self._inflight, self._covered = {}, {}
+        nc = self._native() if native_pending else None
         if async_op:
+            if nc is not None:                          # buckets that went through gg_comm_*: their handle orders the compute stream behind them
+                works.append(_NativeWork(nc))
             return works
         for w in works:
             w.wait()
-        nc = self._native()
         if nc is not None:
             nc.wait()                                   # the compute stream is ordered behind the native collectives
         return []

@@ -17,8 +17,10 @@ from . import ops
 
 
 def score_batch(pred_llh: torch.Tensor, true_llh: torch.Tensor):
-    """(distance_km float64 (N,), score int32 (N,)) on the GPU; rows are (lon, lat) in degrees like the reference's arrays."""
-    return ops.geoguessr_score(pred_llh.float(), true_llh.float())
+    """(distance_km float64 (N,), score int32 (N,)) on the GPU; rows are (lon, lat) in degrees like the reference's arrays.  float64 rows stay
+    float64 (``haversine_np`` runs on float64 arrays, run_benchmark.py:28-47: the integer scores match it bit for bit only then); the model's
+    own float32 predictions are read as float32, which is exact."""
+    return ops.geoguessr_score(pred_llh, true_llh)
 
 
 def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_prob: Optional[Sequence[float]] = None) -> Dict[str, float]:
@@ -43,7 +45,7 @@ def geocell_metrics(results) -> Dict[str, float]:
     preds, cells, topk, labels_lla, labels_cell = (np.asarray(r) for r in results)
     out = {"Geocell_accuracy": float((cells == labels_cell).mean()),
            "Geocell_top5_accuracy": float((topk == labels_cell[:, None]).any(1).mean())}
-    d, s = score_batch(torch.as_tensor(preds, dtype=torch.float32).cuda(), torch.as_tensor(labels_lla, dtype=torch.float32).cuda())
+    d, s = score_batch(torch.as_tensor(preds).cuda(), torch.as_tensor(labels_lla).cuda())
     summ = compute_summary(d, s)
     out.update(Mean_distance_km=summ["avg_distance_km"], Median_distance_km=summ["median_distance_km"], Mean_score=summ["avg_score"])
     return out

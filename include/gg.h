@@ -71,6 +71,7 @@ int gg_splitk_reduce(const float* partials, float* out, int64_t n, int splits, i
 int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
                       int rows_per_scale, void* stream);
 int gg_cast_transpose_f32(const float* in, int R, int C, void* out, int64_t ldo, void* outT, int64_t ldt, void* stream);
+int gg_transpose_f32(const float* in, int R, int C, float* outT, int64_t ldt, void* stream);   /* f32 [R,C] -> f32 [C,ldt], ldt >= R (pad columns untouched) */
 int gg_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
 int gg_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 int64_t gg_colsum_scratch_floats(int M, int C);
@@ -188,8 +189,8 @@ int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per_window);
 /* ---------------------------------------------------------------- reference-precision (fp32) mode
  * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins
  * of the kernels above: f32 activations [tokens, channels], f32 MFMA (v_mfma_f32_16x16x4_f32 -- exact f32 products, f32
- * accumulation), exact erf GELU.  GgTinyVitCfg.act_dtype = 1 runs the whole encoder on them. */
-int gg_gemm_nt_f32(const GgGemmArgs* args, void* stream);   /* all matrices f32; K, lda, ldb multiples of 4; no split-K / A2 / BatchNorm-fused forms */
+ * accumulation), erf GELU through an fp32-accurate Phi (gg_phi_f32: 1.2 ulp of 1).  GgTinyVitCfg.act_dtype = 1 runs the whole encoder on them. */
+int gg_gemm_nt_f32(const GgGemmArgs* args, void* stream);   /* all matrices f32; K, lda, ldb multiples of 4; no split-K; the A2 (two-source) and BatchNorm-fused forms of GgGemmArgs are honoured (see below) */
 int gg_gemm_tn_f32_splits(int M, int N, int K);
 int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale,
                    float* partials, int splits, void* stream);
@@ -283,6 +284,8 @@ int gg_proto_refine(const GgProtoRefineArgs* args, void* stream);
 /* run_benchmark.py:25-65: dist_km[i] = haversine_np (fp64, R = 6371 km; may be NULL), score[i] = geoguessr_score_from_distance =
  * int(round(clamp(5000*exp(-d/1492.7), 0, 5000))) with Python's round-half-to-even: integer output, bit-exact vs the reference */
 int gg_geoguessr_score(const float* pred_llh, const float* true_llh, int N, double* dist_km, int32_t* score, void* stream);
+ /* float64 coordinates (the dtype of the reference's arrays) are not narrowed; a is clamped to 1 before asin; a non-finite distance scores -1 */
+int gg_geoguessr_score_f64(const double* pred_llh, const double* true_llh, int N, double* dist_km, int32_t* score, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (main_coordinator_idun_s3.py:286-291) */
 int gg_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, int step, float lr, float beta1,
@@ -325,7 +328,7 @@ typedef struct GgTinyVitCfg {
     float mlp_ratio, mbconv_expand_ratio;
     float bn_eps, ln_eps, bn_momentum;
     int act_dtype;       /* 0: bf16 activations + bf16 MFMA operands (fp32 accumulate / statistics / master weights);
-                            1: reference-precision mode -- f32 activations, f32 MFMA (v_mfma_f32_16x16x4_f32), exact erf: the
+                            1: reference-precision mode -- f32 activations, f32 MFMA (v_mfma_f32_16x16x4_f32), erf GELU at fp32 accuracy (1.2 ulp): the
                                arithmetic of the reference's own torch fp32 forward / backward */
     int features_only;   /* 1: models/tinyvit.py:38-46,139-143 (timm features_only=True): the output is the global-average-pooled
                                last feature map, head.norm is not applied (its parameters stay in the table, unused) */
@@ -338,6 +341,9 @@ int64_t gg_tinyvit_param_floats(const GgTinyVitCfg* cfg);      /* flat f32 param
 int64_t gg_tinyvit_buffer_floats(const GgTinyVitCfg* cfg);     /* flat f32 running_mean/var buffer length */
 int gg_tinyvit_num_counters(const GgTinyVitCfg* cfg);          /* num_batches_tracked entries (int64) */
 int gg_tinyvit_num_drop_slots(const GgTinyVitCfg* cfg);        /* DropPath slots: 1 per MBConv, 2 per TinyVitBlock */
+/* one step's DropPath rows for gg_tinyvit_forward's drop_scales: out[s][b] = Bernoulli(1 - rates[s]) / (1 - rates[s]) (timm DropPath with
+ * scale_by_keep).  Counter-based: (seed, counter) fully determine the rows, the caller advances `counter` once per training forward. */
+int gg_drop_path_scales(const float* rates, int slots, int batch, uint64_t seed, uint64_t counter, float* out, void* stream);
 int64_t gg_tinyvit_wcache_bytes(const GgTinyVitCfg* cfg);      /* bf16 copies (W and W^T) of the GEMM weights */
 int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training);
 int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream);

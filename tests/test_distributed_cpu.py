@@ -11,6 +11,7 @@ import socket
 import types
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -167,3 +168,23 @@ def test_train_model_two_ranks_uneven_dataset():
         assert c0[0] == 7 and c0 == c1                       # every rank sees the WHOLE validation set, gathered in dataset order
     assert nlog0 > 0
     assert set(saved) == {"lin.weight", "lin.bias"}          # save-best wrote the state dict on rank 0
+
+
+def test_bench_refuses_more_gpus_than_the_machine_has():
+    """`python bench.py --gpus N` without a launcher must never report an N-GPU number from fewer ranks (it self-launches torch.distributed.run
+    when the devices exist): on a machine with fewer than N GPUs it exits non-zero with a clear message and prints no result line; a launcher
+    whose WORLD_SIZE disagrees with --gpus is refused as well."""
+    import subprocess, sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this machine really has 8 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GG_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert r.returncode != 0 and "--gpus 8 requested" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True, text=True,
+                       timeout=300, cwd=root)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -514,6 +514,21 @@ def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids
     np.testing.assert_allclose(float(r2["loss"]), float(g["hard_ce"]), rtol=2e-5)
     lh, dlh = G.hard_ce(logits, g["argmin"])
     np.testing.assert_allclose(r2["dlogits"].float().cpu().numpy()[:, :12647], dlh, rtol=2e-2, atol=2e-6)
+    # fp32 dlogits (the reference-precision mode of the head): SURVEY 8(c)'s fp32 class against the REFERENCE fixture
+    r3 = ops.geo_head(dev(torch.from_numpy(logits)), cent, labels=dev(torch.from_numpy(labels)), mode=1, want_dlogits=True, dlogits_f32=True)
+    assert r3["dlogits"].dtype == torch.float32
+    dl3 = r3["dlogits"].cpu().numpy()[:, :12647]
+    rel = np.linalg.norm((dl3 - g["dlogits"]).astype(np.float64)) / np.linalg.norm(g["dlogits"].astype(np.float64))
+    print(f"geo_head f32: loss rel {abs(float(r3['loss']) / float(g['loss']) - 1):.2e}, dlogits rel-L2 {rel:.2e}, "
+          f"max abs {np.abs(dl3 - g['dlogits']).max():.2e}")
+    np.testing.assert_allclose(float(r3["loss"]), float(g["loss"]), rtol=1e-5)
+    # element-wise the soft targets carry the fp32 trig rounding of the distances (d/65 km in the exponent: a 0.02 km difference between two
+    # correctly rounded libms is 3e-4 relative on that element; the numpy oracle itself is at 1e-3 against the fixture), the norm does not
+    np.testing.assert_allclose(dl3, g["dlogits"], rtol=1e-3, atol=1e-8)
+    assert rel < 1e-4, rel
+    r4 = ops.geo_head(dev(torch.from_numpy(logits)), cent, labels_clf=dev(torch.from_numpy(g["argmin"])), mode=2, want_dlogits=True, dlogits_f32=True)
+    np.testing.assert_allclose(float(r4["loss"]), float(g["hard_ce"]), rtol=1e-5)
+    np.testing.assert_allclose(r4["dlogits"].cpu().numpy()[:, :12647], dlh, rtol=1e-5, atol=1e-8)
 
 
 def test_geo_head_small_k_and_edge_rows(ops):

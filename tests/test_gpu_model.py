@@ -1,9 +1,11 @@
 """Model-level parity on the GPU: whole TinyViT forward / backward, SuperGuessr step, CLIP tower and the drop-in call
 surface, against the CPU oracle and the reference-generated golden fixtures.  Everything goes through libgg.so.
 
-Tolerances (stated per SURVEY.md 8c): the HIP path stores activations / GEMM operands in bf16 with fp32 accumulation;
-vs the pure-fp32 oracle we allow embedding |err| <= 6e-2 on unit-variance LayerNorm outputs, loss rel 1e-2 and gradient
-cosine >= 0.98; vs the bf16-storage-emulating oracle the same checks are ~3x tighter."""
+Tolerances (stated per SURVEY.md 8c), per arithmetic mode.  fp32 mode (the reference's precision) against the
+REFERENCE-generated fixtures: loss rel <= 1e-5, predicted geocell and top-5 indices identical except where two logits lie within
+1e-4 of each other, gradients rel-L2 <= 1e-4.  bf16 mode (bf16 storage / MFMA operands, fp32 accumulation): vs the pure-fp32 oracle
+embedding |err| <= 6e-2 on unit-variance LayerNorm outputs, loss rel 1e-2 and gradient cosine >= 0.98; vs the bf16-storage-emulating
+oracle the same checks are ~3x tighter."""
 import os
 
 import numpy as np
@@ -15,9 +17,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["fp32", "bf16"])
 def _precision_mode(request, monkeypatch):
-    """Every model-level test of this file runs in both arithmetic modes (the modules read $GG_PRECISION when no precision= is given);
-    the tolerances written below are the bf16 ones, the fp32 mode meets them with orders of magnitude to spare (its own tight bounds:
-    tests/test_gpu_precision.py)."""
+    """Every model-level test of this file runs in both arithmetic modes (the modules read $GG_PRECISION when no precision= is given).
+    The reference-golden tests branch on the mode (fp32: SURVEY 8(c)'s fp32 class; bf16: the bf16 class); the oracle-vs-TinyViT tests keep
+    one bf16-sized bound here, their tight fp32 bounds are tests/test_gpu_precision.py."""
     monkeypatch.setenv("GG_PRECISION", request.param)
     yield request.param
 
@@ -39,6 +41,11 @@ def _randomize(bb, seed=0):
                 p.copy_(0.5 * torch.randn(p.shape, generator=g))
             elif name.endswith(".weight") and p.dim() == 2:
                 p.copy_(0.05 * torch.randn(p.shape, generator=g))
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).flatten().double(), torch.as_tensor(b).flatten().double()
+    return float((a - b).norm() / (b.norm() + 1e-300))
 
 
 def _cos(a, b):
@@ -160,46 +167,70 @@ def test_tinyvit_train_step_matches_oracle(adapter5m, centroids, unfrozen):
     assert int(bb.state_dict()["patch_embed.conv1.bn.num_batches_tracked"]) == 1
 
 
-def test_superguessr_head_matches_reference_golden(golden_dir, centroids):
-    """Embeddings-only SuperGuessr (config c5) against outputs of the REAL reference (tests/golden/head.npz)."""
+def test_superguessr_head_matches_reference_golden(golden_dir, centroids, _precision_mode):
+    """Embeddings-only SuperGuessr (config c5) against outputs of the REAL reference (tests/golden/head.npz; models/super_guessr.py:347-383).
+    fp32 mode: SURVEY 8(c)'s fp32 class -- loss rel 1e-5, geocell / top-5 indices identical outside logit gaps < 1e-4, gradients rel-L2 1e-4."""
     from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from oracle import geo_ref as G
+    f32 = _precision_mode == "fp32"
     g = np.load(os.path.join(golden_dir, "head.npz"))
     rng = np.random.default_rng(int(g["seed"]))
     W = rng.standard_normal((12647, 576), dtype=np.float32) * np.float32(0.05)
     b = rng.standard_normal((12647,), dtype=np.float32) * np.float32(0.1)
     emb = rng.standard_normal((32, 4, 576), dtype=np.float32)
     model = SuperGuessr(base_model=None, panorama=True, should_smooth_labels=True, embed_dim=576).cuda().train()
+    assert model.precision == _precision_mode
     with torch.no_grad():
         model.cell_layer.weight.copy_(torch.from_numpy(W)); model.cell_layer.bias.copy_(torch.from_numpy(b))
     e = torch.from_numpy(emb).cuda().requires_grad_(True)
     out = model(embedding=e, labels=torch.from_numpy(g["labels"]).cuda(), labels_clf=torch.from_numpy(g["labels_clf"]).cuda())
     out.loss.backward()
-    assert abs(float(out.loss) - float(g["loss"])) / float(g["loss"]) < 2e-3
-    agree = (out.preds_geocell.cpu().numpy() == g["preds_geocell"]).mean()
-    assert agree >= 0.9, agree                                   # bf16 logits: near-ties may flip (SURVEY 8c)
-    ov = np.mean([len(set(a) & set(r)) for a, r in zip(out.top5_geocells.indices.cpu().numpy(), g["top5_idx"])])
-    assert ov >= 4.5, ov
-    same = out.preds_geocell.cpu().numpy() == g["preds_geocell"]
-    np.testing.assert_allclose(out.preds_LLH.cpu().numpy()[same], g["preds_LLH"][same])
-    assert _cos(e.grad.cpu(), torch.from_numpy(g["demb"])) > 0.995
+    loss_rel = abs(float(out.loss) - float(g["loss"])) / float(g["loss"])
+    preds, top5 = out.preds_geocell.cpu().numpy(), out.top5_geocells.indices.cpu().numpy()
     dW = model.cell_layer.weight.grad.cpu().numpy()
-    assert _cos(torch.from_numpy(dW[g["labels_clf"][:8]]), torch.from_numpy(g["dW_rows"])) > 0.995
-    np.testing.assert_allclose(np.abs(dW).astype(np.float64).sum(), float(g["dW_abs_sum"]), rtol=2e-2)
-    np.testing.assert_allclose(np.abs(model.cell_layer.bias.grad.cpu().numpy()).astype(np.float64).sum(), float(g["db_abs_sum"]), rtol=2e-2)
+    demb_rel = _rel(e.grad.cpu(), g["demb"])
+    dW_rel = _rel(dW[g["labels_clf"][:8]], g["dW_rows"])
+    print(f"head[{_precision_mode}]: loss rel {loss_rel:.2e}, demb rel-L2 {demb_rel:.2e}, dW rows rel-L2 {dW_rel:.2e}")
+    if f32:
+        assert loss_rel < 1e-5, loss_rel
+        # rows whose six largest reference logits are separated by >= 1e-4 must agree exactly (the pinned oracle supplies the gaps)
+        z = np.sort(G.head_forward(emb, W, b, centroids)["logits"], axis=-1)[:, ::-1][:, :6]
+        clear = (z[:, :-1] - z[:, 1:]).min(-1) >= 1e-4
+        assert clear.mean() > 0.9
+        np.testing.assert_array_equal(preds[clear], g["preds_geocell"][clear])
+        np.testing.assert_array_equal(top5[clear], g["top5_idx"][clear])
+        np.testing.assert_allclose(out.top5_geocells.values.detach().cpu().numpy()[clear], g["top5_vals"][clear], rtol=1e-4)
+        assert demb_rel < 1e-4 and dW_rel < 1e-4, (demb_rel, dW_rel)
+        sum_tol = 1e-4
+    else:
+        assert loss_rel < 2e-3
+        agree = (preds == g["preds_geocell"]).mean()
+        assert agree >= 0.9, agree                                   # bf16 logits: near-ties may flip (SURVEY 8c)
+        ov = np.mean([len(set(a) & set(r)) for a, r in zip(top5, g["top5_idx"])])
+        assert ov >= 4.5, ov
+        assert _cos(e.grad.cpu(), torch.from_numpy(g["demb"])) > 0.995
+        assert _cos(torch.from_numpy(dW[g["labels_clf"][:8]]), torch.from_numpy(g["dW_rows"])) > 0.995
+        sum_tol = 2e-2
+    same = preds == g["preds_geocell"]
+    np.testing.assert_allclose(out.preds_LLH.cpu().numpy()[same], g["preds_LLH"][same])
+    np.testing.assert_allclose(np.abs(dW).astype(np.float64).sum(), float(g["dW_abs_sum"]), rtol=sum_tol)
+    np.testing.assert_allclose(np.abs(model.cell_layer.bias.grad.cpu().numpy()).astype(np.float64).sum(), float(g["db_abs_sum"]), rtol=sum_tol)
     # hard-label CE and serving return
     model.should_smooth_labels = False
     out_h = model(embedding=torch.from_numpy(emb).cuda(), labels=torch.from_numpy(g["labels"]).cuda(), labels_clf=torch.from_numpy(g["labels_clf"]).cuda())
-    assert abs(float(out_h.loss) - float(g["loss_hard"])) / float(g["loss_hard"]) < 2e-3
+    assert abs(float(out_h.loss) - float(g["loss_hard"])) / float(g["loss_hard"]) < (1e-5 if f32 else 2e-3)
     model.serving = True
     model.eval()
     llh, topk, embedding = model(embedding=torch.from_numpy(emb).cuda(), labels_clf=None)
     assert llh.shape == (32, 2) and topk.indices.shape == (32, 5) and embedding.shape == (32, 4, 576)
 
 
-def test_training_trace_matches_reference_golden(golden_dir):
-    """3 steps of the legacy loop contract (AdamW lr 2e-5) on embeddings vs the reference trace (train_trace.npz)."""
+def test_training_trace_matches_reference_golden(golden_dir, _precision_mode):
+    """3 steps of the legacy loop contract (AdamW lr 2e-5, training/train_eval_loop.py:188-190,233-242) on embeddings vs the reference
+    trace (train_trace.npz).  fp32 mode: losses rel 1e-5, the weight movement and the final bias values at fp32 rounding."""
     from geoguessr_ai_amd.models.super_guessr import SuperGuessr
     from geoguessr_ai_amd.optim import AdamW
+    f32 = _precision_mode == "fp32"
     g = np.load(os.path.join(golden_dir, "train_trace.npz"))
     rng = np.random.default_rng(int(g["seed"]))
     W0 = rng.standard_normal((12647, 576), dtype=np.float32) * np.float32(0.02)
@@ -214,9 +245,16 @@ def test_training_trace_matches_reference_golden(golden_dir):
         out = model(embedding=torch.from_numpy(emb_t[s]).cuda(), labels=torch.from_numpy(lab3[s]).cuda())
         out.loss.backward(); opt.step(); opt.zero_grad()
         losses.append(float(out.loss))
-    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
-    delta = (model.cell_layer.weight.detach().cpu().numpy() - W0)
-    np.testing.assert_allclose(np.abs(delta).astype(np.float64).sum(), float(g["W_delta_abs_sum"]), rtol=5e-2)
+    Wf = model.cell_layer.weight.detach().cpu().numpy()
+    delta = np.abs(Wf - W0).astype(np.float64).sum()
+    bf = model.cell_layer.bias.detach().cpu().numpy()[:64]
+    print(f"trace[{_precision_mode}]: loss rel {np.abs(np.asarray(losses) / g['losses'] - 1).max():.2e}, "
+          f"|dW| rel {abs(delta / float(g['W_delta_abs_sum']) - 1):.2e}, b_final rel-L2 {_rel(bf, g['b_final']):.2e}")
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-5 if f32 else 2e-3)
+    np.testing.assert_allclose(delta, float(g["W_delta_abs_sum"]), rtol=1e-3 if f32 else 5e-2)
+    if f32:
+        assert _rel(bf, g["b_final"]) < 1e-3
+        assert abs(float(Wf.astype(np.float64).sum()) - float(g["W_final_checksum"])) < 1e-3 * delta
 
 
 def test_clip_tower_matches_transformers_golden(golden_dir):
