@@ -153,7 +153,8 @@ def allreduce_cost(opt, dev, world, reps=5):
     backward pass (bucket launch from the stage callback), so this is an upper bound of their exposed share."""
     import torch
     import torch.distributed as dist
-    bufs = [torch.zeros_like(t) for t in opt.grad_buffers()]
+    shapes = [bb.flat_grads()[s:e] for bb in opt.backbones for s, e in bb.trainable_ranges()] + [p.data for p in opt.loose]   # (the head's .grad is None after zero_grad)
+    bufs = [torch.zeros_like(t) for t in shapes]
     nbytes = sum(b.numel() * b.element_size() for b in bufs)
     for b in bufs:
         dist.all_reduce(b)

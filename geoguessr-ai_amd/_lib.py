@@ -62,7 +62,7 @@ class TinyVitCfg(C.Structure):
 
 class ClipCfg(C.Structure):
     _fields_ = [("hidden_size", C.c_int), ("intermediate_size", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int),
-                ("image_size", C.c_int), ("patch_size", C.c_int), ("ln_eps", C.c_float)]
+                ("image_size", C.c_int), ("patch_size", C.c_int), ("ln_eps", C.c_float), ("act_dtype", C.c_int)]
 
 
 STAGE_DONE_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)      # GgStageDoneFn (host callback of gg_tinyvit_backward)
@@ -196,9 +196,11 @@ SIGNATURES = {
                                  C.POINTER(_L)]),
     "gg_clip_param_floats": (_L, [C.POINTER(ClipCfg)]),
     "gg_clip_wcache_bytes": (_L, [C.POINTER(ClipCfg)]),
-    "gg_clip_workspace_bytes": (_L, [C.POINTER(ClipCfg), _I]),
+    "gg_clip_workspace_bytes": (_L, [C.POINTER(ClipCfg), _I, _I, C.c_char_p]),
+    "gg_clip_first_trained_layer": (_I, [C.POINTER(ClipCfg), C.c_char_p]),
     "gg_clip_refresh_weights": (_I, [C.POINTER(ClipCfg), _P, _P, _P]),
-    "gg_clip_forward": (_I, [C.POINTER(ClipCfg), _I, _P, _P, _P, _P, _P, _P, _P]),
+    "gg_clip_forward": (_I, [C.POINTER(ClipCfg), _I, _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
+    "gg_clip_backward": (_I, [C.POINTER(ClipCfg), _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
 }
 SYMBOLS = list(SIGNATURES)
 

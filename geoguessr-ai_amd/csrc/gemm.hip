@@ -236,17 +236,27 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
         if (p.debug & 2) continue;
         if (EPI == EPI_GELU) {
             if (p.preact) store8(p.preact, m, v, true);
+            if (p.act == GG_ACT_QUICK_GELU) {       // CLIP fc1 in training (uniform branch: the pre-activation copy lives in this epilogue class)
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const f32x2 r = gg_gelu_v2((f32x2){(float)v[j], (float)v[j + 1]});
-                v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)gg_quick_gelu((float)v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 r = gg_gelu_v2((f32x2){(float)v[j], (float)v[j + 1]});
+                    v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+                }
             }
         }
         if (EPI == EPI_DGELU) {
+            if (p.dact == GG_ACT_QUICK_GELU) {
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const f32x2 r = (f32x2){(float)v[j], (float)v[j + 1]} * gg_gelu_grad_v2((f32x2){(float)ex[pass][j], (float)ex[pass][j + 1]});
-                v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+                for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * gg_quick_gelu_grad((float)ex[pass][j]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2 r = (f32x2){(float)v[j], (float)v[j + 1]} * gg_gelu_grad_v2((f32x2){(float)ex[pass][j], (float)ex[pass][j + 1]});
+                    v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+                }
             }
         }
         if (EPI == EPI_LINEAR && p.residual) {
@@ -748,10 +758,10 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
         GG_CHECK(!a->bias && !a->act && !a->preact && !a->residual && !a->colstats && !a->dact && !a->rowscale,
                  "gg_gemm_nt: split-K writes raw f32 partials, no epilogue allowed");
     if (a->rowscale) GG_CHECK(a->rows_per_scale > 0, "gg_gemm_nt: rows_per_scale must be > 0");
-    GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU, "gg_gemm_nt: only the GELU derivative epilogue is built");
+    GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU || a->dact == GG_ACT_QUICK_GELU, "gg_gemm_nt: dact must be GELU or QuickGELU");
     GG_CHECK(!(a->dact_preact && (a->bias || a->act || a->residual || a->preact)), "gg_gemm_nt: dact excludes bias/act/residual/preact");
     GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt: an activation epilogue excludes rowscale/residual");
-    GG_CHECK(!a->preact || a->act == GG_ACT_GELU, "gg_gemm_nt: preact is only available with the GELU epilogue");
+    GG_CHECK(!a->preact || a->act == GG_ACT_GELU || a->act == GG_ACT_QUICK_GELU, "gg_gemm_nt: preact is only available with an activation epilogue");
     GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->out_f32),
              "gg_gemm_nt: colstats is only available on the plain and BatchNorm-backward bf16 epilogues");
     GG_CHECK(!a->out_f32 || !(a->act || a->rowscale || a->residual || a->dact_preact || a->preact), "gg_gemm_nt: f32 output supports bias only");
@@ -805,7 +815,7 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     if (a->out_f32 || split > 1) epi = EPI_F32;
     else if (p.bn_y) epi = EPI_BNBWD;
     else if (p.dact) epi = EPI_DGELU;
-    else if (a->act == GG_ACT_GELU) epi = EPI_GELU;
+    else if (a->act == GG_ACT_GELU || (a->act == GG_ACT_QUICK_GELU && a->preact)) epi = EPI_GELU;      // (row-phase epilogue: pre-activation copy)
     else if (a->act == GG_ACT_QUICK_GELU) epi = EPI_QGELU;
     else if (a->bias || a->rowscale || a->residual) epi = EPI_LINEAR;
     else epi = EPI_PLAIN;

@@ -39,6 +39,7 @@ struct F32GemmParams {
     const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
     unsigned long long* trace;      // dev (gg_gemm_f32_set_trace): per-workgroup [hw_id, xcc_id, t_start, t_first_data, t_loop_end, t_epilogue_end, tile, 0] (100 MHz ticks)
     int stagger;        // experiment (GG_GEMM_F32_STAGGER): first-round workgroups start hash(blockIdx) * stagger * 0.45 us late
+    int quick;          // FE_GELU / FE_DGELU: the activation is QuickGELU (CLIP) instead of erf GELU
 };
 
 __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float offset of 16-byte chunk kc (0..7) of a tile row
@@ -141,8 +142,13 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                             if (full) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
                             else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
                         }
+                        if (p.quick) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+                            for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+                        }
                     }
                     if (EPI == FE_QGELU) {
 #pragma unroll
@@ -150,8 +156,16 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     }
                     if (EPI == FE_DGELU) {
                         const f32x4 h = aux[AUX ? gi : 0][AUX ? mt : 0];
+                        if (p.quick) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
+                            for (int r = 0; r < 4; ++r) {
+                                const float sg = 1.0f / (1.0f + expf(-1.702f * h[r]));
+                                v[r] *= (sg + 1.702f * h[r] * sg * (1.0f - sg)) * rs;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
+                        }
                     }
                     if (EPI == FE_LINEAR) {
                         v *= rs;
@@ -635,10 +649,10 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         else GG_CHECK(!(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->bn_y), "gg_gemm_nt_f32: the BatchNorm prologue is built with the plain (+ column statistics) epilogue");
     } else GG_CHECK(!a->A2, "gg_gemm_nt_f32: A2 without coefficients");
     if (a->rowscale) GG_CHECK(a->rows_per_scale > 0, "gg_gemm_nt_f32: rows_per_scale must be > 0");
-    GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU, "gg_gemm_nt_f32: only the GELU derivative epilogue is built");
+    GG_CHECK(!a->dact_preact || a->dact == GG_ACT_GELU || a->dact == GG_ACT_QUICK_GELU, "gg_gemm_nt_f32: dact must be GELU or QuickGELU");
     GG_CHECK(!(a->dact_preact && (a->bias || a->act || a->residual || a->preact)), "gg_gemm_nt_f32: dact excludes bias/act/residual/preact");
     GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt_f32: an activation epilogue excludes rowscale/residual");
-    GG_CHECK(!a->preact || a->act == GG_ACT_GELU, "gg_gemm_nt_f32: preact is only available with the GELU epilogue");
+    GG_CHECK(!a->preact || a->act == GG_ACT_GELU || a->act == GG_ACT_QUICK_GELU, "gg_gemm_nt_f32: preact is only available with an activation epilogue");
     GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact), "gg_gemm_nt_f32: colstats needs the plain or BatchNorm-backward epilogue");
     GG_CHECK(!a->preact || ((uintptr_t)a->preact & 15) == 0, "gg_gemm_nt_f32: preact must be 16-byte aligned");
     GG_CHECK(!a->residual || ((uintptr_t)a->residual & 15) == 0, "gg_gemm_nt_f32: residual must be 16-byte aligned");
@@ -648,6 +662,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.M = a->M; p.N = a->N; p.K = a->K; p.bias = a->bias; p.preact = (float*)a->preact;
     p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = (const float*)a->residual; p.ldr = a->ldr;
     p.dact_preact = (const float*)a->dact_preact; p.colstats = a->colstats;
+    p.quick = (a->dact_preact ? a->dact : a->act) == GG_ACT_QUICK_GELU;
     p.bn_y = (const float*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
     p.A2 = (const float*)a->A2; p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     const int rem = a->N % 128;
@@ -673,7 +688,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     int epi;
     if (a->bn_y) epi = FE_BNBWD;
     else if (a->dact_preact) epi = FE_DGELU;
-    else if (a->act == GG_ACT_GELU) epi = FE_GELU;
+    else if (a->act == GG_ACT_GELU || (a->act == GG_ACT_QUICK_GELU && a->preact)) epi = FE_GELU;
     else if (a->act == GG_ACT_QUICK_GELU) epi = FE_QGELU;
     else if (a->bias || a->rowscale || a->residual) epi = FE_LINEAR;
     else epi = FE_PLAIN;

@@ -339,7 +339,10 @@ class SuperGuessr(nn.Module):
         if self.base_model is not None and pixel_values is not None:
             if pixel_values.dim() > 4:
                 pixel_values = pixel_values.squeeze(1)
-            outs = self.base_model(pixel_values=pixel_values)
+            if hasattr(self.base_model, "forward_hip") and hasattr(self.base_model, "num_tokens"):
+                outs = self.base_model(pixel_values=pixel_values, return_last_hidden=False)      # HIP CLIP tower: only the token mean is needed
+            else:
+                outs = self.base_model(pixel_values=pixel_values)
             if hasattr(outs, "pooled_mean"):                      # HIP CLIP tower: token mean already taken on device
                 embedding = outs.pooled_mean
             elif hasattr(outs, "last_hidden_state") and self.mode == "transformer" and outs.last_hidden_state.shape[1] != 1:

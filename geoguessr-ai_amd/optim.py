@@ -120,8 +120,9 @@ class AdamW:
         if self._world() == 1:
             return
         for bb in self.backbones:
-            self._bcast(bb._flat_buf, src)
-            self._bcast(bb._counters, src)
+            for t in (bb._flat_buf, bb._counters):
+                if t.numel() > 0:          # (the CLIP tower has no buffers)
+                    self._bcast(t, src)
         nc = self._native()
         if nc is not None:
             nc.wait()

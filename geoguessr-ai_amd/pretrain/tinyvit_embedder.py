@@ -1,12 +1,12 @@
 """Drop-in for the reference's ``pretrain/tinyvit_embedder.py`` (``TinyViTEmbedding``, :8-124): frozen TinyViT with
-``num_classes=0`` run under ``no_grad``; panorama kwargs ``image_2..4`` stack on dim 1.  PIL inputs need timm's eval
-transform (absent here): tensors only."""
+``num_classes=0`` run under ``no_grad``; panorama kwargs ``image_2..4`` stack on dim 1.  Float tensors are pixel_values (:70-72); PIL images /
+uint8 arrays or tensors go through the tensor side of timm's eval transform on the device (:56-69: centre crop at the variant's crop_pct,
+resize to the model's input size, /255, ImageNet mean / std -- ``training.preprocess.images_to_pixel_values``)."""
 from __future__ import annotations
 
 import torch
 from torch import Tensor
 
-from .. import _lib as L
 from ..models.tinyvit import TinyViTAdapter
 
 
@@ -24,13 +24,19 @@ class TinyViTEmbedding(torch.nn.Module):
         self.eval()
 
     def _get_embedding(self, image) -> Tensor:
-        if not isinstance(image, Tensor):
-            raise L.GgError("TinyViTEmbedding expects preprocessed pixel tensors (timm transforms are not available)")
+        if isinstance(image, Tensor) and image.is_floating_point():
+            pixel_values = image
+        else:
+            from ..training.preprocess import TINYVIT_MEAN, TINYVIT_STD, images_to_pixel_values
+            bb = self.tinyvit_model.backbone
+            # timm's pretrained_cfg: crop_pct 0.95 for the 224 variants, 1.0 ("squash"-free centre crop) for the 384 / 512 ones
+            crop = 0.95 if bb.cfg.img_size == 224 else 1.0
+            pixel_values = images_to_pixel_values(image, bb.cfg.img_size, TINYVIT_MEAN, TINYVIT_STD, bb.flat_params.device, crop_pct=crop)
         with torch.no_grad():
-            return self.tinyvit_model(pixel_values=image).pooler_output
+            return self.tinyvit_model(pixel_values=pixel_values).pooler_output
 
     def forward(self, image, **kwargs) -> Tensor:
-        if isinstance(image, Tensor) or "image_2" not in kwargs:
+        if "image_2" not in kwargs:
             return self._get_embedding(image)
         embs = [self._get_embedding(image)] + [self._get_embedding(kwargs[c]) for c in ("image_2", "image_3", "image_4")]
         return torch.stack(embs, dim=1)

@@ -380,20 +380,32 @@ int gg_preprocess_bilinear(const void* src, int src_u8, int N, int Hs, int Ws, f
 int gg_segment_mean(const float* emb, int64_t ld, const int64_t* ptr, const int64_t* member, int num_segments, int D, float* out,
                     void* stream);
 
-/* ---------------------------------------------------------------- CLIP vision tower, inference
- * (transformers CLIPVisionModel as used by pretrain/clip_embedder.py:63-65: mean over all tokens of last_hidden_state) */
+/* ---------------------------------------------------------------- CLIP vision tower: inference and fine-tuning
+ * transformers CLIPVisionModel as the reference uses it: the embedder's mean over all tokens of last_hidden_state (no post_layernorm;
+ * pretrain/clip_embedder.py:51-66) and the trainable base model of SuperGuessr (models/super_guessr.py:134-150,323-325: the last
+ * encoder layer is fine-tuned when the pretrained head exists, every layer otherwise; main_coordinator_idun_s3.py:183-203).
+ * act_dtype 1 = fp32 (the reference's precision: f32 activations, f32 MFMA), 0 = bf16 activations / MFMA operands with f32 accumulation.
+ * Parameters: one flat f32 buffer, HF state-dict names without the "vision_model." prefix (gg_clip_tensor_info).  `trainable` (host,
+ * one byte per tensor, NULL = all) selects the tensors whose gradients gg_clip_backward accumulates; a training forward keeps the
+ * activations of every layer from the first trainable one up (gg_clip_first_trained_layer), frozen layers below run in place. */
 typedef struct GgClipCfg {
     int hidden_size, intermediate_size, num_layers, num_heads, image_size, patch_size;
     float ln_eps;
+    int act_dtype;                         /* 0 bf16, 1 fp32 */
 } GgClipCfg;
 int gg_clip_num_tensors(const GgClipCfg* cfg);
 int gg_clip_tensor_info(const GgClipCfg* cfg, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4);
 int64_t gg_clip_param_floats(const GgClipCfg* cfg);
 int64_t gg_clip_wcache_bytes(const GgClipCfg* cfg);
-int64_t gg_clip_workspace_bytes(const GgClipCfg* cfg, int batch);
+int64_t gg_clip_workspace_bytes(const GgClipCfg* cfg, int batch, int training, const uint8_t* trainable);
+int gg_clip_first_trained_layer(const GgClipCfg* cfg, const uint8_t* trainable);   /* 0 when an embedding-side tensor is trainable; num_layers: none */
 int gg_clip_refresh_weights(const GgClipCfg* cfg, const float* params, void* wcache, void* stream);
-int gg_clip_forward(const GgClipCfg* cfg, int batch, const float* params, const void* wcache, const float* x, void* workspace,
-                    float* out /* f32 (batch, hidden) */, float* last_hidden /* f32 (batch,T,hidden) or NULL */, void* stream);
+int gg_clip_forward(const GgClipCfg* cfg, int batch, int training, const float* params, const void* wcache, const float* x, void* workspace,
+                    float* out /* f32 (batch, hidden) */, float* last_hidden /* f32 (batch,T,hidden) or NULL */, const uint8_t* trainable, void* stream);
+/* backward of the training forward that last wrote `workspace` (same cfg / batch / trainable).  d_out: gradient of `out` or NULL;
+ * d_last_hidden: gradient of last_hidden or NULL (both: summed).  Gradients are ACCUMULATED into `grads` (flat, parameter offsets). */
+int gg_clip_backward(const GgClipCfg* cfg, int batch, const float* params, const void* wcache, void* workspace, const float* d_out,
+                     const float* d_last_hidden, float* grads, const uint8_t* trainable, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,3 +94,20 @@ def forward(cfg: ClipVisionConfig, st: Dict[str, torch.Tensor], x: torch.Tensor,
         m_ = q(quick_gelu(q(F.linear(m_, q(st[f"{p}.mlp.fc1.weight"]), st[f"{p}.mlp.fc1.bias"]))))
         h = q(h + F.linear(m_, q(st[f"{p}.mlp.fc2.weight"]), st[f"{p}.mlp.fc2.bias"]))
     return h.mean(dim=1)
+
+
+def train_step(cfg: ClipVisionConfig, st: Dict[str, torch.Tensor], W: torch.Tensor, b: torch.Tensor, centroids: torch.Tensor,
+               pixel_values: torch.Tensor, labels: torch.Tensor, trainable=None, emulate_bf16: bool = False):
+    """One SuperGuessr-on-CLIP training forward + backward (models/super_guessr.py:309-383 with a CLIPVisionModel base: token mean of
+    last_hidden_state per view, 4-view mean, Linear, haversine-smoothed soft CE) by torch autograd over ``forward``.  pixel_values
+    (N,4,3,H,W) -> dict(loss, embedding (N,4,D), grads{name}).  PINNED against the reference run in ``tests/golden/clip_train.npz``."""
+    from . import step_ref as S
+    n, v = pixel_values.shape[:2]
+    stg = {k: (t.clone().requires_grad_(True) if (t.is_floating_point() and (trainable is None or k in trainable)) else t.clone()) for k, t in st.items()}
+    Wg, bg = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    emb = forward(cfg, stg, pixel_values.reshape(n * v, *pixel_values.shape[2:]), emulate_bf16=emulate_bf16).view(n, v, -1)
+    loss, logits = S.head_loss(emb, Wg, bg, centroids, labels, emulate_bf16=emulate_bf16)
+    loss.backward()
+    grads = {k: t.grad for k, t in stg.items() if t.requires_grad and t.grad is not None}
+    grads["cell_layer.weight"], grads["cell_layer.bias"] = Wg.grad, bg.grad
+    return dict(loss=loss.detach(), embedding=emb.detach(), logits=logits.detach(), grads=grads)

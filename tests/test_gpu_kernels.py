@@ -525,7 +525,7 @@ def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids
     # element-wise the soft targets carry the fp32 trig rounding of the distances (d/65 km in the exponent: a 0.02 km difference between two
     # correctly rounded libms is 3e-4 relative on that element; the numpy oracle itself is at 1e-3 against the fixture), the norm does not
     np.testing.assert_allclose(dl3, g["dlogits"], rtol=1e-3, atol=1e-8)
-    assert rel < 1e-4, rel
+    assert rel < 2e-5, rel                      # measured 7e-6
     r4 = ops.geo_head(dev(torch.from_numpy(logits)), cent, labels_clf=dev(torch.from_numpy(g["argmin"])), mode=2, want_dlogits=True, dlogits_f32=True)
     np.testing.assert_allclose(float(r4["loss"]), float(g["hard_ce"]), rtol=1e-5)
     np.testing.assert_allclose(r4["dlogits"].cpu().numpy()[:, :12647], dlh, rtol=1e-5, atol=1e-8)

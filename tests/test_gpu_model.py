@@ -257,21 +257,6 @@ def test_training_trace_matches_reference_golden(golden_dir, _precision_mode):
         assert abs(float(Wf.astype(np.float64).sum()) - float(g["W_final_checksum"])) < 1e-3 * delta
 
 
-def test_clip_tower_matches_transformers_golden(golden_dir):
-    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
-    g = np.load(os.path.join(golden_dir, "clip_tiny.npz"))
-    hs, inter, Lr, nh, img, ps = [int(v) for v in g["cfg"]]
-    tower = CLIPVisionTower("tiny", hidden_size=hs, intermediate_size=inter, num_layers=Lr, num_heads=nh, image_size=img, patch_size=ps)
-    tower.load_hf_state_dict({k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")})
-    tower = tower.cuda()
-    out = tower(pixel_values=torch.from_numpy(g["x"]).cuda())
-    y = out.pooled_mean.cpu().numpy()
-    assert np.abs(y - g["y"]).max() < 3e-2, np.abs(y - g["y"]).max()
-    lh = out.last_hidden_state.cpu().numpy()
-    assert np.abs(lh - g["last_hidden_state"]).max() < 8e-2
-    assert _cos(torch.from_numpy(lh), torch.from_numpy(g["last_hidden_state"])) > 0.999
-
-
 def test_no_cpu_fallback():
     from geoguessr_ai_amd import _lib as L
     from geoguessr_ai_amd.models.super_guessr import SuperGuessr

@@ -258,34 +258,6 @@ def test_fp32_mode_large_windows_train_step(name, centroids):
     _grad_table(case, 2e-3, f"fp32 {name}")
 
 
-def test_clip_large_patch14_336_tower():
-    """CLIPVisionTower("openai/clip-vit-large-patch14-336") -- the reference's CLIP_MODEL (config.py:6): 577 tokens, patch 14 (contraction
-    588 -> padded 592), 24 layers; batch 2 against the CPU oracle with the same random weights."""
-    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower, CLIPEmbedding
-    from oracle import clip_ref as CR
-    tower = CLIPVisionTower("openai/clip-vit-large-patch14-336", seed=3)
-    assert tower.config.hidden_size == 1024
-    st = {k: v.clone() for k, v in tower.named_views().items()}
-    tower = tower.cuda()
-    x = torch.randn(2, 3, 336, 336, generator=torch.Generator().manual_seed(4))
-    out = tower(pixel_values=x.cuda())
-    assert out.last_hidden_state.shape == (2, 577, 1024)
-    cfg = CR.ClipVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=336, patch_size=14)
-    with torch.no_grad():
-        ref = CR.forward(cfg, st, x, emulate_bf16=True)
-    got = out.pooled_mean.cpu()
-    rel = float((got - ref).norm() / ref.norm())
-    print(f"\n[CLIP L/14-336] pooled embedding rel-L2 vs bf16-emulating oracle {rel:.3e}")
-    assert rel < 2e-2
-    # the reference's wrapper class (pretrain/clip_embedder.py:10-101): a tensor `image` is embedded on its own (:85-86)
-    e = CLIPEmbedding("openai/clip-vit-base-patch32", device="cuda", panorama=True)
-    xs = [torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(10 + i)) for i in range(4)]
-    single = e(xs[0].cuda(), image_2=xs[1].cuda(), image_3=xs[2].cuda(), image_4=xs[3].cuda())
-    assert single.shape == (2, 768)
-    assert torch.equal(single, e.clip_model(pixel_values=xs[0].cuda()).last_hidden_state.mean(dim=1)) or \
-        torch.allclose(single, e.clip_model(pixel_values=xs[0].cuda()).last_hidden_state.mean(dim=1), atol=2e-3)
-
-
 def test_features_only_adapter_and_tinyvit_embedding():
     """features_only=True (models/tinyvit.py:38-46,139-143): pooled last feature map without head.norm; TinyViTEmbedding wrapper."""
     from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter

@@ -92,3 +92,19 @@ def test_tinyvit_window_partition_equals_blockwise_attention():
     np.testing.assert_allclose(torch.roll(taps_a["stages.1.blocks.0.x1"], (7, 14), (1, 2)).numpy(),
                                taps_b["stages.1.blocks.0.x1"].numpy(), rtol=1e-4, atol=1e-5)
     assert y.shape == ys.shape
+
+
+def test_clip_training_step_matches_reference_golden(golden_dir, centroids):
+    """``oracle.clip_ref.train_step`` (torch autograd over the restated tower + ``step_ref.head_loss``) against the REFERENCE's SuperGuessr run
+    on a transformers CLIPVisionModel base (tests/golden/clip_train.npz): loss, (N,4,C) embedding, every parameter gradient."""
+    from tests import clip_golden as CG
+    case = CG.load(golden_dir)
+    g = case["g"]
+    cfg = C.ClipVisionConfig(*case["cfg"])
+    r = C.train_step(cfg, case["weights"], case["W"], case["b"], torch.from_numpy(centroids), case["x"], case["labels"])
+    np.testing.assert_allclose(float(r["loss"]), float(g["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(r["embedding"].numpy(), g["embedding"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_array_equal(r["logits"].argmax(-1).numpy(), g["preds_geocell"])
+    errs = CG.grad_errors(case, r["grads"])
+    assert len(errs) == 39 and max(errs.values()) < 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    np.testing.assert_allclose(r["grads"]["cell_layer.weight"].numpy()[g["labels_clf"]], g["dW_rows"], rtol=1e-4, atol=1e-9)
