@@ -35,7 +35,7 @@ def test_clip_forward_matches_transformers_golden(golden_dir, precision):
     tower = _tiny_tower(case, precision).cuda().eval()
     assert {k for k in tower.state_dict()} == {"vision_model." + n for n in case["names"]}          # HF (transformers 4.x) state-dict keys
     out = tower(pixel_values=torch.from_numpy(g["x"]).cuda())
-    y, lh = out.pooled_mean.cpu().numpy(), out.last_hidden_state.cpu().numpy()
+    y, lh = out.pooled_mean.detach().cpu().numpy(), out.last_hidden_state.detach().cpu().numpy()
     e_y, e_lh = _rel(y, g["y"]), _rel(lh, g["last_hidden_state"])
     print(f"\n[CLIP tiny {precision}] pooled rel-L2 {e_y:.2e} (max abs {np.abs(y - g['y']).max():.2e}), last_hidden rel-L2 {e_lh:.2e}")
     if precision == "fp32":
@@ -87,7 +87,7 @@ def test_superguessr_on_clip_training_matches_reference_golden(golden_dir, centr
           f"{len(errs)} tower gradients: worst {worst} {errs[worst]:.2e}, median {float(np.median(list(errs.values()))):.2e}")
     if precision == "fp32":
         assert loss_rel < 1e-5 and emb_rel < 1e-4 and dW_rel < 1e-4
-        assert errs[worst] < 1e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+        assert errs[worst] < 1e-4, sorted(errs.items(), key=lambda kv: -kv[1])[:5]          # measured 8e-6
         np.testing.assert_array_equal(out.preds_geocell.cpu().numpy(), g["preds_geocell"])
     else:
         assert loss_rel < 5e-3 and emb_rel < 3e-2 and dW_rel < 5e-2
@@ -139,7 +139,7 @@ def test_clip_base_patch32_last_layer_finetune_matches_oracle(centroids):
     loss_rel = abs(float(out.loss.detach()) - float(ref["loss"])) / float(ref["loss"])
     print(f"\n[CLIP B/32 fp32, layer 11 trainable] loss rel {loss_rel:.2e}, embedding rel-L2 {_rel(out.embedding.detach(), ref['embedding']):.2e}, "
           f"{len(errs)} gradients: worst {worst} {errs[worst]:.2e}")
-    assert loss_rel < 1e-5 and _rel(out.embedding.detach(), ref["embedding"]) < 1e-4 and errs[worst] < 1e-3
+    assert loss_rel < 1e-5 and _rel(out.embedding.detach(), ref["embedding"]) < 1e-4 and errs[worst] < 2e-4      # measured 2e-5
     assert _rel(model.cell_layer.weight.grad, ref["grads"]["cell_layer.weight"]) < 1e-4
     opt.step(); opt.zero_grad()
     out2 = model(pixel_values=x.cuda(), labels=labels.cuda())
@@ -170,7 +170,7 @@ def test_clip_large_patch14_336_forward_and_finetune_fp32(centroids):
     worst = max(errs, key=errs.get)
     print(f"\n[CLIP L/14-336 fp32] embedding rel-L2 {emb_rel:.2e}, loss rel {abs(float(out.loss.detach()) / float(ref['loss']) - 1):.2e}, "
           f"layer-23 gradients worst {worst} {errs[worst]:.2e}")
-    assert emb_rel < 1e-4 and abs(float(out.loss.detach()) / float(ref["loss"]) - 1) < 1e-5 and errs[worst] < 1e-3
+    assert emb_rel < 1e-4 and abs(float(out.loss.detach()) / float(ref["loss"]) - 1) < 1e-5 and errs[worst] < 2e-4
     model.eval()
     with torch.no_grad():
         o = tower(pixel_values=x[0].cuda())
