@@ -102,14 +102,21 @@ def clock_under_gemm_load(dev):
 def pmc_traffic(precision):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     runs; tools/profile_round.sh + tools/pmc_traffic.py).  PMC collection cannot run inside the timed process, so this is the offline
-    measurement of the same workload; None when no file for this precision is committed."""
-    for name in (f"r02_hbm_traffic_pmc_{precision}.json",) + (("r01_hbm_traffic_pmc.json",) if precision == "bf16" else ()):
+    measurement of the same workload.  The file records the sha256 of the kernel sources it was measured on: when the running tree differs the
+    figure is still reported but marked ``stale``.  -> (bytes or None, info dict)."""
+    from geoguessr_ai_amd import _lib as L
+    names = [f"r03_hbm_traffic_pmc_{precision}.json", f"r02_hbm_traffic_pmc_{precision}.json"] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
+    for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["per_kernel_class"]["gemm_nt"]["traffic_bytes_per_launch"]
+                d = json.load(f)
+            val = d["per_kernel_class"]["gemm_nt"]["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             continue
-    return None
+        prof_hash = d.get("source_hash")
+        return val, dict(file="profiles/" + name, git_head=d.get("git_head"), source_hash=prof_hash,
+                         stale=(prof_hash is None or prof_hash != L.source_hash()))
+    return None, None
 
 
 def self_launch(args) -> int:
@@ -255,7 +262,8 @@ def run_mode(precision, args, rank, world, dev, x, lab):
         ach_tf, ach_gb = fl_ / max(ms_, 1e-9) / 1e9, by_ / max(ms_, 1e-9) / 1e6
         intensity = fl_ / max(by_, 1.0)
         kern = "gemm_nt_f32_kernel (+ gemm_tn_f32_kernel weight gradients)" if precision == "fp32" else "gemm_nt_kernel (+ gemm_tn_kernel weight gradients)"
-        common = dict(kernel=kern, traffic=pmc_traffic(precision), launches=n_ // args.steps, avg_launch_us=round(1e3 * ms_ / max(n_, 1), 2),
+        traffic, traffic_info = pmc_traffic(precision)
+        common = dict(kernel=kern, traffic=traffic, traffic_source=traffic_info, launches=n_ // args.steps, avg_launch_us=round(1e3 * ms_ / max(n_, 1), 2),
                       gemm_ms_per_step=round(ms_ / args.steps, 3), algorithmic_gflop_per_launch=round(fl_ / max(n_, 1) / 1e9, 3),
                       algorithmic_bytes_per_launch=int(by_ / max(n_, 1)), flop_per_byte=round(intensity, 1),
                       mfma_achieved_tflops=round(ach_tf, 2), mfma_frac=round(ach_tf / peak_tf, 4),

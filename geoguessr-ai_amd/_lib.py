@@ -249,3 +249,18 @@ def stream() -> int:
 
 def f32(x: float) -> C.c_float:
     return C.c_float(float(x))
+
+
+def source_hash() -> str:
+    """sha256 over the sources libgg.so is built from (csrc/* and include/gg.h, in name order): identifies the build that a committed profile
+    (profiles/*_hbm_traffic_pmc_*.json) was measured on -- bench.py marks its traffic figure stale when the running tree differs."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(os.path.join(root, "csrc", f) for f in os.listdir(os.path.join(root, "csrc")) if f.endswith((".hip", ".h", ".cpp", "Makefile")))
+    files.append(os.path.join(os.path.dirname(root), "include", "gg.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()

@@ -64,7 +64,7 @@ __device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 
 
 // Epilogue shared by both NT kernels: lane holds C[m = m0 + wm*WROWS + mt*16 + lr][n = n0 + wn*WCOLS + nt*16 + lg*4 + r]; results leave straight
 // from the accumulator fragments (16-byte stores, 64-byte runs per row).  `smem`: at least 2*WM*BN floats, no longer read by anyone.
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int GNMAX = 2>
 __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
                                                   int tm, int wm, int wn, int lr, int lg) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
     // the epilogue's second tensor (BatchNorm-backward: saved conv output; GELU': saved pre-activation; linear: residual) for the whole
     // tile, all 16 loads in flight at once -- fetched inside the loop below they were 16 serialised memory round trips per tile
     constexpr bool AUX = EPI == FE_BNBWD || EPI == FE_DGELU || EPI == FE_LINEAR;
-    constexpr int GN = (TN * TM > 8) ? 2 : TN;               // n-tiles per prefetch group: at most 8 x 16 bytes per lane in flight (32 registers)
+    constexpr int GN = (TN * TM > 8) ? GNMAX : TN;           // n-tiles per prefetch group: at most 8 x 16 bytes per lane in flight (32 registers; 16 in the 4-per-CU form)
     const float* aux_src = EPI == FE_BNBWD ? p.bn_y : (EPI == FE_DGELU ? p.dact_preact : (EPI == FE_LINEAR ? p.residual : nullptr));
     const int64_t aux_ld = EPI == FE_LINEAR ? p.ldr : p.ldc;
     const bool aux_vec = (aux_ld & 3) == 0;
@@ -173,8 +173,13 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     }
                 }
                 if (ok && !((p.debug & 2) && v[0] != 12345.678f)) {
-                    float* g = p.C + (int64_t)m * p.ldc + n;
-                    if (full) { if (p.debug & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g)); else *reinterpret_cast<f32x4*>(g) = v; }
+                    float* g = p.C + (int64_t)((p.debug & 256) ? (m & 4095) : m) * p.ldc + n;      // (256: timing experiment, every store lands in a cache-resident 4096-row window)
+                    if (full) {
+                        if (p.debug & 32) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(v) : "memory");            // write-through (drops the L2 line)
+                        else if (p.debug & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g), "v"(v) : "memory");
+                        else if (p.debug & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
+                        else *reinterpret_cast<f32x4*>(g) = v;
+                    }
                     else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
                 }
             }
@@ -377,7 +382,11 @@ template <int IPW> __device__ __forceinline__ void wait_stages_outstanding(int n
 }
 // BNC < BN: the tile computes BNC columns (N = 96 / 576 ...: no MFMA work on padding) while the LDS image and the DMA pattern stay those of
 // the BN-row B panel -- rows >= BNC are outside the buffer resource's range and arrive as zeros without touching memory.
-template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN>
+// SB (single fragment buffer, NST = 2, OCC = 4): the small-K form.  With K <= 192 a tile is 6 - 12 stages long and a workgroup spends as long
+// waiting for its first operands and draining its epilogue as in the k-loop; what hides that is MORE resident workgroups, not a deeper
+// pipeline inside one.  One fragment register set (32 instead of 64 registers: 4 waves per SIMD) and a 2-stage ring (32 KB: 4 workgroups
+// per CU); the fragment reads of a stage are exposed to this wave, the three other waves of the SIMD fill the matrix pipe meanwhile.
+template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
     constexpr int BM = 128, SK = 16;
     constexpr int TM = BM / WM / 16, TN = BNC / WN / 16;
@@ -436,11 +445,39 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nk = (p.K + SK - 1) / SK;
+    if (SB) {
+        issue_stage(0);
+        wait_vmcnt<0>();
+    } else {
 #pragma unroll
-    for (int st = 0; st < NST; ++st)
-        if (st < nk) issue_stage(st);
-    wait_stages_outstanding<IPW>(min(nk, NST) - 1);             // stage 0 has landed (this wave's part) ...
+        for (int st = 0; st < NST; ++st)
+            if (st < nk) issue_stage(st);
+        wait_stages_outstanding<IPW>(min(nk, NST) - 1);         // stage 0 has landed (this wave's part) ...
+    }
     __builtin_amdgcn_s_barrier();                                 // ... and everybody else's
+    if (SB) {
+        f32x4 xs[TM], ws[TN];
+        if (p.trace) tr1 = wall_clock64();
+        for (int s = 0; s < nk; ++s) {
+            if (s > 0) {
+                wait_vmcnt<0>();                                  // this wave's DMAs of stage s have landed ...
+                __builtin_amdgcn_s_barrier();                     // ... everybody's have, and every wave has consumed stage s - 1 (its MFMAs needed the reads)
+            }
+            if (s + 1 < nk) issue_stage(s + 1);                   // NST == 2: into the buffer stage s - 1 occupied
+            frag_read(s, xs, ws);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < TM; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[nt][q], xs[mt][q], acc[nt][mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (p.trace) tr2 = wall_clock64();
+        gemm_f32_epilogue<BM, BNC, WM, WN, EPI, 1>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+        return;
+    }
     f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
     if (p.trace) tr1 = wall_clock64();
     frag_read(0, xa, wa);
@@ -667,6 +704,8 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.A2 = (const float*)a->A2; p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     const int rem = a->N % 128;
     bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
+    static const char* nk_env = getenv("GG_GEMM_F32_NARROW_K");      // A/B: 128 x 64 tiles (more, lighter workgroups per CU) for K <= this
+    if (nk_env && a->K <= atoi(nk_env)) narrow = true;
     // 96-column tiles (ring kernel only) when they cover N with less padding than both 128 and 64 would (N = 96, 288, ...: +14 % at N = 96;
     // at equal padding the 64-wide tile's 3 workgroups per CU win, N = 576: 126 vs 118 TFLOP/s)
     static const char* w96_env = getenv("GG_GEMM_F32_NO_W96");
@@ -703,9 +742,16 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     const int resident = 256 * (a->a_bn_stat ? 2 : (narrow ? 4 : 3));      // workgroups the persistent variants keep resident (launch bounds)
     dim3 grid((ring || np_env || p.tilesM * p.tilesN <= resident) ? p.tilesM * p.tilesN : resident);
     hipStream_t st = (hipStream_t)stream;
+    // the single-fragment-buffer form (4 workgroups per CU; 6 for the 128 x 64 tile) is the default for every K: +2...+7 % on the model's shapes
+    // against the double-buffered 3-per-CU form (tools/ab_gemm_sb.sh).  GG_GEMM_F32_SB=<K threshold> (0: off) for A/B runs
+    static const char* sb_env = getenv("GG_GEMM_F32_SB");
+    const int sb_k = sb_env ? atoi(sb_env) : (1 << 30);
+    const bool sb = ring && !wide96 && a->K <= sb_k;
 #define GG_LAUNCH_F32(E)                                                                                          \
     do {                                                                                                          \
-        if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
+        if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : 6), 64, true>), grid, dim3(256), 0, st, p); \
+        else if (sb) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true>), grid, dim3(256), 0, st, p); \
+        else if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
         else if (ring4 && !narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 4, 2>), grid, dim3(256), 0, st, p); \
         else if (ring && narrow && ringn == 43) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 3>), grid, dim3(256), 0, st, p); \
         else if (ring && narrow && ringn == 34) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 3, 4>), grid, dim3(256), 0, st, p); \

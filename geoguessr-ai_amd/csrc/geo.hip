@@ -273,11 +273,13 @@ __global__ void score_kernel(const T* __restrict__ pred, const T* __restrict__ t
     const double lon1 = (double)pred[2 * i] * d2r, lat1 = (double)pred[2 * i + 1] * d2r;
     const double lon2 = (double)truth[2 * i] * d2r, lat2 = (double)truth[2 * i + 1] * d2r;
     const double sa = sin((lat2 - lat1) / 2.0), sb = sin((lon2 - lon1) / 2.0);
-    const double a = fmin(sa * sa + cos(lat1) * cos(lat2) * (sb * sb), 1.0);
+    const double raw = sa * sa + cos(lat1) * cos(lat2) * (sb * sb);
+    const double a = fmin(raw, 1.0);                       // (fmin drops a NaN operand: non-finite inputs are caught on `raw` below)
     const double c = 2.0 * asin(sqrt(a));
     double km = (6371000.0 * c) / 1000.0;
-    if (dist_km) dist_km[i] = km;
-    if (!(fabs(km) <= 1.0e300)) { score[i] = -1; return; }
+    const bool finite = (raw == raw) && fabs(km) <= 1.0e300;
+    if (dist_km) dist_km[i] = finite ? km : raw;
+    if (!finite) { score[i] = -1; return; }
     if (km < 0.0) km = 0.0;
     double pts = 5000.0 * exp(-(km / 1492.7));
     pts = fmax(0.0, fmin(5000.0, pts));

@@ -580,7 +580,7 @@ def test_scoring_float64_inputs_and_non_finite_rows():
     bad = torch.tensor([[float("nan"), 0.0], [10.0, 20.0], [0.0, 0.0]], dtype=torch.float64).cuda()
     ok = torch.tensor([[0.0, 0.0], [-170.0, -20.0], [180.0, 0.0]], dtype=torch.float64).cuda()
     dd, ss = scoring.score_batch(bad, ok)
-    assert int(ss[0]) == -1 and np.isfinite(float(dd[1])) and abs(float(dd[1]) - np.pi * 6371.0) < 1e-6 and int(ss[1]) == 0
+    assert int(ss[0]) == -1 and not np.isfinite(float(dd[0])) and np.isfinite(float(dd[1])) and abs(float(dd[1]) - np.pi * 6371.0) < 1e-6 and int(ss[1]) == 0
     assert abs(float(dd[2]) - np.pi * 6371.0) < 1e-6
 
 
