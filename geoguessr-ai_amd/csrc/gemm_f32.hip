@@ -54,6 +54,9 @@ enum { FE_PLAIN = 0, FE_LINEAR = 1, FE_GELU = 2, FE_QGELU = 3, FE_DGELU = 4, FE_
 __device__ __forceinline__ float act_grad_exact_f(float x, int act) { return gg_act_grad_f32(x, act); }
 __device__ __forceinline__ float act_exact_f(float x, int act) { return gg_act_f32(x, act); }
 
+__device__ __forceinline__ float ror8_f(float v) {          // value of lane (l + 8) % 16 of the same 16-lane DPP row
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 lanes of a DPP row, result in every lane of the row
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
@@ -70,6 +73,9 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     const bool vec_c = (p.ldc & 3) == 0;
+    // full-line stores: a lane's 16 bytes of two neighbouring n-tiles are regrouped (one DPP row rotate) so that a store instruction writes
+    // 8 rows x 128 B (whole cache lines) instead of 16 rows x 64 B (every line in two halves, 4 stores apart)
+    const bool pair_store = TN >= 2 && vec_c && (p.ldc & 31) == 0 && (p.debug & 128) == 0;      // (debug 128: the 64-byte-run stores, for A/B)
         float* red = smem;                                    // [WM][2][BN] column partials (the k-loop's last barrier has passed)
     // the epilogue's second tensor (BatchNorm-backward: saved conv output; GELU': saved pre-activation; linear: residual) for the whole
     // tile, all 16 loads in flight at once -- fetched inside the loop below they were 16 serialised memory round trips per tile
@@ -136,6 +142,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 } else if (ok) {
                     const float rs = ((EPI == FE_LINEAR || EPI == FE_DGELU) && p.rowscale) ? p.rowscale[m / p.rows_per_scale] : 1.f;
                     v += b4;
+                    if (EPI == FE_GELU && pair_store && nt < (TN & ~1)) { acc[nt][mt] = v; continue; }      // pre-activation copy + activation happen at the paired store
                     if (EPI == FE_GELU) {
                         if (p.preact) {
                             float* g = p.preact + (int64_t)m * p.ldc + n;
@@ -172,6 +179,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                         v += aux[AUX ? gi : 0][AUX ? mt : 0];            // zeros without a residual
                     }
                 }
+                if (pair_store && nt < (TN & ~1)) { acc[nt][mt] = v; continue; }      // stored below, two n-tiles at a time
                 if (ok && !((p.debug & 2) && v[0] != 12345.678f)) {
                     float* g = p.C + (int64_t)((p.debug & 256) ? (m & 4095) : m) * p.ldc + n;      // (256: timing experiment, every store lands in a cache-resident 4096-row window)
                     if (full) {
@@ -193,6 +201,48 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                         const int col = wn * WCOLS + nt * 16 + lg * 4 + r;
                         red[(wm * 2 + 0) * BN + col] = a;
                         red[(wm * 2 + 1) * BN + col] = b;
+                    }
+                }
+            }
+        }
+    }
+    if (pair_store && !(p.debug & 2)) {
+        const int h = lr >> 3, l7 = lr & 7;
+#pragma unroll
+        for (int e = 0; e + 1 < TN; e += 2) {
+            const int ne = n0 + wn * WCOLS + e * 16 + lg * 4;
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const f32x4 ve = acc[e][mt], vo = acc[e + 1][mt];
+                // row_ror:8: the partner row's odd tile
+                const float x0 = ror8_f(vo[0]), x1 = ror8_f(vo[1]), x2 = ror8_f(vo[2]), x3 = ror8_f(vo[3]);
+                const f32x4 X = {x0, x1, x2, x3};
+                const int mb = m0 + wm * WROWS + mt * 16;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {          // store 1: rows mb .. mb+7, store 2: rows mb+8 .. mb+15; each row = the 128 B of tiles e | e+1
+                    const bool own = (h == half);
+                    f32x4 d = own ? ve : X;
+                    const int n = own ? ne : ne + 16;
+                    const int m = mb + 8 * half + l7;
+                    if (m < p.M && n < p.N) {
+                        const bool full4 = n + 3 < p.N;
+                        if (EPI == FE_GELU) {
+                            if (p.preact) {
+                                float* gp = p.preact + (int64_t)m * p.ldc + n;
+                                if (full4) __builtin_nontemporal_store(d, reinterpret_cast<f32x4*>(gp));
+                                else { for (int r = 0; r < 4; ++r) if (n + r < p.N) gp[r] = d[r]; }
+                            }
+                            if (p.quick) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) d[r] = d[r] / (1.0f + expf(-1.702f * d[r]));
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) d[r] = gelu_exact(d[r]);
+                            }
+                        }
+                        float* g = p.C + (int64_t)m * p.ldc + n;
+                        if (full4) *reinterpret_cast<f32x4*>(g) = d;
+                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = d[r]; }
                     }
                 }
             }
@@ -386,15 +436,23 @@ template <int IPW> __device__ __forceinline__ void wait_stages_outstanding(int n
 // waiting for its first operands and draining its epilogue as in the k-loop; what hides that is MORE resident workgroups, not a deeper
 // pipeline inside one.  One fragment register set (32 instead of 64 registers: 4 waves per SIMD) and a 2-stage ring (32 KB: 4 workgroups
 // per CU); the fragment reads of a stage are exposed to this wave, the three other waves of the SIMD fill the matrix pipe meanwhile.
-template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false>
+// PRO (SB form only): the A operand is transformed on its way from LDS to the matrix pipe -- PRO 1: A := a_act(A * sc[k] + sh[k]) (BatchNorm +
+// activation of the previous ConvNorm: MBConv conv3 reads conv2's saved pre-BatchNorm output), PRO 2: A := c0[k] A + c1[k] A2 + c2[k] (BatchNorm
+// backward's apply step; A2 rides the ring as a third operand panel).  The per-k coefficients live in LDS (K <= PTK = 384: every MBConv /
+// PatchMerging shape of the 5M / 11M / 21M models); rows beyond M and chunks beyond K are zeroed AFTER the transform (they feed the column
+// statistics / must not add the affine's constant term).  With WN == 1 (the 4 x 1 wave layout used for N <= 96) every A element is
+// transformed by exactly one wave.
+template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false, int PRO = 0>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
-    constexpr int BM = 128, SK = 16;
+    constexpr int BM = 128, SK = 16, PTK = 384;
     constexpr int TM = BM / WM / 16, TN = BNC / WN / 16;
     constexpr int WCOLS = BNC / WN;
-    constexpr int ROWS = BM + BN, STAGE = ROWS * SK;            // floats per stage
+    constexpr int ROWS = BM + BN + (PRO == 2 ? BM : 0), STAGE = ROWS * SK;      // floats per stage
     constexpr int IPW = ROWS / 16 / 4;                            // 1-KiB DMA instructions per wave per stage (16 rows x 64 B each)
-    constexpr int JA = BM / 64;                                   // the first JA of a wave's blocks are A rows, the rest B rows
+    constexpr int JA = BM / 64, JB = JA + BN / 64;                // of a wave's blocks the first JA are A rows, then B rows up to JB, then A2 rows
+    static_assert(PRO == 0 || SB, "the A prologues are built on the single-buffer form");
     __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];
+    __shared__ __attribute__((aligned(16))) float ptab[PRO ? 3 * PTK : 4];
     const int tiles = p.tilesM * p.tilesN;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     unsigned long long mt0 = 0;
@@ -413,14 +471,25 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     const unsigned bytesB = (unsigned)min(p.N - n0, BNC) * (unsigned)p.ldb * 4u;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
-    // DMA geometry: block blk = wave + 4 j covers tile rows 16 blk .. 16 blk + 15 (A rows first, then B rows) x 16 k: lane -> (row lane/4, 16-byte chunk lane%4)
+    const __amdgpu_buffer_rsrc_t rsA2 = PRO == 2 ? __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000) : rsA;
+    if (PRO == 1) {
+        for (int k = threadIdx.x; k < p.K; k += 256) {
+            const float sc = p.a_gamma[k] * p.a_stat[p.K + k];
+            ptab[k] = sc; ptab[PTK + k] = p.a_beta[k] - p.a_stat[k] * sc;
+        }
+    }
+    if (PRO == 2) {
+        for (int k = threadIdx.x; k < p.K; k += 256) { ptab[k] = p.a_stat[k]; ptab[PTK + k] = p.a_stat[p.K + k]; ptab[2 * PTK + k] = p.a_stat[2 * p.K + k]; }
+    }
+    if (PRO) __syncthreads();
+    // DMA geometry: block blk = wave + 4 j covers tile rows 16 blk .. 16 blk + 15 (A rows first, then B rows, then A2 rows) x 16 k: lane -> (row lane/4, 16-byte chunk lane%4)
     const int drow = lane >> 2, dch = lane & 3;
     unsigned voff[IPW];
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
         const int blk = wave + 4 * j;
-        const int row = (j < JA ? blk : blk - BM / 16) * 16 + drow;
-        voff[j] = (unsigned)row * (unsigned)(j < JA ? p.lda : p.ldb) * 4u + dch * 16u;
+        const int row = (j < JA ? blk : (j < JB ? blk - BM / 16 : blk - (BM + BN) / 16)) * 16 + drow;
+        voff[j] = (unsigned)row * (unsigned)((j < JA || j >= JB) ? p.lda : p.ldb) * 4u + dch * 16u;
     }
     auto issue_stage = [&](int st) {
         const int k0 = st * SK;
@@ -428,7 +497,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         float* base = smem + (st % NST) * STAGE;
 #pragma unroll
         for (int j = 0; j < IPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : rsB, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : (j < JB ? rsB : rsA2), (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
                                                      (int)(kin ? voff[j] : 0xFFFFFFF0u), k0 * 4, 0, 0);
     };
     const int a_off = (wm * (BM / WM) + lr) * SK + lg * 4, b_off = BM * SK + (wn * WCOLS + lr) * SK + lg * 4;
@@ -465,6 +534,27 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
             }
             if (s + 1 < nk) issue_stage(s + 1);                   // NST == 2: into the buffer stage s - 1 occupied
             frag_read(s, xs, ws);
+            if (PRO) {
+                const int kq = s * SK + lg * 4;                   // this lane's fragments hold contraction columns kq .. kq + 3 of 16 rows each
+                const bool kin = kq < p.K;
+                const int kc = min(kq, p.K - 4);
+                const f32x4 c0 = *reinterpret_cast<const f32x4*>(ptab + kc), c1 = *reinterpret_cast<const f32x4*>(ptab + PTK + kc);
+                const f32x4 c2 = PRO == 2 ? *reinterpret_cast<const f32x4*>(ptab + 2 * PTK + kc) : c0;
+                const float* base2 = smem + (s % NST) * STAGE + (BM + BN) * SK;
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) {
+                    const bool rok = kin && (m0 + wm * (BM / WM) + mt * 16 + lr < p.M);
+                    f32x4 v = xs[mt];
+                    if (PRO == 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = act_exact_f(fmaf(v[j], c0[j], c1[j]), p.a_act);
+                    } else {
+                        const f32x4 x2 = *reinterpret_cast<const f32x4*>(base2 + a_off + mt * 16 * SK);
+                        v = c0 * v + (c1 * x2 + c2);
+                    }
+                    xs[mt] = rok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -760,6 +850,22 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);           \
         else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);                      \
     } while (0)
+    static const char* pro_ring_env = getenv("GG_GEMM_F32_PRO_RING");      // A/B: "0" = the register-staged prologue kernels
+    if (a->a_bn_stat && a->K <= 384 && !(pro_ring_env && pro_ring_env[0] == '0') && (p.debug & 5) == 0) {
+        // prologue GEMMs on the LDS-DMA ring (single-buffer form): the transform is applied to the A fragments after the LDS read
+        dim3 rgrid(p.tilesM * p.tilesN);
+        if (a->A2) {        // PRO 2, linear epilogue; the third operand panel makes a stage 24 KB: 3 workgroups per CU
+            if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 4, 1, FE_LINEAR, 2, 3, 96, true, 2>), rgrid, dim3(256), 0, st, p);
+            else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, FE_LINEAR, 2, 4, 64, true, 2>), rgrid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, FE_LINEAR, 2, 3, 128, true, 2>), rgrid, dim3(256), 0, st, p);
+        } else {            // PRO 1, plain (+ column statistics) epilogue
+            if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 4, 1, FE_PLAIN, 2, 4, 96, true, 1>), rgrid, dim3(256), 0, st, p);
+            else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, FE_PLAIN, 2, 4, 64, true, 1>), rgrid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, FE_PLAIN, 2, 4, 128, true, 1>), rgrid, dim3(256), 0, st, p);
+        }
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     if (a->a_bn_stat) {       // prologue kernels: (PRO 1, plain epilogue) / (PRO 2, linear epilogue)
         if (a->A2) {
             if (wide96) hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, FE_LINEAR, 2, 96>), grid, dim3(256), 0, st, p);
