@@ -50,7 +50,8 @@ class ProtoRefineArgs(C.Structure):
                 ("candidate_cells", C.c_void_p), ("candidate_probs", C.c_void_p), ("num_candidates", C.c_int),
                 ("topk", C.c_int), ("cell_ptr", C.c_void_p), ("num_cells", C.c_int), ("proto_emb", C.c_void_p),
                 ("proto_lnglat", C.c_void_p), ("max_refinement", C.c_float), ("temperature", C.c_float),
-                ("out_llh", C.c_void_p), ("out_cell", C.c_void_p), ("out_idx", C.c_void_p)]
+                ("out_llh", C.c_void_p), ("out_cell", C.c_void_p), ("out_idx", C.c_void_p),
+                ("member_ptr", C.c_void_p), ("member_emb", C.c_void_p), ("member_lnglat", C.c_void_p)]
 
 
 class TinyVitCfg(C.Structure):

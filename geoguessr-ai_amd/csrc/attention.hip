@@ -922,7 +922,7 @@ extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
     GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 8.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
     const int nkt = attn_nkt(p.N);
 #define GG_FWD(D_, K_) hipLaunchKernelGGL((attn_fwd_kernel<D_, K_>), grid, block, 0, s, p)
-    static const char* small_env = getenv("GG_ATTN_SMALL");
+    static const char* small_env = gg_dev_env("GG_ATTN_SMALL");
     if (a->head_dim == 32 && nkt == 4 && !(small_env && small_env[0] == '0') && a->num_windows >= 64) {
         constexpr int GW = 8;          // windows per workgroup
         const dim3 g2((unsigned)(gg_cdiv(a->num_windows, GW) * a->num_heads));
@@ -958,7 +958,7 @@ extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
         if (p.dbias) hipLaunchKernelGGL((attn_bwd_kernel<32, K_, true>), grid, block, 0, s, p);          \
         else hipLaunchKernelGGL((attn_bwd_kernel<32, K_, false>), grid, block, 0, s, p);                 \
     } while (0)
-    static const char* small_env = getenv("GG_ATTN_SMALL");
+    static const char* small_env = gg_dev_env("GG_ATTN_SMALL");
     int part_rows = a->num_windows;
     if (nkt == 4 && !(small_env && small_env[0] == '0') && a->num_windows >= 64) {
         constexpr int GW = 8;

@@ -600,7 +600,7 @@ size_t flash_lds_fwd(const FlashParams& p, int D, int R) { return ((size_t)2 * R
 size_t flash_lds_dkv(const FlashParams& p, int D, int R, bool dbias) { return ((size_t)2 * R * (D + 4) + p.nbpad * (dbias ? 2 : 1) + 3 * R) * 4; }
 // resident form: more than one 64-row tile (a single tile is already staged once) and two workgroups still fit a CU's 160 KB
 bool flash_resident(const FlashParams& p, int D, bool dbias) {
-    static const bool off = getenv("GG_ATTN_FLASH_NO_RES") != nullptr;
+    static const bool off = gg_dev_env("GG_ATTN_FLASH_NO_RES") != nullptr;
     return !off && p.ntile > 1 && flash_lds_dkv(p, D, p.npad, dbias) <= 64 * 1024;
 }
 
@@ -647,7 +647,7 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
             8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
 #define GG_FL_BWD2(T_, D_, R_)                                                                                \
     do {                                                                                                      \
-        if (R_ && D_ == 32 && !getenv("GG_ATTN_DQ_QS1")) hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_, 2>), grid, dim3(64 * ((p.npad / 16 + 1) / 2)), lds_q, s, p); \
+        if (R_ && D_ == 32 && !gg_dev_env("GG_ATTN_DQ_QS1")) hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_, 2>), grid, dim3(64 * ((p.npad / 16 + 1) / 2)), lds_q, s, p); \
         else hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_>), grid, block, lds_q, s, p);                 \
         if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true, R_>), grid, block, lds_kv, s, p); \
         else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false, R_>), grid, block, lds_kv, s, p);        \

@@ -45,6 +45,14 @@ extern "C" const char* gg_last_error(void);
         if (r_ != 0) return r_; \
     } while (0)
 
+// Development switches (A/B timing of alternative kernels / schedules): read ONLY when GG_DEV_SWITCHES is set, so that a stray variable in a
+// production environment cannot move the library off its tested default path.  Every alternative a switch selects is also a shape fallback of
+// the default path; tests/test_gpu_switches.py runs the parity step under each group of switches.
+#include <stdlib.h>
+static inline const char* gg_dev_env(const char* name) {
+    static const bool on = getenv("GG_DEV_SWITCHES") != nullptr;
+    return on ? getenv(name) : nullptr;
+}
 static inline int64_t gg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t gg_align(int64_t a, int64_t b) { return gg_cdiv(a, b) * b; }
 

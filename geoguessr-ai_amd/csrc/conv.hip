@@ -1352,22 +1352,22 @@ static DwGeom dw_geom(int64_t npix, int C, int lds_floats_per_pp) {
 // stride-1 convs take the column-walking kernel: PX columns x C/NC channel groups per block (<= 256 threads), whole image height.
 // NC = 8 channels per thread, 4 for the doubly fused backward kernel.
 static int dw_walk_px(int C, int nc = 8) { return std::max(1, 256 / (C / nc)); }
-static bool dw_walk_ok(int C, int stride) { return stride == 1 && (C / 8) <= 256 && getenv("GG_DW_TILED") == nullptr; }
+static bool dw_walk_ok(int C, int stride) { return stride == 1 && (C / 8) <= 256 && gg_dev_env("GG_DW_TILED") == nullptr; }
 static bool dw_walk_fused4(int C) { return (C / 4) <= 256; }       // both fusions at once run 4 channels per thread
 // fused stride-1 forward (producer BatchNorm + activation on load): 4 output columns x 4 channels per thread
 static const int kDwMultiCols = 4;
 static bool dw_multi_ok(int C) {
     const int CG = C / 4, PX = std::max(1, 256 / std::max(CG, 1));
-    return (C & 3) == 0 && CG <= 256 && (size_t)PX * 2 * C * sizeof(float) <= 64 * 1024 && getenv("GG_DW_TILED") == nullptr &&
-           getenv("GG_DW_NO_MULTI") == nullptr;
+    return (C & 3) == 0 && CG <= 256 && (size_t)PX * 2 * C * sizeof(float) <= 64 * 1024 && gg_dev_env("GG_DW_TILED") == nullptr &&
+           gg_dev_env("GG_DW_NO_MULTI") == nullptr;
 }
-static bool dw_multi_plain(int C) { return getenv("GG_DW_NO_MULTI_PLAIN") == nullptr && dw_multi_ok(C); }      // the plain stride-1 forward too: half the loads per result (-8..15 % on 14x14 / 28x28 maps)
-static bool dw_multi_bwd(int C) { return getenv("GG_DW_NO_MULTI_BWD") == nullptr && dw_multi_ok(C); }          // stride-1 data gradients (plain and fused)
+static bool dw_multi_plain(int C) { return gg_dev_env("GG_DW_NO_MULTI_PLAIN") == nullptr && dw_multi_ok(C); }      // the plain stride-1 forward too: half the loads per result (-8..15 % on 14x14 / 28x28 maps)
+static bool dw_multi_bwd(int C) { return gg_dev_env("GG_DW_NO_MULTI_BWD") == nullptr && dw_multi_ok(C); }          // stride-1 data gradients (plain and fused)
 static const int kDwMultiColsEpi = 2;       // variants with the act'(BN) epilogue: 2 columns per thread (4 spill at 256 registers)
 static int dw_multi_nbx(int W, int C, int ncol = kDwMultiCols) { return (int)gg_cdiv(W, std::max(1, 256 / (C / 4)) * ncol); }
 // stride-2 forward: the walking kernel when its per-thread state fits (8 channels per thread, <= 256 channel groups) and the image fits the
 // 30-bit offsets; GG_DW_TILED keeps the LDS-tiled kernel
-static bool dw_s2_walk_ok(int C) { return (C / 8) <= 256 && (C & 7) == 0 && getenv("GG_DW_TILED") == nullptr && getenv("GG_DW_S2_TILED") == nullptr; }
+static bool dw_s2_walk_ok(int C) { return (C / 8) <= 256 && (C & 7) == 0 && gg_dev_env("GG_DW_TILED") == nullptr && gg_dev_env("GG_DW_S2_TILED") == nullptr; }
 static int dwconv_s2_walk_launch(const void* x, const float* wt, void* y, int B, int H, int W, int C, float* colstats, void* stream,
                                  const DwWalkFuse* fuse) {
     GG_CHECK((int64_t)H * W * C * 2 < 0x40000000LL, "dwconv: image too large for 30-bit offsets");

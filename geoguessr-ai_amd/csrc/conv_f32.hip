@@ -422,7 +422,7 @@ WalkGeom multi_geom(int B, int H, int W, int C) {
     return g;
 }
 bool dw_use_multi(int stride) {
-    static const bool off = getenv("GG_DW_F32_NO_MULTI") != nullptr;
+    static const bool off = gg_dev_env("GG_DW_F32_NO_MULTI") != nullptr;
     return stride == 1 && !off;
 }
 int grid_for(int64_t n, int cap = 16384) { return (int)std::max<int64_t>(1, std::min<int64_t>(gg_cdiv(n, 256), cap)); }

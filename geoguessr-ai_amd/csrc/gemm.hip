@@ -796,9 +796,9 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     kps = (int)gg_align(kps, BK);
     p.k_per_split = kps;
     // tile choice: HBM-bound shapes (short K loop or a single narrow N tile) take the light 128x64 tile
-    static const char* dbg = getenv("GG_GEMM_DEBUG");
+    static const char* dbg = gg_dev_env("GG_GEMM_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
-    static const char* force = getenv("GG_GEMM_TILE");
+    static const char* force = gg_dev_env("GG_GEMM_TILE");
     const int rem = a->N % 128;
     bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);     // a 128-wide tile would be at most half full
     if (force) narrow = force[0] == 'n';

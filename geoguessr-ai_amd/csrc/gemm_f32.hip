@@ -38,7 +38,6 @@ struct F32GemmParams {
     // PRO 2: A := coef0*A + coef1*A2 + coef2 (a_stat = coef [3][K]: BatchNorm backward's apply step formed while staging)
     const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
     unsigned long long* trace;      // dev (gg_gemm_f32_set_trace): per-workgroup [hw_id, xcc_id, t_start, t_first_data, t_loop_end, t_epilogue_end, tile, 0] (100 MHz ticks)
-    int stagger;        // experiment (GG_GEMM_F32_STAGGER): first-round workgroups start hash(blockIdx) * stagger * 0.45 us late
     int quick;          // FE_GELU / FE_DGELU: the activation is QuickGELU (CLIP) instead of erf GELU
 };
 
@@ -181,13 +180,8 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 }
                 if (pair_store && nt < (TN & ~1)) { acc[nt][mt] = v; continue; }      // stored below, two n-tiles at a time
                 if (ok && !((p.debug & 2) && v[0] != 12345.678f)) {
-                    float* g = p.C + (int64_t)((p.debug & 256) ? (m & 4095) : m) * p.ldc + n;      // (256: timing experiment, every store lands in a cache-resident 4096-row window)
-                    if (full) {
-                        if (p.debug & 32) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(v) : "memory");            // write-through (drops the L2 line)
-                        else if (p.debug & 64) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(g), "v"(v) : "memory");
-                        else if (p.debug & 8) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g));
-                        else *reinterpret_cast<f32x4*>(g) = v;
-                    }
+                    float* g = p.C + (int64_t)m * p.ldc + n;
+                    if (full) *reinterpret_cast<f32x4*>(g) = v;
                     else { for (int r = 0; r < 4; ++r) if (n + r < p.N) g[r] = v[r]; }
                 }
             }
@@ -457,10 +451,6 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     unsigned long long mt0 = 0;
     if (p.trace) { tr0 = wall_clock64(); mt0 = __builtin_readcyclecounter(); }
-    if (p.stagger > 0 && blockIdx.x < 256 * OCC) {
-        const int d = (int)((blockIdx.x * 2654435761u) >> 28) * p.stagger;
-        for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(16);
-    }
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
     const int tm = bid / p.tilesN, tn = bid % p.tilesN;
     const int m0 = tm * BM, n0 = tn * BNC;
@@ -794,21 +784,17 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.A2 = (const float*)a->A2; p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     const int rem = a->N % 128;
     bool narrow = a->N <= 64 || (rem != 0 && rem <= 64);
-    static const char* nk_env = getenv("GG_GEMM_F32_NARROW_K");      // A/B: 128 x 64 tiles (more, lighter workgroups per CU) for K <= this
-    if (nk_env && a->K <= atoi(nk_env)) narrow = true;
     // 96-column tiles (ring kernel only) when they cover N with less padding than both 128 and 64 would (N = 96, 288, ...: +14 % at N = 96;
     // at equal padding the 64-wide tile's 3 workgroups per CU win, N = 576: 126 vs 118 TFLOP/s)
-    static const char* w96_env = getenv("GG_GEMM_F32_NO_W96");
+    static const char* w96_env = gg_dev_env("GG_GEMM_F32_NO_W96");
     const int64_t pad96 = gg_cdiv(a->N, 96) * 96, pad128 = gg_cdiv(a->N, 128) * 128, pad64 = gg_cdiv(a->N, 64) * 64;
     const bool wide96 = !w96_env && a->N > 64 && pad96 < pad128 && pad96 < pad64;
     if (wide96) narrow = false;
     const int bn = wide96 ? 96 : (narrow ? 64 : 128);
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
-    static const char* dbg = getenv("GG_GEMM_F32_DEBUG");
+    static const char* dbg = gg_dev_env("GG_GEMM_F32_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
     p.trace = g_f32_trace;
-    static const char* stg = getenv("GG_GEMM_F32_STAGGER");
-    p.stagger = stg ? atoi(stg) : 0;
     const double mn = (double)a->M * a->N;
     GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
             4.0 * ((double)a->M * a->K * (a->A2 ? 2 : 1) + (double)a->N * a->K + mn) +
@@ -823,18 +809,15 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     else epi = FE_PLAIN;
     // default: the LDS-DMA ring kernel, one workgroup per tile.  GG_GEMM_F32_RING=0: the register-staged kernel with persistent
     // workgroups (at most the resident count, each walks tiles t, t + grid, ...) -- kept for A/B timing and the DEBUG ablations
-    static const char* ring_env = getenv("GG_GEMM_F32_RING");
-    static const char* np_env = getenv("GG_GEMM_F32_NO_PERSIST");
+    static const char* ring_env = gg_dev_env("GG_GEMM_F32_RING");
+    static const char* np_env = gg_dev_env("GG_GEMM_F32_NO_PERSIST");
     const bool ring = ((!(ring_env && ring_env[0] == '0') && (p.debug & 5) == 0) || wide96) && !a->a_bn_stat;
-    const bool ring4 = ring && ring_env && ring_env[0] == '4';      // A/B: the 4-stage ring at 2 workgroups per CU
-    static const char* ringn_env = getenv("GG_GEMM_F32_RINGN");     // A/B for the 128x64 tile: "43" = 4 stages, 3 WG/CU; "34" = 3 stages, 4 WG/CU
-    const int ringn = ringn_env ? atoi(ringn_env) : 0;
     const int resident = 256 * (a->a_bn_stat ? 2 : (narrow ? 4 : 3));      // workgroups the persistent variants keep resident (launch bounds)
     dim3 grid((ring || np_env || p.tilesM * p.tilesN <= resident) ? p.tilesM * p.tilesN : resident);
     hipStream_t st = (hipStream_t)stream;
     // the single-fragment-buffer form (4 workgroups per CU; 6 for the 128 x 64 tile) is the default for every K: +2...+7 % on the model's shapes
     // against the double-buffered 3-per-CU form (tools/ab_gemm_sb.sh).  GG_GEMM_F32_SB=<K threshold> (0: off) for A/B runs
-    static const char* sb_env = getenv("GG_GEMM_F32_SB");
+    static const char* sb_env = gg_dev_env("GG_GEMM_F32_SB");
     const int sb_k = sb_env ? atoi(sb_env) : (1 << 30);
     const bool sb = ring && !wide96 && a->K <= sb_k;
 #define GG_LAUNCH_F32(E)                                                                                          \
@@ -842,15 +825,12 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : 6), 64, true>), grid, dim3(256), 0, st, p); \
         else if (sb) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true>), grid, dim3(256), 0, st, p); \
         else if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
-        else if (ring4 && !narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 4, 2>), grid, dim3(256), 0, st, p); \
-        else if (ring && narrow && ringn == 43) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 3>), grid, dim3(256), 0, st, p); \
-        else if (ring && narrow && ringn == 34) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 3, 4>), grid, dim3(256), 0, st, p); \
         else if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 2>), grid, dim3(256), 0, st, p);    \
         else if (ring) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3>), grid, dim3(256), 0, st, p);       \
         else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_kernel<64, 4, 1, E>), grid, dim3(256), 0, st, p);           \
         else hipLaunchKernelGGL((gemm_nt_f32_kernel<128, 2, 2, E>), grid, dim3(256), 0, st, p);                      \
     } while (0)
-    static const char* pro_ring_env = getenv("GG_GEMM_F32_PRO_RING");      // A/B: "0" = the register-staged prologue kernels
+    static const char* pro_ring_env = gg_dev_env("GG_GEMM_F32_PRO_RING");      // A/B: "0" = the register-staged prologue kernels
     if (a->a_bn_stat && a->K <= 384 && !(pro_ring_env && pro_ring_env[0] == '0') && (p.debug & 5) == 0) {
         // prologue GEMMs on the LDS-DMA ring (single-buffer form): the transform is applied to the A fragments after the LDS read
         dim3 rgrid(p.tilesM * p.tilesN);

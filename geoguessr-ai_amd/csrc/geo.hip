@@ -202,7 +202,9 @@ __global__ __launch_bounds__(64) void proto_refine_kernel(const float* __restric
                                                           const int64_t* __restrict__ cell_ptr, int num_cells,
                                                           const float* __restrict__ proto_emb, const float* __restrict__ proto_ll, int topk,
                                                           float max_refinement, float temperature, float* __restrict__ out_llh,
-                                                          int64_t* __restrict__ out_cell, int64_t* __restrict__ out_idx) {
+                                                          int64_t* __restrict__ out_cell, int64_t* __restrict__ out_idx,
+                                                          const int64_t* __restrict__ member_ptr, const float* __restrict__ member_emb,
+                                                          const float* __restrict__ member_ll) {
     extern __shared__ float e[];   // D floats: the query embedding (mean over V views)
     const int b = blockIdx.x, lane = threadIdx.x;
     for (int d = lane; d < D; d += 64) {
@@ -229,7 +231,21 @@ __global__ __launch_bounds__(64) void proto_refine_kernel(const float* __restric
             if (logit > best) { best = logit; bestp = pi; }   // first maximum, like torch.argmax
         }
         if (bestp < 0) { top_d[c] = -100000.0f; top_lon[c] = 0.f; top_lat[c] = 0.f; }
-        else { top_d[c] = best; top_lon[c] = proto_ll[2 * bestp]; top_lat[c] = proto_ll[2 * bestp + 1]; }
+        else {
+            top_d[c] = best; top_lon[c] = proto_ll[2 * bestp]; top_lat[c] = proto_ll[2 * bestp + 1];
+            // _within_cluster_refinement (:239-269): the member at argmax of the Euclidean distances (first maximum) answers for the cluster
+            const int64_t m0 = member_ptr ? member_ptr[bestp] : 0, m1 = member_ptr ? member_ptr[bestp + 1] : 0;
+            float far = -INFINITY;
+            for (int64_t mi = m0; mi < m1; ++mi) {
+                float s = 0.f;
+                for (int d = lane; d < D; d += 64) {
+                    const float df = member_emb[mi * D + d] - e[d];
+                    s += df * df;
+                }
+                s = sqrtf(gg_wave_sum(s));
+                if (s > far) { far = s; top_lon[c] = member_ll[2 * mi]; top_lat[c] = member_ll[2 * mi + 1]; }
+            }
+        }
     }
     if (lane == 0) {
         float ex[8], sum = 0.f;
@@ -418,9 +434,11 @@ extern "C" int gg_proto_refine(const GgProtoRefineArgs* a, void* stream) {
     GG_CHECK(a->topk > 0 && a->topk <= 8 && a->topk <= a->num_candidates,
              "gg_proto_refine: \"topk\" must be <= number of candidates passed (and <= 8): topk=%d candidates=%d", a->topk, a->num_candidates);
     GG_CHECK(a->out_llh && a->out_cell && a->out_idx, "gg_proto_refine: null output");
+    GG_CHECK(!a->member_ptr || (a->member_emb && a->member_lnglat), "gg_proto_refine: member_ptr without member_emb / member_lnglat");
     hipLaunchKernelGGL(proto_refine_kernel, dim3(a->B), dim3(64), (size_t)a->D * sizeof(float), (hipStream_t)stream, a->embedding, a->V,
                        a->D, a->initial_preds, a->candidate_cells, a->candidate_probs, a->num_candidates, a->cell_ptr, a->num_cells,
-                       a->proto_emb, a->proto_lnglat, a->topk, a->max_refinement, a->temperature, a->out_llh, a->out_cell, a->out_idx);
+                       a->proto_emb, a->proto_lnglat, a->topk, a->max_refinement, a->temperature, a->out_llh, a->out_cell, a->out_idx,
+                       a->member_ptr, a->member_emb, a->member_lnglat);
     GG_LAUNCH_CHECK();
     return 0;
 }

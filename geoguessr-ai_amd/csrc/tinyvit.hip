@@ -352,22 +352,22 @@ struct Exec {
     // loaded (and transformed) by its three neighbouring columns: the erf work triples and the conv turns VALU-bound
     // (measured at 1024 images: +4.7 ms conv vs -2.7 ms elementwise) -> off by default.
     bool f32 = false;       // reference-precision mode: f32 activations / cached weights, f32 MFMA, every fusion below off (set by exec_init)
-    bool fuse_dw = getenv("GG_FUSE_DW") != nullptr;
+    bool fuse_dw = gg_dev_env("GG_FUSE_DW") != nullptr;
     // the stride-2 depthwise conv of PatchMerging stages its input tile in LDS: BatchNorm1 + GELU are applied once per staged element
     // (17x17 inputs per 8x8 outputs = 1.13x), the apply pass and the activation tensor disappear
-    bool fuse_dw_s2 = getenv("GG_NO_FUSE_DW_S2") == nullptr;
+    bool fuse_dw_s2 = gg_dev_env("GG_NO_FUSE_DW_S2") == nullptr;
     // MBConv.conv2 likewise through the 4-columns-per-thread stride-1 kernel (1.5 BatchNorm+GELU evaluations per input element)
-    bool fuse_dw_s1 = getenv("GG_NO_FUSE_DW_S1") == nullptr;
+    bool fuse_dw_s1 = gg_dev_env("GG_NO_FUSE_DW_S1") == nullptr;
     // Frozen depthwise taps: the data gradient forms BatchNorm backward's apply step (dy = c0*dz + c1*y + c2) while it loads its
     // input, and (MBConv) emits dz = da*act'(BN(y)) + the reduce sums of the ConvNorm in front: apply and reduce passes and
     // the dy / da tensors disappear.  GG_NO_FUSE_BNBWD=1 / GG_NO_FUSE_BNBWD_EPI=1 restore the separate passes.
-    bool fuse_bnbwd = getenv("GG_NO_FUSE_BNBWD") == nullptr;
-    bool fuse_bnbwd_epi = getenv("GG_NO_FUSE_BNBWD_EPI") == nullptr;
+    bool fuse_bnbwd = gg_dev_env("GG_NO_FUSE_BNBWD") == nullptr;
+    bool fuse_bnbwd_epi = gg_dev_env("GG_NO_FUSE_BNBWD_EPI") == nullptr;
     // Frozen ConvNorm chains: BatchNorm backward's reduce rides in the epilogue of the conv dgrad that produces its input
     // gradient, and its apply step is folded into the weights of the 1x1 dgrad that consumes its output gradient.
-    bool fuse_bngemm = getenv("GG_NO_BNGEMM") == nullptr;
+    bool fuse_bngemm = gg_dev_env("GG_NO_BNGEMM") == nullptr;
     // MBConv conv3 applies BatchNorm2 + GELU in its A prologue (one N tile: each element is transformed once)
-    bool fuse_pro = getenv("GG_NO_PRO") == nullptr;
+    bool fuse_pro = gg_dev_env("GG_NO_PRO") == nullptr;
     bool fuse_lnbn = true;           // fp32: local_conv's BatchNorm apply inside norm2 (off with GG_F32_NO_FUSE)
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
@@ -376,7 +376,7 @@ struct Exec {
         f32 = m->f32;
         // reference-precision mode: the same fusions where an f32 twin exists (MBConv / PatchMerging forward, the stride-1 data gradients, the
         // GEMM-side BatchNorm epilogue / prologues); GG_F32_NO_FUSE=1 runs every BatchNorm pass on its own (the schedule the fusions are tested against)
-        if (f32 && getenv("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = fuse_lnbn = false;
+        if (f32 && gg_dev_env("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = fuse_lnbn = false;
         if (f32) fuse_dw = false;
     }
     act_t* A(int64_t off) const { return reinterpret_cast<act_t*>(ws + off); }

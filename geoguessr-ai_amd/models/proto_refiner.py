@@ -8,8 +8,11 @@ keeps as one HF ``Dataset`` per geocell (:104-113).  The constructor builds it t
 ``ProtoDataManager`` -> per-cluster mean embeddings (built on the GPU by ``gg_segment_mean`` or loaded from
 ``data/geocells/protos/proto_{i}``) -- or from a ready table (``from_clusters``).
 
-Within-cluster refinement (:239-269) uses the cluster centroid -- the only branch that can execute in the reference as
-shipped (``self.dataset`` is undefined at :254).
+Within-cluster refinement (:239-269): by default a cluster answers with its centroid -- the only branch that can execute in the
+reference as shipped (``self.dataset`` is undefined at :254).  ``within_cluster=True`` runs the branch the reference's code
+describes: a per-cluster member table (view-averaged member embeddings + their (lng, lat) labels, built from the same per-panorama
+embeddings the prototypes are built from, or passed in) rides along, and a cluster with members answers with the member at ``argmax`` of
+the Euclidean distances (:262-268, restated as written), inside the same launch.
 """
 from __future__ import annotations
 
@@ -41,7 +44,8 @@ class ProtoRefiner(nn.Module):
     def __init__(self, topk: int = 5, max_refinement: int = 1000, temperature: float = 1.6, proto_path: str = PROTO_PATH,
                  protos=None, verbose: bool = False, clip_db_path: str = "data/sqlite/clip/dataset.sqlite",
                  tinyvit_db_path: str = "data/sqlite/tinyvit/dataset.sqlite", backend: str = "clip", cell_ptr=None, proto_emb=None,
-                 proto_lnglat=None, embeddings=None, latlon_by_index=None, protos_dir: str = PROTOS_DIR, save_protos: bool = True):
+                 proto_lnglat=None, embeddings=None, latlon_by_index=None, protos_dir: str = PROTOS_DIR, save_protos: bool = True,
+                 within_cluster: bool = False, member_ptr=None, member_emb=None, member_lnglat=None):
         super().__init__()
         self.topk = topk
         self.max_refinement = max_refinement
@@ -52,6 +56,7 @@ class ProtoRefiner(nn.Module):
         self.backend = backend
         self.temperature = Parameter(torch.tensor(float(temperature)), requires_grad=False)
         self.geo_scaling = Parameter(torch.tensor(20.0), requires_grad=False)
+        self.within_cluster = bool(within_cluster)
         if cell_ptr is None:
             import pandas as pd
             from .utils import ProtoDataManager
@@ -76,11 +81,25 @@ class ProtoRefiner(nn.Module):
             cell_ptr = np.concatenate([[0], np.cumsum(np.bincount(gi, minlength=num_geocells))]).astype(np.int64)
             proto_emb = np.asarray(tab["embedding"], np.float32)[order]
             proto_lnglat = np.stack([tab["centroid_lng"], tab["centroid_lat"]], 1).astype(np.float32)[order]
+            if self.within_cluster and member_ptr is None:
+                member_ptr, member_emb, member_lnglat = self._member_table(order, embeddings, latlon_by_index,
+                                                                           clip_db_path if backend == "clip" else tinyvit_db_path)
         self.register_buffer("cell_ptr", torch.as_tensor(np.asarray(cell_ptr), dtype=torch.int64).contiguous())
         self.register_buffer("proto_emb", torch.as_tensor(np.asarray(proto_emb), dtype=torch.float32).contiguous())
         self.register_buffer("proto_lnglat", torch.as_tensor(np.asarray(proto_lnglat), dtype=torch.float32).contiguous())
         self.num_geocells = self.cell_ptr.numel() - 1
         assert self.proto_emb.shape[0] == self.proto_lnglat.shape[0] == int(self.cell_ptr[-1])
+        if self.within_cluster:
+            if member_ptr is None:
+                raise ValueError("within_cluster=True needs the member table (member_ptr / member_emb / member_lnglat) or per-panorama embeddings")
+            mp = torch.as_tensor(np.asarray(member_ptr), dtype=torch.int64).contiguous()
+            assert mp.numel() == self.proto_emb.shape[0] + 1, "member_ptr must have one entry per prototype row + 1"
+            me = torch.as_tensor(np.asarray(member_emb) if not torch.is_tensor(member_emb) else member_emb, dtype=torch.float32)
+            me = (me.mean(dim=1) if me.dim() == 3 else me).contiguous()                  # (n, 4, D) member embeddings are averaged over views (:258-260)
+            assert me.shape[0] == int(mp[-1]) and me.shape[1] == self.proto_emb.shape[1]
+            self.register_buffer("member_ptr", mp)
+            self.register_buffer("member_emb", me)
+            self.register_buffer("member_lnglat", torch.as_tensor(np.asarray(member_lnglat), dtype=torch.float32).contiguous())
 
     # ---- prototype build / load (models/proto_refiner.py:271-345) ---------------------------------------------------------
     def _build_prototypes(self, embeddings, latlon_by_index, db_path):
@@ -97,6 +116,29 @@ class ProtoRefiner(nn.Module):
         protos = build_prototypes_from_members(emb, tab["ptr"], tab["member"], latlon_by_index)
         tab["embedding"] = protos.cpu().numpy()
         return tab
+
+    def _member_table(self, order, embeddings, latlon_by_index, db_path):
+        """CSR member lists per prototype row (rows in the order the prototype table ends up in): the proto_df ``indices`` of each cluster that
+        point at a valid sample, with the samples' view-averaged embeddings and (lng, lat) labels -- what ``self.dataset["train"][cluster["indices"]]``
+        would hand the reference's ``_within_cluster_refinement`` (:254-268)."""
+        if embeddings is None:
+            from ..embedding_store import read_panorama_embeddings
+            embeddings, latlon_by_index = read_panorama_embeddings(db_path)
+        if latlon_by_index is None:
+            raise ValueError("within_cluster=True needs latlon_by_index (the samples' (lat, lon) labels)")
+        emb = torch.as_tensor(np.asarray(embeddings) if not torch.is_tensor(embeddings) else embeddings, dtype=torch.float32)
+        emb = emb.mean(dim=1) if emb.dim() == 3 else emb
+        ll = np.asarray(latlon_by_index, np.float64)
+        tab = self.proto_manager.cluster_table()
+        ptr, member = np.asarray(tab["ptr"], np.int64), np.asarray(tab["member"], np.int64)
+        lists = []
+        for j in order:
+            m = member[ptr[j]:ptr[j + 1]]
+            m = m[(m >= 0) & (m < min(len(ll), emb.shape[0]))]
+            lists.append(m[np.isfinite(ll[m]).all(axis=1)] if m.size else m)
+        mptr = np.concatenate([[0], np.cumsum([len(m) for m in lists])]).astype(np.int64)
+        flat = np.concatenate(lists) if lists and mptr[-1] > 0 else np.zeros((0,), np.int64)
+        return mptr, emb[torch.from_numpy(flat)], np.stack([ll[flat, 1], ll[flat, 0]], 1).astype(np.float32)       # labels as (lng, lat)
 
     @staticmethod
     def _table_from_cells(cells):
@@ -148,6 +190,13 @@ class ProtoRefiner(nn.Module):
         ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         emb = np.asarray(embeddings, np.float32)[order]
         ll = np.stack([np.asarray(centroid_lng, np.float32), np.asarray(centroid_lat, np.float32)], 1)[order]
+        if kw.get("member_ptr") is not None:          # member lists arrive in the caller's cluster order: carry them through the sort
+            mp = np.asarray(kw["member_ptr"], np.int64)
+            me, ml = np.asarray(kw["member_emb"], np.float32), np.asarray(kw["member_lnglat"], np.float32)
+            rows = [np.arange(mp[j], mp[j + 1]) for j in order]
+            flat = np.concatenate(rows) if rows else np.zeros((0,), np.int64)
+            kw.update(member_ptr=np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64), member_emb=me[flat], member_lnglat=ml[flat],
+                      within_cluster=True)
         return cls(cell_ptr=ptr, proto_emb=emb, proto_lnglat=ll, **kw)
 
     def __str__(self):
@@ -182,6 +231,8 @@ class ProtoRefiner(nn.Module):
         a.proto_emb, a.proto_lnglat = L.ptr(self.proto_emb), L.ptr(self.proto_lnglat)
         a.max_refinement, a.temperature = float(self.max_refinement), float(self.temperature.item())
         a.out_llh, a.out_cell, a.out_idx = L.ptr(out_llh), L.ptr(out_cell), L.ptr(out_idx)
+        if self.within_cluster:
+            a.member_ptr, a.member_emb, a.member_lnglat = L.ptr(self.member_ptr), L.ptr(self.member_emb), L.ptr(self.member_lnglat)
         L.check(L.lib().gg_proto_refine(C.byref(a), L.stream()), "gg_proto_refine")
         self.last_guess_index = out_idx
         if self.verbose:

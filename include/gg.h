@@ -279,6 +279,11 @@ typedef struct GgProtoRefineArgs {
     const float* proto_lnglat;            /* f32 (P,2) */
     float max_refinement, temperature;
     float* out_llh; int64_t* out_cell; int64_t* out_idx;
+    /* optional within-cluster refinement (models/proto_refiner.py:239-269): members of prototype (cluster) j are rows member_ptr[j]..member_ptr[j+1]
+     * of member_emb (f32 (Nm,D), already averaged over views) / member_lnglat (f32 (Nm,2)).  A cluster with members answers with the coordinates of
+     * the member at torch.argmax of the Euclidean distances (the reference's choice, :264-265); an empty cluster, or member_ptr == NULL, with its
+     * centroid (:251-252). */
+    const int64_t* member_ptr; const float* member_emb; const float* member_lnglat;
 } GgProtoRefineArgs;
 int gg_proto_refine(const GgProtoRefineArgs* args, void* stream);
 /* run_benchmark.py:25-65: dist_km[i] = haversine_np (fp64, R = 6371 km; may be NULL), score[i] = geoguessr_score_from_distance =

@@ -5,8 +5,9 @@ TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  Helpers PINNED by
 ``tests/golden/proto_helpers.npz`` (reference ``_euclidean_distance`` :364-376,
 ``_temperature_softmax`` :378-389, ``preprocessing/geo_utils.haversine`` :39-54).  The
 reference ``forward`` itself cannot run as shipped (hard-coded "cuda", undefined
-``self.dataset`` at :254 -- SURVEY.md C10), so the loop below restates it line by line with
-the only within-cluster branch that works as shipped: the cluster centroid (:251-252).
+``self.dataset`` at :254 -- SURVEY.md C10), so the loop below restates it line by line; the
+within-cluster step (:239-269) answers with the cluster centroid for an empty cluster (the only branch that runs as shipped) and, when
+a member table is supplied, with the member the reference's code selects.
 
 Prototype table: ``cell_ptr`` (K+1,) int, prototypes of cell c are rows
 ``cell_ptr[c]:cell_ptr[c+1]`` of ``proto_emb`` (P,D) f32 / ``proto_lnglat`` (P,2) f32.
@@ -41,8 +42,20 @@ def haversine_gate_km(a: np.ndarray, b: np.ndarray) -> float:
     return float(np.float64(EARTH_RADIUS_M) * np.float64(c) / 1000.0)
 
 
+def within_cluster(emb, j, proto_lnglat, member_ptr, member_emb, member_lnglat):
+    """models/proto_refiner.py:239-269 for prototype row j: count == 0 (no members) -> the cluster centroid (:251-252); otherwise the labels of the
+    member at ``torch.argmax`` of the Euclidean distances between the member embeddings and the query (:262-268 -- the reference takes the
+    LARGEST distance; restated as written)."""
+    if member_ptr is None or member_ptr[j + 1] == member_ptr[j]:
+        return float(proto_lnglat[j, 0]), float(proto_lnglat[j, 1])
+    lo, hi = int(member_ptr[j]), int(member_ptr[j + 1])
+    k = int(np.argmax(euclidean_distance(member_emb[lo:hi], emb)))
+    return float(member_lnglat[lo + k, 0]), float(member_lnglat[lo + k, 1])
+
+
 def refine(embedding, initial_preds, candidate_cells, candidate_probs, cell_ptr, proto_emb,
-           proto_lnglat, topk: int = 5, max_refinement: float = 1000.0, temperature: float = 1.6):
+           proto_lnglat, topk: int = 5, max_refinement: float = 1000.0, temperature: float = 1.6,
+           member_ptr=None, member_emb=None, member_lnglat=None):
     """Returns (preds_LLH (B,2) f32, preds_geocell (B,) i64, guess_index (B,) i64)."""
     if embedding.ndim == 3:
         embedding = embedding.mean(axis=1)                      # :150-151
@@ -64,7 +77,7 @@ def refine(embedding, initial_preds, candidate_cells, candidate_probs, cell_ptr,
             logits = -euclidean_distance(proto_emb[lo:hi], emb)  # :190
             j = int(np.argmax(logits))                           # :194
             top_d.append(float(logits[j]))
-            top_p.append((float(proto_lnglat[lo + j, 0]), float(proto_lnglat[lo + j, 1])))
+            top_p.append(within_cluster(emb, lo + j, proto_lnglat, member_ptr, member_emb, member_lnglat))      # :201-202
         probs = temperature_softmax(np.asarray(top_d, np.float32), temperature)   # :205-206
         c = candidate_probs[i, :topk].astype(np.float32)
         final = c * probs                                        # :210

@@ -587,6 +587,45 @@ def test_proto_refine_matches_oracle():
     np.testing.assert_array_equal(ref.last_guess_index.cpu().numpy(), o_idx)
 
 
+def test_proto_refine_within_cluster_matches_oracle():
+    """within_cluster=True (models/proto_refiner.py:239-269): a cluster with members answers with the member at argmax of the Euclidean distances,
+    an empty cluster with its centroid; (n, 4, D) member embeddings are averaged over views first.  Against the oracle's restatement."""
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    from oracle import proto_ref as P
+    rng = np.random.default_rng(12)
+    Kc, D, B = 30, 48, 41
+    counts = rng.poisson(2.0, Kc) + 1
+    gi = np.repeat(np.arange(Kc), counts)
+    gi = gi[rng.permutation(len(gi))]                                  # clusters arrive unsorted: the member lists must follow the sort
+    R = len(gi)
+    emb = rng.standard_normal((R, D), dtype=np.float32)
+    lng, lat = rng.uniform(-180, 180, R).astype(np.float32), rng.uniform(-90, 90, R).astype(np.float32)
+    nmem = rng.integers(0, 5, R)
+    nmem[:3] = 0                                                       # clusters without members -> centroid
+    mptr = np.concatenate([[0], np.cumsum(nmem)]).astype(np.int64)
+    memb = rng.standard_normal((int(mptr[-1]), 4, D), dtype=np.float32)
+    mll = np.stack([rng.uniform(-180, 180, int(mptr[-1])), rng.uniform(-90, 90, int(mptr[-1]))], 1).astype(np.float32)
+    ref = ProtoRefiner.from_clusters(gi, emb, lng, lat, Kc, topk=5, max_refinement=30000, member_ptr=mptr, member_emb=memb, member_lnglat=mll).cuda().eval()
+    assert ref.within_cluster and ref.member_emb.shape == (int(mptr[-1]), D)
+    q = rng.standard_normal((B, 4, D), dtype=np.float32)
+    cands = np.stack([rng.permutation(Kc)[:5] for _ in range(B)]).astype(np.int64)
+    probs = np.sort(rng.dirichlet(np.ones(5), B).astype(np.float32), 1)[:, ::-1].copy()
+    init = np.stack([rng.uniform(-180, 180, B), rng.uniform(-90, 90, B)], 1).astype(np.float32)
+    _, llh, cell = ref(torch.from_numpy(q), torch.from_numpy(init), torch.from_numpy(cands), torch.from_numpy(probs))
+    args = (q, init, cands, probs, ref.cell_ptr.cpu().numpy(), ref.proto_emb.cpu().numpy(), ref.proto_lnglat.cpu().numpy())
+    o_llh, o_cell, o_idx = P.refine(*args, max_refinement=30000, member_ptr=ref.member_ptr.cpu().numpy(), member_emb=ref.member_emb.cpu().numpy(),
+                                    member_lnglat=ref.member_lnglat.cpu().numpy())
+    np.testing.assert_array_equal(cell.cpu().numpy(), o_cell)
+    np.testing.assert_allclose(llh.cpu().numpy(), o_llh)
+    np.testing.assert_array_equal(ref.last_guess_index.cpu().numpy(), o_idx)
+    c_llh, _, _ = P.refine(*args, max_refinement=30000)                # centroid answers differ: the member branch really ran
+    assert (np.abs(c_llh - o_llh).max(axis=1) > 1e-3).mean() > 0.5
+    # the sorted member table equals a direct gather in sorted-cluster order
+    order = np.argsort(gi, kind="stable")
+    want = np.concatenate([memb[mptr[j]:mptr[j + 1]].mean(1) for j in order if mptr[j + 1] > mptr[j]])
+    np.testing.assert_allclose(ref.member_emb.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+
+
 def test_scoring_matches_reference_golden(ops, golden_dir):
     """gg_geoguessr_score against run_benchmark.py:25-65 executed by tests/golden/make_golden_r2.py: fp64 distances, INTEGER scores
     (clamp + round-half-even) bit-exact."""

@@ -2,7 +2,8 @@
 """Secondary numbers of SURVEY.md 8(d) on one MI355X (the headline c2 line is bench.py's):
   c1  TinyViT-5M-224, batch 8, forward + geocell hard-CE + backward + AdamW (panorama=False)
   c2u TinyViT-21M-224, 256 panoramas, every parameter trainable
-  c4  CLIP ViT-B/32 vision tower, batch 1024, inference (random weights, bf16 MFMA)
+  c4  CLIP ViT-B/32 vision tower, batch 1024, inference (random weights; fp32 = the reference's precision, bf16 = 16-bit MFMA operands)
+  c4-train  SuperGuessr on the CLIP ViT-B/32 base, 64 panoramas, reference freeze policy with the head file present, forward + backward + AdamW
   c5  SuperGuessr head (serving) + ProtoRefiner on precomputed embeddings, batch 4096
 Prints one JSON object per case.  Synthetic inputs as in bench.py."""
 import json, os, sys, time
@@ -58,13 +59,37 @@ for prec in precisions:
         train_case("c2-unfrozen", "tiny_vit_21m_224", 256, True, True, True, 5, 2, prec)
 if "c4" in cases:
     from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
-    tower = CLIPVisionTower("openai/clip-vit-base-patch32").to(dev).eval()
-    x = torch.randn(1024, 3, 224, 224, device=dev)
-    with torch.no_grad():
-        dt = timed(lambda: tower(pixel_values=x), 5, 2)
-    print(json.dumps(dict(case="c4", model="CLIP ViT-B/32 vision tower (random weights)", images_per_step=1024, ms_per_step=round(dt * 1e3, 3),
-                          images_per_s=round(1024 / dt, 1))))
-    del tower, x
+    for prec in precisions:           # fp32 = the reference's precision (pretrain/clip_embedder.py:51-66 runs the tower in fp32), bf16 = 16-bit MFMA operands
+        tower = CLIPVisionTower("openai/clip-vit-base-patch32", precision=prec).to(dev).eval()
+        x = torch.randn(1024, 3, 224, 224, device=dev)
+        with torch.no_grad():
+            dt = timed(lambda: tower(pixel_values=x, return_last_hidden=False), 5, 2)
+        print(json.dumps(dict(case="c4", precision=prec, model="CLIP ViT-B/32 vision tower (random weights), inference", images_per_step=1024,
+                              ms_per_step=round(dt * 1e3, 3), images_per_s=round(1024 / dt, 1), tflops=round(1024 / dt * 8.82e9 / 1e12, 1))))
+        del tower, x
+        import gc; gc.collect(); torch.cuda.empty_cache()
+if "c4t" in cases or "c4" in cases:
+    # SuperGuessr on a CLIP ViT-B/32 base, 4-heading panoramas, last encoder layer + embeddings trainable (models/super_guessr.py:134-150), fwd+bwd+AdamW
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
+    for prec in precisions:
+        torch.manual_seed(0)
+        tower = CLIPVisionTower("openai/clip-vit-base-patch32", precision=prec)
+        model = SuperGuessr(tower, panorama=True, should_smooth_labels=True).to(dev).train()
+        for layer in list(tower.vision_model.encoder.layers)[:-1]:
+            for p_ in layer.parameters():
+                p_.requires_grad = False
+        opt = AdamW(model, lr=2e-5)
+        n = 64
+        x = torch.randn(n, 4, 3, 224, 224, device=dev)
+        lab = torch.stack([torch.rand(n, device=dev) * 360 - 180, torch.rand(n, device=dev) * 180 - 90], 1)
+        def step():
+            out = model(pixel_values=x, labels=lab)
+            out.loss.backward(); opt.step(); opt.zero_grad()
+        dt = timed(step, 5, 2)
+        print(json.dumps(dict(case="c4-train", precision=prec, model="SuperGuessr on CLIP ViT-B/32, encoder layers[:-1] frozen (embeddings + last layer + head train)",
+                              images_per_step=4 * n, ms_per_step=round(dt * 1e3, 3), images_per_s=round(4 * n / dt, 1))))
+        del model, tower, opt, x
+        import gc; gc.collect(); torch.cuda.empty_cache()
 if "c5" in cases:
     torch.manual_seed(0)
     Bq, D, K = 4096, 576, 12647
