@@ -66,10 +66,13 @@ __device__ __forceinline__ float row16_sum(float v) {        // sum over the 16 
 
 // Epilogue shared by both NT kernels: lane holds C[m = m0 + wm*WROWS + mt*16 + lr][n = n0 + wn*WCOLS + nt*16 + lg*4 + r]; results leave straight
 // from the accumulator fragments (16-byte stores, 64-byte runs per row).  `smem`: at least 2*WM*BN floats, no longer read by anyone.
-template <int BM, int BN, int WM, int WN, int EPI, int GNMAX = 2>
+// MSPLIT = 2: the tile's 16-row blocks are processed in two halves (half the second-tensor prefetch registers per n-tile, which lets the 4-per-CU
+// form prefetch two n-tiles at a time and fetch them as whole 128-byte lines)
+template <int BM, int BN, int WM, int WN, int EPI, int GNMAX = 2, int MSPLIT = 1>
 __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
                                                   int tm, int wm, int wn, int lr, int lg) {
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16, TMH = TM / MSPLIT;
+    static_assert(TM % MSPLIT == 0, "MSPLIT must divide the m-tiles of a wave");
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     const bool vec_c = (p.ldc & 3) == 0;
     // full-line stores: a lane's 16 bytes of two neighbouring n-tiles are regrouped (one DPP row rotate) so that a store instruction writes
@@ -83,23 +86,55 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
     const float* aux_src = EPI == FE_BNBWD ? p.bn_y : (EPI == FE_DGELU ? p.dact_preact : (EPI == FE_LINEAR ? p.residual : nullptr));
     const int64_t aux_ld = EPI == FE_LINEAR ? p.ldr : p.ldc;
     const bool aux_vec = (aux_ld & 3) == 0;
-    f32x4 aux[AUX ? GN : 1][AUX ? TM : 1];
+    f32x4 aux[AUX ? GN : 1][AUX ? TMH : 1];
+    // whole-line fetch of the second tensor: with two n-tiles per group a load instruction reads 8 rows x 128 B (lanes lr < 8: tile e of row lr & 7,
+    // lanes lr >= 8: tile o of the same row; second load: rows 8..15) and one DPP row rotate hands every lane its own fragment
+    const bool pair_aux = AUX && GN == 2 && aux_src != nullptr && aux_vec && (aux_ld & 31) == 0 && (p.N & 31) == 0 && (p.debug & 128) == 0;
+    const int hh = lr >> 3, l7 = lr & 7;
+#pragma unroll
+    for (int mh = 0; mh < MSPLIT; ++mh) {
 #pragma unroll
     for (int g0 = 0; g0 < TN; g0 += GN) {
+        const bool paired = pair_aux && g0 + 1 < TN;
         if (AUX) {
+            if (paired) {
+                const int ne = n0 + wn * WCOLS + g0 * 16 + lg * 4;
 #pragma unroll
-            for (int gi = 0; gi < GN; ++gi) {
-                const int n = n0 + wn * WCOLS + (g0 + gi) * 16 + lg * 4;
+                for (int mtl = 0; mtl < TMH; ++mtl) {
+                    const int mb = m0 + wm * WROWS + (mh * TMH + mtl) * 16;
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) {
-                    const int m = m0 + wm * WROWS + mt * 16 + lr;
-                    f32x4 h = {0.f, 0.f, 0.f, 0.f};
-                    if (g0 + gi < TN && aux_src && m < p.M && n < p.N) {
-                        const float* g = aux_src + (int64_t)m * aux_ld + n;
-                        if (aux_vec && n + 3 < p.N) h = *reinterpret_cast<const f32x4*>(g);
-                        else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
+                    for (int half = 0; half < 2; ++half) {
+                        const int m = mb + 8 * half + l7, n = (hh == half) ? ne : ne + 16;
+                        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                        if (m < p.M) h = *reinterpret_cast<const f32x4*>(aux_src + (int64_t)m * aux_ld + n);
+                        aux[AUX ? half : 0][AUX ? mtl : 0] = h;
                     }
-                    aux[AUX ? gi : 0][AUX ? mt : 0] = h;
+                }
+            } else {
+#pragma unroll
+                for (int gi = 0; gi < GN; ++gi) {
+                    const int n = n0 + wn * WCOLS + (g0 + gi) * 16 + lg * 4;
+#pragma unroll
+                    for (int mtl = 0; mtl < TMH; ++mtl) {
+                        const int m = m0 + wm * WROWS + (mh * TMH + mtl) * 16 + lr;
+                        f32x4 h = {0.f, 0.f, 0.f, 0.f};
+                        if (g0 + gi < TN && aux_src && m < p.M && n < p.N) {
+                            const float* g = aux_src + (int64_t)m * aux_ld + n;
+                            if (aux_vec && n + 3 < p.N) h = *reinterpret_cast<const f32x4*>(g);
+                            else { for (int r = 0; r < 4; ++r) if (n + r < p.N) h[r] = g[r]; }
+                        }
+                        aux[AUX ? gi : 0][AUX ? mtl : 0] = h;
+                    }
+                }
+            }
+            if (paired) {      // lanes' own fragments: tile e from the load that covered this lane's row half, tile o from the partner lane's
+#pragma unroll
+                for (int mtl = 0; mtl < TMH; ++mtl) {
+                    const f32x4 t0 = aux[0][AUX ? mtl : 0], t1 = aux[AUX && GN > 1 ? 1 : 0][AUX ? mtl : 0];
+                    const f32x4 r0 = {ror8_f(t0[0]), ror8_f(t0[1]), ror8_f(t0[2]), ror8_f(t0[3])};
+                    const f32x4 r1 = {ror8_f(t1[0]), ror8_f(t1[1]), ror8_f(t1[2]), ror8_f(t1[3])};
+                    aux[0][AUX ? mtl : 0] = hh ? t1 : t0;
+                    aux[AUX && GN > 1 ? 1 : 0][AUX ? mtl : 0] = hh ? r1 : r0;
                 }
             }
         }
@@ -124,7 +159,8 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 }
             }
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
+            for (int mtl = 0; mtl < TMH; ++mtl) {
+                const int mt = mh * TMH + mtl;
                 const int m = m0 + wm * WROWS + mt * 16 + lr;
                 f32x4 v = acc[nt][mt];
                 const bool ok = m < p.M && n < p.N;
@@ -133,7 +169,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     if (p.colstats) { cs += v; cq += v * v; }   // rows beyond M / columns beyond N hold exact zeros (range-checked operand loads)
                 } else if (EPI == FE_BNBWD) {
                     if (ok) {       // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat
-                        const f32x4 yv = aux[AUX ? gi : 0][AUX ? mt : 0];
+                        const f32x4 yv = aux[AUX ? gi : 0][AUX ? mtl : 0];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] *= act_grad_exact_f(fmaf(yv[r], bsc[r], bsh[r]), p.bn_act);
                         cs += v; cq += v * (yv * brs + bnm);
@@ -161,7 +197,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                         for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
                     }
                     if (EPI == FE_DGELU) {
-                        const f32x4 h = aux[AUX ? gi : 0][AUX ? mt : 0];
+                        const f32x4 h = aux[AUX ? gi : 0][AUX ? mtl : 0];
                         if (p.quick) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -175,7 +211,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     }
                     if (EPI == FE_LINEAR) {
                         v *= rs;
-                        v += aux[AUX ? gi : 0][AUX ? mt : 0];            // zeros without a residual
+                        v += aux[AUX ? gi : 0][AUX ? mtl : 0];            // zeros without a residual
                     }
                 }
                 if (pair_store && nt < (TN & ~1)) { acc[nt][mt] = v; continue; }      // stored below, two n-tiles at a time
@@ -193,15 +229,16 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                     const float a = row16_sum(cs[r]), b = row16_sum(cq[r]);
                     if (lr == 0) {
                         const int col = wn * WCOLS + nt * 16 + lg * 4 + r;
-                        red[(wm * 2 + 0) * BN + col] = a;
-                        red[(wm * 2 + 1) * BN + col] = b;
+                        if (mh == 0) { red[(wm * 2 + 0) * BN + col] = a; red[(wm * 2 + 1) * BN + col] = b; }
+                        else { red[(wm * 2 + 0) * BN + col] += a; red[(wm * 2 + 1) * BN + col] += b; }
                     }
                 }
             }
         }
     }
+    }      // mh
     if (pair_store && !(p.debug & 2)) {
-        const int h = lr >> 3, l7 = lr & 7;
+        const int h = hh;
 #pragma unroll
         for (int e = 0; e + 1 < TN; e += 2) {
             const int ne = n0 + wn * WCOLS + e * 16 + lg * 4;
@@ -555,7 +592,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         }
         __builtin_amdgcn_s_barrier();
         if (p.trace) tr2 = wall_clock64();
-        gemm_f32_epilogue<BM, BNC, WM, WN, EPI, 1>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+        // second-tensor fetch as whole lines (two n-tiles per group, M in two halves) where the registers allow it: the GELU' and residual epilogues
+        // of the 128 x 128 tile; the BatchNorm-backward epilogue keeps one n-tile per group (its per-column coefficients need the registers)
+        constexpr bool PAIR_AUX = (EPI == FE_DGELU || EPI == FE_LINEAR) && TM == 4 && PRO == 0;
+        gemm_f32_epilogue<BM, BNC, WM, WN, EPI, (PAIR_AUX ? 2 : 1), (PAIR_AUX ? 2 : 1)>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
         return;
     }
     f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
@@ -822,7 +862,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     const bool sb = ring && !wide96 && a->K <= sb_k;
 #define GG_LAUNCH_F32(E)                                                                                          \
     do {                                                                                                          \
-        if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : 6), 64, true>), grid, dim3(256), 0, st, p); \
+        if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true>), grid, dim3(256), 0, st, p); \
         else if (sb) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true>), grid, dim3(256), 0, st, p); \
         else if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
         else if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 2>), grid, dim3(256), 0, st, p);    \
