@@ -148,6 +148,8 @@ SIGNATURES = {
     "gg_bn_bwd_apply_f32": (_I, [_P, _P, _P, _L, _I, _P, _I, _P, _P]),
     "gg_dwconv3x3_fwd_fused_f32": (_I, [_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "gg_dwconv3x3_bwd_data_fused_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "gg_dwconv_f32_s2_fused_stat_rows": (_I, [_I, _I, _I, _I]),
+    "gg_dwconv3x3_s2_bwd_data_fused_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "gg_token_mean_fwd_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gg_token_mean_bwd_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gg_view_mean_fwd_f32": (_I, [_P, _P, _L, _I, _I, _I, _P]),

@@ -384,6 +384,84 @@ __global__ __launch_bounds__(256) void dw3x3_s2_bwd_data_f32_kernel(const float*
     }
 }
 
+// The same gather with the BatchNorm-backward passes of the ConvNorms on both sides riding on it (PatchMerging backward, frozen chain):
+//   IN: dy = c0*dz + c1*y2 + c2 formed at every tap from the GEMM-epilogue dz2 and the saved conv2 output (coef [3][C]): no apply pass, no dy tensor;
+//   EP: out = dz1 = da1 * act'(BN1(y1)) and one partial row [2][C] per block of (sum dz1, sum dz1 * xhat1): no reduce pass, no da1 tensor.
+// A thread keeps ONE group of 4 channels for all its pixels (threads = C/4 channel groups x PX pixels), so the column sums stay in registers.
+template <bool IN, bool EP>
+__global__ __launch_bounds__(256) void dw3x3_s2_bwd_data_fused_f32_kernel(const float* __restrict__ dz, const float* __restrict__ y2, const float* __restrict__ coef,
+                                                                          const float* __restrict__ taps, float* __restrict__ out, int B, int H, int W, int C, int Ho,
+                                                                          int Wo, const float* __restrict__ ep_y, const float* __restrict__ ep_stat,
+                                                                          const float* __restrict__ ep_gamma, const float* __restrict__ ep_beta, int ep_act,
+                                                                          float* __restrict__ part, int64_t px_per_block) {
+    __shared__ float red[256 * 8];
+    const int CG = C >> 2, PX = blockDim.x / CG;
+    const int g = threadIdx.x % CG, px = threadIdx.x / CG, c4 = g * 4;
+    f32x4 tw[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tw[k] = *reinterpret_cast<const f32x4*>(taps + k * C + c4);
+    f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1;
+    if (IN) { c0 = *reinterpret_cast<const f32x4*>(coef + c4); c1 = *reinterpret_cast<const f32x4*>(coef + C + c4); c2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4); }
+    f32x4 sc = c1, sh = c1, rs = c1, nm = c1;
+    if (EP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mu = ep_stat[c4 + r], rstd = ep_stat[C + c4 + r];
+            sc[r] = ep_gamma[c4 + r] * rstd; sh[r] = ep_beta[c4 + r] - mu * sc[r]; rs[r] = rstd; nm[r] = -mu * rstd;
+        }
+    }
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
+    const int64_t total = (int64_t)B * H * W;
+    const int64_t p0 = blockIdx.x * px_per_block, p1 = p0 + px_per_block < total ? p0 + px_per_block : total;
+    for (int64_t p = p0 + px; p < p1; p += PX) {
+        const unsigned pu = (unsigned)p;
+        const int ix = (int)(pu % (unsigned)W);
+        const int iy = (int)((pu / (unsigned)W) % (unsigned)H);
+        const int b = (int)(pu / ((unsigned)W * (unsigned)H));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oy = ty >> 1;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ox = tx >> 1;
+                if (ox >= Wo) continue;
+                const int64_t q = (((int64_t)b * Ho + oy) * Wo + ox) * C + c4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(dz + q);
+                if (IN) v = c0 * v + (c1 * *reinterpret_cast<const f32x4*>(y2 + q) + c2);
+                acc += tw[ky * 3 + kx] * v;
+            }
+        }
+        if (EP) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(ep_y + p * C + c4);
+            const f32x4 xh = yv * rs + nm, z = yv * sc + sh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= gg_act_grad_f32(z[r], ep_act);
+            cs += acc; cq += acc * xh;
+        }
+        *reinterpret_cast<f32x4*>(out + p * C + c4) = acc;
+    }
+    if (EP) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[threadIdx.x * 8 + r] = cs[r]; red[threadIdx.x * 8 + 4 + r] = cq[r]; }
+        __syncthreads();
+        if (px == 0) {
+            for (int j = 1; j < PX; ++j) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[r] += red[(j * CG + g) * 8 + r]; cq[r] += red[(j * CG + g) * 8 + 4 + r]; }
+            }
+            float* row = part + (int64_t)blockIdx.x * 2 * C;
+            *reinterpret_cast<f32x4*>(row + c4) = cs;
+            *reinterpret_cast<f32x4*>(row + C + c4) = cq;
+        }
+    }
+}
+
 // part [nparts][9][C] -> grad (C,1,3,3) (+)=
 __global__ void dw_wgrad_final_f32_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ grad, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;       // over 9*C, part layout [k][c]
@@ -544,6 +622,40 @@ extern "C" int gg_dwconv3x3_bwd_data_f32(const float* dy, const float* taps, flo
     if (stride == 1) return dw_walk_launch(DWM_FLIP, dy, taps, dx, nullptr, B, H, W, C, 1, nullptr, stream);
     hipLaunchKernelGGL(dw3x3_s2_bwd_data_f32_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4), 65536)), dim3(256), 0, (hipStream_t)stream, dy, taps,
                        dx, B, H, W, C, Ho, Wo);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+static int dw_s2_fused_blocks(int B, int H, int W, int C) {
+    const int CG = C / 4, PX = std::max(1, 256 / CG);
+    const int64_t total = (int64_t)B * H * W;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(4096, gg_cdiv(total, (int64_t)PX * 8)));
+}
+extern "C" int gg_dwconv_f32_s2_fused_stat_rows(int B, int H, int W, int C) { return dw_s2_fused_blocks(B, H, W, C); }
+// stride-2 data gradient (H, W = the conv INPUT map) with the BatchNorm-backward passes on both sides riding on it; see the kernel
+extern "C" int gg_dwconv3x3_s2_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H,
+                                                  int W, int C, const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta,
+                                                  int ep_act, float* ep_partials, void* stream) {
+    GG_CHECK(dz_in && taps && out && B > 0 && H > 0 && W > 0 && (C & 3) == 0 && C <= 1024, "gg_dwconv3x3_s2_bwd_data_fused_f32: bad args (C %% 4, C <= 1024)");
+    GG_CHECK(!in_coef || y_in, "gg_dwconv3x3_s2_bwd_data_fused_f32: in_coef needs y_in");
+    GG_CHECK(!ep_y || (ep_stat && ep_gamma && ep_beta && ep_partials), "gg_dwconv3x3_s2_bwd_data_fused_f32: the epilogue needs stat, gamma, beta and partials");
+    GG_CHECK((int64_t)B * H * W < ((int64_t)1 << 32), "gg_dwconv3x3_s2_bwd_data_fused_f32: too many pixels for 32-bit decoding");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 4.0 * B * C * ((double)H * W * (1.0 + (ep_y != nullptr)) + (double)Ho * Wo * (1.0 + (in_coef != nullptr))), stream);
+    const int CG = C / 4, PX = std::max(1, 256 / CG);
+    const int blocks = dw_s2_fused_blocks(B, H, W, C);
+    const int64_t total = (int64_t)B * H * W;
+    const int64_t ppb = gg_align(gg_cdiv(total, blocks), PX);
+    const dim3 grid((unsigned)gg_cdiv(total, ppb)), block((unsigned)(CG * PX));
+    GG_CHECK((int)grid.x <= blocks, "gg_dwconv3x3_s2_bwd_data_fused_f32: internal grid error");
+    if (ep_y && (int)grid.x < blocks)       // rows the finalize step will read but no block writes
+        GG_HIP(hipMemsetAsync(ep_partials + (int64_t)grid.x * 2 * C, 0, (size_t)(blocks - grid.x) * 2 * C * sizeof(float), (hipStream_t)stream));
+#define GG_S2F(I_, E_) hipLaunchKernelGGL((dw3x3_s2_bwd_data_fused_f32_kernel<I_, E_>), grid, block, 0, (hipStream_t)stream, dz_in, y_in, in_coef, taps, out, B, H, W, \
+                                          C, Ho, Wo, ep_y, ep_stat, ep_gamma, ep_beta, ep_act, ep_partials, ppb)
+    if (in_coef && ep_y) GG_S2F(true, true);
+    else if (in_coef) GG_S2F(true, false);
+    else if (ep_y) GG_S2F(false, true);
+    else GG_S2F(false, false);
+#undef GG_S2F
     GG_LAUNCH_CHECK();
     return 0;
 }

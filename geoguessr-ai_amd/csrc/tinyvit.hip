@@ -836,13 +836,16 @@ static int backward_impl(Exec& e, const float* d_out) {
         if (e.fuse_bngemm && !e.tr(st.merge.c1.w.t_w) && !e.tr(st.merge.c2.w.t_w) && C % 64 == 0) {
             GG_TRY(gemm_bnbwd(e, t_a, C, e.Wt(st.merge.c3.w), st.merge.c3.w.Np, t_d, M, C, C, st.merge.c2.bn, ma.c2, GG_ACT_GELU));   // dz2 -> t_d
             GG_TRY(bn_bwd_fin_gemm(e, st.merge.c2.bn, ma.c2, M));
-            if (e.fuse_bnbwd && e.fuse_bnbwd_epi && !e.f32) {
+            if (e.fuse_bnbwd && e.fuse_bnbwd_epi) {
                 // the stride-2 data gradient forms dy2 from (dz2, y2) at its taps and emits dz1 = da1*GELU'(BN1(y1)) + BN1's sums
-                GG_TRY(gg_dwconv3x3_s2_bwd_data_fused(t_d, e.A(ma.c2.y), bn_coef(e, M, C), e.Taps(st.merge.c2.w), t_b, B, rin, rin, C,
+                if (e.f32) GG_TRY(gg_dwconv3x3_s2_bwd_data_fused_f32((const float*)t_d, (const float*)e.A(ma.c2.y), bn_coef(e, M, C), e.Taps(st.merge.c2.w),
+                                                                     (float*)t_b, B, rin, rin, C, (const float*)e.A(ma.c1.y), e.F(ma.c1.stat),
+                                                                     e.P(st.merge.c1.bn.t_g), e.P(st.merge.c1.bn.t_b), GG_ACT_GELU, e.F(L.statpart), e.st));
+                else GG_TRY(gg_dwconv3x3_s2_bwd_data_fused(t_d, e.A(ma.c2.y), bn_coef(e, M, C), e.Taps(st.merge.c2.w), t_b, B, rin, rin, C,
                                                       e.A(ma.c1.y), e.F(ma.c1.stat), e.P(st.merge.c1.bn.t_g), e.P(st.merge.c1.bn.t_b),
                                                       GG_ACT_GELU, e.F(L.statpart), e.st));                    // dz1 -> t_b
                 const bool tr1 = e.tr(st.merge.c1.bn.t_g);
-                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), gg_dwconv_s2_fused_stat_rows(B, rin, rin, C), C, Min, e.F(ma.c1.stat),
+                GG_TRY(gg_bn_bwd_finalize(e.F(L.statpart), e.f32 ? gg_dwconv_f32_s2_fused_stat_rows(B, rin, rin, C) : gg_dwconv_s2_fused_stat_rows(B, rin, rin, C), C, Min, e.F(ma.c1.stat),
                                           e.P(st.merge.c1.bn.t_g), bn_coef(e, Min, C), tr1 ? e.Gd(st.merge.c1.bn.t_g) : nullptr,
                                           tr1 ? e.Gd(st.merge.c1.bn.t_b) : nullptr, 1, e.st));
                 GG_TRY(gemm_folded_dgrad(e, st.merge.c1.w, t_b, e.A(ma.c1.y), bn_coef(e, Min, C), e.F(ma.c1.stat), dx, Min, nullptr));

@@ -643,15 +643,18 @@ def segment_mean(emb, ptr, member):
 
 def dwconv3x3_s2_bwd_data_fused(dz_in, y_in, in_coef, taps, H, W, ep_y=None, ep_stat=None, ep_gamma=None, ep_beta=None, ep_act=None):
     """Stride-2 depthwise data gradient with the BatchNorm-backward apply (input side) and act'(BN) + reduce (output side) fused.
-    dz_in / y_in: (B, Ho, Wo, C) bf16; returns (out (B,H,W,C) bf16, partial rows [rows,2,C] or None)."""
+    dz_in / y_in: (B, Ho, Wo, C) bf16 or f32 (by ``dz_in.dtype``); returns (out (B,H,W,C), partial rows [rows,2,C] or None)."""
     L.require_gpu()
     B, Ho, Wo, Cc = dz_in.shape
-    out = torch.empty((B, H, W, Cc), dtype=BF16, device=dz_in.device)
+    DT = dz_in.dtype
+    f32 = DT == F32
+    lib = L.lib()
+    out = torch.empty((B, H, W, Cc), dtype=DT, device=dz_in.device)
     part = None
+    rows_fn = lib.gg_dwconv_f32_s2_fused_stat_rows if f32 else lib.gg_dwconv_s2_fused_stat_rows
     if ep_y is not None:
-        rows = L.lib().gg_dwconv_s2_fused_stat_rows(B, H, W, Cc)
-        part = torch.zeros((L.lib().gg_stat_rows_capacity(rows), 2, Cc), dtype=F32, device=dz_in.device)
-    L.check(L.lib().gg_dwconv3x3_s2_bwd_data_fused(_p(dz_in, BF16), _p(y_in, BF16), _p(in_coef, F32), _p(taps, F32), _p(out), B, H, W, Cc,
-                                                   _p(ep_y, BF16), _p(ep_stat, F32), _p(ep_gamma, F32), _p(ep_beta, F32), ACT[ep_act],
-                                                   _p(part), L.stream()), "gg_dwconv3x3_s2_bwd_data_fused")
-    return out, (part[:L.lib().gg_dwconv_s2_fused_stat_rows(B, H, W, Cc)] if part is not None else None)
+        part = torch.zeros((lib.gg_stat_rows_capacity(rows_fn(B, H, W, Cc)), 2, Cc), dtype=F32, device=dz_in.device)
+    fn = lib.gg_dwconv3x3_s2_bwd_data_fused_f32 if f32 else lib.gg_dwconv3x3_s2_bwd_data_fused
+    L.check(fn(_p(dz_in, DT), _p(y_in, DT), _p(in_coef, F32), _p(taps, F32), _p(out), B, H, W, Cc, _p(ep_y, DT), _p(ep_stat, F32), _p(ep_gamma, F32),
+               _p(ep_beta, F32), ACT[ep_act], _p(part), L.stream()), "gg_dwconv3x3_s2_bwd_data_fused")
+    return out, (part[:rows_fn(B, H, W, Cc)] if part is not None else None)

@@ -227,6 +227,10 @@ int gg_dwconv3x3_fwd_fused_f32(const float* x_prebn, const float* in_stat, const
 int gg_dwconv3x3_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H, int W, int C,
                                     const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
                                     float* ep_partials /* gg_dwconv_f32_stat_rows(B,H,W,C,1) rows */, void* stream);
+int gg_dwconv_f32_s2_fused_stat_rows(int B, int H, int W, int C);         /* partial rows of the stride-2 fused data gradient (H, W = the conv INPUT map) */
+int gg_dwconv3x3_s2_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H, int W,
+                                       int C, const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
+                                       float* ep_partials, void* stream);   /* f32 twin of gg_dwconv3x3_s2_bwd_data_fused (PatchMerging backward) */
 int gg_token_mean_fwd_f32(const float* x, float* out, int B, int T, int C, void* stream);
 int gg_token_mean_bwd_f32(const float* dout, float* dx, int B, int T, int C, void* stream);
 int gg_view_mean_fwd_f32(const float* emb, float* out, int64_t ldo, int N, int V, int C, void* stream);

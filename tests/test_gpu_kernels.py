@@ -723,3 +723,42 @@ def test_dwconv_stride2_data_gradient_with_batchnorm_fusions(ops, C, H):
     close(s[1], (oq * ((y1 - mean) * rstd)).sum((0, 1, 2)), rtol=1e-3, atol=5e-2, what="s2 fused sum dz*xhat")
     plain, _ = ops.dwconv3x3_s2_bwd_data_fused(dev(dy, BF), None, None, dev(taps), H, H)
     close(plain, da, rtol=2e-2, atol=2e-2, what="s2 plain dgrad")
+
+
+@pytest.mark.parametrize("C,H,B", [(192, 12, 2), (40, 7, 3), (384, 28, 5)])
+def test_dwconv_stride2_data_gradient_with_batchnorm_fusions_f32(ops, C, H, B):
+    """gg_dwconv3x3_s2_bwd_data_fused_f32 (PatchMerging backward of the fp32 mode): the same composition in fp32 at fp32 tolerances; every
+    combination of the two fusions; an odd map (7 -> 4) and enough pixels for several blocks."""
+    Ho = (H - 1) // 2 + 1
+    dz = rnd(B, Ho, Ho, C, seed=190); y2 = rnd(B, Ho, Ho, C, seed=191)
+    coef = torch.stack([1 + 0.2 * rnd(C, seed=192), 0.3 * rnd(C, seed=193), 0.1 * rnd(C, seed=194)])
+    w = rnd(C, 1, 3, 3, seed=195, scale=0.4); taps = w.view(C, 9).t().contiguous()
+    y1 = rnd(B, H, H, C, seed=196) + 0.3
+    gamma, beta = 1 + 0.2 * rnd(C, seed=197), 0.2 * rnd(C, seed=198)
+    mean, var = y1.mean((0, 1, 2)), y1.var((0, 1, 2), unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+
+    def conv_t(dy):
+        xr = torch.zeros(B, C, H, H, requires_grad=True)
+        F.conv2d(xr, w, None, 2, 1, 1, C).backward(dy.permute(0, 3, 1, 2))
+        return xr.grad.permute(0, 2, 3, 1)
+    dy = coef[0] * dz + coef[1] * y2 + coef[2]
+    z = ((y1 - mean) * rstd * gamma + beta).requires_grad_(True)
+    F.gelu(z).sum().backward()
+    stat = dev(torch.stack([mean, rstd]))
+    out, part = ops.dwconv3x3_s2_bwd_data_fused(dev(dz), dev(y2), dev(coef), dev(taps), H, H, ep_y=dev(y1), ep_stat=stat, ep_gamma=dev(gamma),
+                                                ep_beta=dev(beta), ep_act="gelu")
+    ref = conv_t(dy) * z.grad
+    close(out, ref, rtol=2e-4, atol=2e-5, what="f32 s2 fused dgrad (both fusions)")
+    s = part.double().cpu().sum(0)
+    close(s[0], ref.double().sum((0, 1, 2)), rtol=2e-4, atol=2e-3, what="f32 s2 fused sum dz")
+    close(s[1], (ref.double() * ((y1 - mean) * rstd).double()).sum((0, 1, 2)), rtol=2e-4, atol=2e-3, what="f32 s2 fused sum dz*xhat")
+    only_in, _ = ops.dwconv3x3_s2_bwd_data_fused(dev(dz), dev(y2), dev(coef), dev(taps), H, H)
+    close(only_in, conv_t(dy), rtol=2e-4, atol=2e-5, what="f32 s2 dgrad, input fusion only")
+    only_ep, part2 = ops.dwconv3x3_s2_bwd_data_fused(dev(dy), None, None, dev(taps), H, H, ep_y=dev(y1), ep_stat=stat, ep_gamma=dev(gamma),
+                                                     ep_beta=dev(beta), ep_act="gelu")
+    close(only_ep, ref, rtol=2e-4, atol=2e-5, what="f32 s2 dgrad, output fusion only")
+    close(part2.double().cpu().sum(0)[0], s[0], rtol=1e-5, atol=1e-4, what="partials agree")
+    plain, _ = ops.dwconv3x3_s2_bwd_data_fused(dev(dy), None, None, dev(taps), H, H)
+    close(plain, conv_t(dy), rtol=2e-4, atol=2e-5, what="f32 s2 plain dgrad")
+    close(plain, ops.dwconv3x3_bwd_data(dev(dy), dev(taps), B, H, H, C, stride=2), rtol=0, atol=0, what="same arithmetic as the unfused gather")
