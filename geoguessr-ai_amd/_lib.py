@@ -150,6 +150,11 @@ SIGNATURES = {
     "gg_dwconv3x3_bwd_data_fused_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "gg_dwconv_f32_s2_fused_stat_rows": (_I, [_I, _I, _I, _I]),
     "gg_dwconv3x3_s2_bwd_data_fused_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "gg_gemm_nt_f16": (_I, [C.POINTER(GemmArgs), _P]),
+    "gg_layernorm_fwd_f16": (_I, [_P, _P, _P, _L, _I, _F, _P, _P]),
+    "gg_token_mean_fwd_f16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "gg_cast_f32_to_f16": (_I, [_P, _P, _L, _P]),
+    "gg_cast_f16_to_f32": (_I, [_P, _P, _L, _P]),
     "gg_token_mean_fwd_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gg_token_mean_bwd_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "gg_view_mean_fwd_f32": (_I, [_P, _P, _L, _I, _I, _I, _P]),

@@ -53,6 +53,16 @@ template <> struct Ld4<bf16> {
     }
 };
 
+template <> struct Ld4<f16> {
+    static __device__ __forceinline__ f32x4 load(const f16* p) {
+        const f16x4 v = *reinterpret_cast<const f16x4*>(p);
+        return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+    static __device__ __forceinline__ void store(f16* p, f32x4 v) {
+        *reinterpret_cast<f16x4*>(p) = (f16x4){(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    }
+};
+
 __device__ __forceinline__ int64_t fl_origin(const FlashParams& p, int w) {
     if (p.ws == 0) return (int64_t)w * p.N;
     const int per_img = p.nWx * p.nWy;
@@ -567,7 +577,7 @@ __global__ void flash_dbias_final_kernel(const float* __restrict__ rows, int nro
 
 int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) {
     GG_CHECK(a && a->qkv, "%s: null qkv", who);
-    GG_CHECK(dtype == 0 || dtype == 1, "%s: dtype must be 0 (bf16) or 1 (f32)", who);
+    GG_CHECK(dtype == 0 || dtype == 1 || dtype == 2, "%s: dtype must be 0 (bf16), 1 (f32) or 2 (fp16, forward only)", who);
     GG_CHECK(a->head_dim == 32 || a->head_dim == 64, "%s: head_dim must be 32 or 64 (got %d)", who, a->head_dim);
     GG_CHECK(a->tokens_per_window > 0 && a->num_windows > 0 && a->num_heads > 0, "%s: bad window/head/token count", who);
     GG_CHECK((a->ld & 3) == 0 && (a->q_off & 3) == 0 && (a->k_off & 3) == 0 && (a->v_off & 3) == 0 && (a->head_stride & 3) == 0,
@@ -614,7 +624,7 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
     const dim3 grid((unsigned)(a->num_windows * a->num_heads * (res ? 1 : p.ntile))), block(res ? 64 * std::min(16, p.npad / 16) : 256);
     const size_t lds = flash_lds_fwd(p, a->head_dim, res ? p.npad : 64);
     hipStream_t s = (hipStream_t)stream;
-    const double es = dtype ? 4.0 : 2.0;
+    const double es = dtype == 1 ? 4.0 : 2.0;
     GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
             4.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
 #define GG_FL_FWD(T_, D_)                                                                                     \
@@ -623,6 +633,7 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
         else hipLaunchKernelGGL((flash_fwd_kernel<T_, D_, false>), grid, block, lds, s, p);                   \
     } while (0)
     if (dtype == 1) { if (a->head_dim == 32) GG_FL_FWD(float, 32); else GG_FL_FWD(float, 64); }
+    else if (dtype == 2) { if (a->head_dim == 32) GG_FL_FWD(f16, 32); else GG_FL_FWD(f16, 64); }
     else { if (a->head_dim == 32) GG_FL_FWD(bf16, 32); else GG_FL_FWD(bf16, 64); }
 #undef GG_FL_FWD
     GG_LAUNCH_CHECK();
@@ -633,6 +644,7 @@ extern "C" int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per
 }
 extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stream) {
     FlashParams p;
+    GG_CHECK(dtype != 2, "gg_attention_flash_bwd: fp16 storage is inference-only");
     GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_bwd"));
     GG_CHECK(a->dout && a->dqkv && (a->lddo & 3) == 0 && ((uintptr_t)a->dout & 15) == 0 && ((uintptr_t)a->dqkv & 15) == 0,
              "gg_attention_flash_bwd: bad dout/dqkv");

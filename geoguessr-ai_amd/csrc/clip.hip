@@ -3,10 +3,11 @@
 // for SuperGuessr with a CLIP base (models/super_guessr.py:134-150,323-325: the last encoder layer is fine-tuned when the pretrained
 // head exists, every layer otherwise; main_coordinator_idun_s3.py:183-203 builds that model for training).
 //
-// A static schedule of libgg launches on one stream, in one of two arithmetic modes (GgClipCfg.act_dtype):
+// A static schedule of libgg launches on one stream, in one of three arithmetic modes (GgClipCfg.act_dtype):
 //   1  fp32 -- the reference's precision: f32 activations, v_mfma_f32_16x16x4_f32 GEMMs (gg_gemm_nt_f32 / gg_gemm_tn_f32), f32 LayerNorm, f32
 //      online-softmax attention (head dim 64);
-//   0  bf16 -- bf16 activations / MFMA operands, f32 accumulation, f32 statistics.
+//   0  bf16 -- bf16 activations / MFMA operands, f32 accumulation, f32 statistics;
+//   2  fp16 -- the same with fp16 storage / v_mfma_f32_16x16x32_f16 (BASELINE config c4 names fp16), inference only.
 // Patch embedding is a pure GEMM (stride == kernel); q/k/v projections are one [3D, D] GEMM; QuickGELU rides on fc1's epilogue (with the
 // pre-activation copy the backward pass needs), residual adds on out_proj's and fc2's.  Training keeps, for every layer from the first
 // trainable one up, the tensors its backward pass reads (layer input, both LayerNorm outputs + statistics, qkv, attention output + row
@@ -33,7 +34,7 @@ struct CModel {
     int64_t wpatch;
     std::vector<LayerP> layers;
     int T, G, Kpatch, Kraw;
-    bool f32; int es;                  // activation / cached-weight element size: 4 (fp32 mode) or 2 (bf16 mode)
+    bool f32, f16; int es;             // activation / cached-weight element size: 4 (fp32 mode) or 2 (bf16 / fp16 modes)
 };
 static int addt(CModel& m, const std::string& n, std::initializer_list<int64_t> shape) {
     TInfo t; t.name = n; t.ndim = (int)shape.size(); t.numel = 1;
@@ -49,8 +50,8 @@ static int64_t wca(CModel& m, int64_t bytes) { int64_t o = m.wc_bytes; m.wc_byte
 static int build(const GgClipCfg* c, CModel& m) {
     GG_CHECK(c, "clip: null config");
     m.cfg = *c;
-    GG_CHECK(c->act_dtype == 0 || c->act_dtype == 1, "clip: act_dtype must be 0 (bf16) or 1 (fp32), got %d", c->act_dtype);
-    m.f32 = c->act_dtype == 1; m.es = m.f32 ? 4 : 2;
+    GG_CHECK(c->act_dtype >= 0 && c->act_dtype <= 2, "clip: act_dtype must be 0 (bf16), 1 (fp32) or 2 (fp16), got %d", c->act_dtype);
+    m.f32 = c->act_dtype == 1; m.f16 = c->act_dtype == 2; m.es = m.f32 ? 4 : 2;
     const int D = c->hidden_size, I = c->intermediate_size, P = c->patch_size;
     GG_CHECK(D > 0 && D % 64 == 0 && D <= 1024 && c->num_heads > 0 && D / c->num_heads == 64, "clip: head_dim must be 64 and hidden <= 1024 (hidden %d, heads %d)", D, c->num_heads);
     GG_CHECK(P > 0 && c->image_size % P == 0 && I % 8 == 0 && c->num_layers > 0, "clip: bad patch/image/intermediate size or layer count");
@@ -85,10 +86,38 @@ static int build(const GgClipCfg* c, CModel& m) {
     return 0;
 }
 
-// ---- element-type helpers (the two storage types of the runtime) -------------------------------------------------------------------------------
+// ---- element-type helpers (the storage types of the runtime) -------------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 from_f<f16>(float v) { return (f16)v; }
+// f32 [R][C] -> fp16 copy [R][ldo] and / or transpose [C][ldt] (weight cache of the fp16 mode; the bf16 twin is gg_cast_transpose_f32)
+__global__ __launch_bounds__(256) void cast_transpose_f16_kernel(const float* __restrict__ in, int R, int C, f16* __restrict__ out, int64_t ldo,
+                                                                f16* __restrict__ outT, int64_t ldt) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < R && c < C) {
+            v = in[(int64_t)r * C + c];
+            if (out) out[(int64_t)r * ldo + c] = (f16)v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    if (outT) {
+        for (int i = ty; i < 64; i += 4) {
+            const int c = c0 + i, r = r0 + tx;
+            if (c < C && r < R) outT[(int64_t)c * ldt + r] = (f16)tile[tx][i];
+        }
+    }
+}
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = (TO)(float)in[i];
+}
 
 // x f32 NCHW (B,3,S,S) -> col [B*G*G, K], k = (c, py, px)  (== Conv2d(kernel=stride=P) weight flatten); K = 3*P*P padded to 8 (zero columns)
 template <typename T>
@@ -249,9 +278,10 @@ struct Exec {
         memset(&g, 0, sizeof(g));
         g.A = Am; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)Mm; g.N = N; g.K = K;
         g.bias = bias; g.act = act; g.preact = preact; g.residual = residual; g.ldr = ldc; g.dact_preact = dact_preact; g.dact = dact;
-        return m->f32 ? gg_gemm_nt_f32(&g, st) : gg_gemm_nt(&g, st);
+        return m->f32 ? gg_gemm_nt_f32(&g, st) : (m->f16 ? gg_gemm_nt_f16(&g, st) : gg_gemm_nt(&g, st));
     }
     int ln_fwd(const void* x, int tg, int tb, int64_t M, void* out, float* mean, float* rstd) const {
+        if (m->f16) return gg_layernorm_fwd_f16(x, P(tg), P(tb), M, m->cfg.hidden_size, m->cfg.ln_eps, out, st);
         return gg_layernorm_fwd(x, m->f32, P(tg), P(tb), M, m->cfg.hidden_size, m->cfg.ln_eps, out, m->f32, mean, rstd, st);
     }
     // dx = LayerNorm backward of dout (+ dres), dgamma / dbeta accumulated when trainable
@@ -296,6 +326,18 @@ template <typename T> static int embed_fwd(const Exec& e, const float* x, void* 
 }
 }  // namespace
 
+extern "C" int gg_cast_f32_to_f16(const float* in, void* out, int64_t n, void* stream) {
+    GG_CHECK(in && out && n > 0, "gg_cast_f32_to_f16: bad args");
+    hipLaunchKernelGGL((cast_kernel<float, f16>), dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, in, (f16*)out, n);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_cast_f16_to_f32(const void* in, float* out, int64_t n, void* stream) {
+    GG_CHECK(in && out && n > 0, "gg_cast_f16_to_f32: bad args");
+    hipLaunchKernelGGL((cast_kernel<f16, float>), dim3(grid1d(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)in, out, n);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int gg_clip_num_tensors(const GgClipCfg* cfg) { CModel m; return build(cfg, m) ? -1 : (int)m.t.size(); }
 extern "C" int gg_clip_tensor_info(const GgClipCfg* cfg, int i, char* name, int cap, int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4) {
     CModel m;
@@ -336,9 +378,16 @@ extern "C" int gg_clip_refresh_weights(const GgClipCfg* cfg, const float* params
             GG_HIP(hipMemcpyAsync(wc + n + r0 * C * 4, W, (size_t)R * C * 4, hipMemcpyDeviceToDevice, st));
             return gg_transpose_f32(W, R, C, (float*)(wc + t) + c0, ldt, st);
         }
+        if (m.f16) {
+            hipLaunchKernelGGL(cast_transpose_f16_kernel, dim3((unsigned)gg_cdiv(C, 64), (unsigned)gg_cdiv(R, 64)), dim3(256), 0, st, W, R, C,
+                               (f16*)(wc + n) + r0 * C, (int64_t)C, (f16*)(wc + t) + c0, ldt);
+            GG_LAUNCH_CHECK();
+            return 0;
+        }
         return gg_cast_transpose_f32(W, R, C, (bf16*)(wc + n) + r0 * C, C, (bf16*)(wc + t) + c0, ldt, st);
     };
-    if (m.f32) hipLaunchKernelGGL(cast_pad_rows_kernel<float>, dim3(grid1d((int64_t)D * m.Kpatch)), dim3(256), 0, st, P(m.patch_w), (float*)(wc + m.wpatch), D, m.Kraw, m.Kpatch);
+    if (m.f16) hipLaunchKernelGGL(cast_pad_rows_kernel<f16>, dim3(grid1d((int64_t)D * m.Kpatch)), dim3(256), 0, st, P(m.patch_w), (f16*)(wc + m.wpatch), D, m.Kraw, m.Kpatch);
+    else if (m.f32) hipLaunchKernelGGL(cast_pad_rows_kernel<float>, dim3(grid1d((int64_t)D * m.Kpatch)), dim3(256), 0, st, P(m.patch_w), (float*)(wc + m.wpatch), D, m.Kraw, m.Kpatch);
     else hipLaunchKernelGGL(cast_pad_rows_kernel<bf16>, dim3(grid1d((int64_t)D * m.Kpatch)), dim3(256), 0, st, P(m.patch_w), (bf16*)(wc + m.wpatch), D, m.Kraw, m.Kpatch);
     GG_LAUNCH_CHECK();
     for (auto& l : m.layers) {
@@ -364,13 +413,14 @@ extern "C" int gg_clip_forward(const GgClipCfg* cfg, int batch, int training, co
     GG_CHECK(batch > 0 && params && wcache && x && workspace && out, "gg_clip_forward: null pointer / bad batch");
     GG_CHECK(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, "gg_clip_forward: workspace / wcache must be 256-byte aligned");
     const Train tr = train_of(m, training, trainable);
+    GG_CHECK(!(m.f16 && training && tr.l0 < m.cfg.num_layers), "gg_clip_forward: the fp16 mode is inference-only (train in fp32 or bf16)");
     CPlan L; plan(m, batch, tr, training != 0, L);
     Exec e{&m, &L, batch, (hipStream_t)stream, params, (const char*)wcache, (char*)workspace, nullptr, trainable};
     const int D = m.cfg.hidden_size, I = m.cfg.intermediate_size, T = m.T, B = batch, nl = m.cfg.num_layers;
     const int64_t M = (int64_t)B * T;
     const bool keep = training && tr.l0 < nl;
     auto saved = [&](int i) { return keep && i >= tr.l0; };
-    GG_TRY(m.f32 ? embed_fwd<float>(e, x, e.A(L.tok)) : embed_fwd<bf16>(e, x, e.A(L.tok)));
+    GG_TRY(m.f32 ? embed_fwd<float>(e, x, e.A(L.tok)) : (m.f16 ? embed_fwd<f16>(e, x, e.A(L.tok)) : embed_fwd<bf16>(e, x, e.A(L.tok))));
     int64_t cur = saved(0) ? L.la[0].xin : L.s_x;
     GG_TRY(e.ln_fwd(e.A(L.tok), m.pre_g, m.pre_b, M, e.A(cur), keep && tr.embed ? e.F(L.mean0) : nullptr, keep && tr.embed ? e.F(L.rstd0) : nullptr));
     for (int i = 0; i < nl; ++i) {
@@ -384,7 +434,7 @@ extern "C" int gg_clip_forward(const GgClipCfg* cfg, int batch, int training, co
         GG_TRY(e.gemm(e.A(A1), D, e.W(l.wqkv), D, e.A(QKV), 3 * D, M, 3 * D, D, (const float*)e.W(l.bqkv)));
         GgAttnArgs at;
         e.attn_args(at, e.A(QKV), e.A(O), sv ? e.F(a.lse) : nullptr);
-        if (m.f32 || sv || T > 256) GG_TRY(gg_attention_flash_fwd(&at, m.f32 ? 1 : 0, e.st));
+        if (m.f32 || m.f16 || sv || T > 256) GG_TRY(gg_attention_flash_fwd(&at, m.f32 ? 1 : (m.f16 ? 2 : 0), e.st));      // (fp16: fp16 storage, f32 arithmetic)
         else GG_TRY(gg_attention_fwd(&at, e.st));
         // x_mid = x + out_proj(o)   (in place when nothing is kept: each element is read then written by the same lane)
         GG_TRY(e.gemm(e.A(O), D, e.W(l.wo), D, e.A(XMID), D, M, D, D, e.P(l.o_b), 0, nullptr, e.A(cur)));
@@ -396,6 +446,9 @@ extern "C" int gg_clip_forward(const GgClipCfg* cfg, int batch, int training, co
     if (m.f32) {
         GG_TRY(gg_token_mean_fwd_f32((const float*)e.A(cur), out, B, T, D, e.st));
         if (last_hidden) GG_HIP(hipMemcpyAsync(last_hidden, e.A(cur), (size_t)M * D * 4, hipMemcpyDeviceToDevice, e.st));
+    } else if (m.f16) {
+        GG_TRY(gg_token_mean_fwd_f16(e.A(cur), out, B, T, D, e.st));
+        if (last_hidden) GG_TRY(gg_cast_f16_to_f32(e.A(cur), last_hidden, M * D, e.st));
     } else {
         GG_TRY(gg_token_mean_fwd(e.A(cur), out, B, T, D, e.st));
         if (last_hidden) GG_TRY(gg_cast_bf16_to_f32(e.A(cur), last_hidden, M * D, e.st));
@@ -414,6 +467,7 @@ extern "C" int gg_clip_backward(const GgClipCfg* cfg, int batch, const float* pa
     const Train tr = train_of(m, 1, trainable);
     const int nl = m.cfg.num_layers;
     if (tr.l0 >= nl) return 0;                    // nothing in the tower is trainable
+    GG_CHECK(!m.f16, "gg_clip_backward: the fp16 mode is inference-only");
     CPlan L; plan(m, batch, tr, true, L);
     Exec e{&m, &L, batch, (hipStream_t)stream, params, (const char*)wcache, (char*)workspace, grads, trainable};
     const int D = m.cfg.hidden_size, I = m.cfg.intermediate_size, T = m.T, B = batch;

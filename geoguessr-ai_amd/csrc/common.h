@@ -9,6 +9,9 @@ typedef __bf16 bf16;
 typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16;                                  // fp16 storage of the CLIP tower's fp16 mode (fp32 accumulation everywhere)
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 

@@ -740,8 +740,16 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
 }
 
 // ------------------------------------------------------------------------------------------- host
-extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
+// This file is also compiled a second time with the 16-bit operand type swapped to fp16 (gemm_f16.hip: `bf16` / the MFMA builtin redefined,
+// everything inside namespace gg_f16): GG_GEMM_NT_NAME is the exported name of that build's NT entry point, and only it is exported there.
+#ifndef GG_GEMM_NT_NAME
+#define GG_GEMM_NT_NAME gg_gemm_nt
+#endif
+extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     GG_CHECK(a && a->A && a->B && a->C, "gg_gemm_nt: null operand");
+#ifdef GG_GEMM_SECOND_TYPE
+    GG_CHECK(!a->a_bn_stat && !a->A2 && !a->bn_y && !a->colstats && a->split_k <= 1, "gg_gemm_nt_f16: the BatchNorm-fused / two-source / split-K forms exist in the bf16 build only");
+#endif
     GG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     GG_CHECK((a->K & 7) == 0 && (a->lda & 7) == 0 && (a->ldb & 7) == 0,
              "gg_gemm_nt: K, lda, ldb must be multiples of 8 (16-byte rows): K=%d lda=%lld ldb=%lld", a->K,
@@ -844,6 +852,7 @@ extern "C" int gg_gemm_nt(const GgGemmArgs* a, void* stream) {
     GG_LAUNCH_CHECK();
     return 0;
 }
+#ifndef GG_GEMM_SECOND_TYPE      // (the helpers below are type-independent or bf16-only: exported by the bf16 build)
 extern "C" int gg_gemm_colstats_rows(int M) { return (int)gg_cdiv(M, 128); }
 extern "C" int gg_stat_rows_capacity(int rows) { return rows + GG_REDUCE_SLICES; }
 
@@ -1010,3 +1019,4 @@ static int gemm_tn_launch(const void* dY, int64_t ldy, const void* Y2, const flo
     GG_LAUNCH_CHECK();
     return 0;
 }
+#endif  // GG_GEMM_SECOND_TYPE

@@ -22,6 +22,19 @@ template <> struct Vec8<bf16> {
         *reinterpret_cast<bf16x8*>(p) = v;
     }
 };
+template <> struct Vec8<f16> {
+    static __device__ __forceinline__ void load(const f16* p, float (&f)[8]) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+    }
+    static __device__ __forceinline__ void store(f16* p, const float (&f)[8]) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (f16)f[j];
+        *reinterpret_cast<f16x8*>(p) = v;
+    }
+};
 template <> struct Vec8<float> {
     static __device__ __forceinline__ void load(const float* p, float (&f)[8]) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -853,6 +866,21 @@ extern "C" int gg_token_mean_fwd(const void* x, float* out, int B, int T, int C,
 extern "C" int gg_token_mean_bwd(const float* dout, void* dx, int B, int T, int C, void* stream) {
     GG_CHECK(dout && dx && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_bwd: bad args");
     hipLaunchKernelGGL(token_mean_bwd_kernel<bf16>, dim3(grid_for((int64_t)B * T * (C / 8))), dim3(256), 0, (hipStream_t)stream, dout, (bf16*)dx, B, T, C);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// fp16 storage (CLIP tower, act_dtype 2): LayerNorm forward and the token mean
+extern "C" int gg_layernorm_fwd_f16(const void* x, const float* gamma, const float* beta, int64_t M, int C, float eps, void* out, void* stream) {
+    GG_CHECK(x && gamma && beta && out && M > 0 && (C & 7) == 0 && C <= 1024, "gg_layernorm_fwd_f16: bad args (C %% 8, C <= 1024)");
+    GG_PROF(GG_CAT_NORM, 0, 4.0 * M * C, stream);
+    hipLaunchKernelGGL((layernorm_fwd_kernel<f16, f16>), dim3(ln_blocks(M)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma, beta, M, C, eps, (f16*)out,
+                       (float*)nullptr, (float*)nullptr);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_token_mean_fwd_f16(const void* x, float* out, int B, int T, int C, void* stream) {
+    GG_CHECK(x && out && B > 0 && T > 0 && (C & 7) == 0, "gg_token_mean_fwd_f16: bad args");
+    hipLaunchKernelGGL(token_mean_fwd_kernel<f16>, dim3(grid_for((int64_t)B * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const f16*)x, out, B, T, C);
     GG_LAUNCH_CHECK();
     return 0;
 }

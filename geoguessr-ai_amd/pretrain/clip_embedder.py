@@ -9,7 +9,8 @@
   (``gg_clip_forward`` / ``gg_clip_backward``), parameters are views into one flat fp32 buffer like the TinyViT backbone's, so
   ``optim.AdamW`` and the RCCL gradient exchange treat both encoders alike.
 
-Arithmetic: ``precision="fp32"`` (default; the reference runs the tower in fp32) or ``"bf16"``.  No hub download: weights come from a
+Arithmetic: ``precision="fp32"`` (default; the reference runs the tower in fp32), ``"bf16"``, or ``"fp16"`` (inference only: the precision BASELINE
+config c4 names).  No hub download: weights come from a
 state dict (HF names, with or without the leading ``vision_model.``)."""
 from __future__ import annotations
 
@@ -34,8 +35,10 @@ CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 def _precision_code(precision: Optional[str]) -> int:
     from ..models.tinyvit import PRECISIONS, default_precision
     p = precision or default_precision()
+    if p in ("fp16", "f16", "float16", "half"):
+        return 2                      # CLIP only, inference only (BASELINE config c4: "MFMA fp16")
     if p not in PRECISIONS:
-        raise ValueError(f"precision='{p}' (known: bf16, fp32)")
+        raise ValueError(f"precision='{p}' (known: bf16, fp16, fp32)")
     return PRECISIONS[p]
 
 
@@ -47,7 +50,7 @@ class _VisionModel(FlatStore):
     def __init__(self, cfg: L.ClipCfg, seed: int):
         super().__init__()
         self.cfg = cfg
-        self.precision = "fp32" if cfg.act_dtype == 1 else "bf16"
+        self.precision = {0: "bf16", 1: "fp32", 2: "fp16"}[cfg.act_dtype]
         lib = L.lib()
         n = lib.gg_clip_num_tensors(C.byref(cfg))
         if n < 0:
@@ -87,7 +90,7 @@ class CLIPVisionTower(nn.Module):
         c.image_size, c.patch_size, c.ln_eps = kw["image_size"], kw["patch_size"], 1e-5
         c.act_dtype = _precision_code(precision)
         self.cfg = c
-        self.precision = "fp32" if c.act_dtype == 1 else "bf16"
+        self.precision = {0: "bf16", 1: "fp32", 2: "fp16"}[c.act_dtype]
         self.config = SimpleNamespace(hidden_size=kw["hidden_size"], _name_or_path=model_name, **{k: v for k, v in kw.items() if k != "hidden_size"})
         self.vision_model = _VisionModel(c, seed)
         self.num_tokens = (c.image_size // c.patch_size) ** 2 + 1
@@ -177,6 +180,8 @@ class CLIPVisionTower(nn.Module):
     def forward(self, pixel_values: Tensor = None, return_last_hidden: bool = True):
         vm = self.vision_model
         need = torch.is_grad_enabled() and any(p.requires_grad for p in vm._params.values())      # (no dropout / BatchNorm: train and eval compute the same)
+        if need and self.precision == "fp16":
+            raise L.GgError("CLIPVisionTower(precision='fp16') is inference-only: run under torch.no_grad() / freeze it, or train in fp32 / bf16")
         if not need:
             out, last = self.forward_hip(pixel_values, False, return_last_hidden)
         else:

@@ -179,7 +179,7 @@ int gg_attention_expand_bias(const float* table /* [num_heads][ws*ws] */, int nu
 int gg_attention_fwd(const GgAttnArgs* args, void* stream);
 int gg_attention_bwd(const GgAttnArgs* args, void* stream);
 /* Online-softmax (flash) form for ANY tokens_per_window (1024-token windows of the reference's default tiny_vit_21m_512, config.py:9;
- * 577 tokens of CLIP ViT-L/14-336, config.py:6) and for the reference-precision mode: dtype 0 = bf16, 1 = f32 storage of
+ * 577 tokens of CLIP ViT-L/14-336, config.py:6) and for the reference-precision mode: dtype 0 = bf16, 1 = f32, 2 = fp16 (forward only) storage of
  * qkv / out / dout / dqkv; arithmetic is f32 MFMA either way.  window_size <= 32.  dbias_scratch (optional): f32
  * [gg_attention_flash_dbias_rows(num_windows, tokens_per_window)][num_heads][ws*ws]. */
 int gg_attention_flash_fwd(const GgAttnArgs* args, int dtype, void* stream);
@@ -231,6 +231,14 @@ int gg_dwconv_f32_s2_fused_stat_rows(int B, int H, int W, int C);         /* par
 int gg_dwconv3x3_s2_bwd_data_fused_f32(const float* dz_in, const float* y_in, const float* in_coef, const float* taps, float* out, int B, int H, int W,
                                        int C, const float* ep_y, const float* ep_stat, const float* ep_gamma, const float* ep_beta, int ep_act,
                                        float* ep_partials, void* stream);   /* f32 twin of gg_dwconv3x3_s2_bwd_data_fused (PatchMerging backward) */
+/* fp16 storage (the CLIP tower's act_dtype 2 -- BASELINE config c4 "MFMA fp16"; inference only): gg_gemm_nt with fp16 A / B / C / residual on
+ * v_mfma_f32_16x16x32_f16 (bias, QuickGELU / GELU, residual epilogues; no BatchNorm-fused / two-source / split-K forms), LayerNorm forward, the
+ * token mean, an f32 -> fp16 cast; attention runs through gg_attention_flash_fwd with dtype 2 (fp16 storage, f32 arithmetic). */
+int gg_gemm_nt_f16(const GgGemmArgs* args, void* stream);
+int gg_layernorm_fwd_f16(const void* x, const float* gamma, const float* beta, int64_t M, int C, float eps, void* out, void* stream);
+int gg_token_mean_fwd_f16(const void* x, float* out, int B, int T, int C, void* stream);
+int gg_cast_f32_to_f16(const float* in, void* out, int64_t n, void* stream);
+int gg_cast_f16_to_f32(const void* in, float* out, int64_t n, void* stream);
 int gg_token_mean_fwd_f32(const float* x, float* out, int B, int T, int C, void* stream);
 int gg_token_mean_bwd_f32(const float* dout, float* dx, int B, int T, int C, void* stream);
 int gg_view_mean_fwd_f32(const float* emb, float* out, int64_t ldo, int N, int V, int C, void* stream);
@@ -393,14 +401,15 @@ int gg_segment_mean(const float* emb, int64_t ld, const int64_t* ptr, const int6
  * transformers CLIPVisionModel as the reference uses it: the embedder's mean over all tokens of last_hidden_state (no post_layernorm;
  * pretrain/clip_embedder.py:51-66) and the trainable base model of SuperGuessr (models/super_guessr.py:134-150,323-325: the last
  * encoder layer is fine-tuned when the pretrained head exists, every layer otherwise; main_coordinator_idun_s3.py:183-203).
- * act_dtype 1 = fp32 (the reference's precision: f32 activations, f32 MFMA), 0 = bf16 activations / MFMA operands with f32 accumulation.
+ * act_dtype 1 = fp32 (the reference's precision: f32 activations, f32 MFMA), 0 = bf16 and 2 = fp16 activations / MFMA operands with f32
+ * accumulation (2: inference only -- BASELINE config c4 names fp16).
  * Parameters: one flat f32 buffer, HF state-dict names without the "vision_model." prefix (gg_clip_tensor_info).  `trainable` (host,
  * one byte per tensor, NULL = all) selects the tensors whose gradients gg_clip_backward accumulates; a training forward keeps the
  * activations of every layer from the first trainable one up (gg_clip_first_trained_layer), frozen layers below run in place. */
 typedef struct GgClipCfg {
     int hidden_size, intermediate_size, num_layers, num_heads, image_size, patch_size;
     float ln_eps;
-    int act_dtype;                         /* 0 bf16, 1 fp32 */
+    int act_dtype;                         /* 0 bf16, 1 fp32, 2 fp16 (inference only) */
 } GgClipCfg;
 int gg_clip_num_tensors(const GgClipCfg* cfg);
 int gg_clip_tensor_info(const GgClipCfg* cfg, int i, char* name, int name_cap, int64_t* offset, int64_t* numel, int* ndim, int64_t* shape4);

@@ -28,12 +28,18 @@ def _tiny_tower(case, precision, name="openai/clip-vit-tiny-golden"):
     return tower
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_clip_forward_matches_transformers_golden(golden_dir, precision):
     case = CG.load(golden_dir)
     g = np.load(os.path.join(golden_dir, "clip_tiny.npz"))
     tower = _tiny_tower(case, precision).cuda().eval()
     assert {k for k in tower.state_dict()} == {"vision_model." + n for n in case["names"]}          # HF (transformers 4.x) state-dict keys
+    if precision == "fp16":          # BASELINE config c4's precision: inference only
+        from geoguessr_ai_amd import _lib as L
+        with pytest.raises(L.GgError, match="inference-only"):
+            tower(pixel_values=torch.from_numpy(g["x"]).cuda())
+        for p in tower.parameters():
+            p.requires_grad = False
     out = tower(pixel_values=torch.from_numpy(g["x"]).cuda())
     y, lh = out.pooled_mean.detach().cpu().numpy(), out.last_hidden_state.detach().cpu().numpy()
     e_y, e_lh = _rel(y, g["y"]), _rel(lh, g["last_hidden_state"])
@@ -41,6 +47,8 @@ def test_clip_forward_matches_transformers_golden(golden_dir, precision):
     if precision == "fp32":
         assert e_y < 1e-4 and e_lh < 1e-4
         np.testing.assert_allclose(y, g["y"], rtol=1e-4, atol=2e-5)
+    elif precision == "fp16":        # 11-bit significand storage, f32 accumulation: an order of magnitude tighter than bf16
+        assert np.abs(y - g["y"]).max() < 4e-3 and e_lh < 2e-3
     else:
         assert np.abs(y - g["y"]).max() < 3e-2 and e_lh < 2e-2
 
@@ -204,3 +212,20 @@ def test_clip_embedding_wrapper_tensor_and_raw_image_inputs():
     assert two.shape == (2, 768) and torch.allclose(two[0], a[0], atol=1e-6)
     u8 = torch.from_numpy(img).permute(2, 0, 1)
     assert torch.allclose(e(u8), a, atol=1e-6)
+
+
+def test_clip_base_patch32_fp16_inference_matches_oracle():
+    """BASELINE config c4 (CLIP ViT-B/32 embedder, inference, "MFMA fp16") at the real shapes, batch 8: the fp16 mode (fp16 storage, v_mfma_f32_16x16x32_f16
+    GEMMs, f32 accumulation / LayerNorm statistics / softmax) against the pinned fp32 oracle."""
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPEmbedding
+    from oracle import clip_ref as CR
+    e = CLIPEmbedding("openai/clip-vit-base-patch32", device="cuda", precision="fp16")
+    assert e.clip_model.precision == "fp16"
+    st = {k: v.detach().cpu().clone() for k, v in e.clip_model.named_views().items()}
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    got = e(x.cuda()).cpu()
+    with torch.no_grad():
+        ref = CR.forward(CR.ClipVisionConfig(), st, x)
+    rel = _rel(got, ref)
+    print(f"\n[CLIP B/32 fp16 inference] pooled embedding rel-L2 vs fp32 oracle {rel:.2e}, max abs {float((got - ref).abs().max()):.2e}")
+    assert rel < 3e-3

@@ -59,8 +59,10 @@ for prec in precisions:
         train_case("c2-unfrozen", "tiny_vit_21m_224", 256, True, True, True, 5, 2, prec)
 if "c4" in cases:
     from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
-    for prec in precisions:           # fp32 = the reference's precision (pretrain/clip_embedder.py:51-66 runs the tower in fp32), bf16 = 16-bit MFMA operands
+    for prec in precisions + ["fp16"]:  # fp32 = the reference's precision (pretrain/clip_embedder.py:51-66 runs the tower in fp32), fp16 = BASELINE c4's, bf16
         tower = CLIPVisionTower("openai/clip-vit-base-patch32", precision=prec).to(dev).eval()
+        for p_ in tower.parameters():
+            p_.requires_grad = False
         x = torch.randn(1024, 3, 224, 224, device=dev)
         with torch.no_grad():
             dt = timed(lambda: tower(pixel_values=x, return_last_hidden=False), 5, 2)
