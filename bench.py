@@ -261,7 +261,8 @@ def run_mode(precision, args, rank, world, dev, x, lab):
         ms_, n_, fl_, by_ = tot[0]
         ach_tf, ach_gb = fl_ / max(ms_, 1e-9) / 1e9, by_ / max(ms_, 1e-9) / 1e6
         intensity = fl_ / max(by_, 1.0)
-        kern = "gemm_nt_f32_kernel (+ gemm_tn_f32_kernel weight gradients)" if precision == "fp32" else "gemm_nt_kernel (+ gemm_tn_kernel weight gradients)"
+        kern = ("gemm_nt_f32_ring_kernel (LDS-DMA ring, single-buffer form; + gemm_tn_f32_kernel weight gradients)" if precision == "fp32"
+                else "gemm_nt_kernel (+ gemm_tn_kernel weight gradients)")
         traffic, traffic_info = pmc_traffic(precision)
         common = dict(kernel=kern, traffic=traffic, traffic_source=traffic_info, launches=n_ // args.steps, avg_launch_us=round(1e3 * ms_ / max(n_, 1), 2),
                       gemm_ms_per_step=round(ms_ / args.steps, 3), algorithmic_gflop_per_launch=round(fl_ / max(n_, 1) / 1e9, 3),
