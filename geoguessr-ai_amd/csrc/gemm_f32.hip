@@ -596,6 +596,15 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         // of the 128 x 128 tile; the BatchNorm-backward epilogue keeps one n-tile per group (its per-column coefficients need the registers)
         constexpr bool PAIR_AUX = (EPI == FE_DGELU || EPI == FE_LINEAR) && TM == 4 && PRO == 0;
         gemm_f32_epilogue<BM, BNC, WM, WN, EPI, (PAIR_AUX ? 2 : 1), (PAIR_AUX ? 2 : 1)>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
+        if (p.trace && threadIdx.x == 0) {        // dev trace (gg_gemm_f32_set_trace), same record as the double-buffered form; no per-stage wait split
+            unsigned hw, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+            t[0] = hw | ((unsigned long long)(xcc & 0xF) << 32); t[1] = __builtin_readcyclecounter() - mt0; t[2] = tr0; t[3] = tr1; t[4] = tr2; t[5] = wall_clock64();
+            t[6] = 0; t[7] = 0;
+        }
         return;
     }
     f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
