@@ -393,16 +393,21 @@ __global__ __launch_bounds__(256) void dw3x3_s2_bwd_data_fused_f32_kernel(const 
                                                                           const float* __restrict__ taps, float* __restrict__ out, int B, int H, int W, int C, int Ho,
                                                                           int Wo, const float* __restrict__ ep_y, const float* __restrict__ ep_stat,
                                                                           const float* __restrict__ ep_gamma, const float* __restrict__ ep_beta, int ep_act,
-                                                                          float* __restrict__ part, int64_t px_per_block) {
+                                                                          float* __restrict__ part, int64_t quads_per_block) {
+    // Work item = one 2 x 2 QUAD of input pixels rooted at (2a, 2b): its four pixels read the same 2 x 2 neighbourhood dy[a..a+1][b..b+1] and split the nine taps
+    // 1 + 2 + 2 + 4 between them (stride 2, pad 1: an even row sees only tap row 1 of output row a, an odd row tap row 2 of a and tap row 0 of a + 1; columns likewise),
+    // so the 4 (x2 with IN) gradient loads and the 4 ep_y loads of a quad are all in flight before the first use -- the per-pixel gather issued <= 4 dependent,
+    // branch-guarded loads per pixel and ran at 2.5 TB/s.
     __shared__ float red[256 * 8];
     const int CG = C >> 2, PX = blockDim.x / CG;
     const int g = threadIdx.x % CG, px = threadIdx.x / CG, c4 = g * 4;
     f32x4 tw[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) tw[k] = *reinterpret_cast<const f32x4*>(taps + k * C + c4);
-    f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = {0.f, 0.f, 0.f, 0.f}, c2 = c1;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 c0 = {1.f, 1.f, 1.f, 1.f}, c1 = zero, c2 = zero;
     if (IN) { c0 = *reinterpret_cast<const f32x4*>(coef + c4); c1 = *reinterpret_cast<const f32x4*>(coef + C + c4); c2 = *reinterpret_cast<const f32x4*>(coef + 2 * C + c4); }
-    f32x4 sc = c1, sh = c1, rs = c1, nm = c1;
+    f32x4 sc = zero, sh = zero, rs = zero, nm = zero;
     if (EP) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -410,41 +415,60 @@ __global__ __launch_bounds__(256) void dw3x3_s2_bwd_data_fused_f32_kernel(const 
             sc[r] = ep_gamma[c4 + r] * rstd; sh[r] = ep_beta[c4 + r] - mu * sc[r]; rs[r] = rstd; nm[r] = -mu * rstd;
         }
     }
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
-    const int64_t total = (int64_t)B * H * W;
-    const int64_t p0 = blockIdx.x * px_per_block, p1 = p0 + px_per_block < total ? p0 + px_per_block : total;
-    for (int64_t p = p0 + px; p < p1; p += PX) {
-        const unsigned pu = (unsigned)p;
-        const int ix = (int)(pu % (unsigned)W);
-        const int iy = (int)((pu / (unsigned)W) % (unsigned)H);
-        const int b = (int)(pu / ((unsigned)W * (unsigned)H));
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ty = iy + 1 - ky;
-            if (ty < 0 || (ty & 1)) continue;
-            const int oy = ty >> 1;
-            if (oy >= Ho) continue;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tx = ix + 1 - kx;
-                if (tx < 0 || (tx & 1)) continue;
-                const int ox = tx >> 1;
-                if (ox >= Wo) continue;
-                const int64_t q = (((int64_t)b * Ho + oy) * Wo + ox) * C + c4;
-                f32x4 v = *reinterpret_cast<const f32x4*>(dz + q);
-                if (IN) v = c0 * v + (c1 * *reinterpret_cast<const f32x4*>(y2 + q) + c2);
-                acc += tw[ky * 3 + kx] * v;
-            }
+    f32x4 cs = zero, cq = zero;
+    const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;                 // quads per image column / row (== Ho, Wo)
+    const int64_t total = (int64_t)B * QH * QW;
+    const int64_t q0 = blockIdx.x * quads_per_block, q1 = q0 + quads_per_block < total ? q0 + quads_per_block : total;
+    for (int64_t q = q0 + px; q < q1; q += PX) {
+        const unsigned qu = (unsigned)q;
+        const int qb = (int)(qu % (unsigned)QW), qa = (int)((qu / (unsigned)QW) % (unsigned)QH), b = (int)(qu / ((unsigned)QW * (unsigned)QH));
+        const bool a1 = qa + 1 < Ho, b1 = qb + 1 < Wo;              // (qa < Ho and qb < Wo always: QH == Ho, QW == Wo)
+        const int64_t o00 = (((int64_t)b * Ho + qa) * Wo + qb) * C + c4;
+        const int64_t o01 = o00 + C, o10 = o00 + (int64_t)Wo * C, o11 = o10 + C;
+        f32x4 d00 = *reinterpret_cast<const f32x4*>(dz + o00);
+        f32x4 d01 = b1 ? *reinterpret_cast<const f32x4*>(dz + o01) : zero;
+        f32x4 d10 = a1 ? *reinterpret_cast<const f32x4*>(dz + o10) : zero;
+        f32x4 d11 = (a1 && b1) ? *reinterpret_cast<const f32x4*>(dz + o11) : zero;
+        if (IN) {      // dy = c0 dz + c1 y2 + c2 at the positions that exist (beyond the map the gradient is zero, not c2)
+            const f32x4 y00 = *reinterpret_cast<const f32x4*>(y2 + o00);
+            const f32x4 y01 = b1 ? *reinterpret_cast<const f32x4*>(y2 + o01) : zero;
+            const f32x4 y10 = a1 ? *reinterpret_cast<const f32x4*>(y2 + o10) : zero;
+            const f32x4 y11 = (a1 && b1) ? *reinterpret_cast<const f32x4*>(y2 + o11) : zero;
+            d00 = c0 * d00 + (c1 * y00 + c2);
+            d01 = b1 ? c0 * d01 + (c1 * y01 + c2) : zero;
+            d10 = a1 ? c0 * d10 + (c1 * y10 + c2) : zero;
+            d11 = (a1 && b1) ? c0 * d11 + (c1 * y11 + c2) : zero;
         }
+        const int iy = 2 * qa, ix = 2 * qb;
+        const bool r1 = iy + 1 < H, k1 = ix + 1 < W;                // the quad's odd row / column exist (odd maps: the last quad is cut)
+        const int64_t p00 = (((int64_t)b * H + iy) * W + ix) * C + c4;
+        const int64_t p01 = p00 + C, p10 = p00 + (int64_t)W * C, p11 = p10 + C;
+        f32x4 e00 = zero, e01 = zero, e10 = zero, e11 = zero;
         if (EP) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(ep_y + p * C + c4);
-            const f32x4 xh = yv * rs + nm, z = yv * sc + sh;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] *= gg_act_grad_f32(z[r], ep_act);
-            cs += acc; cq += acc * xh;
+            e00 = *reinterpret_cast<const f32x4*>(ep_y + p00);
+            if (k1) e01 = *reinterpret_cast<const f32x4*>(ep_y + p01);
+            if (r1) e10 = *reinterpret_cast<const f32x4*>(ep_y + p10);
+            if (r1 && k1) e11 = *reinterpret_cast<const f32x4*>(ep_y + p11);
         }
-        *reinterpret_cast<f32x4*>(out + p * C + c4) = acc;
+        // taps [ky*3 + kx]:  x[iy][ix] collects w[ky][kx] dy[oy][ox] with iy = 2 oy + ky - 1, ix = 2 ox + kx - 1
+        f32x4 v00 = tw[4] * d00;
+        f32x4 v01 = tw[5] * d00 + tw[3] * d01;
+        f32x4 v10 = tw[7] * d00 + tw[1] * d10;
+        f32x4 v11 = tw[8] * d00 + tw[6] * d01 + (tw[2] * d10 + tw[0] * d11);
+        if (EP) {
+            auto fin = [&](f32x4& v, const f32x4& yv, bool on) {
+                if (!on) return;
+                const f32x4 xh = yv * rs + nm, z = yv * sc + sh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= gg_act_grad_f32(z[r], ep_act);
+                cs += v; cq += v * xh;
+            };
+            fin(v00, e00, true); fin(v01, e01, k1); fin(v10, e10, r1); fin(v11, e11, r1 && k1);
+        }
+        *reinterpret_cast<f32x4*>(out + p00) = v00;
+        if (k1) *reinterpret_cast<f32x4*>(out + p01) = v01;
+        if (r1) *reinterpret_cast<f32x4*>(out + p10) = v10;
+        if (r1 && k1) *reinterpret_cast<f32x4*>(out + p11) = v11;
     }
     if (EP) {
 #pragma unroll
@@ -625,10 +649,10 @@ extern "C" int gg_dwconv3x3_bwd_data_f32(const float* dy, const float* taps, flo
     GG_LAUNCH_CHECK();
     return 0;
 }
-static int dw_s2_fused_blocks(int B, int H, int W, int C) {
+static int dw_s2_fused_blocks(int B, int H, int W, int C) {       // work items are 2 x 2 quads of input pixels
     const int CG = C / 4, PX = std::max(1, 256 / CG);
-    const int64_t total = (int64_t)B * H * W;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(4096, gg_cdiv(total, (int64_t)PX * 8)));
+    const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(4096, gg_cdiv(total, (int64_t)PX * 4)));
 }
 extern "C" int gg_dwconv_f32_s2_fused_stat_rows(int B, int H, int W, int C) { return dw_s2_fused_blocks(B, H, W, C); }
 // stride-2 data gradient (H, W = the conv INPUT map) with the BatchNorm-backward passes on both sides riding on it; see the kernel
@@ -643,7 +667,7 @@ extern "C" int gg_dwconv3x3_s2_bwd_data_fused_f32(const float* dz_in, const floa
     GG_PROF(GG_CAT_DWCONV, 18.0 * B * Ho * Wo * C, 4.0 * B * C * ((double)H * W * (1.0 + (ep_y != nullptr)) + (double)Ho * Wo * (1.0 + (in_coef != nullptr))), stream);
     const int CG = C / 4, PX = std::max(1, 256 / CG);
     const int blocks = dw_s2_fused_blocks(B, H, W, C);
-    const int64_t total = (int64_t)B * H * W;
+    const int64_t total = (int64_t)B * Ho * Wo;                       // quads: ceil(H/2) x ceil(W/2) == Ho x Wo
     const int64_t ppb = gg_align(gg_cdiv(total, blocks), PX);
     const dim3 grid((unsigned)gg_cdiv(total, ppb)), block((unsigned)(CG * PX));
     GG_CHECK((int)grid.x <= blocks, "gg_dwconv3x3_s2_bwd_data_fused_f32: internal grid error");

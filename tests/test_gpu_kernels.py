@@ -761,4 +761,4 @@ def test_dwconv_stride2_data_gradient_with_batchnorm_fusions_f32(ops, C, H, B):
     close(part2.double().cpu().sum(0)[0], s[0], rtol=1e-5, atol=1e-4, what="partials agree")
     plain, _ = ops.dwconv3x3_s2_bwd_data_fused(dev(dy), None, None, dev(taps), H, H)
     close(plain, conv_t(dy), rtol=2e-4, atol=2e-5, what="f32 s2 plain dgrad")
-    close(plain, ops.dwconv3x3_bwd_data(dev(dy), dev(taps), B, H, H, C, stride=2), rtol=0, atol=0, what="same arithmetic as the unfused gather")
+    close(plain, ops.dwconv3x3_bwd_data(dev(dy), dev(taps), B, H, H, C, stride=2), rtol=1e-5, atol=1e-6, what="agrees with the unfused gather (tap order differs)")
