@@ -71,8 +71,7 @@ __global__ __launch_bounds__(256) void im2col_nhwc_f32_kernel(const float* __res
             v = *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + iy) * W + ix) * C + g * 4);
             if (BN) {
                 const f32x4 sc = *reinterpret_cast<const f32x4*>(tab + g * 4), sh = *reinterpret_cast<const f32x4*>(tab + 512 + g * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = act_exact(fmaf(v[j], sc[j], sh[j]), act);
+                v = gg_act_f32_v4(v * sc + sh, act);
             }
         }
         *reinterpret_cast<f32x4*>(col + p * (9 * C) + tap * C + g * 4) = v;
@@ -173,8 +172,7 @@ __global__ __launch_bounds__(256) void dw3x3_walk_f32_kernel(const float* __rest
     auto ld = [&](const float* p, const float* p2) {
         f32x4 v = *reinterpret_cast<const f32x4*>(p);
         if (IN == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = act_exact(fmaf(v[j], ia[j], ib[j]), fz.in_act);
+            v = gg_act_f32_v4(v * ia + ib, fz.in_act);
         }
         if (IN == 2) v = ia * v + (ib * *reinterpret_cast<const f32x4*>(p2) + ic);
         return v;
@@ -209,8 +207,7 @@ __global__ __launch_bounds__(256) void dw3x3_walk_f32_kernel(const float* __rest
                 const int64_t oo = (((int64_t)b * Ho + oy) * Wo + ox) * C + cg * 4;
                 if (EPI) {      // dz = da * act'(gamma*xhat + beta); sums of dz and dz*xhat
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(fz.ep_y + oo);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] *= act_grad_exact(fmaf(yv[j], esc[j], esh[j]), fz.ep_act);
+                    o *= gg_act_grad_f32_v4(yv * esc + esh, fz.ep_act);
                     acc[0] += o; acc[1] += o * (yv * ers + enm);
                 } else if (part) { acc[0] += o; acc[1] += o * o; }
                 *reinterpret_cast<f32x4*>(y + oo) = o;
@@ -296,8 +293,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_multi_f32_kernel(const float* __
         for (int j = 0; j < OX + 2; ++j) {
             f32x4 t = v[j];
             if (IN == 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) t[q] = act_exact(fmaf(t[q], ia[q], ib[q]), fz.in_act);
+                t = gg_act_f32_v4(t * ia + ib, fz.in_act);
             }
             if (IN == 2) t = ia * t + (ib * v2[IN == 2 ? j : 0] + ic);
             r[j] = (rok && cok[j]) ? t : zero;             // padding is zero AFTER the transform
@@ -321,8 +317,7 @@ __global__ __launch_bounds__(256) void dw3x3_s1_multi_f32_kernel(const float* __
             if (ox0 + j < W) {
                 if (EPI) {
                     const f32x4 yv = ey[EPI ? j : 0];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] *= act_grad_exact(fmaf(yv[q], esc[q], esh[q]), fz.ep_act);
+                    o *= gg_act_grad_f32_v4(yv * esc + esh, fz.ep_act);
                     s0 += o; s1 += o * (yv * ers + enm);
                 } else if (part) { s0 += o; s1 += o * o; }
                 *reinterpret_cast<f32x4*>(y + obase + (int64_t)j * C) = o;
@@ -459,8 +454,7 @@ __global__ __launch_bounds__(256) void dw3x3_s2_bwd_data_fused_f32_kernel(const 
             auto fin = [&](f32x4& v, const f32x4& yv, bool on) {
                 if (!on) return;
                 const f32x4 xh = yv * rs + nm, z = yv * sc + sh;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= gg_act_grad_f32(z[r], ep_act);
+                v *= gg_act_grad_f32_v4(z, ep_act);
                 cs += v; cq += v * xh;
             };
             fin(v00, e00, true); fin(v01, e01, k1); fin(v10, e10, r1); fin(v11, e11, r1 && k1);

@@ -170,8 +170,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                 } else if (EPI == FE_BNBWD) {
                     if (ok) {       // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat
                         const f32x4 yv = aux[AUX ? gi : 0][AUX ? mtl : 0];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] *= act_grad_exact_f(fmaf(yv[r], bsc[r], bsh[r]), p.bn_act);
+                        v *= gg_act_grad_f32_v4(yv * bsc + bsh, p.bn_act);
                         cs += v; cq += v * (yv * brs + bnm);
                     }
                 } else if (ok) {
@@ -188,8 +187,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
                         } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = gelu_exact(v[r]);
+                            v = gg_act_f32_v4(v, GG_ACT_GELU);
                         }
                     }
                     if (EPI == FE_QGELU) {
@@ -205,8 +203,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
                                 v[r] *= (sg + 1.702f * h[r] * sg * (1.0f - sg)) * rs;
                             }
                         } else {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] *= gelu_grad_exact(h[r]) * rs;
+                            v *= gg_act_grad_f32_v4(h, GG_ACT_GELU) * rs;
                         }
                     }
                     if (EPI == FE_LINEAR) {
@@ -267,8 +264,7 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) d[r] = d[r] / (1.0f + expf(-1.702f * d[r]));
                             } else {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) d[r] = gelu_exact(d[r]);
+                                d = gg_act_f32_v4(d, GG_ACT_GELU);
                             }
                         }
                         float* g = p.C + (int64_t)m * p.ldc + n;
@@ -573,8 +569,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
                     const bool rok = kin && (m0 + wm * (BM / WM) + mt * 16 + lr < p.M);
                     f32x4 v = xs[mt];
                     if (PRO == 1) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = act_exact_f(fmaf(v[j], c0[j], c1[j]), p.a_act);
+                        v = gg_act_f32_v4(v * c0 + c1, p.a_act);
                     } else {
                         const f32x4 x2 = *reinterpret_cast<const f32x4*>(base2 + a_off + mt * 16 * SK);
                         v = c0 * v + (c1 * x2 + c2);
