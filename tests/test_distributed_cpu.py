@@ -93,6 +93,52 @@ def test_two_rank_real_backbone_layout():
     assert eq(hw0, hw1) and float(hw0[0, 0]) == 3.0 and float(hb0[0]) == 30.0            # loose parameters summed too
 
 
+def _clip_worker(rank, world, port, out):
+    _init(rank, world, port)
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
+    from geoguessr_ai_amd.optim import AdamW
+    tower = CLIPVisionTower("openai/clip-vit-tiny-ddp", seed=100 + rank, hidden_size=128, intermediate_size=512, num_layers=3, num_heads=2, image_size=64,
+                            patch_size=32)
+    layers = list(tower.vision_model.encoder.layers)
+    for layer in layers[:-1]:                                      # models/super_guessr.py:140-146: only the last encoder layer (+ embeddings) trains
+        for p in layer.parameters():
+            p.requires_grad = False
+    vm = tower.vision_model
+    opt = AdamW(tower, lr=1e-3)
+    assert len(opt.backbones) == 1 and opt.backbones[0] is vm and not opt.loose
+    opt.broadcast_params()
+    p0 = vm.flat_params.clone()
+    ranges = vm.trainable_ranges()
+    fg = vm.flat_grads()
+    g = torch.Generator().manual_seed(rank)
+    for s, e in ranges:
+        fg[s:e] = torch.randn(e - s, generator=g)
+    frozen = slice(ranges[0][1], ranges[0][1] + 32)                # first floats of frozen layer 0
+    fg[frozen] = 7.0 + rank
+    local = fg.clone()
+    with opt.overlap_allreduce(enabled=True):
+        vm._grad_ready_hook(0, vm.param_floats)                    # what CLIPVisionTower.backward_hip does after gg_clip_backward
+        launched = len(opt._inflight)
+    opt.allreduce_grads()
+    n = lambda t: t.detach().numpy().copy()
+    out.put((rank, n(p0), n(local), n(fg), ranges, launched, (frozen.start, frozen.stop)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_clip_tower_layout():
+    """The CLIP tower's flat storage under the reference's fine-tune policy (encoder layers[:-1] frozen): rank 0's weights everywhere, the trainable
+    ranges (embeddings | last layer + post_layernorm) summed over the ranks, frozen floats never exchanged."""
+    r0, r1 = _spawn(_clip_worker)
+    _, pa, loc0, g0, ranges, l0, probe = r0
+    _, pb, loc1, g1, _, l1, _ = r1
+    assert np.array_equal(pa, pb)
+    assert len(ranges) == 2 and ranges[0][0] == 0 and l0 == l1 == 2
+    for s, e in ranges:
+        assert np.array_equal(g0[s:e], g1[s:e]) and np.allclose(g0[s:e], loc0[s:e] + loc1[s:e])
+    assert float(g0[probe[0]]) == 7.0 and float(g1[probe[0]]) == 8.0
+
+
 class _ToyModel(torch.nn.Module):
     """CPU stand-in with SuperGuessr's call surface (ModelOutput, num_candidates): linear geocell classifier on embeddings."""
 
