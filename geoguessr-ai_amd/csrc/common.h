@@ -274,27 +274,67 @@ __device__ __forceinline__ float gg_block_max(float v, float* red) {
 // folded to <= GG_REDUCE_SLICES rows by a bandwidth-shaped kernel (coalesced along W, fp64 accumulation).  The folded
 // rows are written BEHIND the valid rows of the same buffer, which therefore needs nparts + GG_REDUCE_SLICES rows.
 #define GG_REDUCE_SLICES 64
-static __global__ __launch_bounds__(256) void gg_reduce_rows_kernel(const float* __restrict__ part, int nparts, int W,
-                                                                    float* __restrict__ out, int rows_per_slice) {
-    __shared__ double red[4][64];
+// a finalize kernel shaped by gg_fold_cols2 (64 columns x GG_FOLD_TY row lanes per block) takes this many rows directly
+#define GG_REDUCE_DIRECT_MAX 512
+#define GG_FOLD_TY 16
+static __global__ __launch_bounds__(1024) void gg_reduce_rows_kernel(const float* __restrict__ part, int nparts, int W,
+                                                                     float* __restrict__ out, int rows_per_slice) {
+    __shared__ double red[GG_FOLD_TY][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + tx;
     const int r0 = blockIdx.y * rows_per_slice, r1 = min(nparts, r0 + rows_per_slice);
-    double s = 0.0;
-    if (col < W)
-        for (int r = r0 + ty; r < r1; r += 4) s += (double)part[(int64_t)r * W + col];
-    red[ty][tx] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (col < W) {
+        const float* p = part + col;
+        int r = r0 + ty;
+        for (; r + 3 * GG_FOLD_TY < r1; r += 4 * GG_FOLD_TY) {          // four independent loads in flight per lane
+            const float a = p[(int64_t)r * W], b = p[(int64_t)(r + GG_FOLD_TY) * W], c = p[(int64_t)(r + 2 * GG_FOLD_TY) * W],
+                        d = p[(int64_t)(r + 3 * GG_FOLD_TY) * W];
+            s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+        }
+        for (; r < r1; r += GG_FOLD_TY) s0 += (double)p[(int64_t)r * W];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (ty == 0 && col < W) out[(int64_t)blockIdx.y * W + col] = (float)(red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+    if (ty == 0 && col < W) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < GG_FOLD_TY; ++i) t += red[i][tx];
+        out[(int64_t)blockIdx.y * W + col] = (float)t;
+    }
 }
-// returns the rows to finalize from (either the originals or the folded ones) through *rows / *nrows
-static inline void gg_reduce_rows(float* part, int nparts, int W, hipStream_t st, const float** rows, int* nrows) {
-    if (nparts <= GG_REDUCE_SLICES) { *rows = part; *nrows = nparts; return; }
+// returns the rows to finalize from (either the originals or the folded ones) through *rows / *nrows; direct_max = the row count the
+// caller's finalize kernel handles without folding
+static inline void gg_reduce_rows(float* part, int nparts, int W, hipStream_t st, const float** rows, int* nrows, int direct_max = GG_REDUCE_SLICES) {
+    if (nparts <= direct_max) { *rows = part; *nrows = nparts; return; }
     const int rps = (int)((nparts + GG_REDUCE_SLICES - 1) / GG_REDUCE_SLICES);
     const int slices = (nparts + rps - 1) / rps;
     float* out = part + (int64_t)nparts * W;
-    hipLaunchKernelGGL(gg_reduce_rows_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)slices), dim3(256), 0, st, part, nparts, W, out, rps);
+    hipLaunchKernelGGL(gg_reduce_rows_kernel, dim3((unsigned)((W + 63) / 64), (unsigned)slices), dim3(64 * GG_FOLD_TY), 0, st, part, nparts, W, out, rps);
     *rows = out; *nrows = slices;
+}
+// Block of 64 x GG_FOLD_TY threads (launch with dim3(64 * GG_FOLD_TY)): fp64 sums over rows [0, nrows) of part[.][W] at columns c0 and c1
+// for the block's 64 channels.  The totals are valid in the threads with (threadIdx.x >> 6) == 0; `ok` = this lane's channel exists.
+__device__ __forceinline__ void gg_fold_cols2(const float* __restrict__ part, int nrows, int64_t W, int c0, int c1, bool ok, double& s, double& q) {
+    __shared__ double red[2][GG_FOLD_TY][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (ok) {
+        int r = ty;
+        for (; r + GG_FOLD_TY < nrows; r += 2 * GG_FOLD_TY) {
+            const float x0 = part[r * W + c0], y0 = part[r * W + c1], x1 = part[(r + GG_FOLD_TY) * W + c0], y1 = part[(r + GG_FOLD_TY) * W + c1];
+            a0 += (double)x0; b0 += (double)y0; a1 += (double)x1; b1 += (double)y1;
+        }
+        if (r < nrows) { a0 += (double)part[r * W + c0]; b0 += (double)part[r * W + c1]; }
+    }
+    red[0][ty][tx] = a0 + a1;
+    red[1][ty][tx] = b0 + b1;
+    __syncthreads();
+    s = 0.0; q = 0.0;
+    if (ty == 0) {
+#pragma unroll
+        for (int i = 0; i < GG_FOLD_TY; ++i) { s += red[0][i][tx]; q += red[1][i][tx]; }
+    }
 }
 
 // XCD-aware block remap: consecutive logical ids land on the same XCD (bijective for any n).

@@ -53,15 +53,12 @@ template <typename T> __device__ __forceinline__ float act_grad_t(float x, int a
 
 // ------------------------------------------------------------------------------ BN statistics
 // part [nparts][2][C] -> stat [2][C] = (mean, rstd); running stats updated with unbiased variance.
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, float eps, float momentum,
+__global__ __launch_bounds__(64 * GG_FOLD_TY) void bn_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, float eps, float momentum,
                                    float* __restrict__ stat, float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) {
-        s += (double)part[(int64_t)i * 2 * C + c];
-        q += (double)part[(int64_t)i * 2 * C + C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, q;
+    gg_fold_cols2(part, nparts, 2 * (int64_t)C, c, C + c, c < C, s, q);
+    if (c >= C || (threadIdx.x >> 6) != 0) return;
     const double mean = s / count;
     double var = q / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -171,16 +168,13 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dout, const T* __rest
 }
 // part [nparts][2][C] (sum g, sum g*xhat) -> coef [3][C] with  dy = coef0*g + coef1*y + coef2  ==
 // gamma*rstd*(g - mean(g) - xhat*mean(g*xhat));  optional dgamma (+)= sum g*xhat, dbeta (+)= sum g
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ stat,
+__global__ __launch_bounds__(64 * GG_FOLD_TY) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ stat,
                                        const float* __restrict__ gamma, float* __restrict__ coef, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) {
-        s += (double)part[(int64_t)i * 2 * C + c];
-        q += (double)part[(int64_t)i * 2 * C + C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, q;
+    gg_fold_cols2(part, nparts, 2 * (int64_t)C, c, C + c, c < C, s, q);
+    if (c >= C || (threadIdx.x >> 6) != 0) return;
     const double mu = stat[c], rstd = stat[C + c];
     const double a = (double)gamma[c] * rstd, k2 = s / count, k3 = q / count;
     coef[c] = (float)a;
@@ -548,15 +542,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const TG* __restrict
     }
 }
 // part [nparts][2][C] -> dgamma (+)= part[.][0], dbeta (+)= part[.][1]
-__global__ void ln_param_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
+__global__ __launch_bounds__(64 * GG_FOLD_TY) void ln_param_final_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ dgamma,
                                       float* __restrict__ dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int i = 0; i < nparts; ++i) {
-        s += (double)part[(int64_t)i * 2 * C + c];
-        q += (double)part[(int64_t)i * 2 * C + C + c];
-    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s, q;
+    gg_fold_cols2(part, nparts, 2 * (int64_t)C, c, C + c, c < C, s, q);
+    if (c >= C || (threadIdx.x >> 6) != 0) return;
     dgamma[c] = accumulate ? dgamma[c] + (float)s : (float)s;
     dbeta[c] = accumulate ? dbeta[c] + (float)q : (float)q;
 }
@@ -641,8 +632,8 @@ extern "C" int gg_bn_finalize(float* part, int nparts, int C, int64_t count, flo
                               float* running_mean, float* running_var, void* stream) {
     GG_CHECK(part && stat && nparts > 0 && C > 0 && count > 0, "gg_bn_finalize: bad args");
     const float* rows; int nrows;
-    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
+    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows, GG_REDUCE_DIRECT_MAX);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)gg_cdiv(C, 64)), dim3(64 * GG_FOLD_TY), 0, (hipStream_t)stream, rows, nrows, C,
                        (double)count, eps, momentum, stat, running_mean, running_var);
     GG_LAUNCH_CHECK();
     return 0;
@@ -701,8 +692,8 @@ extern "C" int gg_bn_bwd_finalize(float* part, int nparts, int C, int64_t count,
                                   float* dgamma, float* dbeta, int accumulate, void* stream) {
     GG_CHECK(part && stat && gamma && coef && nparts > 0 && C > 0 && count > 0, "gg_bn_bwd_finalize: bad args");
     const float* rows; int nrows;
-    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, rows, nrows, C,
+    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows, GG_REDUCE_DIRECT_MAX);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)gg_cdiv(C, 64)), dim3(64 * GG_FOLD_TY), 0, (hipStream_t)stream, rows, nrows, C,
                        (double)count, stat, gamma, coef, dgamma, dbeta, accumulate);
     GG_LAUNCH_CHECK();
     return 0;
@@ -851,8 +842,8 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
                            gamma, M, C, (const bf16*)dres, (bf16*)dx, part);
     if (dgamma) {
         const float* rows; int nrows;
-        gg_reduce_rows(part, nb, 2 * C, s, &rows, &nrows);
-        hipLaunchKernelGGL(ln_param_final_kernel, dim3((unsigned)gg_cdiv(C, 128)), dim3(128), 0, s, rows, nrows, C, dgamma, dbeta, accumulate);
+        gg_reduce_rows(part, nb, 2 * C, s, &rows, &nrows, GG_REDUCE_DIRECT_MAX);
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((unsigned)gg_cdiv(C, 64)), dim3(64 * GG_FOLD_TY), 0, s, rows, nrows, C, dgamma, dbeta, accumulate);
     }
     GG_LAUNCH_CHECK();
     return 0;

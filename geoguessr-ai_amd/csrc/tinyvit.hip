@@ -1067,12 +1067,27 @@ extern "C" int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, co
     if (bytes) *bytes = p.regs[it->second].bytes;
     return 0;
 }
+// `only` (host, one byte per tensor, or NULL = every tensor): the tensors whose cached forms are rebuilt.  After an optimizer step only the
+// trainable tensors changed -- under the reference freeze policy 14 of the 52 cached matrices -- so the per-step refresh skips the frozen ones.
+static int refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, const uint8_t* only, void* stream);
 extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream) {
+    return refresh_weights(cfg, params, wcache, nullptr, stream);
+}
+extern "C" int gg_tinyvit_refresh_weights_masked(const GgTinyVitCfg* cfg, const float* params, void* wcache, const uint8_t* only, void* stream) {
+    return refresh_weights(cfg, params, wcache, only, stream);
+}
+static int refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, const uint8_t* only, void* stream) {
     Model m;
     GG_TRY(build_model(cfg, m));
     GG_CHECK(params && wcache, "gg_tinyvit_refresh_weights: null pointer");
     char* wc = (char*)wcache;
     hipStream_t st = (hipStream_t)stream;
+    auto repack_dense = [&](const DenseW& w, const float* pp, const Model& mm, char* c, hipStream_t s) -> int {
+        return (only && !only[w.t_w]) ? 0 : ::repack_dense(w, pp, mm, c, s);
+    };
+    auto repack_dw = [&](const DwW& w, const float* pp, const Model& mm, char* c, hipStream_t s) -> int {
+        return (only && !only[w.t_w]) ? 0 : ::repack_dw(w, pp, mm, c, s);
+    };
     GG_TRY(repack_dense(m.pe1.w, params, m, wc, st));
     GG_TRY(repack_dense(m.pe2.w, params, m, wc, st));
     for (auto& l : m.mb) {
@@ -1090,7 +1105,7 @@ extern "C" int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* 
             GG_TRY(repack_dense(b.fc1, params, m, wc, st));
             GG_TRY(repack_dense(b.fc2, params, m, wc, st));
             GG_TRY(repack_dw(b.local.w, params, m, wc, st));
-            if (b.bias_full >= 0)
+            if (b.bias_full >= 0 && !(only && !only[b.t_ab]))
                 GG_TRY(gg_attention_expand_bias(params + m.tensors[b.t_ab].offset, m.stages[s].heads, m.stages[s].ws, kAttnScale,
                                                 wc + b.bias_full, stream));
         }

@@ -137,8 +137,17 @@ class FlatStore(_Tree):
             ranges.append(tuple(cur))
         return ranges
 
-    def mark_params_dirty(self):
+    def mark_params_dirty(self, only: Optional[bytes] = None):
+        """A raw-pointer writer (the fused AdamW kernel, a broadcast, a checkpoint load) changed parameters behind torch's version counters: the
+        weight cache must be rebuilt.  ``only`` = the trainable mask the writer went by (one byte per tensor): then only those tensors' cached
+        forms are rebuilt (masks of several writes are OR-ed); ``None`` = anything may have changed."""
         self._wcache_version = -1
+        if only is None:
+            self._dirty_only = None
+            self._dirty_all = True
+        elif not getattr(self, "_dirty_all", True):
+            prev = getattr(self, "_dirty_only", None)
+            self._dirty_only = bytes(only) if prev is None else bytes(a | b for a, b in zip(prev, only))
 
     def _param_version(self):
         """Changes whenever any parameter is written through torch (``torch.optim`` steps, ``load_state_dict``, ``p.copy_``):

@@ -312,9 +312,9 @@ class SuperGuessr(nn.Module):
             self._wt32_version, self._wc_dirty = ver, False
         return self._wt32
 
-    def mark_params_dirty(self):
+    def mark_params_dirty(self, backbone: bool = True):
         self._wc_dirty = True
-        bb = getattr(self.base_model, "backbone", None)
+        bb = getattr(self.base_model, "backbone", None) if backbone else None
         if bb is not None and hasattr(bb, "mark_params_dirty"):
             bb.mark_params_dirty()
 

@@ -146,11 +146,20 @@ class TinyVitBackbone(FlatStore):
             nbytes = lib.gg_tinyvit_wcache_bytes(C.byref(self.cfg))
             self._wcache = torch.zeros(nbytes, dtype=torch.uint8, device=self._flat.device)
             self._wcache_version = -1
+            self._dirty_all = True
         ver = self._param_version()
         if self._wcache_version != ver:
-            L.check(lib.gg_tinyvit_refresh_weights(C.byref(self.cfg), L.ptr(self._flat, torch.float32, "params"),
-                                                   L.ptr(self._wcache), L.stream()), "gg_tinyvit_refresh_weights")
-            self._wcache_version = ver
+            # full rebuild unless the only writers since the last sync were masked raw-pointer writers (the fused optimizer) AND torch's own
+            # version counters did not move (no load_state_dict / copy_ / torch.optim step in between)
+            only = None if (getattr(self, "_dirty_all", True) or getattr(self, "_synced_ver", None) != ver) else getattr(self, "_dirty_only", None)
+            if only is None:
+                L.check(lib.gg_tinyvit_refresh_weights(C.byref(self.cfg), L.ptr(self._flat, torch.float32, "params"),
+                                                       L.ptr(self._wcache), L.stream()), "gg_tinyvit_refresh_weights")
+            else:
+                L.check(lib.gg_tinyvit_refresh_weights_masked(C.byref(self.cfg), L.ptr(self._flat, torch.float32, "params"),
+                                                              L.ptr(self._wcache), only, L.stream()), "gg_tinyvit_refresh_weights_masked")
+            self._wcache_version = self._synced_ver = ver
+            self._dirty_all, self._dirty_only = False, None
 
     def _workspace(self, batch: int, training: bool) -> torch.Tensor:
         need = L.lib().gg_tinyvit_workspace_bytes(C.byref(self.cfg), batch, int(training))

@@ -218,14 +218,17 @@ class AdamW:
             m, v = self._st(("bb", i), fp)
             for s, e in bb.trainable_ranges():
                 ops.adamw_step(fp[s:e], fg[s:e], m[s:e], v[s:e], **kw)
-            bb.mark_params_dirty()
+            bb.mark_params_dirty(only=bb.trainable_mask())          # only these tensors' cached forms need rebuilding
         for p in self.loose:
             if p.grad is None:
                 continue
             m, v = self._st(id(p), p.data)
             ops.adamw_step(p.data.view(-1), p.grad.contiguous().view(-1), m.view(-1), v.view(-1), **kw)
         if hasattr(self.model, "mark_params_dirty"):
-            self.model.mark_params_dirty()
+            try:
+                self.model.mark_params_dirty(backbone=False)          # the head's cached weight copies; the backbones were marked above
+            except TypeError:
+                self.model.mark_params_dirty()
 
     def zero_grad(self, set_to_none: bool = True):
         for bb in self.backbones:

@@ -364,6 +364,8 @@ int gg_drop_path_scales(const float* rates, int slots, int batch, uint64_t seed,
 int64_t gg_tinyvit_wcache_bytes(const GgTinyVitCfg* cfg);      /* bf16 copies (W and W^T) of the GEMM weights */
 int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training);
 int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream);
+/* the same for a subset: `only` (host, one byte per tensor of gg_tinyvit_tensor_info) marks the tensors that changed (after an optimizer step: the trainable ones) */
+int gg_tinyvit_refresh_weights_masked(const GgTinyVitCfg* cfg, const float* params, void* wcache, const uint8_t* only, void* stream);
 /* x: f32 NCHW (batch,in_chans,img,img).  drop_scales: f32 [num_drop_slots][batch] = keep/(1-p) or NULL.
  * out: f32 (batch, embed_dims[3]).  training: batch-stat BN + running-stat update + activations kept for backward. */
 /* trainable: host uint8[num_tensors] or NULL -- the freeze policy the backward will run with; activations that only a frozen

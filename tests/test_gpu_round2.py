@@ -376,6 +376,46 @@ def test_weight_cache_follows_torch_optim_and_load_state_dict():
     assert float((y3 - y2).abs().max()) > 1.0                    # and a direct p.copy_
 
 
+def test_masked_weight_refresh_equals_full_refresh(centroids):
+    """After a fused AdamW step on a partly frozen backbone only the trainable tensors' cached forms are rebuilt: the next forward must be
+    bit-identical to one after a full rebuild, and a torch-side write to a FROZEN tensor in between must still be noticed."""
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.optim import AdamW
+    torch.manual_seed(1)
+    base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.0)
+    m = SuperGuessr(base, panorama=True, should_smooth_labels=True, centroids=centroids[:64]).cuda().train()
+    bb = m.base_model.backbone
+    mask = bb.trainable_mask()
+    assert 0 < sum(mask) < len(mask)                           # the reference's default: last layers only
+    opt = AdamW(m, lr=1e-2)
+    x = torch.randn(2, 4, 3, 224, 224, device="cuda")
+    lab = torch.tensor([[10.0, 50.0], [-70.0, -20.0]], device="cuda")
+    m(pixel_values=x, labels=lab).loss.backward()
+    opt.step(); opt.zero_grad()
+    assert bb._dirty_all is False and bb._dirty_only == bytes(mask)
+    m.eval()
+    with torch.no_grad():
+        y_masked = m.base_model(pixel_values=x.flatten(0, 1)).pooler_output.clone()
+        assert bb._dirty_only is None
+        bb.mark_params_dirty()
+        y_full = m.base_model(pixel_values=x.flatten(0, 1)).pooler_output.clone()
+    assert torch.equal(y_masked, y_full)
+    # fused step + a torch write to a frozen tensor before the next forward: the version counter moved -> full rebuild
+    m.train()
+    m(pixel_values=x, labels=lab).loss.backward()
+    opt.step(); opt.zero_grad()
+    frozen = next(k for k, p in bb._params.items() if not p.requires_grad and k.endswith("mlp.fc1.weight"))
+    with torch.no_grad():
+        bb._params[frozen].mul_(0.25)
+    m.eval()
+    with torch.no_grad():
+        y_a = m.base_model(pixel_values=x.flatten(0, 1)).pooler_output.clone()
+        bb.mark_params_dirty()
+        y_b = m.base_model(pixel_values=x.flatten(0, 1)).pooler_output.clone()
+    assert torch.equal(y_a, y_b) and float((y_a - y_full).abs().max()) > 1e-3
+
+
 def test_backward_of_a_stale_forward_is_refused():
     from geoguessr_ai_amd import _lib as L
     from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
