@@ -79,6 +79,7 @@ SIGNATURES = {
     "gg_gemm_tn_splits": (_I, [_I, _I, _I]),
     "gg_gemm_tn": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),
     "gg_gemm_tn_bn": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _P, _I, _P]),
+    "gg_gemm_tn_bn_f32": (_I, [_P, _P, _L, _P, _P, _L, _I, _I, _I, _P, _I, _P]),
     "gg_splitk_reduce": (_I, [_P, _P, _L, _I, _I, _F, _P]),
     "gg_transpose_bf16": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "gg_cast_transpose_f32": (_I, [_P, _I, _I, _P, _L, _P, _L, _P]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     "gg_im2col_nhwc_bn_bf16": (_I, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "gg_col2im_nhwc_bf16": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_col2im_nhwc_bnbwd_bf16": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "gg_col2im_nhwc_bnbwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "gg_dwconv_stat_rows": (_I, [_I, _I, _I, _I, _I]),
     "gg_dwconv_tiled_stat_rows": (_I, [_I, _I]),
     "gg_dwconv_fused_stat_rows": (_I, [_I, _I, _I, _I, _I]),
@@ -119,6 +121,9 @@ SIGNATURES = {
     "gg_layernorm_fwd_bn_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gg_layernorm_bwd_scratch_floats": (_L, [_L, _I]),
     "gg_layernorm_bwd": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _I, _P]),
+    "gg_layernorm_bwd_colsum_rows": (_I, [_L]),
+    "gg_layernorm_bwd_colsum": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "gg_bn_bwd_coef_from_x": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P]),
     "gg_token_mean_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "gg_token_mean_bwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "gg_view_mean_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P]),

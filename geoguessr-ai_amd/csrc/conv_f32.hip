@@ -110,6 +110,62 @@ __global__ __launch_bounds__(256) void col2im_nhwc_f32_kernel(const float* __res
     }
 }
 
+// col2im (stride-2 3x3) + the BatchNorm-backward reduce of the ConvNorm whose output was gathered: da is formed per pixel, multiplied by
+// act'(BN(y)) and written as dz; per-channel (sum dz, sum dz*xhat) leave as one partial row per block.  da is never written and the
+// stand-alone reduce pass never runs (f32 twin of col2im_nhwc_bnbwd_kernel; PatchEmbed conv1 <- conv2).  Thread = (4 channels, pixel lane).
+__global__ __launch_bounds__(256) void col2im_nhwc_bnbwd_f32_kernel(const float* __restrict__ dcol, const float* __restrict__ y,
+                                                                    const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int act, float* __restrict__ dz,
+                                                                    float* __restrict__ part, int B, int H, int W, int C, int Ho, int Wo, int CG, int PP) {
+    extern __shared__ float c2i_red[];          // [PP][2][C]
+    const int g = threadIdx.x % CG, pp = threadIdx.x / CG;
+    const int c0 = g * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+    if (pp < PP) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(stat + c0), rstd = *reinterpret_cast<const f32x4*>(stat + C + c0);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+        const int64_t npix = (int64_t)B * H * W;
+        const unsigned HW = (unsigned)H * (unsigned)W;
+        for (int64_t p = (int64_t)blockIdx.x * PP + pp; p < npix; p += (int64_t)gridDim.x * PP) {
+            const unsigned pu = (unsigned)p;
+            const unsigned b = pu / HW, rem = pu - b * HW;
+            const int iy = (int)(rem / (unsigned)W), ix = (int)(rem - (unsigned)iy * (unsigned)W);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + p * C + c0);
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            // oy = (iy + 1 - ky) / 2 with iy + 1 - ky even -> ky = 1 for even rows, ky in {0, 2} for odd rows; same in x.  Tap order (ky, kx)
+            // ascending, as col2im_nhwc_f32_kernel adds them: the sum is bit-identical to the unfused route's da
+            const int ky0 = (iy & 1) ? 0 : 1, nky = (iy & 1) ? 2 : 1;
+            const int kx0 = (ix & 1) ? 0 : 1, nkx = (ix & 1) ? 2 : 1;
+            for (int a = 0; a < nky; ++a) {
+                const int ky = ky0 + 2 * a, oy = (iy + 1 - ky) >> 1;
+                if (oy < 0 || oy >= Ho) continue;
+                for (int c = 0; c < nkx; ++c) {
+                    const int kx = kx0 + 2 * c, ox = (ix + 1 - kx) >> 1;
+                    if (ox < 0 || ox >= Wo) continue;
+                    acc += *reinterpret_cast<const f32x4*>(dcol + (((int64_t)b * Ho + oy) * Wo + ox) * (9 * C) + (ky * 3 + kx) * C + c0);
+                }
+            }
+            const f32x4 xh = (v - mu) * rstd;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = acc[j] * gg_act_grad_f32(fmaf(ga[j], xh[j], be[j]), act);
+            s += o;
+            q += o * xh;
+            *reinterpret_cast<f32x4*>(dz + p * C + c0) = o;
+        }
+    }
+    if (pp < PP) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c2i_red[(pp * 2 + 0) * C + c0 + j] = s[j]; c2i_red[(pp * 2 + 1) * C + c0 + j] = q[j]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < PP; ++k) t += c2i_red[k * 2 * C + i];
+        part[(int64_t)blockIdx.x * 2 * C + i] = t;
+    }
+}
+
 // ---------------------------------------------------------------- column-walking depthwise 3x3
 // Thread = (4 channels, one output column); a block covers PX adjacent output columns x all C channels of one image and walks down a
 // strip of output rows.  MODE 0: y = conv(x, taps) (+ per-block partial BatchNorm statistics of y); MODE 1: the same with flipped taps
@@ -544,6 +600,24 @@ extern "C" int gg_im2col_nhwc_f32(const float* x, const float* stat, const float
     const dim3 grid(grid_for((int64_t)B * Ho * Wo * 9 * (C / 4), 65536));
     if (stat) hipLaunchKernelGGL(im2col_nhwc_f32_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, stat, gamma, beta, act, col, B, H, W, C, Ho, Wo, stride);
     else hipLaunchKernelGGL(im2col_nhwc_f32_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, stat, gamma, beta, act, col, B, H, W, C, Ho, Wo, stride);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// stride-2 3x3 only (PatchEmbed).  part: [nparts][2][C] with nparts rows as given (<= 65535); follow with gg_bn_bwd_finalize(part, nparts, ...)
+extern "C" int gg_col2im_nhwc_bnbwd_f32(const float* dcol, const float* y, const float* stat, const float* gamma, const float* beta, int act,
+                                        float* dz, float* part, int nparts, int B, int H, int W, int C, void* stream) {
+    GG_CHECK(dcol && y && stat && gamma && beta && dz && part && nparts > 0 && nparts <= 65535 && B > 0 && (C & 3) == 0 && C / 4 <= 256,
+             "gg_col2im_nhwc_bnbwd_f32: bad args");
+    GG_CHECK(((uintptr_t)dcol & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)dz & 15) == 0 && ((uintptr_t)stat & 15) == 0 &&
+             ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0, "gg_col2im_nhwc_bnbwd_f32: operands must be 16-byte aligned");
+    GG_CHECK((int64_t)B * H * W < ((int64_t)1 << 32), "gg_col2im_nhwc_bnbwd_f32: tensor too large for 32-bit pixel indexing");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int CG = C / 4, PP = std::max(1, 256 / CG);
+    const size_t lds = (size_t)PP * 2 * C * sizeof(float);
+    GG_CHECK(lds <= 64 * 1024, "gg_col2im_nhwc_bnbwd_f32: C too large");
+    GG_PROF(GG_CAT_MOVE, 0, 12.0 * B * H * W * C + 36.0 * B * Ho * Wo * C, stream);
+    hipLaunchKernelGGL(col2im_nhwc_bnbwd_f32_kernel, dim3((unsigned)nparts), dim3(CG * PP), lds, (hipStream_t)stream, dcol, y, stat, gamma, beta, act,
+                       dz, part, B, H, W, C, Ho, Wo, CG, PP);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -653,11 +653,15 @@ struct F32TnParams {
     const float* rowscale; int rows_per_scale;
     float* part;
     int tilesN, tilesK, m_per_split;
+    const float* Y2; const float* coef;      // BN form: dY := coef0*dY + coef1*Y2 + coef2 per column while staging (Y2 laid out like dY)
 };
 // SMALL (N <= 64 and K <= 64, e.g. patch_embed.conv1: 48 x 32 over 12.8 M rows): one 16x16-fragment block covers the whole result, so the four
 // waves split the ROWS of every 32-row step instead of the (n, k) plane and each writes its own slab (slab = 4 * block + wave; the
 // caller's slab reduce sums them like any other split).  Fragments entirely beyond N / K are skipped in both forms.
-template <bool SMALL>
+// BN: the left operand is BatchNorm backward's apply step dy = c0*dz + c1*y + c2 (gg_bn_bwd_finalize's coef) of the two tensors (dz, y), formed
+// per 16-byte chunk between the global load and the LDS store -- the weight gradient of a ConvNorm straight from (dz, y), no dy tensor.  Rows
+// beyond the split read as zero in X, so the c2 they would contribute to dy meets a zero and drops out.
+template <bool SMALL, bool BN = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
     constexpr int TB = 128, MS = 32, RS = TB + 16;
     constexpr int LS = MS * (TB / 4) / 256;                 // 16-byte chunks per thread per operand per step (= 4)
@@ -685,13 +689,24 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
         vox[i] = ((unsigned)(srow + 8 * i) * (unsigned)p.ldx + (unsigned)(k0 + sch * 4)) * 4u;
     }
     const unsigned stepY = (unsigned)MS * (unsigned)p.ldy * 4u, stepX = (unsigned)MS * (unsigned)p.ldx * 4u;
-    f32x4 ry[LS], rx[LS];
+    f32x4 ry[LS], rx[LS], ry2[BN ? LS : 1];
     float rsc[LS];
+    f32x4 cf0 = {0.f, 0.f, 0.f, 0.f}, cf1 = cf0, cf2 = cf0;
+    __amdgpu_buffer_rsrc_t rsY2 = rsY;
+    if (BN) {
+        rsY2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Y2 + (int64_t)mbeg * p.ldy), 0, (int)((unsigned)nrows * (unsigned)p.ldy * 4u), 0x00020000);
+        if (yok) {
+            cf0 = *reinterpret_cast<const f32x4*>(p.coef + n0 + sch * 4);
+            cf1 = *reinterpret_cast<const f32x4*>(p.coef + p.N + n0 + sch * 4);
+            cf2 = *reinterpret_cast<const f32x4*>(p.coef + 2 * p.N + n0 + sch * 4);
+        }
+    }
     auto load_step = [&](int m0) {
         const unsigned st = (unsigned)(m0 - mbeg) / MS;
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
             ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
+            if (BN) ry2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY2, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
             rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(xok ? vox[i] + st * stepX : 0xFFFFFFF0u), 0, 0));
         }
         if (p.rowscale) {
@@ -706,6 +721,10 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (mbeg < mend) load_step(mbeg);
     for (int m0 = mbeg; m0 < mend; m0 += MS) {
+        if (BN) {
+#pragma unroll
+            for (int i = 0; i < LS; ++i) ry[i] = cf0 * ry[i] + (cf1 * ry2[i] + cf2);
+        }
         if (p.rowscale) {
 #pragma unroll
             for (int i = 0; i < LS; ++i) ry[i] *= rsc[i];
@@ -916,7 +935,19 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     return 0;
 }
 
+static int gemm_tn_f32_launch(const void* dY, const void* Y2, const float* coef, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale,
+                              int rows_per_scale, float* partials, int splits, void* stream);
 extern "C" int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale,
+                              int rows_per_scale, float* partials, int splits, void* stream) {
+    return gemm_tn_f32_launch(dY, nullptr, nullptr, ldy, X, ldx, M, N, K, rowscale, rows_per_scale, partials, splits, stream);
+}
+// weight gradient of a ConvNorm from (dz, y, coef): the left operand is coef0*dz + coef1*y + coef2 per column (y laid out like dz, ld = ldy)
+extern "C" int gg_gemm_tn_bn_f32(const void* dz, const void* y, int64_t ldy, const float* coef, const void* X, int64_t ldx, int M, int N, int K,
+                                 float* partials, int splits, void* stream) {
+    GG_CHECK(y && coef && ((uintptr_t)y & 15) == 0 && ((uintptr_t)coef & 15) == 0, "gg_gemm_tn_bn_f32: y / coef missing or misaligned");
+    return gemm_tn_f32_launch(dz, y, coef, ldy, X, ldx, M, N, K, nullptr, 0, partials, splits, stream);
+}
+static int gemm_tn_f32_launch(const void* dY, const void* Y2, const float* coef, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale,
                               int rows_per_scale, float* partials, int splits, void* stream) {
     GG_CHECK(dY && X && partials && M > 0 && N > 0 && K > 0 && splits > 0, "gg_gemm_tn_f32: bad args");
     GG_CHECK((N & 3) == 0 && (K & 3) == 0 && (ldy & 3) == 0 && (ldx & 3) == 0, "gg_gemm_tn_f32: N, K, ldy, ldx must be multiples of 4");
@@ -925,15 +956,19 @@ extern "C" int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_
     F32TnParams p;
     p.dY = (const float*)dY; p.ldy = ldy; p.X = (const float*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
     p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials;
+    p.Y2 = (const float*)Y2; p.coef = coef;
     p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
     const bool small = N <= 64 && K <= 64 && (splits & 3) == 0;      // gg_gemm_tn_f32_splits returns a multiple of 4 for these shapes
     const int blocks = small ? splits / 4 : splits;
     p.m_per_split = (int)gg_align(gg_cdiv(M, blocks), 32);
     GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 32), "gg_gemm_tn_f32: a split's rows must span < 4 GiB per operand (use more splits)");
     GG_CHECK((int64_t)p.tilesN * p.tilesK * blocks < ((int64_t)1 << 31), "gg_gemm_tn_f32: grid too large");
-    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * M * ((double)N + K) + 4.0 * splits * (double)N * K, stream);
-    if (small) hipLaunchKernelGGL(gemm_tn_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm_tn_f32_kernel<false>, dim3((unsigned)(p.tilesN * p.tilesK * blocks)), dim3(256), 0, (hipStream_t)stream, p);
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * M * ((double)N * (Y2 ? 2 : 1) + K) + 4.0 * splits * (double)N * K, stream);
+    if (Y2) {
+        if (small) hipLaunchKernelGGL((gemm_tn_f32_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true>), dim3((unsigned)(p.tilesN * p.tilesK * blocks)), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (small) hipLaunchKernelGGL((gemm_tn_f32_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_tn_f32_kernel<false>), dim3((unsigned)(p.tilesN * p.tilesK * blocks)), dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -185,6 +185,21 @@ __global__ __launch_bounds__(64 * GG_FOLD_TY) void bn_bwd_finalize_kernel(const 
         dbeta[c] = accumulate ? dbeta[c] + (float)s : (float)s;
     }
 }
+// the same coefficients from (sum g*x, sum g) with x = gamma*xhat + beta the BatchNorm's OUTPUT (rows left by gg_layernorm_bwd_colsum); the
+// BatchNorm's own parameter gradients would need a division by gamma and are not formed: frozen BatchNorm parameters only
+__global__ __launch_bounds__(64 * GG_FOLD_TY) void bn_bwd_coef_from_x_kernel(const float* __restrict__ part, int nparts, int C, double count,
+                                                                           const float* __restrict__ stat, const float* __restrict__ gamma,
+                                                                           const float* __restrict__ beta, float* __restrict__ coef) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double t, s1;
+    gg_fold_cols2(part, nparts, 2 * (int64_t)C, c, C + c, c < C, t, s1);
+    if (c >= C || (threadIdx.x >> 6) != 0) return;
+    const double mu = stat[c], r = stat[C + c], g = gamma[c];
+    const double u = (t - (double)beta[c] * s1) / count;          // gamma * mean(g * xhat)
+    coef[c] = (float)(g * r);
+    coef[C + c] = (float)(-r * r * u);
+    coef[2 * C + c] = (float)(-g * r * s1 / count + r * r * mu * u);
+}
 // dy = coef0*(rs*dz) + coef1*y + coef2     (same thread geometry as bn_apply)
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ coef, int64_t M,
@@ -366,8 +381,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const T* __restr
         if (mean_out && l16 == 0) { mean_out[m] = mean; rstd_out[m] = rstd; }
     }
 }
-// backward, same geometry.  PARAMS: accumulate (sum dout*xhat, sum dout) per channel -> part [gridDim.x][2][C]
-template <typename T, int NCH, bool PARAMS>
+// backward, same geometry.  PARAMS 1: accumulate (sum dout*xhat, sum dout) per channel -> part [gridDim.x][2][C] (the LayerNorm's own
+// parameter gradients).  PARAMS 2: accumulate (sum dx*x, sum dx) of the RESULT dx against the raw input x instead -- the column sums the
+// BatchNorm in front of this LayerNorm needs for its backward (gg_bn_bwd_coef_from_x), so that no separate reduce pass reads dx again
+template <typename T, int NCH, int PARAMS>
 __global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const T* __restrict__ dout, const T* __restrict__ x,
                                                                 const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                                 const float* __restrict__ gamma, int64_t M, int C,
@@ -418,11 +435,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const T* __restr
                 dxh[k][j] = dv * g[k][j];
                 s1 += dxh[k][j];
                 s2 = fmaf(dxh[k][j], xh[k][j], s2);
-                if (PARAMS) { dg[k][j] = fmaf(dv, xh[k][j], dg[k][j]); db[k][j] += dv; }
+                if (PARAMS == 1) { dg[k][j] = fmaf(dv, xh[k][j], dg[k][j]); db[k][j] += dv; }
             }
         }
         s1 = gg_group16_sum(s1) * invC;
         s2 = gg_group16_sum(s2) * invC;
+        const float inv_rstd = PARAMS == 2 ? 1.f / rstd : 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = l16 + 16 * k;
@@ -433,6 +451,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_g16_kernel(const T* __restr
                     float r = rstd * (dxh[k][j] - s1 - xh[k][j] * s2);
                     if (dres) r += rr[k][j];
                     o[j] = r;
+                    if (PARAMS == 2) { dg[k][j] = fmaf(r, fmaf(xh[k][j], inv_rstd, mean), dg[k][j]); db[k][j] += r; }
                 }
                 Vec8<T>::store(dx + m * C + ch * 8, o);
             }
@@ -825,9 +844,9 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
     if (nchl <= 5) {
 #define GG_LN_BWD2(T_, N_)                                                                                                             \
     do {                                                                                                                               \
-        if (part) hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, true>), dim3(nb), dim3(256), lds, s, (const T_*)dout, (const T_*)x, \
+        if (part) hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, 1>), dim3(nb), dim3(256), lds, s, (const T_*)dout, (const T_*)x, \
                                      mean, rstd, gamma, M, C, (const T_*)dres, (T_*)dx, part);                                          \
-        else hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, false>), dim3(nb), dim3(256), 0, s, (const T_*)dout, (const T_*)x,   \
+        else hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, 0>), dim3(nb), dim3(256), 0, s, (const T_*)dout, (const T_*)x,   \
                                 mean, rstd, gamma, M, C, (const T_*)dres, (T_*)dx, part);                                               \
     } while (0)
 #define GG_LN_BWD(N_) do { if (f32) GG_LN_BWD2(float, N_); else GG_LN_BWD2(bf16, N_); } while (0)
@@ -845,6 +864,33 @@ extern "C" int gg_layernorm_bwd(const void* dout, const void* x, int f32, const 
         gg_reduce_rows(part, nb, 2 * C, s, &rows, &nrows, GG_REDUCE_DIRECT_MAX);
         hipLaunchKernelGGL(ln_param_final_kernel, dim3((unsigned)gg_cdiv(C, 64)), dim3(64 * GG_FOLD_TY), 0, s, rows, nrows, C, dgamma, dbeta, accumulate);
     }
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_layernorm_bwd_colsum_rows(int64_t M) { return std::min(ln_blocks(M), 512); }
+extern "C" int gg_layernorm_bwd_colsum(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma,
+                                       int64_t M, int C, const void* dres, void* dx, float* part, void* stream) {
+    GG_CHECK(dout && x && mean && rstd && gamma && dx && part && M > 0 && (C & 7) == 0 && C <= 640, "gg_layernorm_bwd_colsum: bad args (C %% 8, C <= 640)");
+    const int nb = gg_layernorm_bwd_colsum_rows(M);
+    GG_PROF(GG_CAT_NORM, 0, (dres ? 4.0 : 3.0) * (f32 ? 4.0 : 2.0) * M * C, stream);
+    const size_t lds = (size_t)4 * 2 * C * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+#define GG_LN_BWD2(T_, N_) hipLaunchKernelGGL((layernorm_bwd_g16_kernel<T_, N_, 2>), dim3(nb), dim3(256), lds, s, (const T_*)dout, (const T_*)x, \
+                                              mean, rstd, gamma, M, C, (const T_*)dres, (T_*)dx, part)
+#define GG_LN_BWD(N_) do { if (f32) GG_LN_BWD2(float, N_); else GG_LN_BWD2(bf16, N_); } while (0)
+    switch ((C / 8 + 15) / 16) { case 1: GG_LN_BWD(1); break; case 2: GG_LN_BWD(2); break; case 3: GG_LN_BWD(3); break; case 4: GG_LN_BWD(4); break; default: GG_LN_BWD(5); }
+#undef GG_LN_BWD
+#undef GG_LN_BWD2
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int gg_bn_bwd_coef_from_x(float* part, int nparts, int C, int64_t count, const float* stat, const float* gamma, const float* beta,
+                                     float* coef, void* stream) {
+    GG_CHECK(part && stat && gamma && beta && coef && nparts > 0 && C > 0 && count > 0, "gg_bn_bwd_coef_from_x: bad args");
+    const float* rows; int nrows;
+    gg_reduce_rows(part, nparts, 2 * C, (hipStream_t)stream, &rows, &nrows, GG_REDUCE_DIRECT_MAX);
+    hipLaunchKernelGGL(bn_bwd_coef_from_x_kernel, dim3((unsigned)gg_cdiv(C, 64)), dim3(64 * GG_FOLD_TY), 0, (hipStream_t)stream, rows, nrows, C,
+                       (double)count, stat, gamma, beta, coef);
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -368,6 +368,7 @@ struct Exec {
     bool fuse_bngemm = gg_dev_env("GG_NO_BNGEMM") == nullptr;
     // MBConv conv3 applies BatchNorm2 + GELU in its A prologue (one N tile: each element is transformed once)
     bool fuse_pro = gg_dev_env("GG_NO_PRO") == nullptr;
+    bool fuse_lncol = gg_dev_env("GG_NO_LN_COLSUM") == nullptr;   // norm2's backward leaves local_conv's BatchNorm-backward column sums (frozen blocks)
     bool fuse_lnbn = true;           // fp32: local_conv's BatchNorm apply inside norm2 (off with GG_F32_NO_FUSE)
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
@@ -376,7 +377,7 @@ struct Exec {
         f32 = m->f32;
         // reference-precision mode: the same fusions where an f32 twin exists (MBConv / PatchMerging forward, the stride-1 data gradients, the
         // GEMM-side BatchNorm epilogue / prologues); GG_F32_NO_FUSE=1 runs every BatchNorm pass on its own (the schedule the fusions are tested against)
-        if (f32 && gg_dev_env("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = fuse_lnbn = false;
+        if (f32 && gg_dev_env("GG_F32_NO_FUSE")) fuse_dw = fuse_dw_s2 = fuse_dw_s1 = fuse_bnbwd = fuse_bnbwd_epi = fuse_bngemm = fuse_pro = fuse_lnbn = fuse_lncol = false;
         if (f32) fuse_dw = false;
     }
     act_t* A(int64_t off) const { return reinterpret_cast<act_t*>(ws + off); }
@@ -669,14 +670,18 @@ static int convnorm_wgrad_from_dz(const Exec& e, const ConvBNDense& c, const Act
     float* part = e.F(e.L->bnscratch);
     const int nb = std::min(gg_bn_bwd_rows(M, bn.C), 65535);
     float* coef = part + ((int64_t)gg_bn_bwd_rows(M, bn.C) + GG_REDUCE_SLICES) * 2 * bn.C;
-    if (dcol) GG_TRY(gg_col2im_nhwc_bnbwd_bf16(dcol, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), act, dz, part, nb, B, H, W, bn.C, e.st));
+    if (dcol && e.f32) GG_TRY(gg_col2im_nhwc_bnbwd_f32((const float*)dcol, (const float*)e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), act, (float*)dz, part, nb, B, H, W, bn.C, e.st));
+    else if (dcol) GG_TRY(gg_col2im_nhwc_bnbwd_bf16(dcol, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), act, dz, part, nb, B, H, W, bn.C, e.st));
+    else if (e.f32) GG_TRY(gg_bn_bwd_reduce_f32((const float*)dout, (const float*)e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, (float*)dz, part, e.st));
     else GG_TRY(gg_bn_bwd_reduce(dout, e.A(a.y), e.F(a.stat), e.P(bn.t_g), e.P(bn.t_b), M, bn.C, act, nullptr, nullptr, 0, dz, part, e.st));
     GG_TRY(gg_bn_bwd_finalize(part, nb, bn.C, M, e.F(a.stat), e.P(bn.t_g), coef, tr ? e.Gd(bn.t_g) : nullptr, tr ? e.Gd(bn.t_b) : nullptr, 1, e.st));
     if (!e.tr(c.w.t_w)) return 0;
     const DenseW& w = c.w;
     const int K = w.Kp;
-    const int split = gg_gemm_tn_splits((int)M, w.N, K);
-    GG_TRY(gg_gemm_tn_bn(dz, e.A(a.y), bn.C, coef, X, ldx, (int)M, w.N, K, e.F(e.L->splitk), split, e.st));
+    const int split = e.f32 ? gg_gemm_tn_f32_splits((int)M, w.N, K) : gg_gemm_tn_splits((int)M, w.N, K);
+    const act_t* dzs = dz ? dz : dout;      // no activation, no residual: dz == dout and the reduce writes nothing
+    if (e.f32) GG_TRY(gg_gemm_tn_bn_f32(dzs, e.A(a.y), bn.C, coef, X, ldx, (int)M, w.N, K, e.F(e.L->splitk), split, e.st));
+    else GG_TRY(gg_gemm_tn_bn(dzs, e.A(a.y), bn.C, coef, X, ldx, (int)M, w.N, K, e.F(e.L->splitk), split, e.st));
     GG_TRY(gg_splitk_reduce(e.F(e.L->splitk), e.F(e.L->splitk), (int64_t)w.N * K, split, 0, 1.0f, e.st));
     return conv_wgrad_scatter(e.F(e.L->splitk), w.N, K, w.cin, w.taps, e.Gd(w.t_w), e.st);
 }
@@ -775,7 +780,11 @@ static int backward_impl(Exec& e, const float* d_out) {
                 GG_TRY(bias_grad(e, l.fc1.t_b, t_b, hid, M, hid, nullptr, 0));
             }
             // dx2 = LN2bwd(db) + dx                                   -> t_b
-            {
+            // frozen block: the same kernel also leaves (sum dx2*x2, sum dx2) per column, all that local_conv's BatchNorm backward needs
+            const bool lncol = e.fuse_lncol && e.fuse_bnbwd && C <= 640 && !e.tr(l.local.w.t_w) && !e.tr(l.local.bn.t_g) && !e.tr(l.ln2.t_g);
+            if (lncol) {
+                GG_TRY(gg_layernorm_bwd_colsum(t_a, e.A(a.x2), e.f32, e.F(a.mean2), e.F(a.rstd2), e.P(l.ln2.t_g), M, C, dx, t_b, e.F(L.lnscratch), e.st));
+            } else {
                 const bool tr = e.tr(l.ln2.t_g);
                 GG_TRY(gg_layernorm_bwd(t_a, e.A(a.x2), e.f32, e.F(a.mean2), e.F(a.rstd2), e.P(l.ln2.t_g), M, C, dx, t_b, e.F(L.lnscratch),
                                         tr ? e.Gd(l.ln2.t_g) : nullptr, tr ? e.Gd(l.ln2.t_b) : nullptr, 1, e.st));
@@ -788,7 +797,9 @@ static int backward_impl(Exec& e, const float* d_out) {
                 GG_TRY(dw_bwd_data(e, l.local.w, t_a, t_c, B, st.res, st.res, 1));
             } else {
                 // frozen taps: BN-backward apply is folded into the conv's staging (no dz / dy tensors at all)
-                GG_TRY(bn_bwd_reduce_fin(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, nullptr));
+                if (lncol) GG_TRY(gg_bn_bwd_coef_from_x(e.F(L.lnscratch), gg_layernorm_bwd_colsum_rows(M), C, M, e.F(a.local.stat), e.P(l.local.bn.t_g),
+                                                        e.P(l.local.bn.t_b), bn_coef(e, M, C), e.st));
+                else GG_TRY(bn_bwd_reduce_fin(e, l.local.bn, a.local, M, GG_ACT_NONE, t_b, nullptr));
                 GG_TRY(dw_bwd_data_fused(e, t_b, e.A(a.local.y), bn_coef(e, M, C), l.local.w, t_c, B, st.res, st.res,
                                                    nullptr, nullptr, nullptr, nullptr, 0, nullptr));
             }
@@ -958,13 +969,25 @@ static int backward_impl(Exec& e, const float* d_out) {
         act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
         const bool need1 = e.tr(m.pe1.w.t_w) || e.tr(m.pe1.bn.t_g);
         const bool need2 = e.tr(m.pe2.w.t_w) || e.tr(m.pe2.bn.t_g) || need1;
-        if (need2) {
+        // f32: conv2's BatchNorm backward stops after reduce + finalize; the weight-gradient GEMM and the data-gradient GEMM form
+        // dy2 = c0*dx + c1*y2 + c2 from (dx, y2) while staging their operand (no apply pass, no dy2 tensor)
+        const bool pe2_two_source = e.f32 && e.fuse_bnbwd && e.fuse_pro && d[0] <= 384 && m.pe2.w.N == m.pe2.bn.C;
+        if (need2 && pe2_two_source) {
+            GG_TRY(convnorm_wgrad_from_dz(e, m.pe2, L.pe2, M0, GG_ACT_NONE, dx, nullptr, e.A(L.col2), m.pe2.w.Kp));
+        } else if (need2) {
             GG_TRY(bn_bwd(e, m.pe2.bn, L.pe2, M0, GG_ACT_NONE, dx, t_b, t_a));                             // dy2 -> t_a [M0, C0]
             if (e.tr(m.pe2.w.t_w)) GG_TRY(dense_wgrad(e, m.pe2.w, e.A(L.col2), m.pe2.w.Kp, t_a, d[0], M0, nullptr, 0, t_b, t_c, true));
         }
         if (need1) {
+            if (pe2_two_source) {
+                GgGemmArgs g;
+                memset(&g, 0, sizeof(g));
+                g.A = dx; g.lda = d[0]; g.A2 = e.A(L.pe2.y); g.a_bn_stat = bn_coef(e, M0, d[0]); g.B = e.Wt(m.pe2.w); g.ldb = m.pe2.w.Np;
+                g.C = t_b; g.ldc = m.pe2.w.Kp; g.M = (int)M0; g.N = m.pe2.w.Kp; g.K = d[0];
+                GG_TRY(gg_gemm_nt_f32(&g, e.st));                                                          // dcol2 -> t_b
+            } else
             GG_TRY(gemm(e, t_a, d[0], e.Wt(m.pe2.w), m.pe2.w.Np, t_b, m.pe2.w.Kp, M0, m.pe2.w.Kp, d[0])); // dcol2 -> t_b
-            if (e.fuse_bnbwd && !e.f32 && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & 7) == 0) {
+            if (e.fuse_bnbwd && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & (e.f32 ? 3 : 7)) == 0) {
                 // col2im + BN1-backward reduce in one pass (dz1 -> t_d; da1 and dy1 are never formed), weight gradient from (dz1, y1, coef)
                 GG_TRY(convnorm_wgrad_from_dz(e, m.pe1, L.pe1, M1, GG_ACT_GELU, nullptr, t_d, e.A(L.col1), 32, t_b, B, H1, H1));
             } else {

@@ -116,8 +116,9 @@ def col2im_nhwc_bnbwd(dcol, y, stat, gamma, beta, act="gelu", nparts=1024):
     B, H, W, Cc = y.shape
     dz = torch.empty_like(y)
     part = torch.zeros((nparts + 64, 2, Cc), dtype=F32, device=y.device)
-    L.check(L.lib().gg_col2im_nhwc_bnbwd_bf16(_p(dcol, BF16), _p(y, BF16), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(dz),
-                                              _p(part), nparts, B, H, W, Cc, L.stream()), "gg_col2im_nhwc_bnbwd_bf16")
+    fn = L.lib().gg_col2im_nhwc_bnbwd_f32 if y.dtype == F32 else L.lib().gg_col2im_nhwc_bnbwd_bf16
+    L.check(fn(_p(dcol, y.dtype), _p(y), _p(stat, F32), _p(gamma, F32), _p(beta, F32), ACT[act], _p(dz),
+               _p(part), nparts, B, H, W, Cc, L.stream()), "gg_col2im_nhwc_bnbwd")
     return dz, part[:nparts]
 
 
@@ -125,10 +126,12 @@ def gemm_tn_bn(dz, y, coef, X, accumulate_into=None):
     """f32 dW[N,K] = (coef0*dz + coef1*y + coef2)^T @ X: a ConvNorm's weight gradient straight from BatchNorm backward's (dz, y, coef)."""
     M, N = dz.shape
     K = X.shape[1]
-    splits = L.lib().gg_gemm_tn_splits(M, N, K)
+    f32 = dz.dtype == F32
+    splits = (L.lib().gg_gemm_tn_f32_splits if f32 else L.lib().gg_gemm_tn_splits)(M, N, K)
     part = torch.empty((splits, N, K), dtype=F32, device=dz.device)
-    L.check(L.lib().gg_gemm_tn_bn(_pr(dz, BF16, "dz"), _pr(y, BF16, "y"), dz.stride(0), _p(coef, F32), _pr(X, BF16, "X"), X.stride(0), M, N, K,
-                                  _p(part), splits, L.stream()), "gg_gemm_tn_bn")
+    fn = L.lib().gg_gemm_tn_bn_f32 if f32 else L.lib().gg_gemm_tn_bn
+    L.check(fn(_pr(dz, dz.dtype, "dz"), _pr(y, dz.dtype, "y"), dz.stride(0), _p(coef, F32), _pr(X, dz.dtype, "X"), X.stride(0), M, N, K,
+               _p(part), splits, L.stream()), "gg_gemm_tn_bn")
     out = accumulate_into if accumulate_into is not None else torch.empty((N, K), dtype=F32, device=dz.device)
     L.check(L.lib().gg_splitk_reduce(_p(part), _p(out, F32), N * K, splits, int(accumulate_into is not None), 1.0, L.stream()),
             "gg_splitk_reduce")
@@ -453,6 +456,26 @@ def layernorm_bwd(dout, x, mean, rstd, gamma, dres=None, want_param_grads=True):
     L.check(L.lib().gg_layernorm_bwd(_p(dout), _p(x), int(f32), _p(mean, F32), _p(rstd, F32), _p(gamma, F32), M, Cc, _p(dres),
                                      _p(dx), _p(scratch), _p(dg), _p(db), 1, L.stream()), "gg_layernorm_bwd")
     return dx, dg, db
+
+
+def layernorm_bwd_colsum(dout, x, mean, rstd, gamma, dres=None):
+    """LayerNorm backward that also leaves the per-block column sums (sum dx*x, sum dx) of its result; returns (dx, part, rows)."""
+    M, Cc = x.shape
+    dx = torch.empty_like(x)
+    rows = L.lib().gg_layernorm_bwd_colsum_rows(M)
+    part = torch.empty(((rows + 64) * 2 * Cc,), dtype=F32, device=x.device)
+    L.check(L.lib().gg_layernorm_bwd_colsum(_p(dout), _p(x), int(x.dtype == F32), _p(mean, F32), _p(rstd, F32), _p(gamma, F32), M, Cc, _p(dres),
+                                            _p(dx), _p(part), L.stream()), "gg_layernorm_bwd_colsum")
+    return dx, part, rows
+
+
+def bn_bwd_coef_from_x(part, rows, count, stat, gamma, beta):
+    """coef [3][C] of dy = c0*g + c1*y + c2 (BatchNorm backward, frozen parameters) from layernorm_bwd_colsum's rows."""
+    Cc = gamma.numel()
+    coef = torch.empty((3, Cc), dtype=F32, device=part.device)
+    L.check(L.lib().gg_bn_bwd_coef_from_x(_p(part), rows, Cc, count, _p(stat, F32), _p(gamma, F32), _p(beta, F32), _p(coef), L.stream()),
+            "gg_bn_bwd_coef_from_x")
+    return coef
 
 
 def token_mean_fwd(x, B, T):

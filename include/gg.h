@@ -67,6 +67,8 @@ int gg_gemm_tn(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, i
    ConvNorm whose dy feeds nothing else (patch_embed.conv1) without the BatchNorm-backward apply pass or the dy tensor */
 int gg_gemm_tn_bn(const void* dz, const void* y, int64_t ldy, const float* coef, const void* X, int64_t ldx, int M, int N, int K, float* partials,
                   int splits, void* stream);
+int gg_gemm_tn_bn_f32(const void* dz, const void* y, int64_t ldy, const float* coef, const void* X, int64_t ldx, int M, int N, int K, float* partials,
+                      int splits /* gg_gemm_tn_f32_splits */, void* stream);      /* f32 storage twin (patch_embed.conv1 / conv2 in the fp32 mode) */
 int gg_splitk_reduce(const float* partials, float* out, int64_t n, int splits, int accumulate, float scale, void* stream);
 int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t ldo, int R, int C, const float* rowscale,
                       int rows_per_scale, void* stream);
@@ -91,6 +93,8 @@ int gg_col2im_nhwc_bf16(const void* dcol, void* dx, int B, int H, int W, int C, 
    nparts partial rows [2][C] (sum dz, sum dz*xhat) for gg_bn_bwd_finalize; da is never stored */
 int gg_col2im_nhwc_bnbwd_bf16(const void* dcol, const void* y, const float* stat, const float* gamma, const float* beta, int act, void* dz,
                               float* part, int nparts, int B, int H, int W, int C, void* stream);
+int gg_col2im_nhwc_bnbwd_f32(const float* dcol, const float* y, const float* stat, const float* gamma, const float* beta, int act, float* dz,
+                             float* part, int nparts, int B, int H, int W, int C /* % 4 */, void* stream);
 int gg_dwconv_stat_rows(int B, int Ho, int Wo, int C, int stride);   /* partial-statistics rows gg_dwconv3x3_fwd writes */
 int gg_dwconv_tiled_stat_rows(int B, int Ho);                          /* ... the producer-fused forward variant (LDS-tiled kernel) */
 int gg_dwconv_fused_stat_rows(int B, int H, int W, int C, int with_input_fusion);   /* ... the fused data gradient with ep_y */
@@ -145,6 +149,16 @@ int gg_layernorm_fwd_bn(const void* y, const float* bn_stat, const float* bn_gam
 int64_t gg_layernorm_bwd_scratch_floats(int64_t M, int C);
 int gg_layernorm_bwd(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma, int64_t M,
                      int C, const void* dres, void* dx, float* scratch, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* the same backward that also leaves per-block column sums [rows][2][C] = (sum dx*x, sum dx) of its result dx (LayerNorm backward + dres)
+   against its raw input x.  When x = BatchNorm(y) with FROZEN BatchNorm parameters, gg_bn_bwd_coef_from_x turns them into the coefficients
+   dy = c0*dx + c1*y + c2 of that BatchNorm's backward (consumed by the fused depthwise data gradient), so the stand-alone reduce pass over
+   (dx, y) disappears (TinyViT block: local_conv's BatchNorm sits in front of norm2; timm tiny_vit.py TinyVitBlock.forward).
+   part: (gg_layernorm_bwd_colsum_rows(M) + 64) rows; C <= 640; no LayerNorm parameter gradients in this form */
+int gg_layernorm_bwd_colsum_rows(int64_t M);
+int gg_layernorm_bwd_colsum(const void* dout, const void* x, int f32, const float* mean, const float* rstd, const float* gamma, int64_t M, int C,
+                            const void* dres, void* dx, float* part, void* stream);
+int gg_bn_bwd_coef_from_x(float* part, int nparts, int C, int64_t count, const float* stat /* [mean|rstd][C] */, const float* gamma,
+                          const float* beta, float* coef /* [3][C] */, void* stream);
 int gg_token_mean_fwd(const void* x, float* out, int B, int T, int C, void* stream);
 int gg_token_mean_bwd(const float* dout, void* dx, int B, int T, int C, void* stream);
 int gg_view_mean_fwd(const float* emb, void* out, int64_t ldo, int N, int V, int C, void* stream);   /* models/super_guessr.py:347 */

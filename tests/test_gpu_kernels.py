@@ -109,6 +109,20 @@ def test_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
     close(got, plain.cpu(), rtol=1e-3, atol=1e-2, what="tn fused vs unfused")
 
 
+@pytest.mark.parametrize("M,N,K", [(70001, 48, 32), (3000, 200, 96), (9000, 96, 432), (517, 52, 36)])
+def test_f32_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
+    """f32 twin (gg_gemm_tn_bn_f32; patch_embed.conv1 / conv2 weight gradients in the fp32 mode), both the tiled and the row-split small form."""
+    dz, y, X = rnd(M, N, seed=90, scale=0.1), rnd(M, N, seed=91), rnd(M, K, seed=92)
+    coef = torch.stack([1.0 + 0.1 * rnd(N, seed=93), 0.05 * rnd(N, seed=94), 0.02 * rnd(N, seed=95)])
+    dy = coef[0] * dz + (coef[1] * y + coef[2])
+    ref = dy.double().t() @ X.double()
+    got = ops.gemm_tn_bn(dev(dz), dev(y), dev(coef), dev(X))
+    scale = float(ref.abs().max())
+    assert float((got.cpu().double() - ref).abs().max()) < 2e-5 * scale
+    plain = ops.gemm_tn(dev(dy), dev(X))
+    assert float((got - plain).abs().max()) < 1e-5 * scale
+
+
 def test_gemm_tn_many_slabs_small_matrix(ops):
     """patch_embed.conv1's weight-gradient shape (48 x 32 from millions of rows): >= 64 split slabs of a tiny matrix take the
     column x slab-lane reduction kernel."""
@@ -274,6 +288,29 @@ def test_col2im_fused_batchnorm_backward_reduce(ops, act):
     close(sums[1], (dpre * xh).sum((0, 1, 2)), rtol=2e-3, atol=2e-2, what="sum dz*xhat")
 
 
+@pytest.mark.parametrize("act,C,H", [("gelu", 48, 18), (None, 48, 18), ("gelu", 36, 11)])
+def test_f32_col2im_fused_batchnorm_backward_reduce(ops, act, C, H):
+    """f32 twin (gg_col2im_nhwc_bnbwd_f32): dz equals gg_col2im_nhwc_f32's da times act'(BN(y)); odd sizes cover the border taps."""
+    B = 3
+    Ho = (H - 1) // 2 + 1
+    dcol = dev(rnd(B * Ho * Ho, 9 * C, seed=21, scale=0.5))
+    y = rnd(B, H, H, C, seed=22, scale=1.5)
+    mean, var = rnd(C, seed=23, scale=0.3), rnd(C, seed=24).abs() + 0.5
+    rstd = (var + 1e-5).rsqrt()
+    gamma, beta = rnd(C, seed=25) + 1.0, rnd(C, seed=26, scale=0.3)
+    da = ops.col2im_nhwc(dcol, B, H, H, C, stride=2).cpu()
+    assert da.dtype == torch.float32
+    xh = (y - mean) * rstd
+    pre = (gamma * xh + beta).double().clone().requires_grad_(True)
+    (F.gelu(pre) if act else pre).sum().backward()
+    dpre = da.double() * pre.grad
+    dz, part = ops.col2im_nhwc_bnbwd(dcol, dev(y), dev(torch.stack([mean, rstd])), dev(gamma), dev(beta), act=act, nparts=37)
+    close(dz, dpre.float(), rtol=2e-5, atol=2e-6, what="f32 fused col2im dz")
+    sums = part.cpu().double().sum(0)
+    close(sums[0].float(), dpre.sum((0, 1, 2)).float(), rtol=1e-4, atol=1e-3, what="f32 sum dz")
+    close(sums[1].float(), (dpre * xh.double()).sum((0, 1, 2)).float(), rtol=1e-4, atol=1e-3, what="f32 sum dz*xhat")
+
+
 @pytest.mark.parametrize("C,stride,H", [(16, 1, 12), (48, 2, 14), (384, 1, 8), (576, 2, 14), (40, 1, 7), (24, 2, 9), (64, 2, 15)])
 def test_dwconv(ops, C, stride, H):
     B = 3
@@ -380,6 +417,39 @@ def test_layernorm(ops, C, f32):
     close(dx, xr.grad + dres, rtol=1e-4 if f32 else 2e-2, atol=1e-4 if f32 else 2e-2, what="ln dx")
     close(dg, g_.grad, rtol=1e-2, atol=0.3, what="ln dgamma")
     close(db, b_.grad, rtol=1e-2, atol=0.3, what="ln dbeta")
+
+
+@pytest.mark.parametrize("M,C,f32", [(9000, 384, True), (2500, 192, True), (700, 576, True), (333, 96, True), (9000, 384, False), (1200, 192, False)])
+def test_layernorm_bwd_with_batchnorm_column_sums(ops, M, C, f32):
+    """x = BN_train(y) -> LN(x): gg_layernorm_bwd_colsum's dx equals gg_layernorm_bwd's, and the BatchNorm-backward coefficients
+    gg_bn_bwd_coef_from_x derives from its (sum dx*x, sum dx) rows reproduce torch's dL/dy (timm TinyVitBlock: local_conv.bn -> norm2)."""
+    y = rnd(M, C, seed=80, scale=1.7) + 0.4
+    bg, bb = rnd(C, seed=81) * 0.3 + 1.0, rnd(C, seed=82, scale=0.5)
+    g, b = rnd(C, seed=83) * 0.2 + 1.0, rnd(C, seed=84, scale=0.2)
+    dout, dres = rnd(M, C, seed=85), rnd(M, C, seed=86)
+    if not f32:
+        y, dout, dres = y.to(BF).float(), dout.to(BF).float(), dres.to(BF).float()
+    yr = y.double().clone().requires_grad_(True)
+    x_ref = F.batch_norm(yr, None, None, bg.double(), bb.double(), True, 0.1, 1e-5)
+    (F.layer_norm(x_ref, (C,), g.double(), b.double(), 1e-5) * dout.double()).sum().backward(retain_graph=True)
+    x_ref.backward(dres.double())          # the residual path: x also feeds the block output directly
+    stat = torch.stack([y.double().mean(0), (y.double().var(0, unbiased=False) + 1e-5).rsqrt()]).float()
+    dt = torch.float32 if f32 else BF
+    x = ops.bn_apply(dev(y, dt), dev(stat), dev(bg), dev(bb))
+    _, mean, rstd = ops.layernorm_fwd(x, dev(g), dev(b))
+    dx0, _, _ = ops.layernorm_bwd(dev(dout, dt), x, mean, rstd, dev(g), dres=dev(dres, dt), want_param_grads=False)
+    dx, part, rows = ops.layernorm_bwd_colsum(dev(dout, dt), x, mean, rstd, dev(g), dres=dev(dres, dt))
+    close(dx, dx0.float(), rtol=1e-6 if f32 else 8e-3, atol=1e-6 if f32 else 1e-3, what="dx of the colsum form")      # fma contraction may differ
+    coef = ops.bn_bwd_coef_from_x(part, rows, M, dev(stat), dev(bg), dev(bb)).cpu().double()
+    dy = coef[0] * dx.double().cpu() + coef[1] * y.double() + coef[2]
+    ref = yr.grad
+    tol = 2e-5 if f32 else 3e-2
+    err = float((dy - ref).abs().max() / ref.abs().max())
+    assert err < tol, f"dy through coef_from_x: {err:.2e}"
+    # against the existing two-pass route on the same dx
+    _, dy2, _, _ = ops.bn_bwd(dx, dev(y, dt), dev(stat), dev(bg), dev(bb), want_param_grads=False)
+    err2 = float((dy.float() - dy2.float().cpu()).abs().max() / ref.abs().max())
+    assert err2 < (1e-5 if f32 else 2e-2), f"coef_from_x vs reduce+finalize: {err2:.2e}"
 
 
 def test_pooling(ops):
