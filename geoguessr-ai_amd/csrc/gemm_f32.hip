@@ -13,6 +13,7 @@
 // they feed 4 successive MFMA k-steps (lane (r, g) owns k = 4g + s in step s for BOTH operands, so every k is summed exactly once).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/gg.h"
 
 #define FBK 32   // floats per k-tile
@@ -483,11 +484,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     const int tiles = p.tilesM * p.tilesN;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     unsigned long long mt0 = 0;
+    unsigned long long tw_dma = 0, tw_bar = 0, tw_mfma = 0;       // dev trace: cycles wave 0 spent waiting for its DMAs / at the stage barrier (SB: + fragment reads, MFMA issue)
     if (p.trace) { tr0 = wall_clock64(); mt0 = __builtin_readcyclecounter(); }
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
     const int tm = bid / p.tilesN, tn = bid % p.tilesN;
     const int m0 = tm * BM, n0 = tn * BNC;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a scalar: everything derived from it (LDS destinations of the DMAs, the wave's rows and columns) stays in SGPRs.  fp32 MFMA
+    // and VALU instructions share the SIMD's vector issue (tools/mfma_shadow.hip: every VALU instruction next to an MFMA adds its own 5 - 8
+    // cycles, tools/valu_under_mfma.hip: another wave's VALU does not issue at all while MFMAs are pending), so a VALU instruction in the k-loop
+    // or the epilogue is matrix time lost, a SALU / LDS / memory instruction is not
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
     const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 4u;
@@ -514,23 +520,30 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         const int row = (j < JA ? blk : (j < JB ? blk - BM / 16 : blk - (BM + BN) / 16)) * 16 + drow;
         voff[j] = (unsigned)row * (unsigned)((j < JA || j >= JB) ? p.lda : p.ldb) * 4u + dch * 16u;
     }
-    auto issue_stage = [&](int st) {
+    auto issue_stage_at = [&](int st, float* base) {
         const int k0 = st * SK;
-        const bool kin = (k0 + dch * 4) < p.K;                    // K % 4 == 0: a chunk is entirely in or out
-        float* base = smem + (st % NST) * STAGE;
+        if (k0 + SK <= p.K) {                                     // (uniform) every chunk of the stage is inside K: no per-lane masking
 #pragma unroll
-        for (int j = 0; j < IPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : (j < JB ? rsB : rsA2), (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
-                                                     (int)(kin ? voff[j] : 0xFFFFFFF0u), k0 * 4, 0, 0);
+            for (int j = 0; j < IPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : (j < JB ? rsB : rsA2), (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
+                                                         (int)voff[j], k0 * 4, 0, 0);
+        } else {
+            const bool kin = (k0 + dch * 4) < p.K;                // K % 4 == 0: a chunk is entirely in or out
+#pragma unroll
+            for (int j = 0; j < IPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(j < JA ? rsA : (j < JB ? rsB : rsA2), (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 256), 16,
+                                                         (int)(kin ? voff[j] : 0xFFFFFFF0u), k0 * 4, 0, 0);
+        }
     };
+    auto issue_stage = [&](int st) { issue_stage_at(st, smem + (st % NST) * STAGE); };
     const int a_off = (wm * (BM / WM) + lr) * SK + lg * 4, b_off = BM * SK + (wn * WCOLS + lr) * SK + lg * 4;
-    auto frag_read = [&](int st, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
-        const float* base = smem + (st % NST) * STAGE;
+    auto frag_read_at = [&](const float* base, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(base + a_off + i * 16 * SK);
 #pragma unroll
         for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(base + b_off + i * 16 * SK);
     };
+    auto frag_read = [&](int st, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) { frag_read_at(smem + (st % NST) * STAGE, xf, wf); };
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -550,20 +563,28 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     if (SB) {
         f32x4 xs[TM], ws[TN];
         if (p.trace) tr1 = wall_clock64();
-        for (int s = 0; s < nk; ++s) {
+        unsigned long long c0 = 0, c1 = 0, c2 = 0;
+        // one k-stage; PAR = the ring buffer it lives in (NST == 2), a compile-time constant so that the LDS addresses are immediates
+        auto stage = [&](int s, auto par) {
+            constexpr int PAR = decltype(par)::value;
+            float* const cur = smem + PAR * STAGE;
+            float* const nxt = smem + (1 - PAR) * STAGE;
+            if (p.trace) c0 = __builtin_readcyclecounter();
             if (s > 0) {
                 wait_vmcnt<0>();                                  // this wave's DMAs of stage s have landed ...
                 __builtin_amdgcn_s_barrier();                     // ... everybody's have, and every wave has consumed stage s - 1 (its MFMAs needed the reads)
             }
-            if (s + 1 < nk) issue_stage(s + 1);                   // NST == 2: into the buffer stage s - 1 occupied
-            frag_read(s, xs, ws);
+            if (p.trace) c1 = __builtin_readcyclecounter();
+            if (s + 1 < nk) issue_stage_at(s + 1, nxt);           // into the buffer stage s - 1 occupied
+            frag_read_at(cur, xs, ws);
+            if (p.trace) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); c2 = __builtin_readcyclecounter(); tw_dma += c1 - c0; tw_bar += c2 - c1; }
             if (PRO) {
                 const int kq = s * SK + lg * 4;                   // this lane's fragments hold contraction columns kq .. kq + 3 of 16 rows each
                 const bool kin = kq < p.K;
                 const int kc = min(kq, p.K - 4);
                 const f32x4 c0 = *reinterpret_cast<const f32x4*>(ptab + kc), c1 = *reinterpret_cast<const f32x4*>(ptab + PTK + kc);
                 const f32x4 c2 = PRO == 2 ? *reinterpret_cast<const f32x4*>(ptab + 2 * PTK + kc) : c0;
-                const float* base2 = smem + (s % NST) * STAGE + (BM + BN) * SK;
+                const float* base2 = cur + (BM + BN) * SK;
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt) {
                     const bool rok = kin && (m0 + wm * (BM / WM) + mt * 16 + lr < p.M);
@@ -584,6 +605,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt)
                         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ws[nt][q], xs[mt][q], acc[nt][mt], 0, 0, 0);
+            if (p.trace) tw_mfma += __builtin_readcyclecounter() - c2;
+        };
+        static_assert(!SB || NST == 2, "the single-buffer form walks a 2-stage ring");
+        for (int s = 0; s < nk; s += 2) {
+            stage(s, std::integral_constant<int, 0>{});
+            if (s + 1 < nk) stage(s + 1, std::integral_constant<int, 1>{});
         }
         __builtin_amdgcn_s_barrier();
         if (p.trace) tr2 = wall_clock64();
@@ -595,17 +622,18 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
             unsigned hw, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned long long issued = wall_clock64();     // the epilogue's instructions are issued; what follows is the store drain
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
             t[0] = hw | ((unsigned long long)(xcc & 0xF) << 32); t[1] = __builtin_readcyclecounter() - mt0; t[2] = tr0; t[3] = tr1; t[4] = tr2; t[5] = wall_clock64();
-            t[6] = 0; t[7] = 0;
+            // wave 0 inside the k-loop (shader-clock cycles): [6] = waiting for DMA + barrier | (LDS fragment reads << 32), [7] = MFMA issue | ((issued - tr2) << 32, 10 ns ticks)
+            t[6] = (tw_dma & 0xFFFFFFFFull) | (tw_bar << 32); t[7] = (tw_mfma & 0xFFFFFFFFull) | ((issued - tr2) << 32);
         }
         return;
     }
     f32x4 xa[TM], wa[TN], xb[TM], wb[TN];
     if (p.trace) tr1 = wall_clock64();
     frag_read(0, xa, wa);
-    unsigned long long tw_dma = 0, tw_bar = 0;                    // dev trace: cycles this wave spent waiting for its DMAs / at the stage barrier
     auto step = [&](int s, f32x4 (&xc)[TM], f32x4 (&wc)[TN], f32x4 (&xn)[TM], f32x4 (&wn_)[TN]) {
         const bool more = s + 1 < nk;
         unsigned long long c0 = 0, c1 = 0;

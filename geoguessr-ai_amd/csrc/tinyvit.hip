@@ -969,23 +969,13 @@ static int backward_impl(Exec& e, const float* d_out) {
         act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
         const bool need1 = e.tr(m.pe1.w.t_w) || e.tr(m.pe1.bn.t_g);
         const bool need2 = e.tr(m.pe2.w.t_w) || e.tr(m.pe2.bn.t_g) || need1;
-        // f32: conv2's BatchNorm backward stops after reduce + finalize; the weight-gradient GEMM and the data-gradient GEMM form
-        // dy2 = c0*dx + c1*y2 + c2 from (dx, y2) while staging their operand (no apply pass, no dy2 tensor)
-        const bool pe2_two_source = e.f32 && e.fuse_bnbwd && e.fuse_pro && d[0] <= 384 && m.pe2.w.N == m.pe2.bn.C;
-        if (need2 && pe2_two_source) {
-            GG_TRY(convnorm_wgrad_from_dz(e, m.pe2, L.pe2, M0, GG_ACT_NONE, dx, nullptr, e.A(L.col2), m.pe2.w.Kp));
-        } else if (need2) {
+        // (conv2 keeps the three-pass BatchNorm backward: forming dy2 from (dx, y2) inside both of its GEMMs was measured at +1.7 ms of GEMM time
+        // against the 0.75 ms apply pass it removes -- the two-source prologue kernel at K = 96 runs at 62 TFLOP/s, the plain one at 86)
+        if (need2) {
             GG_TRY(bn_bwd(e, m.pe2.bn, L.pe2, M0, GG_ACT_NONE, dx, t_b, t_a));                             // dy2 -> t_a [M0, C0]
             if (e.tr(m.pe2.w.t_w)) GG_TRY(dense_wgrad(e, m.pe2.w, e.A(L.col2), m.pe2.w.Kp, t_a, d[0], M0, nullptr, 0, t_b, t_c, true));
         }
         if (need1) {
-            if (pe2_two_source) {
-                GgGemmArgs g;
-                memset(&g, 0, sizeof(g));
-                g.A = dx; g.lda = d[0]; g.A2 = e.A(L.pe2.y); g.a_bn_stat = bn_coef(e, M0, d[0]); g.B = e.Wt(m.pe2.w); g.ldb = m.pe2.w.Np;
-                g.C = t_b; g.ldc = m.pe2.w.Kp; g.M = (int)M0; g.N = m.pe2.w.Kp; g.K = d[0];
-                GG_TRY(gg_gemm_nt_f32(&g, e.st));                                                          // dcol2 -> t_b
-            } else
             GG_TRY(gemm(e, t_a, d[0], e.Wt(m.pe2.w), m.pe2.w.Np, t_b, m.pe2.w.Kp, M0, m.pe2.w.Kp, d[0])); // dcol2 -> t_b
             if (e.fuse_bnbwd && m.pe1.w.N == m.pe1.bn.C && (m.pe1.bn.C & (e.f32 ? 3 : 7)) == 0) {
                 // col2im + BN1-backward reduce in one pass (dz1 -> t_d; da1 and dy1 are never formed), weight gradient from (dz1, y1, coef)
