@@ -289,6 +289,163 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
         }
 }
 
+// Row-layout epilogue of the ring kernels (interior tiles of the 64-column wave layouts).  fp32 MFMA and VALU instructions share the SIMD's
+// vector issue (tools/mfma_shadow.hip, tools/valu_under_mfma.hip), so every VALU instruction of an epilogue is matrix time taken from the
+// co-resident workgroups; what the epilogue above spends on DPP lane exchanges (full-line stores and fetches), per-element bounds checks and
+// 64-bit address arithmetic goes away here:
+//   * the accumulators cross the wave's private slice of the (now idle) ring through LDS -- ds_write_b128 in the MFMA layout (lane = 16 x row,
+//     4 columns), ds_read_b128 as whole rows (16 lanes x 16 B = the wave's 64 columns of one row; a store instruction = 4 rows x 256 B) -- LDS
+//     instructions, no VALU; 16-byte slots XOR-swizzled with (row & 7): conflict-free writes, reads at most 2-way on 2 of 8 rows;
+//   * all element-wise work happens in the row layout: a lane's 4 columns are the same for every row, so bias / BatchNorm coefficients are loaded
+//     once per tile, the second tensor (residual, pre-activation, saved conv output) is fetched row-wise (whole lines) straight into place;
+//   * addresses = scalar tile base (SGPR arithmetic) + one per-lane 32-bit offset.
+// LDSF = floats of LDS the ring leaves (>= 4 waves x 16 rows x 64).  Results differ from the epilogue above only in the summation order of the
+// column statistics.
+template <int BM, int WM, int WN, int TM, int EPI, int LDSF>
+__device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, float* smem, f32x4 (&acc)[4][TM], int m0, int n0, int tm, int wave, int lane) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int WROWS = BM / WM;
+    constexpr int CAP = LDSF / 4 / 1024;                                       // 16-row blocks the wave's LDS slice holds
+    constexpr int MTP = CAP >= TM ? TM : ((CAP >= 2 && TM % 2 == 0) ? 2 : 1);   // ... per pass
+    static_assert(MTP >= 1 && TM % MTP == 0, "LDS slice too small");
+    constexpr int NPASS = TM / MTP, RP = MTP * 16, NI = RP / 4;                 // rows per pass, row-layout instructions per pass (4 rows each)
+    constexpr bool AUX = EPI == FE_BNBWD || EPI == FE_DGELU || EPI == FE_LINEAR;
+    constexpr bool STATS = EPI == FE_PLAIN || EPI == FE_BNBWD;
+    constexpr int G = EPI == FE_BNBWD ? 2 : 4;       // row instructions per group (second-tensor fetches in flight; BNBWD keeps 16 coefficient registers)
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;        // MFMA layout: row lr of a 16-row block, columns nt*16 + lg*4 ..
+    const int r4 = lane >> 4, sl = lane & 15;        // row layout: row r4 of 4, 16-byte slot sl of the wave's 64 columns
+    char* const lds = reinterpret_cast<char*>(smem) + wave * (RP * 256);
+    unsigned wb[2], rb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        wb[b] = (unsigned)(lr * 256 + ((((b << 2) | lg) ^ (lr & 7)) << 4));
+        rb[b] = (unsigned)(r4 * 256 + ((sl ^ ((b << 2) | r4)) << 4));
+    }
+    // the first pass's accumulators leave for LDS before anything else is loaded: they are dead from here on, which keeps the per-tile constants
+    // below (up to 24 registers in the BatchNorm-backward form) inside the 128 registers of the 4-per-CU kernels
+    auto to_lds = [&](int ps) {
+#pragma unroll
+        for (int mtl = 0; mtl < MTP; ++mtl)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                *reinterpret_cast<f32x4*>(lds + wb[nt & 1] + mtl * 4096 + (nt >> 1) * 128) = acc[nt][ps * MTP + mtl];
+    };
+    to_lds(0);
+    __builtin_amdgcn_sched_barrier(0);
+    const int mw0 = m0 + wm * WROWS, nw0 = n0 + wn * 64;
+    const float* aux_src = EPI == FE_BNBWD ? p.bn_y : (EPI == FE_DGELU ? p.dact_preact : (EPI == FE_LINEAR ? p.residual : nullptr));
+    const int64_t aux_ld = EPI == FE_LINEAR ? p.ldr : p.ldc;
+    // addressing: one buffer descriptor per tensor on the wave's first element, scalar row offset (soffset), per-lane offset of (row r4, slot sl)
+    const unsigned strideC = (unsigned)p.ldc * 4u, strideX = (unsigned)aux_ld * 4u;
+    const unsigned offC = (unsigned)r4 * strideC + (unsigned)sl * 16u, offX = (unsigned)r4 * strideX + (unsigned)sl * 16u;
+    // STORES take a descriptor rebased per row group (scalar adds) and NO register soffset: with a register soffset the compiler assumes the
+    // hardware has read a 16-byte store's data by the next instruction (LLVM's VMEM-store hazard rule exempts that form) and reused the data
+    // registers for an LDS address in the following instruction -- on gfx950 one workgroup in ~2000 then stored the address
+    char* const cptr = reinterpret_cast<char*>(p.C + (int64_t)mw0 * p.ldc + nw0);
+    char* const pptr = reinterpret_cast<char*>((EPI == FE_GELU && p.preact ? p.preact : p.C) + (int64_t)mw0 * p.ldc + nw0);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)((AUX && aux_src ? aux_src : p.C) + (int64_t)mw0 * aux_ld + nw0), 0, (int)(WROWS * strideX), 0x00020000);
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if ((EPI == FE_LINEAR || EPI == FE_GELU || EPI == FE_QGELU) && p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + nw0 + sl * 4);
+    f32x4 bsc = b4, bsh = b4, brs = b4, bnm = b4, cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
+    if (EPI == FE_BNBWD) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bn_stat + nw0 + sl * 4), rstd = *reinterpret_cast<const f32x4*>(p.bn_stat + p.N + nw0 + sl * 4);
+        bsc = *reinterpret_cast<const f32x4*>(p.bn_gamma + nw0 + sl * 4) * rstd;
+        bsh = *reinterpret_cast<const f32x4*>(p.bn_beta + nw0 + sl * 4) - mu * bsc;
+        brs = rstd; bnm = -mu * rstd;
+    }
+    // per-row scale (DropPath): lane l holds the scale of the wave's row l; a row instruction fetches its rows' values with one ds_bpermute
+    const bool scaled = (EPI == FE_LINEAR || EPI == FE_DGELU) && p.rowscale != nullptr;
+    int rs_lane = 0x3F800000;
+    if (scaled) rs_lane = __builtin_bit_cast(int, p.rowscale[min(mw0 + lane, p.M - 1) / p.rows_per_scale]);
+    const int rs_addr = r4 * 4;
+    const bool quick = p.quick != 0;
+    // FLAG: the one per-launch option that would otherwise become per-element selects -- PLAIN: column statistics wanted; LINEAR: a residual is added
+    auto run = [&](auto flag) {
+        constexpr bool FLAG = decltype(flag)::value;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            if (ps > 0) to_lds(ps);
+#pragma unroll
+            for (int i0 = 0; i0 < NI; i0 += G) {
+                f32x4 aux[AUX ? G : 1];
+                if (AUX && (EPI != FE_LINEAR || FLAG)) {
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        aux[AUX ? j : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)offX, (int)((unsigned)(ps * RP + (i0 + j) * 4) * strideX), 0));
+                }
+#pragma unroll
+                for (int j = 0; j < G; ++j) {
+                    const int i = i0 + j, rel = ps * RP + i * 4;          // the 4 rows mw0 + rel .. + 3, this lane: + r4
+                    f32x4 v = *reinterpret_cast<const f32x4*>(lds + rb[i & 1] + i * 1024);
+                    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(cptr + (size_t)rel * strideC), 0, (int)(4 * strideC), 0x00020000);
+                    float rs = 1.f;
+                    if (EPI == FE_LINEAR || EPI == FE_DGELU) {
+                        if (scaled) rs = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rs_addr + rel * 4, rs_lane));
+                    }
+                    if (EPI == FE_PLAIN) {
+                        if (FLAG) { cs += v; cq += v * v; }
+                    } else if (EPI == FE_LINEAR) {
+                        v = (v + b4) * rs;
+                        if (FLAG) v += aux[AUX ? j : 0];
+                    } else if (EPI == FE_GELU || EPI == FE_QGELU) {
+                        v += b4;
+                        if (EPI == FE_GELU && p.preact) {
+                            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(pptr + (size_t)rel * strideC), 0, (int)(4 * strideC), 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, (int)offC, 0, 2 /* nt */);
+                        }
+                        if (EPI == FE_QGELU || quick) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + expf(-1.702f * v[r]));
+                        } else {
+                            v = gg_act_f32_v4(v, GG_ACT_GELU);
+                        }
+                    } else if (EPI == FE_DGELU) {
+                        const f32x4 h = aux[AUX ? j : 0];
+                        if (quick) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float sg = 1.0f / (1.0f + expf(-1.702f * h[r]));
+                                v[r] *= (sg + 1.702f * h[r] * sg * (1.0f - sg)) * rs;
+                            }
+                        } else {
+                            v *= gg_act_grad_f32_v4(h, GG_ACT_GELU) * rs;
+                        }
+                    } else {      // FE_BNBWD: dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat
+                        const f32x4 yv = aux[AUX ? j : 0];
+                        v *= gg_act_grad_f32_v4(yv * bsc + bsh, p.bn_act);
+                        cs += v; cq += v * (yv * brs + bnm);
+                    }
+                    if (STATS) asm volatile("" : "+v"(cs), "+v"(cq));      // pin the running sums here (left alone, the compiler sinks all 16 row terms to the reduction below and spills them)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)offC, 0, 0);
+                }
+            }
+        }
+    };
+    const bool flag = EPI == FE_PLAIN ? p.colstats != nullptr : (EPI == FE_LINEAR ? p.residual != nullptr : true);
+    if (EPI != FE_PLAIN && EPI != FE_LINEAR) run(std::true_type{});
+    else if (flag) run(std::true_type{});
+    else run(std::false_type{});
+    if (STATS && (EPI == FE_BNBWD || p.colstats)) {      // (the BatchNorm-backward form always has them)
+        // per-lane sums (4 columns, this lane's rows) -> LDS [wave][r4][2][64] -> thread (which, column): over the WM waves and the 4 row lanes
+        __syncthreads();                                      // every wave is done with its transposition slice
+        float* red = smem;
+        *reinterpret_cast<f32x4*>(red + ((wave * 4 + r4) * 2 + 0) * 64 + sl * 4) = cs;
+        *reinterpret_cast<f32x4*>(red + ((wave * 4 + r4) * 2 + 1) * 64 + sl * 4) = cq;
+        __syncthreads();
+        constexpr int BNC = WN * 64;
+        for (int t = threadIdx.x; t < 2 * BNC; t += 256) {
+            const int which = t / BNC, col = t % BNC, wn_ = col >> 6, c = col & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sum += red[(((w * WN + wn_) * 4 + q) * 2 + which) * 64 + c];
+            p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = sum;
+        }
+    }
+}
+
 // PERSISTENT workgroups: the grid is min(tiles, resident workgroups) and a workgroup walks tiles t, t + grid, ...  The operand
 // registers that prefetch the next k-tile are idle during a tile's last k-iteration, so they fetch the NEXT tile's first k-tile
 // there: a tile's prologue (first-load latency, ~10 % of a K = 384 tile, ~25 % of a K = 96 tile when measured by ablation) and its
@@ -470,7 +627,9 @@ template <int IPW> __device__ __forceinline__ void wait_stages_outstanding(int n
 // PatchMerging shape of the 5M / 11M / 21M models); rows beyond M and chunks beyond K are zeroed AFTER the transform (they feed the column
 // statistics / must not add the affine's constant term).  With WN == 1 (the 4 x 1 wave layout used for N <= 96) every A element is
 // transformed by exactly one wave.
-template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false, int PRO = 0>
+// REPI (SB form, 64-column wave layouts): every tile of the launch is interior and aligned (checked by the host) and leaves through the row-layout
+// epilogue; the general epilogue is not compiled in (the two together exceed the 128 registers of the 4-per-CU form)
+template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false, int PRO = 0, bool REPI = false>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
     constexpr int BM = 128, SK = 16, PTK = 384;
     constexpr int TM = BM / WM / 16, TN = BNC / WN / 16;
@@ -617,6 +776,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         // second-tensor fetch as whole lines (two n-tiles per group, M in two halves) where the registers allow it: the GELU' and residual epilogues
         // of the 128 x 128 tile; the BatchNorm-backward epilogue keeps one n-tile per group (its per-column coefficients need the registers)
         constexpr bool PAIR_AUX = (EPI == FE_DGELU || EPI == FE_LINEAR) && TM == 4 && PRO == 0;
+        if constexpr (REPI) {
+            static_assert(TN == 4, "the row-layout epilogue is built for 64-column wave layouts");
+            gemm_f32_epilogue_rows<BM, WM, WN, TM, EPI, NST * STAGE>(p, smem, acc, m0, n0, tm, wave, lane);
+        } else
         gemm_f32_epilogue<BM, BNC, WM, WN, EPI, (PAIR_AUX ? 2 : 1), (PAIR_AUX ? 2 : 1)>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
         if (p.trace && threadIdx.x == 0) {        // dev trace (gg_gemm_f32_set_trace), same record as the double-buffered form; no per-stage wait split
             unsigned hw, xcc;
@@ -911,9 +1074,19 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     static const char* sb_env = gg_dev_env("GG_GEMM_F32_SB");
     const int sb_k = sb_env ? atoi(sb_env) : (1 << 30);
     const bool sb = ring && !wide96 && a->K <= sb_k;
+    // row-layout epilogue (gemm_f32_epilogue_rows): every tile interior, 16-byte rows everywhere, at most three DropPath scales per wave.
+    // GG_GEMM_F32_ROWS_EPI=0: the general epilogue (A/B, parity of the two forms)
+    static const char* rows_env = gg_dev_env("GG_GEMM_F32_ROWS_EPI");
+    const float* xsrc = a->bn_y ? (const float*)a->bn_y : (a->dact_preact ? (const float*)a->dact_preact : (const float*)a->residual);
+    const int64_t xld = (a->bn_y || a->dact_preact) ? a->ldc : a->ldr;
+    const bool rows_epi = sb && !(rows_env && rows_env[0] == '0') && p.debug == 0 && !p.trace && a->M % 128 == 0 && a->N % bn == 0 && (a->ldc & 3) == 0 && a->ldc < (1 << 23) &&
+                          (!xsrc || ((xld & 3) == 0 && xld < (1 << 23))) && (!a->rowscale || a->rows_per_scale >= 32) && (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
+                          (!a->bn_y || ((((uintptr_t)a->bn_stat | (uintptr_t)a->bn_gamma | (uintptr_t)a->bn_beta) & 15) == 0)) && (!a->colstats || ((uintptr_t)a->colstats & 3) == 0);
 #define GG_LAUNCH_F32(E)                                                                                          \
     do {                                                                                                          \
-        if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true>), grid, dim3(256), 0, st, p); \
+        if (sb && narrow && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true, 0, true>), grid, dim3(256), 0, st, p); \
+        else if (sb && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true, 0, true>), grid, dim3(256), 0, st, p); \
+        else if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true>), grid, dim3(256), 0, st, p); \
         else if (sb) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true>), grid, dim3(256), 0, st, p); \
         else if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
         else if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 2>), grid, dim3(256), 0, st, p);    \

@@ -123,6 +123,43 @@ def test_f32_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
     assert float((got - plain).abs().max()) < 1e-5 * scale
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 576, 96), (12544, 576, 2304), (12544, 2304, 576), (12544, 1728, 576), (256, 64, 48)])
+def test_f32_gemm_row_layout_epilogue(ops, M, N, K):
+    """Interior, aligned fp32 launches leave through the row-layout epilogue (gemm_f32_epilogue_rows: accumulators transposed through LDS, all
+    element-wise work on whole rows): every epilogue kind against torch fp64, on both tile widths.  The 12 544-row shapes keep ~2000 workgroups
+    in flight: that is where a 16-byte buffer store with a register soffset lost a data register to the next instruction (1 workgroup in ~2000)."""
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda(); B = (torch.randn(N, K, generator=g) * 0.1).cuda()
+    bias = torch.randn(N, generator=g).cuda(); res = torch.randn(M, N, generator=g).cuda(); rsc = (torch.rand(M // 64, generator=g) + 0.5).cuda()
+    ref = A.double() @ B.double().t()
+    rs_rows = rsc.double().repeat_interleave(64)[:, None]
+    def rel(a, b): return float((a.double() - b).abs().max() / b.abs().max())
+    tol = 2e-5 if K > 1000 else 4e-6
+    assert rel(ops.gemm_nt(A, B), ref) < tol
+    c, st = ops.gemm_nt(A, B, colstats=True)
+    assert rel(c, ref) < tol and rel(st.sum(0)[0], ref.sum(0)) < 1e-4 and rel(st.sum(0)[1], (ref * ref).sum(0)) < 1e-4
+    assert rel(ops.gemm_nt(A, B, bias=bias), ref + bias.double()) < tol
+    assert rel(ops.gemm_nt(A, B, bias=bias, residual=res), ref + bias.double() + res.double()) < tol
+    assert rel(ops.gemm_nt(A, B, bias=bias, residual=res, rowscale=rsc, rows_per_scale=64), (ref + bias.double()) * rs_rows + res.double()) < tol
+    y, pre = ops.gemm_nt(A, B, bias=bias, act="gelu", preact=True)
+    assert rel(y, F.gelu(ref + bias.double())) < tol and rel(pre, ref + bias.double()) < tol
+    assert rel(ops.gemm_nt(A, B, bias=bias, act="gelu"), F.gelu(ref + bias.double())) < tol
+    h = torch.randn(M, N, generator=g).cuda()
+    hh = h.double().clone().requires_grad_(True); F.gelu(hh).sum().backward()
+    assert rel(ops.gemm_nt(A, B, dact_preact=h, dact="gelu", rowscale=rsc, rows_per_scale=64), ref * hh.grad * rs_rows) < tol
+    # BatchNorm-backward epilogue: dz = (A B^T) * gelu'(BN(ysaved)) with the column sums (sum dz, sum dz*xhat)
+    ysv = torch.randn(M, N, generator=g).cuda() * 1.5 + 0.2
+    mean, rstd = ysv.double().mean(0), (ysv.double().var(0, unbiased=False) + 1e-5).rsqrt()
+    gam, bet = (torch.rand(N, generator=g) + 0.5).cuda(), (torch.randn(N, generator=g) * 0.2).cuda()
+    stat = torch.stack([mean, rstd]).float()
+    xh = (ysv.double() - mean) * rstd
+    pre2 = (gam.double() * xh + bet.double()).clone().requires_grad_(True); F.gelu(pre2).sum().backward()
+    dz_ref = ref * pre2.grad
+    dz, coef, dg, db = ops.conv_dgrad_bn_bwd(A, B, ysv, stat, gam, bet, act="gelu")
+    assert rel(dz, dz_ref) < tol
+    assert rel(db, dz_ref.sum(0)) < 1e-4 and rel(dg, (dz_ref * xh).sum(0)) < 1e-4
+
+
 def test_gemm_tn_many_slabs_small_matrix(ops):
     """patch_embed.conv1's weight-gradient shape (48 x 32 from millions of rows): >= 64 split slabs of a tiny matrix take the
     column x slab-lane reduction kernel."""
