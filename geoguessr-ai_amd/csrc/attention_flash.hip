@@ -320,7 +320,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
         d += __shfl_xor(d, 16, 64);
         d += __shfl_xor(d, 32, 64);
         delta[u] = d;
-        lse2[u] = (qok[u] ? p.lse[qtok[u] * p.nh + h] : 0.f) * 1.4426950408889634f;
+        lse2[u] = -(qok[u] ? p.lse[qtok[u] * p.nh + h] : 0.f) / p.scale;          // initial value of the S accumulators (see fl_stage_rowstats)
         qlin[u] = has_bias ? fl_lin4(p, min(qi, p.N - 1)) + 4 * (p.ws - 1) * 2 * p.ws : 0;       // + the table's centre (dy = dx = 0)
     }
     const bool wave_on = strip0 * 16 < p.N;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             if (kt >= nsub) continue;
             f32x4 st[QS], dp[QS];
 #pragma unroll
-            for (int u = 0; u < QS; ++u) st[u] = dp[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < QS; ++u) { st[u] = (f32x4){lse2[u], lse2[u], lse2[u], lse2[u]}; dp[u] = (f32x4){-delta[u], -delta[u], -delta[u], -delta[u]}; }
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
@@ -374,10 +374,9 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kl = 16 * kt + 4 * lg + r;
-                    const float s = fmaf(st[u][r], sc2, bia[u][r]);
-                    float pr = __builtin_amdgcn_exp2f(s - lse2[u]);      // rows beyond N are never stored: no query mask needed in this pass
+                    float pr = __builtin_amdgcn_exp2f(fmaf(st[u][r], sc2, bia[u][r]));      // rows beyond N are never stored: no query mask needed in this pass
                     if (tail && t0 + kl >= p.N) pr = 0.f;
-                    st[u][r] = pr * (dp[u][r] - delta[u]);               // dS^T; the softmax scale is applied once, to dQ
+                    st[u][r] = pr * dp[u][r];                            // dS^T; the softmax scale is applied once, to dQ
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -401,7 +400,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
 }
 
 // ------------------------------------------------------------------------------------------- backward, pass B: dK, dV (+ dbias)
-// delta[q] = sum_d dO[q][d] O[q][d] and lse[q] of rows [t0, t0+n) into LDS: 4 lanes per row
+// -delta[q] = -sum_d dO[q][d] O[q][d] and -lse[q] / scale of rows [t0, t0+n) into LDS: 4 lanes per row
 template <typename T, int D>
 __device__ __forceinline__ void fl_stage_rowstats(const FlashParams& p, const T* dout, const T* outp, int64_t origin, int h, int t0, int n,
                                                   float* lse_s, float* del_s) {
@@ -421,7 +420,9 @@ __device__ __forceinline__ void fl_stage_rowstats(const FlashParams& p, const T*
         }
         dsum += __shfl_xor(dsum, 1, 64);
         dsum += __shfl_xor(dsum, 2, 64);
-        if (part == 0 && row < n) { del_s[row] = dsum; lse_s[row] = ok ? p.lse[tok * p.nh + h] * 1.4426950408889634f : INFINITY; }   // base-2 lse
+        // stored negated and in the units of the raw products: they become the INITIAL VALUES of the S / dP accumulators, so that "- lse" and
+        // "- delta" cost no VALU instruction per score (fp32 MFMA and VALU share the SIMD's issue: tools/mfma_shadow.hip).  -inf for padded queries: P = 0
+        if (part == 0 && row < n) { del_s[row] = -dsum; lse_s[row] = ok ? -p.lse[tok * p.nh + h] / p.scale : -INFINITY; }
     }
 }
 template <typename T, int D, bool DBIAS, bool RES>
@@ -498,7 +499,8 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
 #pragma unroll
         for (int qs = 0; qs < 4; ++qs) {
             if (qs >= nsub) continue;
-            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            const int q4 = ro + 16 * qs + 4 * lg;                              // this lane's 4 consecutive queries: one 16-byte read per array
+            f32x4 st = *reinterpret_cast<const f32x4*>(lse_s + q4), dp = *reinterpret_cast<const f32x4*>(del_s + q4);      // S - lse / scale, dP - delta
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 const f32x4 qa = *reinterpret_cast<const f32x4*>(Qt + (16 * qs + lr) * RS + 16 * c + 4 * lg);
@@ -511,8 +513,6 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
             }
             // lane holds S / dP [q = t0 + 16qs + 4lg + r][key = lr]
             f32x4 pr, ds;
-            const int q4 = ro + 16 * qs + 4 * lg;                              // this lane's 4 consecutive queries: one 16-byte read per array
-            const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_s + q4), del4 = *reinterpret_cast<const f32x4*>(del_s + q4);
             i32x4 boff4 = {0, 0, 0, 0};
             f32x4 bia = {0.f, 0.f, 0.f, 0.f};
             if (has_bias) {
@@ -524,9 +524,8 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
             for (int r = 0; r < 4; ++r) {
                 const int ql = 16 * qs + 4 * lg + r;
                 const int boff = boff4[r];
-                const float s = fmaf(st[r], sc2, bia[r]);
-                const float e = __builtin_amdgcn_exp2f(s - lse4[r]);           // lse_s = +inf for padded queries -> 0; a padded key's column is never stored
-                const float g = e * (dp[r] - del4[r]);
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r]));     // -inf for padded queries -> 0; a padded key's column is never stored
+                const float g = e * dp[r];
                 pr[r] = e;
                 ds[r] = g;                                                     // the softmax scale is applied once, to dK
                 if (DBIAS && kok && t0 + ql < p.N) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dbt) + boff), g);
