@@ -301,39 +301,44 @@ __device__ __forceinline__ void gemm_f32_epilogue(const F32GemmParams& p, float*
 //   * addresses = scalar tile base (SGPR arithmetic) + one per-lane 32-bit offset.
 // LDSF = floats of LDS the ring leaves (>= 4 waves x 16 rows x 64).  Results differ from the epilogue above only in the summation order of the
 // column statistics.
-template <int BM, int WM, int WN, int TM, int EPI, int LDSF>
-__device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, float* smem, f32x4 (&acc)[4][TM], int m0, int n0, int tm, int wave, int lane) {
+template <int BM, int WM, int WN, int TM, int TN, int EPI, int LDSF>
+__device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, float* smem, f32x4 (&acc)[TN][TM], int m0, int n0, int tm, int wave, int lane) {
+    // TN = 4: the wave's 64 columns = 16 slots of 16 bytes, a row instruction = 4 rows x 16 slots; TN = 6 (the 96-column tile): 24 slots, a row
+    // instruction = 2 rows x 24 slots on 48 of the 64 lanes
+    static_assert(TN == 4 || TN == 6, "row-layout epilogue: 64- or 96-column wave tiles");
+    constexpr int SLOTS = TN * 4, PITCH = SLOTS * 16, RPI = 64 / SLOTS, WCOLS = TN * 16;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr int WROWS = BM / WM;
-    constexpr int CAP = LDSF / 4 / 1024;                                       // 16-row blocks the wave's LDS slice holds
+    constexpr int CAP = LDSF / 4 / (SLOTS * 64);                               // 16-row blocks the wave's LDS slice holds
     constexpr int MTP = CAP >= TM ? TM : ((CAP >= 2 && TM % 2 == 0) ? 2 : 1);   // ... per pass
     static_assert(MTP >= 1 && TM % MTP == 0, "LDS slice too small");
-    constexpr int NPASS = TM / MTP, RP = MTP * 16, NI = RP / 4;                 // rows per pass, row-layout instructions per pass (4 rows each)
+    constexpr int NPASS = TM / MTP, RP = MTP * 16, NI = RP / RPI;               // rows per pass, row-layout instructions per pass (RPI rows each)
     constexpr bool AUX = EPI == FE_BNBWD || EPI == FE_DGELU || EPI == FE_LINEAR;
     constexpr bool STATS = EPI == FE_PLAIN || EPI == FE_BNBWD;
     constexpr int G = EPI == FE_BNBWD ? 2 : 4;       // row instructions per group (second-tensor fetches in flight; BNBWD keeps 16 coefficient registers)
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;        // MFMA layout: row lr of a 16-row block, columns nt*16 + lg*4 ..
-    const int r4 = lane >> 4, sl = lane & 15;        // row layout: row r4 of 4, 16-byte slot sl of the wave's 64 columns
-    char* const lds = reinterpret_cast<char*>(smem) + wave * (RP * 256);
-    unsigned wb[2], rb[2];
+    const int r4 = lane / SLOTS, sl = lane % SLOTS;  // row layout: row r4 of RPI, 16-byte slot sl of the wave's columns
+    const bool active = lane < RPI * SLOTS;
+    char* const lds = reinterpret_cast<char*>(smem) + wave * (RP * PITCH);
+    constexpr int NRB = 8 / RPI;                     // (row & 7) of instruction i, lane row r4: ((i % NRB) * RPI) | r4
+    unsigned wb[2], rb[NRB];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        wb[b] = (unsigned)(lr * 256 + ((((b << 2) | lg) ^ (lr & 7)) << 4));
-        rb[b] = (unsigned)(r4 * 256 + ((sl ^ ((b << 2) | r4)) << 4));
-    }
+    for (int b = 0; b < 2; ++b) wb[b] = (unsigned)(lr * PITCH + ((((b << 2) | lg) ^ (lr & 7)) << 4));
+#pragma unroll
+    for (int b = 0; b < NRB; ++b) rb[b] = (unsigned)(r4 * PITCH + ((sl ^ ((b * RPI) | r4)) << 4));
     // the first pass's accumulators leave for LDS before anything else is loaded: they are dead from here on, which keeps the per-tile constants
     // below (up to 24 registers in the BatchNorm-backward form) inside the 128 registers of the 4-per-CU kernels
     auto to_lds = [&](int ps) {
 #pragma unroll
         for (int mtl = 0; mtl < MTP; ++mtl)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                *reinterpret_cast<f32x4*>(lds + wb[nt & 1] + mtl * 4096 + (nt >> 1) * 128) = acc[nt][ps * MTP + mtl];
+            for (int nt = 0; nt < TN; ++nt)
+                *reinterpret_cast<f32x4*>(lds + wb[nt & 1] + mtl * (16 * PITCH) + (nt >> 1) * 128) = acc[nt][ps * MTP + mtl];
     };
     to_lds(0);
     __builtin_amdgcn_sched_barrier(0);
-    const int mw0 = m0 + wm * WROWS, nw0 = n0 + wn * 64;
+    const int mw0 = m0 + wm * WROWS, nw0 = n0 + wn * WCOLS;
     const float* aux_src = EPI == FE_BNBWD ? p.bn_y : (EPI == FE_DGELU ? p.dact_preact : (EPI == FE_LINEAR ? p.residual : nullptr));
     const int64_t aux_ld = EPI == FE_LINEAR ? p.ldr : p.ldc;
     // addressing: one buffer descriptor per tensor on the wave's first element, scalar row offset (soffset), per-lane offset of (row r4, slot sl)
@@ -346,10 +351,10 @@ __device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, f
     char* const pptr = reinterpret_cast<char*>((EPI == FE_GELU && p.preact ? p.preact : p.C) + (int64_t)mw0 * p.ldc + nw0);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)((AUX && aux_src ? aux_src : p.C) + (int64_t)mw0 * aux_ld + nw0), 0, (int)(WROWS * strideX), 0x00020000);
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-    if ((EPI == FE_LINEAR || EPI == FE_GELU || EPI == FE_QGELU) && p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + nw0 + sl * 4);
+    if ((EPI == FE_LINEAR || EPI == FE_GELU || EPI == FE_QGELU) && p.bias) b4 = *reinterpret_cast<const f32x4*>(p.bias + nw0 + min(sl, SLOTS - 1) * 4);
     f32x4 bsc = b4, bsh = b4, brs = b4, bnm = b4, cs = {0.f, 0.f, 0.f, 0.f}, cq = cs;
     if (EPI == FE_BNBWD) {
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bn_stat + nw0 + sl * 4), rstd = *reinterpret_cast<const f32x4*>(p.bn_stat + p.N + nw0 + sl * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(p.bn_stat + nw0 + sl * 4), rstd = *reinterpret_cast<const f32x4*>(p.bn_stat + p.N + nw0 + sl * 4);      // (sl < SLOTS always: lane % SLOTS)
         bsc = *reinterpret_cast<const f32x4*>(p.bn_gamma + nw0 + sl * 4) * rstd;
         bsh = *reinterpret_cast<const f32x4*>(p.bn_beta + nw0 + sl * 4) - mu * bsc;
         brs = rstd; bnm = -mu * rstd;
@@ -372,13 +377,13 @@ __device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, f
                 if (AUX && (EPI != FE_LINEAR || FLAG)) {
 #pragma unroll
                     for (int j = 0; j < G; ++j)
-                        aux[AUX ? j : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)offX, (int)((unsigned)(ps * RP + (i0 + j) * 4) * strideX), 0));
+                        aux[AUX ? j : 0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(active ? offX : 0xFFFFFFF0u), (int)((unsigned)(ps * RP + (i0 + j) * RPI) * strideX), 0));
                 }
 #pragma unroll
                 for (int j = 0; j < G; ++j) {
-                    const int i = i0 + j, rel = ps * RP + i * 4;          // the 4 rows mw0 + rel .. + 3, this lane: + r4
-                    f32x4 v = *reinterpret_cast<const f32x4*>(lds + rb[i & 1] + i * 1024);
-                    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(cptr + (size_t)rel * strideC), 0, (int)(4 * strideC), 0x00020000);
+                    const int i = i0 + j, rel = ps * RP + i * RPI;        // the RPI rows mw0 + rel .., this lane: + r4
+                    f32x4 v = *reinterpret_cast<const f32x4*>(lds + rb[i % NRB] + i * (RPI * PITCH));
+                    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(cptr + (size_t)rel * strideC), 0, (int)(RPI * strideC), 0x00020000);
                     float rs = 1.f;
                     if (EPI == FE_LINEAR || EPI == FE_DGELU) {
                         if (scaled) rs = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(rs_addr + rel * 4, rs_lane));
@@ -391,8 +396,8 @@ __device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, f
                     } else if (EPI == FE_GELU || EPI == FE_QGELU) {
                         v += b4;
                         if (EPI == FE_GELU && p.preact) {
-                            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(pptr + (size_t)rel * strideC), 0, (int)(4 * strideC), 0x00020000);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, (int)offC, 0, 2 /* nt */);
+                            const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(pptr + (size_t)rel * strideC), 0, (int)(RPI * strideC), 0x00020000);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, (int)(active ? offC : 0xFFFFFFF0u), 0, 2 /* nt */);
                         }
                         if (EPI == FE_QGELU || quick) {
 #pragma unroll
@@ -417,7 +422,7 @@ __device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, f
                         cs += v; cq += v * (yv * brs + bnm);
                     }
                     if (STATS) asm volatile("" : "+v"(cs), "+v"(cq));      // pin the running sums here (left alone, the compiler sinks all 16 row terms to the reduction below and spills them)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)offC, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)(active ? offC : 0xFFFFFFF0u), 0, 0);      // (idle lanes of the 24-slot form: out of range, dropped)
                 }
             }
         }
@@ -430,17 +435,19 @@ __device__ __forceinline__ void gemm_f32_epilogue_rows(const F32GemmParams& p, f
         // per-lane sums (4 columns, this lane's rows) -> LDS [wave][r4][2][64] -> thread (which, column): over the WM waves and the 4 row lanes
         __syncthreads();                                      // every wave is done with its transposition slice
         float* red = smem;
-        *reinterpret_cast<f32x4*>(red + ((wave * 4 + r4) * 2 + 0) * 64 + sl * 4) = cs;
-        *reinterpret_cast<f32x4*>(red + ((wave * 4 + r4) * 2 + 1) * 64 + sl * 4) = cq;
+        if (active) {
+            *reinterpret_cast<f32x4*>(red + ((wave * RPI + r4) * 2 + 0) * WCOLS + sl * 4) = cs;
+            *reinterpret_cast<f32x4*>(red + ((wave * RPI + r4) * 2 + 1) * WCOLS + sl * 4) = cq;
+        }
         __syncthreads();
-        constexpr int BNC = WN * 64;
+        constexpr int BNC = WN * WCOLS;
         for (int t = threadIdx.x; t < 2 * BNC; t += 256) {
-            const int which = t / BNC, col = t % BNC, wn_ = col >> 6, c = col & 63;
+            const int which = t / BNC, col = t % BNC, wn_ = col / WCOLS, c = col % WCOLS;
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sum += red[(((w * WN + wn_) * 4 + q) * 2 + which) * 64 + c];
+                for (int q = 0; q < RPI; ++q) sum += red[(((w * WN + wn_) * RPI + q) * 2 + which) * WCOLS + c];
             p.colstats[(int64_t)tm * 2 * p.N + which * p.N + n0 + col] = sum;
         }
     }
@@ -777,8 +784,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         // of the 128 x 128 tile; the BatchNorm-backward epilogue keeps one n-tile per group (its per-column coefficients need the registers)
         constexpr bool PAIR_AUX = (EPI == FE_DGELU || EPI == FE_LINEAR) && TM == 4 && PRO == 0;
         if constexpr (REPI) {
-            static_assert(TN == 4, "the row-layout epilogue is built for 64-column wave layouts");
-            gemm_f32_epilogue_rows<BM, WM, WN, TM, EPI, NST * STAGE>(p, smem, acc, m0, n0, tm, wave, lane);
+            gemm_f32_epilogue_rows<BM, WM, WN, TM, TN, EPI, NST * STAGE>(p, smem, acc, m0, n0, tm, wave, lane);
         } else
         gemm_f32_epilogue<BM, BNC, WM, WN, EPI, (PAIR_AUX ? 2 : 1), (PAIR_AUX ? 2 : 1)>(p, smem, acc, m0, n0, tm, wm, wn, lr, lg);
         if (p.trace && threadIdx.x == 0) {        // dev trace (gg_gemm_f32_set_trace), same record as the double-buffered form; no per-stage wait split
@@ -1079,15 +1085,18 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     static const char* rows_env = gg_dev_env("GG_GEMM_F32_ROWS_EPI");
     const float* xsrc = a->bn_y ? (const float*)a->bn_y : (a->dact_preact ? (const float*)a->dact_preact : (const float*)a->residual);
     const int64_t xld = (a->bn_y || a->dact_preact) ? a->ldc : a->ldr;
-    const bool rows_epi = sb && !(rows_env && rows_env[0] == '0') && p.debug == 0 && !p.trace && a->M % 128 == 0 && a->N % bn == 0 && (a->ldc & 3) == 0 && a->ldc < (1 << 23) &&
+    const bool rows_ok = !(rows_env && rows_env[0] == '0') && p.debug == 0 && !p.trace && a->M % 128 == 0 && a->N % bn == 0 && (a->ldc & 3) == 0 && a->ldc < (1 << 23) &&
                           (!xsrc || ((xld & 3) == 0 && xld < (1 << 23))) && (!a->rowscale || a->rows_per_scale >= 32) && (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
                           (!a->bn_y || ((((uintptr_t)a->bn_stat | (uintptr_t)a->bn_gamma | (uintptr_t)a->bn_beta) & 15) == 0)) && (!a->colstats || ((uintptr_t)a->colstats & 3) == 0);
+    const bool rows_epi = sb && rows_ok;
+    const bool sb96 = ring && wide96 && rows_ok && a->K <= sb_k;      // N = 96, 288: the 4 x 1 wave layout of the single-buffer form with the row-layout epilogue
 #define GG_LAUNCH_F32(E)                                                                                          \
     do {                                                                                                          \
         if (sb && narrow && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true, 0, true>), grid, dim3(256), 0, st, p); \
         else if (sb && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true, 0, true>), grid, dim3(256), 0, st, p); \
         else if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true>), grid, dim3(256), 0, st, p); \
         else if (sb) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true>), grid, dim3(256), 0, st, p); \
+        else if (sb96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 4, 1, E, 2, 4, 96, true, 0, true>), grid, dim3(256), 0, st, p); \
         else if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3, 96>), grid, dim3(256), 0, st, p); \
         else if (ring && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 4, 2>), grid, dim3(256), 0, st, p);    \
         else if (ring) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 3, 3>), grid, dim3(256), 0, st, p);       \
@@ -1098,7 +1107,15 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     if (a->a_bn_stat && a->K <= 384 && !(pro_ring_env && pro_ring_env[0] == '0') && (p.debug & 5) == 0) {
         // prologue GEMMs on the LDS-DMA ring (single-buffer form): the transform is applied to the A fragments after the LDS read
         dim3 rgrid(p.tilesM * p.tilesN);
-        if (a->A2) {        // PRO 2, linear epilogue; the third operand panel makes a stage 24 KB: 3 workgroups per CU
+        if (a->A2 && rows_ok) {
+            if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 4, 1, FE_LINEAR, 2, 3, 96, true, 2, true>), rgrid, dim3(256), 0, st, p);
+            else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, FE_LINEAR, 2, 4, 64, true, 2, true>), rgrid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, FE_LINEAR, 2, 3, 128, true, 2, true>), rgrid, dim3(256), 0, st, p);
+        } else if (rows_ok) {
+            if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 4, 1, FE_PLAIN, 2, 4, 96, true, 1, true>), rgrid, dim3(256), 0, st, p);
+            else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, FE_PLAIN, 2, 4, 64, true, 1, true>), rgrid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, FE_PLAIN, 2, 4, 128, true, 1, true>), rgrid, dim3(256), 0, st, p);
+        } else if (a->A2) {        // PRO 2, linear epilogue; the third operand panel makes a stage 24 KB: 3 workgroups per CU
             if (wide96) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 4, 1, FE_LINEAR, 2, 3, 96, true, 2>), rgrid, dim3(256), 0, st, p);
             else if (narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, FE_LINEAR, 2, 4, 64, true, 2>), rgrid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, FE_LINEAR, 2, 3, 128, true, 2>), rgrid, dim3(256), 0, st, p);

@@ -123,7 +123,8 @@ def test_f32_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
     assert float((got - plain).abs().max()) < 1e-5 * scale
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 576, 96), (12544, 576, 2304), (12544, 2304, 576), (12544, 1728, 576), (256, 64, 48)])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 576, 96), (12544, 576, 2304), (12544, 2304, 576), (12544, 1728, 576), (256, 64, 48), (512, 96, 64), (25088, 96, 384),
+                                   (1024, 288, 128)])
 def test_f32_gemm_row_layout_epilogue(ops, M, N, K):
     """Interior, aligned fp32 launches leave through the row-layout epilogue (gemm_f32_epilogue_rows: accumulators transposed through LDS, all
     element-wise work on whole rows): every epilogue kind against torch fp64, on both tile widths.  The 12 544-row shapes keep ~2000 workgroups
@@ -158,6 +159,19 @@ def test_f32_gemm_row_layout_epilogue(ops, M, N, K):
     dz, coef, dg, db = ops.conv_dgrad_bn_bwd(A, B, ysv, stat, gam, bet, act="gelu")
     assert rel(dz, dz_ref) < tol
     assert rel(db, dz_ref.sum(0)) < 1e-4 and rel(dg, (dz_ref * xh).sum(0)) < 1e-4
+    if K <= 384:
+        # the A-prologue kernels on the same tiles: BN+GELU of A while staging (+ column statistics), and the two-source affine of BatchNorm backward
+        sa = torch.stack([A.double().mean(0), (A.double().var(0, unbiased=False) + 1e-5).rsqrt()]).float()
+        ga, ba = (torch.rand(K, generator=g) + 0.5).cuda(), (torch.randn(K, generator=g) * 0.2).cuda()
+        Ap = F.gelu((A.double() - sa[0].double()) * sa[1].double() * ga.double() + ba.double())
+        c, st = ops.conv_bn_prologue(A, sa, ga, ba, B, act="gelu", colstats=True)
+        refp = Ap @ B.double().t()
+        assert rel(c, refp) < tol and rel(st.sum(0)[0], refp.sum(0)) < 1e-4 and rel(st.sum(0)[1], (refp * refp).sum(0)) < 1e-4
+        y2 = torch.randn(M, K, generator=g).cuda(); coef = torch.stack([1.0 + 0.1 * torch.randn(K, generator=g), 0.05 * torch.randn(K, generator=g), 0.02 * torch.randn(K, generator=g)]).cuda()
+        Wm = B.t().contiguous()                                          # folded_dgrad takes the conv weight [Cout = K, Cin = N]
+        dx = ops.folded_dgrad(A, y2, Wm, coef, None, residual=res)
+        refd = (coef[0].double() * A.double() + coef[1].double() * y2.double() + coef[2].double()) @ Wm.double() + res.double()
+        assert rel(dx, refd) < tol
 
 
 def test_gemm_tn_many_slabs_small_matrix(ops):
