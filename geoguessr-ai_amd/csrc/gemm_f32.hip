@@ -858,7 +858,7 @@ struct F32TnParams {
 // BN: the left operand is BatchNorm backward's apply step dy = c0*dz + c1*y + c2 (gg_bn_bwd_finalize's coef) of the two tensors (dz, y), formed
 // per 16-byte chunk between the global load and the LDS store -- the weight gradient of a ConvNorm straight from (dz, y), no dy tensor.  Rows
 // beyond the split read as zero in X, so the c2 they would contribute to dy meets a zero and drops out.
-template <bool SMALL, bool BN = false>
+template <bool SMALL, bool BN = false, bool FE = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
     constexpr int TB = 128, MS = 32, RS = TB + 16;
     constexpr int LS = MS * (TB / 4) / 256;                 // 16-byte chunks per thread per operand per step (= 4)
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
     const int tn = tile_id / p.tilesK, tk = tile_id % p.tilesK;
     const int n0 = tn * TB, k0 = tk * TB;
     const int mbeg = split_id * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // scalar: the fragment limits below stay in SGPRs
     const int wn = SMALL ? 0 : wave >> 1, wk = SMALL ? 0 : wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
     const int nt_lim = min(4, max(0, (p.N - n0 - wn * 64 + 15) >> 4)), kt_lim = min(4, max(0, (p.K - k0 - wk * 64 + 15) >> 4));   // wave-uniform
@@ -917,6 +917,9 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (mbeg < mend) load_step(mbeg);
+    // FE (host: N and K multiples of 64): every wave's 64 x 64 tile is either entirely live or entirely outside the matrix, so the MFMAs of a live wave
+    // run back to back; the general form wraps each of the 16 MFMAs of a k-step in its own exec-mask branch (16 basic blocks per step)
+    const bool live = nt_lim > 0 && kt_lim > 0;
     for (int m0 = mbeg; m0 < mend; m0 += MS) {
         if (BN) {
 #pragma unroll
@@ -934,7 +937,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
         __syncthreads();
         if (m0 + MS < mend) load_step(m0 + MS);
         const int steps = min(MS, mend - m0 + 3) / 4;              // rows beyond mend are zero anyway; skip whole empty steps
-        const int ss0 = SMALL ? 2 * wave : 0, ss1 = SMALL ? min(steps, 2 * wave + 2) : steps;
+        const int ss0 = SMALL ? 2 * wave : 0, ss1 = (FE && !live) ? 0 : (SMALL ? min(steps, 2 * wave + 2) : steps);
 #pragma unroll 2
         for (int ss = ss0; ss < ss1; ++ss) {
             float yf[4], xf[4];
@@ -947,7 +950,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    if (kt < kt_lim && nt < nt_lim)
+                    if (FE || (kt < kt_lim && nt < nt_lim))
                         acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
         }
         __syncthreads();
@@ -1182,11 +1185,15 @@ static int gemm_tn_f32_launch(const void* dY, const void* Y2, const float* coef,
     GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 32), "gg_gemm_tn_f32: a split's rows must span < 4 GiB per operand (use more splits)");
     GG_CHECK((int64_t)p.tilesN * p.tilesK * blocks < ((int64_t)1 << 31), "gg_gemm_tn_f32: grid too large");
     GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * M * ((double)N * (Y2 ? 2 : 1) + K) + 4.0 * splits * (double)N * K, stream);
+    const bool fe = !small && (N & 63) == 0 && (K & 63) == 0;       // wave tiles all-or-nothing: the branch-free MFMA block
+    const dim3 tgrid((unsigned)(p.tilesN * p.tilesK * blocks));
     if (Y2) {
         if (small) hipLaunchKernelGGL((gemm_tn_f32_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true>), dim3((unsigned)(p.tilesN * p.tilesK * blocks)), dim3(256), 0, (hipStream_t)stream, p);
+        else if (fe) hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true, true>), tgrid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((gemm_tn_f32_kernel<false, true>), tgrid, dim3(256), 0, (hipStream_t)stream, p);
     } else if (small) hipLaunchKernelGGL((gemm_tn_f32_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm_tn_f32_kernel<false>), dim3((unsigned)(p.tilesN * p.tilesK * blocks)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (fe) hipLaunchKernelGGL((gemm_tn_f32_kernel<false, false, true>), tgrid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm_tn_f32_kernel<false>), tgrid, dim3(256), 0, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
