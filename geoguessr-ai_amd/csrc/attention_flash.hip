@@ -189,8 +189,15 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
         f32x4 st[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // padded keys are masked through the accumulators' INITIAL value (-inf stays -inf under the products and the bias): no compare + select
+            // per score (fp32 MFMA and VALU share the SIMD's issue).  Wave-uniform cases: only the window's last sub-tile holds padded keys
+            st[kt] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             if (kt < nsub) {
+                st[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (t0 + 16 * kt + 15 >= p.N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[kt][r] = (t0 + 16 * kt + 4 * lg + r < p.N) ? 0.f : -INFINITY;
+                }
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
                     const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
@@ -215,9 +222,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_fwd_kernel(FlashParams
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {          // scores in the exp2 domain: s * scale * log2 e + bias * log2 e
-                const int kl = 16 * kt + 4 * lg + r;
-                float s = fmaf(st[kt][r], sc2, bia[kt][r]);
-                s = (kt < nsub && t0 + kl < p.N) ? s : -INFINITY;
+                const float s = fmaf(st[kt][r], sc2, bia[kt][r]);
                 st[kt][r] = s;
                 tmax = fmaxf(tmax, s);
             }
@@ -345,6 +350,12 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             f32x4 st[QS], dp[QS];
 #pragma unroll
             for (int u = 0; u < QS; ++u) { st[u] = (f32x4){lse2[u], lse2[u], lse2[u], lse2[u]}; dp[u] = (f32x4){-delta[u], -delta[u], -delta[u], -delta[u]}; }
+            if (t0 + 16 * kt + 15 >= p.N) {          // wave-uniform: only the window's last sub-tile holds padded keys; -inf there -> P = 0
+#pragma unroll
+                for (int u = 0; u < QS; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (t0 + 16 * kt + 4 * lg + r >= p.N) st[u][r] = -INFINITY;
+            }
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(Kt + (16 * kt + lr) * RS + 16 * c + 4 * lg);
@@ -358,7 +369,6 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
                     }
             }
             // lane holds S^T / dP^T [key = t0 + 16kt + 4lg + r][q = lr] of each strip
-            const bool tail = t0 + 16 * kt + 15 >= p.N;        // wave-uniform: only the window's last sub-tile holds padded keys
             f32x4 bia[QS];
 #pragma unroll
             for (int u = 0; u < QS; ++u) bia[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -373,9 +383,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             for (int u = 0; u < QS; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kl = 16 * kt + 4 * lg + r;
-                    float pr = __builtin_amdgcn_exp2f(fmaf(st[u][r], sc2, bia[u][r]));      // rows beyond N are never stored: no query mask needed in this pass
-                    if (tail && t0 + kl >= p.N) pr = 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(st[u][r], sc2, bia[u][r]));      // rows beyond N are never stored: no query mask needed in this pass
                     st[u][r] = pr * dp[u][r];                            // dS^T; the softmax scale is applied once, to dQ
                 }
 #pragma unroll
