@@ -137,3 +137,23 @@ def test_lr_schedule_and_loop_helpers():
             assert shards[r].tolist() == list(DistributedSampler(range(n), num_replicas=world, rank=r, shuffle=False))
         counts = [sum(1 for _ in _batches(dict(a=torch.arange(n)), bs, True, 3, r, world)) for r in range(world)]
         assert counts == [_num_batches(n, bs, world)] * world
+
+
+def test_weight_cache_dirty_mask_bookkeeping():
+    """``mark_params_dirty(only=...)`` (fused optimizer step) accumulates tensor masks until the next refresh; an unmasked mark (checkpoint load,
+    broadcast) means everything.  Host logic only: the backbone is constructed on the CPU and never run."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False)
+    m.freeze_all_but_last_stage()
+    bb = m.backbone
+    mask = bb.trainable_mask()
+    assert len(mask) == len(bb.table) and 0 < sum(mask) < len(mask)
+    bb._dirty_all, bb._dirty_only = False, None                       # state right after a refresh
+    a = bytes(1 if i == 3 else 0 for i in range(len(mask)))
+    bb.mark_params_dirty(only=a)
+    bb.mark_params_dirty(only=mask)
+    assert bb._dirty_all is False and bb._dirty_only == bytes(x | y for x, y in zip(a, mask)) and bb._wcache_version == -1
+    bb.mark_params_dirty()                                            # an unmasked writer in between: full rebuild
+    assert bb._dirty_all is True and bb._dirty_only is None
+    bb.mark_params_dirty(only=mask)                                   # ... and a later masked mark must not narrow it again
+    assert bb._dirty_all is True
