@@ -34,7 +34,7 @@ class AttnArgs(C.Structure):
                 ("tokens_per_window", C.c_int), ("window_size", C.c_int), ("map_h", C.c_int), ("map_w", C.c_int),
                 ("bias", C.c_void_p), ("scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("dout", C.c_void_p), ("lddo", C.c_int64), ("dqkv", C.c_void_p), ("dbias", C.c_void_p), ("dbias_scratch", C.c_void_p),
-                ("lse", C.c_void_p), ("bias_table", C.c_void_p)]
+                ("lse", C.c_void_p), ("bias_table", C.c_void_p), ("ds_scratch", C.c_void_p)]
 
 
 class GeoHeadArgs(C.Structure):
@@ -135,6 +135,7 @@ SIGNATURES = {
     "gg_attention_flash_fwd": (_I, [C.POINTER(AttnArgs), _I, _P]),
     "gg_attention_flash_bwd": (_I, [C.POINTER(AttnArgs), _I, _P]),
     "gg_attention_flash_dbias_rows": (_L, [_I, _I]),
+    "gg_attention_flash_ds_scratch_floats": (_L, [_I, _I, _I]),
     "gg_gemm_nt_f32": (_I, [C.POINTER(GemmArgs), _P]),
     "gg_gemm_tn_f32_splits": (_I, [_I, _I, _I]),
     "gg_gemm_tn_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),

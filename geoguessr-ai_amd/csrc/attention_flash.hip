@@ -34,6 +34,7 @@ struct FlashParams {
     void* dqkv;
     float* dbias; float* dbias_part;  // [nh][ws*ws] accumulated into (atomics) / per-workgroup partial rows [rows][nh][ws*ws]
     float* lse;                       // [tokens][nh]
+    float* ds_scratch;                // [windows][nh][npad][npad] f32 or null: dS handed from the dK/dV pass to the dQ pass
     int ntile;                        // ceil(N / 64)
     int npad, nbpad;                  // tokens rounded up to 16 (rows of a resident LDS image); floats reserved for a bias table
 };
@@ -407,6 +408,81 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
     }
 }
 
+// ------------------------------------------------------------------------------------------- backward, pass A from stored dS
+// With a dS scratch (GgAttnArgs.ds_scratch) the dK/dV pass runs FIRST and leaves dS = P o (dP - delta) of every (query, key) pair as f32
+// [window][head][npad][npad]; this pass then is one product, dQ = scale * dS K: no Q K^T, no dO V^T, no exponentials, no bias lookups -- 1 of the
+// two-pass scheme's 7 products instead of 3 (the scratch costs 2 x npad^2 x 4 bytes of HBM traffic per (window, head): 4.2 GB per 14 x 14 layer).
+// Lane (lr, lg) of a strip reads its query row lr, keys 4 lg .. 4 lg + 3 of a 16-key sub-tile: exactly the B operand of the next 4 MFMA steps.
+template <typename T, int D, bool RES, int QS>
+__global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_ds_kernel(FlashParams p) {
+    constexpr int RS = D + 4, DC = D / 16;
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* Ks = fsm;
+    const int qt = RES ? 0 : blockIdx.x % p.ntile;
+    const int wh = RES ? blockIdx.x : blockIdx.x / p.ntile;
+    const int h = wh % p.nh, w = wh / p.nh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int64_t origin = fl_origin(p, w);
+    const T* qkv = reinterpret_cast<const T*>(p.qkv);
+    const int hc = h * p.head_stride;
+    if (RES) {
+        fl_stage_all<T, D>(p, qkv, p.ld, p.k_off + hc, origin, Ks);
+        __syncthreads();
+    }
+    const float* dsb = p.ds_scratch + (int64_t)wh * p.npad * p.npad;
+    const int nstrips = (p.N + 15) >> 4;
+    const int nwaves = (int)(blockDim.x >> 6);
+    for (int strip0 = RES ? wave * QS : qt * 4 + wave; !RES || strip0 < nstrips; strip0 += nwaves * QS) {
+    f32x4 dq[QS][DC];
+    const float* dsrow[QS];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) dq[u][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dsrow[u] = dsb + (int64_t)min((strip0 + u) * 16 + lr, p.npad - 1) * p.npad + 4 * lg;
+    }
+    const bool wave_on = strip0 * 16 < p.N;
+    for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
+        const int t0 = kt0 * 64;
+        if (!RES) {
+            __syncthreads();
+            fl_stage<T, D>(p, qkv, p.ld, p.k_off + hc, origin, t0, Ks);
+            __syncthreads();
+            if (!wave_on) continue;
+        }
+        const float* Kt = Ks + (RES ? t0 * RS : 0);
+        const int nsub = min(4, (p.N - t0 + 15) / 16);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nsub) continue;
+            f32x4 st[QS];
+#pragma unroll
+            for (int u = 0; u < QS; ++u) st[u] = *reinterpret_cast<const f32x4*>(dsrow[u] + t0 + 16 * kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const float kfs = Kt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+#pragma unroll
+                    for (int u = 0; u < QS; ++u) dq[u][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfs, st[u][r], dq[u][c], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+        const int qi = (strip0 + u) * 16 + lr;
+        if (qi < p.N) {
+            T* dqkv = reinterpret_cast<T*>(p.dqkv);
+            const int64_t qtok = fl_token(p, origin, qi);
+#pragma unroll
+            for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[u][c] * p.scale);
+        }
+    }
+    if (!RES) break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- backward, pass B: dK, dV (+ dbias)
 // -delta[q] = -sum_d dO[q][d] O[q][d] and -lse[q] / scale of rows [t0, t0+n) into LDS: 4 lanes per row
 template <typename T, int D>
@@ -433,7 +509,7 @@ __device__ __forceinline__ void fl_stage_rowstats(const FlashParams& p, const T*
         if (part == 0 && row < n) { del_s[row] = -dsum; lse_s[row] = ok ? -p.lse[tok * p.nh + h] / p.scale : -INFINITY; }
     }
 }
-template <typename T, int D, bool DBIAS, bool RES>
+template <typename T, int D, bool DBIAS, bool RES, bool STORE_DS = false>
 __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashParams p) {
     constexpr int RS = D + 4, DC = D / 16;
     extern __shared__ __attribute__((aligned(16))) float fsm[];
@@ -536,6 +612,8 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
                 const float g = e * dp[r];
                 pr[r] = e;
                 ds[r] = g;                                                     // the softmax scale is applied once, to dK
+                // (padded query rows hold exact zeros -- P = 0 --, padded key columns finite values that meet zero K rows in the dQ pass)
+                if (STORE_DS) p.ds_scratch[((int64_t)wh * p.npad + (t0 + ql)) * p.npad + strip * 16 + lr] = g;
                 if (DBIAS && kok && t0 + ql < p.N) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dbt) + boff), g);
             }
 #pragma unroll
@@ -605,6 +683,7 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.nWx = a->window_size ? a->map_w / a->window_size : 1;
     p.nWy = a->window_size ? a->map_h / a->window_size : 1;
     p.N = a->tokens_per_window; p.nh = a->num_heads; p.scale = a->scale;
+    p.ds_scratch = a->ds_scratch;
     p.dout = a->dout; p.lddo = a->lddo; p.dqkv = a->dqkv; p.dbias = a->dbias; p.dbias_part = a->dbias ? a->dbias_scratch : nullptr; p.lse = a->lse;
     p.ntile = (int)gg_cdiv(a->tokens_per_window, 64);
     p.npad = (int)gg_align(a->tokens_per_window, 16);
@@ -646,6 +725,10 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
     GG_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int64_t gg_attention_flash_ds_scratch_floats(int num_windows, int num_heads, int tokens_per_window) {
+    const int64_t npad = gg_align(tokens_per_window, 16);
+    return (int64_t)num_windows * num_heads * npad * npad;
+}
 extern "C" int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per_window) {
     return (int64_t)num_windows * gg_cdiv(tokens_per_window, 64) + GG_REDUCE_SLICES;
 }
@@ -664,8 +747,18 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     const double es = dtype ? 4.0 : 2.0;
     GG_PROF(GG_CAT_ATTN, 14.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
             8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
+    // with a dS scratch: dK/dV pass first (stores dS), then the one-product dQ pass
+    const size_t lds_k = ((size_t)R * (a->head_dim + 4)) * 4;
+#define GG_FL_BWD_DS(T_, D_, R_)                                                                              \
+    do {                                                                                                      \
+        if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true, R_, true>), grid, block, lds_kv, s, p); \
+        else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false, R_, true>), grid, block, lds_kv, s, p);  \
+        if (R_) hipLaunchKernelGGL((flash_bwd_dq_ds_kernel<T_, D_, R_, 2>), grid, dim3(64 * ((p.npad / 16 + 1) / 2)), lds_k, s, p); \
+        else hipLaunchKernelGGL((flash_bwd_dq_ds_kernel<T_, D_, R_, 1>), grid, block, lds_k, s, p);           \
+    } while (0)
 #define GG_FL_BWD2(T_, D_, R_)                                                                                \
     do {                                                                                                      \
+        if (p.ds_scratch) { GG_FL_BWD_DS(T_, D_, R_); break; }                                                \
         if (R_ && D_ == 32 && !gg_dev_env("GG_ATTN_DQ_QS1")) hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_, 2>), grid, dim3(64 * ((p.npad / 16 + 1) / 2)), lds_q, s, p); \
         else hipLaunchKernelGGL((flash_bwd_dq_kernel<T_, D_, R_>), grid, block, lds_q, s, p);                 \
         if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true, R_>), grid, block, lds_kv, s, p); \
@@ -676,6 +769,7 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     else { if (a->head_dim == 32) GG_FL_BWD(bf16, 32); else GG_FL_BWD(bf16, 64); }
 #undef GG_FL_BWD
 #undef GG_FL_BWD2
+#undef GG_FL_BWD_DS
     if (p.dbias && p.dbias_part) {
         const int Wd = p.nh * p.ws * p.ws;
         const float* rows; int nrows;

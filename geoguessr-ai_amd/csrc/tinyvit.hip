@@ -198,7 +198,7 @@ struct Layout {
     std::vector<BlockAct> blocks[3];
     int64_t pooled, mean_h, rstd_h;
     // scratch
-    int64_t statpart, bnscratch, lnscratch, colsum, splitk, G[5];
+    int64_t statpart, bnscratch, lnscratch, colsum, splitk, attn_ds = -1, G[5];
     int64_t foldw, foldb;        // BatchNorm-backward-folded dgrad weights bf16 [Cin][2*Cout] and bias f32 [Cin]
     int64_t gbytes;
 };
@@ -314,6 +314,15 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         L.lnscratch = p.alloc("scratch.ln", lnsmax, false);
         L.colsum = p.alloc("scratch.colsum", std::max<int64_t>(csmax, 1024), false);
         L.splitk = p.alloc("scratch.splitk", (int64_t)128 << 20, false);      // gg_gemm_tn_f32_splits sizes its slabs against this
+        if (m.f32) {     // dS hand-off between the two passes of the flash attention backward (GgAttnArgs.ds_scratch): the largest stage decides
+            int64_t dsmax = 0;
+            for (int s = 1; s < 4; ++s) {
+                const auto& st = m.stages[s - 1];
+                const int nw = B * (st.res / st.ws) * (st.res / st.ws);
+                dsmax = std::max(dsmax, gg_attention_flash_ds_scratch_floats(nw, st.heads, st.ws * st.ws) * 4);
+            }
+            L.attn_ds = p.alloc("scratch.attn_ds", dsmax, false);
+        }
         int64_t fold = (int64_t)d[0] * 2 * mid;
         for (int s = 0; s < 3; ++s) fold = std::max(fold, (int64_t)(s == 0 ? d[0] : m.stages[s - 1].C) * 2 * m.stages[s].C);
         L.foldw = p.alloc("scratch.foldw", fold * es, false);
@@ -820,6 +829,8 @@ static int backward_impl(Exec& e, const float* d_out) {
             const int64_t prow = flash ? gg_attention_flash_dbias_rows(at.num_windows, at.tokens_per_window) : (int64_t)at.num_windows + 64;
             if (at.dbias && prow * st.heads * st.ws * st.ws * 4 <= ((int64_t)64 << 20))
                 at.dbias_scratch = e.F(L.splitk);      // per-workgroup partials -> deterministic second stage
+            static const bool ds_off = gg_dev_env("GG_ATTN_NO_DS_SCRATCH") != nullptr;
+            if (e.f32 && L.attn_ds >= 0 && !ds_off) at.ds_scratch = e.F(L.attn_ds);
             GG_TRY(e.f32 ? gg_attention_flash_bwd(&at, 1, e.st) : gg_attention_bwd(&at, e.st));
             // da = dqkv . Wqkv                                         -> t_a  [M, C]
             GG_TRY(gemm(e, t_b, 3 * C, e.Wt(l.qkv), l.qkv.Np, t_a, C, M, C, 3 * C));

@@ -505,9 +505,10 @@ def view_mean_f32(emb):
 
 def attention_flash(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off, k_off, v_off, head_stride,
                     window_size=0, map_h=0, map_w=0, bias_table=None, scale=None, dout=None, want_dbias=False, out=None, lse=None,
-                    want_lse=False, deterministic_dbias=True):
+                    want_lse=False, deterministic_dbias=True, ds_handoff=False):
     """Online-softmax attention (any tokens_per_window; bf16 or f32 storage by ``qkv.dtype``).  Forward when ``dout`` is None
-    (returns out, or (out, lse)); else backward given the forward's ``out`` and ``lse`` -> (dqkv, dbias)."""
+    (returns out, or (out, lse)); else backward given the forward's ``out`` and ``lse`` -> (dqkv, dbias).  ``ds_handoff``: give the
+    backward a dS scratch (the dK/dV pass then hands dS to a one-product dQ pass)."""
     L.require_gpu()
     DT = qkv.dtype
     a = L.AttnArgs()
@@ -535,6 +536,10 @@ def attention_flash(qkv, *, num_windows, tokens_per_window, num_heads, head_dim,
         scratch = torch.empty((rows * num_heads * window_size * window_size,), dtype=F32, device=qkv.device)
         a.dbias_scratch = _p(scratch)
     a.out, a.ldo, a.lse = _p(out, DT, "out"), out.stride(0), _p(lse, F32, "lse")
+    ds = None
+    if ds_handoff:
+        ds = torch.empty((L.lib().gg_attention_flash_ds_scratch_floats(num_windows, num_heads, tokens_per_window),), dtype=F32, device=qkv.device)
+        a.ds_scratch = _p(ds)
     L.check(L.lib().gg_attention_flash_bwd(C.byref(a), dt, L.stream()), "gg_attention_flash_bwd")
     return dqkv, dbias
 

@@ -340,6 +340,13 @@ def test_flash_attention_forward_backward(ops, dtype, nh, D, ws, map_hw, batch, 
     if table is not None:
         e = relerr(dtab, dt_ref)
         assert e < (5e-5 if dtype == F32 else 2e-2), f"flash dbias rel err {e}"
+    # dS hand-off (GgAttnArgs.ds_scratch): dK/dV pass first, dQ as one product of the stored dS -- same dk / dv bit for bit, dq to rounding
+    dqkv2, dtab2 = ops.attention_flash(qkv.cuda().to(dtype), dout=dout.cuda().to(dtype), out=out, lse=lse, want_dbias=table is not None, ds_handoff=True, **kw)
+    e = relerr(dqkv2, dq_ref)
+    assert e < (2e-5 if dtype == F32 else 1.5e-2), f"flash dqkv (dS hand-off) rel err {e}"
+    assert float((dqkv2.float() - dqkv.float()).abs().max()) <= (1e-5 if dtype == F32 else 2e-2) * float(dqkv.float().abs().max())
+    if table is not None:          # (LDS float atomics inside a workgroup: equal to rounding, not bit for bit)
+        assert relerr(dtab2, dt_ref) < (5e-5 if dtype == F32 else 2e-2)
 
 
 def test_flash_online_softmax_rescale_branch(ops):

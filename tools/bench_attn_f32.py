@@ -27,5 +27,8 @@ for name, res, ws, Cc, nh in [("s1", 28, 7, 192, 6), ("s2", 14, 14, 384, 12), ("
     tf = timed(lambda: L.check(L.lib().gg_attention_flash_fwd(C.byref(a), 1, L.stream())))
     a.dout, a.lddo, a.dqkv = dout.data_ptr(), Cc, dqkv.data_ptr()
     tb = timed(lambda: L.check(L.lib().gg_attention_flash_bwd(C.byref(a), 1, L.stream())))
+    ds = torch.empty(L.lib().gg_attention_flash_ds_scratch_floats(a.num_windows, nh, N), device="cuda")
+    a.ds_scratch = ds.data_ptr()
+    td = timed(lambda: L.check(L.lib().gg_attention_flash_bwd(C.byref(a), 1, L.stream())))
     fl = 4.0 * M * N * Cc
-    print(f"{name} ws={ws}  fwd {tf*1e3:8.1f} us ({fl/tf/1e9:6.1f} TF/s)   bwd {tb*1e3:8.1f} us ({2.5*fl/tb/1e9:6.1f} TF/s on 5 products)")
+    print(f"{name} ws={ws}  fwd {tf*1e3:8.1f} us ({fl/tf/1e9:6.1f} TF/s)   bwd {tb*1e3:8.1f} us ({2.5*fl/tb/1e9:6.1f} TF/s on 5 products)   bwd with dS hand-off {td*1e3:8.1f} us")
