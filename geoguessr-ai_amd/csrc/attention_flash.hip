@@ -453,19 +453,22 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_ds_kernel(Flash
         }
         const float* Kt = Ks + (RES ? t0 * RS : 0);
         const int nsub = min(4, (p.N - t0 + 15) / 16);
+        // all dS fragments of the 64-key tile in flight before its first MFMA (the pass is bound by these loads: 2 x npad^2 floats per (window, head))
+        f32x4 st[4][QS];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int u = 0; u < QS; ++u) st[kt][u] = kt < nsub ? *reinterpret_cast<const f32x4*>(dsrow[u] + t0 + 16 * kt) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             if (kt >= nsub) continue;
-            f32x4 st[QS];
-#pragma unroll
-            for (int u = 0; u < QS; ++u) st[u] = *reinterpret_cast<const f32x4*>(dsrow[u] + t0 + 16 * kt);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < DC; ++c) {
                     const float kfs = Kt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
 #pragma unroll
-                    for (int u = 0; u < QS; ++u) dq[u][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfs, st[u][r], dq[u][c], 0, 0, 0);
+                    for (int u = 0; u < QS; ++u) dq[u][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfs, st[kt][u][r], dq[u][c], 0, 0, 0);
                 }
         }
     }
