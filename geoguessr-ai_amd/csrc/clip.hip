@@ -229,7 +229,7 @@ struct CPlan {
     int64_t s_x, s_a, s_qkv, s_o, s_h;                        // scratch of the layers that keep nothing (in-place residual stream)
     std::vector<LayerA> la;
     int64_t xfinal;
-    int64_t g_x0, g_x1, g_a, g_qkv, g_o, g_h, splitk, colsum, lnscr;      // backward scratch
+    int64_t g_x0, g_x1, g_a, g_qkv, g_o, g_h, splitk, colsum, lnscr, attn_ds = -1;      // backward scratch (attn_ds: GgAttnArgs.ds_scratch)
     int64_t total;
 };
 static void plan(const CModel& m, int B, const Train& tr, bool training, CPlan& L) {
@@ -258,6 +258,8 @@ static void plan(const CModel& m, int B, const Train& tr, bool training, CPlan& 
         L.splitk = al(sk * 4);
         L.colsum = al(std::max(gg_colsum_scratch_floats((int)M, I), gg_colsum_scratch_floats((int)M, D)) * 4);
         L.lnscr = al(gg_layernorm_bwd_scratch_floats(M, D) * 4);
+        const int64_t dsb = gg_attention_flash_ds_scratch_floats(B, m.cfg.num_heads, m.T) * 4;   // dS hand-off between the two passes of the attention backward
+        if (dsb <= ((int64_t)4 << 30)) L.attn_ds = al(dsb);                                       // (577-token towers at large batches: both passes recompute instead)
     }
     L.total = off;
 }
@@ -495,6 +497,7 @@ extern "C" int gg_clip_backward(const GgClipCfg* cfg, int batch, const float* pa
         GgAttnArgs at;
         e.attn_args(at, e.A(a.qkv), e.A(a.o), e.F(a.lse));
         at.dout = e.A(L.g_o); at.lddo = D; at.dqkv = e.A(L.g_qkv);
+        if (L.attn_ds >= 0) at.ds_scratch = e.F(L.attn_ds);
         GG_TRY(gg_attention_flash_bwd(&at, m.f32 ? 1 : 0, e.st));
         const char* dq = (const char*)e.A(L.g_qkv);
         GG_TRY(e.wgrad(l.q_w, dq, 3 * D, e.A(a.a1), D, M, D, D));
