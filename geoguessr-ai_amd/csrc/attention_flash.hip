@@ -410,7 +410,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
 
 // ------------------------------------------------------------------------------------------- backward, pass A from stored dS
 // With a dS scratch (GgAttnArgs.ds_scratch) the dK/dV pass runs FIRST and leaves dS = P o (dP - delta) of every (query, key) pair as f32
-// [window][head][npad][npad]; this pass then is one product, dQ = scale * dS K: no Q K^T, no dO V^T, no exponentials, no bias lookups -- 1 of the
+// [window][head][key strip][query][16 keys] (npad^2 floats per head); this pass then is one product, dQ = scale * dS K: no Q K^T, no dO V^T, no exponentials, no bias lookups -- 1 of the
 // two-pass scheme's 7 products instead of 3 (the scratch costs 2 x npad^2 x 4 bytes of HBM traffic per (window, head): 4.2 GB per 14 x 14 layer).
 // Lane (lr, lg) of a strip reads its query row lr, keys 4 lg .. 4 lg + 3 of a 16-key sub-tile: exactly the B operand of the next 4 MFMA steps.
 template <typename T, int D, bool RES, int QS>
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_ds_kernel(Flash
     for (int u = 0; u < QS; ++u) {
 #pragma unroll
         for (int c = 0; c < DC; ++c) dq[u][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dsrow[u] = dsb + (int64_t)min((strip0 + u) * 16 + lr, p.npad - 1) * p.npad + 4 * lg;
+        dsrow[u] = dsb + (int64_t)min((strip0 + u) * 16 + lr, p.npad - 1) * 16 + 4 * lg;          // + key strip * npad * 16
     }
     const bool wave_on = strip0 * 16 < p.N;
     for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_ds_kernel(Flash
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int u = 0; u < QS; ++u) st[kt][u] = kt < nsub ? *reinterpret_cast<const f32x4*>(dsrow[u] + t0 + 16 * kt) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int u = 0; u < QS; ++u) st[kt][u] = kt < nsub ? *reinterpret_cast<const f32x4*>(dsrow[u] + (int64_t)(4 * kt0 + kt) * p.npad * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             if (kt >= nsub) continue;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
                 pr[r] = e;
                 ds[r] = g;                                                     // the softmax scale is applied once, to dK
                 // (padded query rows hold exact zeros -- P = 0 --, padded key columns finite values that meet zero K rows in the dQ pass)
-                if (STORE_DS) p.ds_scratch[((int64_t)wh * p.npad + (t0 + ql)) * p.npad + strip * 16 + lr] = g;
+                if (STORE_DS) p.ds_scratch[(((int64_t)wh * (p.npad >> 4) + strip) * p.npad + (t0 + ql)) * 16 + lr] = g;      // [key strip][query][16 keys]: a 16 x 16 tile is 1 KB contiguous
                 if (DBIAS && kok && t0 + ql < p.N) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(dbt) + boff), g);
             }
 #pragma unroll
