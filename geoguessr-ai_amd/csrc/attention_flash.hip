@@ -413,6 +413,52 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
 // [window][head][key strip][query][16 keys] (npad^2 floats per head); this pass then is one product, dQ = scale * dS K: no Q K^T, no dO V^T, no exponentials, no bias lookups -- 1 of the
 // two-pass scheme's 7 products instead of 3 (the scratch costs 2 x npad^2 x 4 bytes of HBM traffic per (window, head): 4.2 GB per 14 x 14 layer).
 // Lane (lr, lg) of a strip reads its query row lr, keys 4 lg .. 4 lg + 3 of a 16-key sub-tile: exactly the B operand of the next 4 MFMA steps.
+// dQ rows of QS query strips from the stored dS and a RESIDENT K image (all p.npad rows in LDS): shared by the stand-alone pass below and by the
+// second phase of the resident dK/dV kernel
+template <typename T, int D, int QS>
+__device__ __forceinline__ void fl_dq_from_ds_resident(const FlashParams& p, const float* Ks, const float* dsb, int strip0, int64_t origin, int hc, int lr, int lg) {
+    constexpr int RS = D + 4, DC = D / 16;
+    f32x4 dq[QS][DC];
+    const float* dsrow[QS];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c) dq[u][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dsrow[u] = dsb + (int64_t)min((strip0 + u) * 16 + lr, p.npad - 1) * 16 + 4 * lg;          // + key strip * npad * 16
+    }
+    for (int kt0 = 0; kt0 < p.ntile; ++kt0) {
+        const int t0 = kt0 * 64;
+        const float* Kt = Ks + t0 * RS;
+        const int nsub = min(4, (p.N - t0 + 15) / 16);
+        f32x4 st[4][QS];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int u = 0; u < QS; ++u) st[kt][u] = kt < nsub ? *reinterpret_cast<const f32x4*>(dsrow[u] + (int64_t)(4 * kt0 + kt) * p.npad * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt >= nsub) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                    const float kfs = Kt[(16 * kt + 4 * lg + r) * RS + 16 * c + lr];
+#pragma unroll
+                    for (int u = 0; u < QS; ++u) dq[u][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(kfs, st[kt][u][r], dq[u][c], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+        const int qi = (strip0 + u) * 16 + lr;
+        if (qi < p.N) {
+            T* dqkv = reinterpret_cast<T*>(p.dqkv);
+            const int64_t qtok = fl_token(p, origin, qi);
+#pragma unroll
+            for (int c = 0; c < DC; ++c) Ld4<T>::store(dqkv + qtok * p.ld + p.q_off + hc + 16 * c + 4 * lg, dq[u][c] * p.scale);
+        }
+    }
+}
 template <typename T, int D, bool RES, int QS>
 __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_ds_kernel(FlashParams p) {
     constexpr int RS = D + 4, DC = D / 16;
@@ -653,6 +699,19 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
             else atomicAdd(&p.dbias[h * nb + i], t);
         }
     }
+    if (STORE_DS && RES) {
+        // second phase of the resident form: this workgroup wrote the whole dS of its (window, head); once every wave's stores are visible the same
+        // workgroup turns it into dQ (one strip per wave) -- the dS it reads back is still in L2 / Infinity Cache, and the separate dQ launch is gone
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        float* Ks = Qs;                                             // the Q image is dead: K takes its place
+        fl_stage_all<T, D>(p, qkv, p.ld, p.k_off + hc, origin, Ks);
+        __syncthreads();
+        const float* dsb = p.ds_scratch + (int64_t)wh * p.npad * p.npad;
+        for (int strip = wave; strip < nstrips; strip += (int)(blockDim.x >> 6))
+            fl_dq_from_ds_resident<T, D, 1>(p, Ks, dsb, strip, origin, hc, lr, lg);
+    }
 }
 
 __global__ void flash_dbias_final_kernel(const float* __restrict__ rows, int nrows, int W, float* __restrict__ dbias) {
@@ -756,8 +815,7 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     do {                                                                                                      \
         if (p.dbias) hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, true, R_, true>), grid, block, lds_kv, s, p); \
         else hipLaunchKernelGGL((flash_bwd_dkv_kernel<T_, D_, false, R_, true>), grid, block, lds_kv, s, p);  \
-        if (R_) hipLaunchKernelGGL((flash_bwd_dq_ds_kernel<T_, D_, R_, 2>), grid, dim3(64 * ((p.npad / 16 + 1) / 2)), lds_k, s, p); \
-        else hipLaunchKernelGGL((flash_bwd_dq_ds_kernel<T_, D_, R_, 1>), grid, block, lds_k, s, p);           \
+        if (!R_) hipLaunchKernelGGL((flash_bwd_dq_ds_kernel<T_, D_, false, 1>), grid, block, lds_k, s, p);    /* (resident form: second phase of the kernel above) */ \
     } while (0)
 #define GG_FL_BWD2(T_, D_, R_)                                                                                \
     do {                                                                                                      \
