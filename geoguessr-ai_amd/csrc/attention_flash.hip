@@ -801,7 +801,8 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     GG_CHECK(a->dout && a->dqkv && (a->lddo & 3) == 0 && ((uintptr_t)a->dout & 15) == 0 && ((uintptr_t)a->dqkv & 15) == 0,
              "gg_attention_flash_bwd: bad dout/dqkv");
     GG_CHECK(a->lse && a->out && (a->ldo & 3) == 0, "gg_attention_flash_bwd: needs the forward's lse and out");
-    const bool res = flash_resident(p, a->head_dim, p.dbias != nullptr);
+    // resident form also for single-tile windows (7 x 7) when a dS scratch is there: the dQ phase then runs inside the dK/dV kernel
+    const bool res = flash_resident(p, a->head_dim, p.dbias != nullptr) || (p.ds_scratch != nullptr && p.ntile == 1);
     const dim3 grid((unsigned)(a->num_windows * a->num_heads * (res ? 1 : p.ntile))), block(res ? 64 * std::min(16, p.npad / 16) : 256);
     const int R = res ? p.npad : 64;
     const size_t lds_q = flash_lds_fwd(p, a->head_dim, R), lds_kv = flash_lds_dkv(p, a->head_dim, R, p.dbias != nullptr);
