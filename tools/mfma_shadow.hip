@@ -14,6 +14,9 @@ __global__ __launch_bounds__(256) void shadow(float* out, unsigned long long* cy
     float v[8];
     for (int i = 0; i < 8; ++i) v[i] = a + i;
     f32x4 w = {a, b, a, b};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 pv[4], pw = {b, a};
+    for (int i = 0; i < 4; ++i) pv[i] = (f32x2){a + i, b + i};
     const unsigned addr = threadIdx.x * 16;
     float* dst = out + (size_t)blockIdx.x * 256 * 64 + threadIdx.x * 4;
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -24,16 +27,19 @@ __global__ __launch_bounds__(256) void shadow(float* out, unsigned long long* cy
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[(i * K + k) & 7]) : "v"(b), "v"(a));
+                else if (KIND == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pv[(i * K + k) & 3]) : "v"(pw));
+                else if (KIND == 4) asm volatile("v_exp_f32 %0, %0" : "+v"(v[(i * K + k) & 7]));
                 else if (KIND == 1) { f32x4 r; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(((0 * 16) & 0xFFF))); }
                 else asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(w) : "memory");
             }
         }
-        if (KIND) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (KIND == 1 || KIND == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     float s = w[0];
     for (int i = 0; i < 16; ++i) s += acc[i][0];
     for (int i = 0; i < 8; ++i) s += v[i];
+    for (int i = 0; i < 4; ++i) s += pv[i].x + pv[i].y;
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
@@ -55,5 +61,7 @@ int main() {
     run<6, 0>(out, cyc, "v_fma_f32"); run<8, 0>(out, cyc, "v_fma_f32"); run<12, 0>(out, cyc, "v_fma_f32");
     run<1, 1>(out, cyc, "ds_read_b128"); run<2, 1>(out, cyc, "ds_read_b128"); run<4, 1>(out, cyc, "ds_read_b128");
     run<1, 2>(out, cyc, "global_store_dwordx4"); run<2, 2>(out, cyc, "global_store_dwordx4");
+    run<1, 3>(out, cyc, "v_pk_fma_f32"); run<2, 3>(out, cyc, "v_pk_fma_f32"); run<4, 3>(out, cyc, "v_pk_fma_f32");
+    run<1, 4>(out, cyc, "v_exp_f32"); run<2, 4>(out, cyc, "v_exp_f32");
     return 0;
 }
