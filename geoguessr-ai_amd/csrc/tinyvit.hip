@@ -321,7 +321,7 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
                 const int nw = B * (st.res / st.ws) * (st.res / st.ws);
                 dsmax = std::max(dsmax, gg_attention_flash_ds_scratch_floats(nw, st.heads, st.ws * st.ws) * 4);
             }
-            L.attn_ds = p.alloc("scratch.attn_ds", dsmax, false);
+            if (dsmax <= ((int64_t)4 << 30)) L.attn_ds = p.alloc("scratch.attn_ds", dsmax, false);      // (32 x 32 windows of the 512-pixel models: 50 MB per image -- both passes recompute instead)
         }
         int64_t fold = (int64_t)d[0] * 2 * mid;
         for (int s = 0; s < 3; ++s) fold = std::max(fold, (int64_t)(s == 0 ? d[0] : m.stages[s - 1].C) * 2 * m.stages[s].C);
