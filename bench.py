@@ -46,32 +46,82 @@ MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0}      # MI355X_MICROARCH.md: dense
 HBM_PEAK_GBS = 8000.0
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
-    """Oracle train step (TinyViT-21M-224 + head, reference freeze policy) on the host cores."""
+def host_cpu():
+    """(logical CPUs the process may use, CPU model string) of this host -- read from /proc, no subprocess."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    return usable, model
+
+
+def cpu_baseline(seconds_budget: float = 14.0):
+    """BASELINE.md section 3, the c2-shaped micro-batch: the CPU oracle's identical step (TinyViT-21M-224 + 12 647-cell head, 8 panoramas =
+    32 images, forward + backward + AdamW, smooth-label loss, reference freeze policy, seed 1234) on the host cores: a multi-thread figure
+    (the headline `value`) and a 1-thread figure on a quarter of the micro-batch, both bounded in wall time.  `cores` = worker threads used
+    (torch intra-op pool); `host_cpus` / `cpu_model` say what the box offers."""
     import torch
-    from oracle import step_ref as S, tinyvit_ref as R
+    from oracle import step_ref as S, tinyvit_ref as R, geo_ref as G
     import numpy as np
+    usable, cpu_model = host_cpu()
     # torch's intra-op pool degrades badly when oversubscribed with the many small ops of a 224-px ViT step
-    # (256 threads: 169 s/step on the GPU box; 8/16/32/64 threads: 10.7/11.3/8.3/4.4 images/s): use 16 worker threads and report that number as `cores`
-    cores = min(os.cpu_count() or 1, int(os.environ.get("GG_CPU_THREADS", "16")))
-    torch.set_num_threads(cores)
+    # (measured on a 256-CPU GPU-box host: 256 threads 169 s/step; 8/16/32/64 threads: 10.7/11.3/8.3/4.4 images/s): 16 worker threads, stated next
+    # to the number of CPUs the box has
+    cores = max(1, min(usable, int(os.environ.get("GG_CPU_THREADS", "16"))))
     cfg = R.config_for("tiny_vit_21m_224", drop_path_rate=0.0)
     st = R.init_state(cfg, 0)
     cent = torch.from_numpy(np.load(os.path.join(ROOT, "geoguessr-ai_amd", "data", "centroids_12647x2_f32.npy")))
     g = torch.Generator().manual_seed(1234)
-    n = 4
+    n = 8
     x = torch.randn(n, 4, 3, 224, 224, generator=g)
     labels = torch.stack([torch.rand(n, generator=g) * 360 - 180, torch.rand(n, generator=g) * 180 - 90], 1)
     W, b = torch.randn(12647, 576, generator=g) * 0.02, torch.zeros(12647)
     trainable = [k for k in st if k.startswith(("patch_embed", "stages.3", "head")) and "running" not in k and "num_batches" not in k]
-    S.train_step(cfg, st, W, b, cent, x, labels, trainable=trainable)       # warm-up
-    t0, steps = time.time(), 0
-    while steps < 1 or (time.time() - t0) < seconds_budget:
-        S.train_step(cfg, st, W, b, cent, x, labels, trainable=trainable)
-        steps += 1
-    dt = time.time() - t0
-    return dict(value=round(steps * n * 4 / dt, 3), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{steps} oracle train steps (fwd+bwd, torch fp32) of {n} panoramas = {n * 4} images, TinyViT-21M-224 + 12647-cell head, {dt:.1f} s")
+    params = {k: st[k] for k in trainable}
+    params["cell_layer.weight"], params["cell_layer.bias"] = W, b
+    mom = {k: (torch.zeros_like(t), torch.zeros_like(t)) for k, t in params.items()}
+    count = [0]
+
+    def step(nn):
+        out = S.train_step(cfg, st, W, b, cent, x[:nn], labels[:nn], trainable=trainable)
+        count[0] += 1
+        with torch.no_grad():            # AdamW (main_coordinator_idun_s3.py:286-291): lr 5e-5, betas (.9, .999), wd .01 -- oracle/geo_ref.adamw_step
+            for k, t in params.items():
+                gk = out["grads"].get(k)
+                if gk is None:
+                    continue
+                m, v = mom[k]
+                pn, mn_, vn = G.adamw_step(t.numpy(), gk.numpy(), m.numpy(), v.numpy(), count[0], 5e-5)
+                t.copy_(torch.from_numpy(np.ascontiguousarray(pn))); m.copy_(torch.from_numpy(np.ascontiguousarray(mn_))); v.copy_(torch.from_numpy(np.ascontiguousarray(vn)))
+
+    def timed(nn, budget, min_steps):
+        step(nn)                                                             # warm-up
+        ts = []
+        t0 = time.time()
+        while len(ts) < min_steps or (time.time() - t0) < budget:
+            t1 = time.time(); step(nn); ts.append(time.time() - t1)
+        return float(np.median(ts)), len(ts), time.time() - t0
+
+    torch.set_num_threads(cores)
+    med, steps, dt = timed(n, seconds_budget, 2)
+    n1 = 2
+    torch.set_num_threads(1)
+    med1, steps1, dt1 = timed(n1, 0.0, 1)
+    torch.set_num_threads(cores)
+    return dict(value=round(n * 4 / med, 3), unit="images/s", cores=cores, kind="port", host_cpus=os.cpu_count(), usable_cpus=usable, cpu_model=cpu_model,
+                one_thread=dict(value=round(n1 * 4 / med1, 3), unit="images/s", cores=1,
+                                sample=f"1 warm-up + {steps1} timed step(s) of {n1} panoramas = {n1 * 4} images, {dt1:.1f} s"),
+                sample=f"1 warm-up + {steps} timed oracle train steps (fwd+bwd+AdamW, torch fp32, median) of {n} panoramas = {n * 4} images, "
+                       f"TinyViT-21M-224 + 12647-cell head, reference freeze policy, {cores} threads on a host with {os.cpu_count()} CPUs ({cpu_model}), {dt:.1f} s")
 
 
 def clock_under_gemm_load(dev):
@@ -103,9 +153,9 @@ def pmc_traffic(precision):
     """HBM bytes per GEMM launch from the committed rocprofv3 PMC passes of this command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate
     runs; tools/profile_round.sh + tools/pmc_traffic.py).  PMC collection cannot run inside the timed process, so this is the offline
     measurement of the same workload.  The file records the sha256 of the kernel sources it was measured on: when the running tree differs the
-    figure is still reported but marked ``stale``.  -> (bytes or None, info dict)."""
+    figure is still reported but marked ``stale``.  -> (bytes or None, info dict, per-class table or None)."""
     from geoguessr_ai_amd import _lib as L
-    names = [f"r03_hbm_traffic_pmc_{precision}.json", f"r02_hbm_traffic_pmc_{precision}.json"] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
+    names = [f"r{r:02d}_hbm_traffic_pmc_{precision}.json" for r in (4, 3, 2)] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -115,20 +165,161 @@ def pmc_traffic(precision):
             continue
         prof_hash = d.get("source_hash")
         return val, dict(file="profiles/" + name, git_head=d.get("git_head"), source_hash=prof_hash,
-                         stale=(prof_hash is None or prof_hash != L.source_hash()))
-    return None, None
+                         stale=(prof_hash is None or prof_hash != L.source_hash())), d["per_kernel_class"]
+    return None, None, None
+
+
+# kernel class of the bench line -> rocprofv3 kernel classes of tools/pmc_traffic.py that make it up
+PMC_CLASSES = {"attention": ("attn",), "dwconv": ("dwconv",), "norm_elementwise": ("bn", "ln"), "data_movement": ("im2col", "col2im")}
+
+
+def class_rooflines(breakdown_raw, steps, precision, pmc_classes, pmc_info):
+    """One roofline-shaped object per non-GEMM kernel class (the GEMM class is the line's `roofline`): attention against the MFMA peak of the mode
+    on its ALGORITHMIC flops (4 N^2 D forward, 10 N^2 D backward per window and head), the streaming classes against 8 TB/s on their algorithmic
+    bytes; `traffic` = PMC HBM bytes per step of the class (same hash-checked file as `roofline.traffic`), `traffic_ratio` = traffic / algorithmic."""
+    out = {}
+    for name, (ms_, n_, fl_, by_) in breakdown_raw.items():
+        if name not in PMC_CLASSES or ms_ <= 0:
+            continue
+        traffic = None
+        if pmc_classes:
+            traffic = sum((pmc_classes.get(k, {}).get("fetch_GB_per_step", 0.0) + pmc_classes.get(k, {}).get("write_GB_per_step", 0.0)) for k in PMC_CLASSES[name]) * 1e9
+        alg_bytes_step = by_ / steps
+        if name == "attention":
+            ach = fl_ / ms_ / 1e9
+            o = dict(bound="mfma", achieved=round(ach, 2), peak=MFMA_PEAK_TF[precision], unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TF[precision], 4),
+                     algorithmic_gflop_per_step=round(fl_ / steps / 1e9, 1))
+        else:
+            ach = by_ / ms_ / 1e6
+            o = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+        o.update(ms_per_step=round(ms_ / steps, 3), launches_per_step=n_ // steps, algorithmic_bytes_per_step=int(alg_bytes_step),
+                 traffic=(int(traffic) if traffic else None), traffic_ratio=(round(traffic / alg_bytes_step, 3) if traffic and alg_bytes_step else None),
+                 traffic_stale=(pmc_info or {}).get("stale"))
+        out[name] = o
+    return out
+
+
+def secondary_cases(dev, budget_s=15.0):
+    """BASELINE.json configs other than the headline, timed in the same process on the same device with the protocol of tools/bench_secondary.py
+    (W warm-up calls, K timed calls between synchronisations), bounded to ~`budget_s` seconds in total:
+      c1  TinyViT-5M-224, batch 8 single images, forward + geocell hard-CE + backward + AdamW (fp32)
+      c4  CLIP ViT-B/32 vision tower inference, batch 1024, fp32 (the reference's precision) and fp16 (BASELINE's), mean over all 50 tokens
+      c5  SuperGuessr serving head + ProtoRefiner on precomputed (4096, 4, 576) embeddings (this rank's shard of the 8-GPU config: no exchange)"""
+    import numpy as np
+    import torch
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
+    from geoguessr_ai_amd.optim import AdamW
+    t_start = time.perf_counter()
+    out = {}
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    def cleanup():
+        gc.collect(); torch.cuda.empty_cache()
+
+    try:
+        torch.manual_seed(0)
+        base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, precision="fp32")
+        model = SuperGuessr(base, panorama=False, should_smooth_labels=False, serving=False).to(dev).train()
+        opt = AdamW(model, lr=5e-5, betas=(0.9, 0.999), weight_decay=0.01)
+        g = torch.Generator(device=dev).manual_seed(330)
+        x = torch.randn(8, 3, 224, 224, device=dev, generator=g)
+        lab = torch.stack([torch.rand(8, device=dev, generator=g) * 360 - 180, torch.rand(8, device=dev, generator=g) * 180 - 90], 1)
+        clf = torch.randint(0, model.num_cells, (8,), device=dev, generator=g)
+
+        def c1():
+            o = model(pixel_values=x, labels=lab, labels_clf=clf)
+            o.loss.backward(); opt.step(); opt.zero_grad()
+        dt = timed(c1, 20, 5)
+        out["c1"] = dict(workload="tiny_vit_5m_224, batch 8 single images, fwd + hard-CE + bwd + AdamW", dtype="fp32", ms_per_step=round(dt * 1e3, 3), images_per_s=round(8 / dt, 1))
+        del model, base, opt, x
+        cleanup()
+        for prec in ("fp32", "fp16"):
+            tower = CLIPVisionTower("openai/clip-vit-base-patch32", precision=prec).to(dev).eval()
+            for p_ in tower.parameters():
+                p_.requires_grad = False
+            xc = torch.randn(1024, 3, 224, 224, device=dev)
+            with torch.no_grad():
+                dt = timed(lambda: tower(pixel_values=xc, return_last_hidden=False), 5 if prec == "fp32" else 10, 2)
+            peak = 157.3 if prec == "fp32" else 2500.0
+            tf = 1024 / dt * 8.82e9 / 1e12
+            out["c4_" + prec] = dict(workload="CLIP ViT-B/32 vision tower inference (random weights), batch 1024", dtype=prec, ms_per_step=round(dt * 1e3, 3),
+                                     images_per_s=round(1024 / dt, 1), tflops=round(tf, 1), frac_of_mfma_peak=round(tf / peak, 4))
+            del tower, xc
+            cleanup()
+        Bq, D = 4096, 576
+        head = SuperGuessr(None, panorama=True, serving=True, embed_dim=D, precision="fp32").to(dev).eval()
+        K = head.num_cells
+        rng = np.random.default_rng(0)
+        counts = rng.poisson(4.0, K)
+        gi = np.repeat(np.arange(K), counts)
+        refiner = ProtoRefiner.from_clusters(gi, rng.standard_normal((len(gi), D), dtype=np.float32), rng.uniform(-180, 180, len(gi)).astype(np.float32),
+                                             rng.uniform(-90, 90, len(gi)).astype(np.float32), K, topk=5).to(dev).eval()
+        emb = torch.randn(Bq, 4, D, device=dev)
+
+        def c5():
+            with torch.no_grad():
+                llh, topk, e = head(embedding=emb)
+                refiner(e, llh, topk.indices, topk.values)
+        dt = timed(c5, 10, 3)
+        out["c5"] = dict(workload="SuperGuessr serving head (576 -> 12647, softmax, top-5) + ProtoRefiner on precomputed embeddings, batch 4096 per GPU", dtype="fp32",
+                         prototypes=int(len(gi)), ms_per_step=round(dt * 1e3, 3), samples_per_s=round(Bq / dt, 1))
+        del head, refiner, emb
+        cleanup()
+    except Exception as e:           # the secondary block must never cost the headline line
+        out["error"] = f"{type(e).__name__}: {e}"
+    out["seconds"] = round(time.perf_counter() - t_start, 1)
+    return out
+
+
+def count_gpus_without_runtime():
+    """GPUs this process would see, counted WITHOUT loading the HIP / HSA runtime (torch.cuda.device_count() falls back to hipGetDeviceCount on
+    builds without amdsmi): KFD topology nodes with a non-zero simd_count are GPUs; HIP_/ROCR_VISIBLE_DEVICES narrow the set.  None = unknown."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir(base):
+        return 0                                  # no amdgpu compute driver on this host
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split(None, 1) for ln in f if " " in ln)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
 
 
 def self_launch(args) -> int:
     """``python bench.py --gpus N`` (N > 1) without a launcher in front: start the driver's own launch line
     (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...``) as a CHILD
-    process, relay rank 0's JSON line and return the child's exit code.  This process never initialises the GPU (counting devices does not),
-    and it is a fork + wait, not an exec.  Fails loudly when the box has fewer than N GPUs -- an N-GPU number must come from N devices."""
+    process group, relay rank 0's JSON line and return the child's exit code.  This process never loads the HIP runtime (devices are counted
+    from the KFD topology in sysfs), and the launch is a spawn + wait, never an exec.  Fails loudly when the box has fewer than N GPUs -- an
+    N-GPU number must come from N devices -- and when the ranks have not finished within GG_BENCH_LAUNCH_TIMEOUT seconds (default 480: a
+    hung RCCL bootstrap must not sit silently until the caller's own limit): the child's process group is then killed and the tail of its
+    stderr printed."""
+    import collections
+    import signal
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()
-    if have < args.gpus and not os.environ.get("GG_BENCH_ONE_DEVICE"):
+    import threading
+    have = count_gpus_without_runtime()
+    if have is not None and have < args.gpus and not os.environ.get("GG_BENCH_ONE_DEVICE"):
         print(f"bench.py: --gpus {args.gpus} requested but this machine exposes {have} GPU(s); refusing to report an {args.gpus}-GPU number "
               f"from fewer devices (GG_BENCH_ONE_DEVICE=1 GG_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU)", file=sys.stderr)
         return 2
@@ -136,20 +327,52 @@ def self_launch(args) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
+    # multi-process GPU work on this image: the host driver only supports dmabuf IPC, and without this RCCL's peer-memory registration
+    # fails with `hipIpcGetMemHandle: invalid argument` (already exported on the driver's boxes; set here for a bare shell)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    limit = float(os.environ.get("GG_BENCH_LAUNCH_TIMEOUT", "480"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     print("bench.py: starting " + " ".join(cmd), file=sys.stderr)
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
-    lines = 0
-    for line in proc.stdout:                 # rank 0 prints exactly one JSON line; anything else on stdout goes to our stderr
-        if line.startswith("{") and '"metric"' in line:
-            sys.stdout.write(line); sys.stdout.flush(); lines += 1
-        else:
-            sys.stderr.write(line)
-    rc = proc.wait()
-    if rc == 0 and lines != 1:
-        print(f"bench.py: the {args.gpus}-rank run printed {lines} result lines instead of 1", file=sys.stderr)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, start_new_session=True)
+    err_tail = collections.deque(maxlen=40)
+    lines = [0]
+
+    def pump_err():
+        for ln in proc.stderr:
+            err_tail.append(ln); sys.stderr.write(ln)
+
+    def pump_out():
+        for ln in proc.stdout:                 # rank 0 prints exactly one JSON line; anything else on stdout goes to our stderr
+            if ln.startswith("{") and '"metric"' in ln:
+                sys.stdout.write(ln); sys.stdout.flush(); lines[0] += 1
+            else:
+                sys.stderr.write(ln)
+
+    threads = [threading.Thread(target=pump_err, daemon=True), threading.Thread(target=pump_out, daemon=True)]
+    for t in threads:
+        t.start()
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGTERM)          # the session we started: torchrun + its ranks, nothing else
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+        except ProcessLookupError:
+            pass
+        for t in threads:
+            t.join(timeout=2)
+        print(f"bench.py: the {args.gpus}-rank run did not finish within {limit:.0f} s (GG_BENCH_LAUNCH_TIMEOUT) and was killed; last stderr lines of the ranks:\n"
+              + "".join(err_tail), file=sys.stderr)
+        return 4
+    for t in threads:
+        t.join(timeout=5)
+    if rc == 0 and lines[0] != 1:
+        print(f"bench.py: the {args.gpus}-rank run printed {lines[0]} result lines instead of 1", file=sys.stderr)
         return 3
     return rc
 
@@ -177,6 +400,7 @@ def allreduce_cost(opt, dev, world, reps=5):
     ms = float(t.item())
     # ring all-reduce moves 2 (n-1)/n of the payload per rank
     return dict(allreduce_ms_per_step=round(ms, 3), allreduce_bytes_per_step=nbytes, allreduce_buckets=len(bufs),
+                allreduce_bucket_bytes=[b.numel() * b.element_size() for b in bufs],
                 allreduce_busbw_gbps=round(2 * (world - 1) / world * nbytes / max(ms, 1e-9) / 1e6, 1))
 
 
@@ -263,7 +487,8 @@ def run_mode(precision, args, rank, world, dev, x, lab):
         intensity = fl_ / max(by_, 1.0)
         kern = ("gemm_nt_f32_ring_kernel (LDS-DMA ring, single-buffer form; + gemm_tn_f32_kernel weight gradients)" if precision == "fp32"
                 else "gemm_nt_kernel (+ gemm_tn_kernel weight gradients)")
-        traffic, traffic_info = pmc_traffic(precision)
+        traffic, traffic_info, pmc_classes = pmc_traffic(precision)
+        res["class_rooflines"] = class_rooflines({name: tot[c] for c, name in enumerate(CATS)}, args.steps, precision, pmc_classes, traffic_info)
         common = dict(kernel=kern, traffic=traffic, traffic_source=traffic_info, launches=n_ // args.steps, avg_launch_us=round(1e3 * ms_ / max(n_, 1), 2),
                       gemm_ms_per_step=round(ms_ / args.steps, 3), algorithmic_gflop_per_launch=round(fl_ / max(n_, 1) / 1e9, 3),
                       algorithmic_bytes_per_launch=int(by_ / max(n_, 1)), flop_per_byte=round(intensity, 1),
@@ -302,6 +527,7 @@ def main():
     ap.add_argument("--unfrozen", action="store_true", help="train every parameter instead of the reference freeze policy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the c1 / c4 / c5 secondary timings (N = 1 only, ~15 s)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -347,6 +573,11 @@ def main():
     results = {m: run_mode(m, args, rank, world, dev, x, lab) for m in modes}
     head = results[modes[0]]
 
+    secondary = None
+    if rank == 0 and world == 1 and not args.no_secondary:
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):       # the shims print like the reference does; stdout carries the one JSON line only
+            secondary = secondary_cases(dev)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -361,9 +592,11 @@ def main():
                                 precision=modes[0]),
                     rccl_ranks=rccl_ranks, comm_backend=(backend if world > 1 else None),
                     allreduce_ms_per_step=head.get("allreduce_ms_per_step"), allreduce_bytes_per_step=head.get("allreduce_bytes_per_step"),
-                    allreduce_busbw_gbps=head.get("allreduce_busbw_gbps"),
+                    allreduce_busbw_gbps=head.get("allreduce_busbw_gbps"), allreduce_buckets=head.get("allreduce_buckets"),
+                    allreduce_bucket_bytes=head.get("allreduce_bucket_bytes"),
                     step_tflops=head["step_tflops"], step_frac_of_mfma_peak=head["step_frac_of_mfma_peak"], loss=head["loss"],
-                    roofline=head.get("roofline"), cpu_baseline=cpu, kernel_breakdown=head.get("kernel_breakdown"))
+                    roofline=head.get("roofline"), cpu_baseline=cpu, class_rooflines=head.get("class_rooflines"),
+                    kernel_breakdown=head.get("kernel_breakdown"), secondary=secondary)
         for m in modes[1:]:
             line[m] = dict(dtype=m, **results[m])
         print(json.dumps(line))

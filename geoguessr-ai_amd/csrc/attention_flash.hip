@@ -808,7 +808,8 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     const size_t lds_q = flash_lds_fwd(p, a->head_dim, R), lds_kv = flash_lds_dkv(p, a->head_dim, R, p.dbias != nullptr);
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype ? 4.0 : 2.0;
-    GG_PROF(GG_CAT_ATTN, 14.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
+    // algorithmic: 5 products (S, dP, dV, dK, dQ) = 10 N^2 D, whatever the pass structure recomputes (attention.hip declares the same)
+    GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
             8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
     // with a dS scratch: dK/dV pass first (stores dS), then the one-product dQ pass
     const size_t lds_k = ((size_t)R * (a->head_dim + 4)) * 4;

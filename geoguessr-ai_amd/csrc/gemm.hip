@@ -814,7 +814,9 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
     // algorithmic bytes: A, B, C once each (bf16; f32 C = 4 bytes) plus every second tensor the epilogue reads or writes
     const double mn = (double)a->M * a->N;
-    GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * a->K,
+    // algorithmic flops: the two-source dgrad (A2) contracts [dz | y] against the folded [c0 W ; c1 W] weights -- a doubled K that exists only
+    // because the BatchNorm-backward apply step was folded into the MFMA; the algorithm's contraction is k_split long (what the fp32 mode declares)
+    GG_PROF(GG_CAT_GEMM, 2.0 * a->M * (double)a->N * (a->A2 ? a->k_split : a->K),
             2.0 * ((double)a->M * a->K + (double)a->N * a->K) + ((a->out_f32 || split > 1) ? 4.0 : 2.0) * mn * std::max(1, split) +
                 2.0 * mn * ((a->preact != nullptr) + (a->residual != nullptr) + (a->dact_preact != nullptr) + (a->bn_y != nullptr)),
             stream);

@@ -234,3 +234,20 @@ def test_bench_refuses_more_gpus_than_the_machine_has():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1"], env=env, capture_output=True, text=True,
                        timeout=300, cwd=root)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_self_launch_kills_a_hung_child_within_its_limit():
+    """`python bench.py --gpus N` as its own launcher: when the ranks have not finished within GG_BENCH_LAUNCH_TIMEOUT the CHILD process group is
+    killed and the parent exits non-zero with a message (a hung RCCL bootstrap must not sit until the caller's limit and print nothing).  Here the
+    limit is far below the ranks' import time, so the timeout path runs whatever the ranks would have done next."""
+    import subprocess, sys, time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(GG_BENCH_ONE_DEVICE="1", GG_DIST_BACKEND="gloo", GG_BENCH_LAUNCH_TIMEOUT="0.5")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--panoramas", "1"], env=env,
+                       capture_output=True, text=True, timeout=120, cwd=root)
+    assert r.returncode == 4, (r.returncode, r.stderr[-2000:])
+    assert "did not finish within" in r.stderr and "was killed" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert time.time() - t0 < 60

@@ -135,3 +135,28 @@ def test_fullsize_clip_embeddings_are_per_sample():
         small = getattr(small, "last_hidden_state", small)
     assert torch.isfinite(full).all()
     assert torch.allclose(full[idx], small, rtol=0, atol=1e-4), float((full[idx] - small).abs().max())
+
+
+def test_fullsize_clip_fp16_c4_embeddings_match_oracle_and_are_per_sample():
+    """BASELINE config c4 at its own size and precision: CLIP ViT-B/32 embedder, inference, batch 1024, fp16 storage + fp16 MFMA (GEMMs and
+    attention).  Size-independent properties: finite, a sample's embedding is the same inside the 1024-image batch and in a batch of 4; and the
+    same four samples against the pinned fp32 oracle (pretrain/clip_embedder.py:63-65: mean over all 50 tokens) at the fp16 tolerance 3e-3."""
+    from geoguessr_ai_amd.pretrain.clip_embedder import CLIPVisionTower
+    from oracle import clip_ref as CR
+    tower = CLIPVisionTower("openai/clip-vit-base-patch32", precision="fp16").cuda().eval()
+    assert tower.precision == "fp16"
+    g = torch.Generator(device="cuda").manual_seed(22)
+    x = torch.randn(1024, 3, 224, 224, device="cuda", generator=g)
+    idx = torch.tensor([0, 3, 512, 1023], device="cuda")
+    with torch.no_grad():
+        full = tower(pixel_values=x, return_last_hidden=False).pooled_mean.float()
+        small = tower(pixel_values=x[idx].contiguous(), return_last_hidden=False).pooled_mean.float()
+    assert full.shape == (1024, 768) and torch.isfinite(full).all()
+    assert torch.allclose(full[idx], small, rtol=0, atol=2e-3), float((full[idx] - small).abs().max())
+    st = {k: v.detach().cpu().clone() for k, v in tower.named_views().items()}
+    with torch.no_grad():
+        ref = CR.forward(CR.ClipVisionConfig(), st, x[idx].cpu())
+    got = full[idx].cpu()
+    rel = float((got - ref).norm() / ref.norm())
+    print(f"\n[c4 fp16, batch 1024] pooled embedding rel-L2 vs fp32 oracle {rel:.2e}, max abs {float((got - ref).abs().max()):.2e}")
+    assert rel < 3e-3

@@ -747,6 +747,32 @@ def test_proto_refine_within_cluster_matches_oracle():
     np.testing.assert_allclose(ref.member_emb.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
 
 
+def test_proto_refine_matches_reference_forward_golden(golden_dir):
+    """``gg_proto_refine`` against the REFERENCE's own ``ProtoRefiner.forward`` run (tests/golden/proto_refine.npz, made by make_golden_r4.py):
+    centroid branch and member branch, missing-prototype sentinel (incl. the all-missing sample), 1000 km gate, 40-prototype cell, (B, 4, D)
+    embeddings, ``candidate_probs=None``.  Geocells and winning slots identical, coordinates equal to float32 rounding of the stored table."""
+    from geoguessr_ai_amd.models.proto_refiner import ProtoRefiner
+    z = np.load(os.path.join(golden_dir, "proto_refine.npz"))
+    for case in ("centroid", "member"):
+        g = {k.split("__", 1)[1]: z[k] for k in z.files if k.startswith(case + "__")}
+        counts = np.diff(g["cell_ptr"])
+        gi = np.repeat(np.arange(len(counts)), counts)
+        kw = {}
+        if case == "member":
+            kw = dict(member_ptr=g["member_ptr"], member_emb=g["member_emb4"], member_lnglat=g["member_lnglat"])
+        ref = ProtoRefiner.from_clusters(gi, g["proto_emb"], g["proto_lnglat"][:, 0], g["proto_lnglat"][:, 1], len(counts), topk=5,
+                                         max_refinement=1000, temperature=1.6, **kw).cuda().eval()
+        t = lambda k: torch.from_numpy(g[k])
+        loss, llh, cell = ref(t("embedding"), t("initial_preds"), t("candidate_cells"), t("candidate_probs"))
+        assert loss is None
+        np.testing.assert_array_equal(cell.cpu().numpy(), g["preds_geocell"])
+        np.testing.assert_array_equal(ref.last_guess_index.cpu().numpy(), g["guess_index"])
+        np.testing.assert_allclose(llh.cpu().numpy(), g["preds_LLH"], rtol=0, atol=1e-5)
+        _, llh0, cell0 = ref(t("embedding").mean(dim=1), t("initial_preds"), t("candidate_cells"), None)
+        np.testing.assert_array_equal(cell0.cpu().numpy(), g["preds_geocell_noprobs"])
+        np.testing.assert_allclose(llh0.cpu().numpy(), g["preds_LLH_noprobs"], rtol=0, atol=1e-5)
+
+
 def test_scoring_matches_reference_golden(ops, golden_dir):
     """gg_geoguessr_score against run_benchmark.py:25-65 executed by tests/golden/make_golden_r2.py: fp64 distances, INTEGER scores
     (clamp + round-half-even) bit-exact."""

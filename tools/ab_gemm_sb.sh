@@ -10,5 +10,5 @@ for cfg in "" "GG_GEMM_F32_SB=0" "GG_GEMM_F32_DEBUG=128" "GG_GEMM_F32_PRO_RING=0
 done
 for cfg in "" "GG_GEMM_F32_SB=0" "GG_GEMM_F32_DEBUG=128"; do
   echo "== step ${cfg:-default}"
-  env $cfg timeout -k 10 300 python bench.py --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c1-200
+  env $cfg timeout -k 10 300 python bench.py --precision fp32 --steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline 2>&1 | tail -1 | cut -c1-200
 done

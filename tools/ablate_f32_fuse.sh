@@ -1,6 +1,6 @@
 # fp32-mode schedule ablation: step time with each BatchNorm fusion family switched off (run on the GPU box)
 cd $GRAFT_REPO_ROOT
-B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --precision fp32"
+B="python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary --precision fp32"
 run() { echo "== $1"; env $2 timeout -k 10 200 $B 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['kernel_breakdown']

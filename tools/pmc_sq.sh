@@ -3,7 +3,7 @@ R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp; cd $R
 rm -rf gpurun_out/pmc_sq
 ( while true; do sleep 60; echo "[pmc_sq] still running" ; done ) &
 HB=$!
-timeout -k 10 380 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES -d $R/gpurun_out/pmc_sq -o s --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --precision fp32 > gpurun_out/pmc_sq.log 2>&1
+timeout -k 10 380 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_BUSY_CYCLES -d $R/gpurun_out/pmc_sq -o s --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline --precision fp32 > gpurun_out/pmc_sq.log 2>&1
 kill $HB
 F=$(find gpurun_out/pmc_sq -name "*counter_collection.csv" | head -1)
 python3 - "$F" > gpurun_out/pmc_sq.txt <<'PY'
