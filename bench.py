@@ -285,24 +285,36 @@ def secondary_cases(dev, budget_s=15.0):
 
 def count_gpus_without_runtime():
     """GPUs this process would see, counted WITHOUT loading the HIP / HSA runtime (torch.cuda.device_count() falls back to hipGetDeviceCount on
-    builds without amdsmi): KFD topology nodes with a non-zero simd_count are GPUs; HIP_/ROCR_VISIBLE_DEVICES narrow the set.  None = unknown."""
+    builds without amdsmi): readable KFD topology nodes with a non-zero simd_count; HIP_/ROCR_VISIBLE_DEVICES
+    narrow the set.  None = unknown."""
     base = "/sys/class/kfd/kfd/topology/nodes"
     if not os.path.isdir(base):
         return 0                                  # no amdgpu compute driver on this host
+    n, unknown = 0, False
     try:
-        n = 0
-        for node in os.listdir(base):
+        nodes = os.listdir(base)
+    except OSError:
+        nodes, unknown = [], True
+    for node in nodes:
+        try:
             with open(os.path.join(base, node, "properties")) as f:
                 props = dict(ln.split(None, 1) for ln in f if " " in ln)
-            if int(props.get("simd_count", "0")) > 0:
-                n += 1
-    except (OSError, ValueError):
-        return None
+            if int(props.get("simd_count", "0").strip() or 0) <= 0:
+                continue                          # a CPU node
+            n += 1
+        except PermissionError:
+            continue                              # a GPU of the host this container was not given (its topology node is unreadable)
+        except (OSError, ValueError):
+            unknown = True                        # cannot tell
+    vis = None
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:
-            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
-    return n
+            k = len([t for t in v.split(",") if t.strip() != ""])
+            vis = k if vis is None else min(vis, k)
+    if unknown and n == 0:
+        return vis                                # None when nothing narrows it either
+    return n if vis is None else min(n, vis)
 
 
 def self_launch(args) -> int:

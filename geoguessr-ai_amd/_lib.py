@@ -136,6 +136,7 @@ SIGNATURES = {
     "gg_attention_flash_bwd": (_I, [C.POINTER(AttnArgs), _I, _P]),
     "gg_attention_flash_dbias_rows": (_L, [_I, _I]),
     "gg_attention_flash_ds_scratch_floats": (_L, [_I, _I, _I]),
+    "gg_attention_flash_single_pass": (_I, [_I, _I, _I, _I]),
     "gg_gemm_nt_f32": (_I, [C.POINTER(GemmArgs), _P]),
     "gg_gemm_tn_f32_splits": (_I, [_I, _I, _I]),
     "gg_gemm_tn_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),

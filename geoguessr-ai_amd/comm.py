@@ -39,6 +39,10 @@ class NativeComm:
         self.stream = torch.cuda.Stream(device=self.device)
         self._pending = False
 
+    def accepts(self, t: torch.Tensor, any_dtype: bool = False) -> bool:
+        """Tensors this communicator carries itself (everything else goes through torch.distributed): contiguous device tensors, f32 for the sum."""
+        return t.is_cuda and t.is_contiguous() and (any_dtype or t.dtype == torch.float32)
+
     def _enter(self):
         self.stream.wait_stream(torch.cuda.current_stream(self.device))      # the collective sees everything enqueued on the compute stream so far
         self._pending = True

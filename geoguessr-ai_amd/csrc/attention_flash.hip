@@ -1225,6 +1225,12 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
     GG_LAUNCH_CHECK();
     return 0;
 }
+extern "C" int gg_attention_flash_single_pass(int tokens_per_window, int head_dim, int window_size, int with_dbias) {
+    FlashParams p{};
+    p.N = tokens_per_window; p.ws = window_size; p.npad = (int)gg_align(tokens_per_window, 16);
+    p.nbpad = (int)gg_align(std::max(4, (2 * window_size - 1) * (2 * window_size - 1)), 4);
+    return (head_dim == 32 || head_dim == 64) && flash_fused_ok(p, head_dim, with_dbias != 0) ? 1 : 0;
+}
 extern "C" int64_t gg_attention_flash_ds_scratch_floats(int num_windows, int num_heads, int tokens_per_window) {
     const int64_t npad = gg_align(tokens_per_window, 16);
     return (int64_t)num_windows * num_heads * npad * npad;

@@ -229,7 +229,7 @@ struct CPlan {
     int64_t s_x, s_a, s_qkv, s_o, s_h;                        // scratch of the layers that keep nothing (in-place residual stream)
     std::vector<LayerA> la;
     int64_t xfinal;
-    int64_t g_x0, g_x1, g_a, g_qkv, g_o, g_h, splitk, colsum, lnscr, attn_ds = -1;      // backward scratch (attn_ds: GgAttnArgs.ds_scratch)
+    int64_t g_x0, g_x1, g_a, g_qkv, g_o, g_h, splitk, colsum, lnscr, lndump, attn_ds = -1;      // lndump: where a frozen LayerNorm tensor's half of a (gamma, beta) gradient pair goes      // backward scratch (attn_ds: GgAttnArgs.ds_scratch)
     int64_t total;
 };
 static void plan(const CModel& m, int B, const Train& tr, bool training, CPlan& L) {
@@ -258,8 +258,12 @@ static void plan(const CModel& m, int B, const Train& tr, bool training, CPlan& 
         L.splitk = al(sk * 4);
         L.colsum = al(std::max(gg_colsum_scratch_floats((int)M, I), gg_colsum_scratch_floats((int)M, D)) * 4);
         L.lnscr = al(gg_layernorm_bwd_scratch_floats(M, D) * 4);
-        const int64_t dsb = gg_attention_flash_ds_scratch_floats(B, m.cfg.num_heads, m.T) * 4;   // dS hand-off between the two passes of the attention backward
-        if (dsb <= ((int64_t)4 << 30)) L.attn_ds = al(dsb);                                       // (577-token towers at large batches: both passes recompute instead)
+        L.lndump = al((int64_t)D * 4);
+        // dS hand-off between the two passes of the attention backward: only towers beyond 256 tokens (ViT-L/14-336: 577 tokens, 22 MB per image) use it -- the
+        // 50-token towers run the single-pass kernel --, and only while it stays at most 4 GB and 1/8 of the workspace planned so far
+        const int64_t dsb = gg_attention_flash_ds_scratch_floats(B, m.cfg.num_heads, m.T) * 4;
+        static const bool ds_off = gg_dev_env("GG_ATTN_NO_DS_SCRATCH") != nullptr;
+        if (!ds_off && !gg_attention_flash_single_pass(m.T, D / m.cfg.num_heads, 0, 0) && dsb <= ((int64_t)4 << 30) && dsb <= off / 8) L.attn_ds = al(dsb);
     }
     L.total = off;
 }
@@ -289,8 +293,10 @@ struct Exec {
     // dx = LayerNorm backward of dout (+ dres), dgamma / dbeta accumulated when trainable
     int ln_bwd(const void* dout, const void* x, const float* mean, const float* rstd, int tg, int tb, int64_t M, const void* dres, void* dx) const {
         const bool t = tr(tg) || tr(tb);
-        return gg_layernorm_bwd(dout, x, m->f32, mean, rstd, P(tg), M, m->cfg.hidden_size, dres, dx, F(L->lnscr), t ? Gd(tg) : nullptr, t ? Gd(tb) : nullptr,
-                                1, st);
+        // the kernel forms dgamma and dbeta together: when only one of the two is trainable, the other's sums are added to a dump row nobody reads, never into the frozen
+        // tensor's region of the flat gradient buffer (which the caller may be exchanging / reading as zeros)
+        return gg_layernorm_bwd(dout, x, m->f32, mean, rstd, P(tg), M, m->cfg.hidden_size, dres, dx, F(L->lnscr), t ? (tr(tg) ? Gd(tg) : F(L->lndump)) : nullptr,
+                                t ? (tr(tb) ? Gd(tb) : F(L->lndump)) : nullptr, 1, st);
     }
     // dW[N,K] += dY[M,N]^T . X[M,K]
     int wgrad(int tw, const void* dY, int64_t ldy, const void* X, int64_t ldx, int64_t M, int N, int K) const {

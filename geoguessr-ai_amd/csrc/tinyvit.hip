@@ -315,13 +315,16 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         L.colsum = p.alloc("scratch.colsum", std::max<int64_t>(csmax, 1024), false);
         L.splitk = p.alloc("scratch.splitk", (int64_t)128 << 20, false);      // gg_gemm_tn_f32_splits sizes its slabs against this
         if (m.f32) {     // dS hand-off between the two passes of the flash attention backward (GgAttnArgs.ds_scratch): the largest stage decides
+            // only windows beyond 256 tokens use it (the single-pass backward keeps dS on the CU), and only while it stays a small part of the workspace:
+            // at most 4 GB and 1/8 of what is planned so far (24 x 24 windows: 16 MB per image; 32 x 32: 50 MB per image -- there both passes recompute)
             int64_t dsmax = 0;
             for (int s = 1; s < 4; ++s) {
                 const auto& st = m.stages[s - 1];
                 const int nw = B * (st.res / st.ws) * (st.res / st.ws);
-                dsmax = std::max(dsmax, gg_attention_flash_ds_scratch_floats(nw, st.heads, st.ws * st.ws) * 4);
+                if (!gg_attention_flash_single_pass(st.ws * st.ws, 32, st.ws, 1))
+                    dsmax = std::max(dsmax, gg_attention_flash_ds_scratch_floats(nw, st.heads, st.ws * st.ws) * 4);
             }
-            if (dsmax <= ((int64_t)4 << 30)) L.attn_ds = p.alloc("scratch.attn_ds", dsmax, false);      // (32 x 32 windows of the 512-pixel models: 50 MB per image -- both passes recompute instead)
+            if (dsmax > 0 && dsmax <= ((int64_t)4 << 30) && dsmax <= p.total / 8) L.attn_ds = p.alloc("scratch.attn_ds", dsmax, false);
         }
         int64_t fold = (int64_t)d[0] * 2 * mid;
         for (int s = 0; s < 3; ++s) fold = std::max(fold, (int64_t)(s == 0 ? d[0] : m.stages[s - 1].C) * 2 * m.stages[s].C);
@@ -790,7 +793,8 @@ static int backward_impl(Exec& e, const float* d_out) {
             }
             // dx2 = LN2bwd(db) + dx                                   -> t_b
             // frozen block: the same kernel also leaves (sum dx2*x2, sum dx2) per column, all that local_conv's BatchNorm backward needs
-            const bool lncol = e.fuse_lncol && e.fuse_bnbwd && C <= 640 && !e.tr(l.local.w.t_w) && !e.tr(l.local.bn.t_g) && !e.tr(l.ln2.t_g);
+            const bool lncol = e.fuse_lncol && e.fuse_bnbwd && C <= 640 && !e.tr(l.local.w.t_w) && !e.tr(l.local.bn.t_g) && !e.tr(l.local.bn.t_b) &&
+                               !e.tr(l.ln2.t_g) && !e.tr(l.ln2.t_b);       // (the fused form produces no LayerNorm / BatchNorm parameter gradients: every one of them must be frozen)
             if (lncol) {
                 GG_TRY(gg_layernorm_bwd_colsum(t_a, e.A(a.x2), e.f32, e.F(a.mean2), e.F(a.rstd2), e.P(l.ln2.t_g), M, C, dx, t_b, e.F(L.lnscratch), e.st));
             } else {
@@ -1164,6 +1168,21 @@ extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const flo
     e.m = &m; e.L = &L; e.B = batch; e.training = true; e.params = params; e.buffers = nullptr; e.counters = nullptr;
     e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = grads;
     e.trainable = trainable; e.stage_done = stage_done; e.stage_user = stage_user;
+    if (trainable) {
+        // The schedule forms the two gradients of a (weight, bias) / (gamma, beta) pair together (BatchNorm / LayerNorm finalize kernels, the fused
+        // frozen-chain forms): a mask that trains one tensor of a pair and freezes the other has no schedule -- refuse it by name instead of silently
+        // leaving a gradient at zero.  (Every policy of the reference freezes whole modules: models/tinyvit.py:90-111.)
+        std::map<std::string, int> by_name;
+        for (size_t i = 0; i < m.tensors.size(); ++i) if (m.tensors[i].kind == GG_KIND_PARAM) by_name[m.tensors[i].name] = (int)i;
+        for (const auto& kv : by_name) {
+            const std::string& n = kv.first;
+            if (n.size() < 7 || n.compare(n.size() - 7, 7, ".weight") != 0) continue;
+            const auto it = by_name.find(n.substr(0, n.size() - 7) + ".bias");
+            if (it == by_name.end()) continue;
+            GG_CHECK((trainable[kv.second] != 0) == (trainable[it->second] != 0),
+                     "gg_tinyvit_backward: %s and %s must be trainable or frozen together (requires_grad differs within the pair)", n.c_str(), it->first.c_str());
+        }
+    }
     e.exec_init();
     return backward_impl(e, d_out);
 }

@@ -95,7 +95,7 @@ class AdamW:
 
     def _bcast(self, t: torch.Tensor, src: int):
         nc = self._native()
-        if nc is not None and t.is_cuda:
+        if nc is not None and nc.accepts(t, any_dtype=True):
             nc.broadcast_(t, src)
         else:
             dist.broadcast(t, src)
@@ -131,7 +131,7 @@ class AdamW:
         if key in self._inflight or tensor is None or tensor.numel() == 0:
             return
         nc = self._native()
-        if nc is not None and tensor.is_cuda and tensor.dtype == torch.float32 and tensor.is_contiguous():
+        if nc is not None and nc.accepts(tensor):
             nc.allreduce_sum_(tensor)                   # on the communicator's own stream, behind an event on the compute stream
             self._inflight[key] = None
         else:

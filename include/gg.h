@@ -185,9 +185,10 @@ typedef struct GgAttnArgs {
     const float* bias_table;              /* COMPACT attention_biases f32 [num_heads][ws*ws] (index |dy|*ws+|dx|, timm's first-seen order)
                                              or NULL: what the online-softmax kernels read (gg_attention_flash_*, and gg_attention_fwd/bwd
                                              beyond 256 tokens per window, where `bias` is ignored) */
-    float* ds_scratch;                    /* optional (gg_attention_flash_bwd): f32 [gg_attention_flash_ds_scratch_floats(...)].  With it the dK/dV pass runs
-                                             first and hands dS to the dQ pass, which then is ONE product (dQ = scale * dS K) instead of three plus a second
-                                             round of exponentials; NULL: both passes recompute the scores */
+    float* ds_scratch;                    /* optional (gg_attention_flash_bwd, windows beyond 256 tokens only -- see gg_attention_flash_single_pass): f32
+                                             [gg_attention_flash_ds_scratch_floats(...)] = 4 * windows * heads * roundup16(tokens)^2 bytes (22 MB per image at
+                                             CLIP ViT-L/14-336).  With it the dK/dV pass runs first and hands dS to the dQ pass, which then is ONE product
+                                             (dQ = scale * dS K) instead of three plus a second round of exponentials; NULL: both passes recompute the scores */
 } GgAttnArgs;
 int gg_attention_padded_tokens(int tokens_per_window);
 /* full[h][q][k] = bf16(table[h][|dy|*ws+|dx|] / scale) (-inf for padded keys): the kernels start their score accumulators from it,
@@ -203,6 +204,9 @@ int gg_attention_flash_fwd(const GgAttnArgs* args, int dtype, void* stream);
 int gg_attention_flash_bwd(const GgAttnArgs* args, int dtype, void* stream);
 int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per_window);
 int64_t gg_attention_flash_ds_scratch_floats(int num_windows, int num_heads, int tokens_per_window);
+/* 1 when gg_attention_flash_bwd runs its single-pass kernel for this window (at most 256 tokens: Q, dO and the dQ accumulator of a whole window fit
+ * one CU's LDS): ds_scratch is then neither needed nor read -- workspace planners skip it. */
+int gg_attention_flash_single_pass(int tokens_per_window, int head_dim, int window_size, int with_dbias);
 
 /* ---------------------------------------------------------------- reference-precision (fp32) mode
  * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins

@@ -251,3 +251,89 @@ def test_bench_self_launch_kills_a_hung_child_within_its_limit():
     assert "did not finish within" in r.stderr and "was killed" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert time.time() - t0 < 60
+
+
+class _FakeNativeComm:
+    """Stands in for comm.NativeComm (gg_comm_* over RCCL) on the CPU: carries the sum over gloo and records what optim.AdamW asks of it."""
+
+    def __init__(self, log):
+        self.log, self._pending = log, False
+
+    def accepts(self, t, any_dtype=False):
+        return t.is_contiguous() and (any_dtype or t.dtype == torch.float32)
+
+    def allreduce_sum_(self, t):
+        self.log.append(("allreduce", t.numel()))
+        dist.all_reduce(t)
+        self._pending = True
+
+    def broadcast_(self, t, root=0):
+        self.log.append(("broadcast", t.numel()))
+        dist.broadcast(t, root)
+        self._pending = True
+
+    def wait(self):
+        self.log.append(("wait",))
+        self._pending = False
+
+
+def _native_order_worker(rank, world, port, out):
+    _init(rank, world, port)
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.optim import AdamW
+    import geoguessr_ai_amd.ops as ops
+    torch.manual_seed(100 + rank)
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False)
+    m.freeze_all_but_last_stage()
+    head = torch.nn.Linear(8, 4)
+    model = torch.nn.ModuleDict(dict(base=m, head=head))
+    bb = m.backbone
+    opt = AdamW(model, lr=1e-3)
+    log = []
+    fake = _FakeNativeComm(log)
+    opt._native = lambda: fake                                      # what GG_NATIVE_COMM=1 selects on the GPU
+    opt.broadcast_params()
+    n_bcast = len([e for e in log if e[0] == "broadcast"])
+    assert log[-1] == ("wait",)                                     # the compute stream is ordered behind the start-up broadcasts
+    del log[:]
+    fg = bb.flat_grads()
+    fg.normal_()
+    head.weight.grad, head.bias.grad = torch.ones_like(head.weight), torch.ones_like(head.bias)
+    with opt.overlap_allreduce(enabled=True):
+        bb._grad_ready_hook(*bb._stage_ranges()[3])                 # the stage-3 bucket leaves from "inside backward"
+    during = list(log)
+    opt.allreduce_grads()
+    assert log[-1] == ("wait",) and not fake._pending               # wait() before anything may read the gradients ...
+    stepped = []
+    real_step = ops.adamw_step
+    ops.adamw_step = lambda *a, **k: stepped.append(len(log))       # ... in particular before the optimizer step (no HIP on this box: record only)
+    try:
+        opt.step()
+    finally:
+        ops.adamw_step = real_step
+    assert stepped and min(stepped) == len(log)                     # no collective was issued after the step began
+    # a failing bucket hook must surface, not be swallowed
+    boom = RuntimeError("bucket launch failed")
+    def bad(*a):
+        raise boom
+    fake.allreduce_sum_ = bad
+    raised = False
+    try:
+        with opt.overlap_allreduce(enabled=True):
+            bb._grad_ready_hook(*bb._stage_ranges()[3])
+    except RuntimeError as e:
+        raised = e is boom
+    out.put((rank, n_bcast, during, [e for e in log if e[0] != "wait"], raised))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_native_comm_call_order():
+    """optim.AdamW over the C-ABI communicator (GG_NATIVE_COMM=1), rehearsed with a recording stand-in on 2 gloo ranks: both ranks issue the SAME
+    buckets in the SAME order (a mismatch is an RCCL deadlock on hardware), the stage-3 bucket leaves during backward, ``wait()`` comes before the
+    optimizer step, and an exception inside a bucket launch is re-raised."""
+    r0, r1 = _spawn(_native_order_worker)
+    assert r0[1] == r1[1] and r0[1] >= 3                            # flat parameters + BatchNorm buffers + counters + loose head tensors
+    assert r0[2] == r1[2] and len(r0[2]) == 1 and r0[2][0][0] == "allreduce"
+    assert r0[3] == r1[3] and [e[0] for e in r0[3]] == ["allreduce"] * len(r0[3]) and len(r0[3]) >= 3      # stage-3 bucket, patch_embed range, head weight + bias
+    assert r0[4] and r1[4]

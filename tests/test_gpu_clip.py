@@ -229,3 +229,33 @@ def test_clip_base_patch32_fp16_inference_matches_oracle():
     rel = _rel(got, ref)
     print(f"\n[CLIP B/32 fp16 inference] pooled embedding rel-L2 vs fp32 oracle {rel:.2e}, max abs {float((got - ref).abs().max()):.2e}")
     assert rel < 3e-3
+
+
+def test_clip_layernorm_gradients_respect_a_half_frozen_pair(golden_dir):
+    """A LayerNorm whose weight is frozen and whose bias trains (or the other way round): the trainable tensor's gradient equals the all-trainable
+    run's, and NOTHING is written into the frozen tensor's region of the flat gradient buffer (the kernel forms dgamma and dbeta together: the
+    frozen half goes to a dump row)."""
+    case = CG.load(golden_dir)
+    x = torch.from_numpy(np.load(os.path.join(golden_dir, "clip_tiny.npz"))["x"]).cuda()
+
+    def run(freeze):
+        tower = _tiny_tower(case, "fp32").cuda().train()
+        for n, p in tower.vision_model._params.items():
+            p.requires_grad = n not in freeze
+        out = tower(pixel_values=x)
+        out.pooled_mean.square().sum().backward()
+        torch.cuda.synchronize()
+        vm = tower.vision_model
+        flat = vm.flat_grads().clone()
+        return {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in vm._params.items()}, flat, {t["name"]: t for t in vm.table}
+
+    full, _, _ = run(())
+    fz = ("encoder.layers.0.layer_norm1.weight", "encoder.layers.1.layer_norm2.bias", "pre_layrnorm.weight")
+    part, flat, table = run(fz)
+    for n in fz:
+        t = table[n]
+        assert float(flat[t["offset"]:t["offset"] + t["numel"]].abs().max()) == 0.0, n          # the frozen tensor's slice of the flat buffer is untouched
+        twin = n.replace(".weight", ".bias") if n.endswith(".weight") else n.replace(".bias", ".weight")
+        assert _rel(part[twin].cpu().numpy(), full[twin].cpu().numpy()) < 1e-5, twin
+    other = "encoder.layers.1.mlp.fc1.weight"
+    assert _rel(part[other].cpu().numpy(), full[other].cpu().numpy()) < 1e-5

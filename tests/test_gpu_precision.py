@@ -416,7 +416,7 @@ def _compare_taps(bb, cfg, taps, batch, dtype, tol, label):
     return rows
 
 
-def _train_step_case(model_name, precision, N, centroids, unfrozen, seed=0, drop_path_rate=None):
+def _train_step_case(model_name, precision, N, centroids, unfrozen, seed=0, drop_path_rate=None, extra_trainable=()):
     from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
     from geoguessr_ai_amd.models.super_guessr import SuperGuessr
     from oracle import tinyvit_ref as R
@@ -432,6 +432,8 @@ def _train_step_case(model_name, precision, N, centroids, unfrozen, seed=0, drop
     if unfrozen:
         base.unfreeze_all()
     bb = base.backbone
+    for n in extra_trainable:
+        bb._params[n].requires_grad_(True)
     trainable = [n for n, p in bb.named_parameters() if p.requires_grad]
     g = torch.Generator().manual_seed(seed + 7)
     x = torch.randn(N, 4, 3, cfg.img_size, cfg.img_size, generator=g)
@@ -499,6 +501,19 @@ def test_fp32_mode_train_step_matches_fp32_oracle(centroids, model_name, N, unfr
     assert e_abs < 5e-4 and relerr(emb, case["emb_o"]) < 1e-4
     assert l_rel < 1e-5
     _grad_table(case, 2e-3, label)
+
+
+def test_a_half_frozen_parameter_pair_is_refused_by_name(centroids):
+    """The TinyViT schedule forms the gradients of a (weight, bias) / (gamma, beta) pair together; a mask that trains ``mlp.norm.bias`` while
+    ``mlp.norm.weight`` stays frozen has no schedule and must fail loudly in backward (it used to leave the bias gradient at zero in the fused
+    frozen-block path) -- while whole modules added to the freeze policy train and match the oracle."""
+    from geoguessr_ai_amd import _lib as L
+    with pytest.raises(L.GgError, match="must be trainable or frozen together"):
+        _train_step_case("tiny_vit_5m_224", "fp32", 2, centroids, False, seed=13, drop_path_rate=0.0, extra_trainable=("stages.1.blocks.0.mlp.norm.bias",))
+    extra = ("stages.1.blocks.0.mlp.norm.bias", "stages.1.blocks.0.mlp.norm.weight", "stages.1.blocks.1.local_conv.bn.bias", "stages.1.blocks.1.local_conv.bn.weight")
+    case = _train_step_case("tiny_vit_5m_224", "fp32", 2, centroids, False, seed=13, drop_path_rate=0.0, extra_trainable=extra)
+    assert all(n in case["grads"] for n in extra)
+    _grad_table(case, 2e-3, "fp32 5m extra norm modules in frozen stages")
 
 
 @pytest.mark.parametrize("model_name,N", [("tiny_vit_21m_224", 4), ("tiny_vit_5m_224", 3)])
