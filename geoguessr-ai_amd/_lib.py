@@ -131,6 +131,7 @@ SIGNATURES = {
     "gg_attention_padded_tokens": (_I, [_I]),
     "gg_attention_expand_bias": (_I, [_P, _I, _I, _F, _P, _P]),
     "gg_attention_fwd": (_I, [C.POINTER(AttnArgs), _P]),
+    "gg_attention_fwd_f16": (_I, [C.POINTER(AttnArgs), _P]),
     "gg_attention_bwd": (_I, [C.POINTER(AttnArgs), _P]),
     "gg_attention_flash_fwd": (_I, [C.POINTER(AttnArgs), _I, _P]),
     "gg_attention_flash_bwd": (_I, [C.POINTER(AttnArgs), _I, _P]),

@@ -125,6 +125,55 @@ __device__ __forceinline__ bf16x8 attn_lds_tr_frag(const bf16* X, int RS, int d0
     u.s[0] = a; u.s[1] = b;
     return u.v;
 }
+// ---- element type of the FORWARD kernel: bf16 (training / inference of the bf16 mode) or fp16 (inference of the CLIP tower's fp16 mode, BASELINE
+// config c4: "MFMA fp16").  Same 16-bit layout, same tiling; what differs is the MFMA instruction and the f32 -> 16-bit conversion.
+template <typename E> struct AE;
+template <> struct AE<bf16> {
+    typedef bf16x8 x8; typedef bf16x4 x4;
+    static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct AE<f16> {
+    typedef f16x8 x8; typedef f16x4 x4;
+    static __device__ __forceinline__ f32x4 mfma(x8 a, x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <typename E> __device__ __forceinline__ typename AE<E>::x8 attn_row_frag_e(const E* base, int64_t ld, int tok, int col) {
+    typename AE<E>::x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tok >= 0) v = *reinterpret_cast<const typename AE<E>::x8*>(base + (int64_t)tok * ld + col);
+    return v;
+}
+template <typename E> __device__ __forceinline__ typename AE<E>::x8 attn_pack_e(const f32x4& a, const f32x4& b) {
+    typename AE<E>::x8 v = {(E)a[0], (E)a[1], (E)a[2], (E)a[3], (E)b[0], (E)b[1], (E)b[2], (E)b[3]};
+    return v;
+}
+template <typename E, int D, int Np>
+__device__ __forceinline__ void attn_load_rows_e(typename AE<E>::x8 (&v)[(Np * (D / 8) + 255) / 256], const E* src, int64_t ld, int col,
+                                                 const int (&tokv)[(Np * (D / 8) + 255) / 256]) {
+    constexpr int CH = D / 8;
+    constexpr int IT = (Np * CH + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) v[i] = attn_row_frag_e<E>(src, ld, tokv[i], col + ((threadIdx.x + i * 256) % CH) * 8);
+}
+template <typename E, int D, int Np>
+__device__ __forceinline__ void attn_store_rows_e(E* X, int RS, const typename AE<E>::x8 (&v)[(Np * (D / 8) + 255) / 256]) {
+    constexpr int CH = D / 8;
+    constexpr int IT = (Np * CH + 255) / 256;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int idx = threadIdx.x + i * 256;
+        if (idx < Np * CH) *reinterpret_cast<typename AE<E>::x8*>(X + (idx / CH) * RS + (idx % CH) * 8) = v[i];
+    }
+}
+template <typename E> __device__ __forceinline__ typename AE<E>::x8 attn_lds_row_frag_e(const E* X, int RS, int row, int col) {
+    return *reinterpret_cast<const typename AE<E>::x8*>(X + row * RS + col);
+}
+template <typename E> __device__ __forceinline__ typename AE<E>::x8 attn_lds_tr_frag_e(const E* X, int RS, int d0, int kbase, int lr, int lg) {
+    const E* p0 = X + (kbase + 4 * lg + (lr >> 2)) * RS + d0 + 4 * (lr & 3);
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * RS));
+    union { s16x4 s[2]; typename AE<E>::x8 v; } u;
+    u.s[0] = a; u.s[1] = b;
+    return u.v;
+}
 // attention_biases[h][|di|*ws+|dj|] -> full[h][q][k] (Np x Np, row-major): the kernels then fetch 4 consecutive keys of a
 // query row with one 16-byte load instead of 4 x (index arithmetic + LDS gather).  Padded keys carry -inf so no mask
 // select is needed; the matrix is symmetric, which the backward's [query][key] orientation uses.
@@ -145,9 +194,9 @@ __global__ void attn_expand_bias_kernel(const float* __restrict__ table, int nh,
 // One chunk of KN key tiles (starting at tile K0) of one query tile.  The score accumulators START as the relative-position
 // bias (the expanded table holds bias / scale, -inf on padded keys), so the bias costs no VALU work and the chunk's tile loads
 // are in flight together before the first MFMA.
-template <int D, int NKT, int K0, int KN>
-__device__ __forceinline__ void attn_fwd_chunk(const AttnParams& p, const bf16* Ks, const bf16* Vs, const bf16* bias_h,
-                                               const bf16x8 (&qf)[D / 32], int qi, int lr, int lg, float c2, float& m, float& l,
+template <typename E, int D, int NKT, int K0, int KN>
+__device__ __forceinline__ void attn_fwd_chunk(const AttnParams& p, const E* Ks, const E* Vs, const bf16* bias_h,
+                                               const typename AE<E>::x8 (&qf)[D / 32], int qi, int lr, int lg, float c2, float& m, float& l,
                                                f32x4 (&o)[D / 16]) {
     constexpr int Np = NKT * 16, RS = D + 8, KS = D / 32, DT = D / 16;
     static_assert((K0 & 1) == 0 && (KN & 1) == 0, "key tiles are consumed in pairs");
@@ -169,8 +218,8 @@ __device__ __forceinline__ void attn_fwd_chunk(const AttnParams& p, const bf16* 
     for (int kt = 0; kt < KN; ++kt) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf = attn_lds_row_frag(Ks, RS, (K0 + kt) * 16 + lr, ks * 32 + lg * 8);
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kt], 0, 0, 0);   // D[i=key][j=query]
+            const typename AE<E>::x8 kf = attn_lds_row_frag_e<E>(Ks, RS, (K0 + kt) * 16 + lr, ks * 32 + lg * 8);
+            s[kt] = AE<E>::mfma(kf, qf[ks], s[kt]);   // D[i=key][j=query]
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
@@ -197,11 +246,11 @@ __device__ __forceinline__ void attn_fwd_chunk(const AttnParams& p, const bf16* 
         }
 #pragma unroll
     for (int kp = 0; kp < KN / 2; ++kp) {
-        const bf16x8 pf = attn_pack(s[2 * kp], s[2 * kp + 1]);   // k = key 32kp + 16(jj>>2) + 4lg + (jj&3)
+        const typename AE<E>::x8 pf = attn_pack_e<E>(s[2 * kp], s[2 * kp + 1]);   // k = key 32kp + 16(jj>>2) + 4lg + (jj&3)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
-            const bf16x8 vf = attn_lds_tr_frag(Vs, RS, dt * 16, (K0 / 2 + kp) * 32, lr, lg);
-            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);   // D[i=d][j=query]
+            const typename AE<E>::x8 vf = attn_lds_tr_frag_e<E>(Vs, RS, dt * 16, (K0 / 2 + kp) * 32, lr, lg);
+            o[dt] = AE<E>::mfma(vf, pf, o[dt]);   // D[i=d][j=query]
         }
     }
 }
@@ -209,26 +258,28 @@ __device__ __forceinline__ void attn_fwd_chunk(const AttnParams& p, const bf16* 
 #ifndef GG_ATTN_CK
 #define GG_ATTN_CK 8
 #endif
-template <int D, int NKT, int K0>
-__device__ __forceinline__ void attn_fwd_chunks(const AttnParams& p, const bf16* Ks, const bf16* Vs, const bf16* bias_h,
-                                                const bf16x8 (&qf)[D / 32], int qi, int lr, int lg, float c2, float& m, float& l,
+template <typename E, int D, int NKT, int K0>
+__device__ __forceinline__ void attn_fwd_chunks(const AttnParams& p, const E* Ks, const E* Vs, const bf16* bias_h,
+                                                const typename AE<E>::x8 (&qf)[D / 32], int qi, int lr, int lg, float c2, float& m, float& l,
                                                 f32x4 (&o)[D / 16]) {
     if constexpr (K0 < NKT) {
         constexpr int KN = (NKT - K0) < GG_ATTN_CK ? (NKT - K0) : GG_ATTN_CK;
-        attn_fwd_chunk<D, NKT, K0, KN>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
-        attn_fwd_chunks<D, NKT, K0 + KN>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
+        attn_fwd_chunk<E, D, NKT, K0, KN>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
+        attn_fwd_chunks<E, D, NKT, K0 + KN>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
     }
 }
 
 // ------------------------------------------------------------------------------------------- forward
-template <int D, int NKT>
+template <int D, int NKT, typename E = bf16>
 __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
     constexpr int Np = NKT * 16;
     constexpr int RS = D + 8;     // 80 / 144-byte rows: 16-B aligned fragments, 8-B aligned transposing reads
     constexpr int KS = D / 32;    // MFMA k-steps over the head dim
     constexpr int DT = D / 16;    // output d tiles
-    __shared__ __attribute__((aligned(16))) bf16 Ks[Np * RS];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[Np * RS];
+    __shared__ __attribute__((aligned(16))) E Ks[Np * RS];
+    __shared__ __attribute__((aligned(16))) E Vs[Np * RS];
+    const E* qkv = reinterpret_cast<const E*>(p.qkv);       // (AttnParams carries the 16-bit tensors as bf16*: same layout for fp16)
+    E* outp = reinterpret_cast<E*>(p.out);
 
     // all heads of a window run on one XCD (logical ids are laid out XCD by XCD): their 192-byte slices of a token row share
     // 128-byte lines, which round-robin dispatch made every XCD fetch separately
@@ -244,15 +295,15 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
     int tokv[(Np * (D / 8) + 255) / 256];
     attn_stage_tokens<D, Np>(p, origin, tokv);
     int qtok = wave < nqt ? attn_token(p, origin, wave * 16 + lr) : -1;
-    bf16x8 qf[KS];
+    typename AE<E>::x8 qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag_e<E>(qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
     {
-        bf16x8 kr[(Np * (D / 8) + 255) / 256], vr[(Np * (D / 8) + 255) / 256];
-        attn_load_rows<D, Np>(kr, p.qkv, p.ld, p.k_off + h * p.head_stride, tokv);
-        attn_load_rows<D, Np>(vr, p.qkv, p.ld, p.v_off + h * p.head_stride, tokv);
-        attn_store_rows<D, Np>(Ks, RS, kr);
-        attn_store_rows<D, Np>(Vs, RS, vr);
+        typename AE<E>::x8 kr[(Np * (D / 8) + 255) / 256], vr[(Np * (D / 8) + 255) / 256];
+        attn_load_rows_e<E, D, Np>(kr, qkv, p.ld, p.k_off + h * p.head_stride, tokv);
+        attn_load_rows_e<E, D, Np>(vr, qkv, p.ld, p.v_off + h * p.head_stride, tokv);
+        attn_store_rows_e<E, D, Np>(Ks, RS, kr);
+        attn_store_rows_e<E, D, Np>(Vs, RS, vr);
     }
     __syncthreads();
 
@@ -261,7 +312,7 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
         if (qt != wave) {
             qtok = attn_token(p, origin, qi);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag(p.qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
+            for (int ks = 0; ks < KS; ++ks) qf[ks] = attn_row_frag_e<E>(qkv, p.ld, qtok, p.q_off + h * p.head_stride + ks * 32 + lg * 8);
         }
         // Keys are visited in chunks of <= 8 tiles with an online-softmax carry (running max m, partial sum l, output o):
         // a chunk's scores are the only big live register array (32 instead of 4*NKT), which is what sets occupancy.
@@ -270,7 +321,7 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const float c2 = p.scale * 1.4426950408889634f;       // exp(scale*(s - m)) = 2^(s*c2 - m*c2)
-        attn_fwd_chunks<D, NKT, 0>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
+        attn_fwd_chunks<E, D, NKT, 0>(p, Ks, Vs, bias_h, qf, qi, lr, lg, c2, m, l, o);
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float mx = m;
@@ -278,8 +329,8 @@ __global__ __launch_bounds__(256, (D == 32 && NKT <= 14) ? 3 : 1) void attn_fwd_
             const float inv = 1.f / l;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                bf16x4 ov = {(bf16)(o[dt][0] * inv), (bf16)(o[dt][1] * inv), (bf16)(o[dt][2] * inv), (bf16)(o[dt][3] * inv)};
-                *reinterpret_cast<bf16x4*>(p.out + (int64_t)qtok * p.ldo + h * D + dt * 16 + lg * 4) = ov;
+                typename AE<E>::x4 ov = {(E)(o[dt][0] * inv), (E)(o[dt][1] * inv), (E)(o[dt][2] * inv), (E)(o[dt][3] * inv)};
+                *reinterpret_cast<typename AE<E>::x4*>(outp + (int64_t)qtok * p.ldo + h * D + dt * 16 + lg * 4) = ov;
             }
             if (p.lse && lg == 0) p.lse[(int64_t)qtok * p.nh + h] = mx * p.scale + __logf(l);
         }
@@ -936,6 +987,29 @@ extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
         if (nkt == 4) GG_FWD(64, 4); else if (nkt == 10) GG_FWD(64, 10); else if (nkt == 14) GG_FWD(64, 14); else GG_FWD(64, 16);
     }
 #undef GG_FWD
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// fp16 twin of the forward (inference of the CLIP tower's fp16 mode: pretrain/clip_embedder.py:63-65 at BASELINE config c4's precision): fp16 storage,
+// QK^T and PV on v_mfma_f32_16x16x32_f16, f32 accumulation and softmax.  No relative-position bias (the CLIP tower has none); sequences beyond 256
+// tokens go to the online-softmax kernel (fp16 storage, f32 arithmetic).
+extern "C" int gg_attention_fwd_f16(const GgAttnArgs* a, void* stream) {
+    if (attn_use_flash(a)) return gg_attention_flash_fwd(a, 2, stream);
+    GG_CHECK(a && !a->bias && !a->bias_table, "gg_attention_fwd_f16: the fp16 forward takes no bias");
+    AttnParams p;
+    GG_TRY(attn_fill(p, a, "gg_attention_fwd_f16"));
+    GG_CHECK(a->out && (a->ldo & 3) == 0, "gg_attention_fwd_f16: bad out");
+    dim3 grid((unsigned)(a->num_windows * a->num_heads)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 8.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
+    const int nkt = attn_nkt(p.N);
+#define GG_FWD16(D_, K_) hipLaunchKernelGGL((attn_fwd_kernel<D_, K_, f16>), grid, block, 0, s, p)
+    if (a->head_dim == 32) {
+        if (nkt == 4) GG_FWD16(32, 4); else if (nkt == 10) GG_FWD16(32, 10); else if (nkt == 14) GG_FWD16(32, 14); else GG_FWD16(32, 16);
+    } else {
+        if (nkt == 4) GG_FWD16(64, 4); else if (nkt == 10) GG_FWD16(64, 10); else if (nkt == 14) GG_FWD16(64, 14); else GG_FWD16(64, 16);
+    }
+#undef GG_FWD16
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -442,7 +442,8 @@ extern "C" int gg_clip_forward(const GgClipCfg* cfg, int batch, int training, co
         GG_TRY(e.gemm(e.A(A1), D, e.W(l.wqkv), D, e.A(QKV), 3 * D, M, 3 * D, D, (const float*)e.W(l.bqkv)));
         GgAttnArgs at;
         e.attn_args(at, e.A(QKV), e.A(O), sv ? e.F(a.lse) : nullptr);
-        if (m.f32 || m.f16 || sv || T > 256) GG_TRY(gg_attention_flash_fwd(&at, m.f32 ? 1 : (m.f16 ? 2 : 0), e.st));      // (fp16: fp16 storage, f32 arithmetic)
+        if (m.f16) GG_TRY(gg_attention_fwd_f16(&at, e.st));      // fp16 MFMA for towers of at most 256 tokens (ViT-B/32: 50); beyond: fp16 storage, f32 arithmetic
+        else if (m.f32 || sv || T > 256) GG_TRY(gg_attention_flash_fwd(&at, m.f32 ? 1 : 0, e.st));
         else GG_TRY(gg_attention_fwd(&at, e.st));
         // x_mid = x + out_proj(o)   (in place when nothing is kept: each element is read then written by the same lane)
         GG_TRY(e.gemm(e.A(O), D, e.W(l.wo), D, e.A(XMID), D, M, D, D, e.P(l.o_b), 0, nullptr, e.A(cur)));

@@ -550,7 +550,10 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
     """forward when ``dout`` is None (returns out, or (out, lse) with ``want_lse``); else backward given the forward's
     ``out`` and ``lse`` -> (dqkv, dbias)."""
     a = L.AttnArgs()
-    a.qkv, a.ld = _p(qkv, BF16, "qkv"), qkv.stride(0)
+    f16 = qkv.dtype == torch.float16            # fp16 storage + fp16 MFMA: forward only, no bias (the CLIP tower's fp16 inference mode)
+    if f16 and (bias is not None or dout is not None):
+        raise L.GgError("attention: the fp16 form is forward-only and takes no bias")
+    a.qkv, a.ld = _p(qkv, torch.float16 if f16 else BF16, "qkv"), qkv.stride(0)
     a.q_off, a.k_off, a.v_off, a.head_stride, a.head_dim = q_off, k_off, v_off, head_stride, head_dim
     a.num_heads, a.num_windows, a.tokens_per_window = num_heads, num_windows, tokens_per_window
     a.window_size, a.map_h, a.map_w = window_size, map_h, map_w
@@ -565,11 +568,14 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
     a.bias = _p(full)
     tokens = qkv.shape[0]
     if dout is None:
-        out = torch.empty((tokens, num_heads * head_dim), dtype=BF16, device=qkv.device)
+        out = torch.empty((tokens, num_heads * head_dim), dtype=qkv.dtype, device=qkv.device)
         a.out, a.ldo = _p(out), out.stride(0)
         lse_t = torch.empty((tokens, num_heads), dtype=F32, device=qkv.device) if want_lse else None
         a.lse = _p(lse_t)
-        L.check(L.lib().gg_attention_fwd(C.byref(a), L.stream()), "gg_attention_fwd")
+        if f16:
+            L.check(L.lib().gg_attention_fwd_f16(C.byref(a), L.stream()), "gg_attention_fwd_f16")
+        else:
+            L.check(L.lib().gg_attention_fwd(C.byref(a), L.stream()), "gg_attention_fwd")
         return (out, lse_t) if want_lse else out
     dqkv = torch.zeros_like(qkv)
     dbias = torch.zeros_like(bias) if (want_dbias and bias is not None) else None

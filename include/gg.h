@@ -196,6 +196,9 @@ int gg_attention_padded_tokens(int tokens_per_window);
 int gg_attention_expand_bias(const float* table /* [num_heads][ws*ws] */, int num_heads, int window_size, float scale, void* full /* bf16 */, void* stream);
 int gg_attention_fwd(const GgAttnArgs* args, void* stream);
 int gg_attention_bwd(const GgAttnArgs* args, void* stream);
+/* fp16 forward (inference; fp16 qkv / out, v_mfma_f32_16x16x32_f16, f32 softmax): the CLIP tower's fp16 mode -- HF CLIPAttention as reached from
+ * pretrain/clip_embedder.py:63-65, at the precision BASELINE config c4 names.  No bias; beyond 256 tokens it forwards to gg_attention_flash_fwd(dtype 2). */
+int gg_attention_fwd_f16(const GgAttnArgs* args, void* stream);
 /* Online-softmax (flash) form for ANY tokens_per_window (1024-token windows of the reference's default tiny_vit_21m_512, config.py:9;
  * 577 tokens of CLIP ViT-L/14-336, config.py:6) and for the reference-precision mode: dtype 0 = bf16, 1 = f32, 2 = fp16 (forward only) storage of
  * qkv / out / dout / dqkv; arithmetic is f32 MFMA either way.  window_size <= 32.  dbias_scratch (optional): f32

@@ -606,6 +606,23 @@ def test_clip_attention_fwd(ops):
     close(out, ref, rtol=2e-2, atol=2e-2, what="clip attn")
 
 
+@pytest.mark.parametrize("B,T,nh,hd", [(4, 50, 3, 64), (2, 197, 2, 64), (3, 49, 2, 32), (1, 256, 1, 64)])
+def test_clip_attention_fwd_fp16(ops, B, T, nh, hd):
+    """fp16 storage + v_mfma_f32_16x16x32_f16 (the CLIP tower's fp16 inference mode, BASELINE c4): 50 tokens (ViT-B/32), 197 (B/16), a 49-token and
+    a full 256-token case, against fp32 attention of the fp16-representable inputs; lse against torch.logsumexp."""
+    D = nh * hd
+    qkv = rnd(B * T, 3 * D, seed=64).half().float()
+    ref = _attn_ref(qkv, nh, hd, 0, 0, 0, B, None, "clip")
+    out, lse = ops.attention(qkv.cuda().half(), num_windows=B, tokens_per_window=T, num_heads=nh, head_dim=hd, q_off=0, k_off=D, v_off=2 * D, head_stride=hd,
+                             want_lse=True)
+    assert out.dtype == torch.float16
+    close(out, ref, rtol=2e-3, atol=2e-3, what="clip attn fp16")
+    q = qkv[:, :D].view(B, T, nh, hd).permute(0, 2, 1, 3)
+    k = qkv[:, D:2 * D].view(B, T, nh, hd).permute(0, 2, 1, 3)
+    lse_ref = torch.logsumexp((q @ k.transpose(-1, -2)) * hd ** -0.5, dim=-1).permute(0, 2, 1).reshape(B * T, nh)
+    close(lse, lse_ref, rtol=1e-3, atol=1e-3, what="clip attn fp16 lse")
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os
