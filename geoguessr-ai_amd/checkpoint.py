@@ -18,9 +18,24 @@ import torch
 def make_state(model, optimizer, scheduler, epoch: int, global_step: int, best_value: float, monitored_value: float,
                config: Optional[dict] = None) -> Dict[str, Any]:
     opt_sd = adamw_state_to_torch(optimizer) if hasattr(optimizer, "backbones") else optimizer.state_dict()
-    return {"epoch": epoch, "global_step": global_step, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt_sd,
-            "scheduler_state_dict": scheduler.state_dict() if scheduler is not None else {}, "best_value": best_value,
-            "monitored_value": monitored_value, "config": dict(config or {})}
+    state = {"epoch": epoch, "global_step": global_step, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt_sd,
+             "scheduler_state_dict": scheduler.state_dict() if scheduler is not None else {}, "best_value": best_value,
+             "monitored_value": monitored_value, "config": dict(config or {})}
+    # extra key (the reference's loaders ignore unknown keys): DropPath stream position of every flat-storage backbone, so a resumed run continues the
+    # mask sequence instead of replaying it from the start
+    dp = {n: m.drop_path_state() for n, m in model.named_modules() if hasattr(m, "drop_path_state")}
+    if dp:
+        state["gg_drop_path_state"] = dp
+    return state
+
+
+def restore_drop_path_state(model, state: Dict[str, Any]) -> None:
+    """Counterpart of the ``gg_drop_path_state`` key written by :func:`make_state` (no-op for checkpoints without it, e.g. the reference's own)."""
+    dp = (state or {}).get("gg_drop_path_state") or {}
+    mods = dict(model.named_modules())
+    for n, st in dp.items():
+        if n in mods and hasattr(mods[n], "load_drop_path_state"):
+            mods[n].load_drop_path_state(st)
 
 
 def _value_from_filename(name: str) -> Optional[float]:

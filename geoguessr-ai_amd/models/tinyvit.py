@@ -183,15 +183,29 @@ class TinyVitBackbone(FlatStore):
         if rates is None or rates.device != dev:          # cached on the device: no host-to-device copy per step (graph-capturable)
             rates = self._rates_dev = torch.tensor(self.drop_rates, dtype=torch.float32, device=dev)
         if generator is not None:
-            seed, counter = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item()), 0
+            # host-side (seed, counter) from the generator's seed + a per-generator call count: no device round trip (a CUDA generator's randint +
+            # .item() was a blocking sync per step), deterministic for a given generator seed and call order
+            counts = self.__dict__.setdefault("_drop_gen_counts", {})
+            seed = int(generator.initial_seed()) & (2 ** 62 - 1)
+            counter = counts.get(seed, 0)
+            counts[seed] = counter + 1
         else:
             if getattr(self, "_drop_seed", None) is None:
-                self._drop_seed, self._drop_counter = int(torch.randint(0, 2 ** 62, (1,)).item()), 0
+                self._drop_seed, self._drop_counter = int(torch.randint(0, 2 ** 62, (1,)).item()), 0      # (CPU RNG, once per backbone)
             seed, counter = self._drop_seed, self._drop_counter
             self._drop_counter += 1
         out = torch.empty((self.num_drop_slots, batch), dtype=torch.float32, device=dev)
         L.check(L.lib().gg_drop_path_scales(L.ptr(rates), self.num_drop_slots, batch, seed, counter, L.ptr(out), L.stream()), "gg_drop_path_scales")
         return out
+
+    # DropPath stream position: kept OUT of state_dict (its keys are the timm contract) and saved by checkpoint.save_checkpoint under its own key, so
+    # a resumed run continues the mask sequence instead of replaying it from counter 0
+    def drop_path_state(self):
+        return dict(drop_seed=getattr(self, "_drop_seed", None), drop_counter=getattr(self, "_drop_counter", 0))
+
+    def load_drop_path_state(self, state):
+        if state and state.get("drop_seed") is not None:
+            self._drop_seed, self._drop_counter = int(state["drop_seed"]), int(state.get("drop_counter", 0))
 
     def forward_hip(self, x: torch.Tensor, training: bool, drop_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
         L.require_gpu()

@@ -32,6 +32,11 @@ def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_p
     p = np.zeros_like(d) if top1_prob is None else np.asarray(torch.as_tensor(top1_prob).cpu() if torch.is_tensor(top1_prob) else top1_prob,
                                                               np.float64)
     n = d.size
+    # gg_geoguessr_score marks a non-finite coordinate pair with distance NaN / score -1; the reference's haversine_np would have propagated the NaN
+    # into every mean silently -- refuse instead of averaging sentinels
+    bad = ~np.isfinite(d) | (s < 0)
+    if bad.any():
+        raise ValueError(f"compute_summary: {int(bad.sum())} of {n} samples have a non-finite distance / sentinel score (first at index {int(np.argmax(bad))})")
     total_distance = total_score = total_top = 0.0
     for i in range(n):                       # the reference accumulates sample by sample in Python floats: keep its summation order
         total_distance += float(d[i]); total_score += float(s[i]); total_top += float(p[i]) if p[i] >= 0 else 0.0

@@ -83,3 +83,51 @@ def test_load_model_state_filters_by_shape():
     rep = load_model_state(m, {"model_state_dict": sd})
     assert rep["loaded"] == ["0.weight"] and "0.bias" in rep["skipped"] and "extra" in rep["skipped"]
     assert torch.equal(m[0].weight.data, torch.ones(3, 4))
+
+
+def test_compute_summary_refuses_sentinel_scores():
+    """gg_geoguessr_score marks non-finite coordinate pairs with distance NaN / score -1: the summary must not average them."""
+    import pytest
+    from geoguessr_ai_amd.scoring import compute_summary
+    ok = compute_summary([10.0, 20.0], [4000, 3000])
+    assert ok["avg_score"] == 3500.0 and ok["num_samples"] == 2
+    with pytest.raises(ValueError, match="sentinel"):
+        compute_summary([10.0, float("nan")], [4000, -1])
+    with pytest.raises(ValueError, match="sentinel"):
+        compute_summary([10.0, 5.0], [4000, -1])
+
+
+def test_raw_image_inputs_are_converted_to_rgb():
+    """PIL images of any mode go through ``convert("RGB")`` like CLIPProcessor / timm's transform; arrays of another layout are refused by name."""
+    import numpy as np
+    import pytest
+    from geoguessr_ai_amd.training.preprocess import _rgb_chw
+    from geoguessr_ai_amd._lib import GgError
+    class FakePIL:                      # the two attributes the path reads (Pillow is optional in this image)
+        mode = "L"
+        def __init__(self): self.converted = None
+        def convert(self, mode):
+            self.converted = mode
+            return np.zeros((5, 7, 3), np.uint8)
+    im = FakePIL()
+    t = _rgb_chw(im)
+    assert im.converted == "RGB" and tuple(t.shape) == (3, 5, 7)
+    with pytest.raises(GgError, match="raw image"):
+        _rgb_chw(np.zeros((5, 7), np.uint8))
+    with pytest.raises(GgError, match="raw image"):
+        _rgb_chw(np.zeros((5, 7, 4), np.uint8))
+
+
+def test_drop_path_state_travels_with_the_checkpoint():
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd import checkpoint as CK
+    import torch
+    m = TinyViTAdapter("tiny_vit_21m_224", pretrained=False)
+    bb = m.backbone
+    bb._drop_seed, bb._drop_counter = 1234567, 42
+    st = CK.make_state(m, torch.optim.SGD(m.parameters(), lr=0.1), None, 0, 0, 0.0, 0.0)
+    assert "gg_drop_path_state" in st and not any("extra_state" in k for k in st["model_state_dict"])       # state_dict keys stay the timm contract
+    m2 = TinyViTAdapter("tiny_vit_21m_224", pretrained=False)
+    CK.restore_drop_path_state(m2, st)
+    assert (m2.backbone._drop_seed, m2.backbone._drop_counter) == (1234567, 42)
+    CK.restore_drop_path_state(m2, {"epoch": 1})            # a checkpoint without the key (the reference's own) is fine

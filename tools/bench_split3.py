@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Experiment: fp32-accurate GEMM on the bf16 matrix pipe.  x = x1 + x2 + x3 with three bf16 terms (24 significand bits); the six
+products x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1) accumulated in fp32 reproduce the fp32 product to ~2^-24.  Here the six products run as ONE bf16
+GEMM of the product library over a 6 K contraction ([x1|x1|x2|x1|x2|x3] . [y1|y2|y1|y3|y2|y1]^T, f32 output), which needs no new kernel: it answers
+(a) the parity question -- error against an fp64 product next to the true f32-MFMA GEMM's -- and (b) gives a LOWER bound on the speed (the operand
+split is done with torch glue and is not timed; a production form would split in the producer's epilogue / the GEMM's loader).
+Shapes: the stage-2 / stage-3 transformer GEMMs of the 1024-image TinyViT-21M step."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from geoguessr_ai_amd import ops
+
+
+def timed(fn, n=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def split3(x):
+    x1 = x.bfloat16(); r = x - x1.float()
+    x2 = r.bfloat16(); r = r - x2.float()
+    return x1, x2, r.bfloat16()
+
+
+def main():
+    dev = "cuda"
+    shapes = [("s2.qkv", 200704, 1152, 384), ("s2.fc1", 200704, 1536, 384), ("s2.fc2", 200704, 384, 1536), ("s2.proj", 200704, 384, 384),
+              ("s3.fc1", 50176, 2304, 576), ("s3.fc2", 50176, 576, 2304)]
+    print(f"{'shape':8s} {'M':>7s} {'N':>5s} {'K':>5s} | f32-MFMA us  TF/s | bf16x3 (6K) us  TF/s-eq | plain bf16 us | rel-L2 err vs fp64: f32-MFMA  bf16x3   bf16 | max|err|/max|ref|: f32-MFMA  bf16x3")
+    for name, M, N, K in shapes:
+        g = torch.Generator(device=dev).manual_seed(1)
+        A = torch.randn(M, K, device=dev, generator=g)
+        B = torch.randn(N, K, device=dev, generator=g) * K ** -0.5
+        a1, a2, a3 = split3(A); b1, b2, b3 = split3(B)
+        A6 = torch.cat([a1, a1, a2, a1, a2, a3], 1).contiguous()
+        B6 = torch.cat([b1, b2, b1, b3, b2, b1], 1).contiguous()
+        out32 = torch.empty(M, N, device=dev); out6 = torch.empty(M, N, device=dev); out16 = torch.empty(M, N, device=dev)
+        t32 = timed(lambda: ops.gemm_nt(A, B, out=out32))
+        t6 = timed(lambda: ops.gemm_nt(A6, B6, out_f32=True, out=out6))
+        t16 = timed(lambda: ops.gemm_nt(a1, b1, out_f32=True, out=out16))
+        rows = 4096
+        ref = A[:rows].double() @ B.double().T
+        def err(o):
+            d = o[:rows].double() - ref
+            return float(d.norm() / ref.norm()), float(d.abs().max() / ref.abs().max())
+        e32, e6, e16 = err(out32), err(out6), err(out16)
+        fl = 2.0 * M * N * K
+        print(f"{name:8s} {M:7d} {N:5d} {K:5d} | {t32*1e3:9.1f} {fl/t32/1e9:6.1f} | {t6*1e3:12.1f} {fl/t6/1e9:8.1f} | {t16*1e3:10.1f} | "
+              f"{e32[0]:.2e} {e6[0]:.2e} {e16[0]:.2e} | {e32[1]:.2e} {e6[1]:.2e}", flush=True)
+        del A, B, A6, B6, out32, out6, out16, a1, a2, a3, b1, b2, b3
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
