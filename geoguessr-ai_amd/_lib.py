@@ -201,6 +201,7 @@ SIGNATURES = {
     "gg_transpose_f32": (_I, [_P, _I, _I, _P, _L, _P]),
     "gg_tinyvit_wcache_bytes": (_L, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_workspace_bytes": (_L, [C.POINTER(TinyVitCfg), _I, _I]),
+    "gg_tinyvit_workspace_bytes_masked": (_L, [C.POINTER(TinyVitCfg), _I, _I, _P]),
     "gg_tinyvit_refresh_weights": (_I, [C.POINTER(TinyVitCfg), _P, _P, _P]),
     "gg_tinyvit_refresh_weights_masked": (_I, [C.POINTER(TinyVitCfg), _P, _P, C.c_char_p, _P]),
     "gg_preprocess_bilinear": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
@@ -208,6 +209,7 @@ SIGNATURES = {
     "gg_tinyvit_forward": (_I, [C.POINTER(TinyVitCfg), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
     "gg_tinyvit_backward": (_I, [C.POINTER(TinyVitCfg), _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P, STAGE_DONE_FN, _P]),
     "gg_tinyvit_activation_info": (_I, [C.POINTER(TinyVitCfg), _I, C.c_char_p, C.POINTER(_L), C.POINTER(_L)]),
+    "gg_tinyvit_activation_info_masked": (_I, [C.POINTER(TinyVitCfg), _I, C.c_char_p, _P, C.POINTER(_L), C.POINTER(_L)]),
     "gg_clip_num_tensors": (_I, [C.POINTER(ClipCfg)]),
     "gg_clip_tensor_info": (_I, [C.POINTER(ClipCfg), _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I),
                                  C.POINTER(_L)]),

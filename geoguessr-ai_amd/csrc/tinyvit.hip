@@ -167,6 +167,40 @@ struct Plan {
     int ring_next = 0;
     int64_t ring_base = 0;
     static constexpr int RING = 10;
+    // Training-time temporaries: tensors that live only between their producer and their one consumer because -- under the trainable mask the plan
+    // was made for -- no weight gradient reads them (the input of a frozen Linear / depthwise conv, the activation tensors the fused forward never
+    // writes).  They alternate between TRING slots of the largest one; `temps` holds their names (gg_tinyvit_activation_info refuses them).
+    const uint8_t* mask = nullptr;       // one byte per tensor of the model, or null = everything trainable
+    bool fwd_dw_s1 = true, fwd_dw_s2 = true, fwd_pro = true;      // which forward fusions the executor will take (they decide who writes act1 / act2)
+    int64_t max_temp = 0, temp_base = 0, gbytes_seen = 0;
+    int temp_next = 0;
+    bool alias_G = false;
+    static constexpr int TRING = 2;
+    std::map<std::string, int> temps;
+    bool tr(int t) const { return mask == nullptr || mask[t] != 0; }
+    int64_t alloc_temp(const std::string& name, int64_t bytes) {
+        if (!training) return alloc(name, bytes, true);
+        bytes = gg_align(std::max<int64_t>(bytes, 16), 256);
+        max_temp = std::max(max_temp, bytes);
+        const int64_t off = dry ? 0 : temp_base + (int64_t)(temp_next % TRING) * max_temp;
+        temp_next++;
+        temps[name] = 1;
+        index[name] = (int)regs.size();
+        regs.push_back({name, off, bytes});
+        return off;
+    }
+    // act1 behind a fused forward with trainable taps: never written in forward, re-formed by backward right before the tap gradient reads it -- all
+    // such layers share ONE region (they are processed one at a time)
+    int64_t max_shared = 0, shared_base = 0;
+    int64_t alloc_shared(const std::string& name, int64_t bytes) {
+        if (!training) return alloc(name, bytes, true);
+        bytes = gg_align(std::max<int64_t>(bytes, 16), 256);
+        max_shared = std::max(max_shared, bytes);
+        temps[name] = 1;
+        index[name] = (int)regs.size();
+        regs.push_back({name, shared_base, bytes});
+        return shared_base;
+    }
     // persistent: always gets its own storage; transient activations share a ring in inference mode
     int64_t alloc(const std::string& name, int64_t bytes, bool transient = true) {
         bytes = gg_align(std::max<int64_t>(bytes, 16), 256);
@@ -240,10 +274,13 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         const std::string n = "stages.0.blocks." + std::to_string(i);
         MBAct& a = L.mb[i];
         a.x = prev;
+        // act1 = GELU(BN1(y1)): the fused depthwise forward never writes it (backward re-forms it as a temporary when conv2's taps train); unfused, it
+        // is read again only by conv2's weight gradient.  act2 = GELU(BN2(y2)): conv3's input, kept only for conv3's weight gradient.
+        const MBConvL& ml = m.mb[i];
         bnreg(n + ".conv1", a.c1, M0, mid, false, B, H0, H0);
-        a.a1 = p.alloc(n + ".act1", M0 * mid * es);
+        a.a1 = !p.tr(ml.c2.w.t_w) ? p.alloc_temp(n + ".act1", M0 * mid * es) : p.fwd_dw_s1 ? p.alloc_shared(n + ".act1", M0 * mid * es) : p.alloc(n + ".act1", M0 * mid * es);
         bnreg(n + ".conv2", a.c2, M0, mid, true, B, H0, H0);
-        a.a2 = p.alloc(n + ".act2", M0 * mid * es);
+        a.a2 = !p.tr(ml.c3.w.t_w) ? p.alloc_temp(n + ".act2", M0 * mid * es) : p.alloc(n + ".act2", M0 * mid * es);
         bnreg(n + ".conv3", a.c3, M0, d[0], false, B, H0, H0);
         a.out = p.alloc(n + ".out", M0 * d[0] * es);
         prev = a.out;
@@ -257,9 +294,9 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         const std::string n = "stages." + std::to_string(s + 1) + ".downsample";
         MergeAct& ma = L.merge[s];
         bnreg(n + ".conv1", ma.c1, Mprev, C, false, B, res, res);
-        ma.a1 = p.alloc(n + ".act1", Mprev * C * es);
+        ma.a1 = !p.tr(st.merge.c2.w.t_w) ? p.alloc_temp(n + ".act1", Mprev * C * es) : p.fwd_dw_s2 ? p.alloc_shared(n + ".act1", Mprev * C * es) : p.alloc(n + ".act1", Mprev * C * es);
         bnreg(n + ".conv2", ma.c2, M, C, true, B, st.res, st.res);
-        ma.a2 = p.alloc(n + ".act2", M * C * es);
+        ma.a2 = !p.tr(st.merge.c3.w.t_w) ? p.alloc_temp(n + ".act2", M * C * es) : p.alloc(n + ".act2", M * C * es);
         bnreg(n + ".conv3", ma.c3, M, C, false, B, st.res, st.res);
         ma.out = p.alloc(n + ".out", M * C * es);
         prev = ma.out;
@@ -268,21 +305,25 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         for (size_t i = 0; i < st.blocks.size(); ++i) {
             const std::string bn = "stages." + std::to_string(s + 1) + ".blocks." + std::to_string(i);
             BlockAct& a = L.blocks[s][i];
+            const BlockL& bl = st.blocks[i];
             a.x0 = prev;
-            a.a = p.alloc(bn + ".ln1", M * C * es);
+            // inputs of frozen Linears / of the frozen local conv are consumed once, right after they are written: ln1 -> qkv, x1 -> local_conv,
+            // ln2 -> fc1, GELU(fc1) -> fc2 (the backward of a frozen block needs x0 / x2 / means for the LayerNorms, qkv / o / lse for the attention,
+            // local_conv.y for its BatchNorm and the fc1 pre-activation for GELU'): 7 C of the block's 19 C floats per token
+            a.a = !p.tr(bl.qkv.t_w) ? p.alloc_temp(bn + ".ln1", M * C * es) : p.alloc(bn + ".ln1", M * C * es);
             a.mean1 = p.alloc(bn + ".mean1", M * 4);
             a.rstd1 = p.alloc(bn + ".rstd1", M * 4);
             a.qkv = p.alloc(bn + ".qkv", M * 3 * C * es);
             a.o = p.alloc(bn + ".attn.out", M * C * es);
             a.lse = p.alloc(bn + ".attn.lse", M * st.heads * 4);
-            a.x1 = p.alloc(bn + ".x1", M * C * es);
+            a.x1 = !p.tr(bl.local.w.t_w) ? p.alloc_temp(bn + ".x1", M * C * es) : p.alloc(bn + ".x1", M * C * es);
             bnreg(bn + ".local_conv", a.local, M, C, true, B, st.res, st.res);
             a.x2 = p.alloc(bn + ".x2", M * C * es);
-            a.b = p.alloc(bn + ".ln2", M * C * es);
+            a.b = !p.tr(bl.fc1.t_w) ? p.alloc_temp(bn + ".ln2", M * C * es) : p.alloc(bn + ".ln2", M * C * es);
             a.mean2 = p.alloc(bn + ".mean2", M * 4);
             a.rstd2 = p.alloc(bn + ".rstd2", M * 4);
             a.hpre = p.alloc(bn + ".fc1.pre", M * hid * es);
-            a.h = p.alloc(bn + ".fc1.act", M * hid * es);
+            a.h = !p.tr(bl.fc2.t_w) ? p.alloc_temp(bn + ".fc1.act", M * hid * es) : p.alloc(bn + ".fc1.act", M * hid * es);
             a.x3 = p.alloc(bn + ".out", M * C * es);
             prev = a.x3;
             track(M * hid); track(M * 3 * C);
@@ -331,13 +372,44 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         L.foldw = p.alloc("scratch.foldw", fold * es, false);
         L.foldb = p.alloc("scratch.foldb", 4096 * 4, false);
         L.gbytes = gg_align(gmax, 256);
-        for (int i = 0; i < 5; ++i) L.G[i] = p.alloc("scratch.G" + std::to_string(i), L.gbytes, false);
+        p.gbytes_seen = L.gbytes;
+        // the forward's temporaries are dead when backward starts and the first two gradient ping-pong buffers are untouched until then: they share
+        // the ring's slots -- unless backward itself re-forms a temporary (act1 for a trainable depthwise conv behind a fused forward)
+        for (int i = 0; i < 5; ++i) {
+            if (i < Plan::TRING && p.alias_G && !p.dry) {
+                L.G[i] = p.temp_base + (int64_t)i * p.max_temp;
+                p.index["scratch.G" + std::to_string(i)] = (int)p.regs.size();
+                p.regs.push_back({"scratch.G" + std::to_string(i), L.G[i], L.gbytes});
+            } else L.G[i] = p.alloc("scratch.G" + std::to_string(i), L.gbytes, false);
+        }
     }
 }
-static void plan_make(const Model& m, int B, bool training, Plan& p, Layout& L) {
+// which forward fusions the executor takes (mirrors Exec::exec_init): they decide who writes the MBConv / PatchMerging activation tensors
+static void plan_flags(const Model& m, Plan& p) {
+    bool fuse_dw = gg_dev_env("GG_FUSE_DW") != nullptr, s1 = gg_dev_env("GG_NO_FUSE_DW_S1") == nullptr, s2 = gg_dev_env("GG_NO_FUSE_DW_S2") == nullptr;
+    bool pro = gg_dev_env("GG_NO_PRO") == nullptr;
+    if (m.f32 && gg_dev_env("GG_F32_NO_FUSE")) fuse_dw = s1 = s2 = pro = false;
+    if (m.f32) fuse_dw = false;
+    p.fwd_dw_s1 = fuse_dw || s1; p.fwd_dw_s2 = fuse_dw || s2; p.fwd_pro = pro;
+}
+static void plan_make(const Model& m, int B, bool training, Plan& p, Layout& L, const uint8_t* mask = nullptr) {
     p.training = training;
     p.dry = true;
+    p.mask = training ? mask : nullptr;
+    plan_flags(m, p);
     plan_build(m, B, p, L);
+    if (training && (p.max_temp > 0 || p.max_shared > 0)) {
+        Plan q;                                    // second pass: the temporaries' ring (= the first two gradient buffers) first, then the shared act1 region, then the rest
+        q.training = true; q.dry = false; q.mask = p.mask; q.temp_base = 0;
+        q.fwd_dw_s1 = p.fwd_dw_s1; q.fwd_dw_s2 = p.fwd_dw_s2; q.fwd_pro = p.fwd_pro;
+        q.alias_G = p.max_temp > 0;
+        q.max_temp = q.alias_G ? std::max(p.max_temp, p.gbytes_seen) : 0;
+        q.shared_base = (int64_t)Plan::TRING * q.max_temp;
+        q.total = q.shared_base + p.max_shared;
+        Layout L2;
+        plan_build(m, B, q, L2);
+        p = q; L = L2;
+    }
     if (!training) {
         Plan q;
         q.training = false; q.dry = false; q.max_transient = p.max_transient;
@@ -1076,24 +1148,32 @@ extern "C" int gg_tinyvit_num_drop_slots(const GgTinyVitCfg* cfg) {
     return n;
 }
 extern "C" int64_t gg_tinyvit_wcache_bytes(const GgTinyVitCfg* cfg) { Model m; return build_model(cfg, m) ? -1 : m.wcache_bytes; }
-extern "C" int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training) {
+extern "C" int64_t gg_tinyvit_workspace_bytes_masked(const GgTinyVitCfg* cfg, int batch, int training, const uint8_t* trainable) {
     Model m;
     if (build_model(cfg, m)) return -1;
     if (batch <= 0) { gg_set_error("gg_tinyvit_workspace_bytes: batch must be > 0"); return -1; }
     Plan p; Layout L;
-    plan_make(m, batch, training != 0, p, L);
+    plan_make(m, batch, training != 0, p, L, trainable);
     return p.total;
 }
-extern "C" int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes) {
+extern "C" int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training) {
+    return gg_tinyvit_workspace_bytes_masked(cfg, batch, training, nullptr);
+}
+extern "C" int gg_tinyvit_activation_info_masked(const GgTinyVitCfg* cfg, int batch, const char* name, const uint8_t* trainable, int64_t* offset,
+                                                 int64_t* bytes) {
     Model m;
     GG_TRY(build_model(cfg, m));
     Plan p; Layout L;
-    plan_make(m, batch, true, p, L);
+    plan_make(m, batch, true, p, L, trainable);
     auto it = p.index.find(name);
     GG_CHECK(it != p.index.end(), "gg_tinyvit_activation_info: no activation named '%s'", name);
+    GG_CHECK(!p.temps.count(name), "gg_tinyvit_activation_info: '%s' is not retained under this trainable mask (a temporary between its producer and its one consumer)", name);
     if (offset) *offset = p.regs[it->second].offset;
     if (bytes) *bytes = p.regs[it->second].bytes;
     return 0;
+}
+extern "C" int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes) {
+    return gg_tinyvit_activation_info_masked(cfg, batch, name, nullptr, offset, bytes);
 }
 // `only` (host, one byte per tensor, or NULL = every tensor): the tensors whose cached forms are rebuilt.  After an optimizer step only the
 // trainable tensors changed -- under the reference freeze policy 14 of the 52 cached matrices -- so the per-step refresh skips the frozen ones.
@@ -1148,7 +1228,7 @@ extern "C" int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int traini
     GG_CHECK(batch > 0 && params && buffers && wcache && x && workspace && out, "gg_tinyvit_forward: null pointer / bad batch");
     GG_CHECK(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, "gg_tinyvit_forward: workspace/wcache must be 256-byte aligned");
     Plan p; Layout L;
-    plan_make(m, batch, training != 0, p, L);
+    plan_make(m, batch, training != 0, p, L, trainable);
     Exec e;
     e.m = &m; e.L = &L; e.B = batch; e.training = training != 0; e.params = params; e.buffers = buffers; e.counters = counters;
     e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = nullptr;
@@ -1163,7 +1243,7 @@ extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const flo
     GG_TRY(build_model(cfg, m));
     GG_CHECK(batch > 0 && params && wcache && workspace && d_out && grads, "gg_tinyvit_backward: null pointer / bad batch");
     Plan p; Layout L;
-    plan_make(m, batch, true, p, L);
+    plan_make(m, batch, true, p, L, trainable);          // the SAME mask the training forward was called with: it decides the workspace layout
     Exec e;
     e.m = &m; e.L = &L; e.B = batch; e.training = true; e.params = params; e.buffers = nullptr; e.counters = nullptr;
     e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = grads;

@@ -161,8 +161,8 @@ class TinyVitBackbone(FlatStore):
             self._wcache_version = self._synced_ver = ver
             self._dirty_all, self._dirty_only = False, None
 
-    def _workspace(self, batch: int, training: bool) -> torch.Tensor:
-        need = L.lib().gg_tinyvit_workspace_bytes(C.byref(self.cfg), batch, int(training))
+    def _workspace(self, batch: int, training: bool, mask=None) -> torch.Tensor:
+        need = L.lib().gg_tinyvit_workspace_bytes_masked(C.byref(self.cfg), batch, int(training), mask)
         if need < 0:
             raise L.GgError(L.lib().gg_last_error().decode())
         ws = self._ws.get(training)
@@ -187,8 +187,9 @@ class TinyVitBackbone(FlatStore):
             # .item() was a blocking sync per step), deterministic for a given generator seed and call order
             counts = self.__dict__.setdefault("_drop_gen_counts", {})
             seed = int(generator.initial_seed()) & (2 ** 62 - 1)
-            counter = counts.get(seed, 0)
-            counts[seed] = counter + 1
+            key = (id(generator), seed)          # per generator OBJECT: two generators seeded alike give the same rows, one generator advances
+            counter = counts.get(key, 0)
+            counts[key] = counter + 1
         else:
             if getattr(self, "_drop_seed", None) is None:
                 self._drop_seed, self._drop_counter = int(torch.randint(0, 2 ** 62, (1,)).item()), 0      # (CPU RNG, once per backbone)
@@ -216,11 +217,11 @@ class TinyVitBackbone(FlatStore):
         x = x.to(device=self._flat.device, dtype=torch.float32).contiguous()
         B = x.shape[0]
         self._ensure_weights()
-        ws = self._workspace(B, training)
+        mask = self.trainable_mask() if training else None      # the workspace keeps no activation that only a frozen weight's gradient would read
+        ws = self._workspace(B, training, mask)
         out = torch.empty((B, self.num_features), dtype=torch.float32, device=x.device)
         if drop_scales is not None:
             assert drop_scales.shape == (self.num_drop_slots, B) and drop_scales.dtype == torch.float32
-        mask = self.trainable_mask() if training else None      # the forward drops activations only frozen weights would need
         self._fwd_mask = mask
         L.check(L.lib().gg_tinyvit_forward(C.byref(self.cfg), B, int(training), L.ptr(self._flat), L.ptr(self._flat_buf),
                                            L.ptr(self._counters), L.ptr(self._wcache), L.ptr(x), L.ptr(drop_scales), L.ptr(ws),
@@ -262,10 +263,11 @@ class TinyVitBackbone(FlatStore):
         ws = self._ws[True]
         mask = self.trainable_mask()
         if getattr(self, "_fwd_mask", None) is not None and mask != self._fwd_mask:
-            extra = [t["name"] for t, a, b in zip([t for t in self.table], mask, self._fwd_mask) if a and not b]
-            if extra:
-                raise L.GgError("requires_grad was switched on between forward and backward for " + ", ".join(extra[:4]) +
-                                " ...: the training forward fused away activations their weight gradients need; run the forward again")
+            # the workspace was laid out (and activations were dropped) for the forward's mask: backward must see the same one
+            changed = [t["name"] for t, a, b in zip([t for t in self.table], mask, self._fwd_mask) if bool(a) != bool(b)]
+            raise L.GgError("requires_grad changed between forward and backward for " + ", ".join(changed[:4]) +
+                            " ...: the training forward laid out its workspace for the mask it saw (activations only a frozen weight's gradient "
+                            "needs are not kept); run the forward again")
         hook = self._grad_ready_hook
         cb = L.STAGE_DONE_FN(0)
         failed = []
@@ -293,8 +295,8 @@ class TinyVitBackbone(FlatStore):
     def activation(self, name: str, batch: int) -> torch.Tensor:
         """Raw bytes of a saved activation of the last training forward (parity tests)."""
         off, nbytes = C.c_int64(), C.c_int64()
-        L.check(L.lib().gg_tinyvit_activation_info(C.byref(self.cfg), batch, name.encode(), C.byref(off), C.byref(nbytes)),
-                "gg_tinyvit_activation_info")
+        L.check(L.lib().gg_tinyvit_activation_info_masked(C.byref(self.cfg), batch, name.encode(), getattr(self, "_fwd_mask", None), C.byref(off),
+                                                          C.byref(nbytes)), "gg_tinyvit_activation_info")
         return self._ws[True][off.value:off.value + nbytes.value]
 
     def forward(self, x):

@@ -387,7 +387,13 @@ int gg_tinyvit_num_drop_slots(const GgTinyVitCfg* cfg);        /* DropPath slots
  * scale_by_keep).  Counter-based: (seed, counter) fully determine the rows, the caller advances `counter` once per training forward. */
 int gg_drop_path_scales(const float* rates, int slots, int batch, uint64_t seed, uint64_t counter, float* out, void* stream);
 int64_t gg_tinyvit_wcache_bytes(const GgTinyVitCfg* cfg);      /* bf16 copies (W and W^T) of the GEMM weights */
-int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training);
+int64_t gg_tinyvit_workspace_bytes(const GgTinyVitCfg* cfg, int batch, int training);      /* = ..._masked(cfg, batch, training, NULL) */
+/* The training workspace depends on which tensors train (`trainable`: one byte per tensor of gg_tinyvit_tensor_info, NULL = all): the inputs of
+ * frozen Linears / depthwise convs (ln1, x1, ln2, GELU(fc1) of a TinyVitBlock; act1 / act2 of MBConv and PatchMerging) are read once, right after
+ * they are written, and share a two-slot ring instead of being kept for backward.  Under the reference's freeze_all_but_last_stage policy
+ * (models/tinyvit.py:106-111) that is 7 of a frozen block's 19 C floats per token.  gg_tinyvit_forward / _backward lay the workspace out for the
+ * mask they are CALLED with: pass the same mask to the size query, the forward and its backward. */
+int64_t gg_tinyvit_workspace_bytes_masked(const GgTinyVitCfg* cfg, int batch, int training, const uint8_t* trainable);
 int gg_tinyvit_refresh_weights(const GgTinyVitCfg* cfg, const float* params, void* wcache, void* stream);
 /* the same for a subset: `only` (host, one byte per tensor of gg_tinyvit_tensor_info) marks the tensors that changed (after an optimizer step: the trainable ones) */
 int gg_tinyvit_refresh_weights_masked(const GgTinyVitCfg* cfg, const float* params, void* wcache, const uint8_t* only, void* stream);
@@ -412,6 +418,8 @@ int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params,
                         GgStageDoneFn stage_done, void* stage_user);
 /* debug / parity: byte offset of a named saved activation inside the workspace (host) */
 int gg_tinyvit_activation_info(const GgTinyVitCfg* cfg, int batch, const char* name, int64_t* offset, int64_t* bytes);
+/* the same for the layout of a trainable mask; a tensor that is only a temporary under that mask is refused */
+int gg_tinyvit_activation_info_masked(const GgTinyVitCfg* cfg, int batch, const char* name, const uint8_t* trainable, int64_t* offset, int64_t* bytes);
 
 /* ---------------------------------------------------------------- either side of the encoder ("next" rows)
  * f3: the batch loop's input conditioning as one kernel (main_coordinator_idun_s3.py:337-381): bilinear resize

@@ -157,3 +157,37 @@ def test_weight_cache_dirty_mask_bookkeeping():
     assert bb._dirty_all is True and bb._dirty_only is None
     bb.mark_params_dirty(only=mask)                                   # ... and a later masked mark must not narrow it again
     assert bb._dirty_all is True
+
+
+def test_training_workspace_follows_the_trainable_mask():
+    """gg_tinyvit_workspace_bytes_masked: under the reference's freeze policy the inputs of frozen Linears / depthwise convs are temporaries (a
+    two-slot ring shared with the first gradient buffers), so the plan shrinks by > 20 %; an all-ones mask equals the unmasked plan; a temporary is
+    refused by gg_tinyvit_activation_info_masked while the tensors backward needs keep distinct, in-range regions."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    m = TinyViTAdapter("tiny_vit_21m_224", pretrained=False, precision="fp32")
+    bb = m.backbone
+    lib = L.lib()
+    B = 64
+    full = lib.gg_tinyvit_workspace_bytes(C.byref(bb.cfg), B, 1)
+    ones = bytes([1] * len(bb.table))
+    assert lib.gg_tinyvit_workspace_bytes_masked(C.byref(bb.cfg), B, 1, ones) == full
+    m.freeze_all_but_last_stage()
+    mask = bb.trainable_mask()
+    frz = lib.gg_tinyvit_workspace_bytes_masked(C.byref(bb.cfg), B, 1, mask)
+    assert 0 < frz < 0.8 * full, (frz, full)
+    assert lib.gg_tinyvit_workspace_bytes_masked(C.byref(bb.cfg), B, 0, mask) == lib.gg_tinyvit_workspace_bytes(C.byref(bb.cfg), B, 0)     # inference: no mask
+    off, nb = C.c_int64(), C.c_int64()
+    for name in ("stages.1.blocks.0.x1", "stages.2.blocks.3.ln2", "stages.2.blocks.3.fc1.act", "stages.0.blocks.0.act2"):
+        assert lib.gg_tinyvit_activation_info_masked(C.byref(bb.cfg), B, name.encode(), mask, C.byref(off), C.byref(nb)) != 0
+        assert b"not retained" in lib.gg_last_error()
+        assert lib.gg_tinyvit_activation_info_masked(C.byref(bb.cfg), B, name.encode(), ones, C.byref(off), C.byref(nb)) == 0      # kept when everything trains
+    spans = []
+    for name in ("stages.1.blocks.0.x2", "stages.1.blocks.0.qkv", "stages.1.blocks.0.attn.out", "stages.1.blocks.0.fc1.pre", "stages.3.blocks.1.x1",
+                 "stages.3.blocks.1.fc1.act", "stages.0.blocks.1.out", "scratch.G2"):
+        assert lib.gg_tinyvit_activation_info_masked(C.byref(bb.cfg), B, name.encode(), mask, C.byref(off), C.byref(nb)) == 0, name
+        assert 0 <= off.value and off.value + nb.value <= frz
+        spans.append((off.value, off.value + nb.value, name))
+    spans.sort()
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])), spans           # retained tensors never overlap

@@ -245,6 +245,49 @@ def test_default_tinyvit_adapter_is_the_512_model():
     assert gsum is not None and torch.isfinite(gsum).all() and float(gsum.abs().sum()) > 0
 
 
+def test_default_512_model_trains_at_batch_64_in_fp32_under_the_freeze_policy():
+    """The reference's default model (tiny_vit_21m_512, config.py:9; main_coordinator_idun_s3.py:212-215) in the reference's precision at 64 images:
+    the mask-aware workspace (inputs of frozen Linears / depthwise convs are temporaries) is < 45 GB -- 53 GB without the mask --, the training
+    step is finite and repeatable bit for bit, the embeddings of a sample do not depend on... the batch-statistics BatchNorm aside, frozen tensors get
+    no gradient and the trainable ones do, and a changed mask between forward and backward is refused."""
+    import ctypes as C
+    import warnings
+    from geoguessr_ai_amd import _lib as L
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = TinyViTAdapter(precision="fp32", drop_path_rate=0.0)
+    _randomize(m.backbone, 3)
+    m = m.cuda().train()
+    m.freeze_all_but_last_stage()
+    bb = m.backbone
+    B = 64
+    need = L.lib().gg_tinyvit_workspace_bytes_masked(C.byref(bb.cfg), B, 1, bb.trainable_mask())
+    assert need < 45e9 and need < 0.8 * L.lib().gg_tinyvit_workspace_bytes(C.byref(bb.cfg), B, 1)
+    x = torch.randn(B, 3, 512, 512, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    grads = []
+    for _ in range(2):
+        for p in bb._params.values():
+            p.grad = None
+        if bb._flat_grad is not None:
+            bb._flat_grad.zero_()
+        out = m(pixel_values=x).pooler_output
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        assert bb._ws[True].numel() == need, (bb._ws[True].numel(), need)
+        grads.append((out.detach().clone(), bb._params["stages.3.blocks.1.mlp.fc2.weight"].grad.clone(), bb._params["patch_embed.conv1.conv.weight"].grad.clone()))
+    assert all(torch.isfinite(t).all() for t in grads[0])
+    assert all(torch.equal(a, b) for a, b in zip(grads[0], grads[1]))                       # same batch, same weights: bit-identical step
+    assert float(grads[0][1].abs().sum()) > 0 and float(grads[0][2].abs().sum()) > 0
+    assert bb._params["stages.2.blocks.0.mlp.fc1.weight"].grad is None and bb._params["stages.0.blocks.0.conv2.conv.weight"].grad is None
+    out = m(pixel_values=x).pooler_output
+    bb._params["stages.2.blocks.0.mlp.fc1.weight"].requires_grad_(True)
+    bb._params["stages.2.blocks.0.mlp.fc1.bias"].requires_grad_(True)
+    with pytest.raises(L.GgError, match="requires_grad changed between forward and backward"):
+        out.sum().backward()
+
+
 @pytest.mark.parametrize("name", ["tiny_vit_21m_384"])
 def test_fp32_mode_large_windows_train_step(name, centroids):
     """24x24 = 576-token windows, fp32 mode, full train step vs the fp32 oracle incl. the attention-bias gradient of stage 3."""
