@@ -480,8 +480,10 @@ def run_mode(precision, args, rank, world, dev, x, lab):
         tot = {c: [0.0, 0, 0.0, 0.0] for c in range(len(CATS))}        # ms, launches, flops, bytes
         ideal_ms, mfma_bound_ms = 0.0, 0.0
         cat, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+        launches = []
         for i in range(lib.gg_prof_count()):
             L.check(lib.gg_prof_record(i, C.byref(cat), C.byref(ms), C.byref(fl), C.byref(by)), "gg_prof_record")
+            launches.append((cat.value, ms.value, fl.value, by.value))
             t = tot[cat.value]
             t[0] += ms.value; t[1] += 1; t[2] += fl.value; t[3] += by.value
             if cat.value == 0:
@@ -517,6 +519,12 @@ def run_mode(precision, args, rank, world, dev, x, lab):
                 pk = peak_tf * mhz / 2400.0
                 roof.update(shader_clock_mhz_under_load=round(mhz, 0), peak_at_measured_clock=round(pk, 1), frac_at_measured_clock=round(ach_tf / pk, 4))
         lib.gg_prof_reset()
+        if args.dump_launches and rank == 0:
+            # one step's launches in issue order (category, ms, algorithmic flops, algorithmic bytes): tools/pmc_traffic.py joins them with the PMC
+            # rows of the same kernels by order to get the HBM over-fetch of every GEMM launch form
+            per = len(launches) // args.steps
+            with open(args.dump_launches + "." + precision + ".json", "w") as f:
+                json.dump(dict(precision=precision, cats=CATS, launches=launches[(args.steps - 1) * per:]), f)
         breakdown["instrumented_ms_per_step"] = round(1e3 * dt_prof / args.steps, 3)
         res.update(roofline=roof, kernel_breakdown=breakdown)
     res["step_tflops"] = round(res["value"] * GFLOP_PER_IMAGE / 1e3, 2)
@@ -539,6 +547,7 @@ def main():
     ap.add_argument("--unfrozen", action="store_true", help="train every parameter instead of the reference freeze policy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch (category, ms, flops, bytes) list of one instrumented step to PATH.<precision>.json")
     ap.add_argument("--no-secondary", action="store_true", help="skip the c1 / c4 / c5 secondary timings (N = 1 only, ~15 s)")
     args = ap.parse_args()
 

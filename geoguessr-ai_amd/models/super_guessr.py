@@ -362,7 +362,7 @@ class SuperGuessr(nn.Module):
             mode = 0
         if not self.training and self.serving:
             mode = 0
-        head_in = embedding if (self.panorama or embedding.dim() == 2) else embedding
+        head_in = embedding
         if self.panorama and self.hierarchical:                 # (N, 4, C) -> self_attn(pos_encoder(x))[:, 0]  (:340-345)
             assert embedding.dim() == 3, "hierarchical=True expects (N, 4, C) embeddings"
             a = self.self_attn

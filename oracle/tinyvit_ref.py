@@ -6,7 +6,7 @@ instantiates through ``timm.create_model(name, num_classes=0, global_pool="avg")
 TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  PARITY UNPINNED: timm 1.0.21
 is not available in this image; this follows the published architecture
 (TinyViT, Wu et al. ECCV 2022) and is self-checked by
-``tests/test_oracle_tinyvit.py`` (parameter totals 20 621 568 / 5 071 764,
+``tests/test_oracle_models.py`` (parameter totals 20 621 568 / 5 071 764,
 state-dict key table, MAC totals 4.250 / 1.255 GMAC).
 
 Everything is functional: parameters and buffers live in a ``dict`` keyed by the

@@ -39,6 +39,40 @@ def load(path, counter):
     return tot, n, shape_tot, shape_n
 
 
+def gemm_forms(fpath, wpath, steps, launches_json, out_txt):
+    """Per GEMM launch FORM (kernel instantiation x grid): measured HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE, KB units) against the algorithmic bytes the
+    launch declares (bench.py --dump-launches), joined by issue order within a step: the i-th GEMM-category launch of the instrumented step is the
+    i-th gemm_nt_* / gemm_tn_* dispatch of a profiled step."""
+    def rows(path, counter):
+        r = [x for x in csv.DictReader(open(path)) if x["Counter_Name"] == counter and ("gemm_nt_" in x["Kernel_Name"] or "gemm_tn_" in x["Kernel_Name"])]
+        if r and "Dispatch_Id" in r[0]:
+            r.sort(key=lambda x: int(x["Dispatch_Id"]))
+        return r
+    F, W = rows(fpath, "FETCH_SIZE"), rows(wpath, "WRITE_SIZE")
+    d = json.load(open(launches_json))
+    gemm = [l for l in d["launches"] if l[0] == 0]
+    per = len(F) // steps
+    if per != len(gemm) or len(W) != len(F):
+        print(f"gemm_forms: {len(F)} / {len(W)} GEMM dispatches over {steps} steps vs {len(gemm)} instrumented launches per step: cannot join", file=sys.stderr)
+        return
+    agg = collections.OrderedDict()
+    for i, (cat, ms, fl, by) in enumerate(gemm):
+        f, w = F[(steps - 1) * per + i], W[(steps - 1) * per + i]
+        assert short(f["Kernel_Name"]) == short(w["Kernel_Name"])
+        key = (short(f["Kernel_Name"]), f.get("Grid_Size", "?"))
+        a = agg.setdefault(key, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += 2048.0 * float(f["Counter_Value"]); a[2] += 1024.0 * float(w["Counter_Value"]); a[3] += by; a[4] += fl; a[5] += ms
+    tot_meas = sum(a[1] + a[2] for a in agg.values()); tot_alg = sum(a[3] for a in agg.values())
+    with open(out_txt, "w") as o:
+        o.write(f"# HBM traffic of every GEMM launch form of one {d['precision']} step (TinyViT-21M-224, 1024 images): PMC (FETCH_SIZE x 2 + WRITE_SIZE) against the\n"
+                f"# algorithmic bytes each launch declares; joined by issue order.  total measured {tot_meas / 1e9:.1f} GB, algorithmic {tot_alg / 1e9:.1f} GB, ratio {tot_meas / tot_alg:.3f}\n")
+        o.write(f"{'kernel':92s} {'grid':>9s} {'n':>3s} {'alg GB':>8s} {'fetch GB':>9s} {'write GB':>9s} {'ratio':>6s} {'excess GB':>9s} {'ms':>7s} {'TFLOP/s':>8s}\n")
+        for (k, g), a in sorted(agg.items(), key=lambda kv: -((kv[1][1] + kv[1][2]) - kv[1][3])):
+            o.write(f"{k:92s} {g:>9s} {a[0]:3d} {a[3] / 1e9:8.2f} {a[1] / 1e9:9.2f} {a[2] / 1e9:9.2f} {(a[1] + a[2]) / max(a[3], 1):6.2f} {((a[1] + a[2]) - a[3]) / 1e9:9.2f} "
+                    f"{a[5]:7.2f} {a[4] / max(a[5], 1e-9) / 1e9:8.1f}\n")
+    print(open(out_txt).read()[:3000])
+
+
 def source_hash():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from geoguessr_ai_amd import _lib
@@ -47,6 +81,8 @@ def source_hash():
 
 def main():
     fpath, wpath, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    if len(sys.argv) > 6:
+        gemm_forms(fpath, wpath, steps, sys.argv[5], sys.argv[6])
     f, nf, sf, snf = load(fpath, "FETCH_SIZE")
     w, nw, sw, _ = load(wpath, "WRITE_SIZE")
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) on the command below; FETCH_SIZE doubled "
