@@ -312,7 +312,12 @@ def test_f32_convnorm_chain_backward_fused_into_gemms(ops, M, Cin, Cmid, Cout):
 
 @pytest.mark.parametrize("dtype", [F32, BF])
 @pytest.mark.parametrize("nh,D,ws,map_hw,batch,linearN", [(3, 32, 7, 14, 2, 0), (2, 32, 14, 14, 2, 0), (2, 32, 32, 32, 1, 0), (2, 32, 24, 24, 1, 0),
-                                                          (2, 64, 0, 0, 2, 577), (3, 64, 0, 0, 3, 50)])
+                                                          (2, 64, 0, 0, 2, 577), (3, 64, 0, 0, 3, 50),
+                                                          # edges of the single-pass backward / balanced forward dispatch: a 256-token window with bias (16 tiles: the
+                                                          # LDS budget decides), one tile, one token, 17 tokens (2 tiles, 1 live row), 256 tokens at head dim 64 (two-pass),
+                                                          # 80 tokens = 5 tiles (the smallest 4 n + 1 strip count: cooperative tail with 4 owner waves)
+                                                          (2, 32, 16, 16, 1, 0), (2, 32, 0, 0, 3, 16), (2, 32, 0, 0, 3, 1), (1, 32, 0, 0, 2, 17), (1, 64, 0, 0, 2, 256),
+                                                          (2, 64, 0, 0, 2, 80), (2, 32, 9, 18, 1, 0)])
 def test_flash_attention_forward_backward(ops, dtype, nh, D, ws, map_hw, batch, linearN):
     if ws:
         N, nw = ws * ws, batch * (map_hw // ws) ** 2
