@@ -1,0 +1,338 @@
+// EXPERIMENT ("the bf16 x 3 split"): an fp32-accurate GEMM on the bf16 matrix pipe.
+//
+//   C[M,N] (f32) = A[M,K] . B[N,K]^T   with   A = a1 + a2 + a3,  B = b1 + b2 + b3   (three bf16 terms each: 24 significand bits)
+//                = (a1 b3 + a2 b2 + a3 b1) + (a1 b2 + a2 b1) + a1 b1                  (six bf16 products, f32 accumulation; the dropped terms are < 2^-24)
+//
+// The fp32 MFMA of gfx950 runs at the vector ALU's rate (157 TFLOP/s; the model's large GEMMs already sit at the clock-limited 125-138); the bf16 MFMA
+// runs at 2.5 PFLOP/s, so six products are worth up to 417 TFLOP/s of fp32-equivalent work -- if a kernel keeps that pipe fed.  Run as ONE bf16 GEMM
+// over a 6 K contraction the library's 128^2 two-barrier kernel gives 133-141 (it re-reads every fragment from LDS once per product).  This kernel
+// stages the three planes of both operands together, so a fragment read from LDS feeds three (A) or up to three (B) products:
+//   * operands: pre-split bf16 planes in HBM, [3][rows][ld] (gg_split3_bf16 makes them; a production form would have the PRODUCER's epilogue write them);
+//   * tile 128 x 128, k-stage 32 (one v_mfma_f32_16x16x32_bf16 step), 512 threads = 2 x 4 waves (64 x 32 per wave: 4 x 2 MFMA tiles, 48 MFMAs per stage);
+//   * LDS-DMA (`buffer_load ... lds`, 16 B per lane, no VGPR staging) into a 3-stage ring of 6 plane tiles (48 KB per stage, two stages in flight), rows of 64 bytes with the
+//     16-byte chunk index XOR-ed with (row >> 2) & 3 on the SOURCE side of the DMA, so the fragment reads (ds_read_b128: 16 rows x one chunk) are
+//     conflict-free without padding;
+//   * one raw s_barrier per stage, the next stage's DMA in flight under the current stage's 48 MFMAs; two waves per SIMD.
+// Plain epilogue (optional bias), f32 result.  Not wired into the model runtimes: measured by tools/bench_split3.py next to the f32-MFMA GEMM.
+#include "common.h"
+#include <stdlib.h>
+#include "../../include/gg.h"
+
+namespace {
+
+struct Split3Params {
+    const bf16* A; int64_t lda, plane_a;      // planes a1, a2, a3 at A + i * plane_a (elements)
+    const bf16* B; int64_t ldb, plane_b;
+    float* C; int64_t ldc;
+    const float* bias;
+    int M, N, K, tilesM, tilesN;
+};
+
+constexpr int S3_BM = 128, S3_BN = 128, S3_SK = 32;          // tile, k-stage (bf16 elements): a row of a plane tile is 64 bytes
+constexpr int S3_TILE = S3_BM * S3_SK;                         // bf16 elements of one plane tile (8 KB)
+constexpr int S3_STAGE = 6 * S3_TILE;                          // a1 a2 a3 b1 b2 b3
+template <int N> __device__ __forceinline__ void wait_outstanding() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// WM x WN waves (each (128 / WM) x (128 / WN) of the tile); PIPE: fragments of stage s + 1 are read into a second register set under the MFMAs of stage s
+template <int WM, int WN, bool PIPE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Params p) {
+    constexpr int NW = WM * WN, TM = S3_BM / WM / 16, TN = S3_BN / WN / 16;
+    constexpr int IPT = 8 / NW;                                  // DMA instructions per plane tile and wave (a tile is 8 wave-slices of 16 rows = 1 KB)
+    constexpr int DPS = 6 * IPT;                                 // ... per stage and wave
+    static_assert(IPT >= 1 && IPT * NW == 8, "waves must divide the 8 slices of a plane tile");
+    extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    const int tm = bid / p.tilesN, tn = bid % p.tilesN;
+    const int m0 = tm * S3_BM, n0 = tn * S3_BN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+    // DMA geometry: slice sl = wave + NW j covers tile rows 16 sl .. 16 sl + 15: lane -> (row 16 sl + lane / 4, LDS chunk slot lane % 4); the slot holds SOURCE chunk
+    // slot ^ ((row >> 2) & 3) = slot ^ (lane >> 4) (16 sl does not touch bits 2-3)
+    const int dchunk = (lane & 3) ^ (lane >> 4);
+    const unsigned rowsA = (unsigned)min(p.M - m0, S3_BM), rowsB = (unsigned)min(p.N - n0, S3_BN);
+    __amdgpu_buffer_rsrc_t rs[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + i * p.plane_a + (int64_t)m0 * p.lda), 0, (int)(rowsA * (unsigned)p.lda * 2u), 0x00020000);
+        rs[3 + i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + i * p.plane_b + (int64_t)n0 * p.ldb), 0, (int)(rowsB * (unsigned)p.ldb * 2u), 0x00020000);
+    }
+    unsigned voffA[IPT], voffB[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const unsigned row = (unsigned)((wave + NW * j) * 16 + (lane >> 2));
+        voffA[j] = row * (unsigned)p.lda * 2u + dchunk * 16u;
+        voffB[j] = row * (unsigned)p.ldb * 2u + dchunk * 16u;
+    }
+    auto issue_stage = [&](int st, bf16* base) {
+        const int k0 = st * S3_SK;
+        const bool kin = k0 + dchunk * 8 < p.K;                 // K % 8 == 0: a chunk is entirely inside or outside (outside: range check -> zeros)
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < IPT; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], (__attribute__((address_space(3))) void*)(base + i * S3_TILE + (wave + NW * j) * 512), 16,
+                                                         (int)(kin ? (i < 3 ? voffA[j] : voffB[j]) : 0xFFFFFFF0u), k0 * 2, 0, 0);
+    };
+    // fragment addresses: row (16 t + lr) of a plane tile, k-chunk lg -> slot lg ^ ((lr >> 2) & 3) (the tile index t does not touch bits 2-3 of the row)
+    const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
+    const int a_off = (wm * (S3_BM / WM) + lr) * S3_SK + fslot, b_off = (wn * (S3_BN / WN) + lr) * S3_SK + fslot;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + S3_SK - 1) / S3_SK;
+    auto frag_read = [&](const bf16* cur, bf16x8 (&xf)[3][TM], bf16x8 (&wf)[3][TN]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * S3_TILE + a_off + mt * 16 * S3_SK);
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + (3 + pl) * S3_TILE + b_off + nt * 16 * S3_SK);
+        }
+    };
+    // small terms first: (a1 b3 + a2 b2 + a3 b1), (a1 b2 + a2 b1), a1 b1.  D = Wfrag x Xfrag: lane owns 4 consecutive n of row m = lr
+    auto mfma_stage = [&](const bf16x8 (&xf)[3][TM], const bf16x8 (&wf)[3][TN]) {
+#define S3_MFMA(PA, PB)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) _Pragma("unroll") for (int mt = 0; mt < TM; ++mt)             \
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB][nt], xf[PA][mt], acc[nt][mt], 0, 0, 0)
+        S3_MFMA(0, 2); S3_MFMA(1, 1); S3_MFMA(2, 0);
+        S3_MFMA(0, 1); S3_MFMA(1, 0);
+        S3_MFMA(0, 0);
+#undef S3_MFMA
+    };
+    issue_stage(0, s3mem);
+    if (nk > 1) issue_stage(1, s3mem + S3_STAGE);
+    if constexpr (PIPE) {
+        // 3-stage ring, software-pipelined: iteration s multiplies the fragments of stage s (already in registers) while the fragments of stage s + 1 are read
+        // from LDS into the other register set and the DMAs of stages s + 2 / s + 3 are in flight
+        bf16x8 xa[3][TM], wa[3][TN], xb[3][TM], wb[3][TN];
+        if (nk > 2) issue_stage(2, s3mem + 2 * S3_STAGE);
+        if (nk > 2) wait_outstanding<2 * DPS>(); else if (nk > 1) wait_outstanding<DPS>(); else wait_outstanding<0>();
+        __builtin_amdgcn_s_barrier();
+        frag_read(s3mem, xa, wa);
+        auto iter = [&](int s, int slot, bf16x8 (&xc)[3][TM], bf16x8 (&wc)[3][TN], bf16x8 (&xn)[3][TM], bf16x8 (&wn_)[3][TN]) {
+            const bool more = s + 1 < nk;
+            if (more) { if (s + 2 < nk) wait_outstanding<DPS>(); else wait_outstanding<0>(); }      // stage s + 1 landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of stage s are in registers ...
+            __builtin_amdgcn_s_barrier();                           // ... everybody's are: slot(s) may be refilled; everybody's DMAs of stage s + 1 have landed
+            if (s + 3 < nk) issue_stage(s + 3, s3mem + slot * S3_STAGE);
+            if (more) frag_read(s3mem + (slot == 2 ? 0 : slot + 1) * S3_STAGE, xn, wn_);
+            mfma_stage(xc, wc);
+        };
+        int slot = 0;
+        for (int s = 0; s < nk; s += 2) {
+            iter(s, slot, xa, wa, xb, wb);
+            slot = slot == 2 ? 0 : slot + 1;
+            if (s + 1 < nk) { iter(s + 1, slot, xb, wb, xa, wa); slot = slot == 2 ? 0 : slot + 1; }
+        }
+    } else {
+        // 3-stage ring, two stages in flight: the DMA of stage s + 2 is issued when stage s starts
+        int cb = 0;
+        for (int s = 0; s < nk; ++s) {
+            bf16* const cur = s3mem + cb * S3_STAGE;
+            if (s + 1 < nk) wait_outstanding<DPS>(); else wait_outstanding<0>();      // this wave's DMAs of stage s have landed (those of stage s + 1 may be in flight) ...
+            __builtin_amdgcn_s_barrier();                           // ... everybody's have, and every wave has read its fragments of stage s - 1
+            if (s + 2 < nk) issue_stage(s + 2, s3mem + (cb == 0 ? 2 : cb - 1) * S3_STAGE);      // into the slot stage s - 1 occupied
+            cb = cb == 2 ? 0 : cb + 1;
+            bf16x8 xf[3][TM], wf[3][TN];
+            frag_read(cur, xf, wf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mfma_stage(xf, wf);
+        }
+    }
+    // epilogue: lane holds C[m = m0 + (128 / WM) wm + 16 mt + lr][n = n0 + (128 / WN) wn + 16 nt + 4 lg + r]
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + wn * (S3_BN / WN) + nt * 16 + lg * 4;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
+        }
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+            const int m = m0 + wm * (S3_BM / WM) + mt * 16 + lr;
+            if (m >= p.M) continue;
+            const f32x4 v = acc[nt][mt] + b;
+            float* dst = p.C + (int64_t)m * p.ldc + n;
+            if (n + 3 < p.N && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+            else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+// Persistent form of the 2 x 4-wave kernel: one workgroup per CU walks tiles t, t + grid, ...; the first two stages of the NEXT tile are issued before the
+// current tile's epilogue, so the result stores and the next operands' latency overlap (with one 144 KB workgroup per CU nothing else would hide them:
+// at K = 384 a tile is 12 stages = 9 us of MFMAs next to ~1.5 us of first-operand latency and ~1 us of stores)
+__global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Params p) {
+    constexpr int WM = 2, WN = 4, NW = 8, TM = 4, TN = 2, DPS = 6;
+    extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
+    const int tiles = p.tilesM * p.tilesN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int dchunk = (lane & 3) ^ (lane >> 4);
+    const unsigned row = (unsigned)(wave * 16 + (lane >> 2));
+    const unsigned voffA = row * (unsigned)p.lda * 2u + dchunk * 16u, voffB = row * (unsigned)p.ldb * 2u + dchunk * 16u;
+    const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
+    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = (wn * 32 + lr) * S3_SK + fslot;
+    const int nk = (p.K + S3_SK - 1) / S3_SK;
+    __amdgpu_buffer_rsrc_t rs[6];
+    auto set_tile = [&](int t, int& m0, int& n0) {
+        const int bid = gg_xcd_remap(t, tiles);
+        m0 = (bid / p.tilesN) * S3_BM; n0 = (bid % p.tilesN) * S3_BN;
+        const unsigned rowsA = (unsigned)min(p.M - m0, S3_BM), rowsB = (unsigned)min(p.N - n0, S3_BN);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + i * p.plane_a + (int64_t)m0 * p.lda), 0, (int)(rowsA * (unsigned)p.lda * 2u), 0x00020000);
+            rs[3 + i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + i * p.plane_b + (int64_t)n0 * p.ldb), 0, (int)(rowsB * (unsigned)p.ldb * 2u), 0x00020000);
+        }
+    };
+    auto issue_stage = [&](int st, bf16* base) {
+        const int k0 = st * S3_SK;
+        const bool kin = k0 + dchunk * 8 < p.K;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], (__attribute__((address_space(3))) void*)(base + i * S3_TILE + wave * 512), 16,
+                                                     (int)(kin ? (i < 3 ? voffA : voffB) : 0xFFFFFFF0u), k0 * 2, 0, 0);
+    };
+    int m0, n0;
+    int t = blockIdx.x;
+    if (t >= tiles) return;
+    set_tile(t, m0, n0);
+    issue_stage(0, s3mem);
+    if (nk > 1) issue_stage(1, s3mem + S3_STAGE);
+    for (; t < tiles; t += gridDim.x) {
+        f32x4 acc[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int cb = 0;
+        for (int s = 0; s < nk; ++s) {
+            bf16* const cur = s3mem + cb * S3_STAGE;
+            // (stage 0 of a tile: the previous tile's result stores were issued after this tile's first DMAs -- in-order return, so wait for everything)
+            if (s + 1 < nk && s > 0) wait_outstanding<DPS>(); else wait_outstanding<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < nk) issue_stage(s + 2, s3mem + (cb == 0 ? 2 : cb - 1) * S3_STAGE);
+            cb = cb == 2 ? 0 : cb + 1;
+            bf16x8 xf[3][TM], wf[3][TN];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * S3_TILE + a_off + mt * 16 * S3_SK);
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + (3 + pl) * S3_TILE + b_off + nt * 16 * S3_SK);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define S3_MFMA(PA, PB)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) _Pragma("unroll") for (int mt = 0; mt < TM; ++mt)             \
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB][nt], xf[PA][mt], acc[nt][mt], 0, 0, 0)
+            S3_MFMA(0, 2); S3_MFMA(1, 1); S3_MFMA(2, 0);
+            S3_MFMA(0, 1); S3_MFMA(1, 0);
+            S3_MFMA(0, 0);
+#undef S3_MFMA
+        }
+        const int em0 = m0, en0 = n0;
+        // next tile's first operands: every wave has read the last stage's fragments once it passes this barrier, so slots 0 / 1 are free
+        // (the next tile starts its ring at slot 0 again)
+        __builtin_amdgcn_s_barrier();
+        if (t + (int)gridDim.x < tiles) {
+            set_tile(t + gridDim.x, m0, n0);
+            issue_stage(0, s3mem);
+            if (nk > 1) issue_stage(1, s3mem + S3_STAGE);
+        }
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+            const int n = en0 + wn * 32 + nt * 16 + lg * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
+            }
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) {
+                const int m = em0 + wm * 64 + mt * 16 + lr;
+                if (m >= p.M) continue;
+                const f32x4 v = acc[nt][mt] + b;
+                float* dst = p.C + (int64_t)m * p.ldc + n;
+                if (n + 3 < p.N && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = v[r];
+                }
+            }
+        }
+    }
+}
+
+// x (f32, [rows][ldx]) -> planes [3][rows][cols] bf16: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx, bf16* __restrict__ out) {
+    const int64_t n4 = rows * (cols / 4);
+    const int64_t plane = rows * cols;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (cols / 4);
+        const int c = (int)(i - r * (cols / 4)) * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16 a = (bf16)v[j];
+            const float r1 = v[j] - (float)a;
+            const bf16 b = (bf16)r1;
+            p1[j] = a; p2[j] = b; p3[j] = (bf16)(r1 - (float)b);
+        }
+        *reinterpret_cast<bf16x4*>(out + r * cols + c) = p1;
+        *reinterpret_cast<bf16x4*>(out + plane + r * cols + c) = p2;
+        *reinterpret_cast<bf16x4*>(out + 2 * plane + r * cols + c) = p3;
+    }
+}
+
+}  // namespace
+
+extern "C" int gg_split3_bf16(const float* x, int64_t rows, int cols, int64_t ldx, void* planes, void* stream) {
+    GG_CHECK(x && planes && rows > 0 && cols > 0 && (cols & 3) == 0 && (ldx & 3) == 0 && ldx >= cols && ((uintptr_t)x & 15) == 0 && ((uintptr_t)planes & 7) == 0,
+             "gg_split3_bf16: bad args (cols %% 4, ldx %% 4, 16-byte aligned x)");
+    GG_PROF(GG_CAT_MOVE, 0, 10.0 * rows * cols, stream);
+    const int64_t n4 = rows * (cols / 4);
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(n4, 256), 16384)), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ldx, (bf16*)planes);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                                 const float* bias, void* stream) {
+    GG_CHECK(a_planes && b_planes && C && M > 0 && N > 0 && K > 0, "gg_gemm_nt_split3: null pointer / bad shape");
+    GG_CHECK((K & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && lda >= K && ldb >= K && ldc >= N, "gg_gemm_nt_split3: K, lda, ldb must be multiples of 8, ld >= K / N");
+    GG_CHECK(((uintptr_t)a_planes & 15) == 0 && ((uintptr_t)b_planes & 15) == 0 && ((uintptr_t)C & 15) == 0, "gg_gemm_nt_split3: 16-byte alignment");
+    GG_CHECK((int64_t)128 * lda * 2 < ((int64_t)1 << 31) && (int64_t)128 * ldb * 2 < ((int64_t)1 << 31), "gg_gemm_nt_split3: row pitch too large");
+    Split3Params p;
+    p.A = (const bf16*)a_planes; p.lda = lda; p.plane_a = (int64_t)M * lda;
+    p.B = (const bf16*)b_planes; p.ldb = ldb; p.plane_b = (int64_t)N * ldb;
+    p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
+    p.tilesM = (int)gg_cdiv(M, S3_BM); p.tilesN = (int)gg_cdiv(N, S3_BN);
+    const size_t lds = (size_t)3 * S3_STAGE * sizeof(bf16);       // 144 KB: one workgroup (8 waves) per CU
+    // form: 0 = 2 x 4 waves, fragments read before the MFMAs (default); 1 = the same, software-pipelined; 2 = 2 x 2 waves (64 x 64 per wave), pipelined;
+    // 3 = form 0 as persistent workgroups with the next tile's first stages issued before the epilogue
+    static const char* fenv = gg_dev_env("GG_SPLIT3_FORM");
+    const int form = fenv ? atoi(fenv) : 0;
+    void (*kern)(Split3Params) = form == 3 ? gemm_nt_split3_persistent_kernel : form == 2 ? gemm_nt_split3_kernel<2, 2, true> : form == 1 ? gemm_nt_split3_kernel<2, 4, true> : gemm_nt_split3_kernel<2, 4, false>;
+    static bool raised[4] = {false, false, false, false};
+    const int fi = form >= 0 && form <= 3 ? form : 0;
+    if (!raised[fi]) {
+        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                 "gg_gemm_nt_split3: cannot raise the dynamic LDS limit");
+        raised[fi] = true;
+    }
+    // algorithmic work = the fp32 product it replaces: 2 M N K flop; bytes: three bf16 planes per operand + the f32 result
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N, stream);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(form == 3 ? std::min(p.tilesM * p.tilesN, 256) : p.tilesM * p.tilesN)), dim3(form == 2 ? 256 : 512), lds, (hipStream_t)stream, p);
+    GG_LAUNCH_CHECK();
+    return 0;
+}

@@ -211,6 +211,14 @@ int64_t gg_attention_flash_ds_scratch_floats(int num_windows, int num_heads, int
  * one CU's LDS): ds_scratch is then neither needed nor read -- workspace planners skip it. */
 int gg_attention_flash_single_pass(int tokens_per_window, int head_dim, int window_size, int with_dbias);
 
+/* ---------------------------------------------------------------- experiment: fp32-accurate GEMM on the bf16 matrix pipe
+ * Not part of the drop-in path (no reference interface behind it): measured by tools/bench_split3.py next to gg_gemm_nt_f32.
+ * gg_split3_bf16: x (f32 [rows][ldx]) -> planes bf16 [3][rows][cols] with x = p1 + p2 + p3 to 24 bits.
+ * gg_gemm_nt_split3: C[M,N] (f32) = A . B^T from the planes of both operands (six bf16 MFMA products, f32 accumulation); K, lda, ldb multiples of 8. */
+int gg_split3_bf16(const float* x, int64_t rows, int cols, int64_t ldx, void* planes, void* stream);
+int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,
+                      void* stream);
+
 /* ---------------------------------------------------------------- reference-precision (fp32) mode
  * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins
  * of the kernels above: f32 activations [tokens, channels], f32 MFMA (v_mfma_f32_16x16x4_f32 -- exact f32 products, f32

@@ -623,6 +623,34 @@ def test_clip_attention_fwd_fp16(ops, B, T, nh, hd):
     close(lse, lse_ref, rtol=1e-3, atol=1e-3, what="clip attn fp16 lse")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 200, 96), (1000, 48, 40), (4099, 384, 384), (129, 1153, 1536), (64, 130, 8)])
+def test_split3_gemm_is_fp32_accurate(M, N, K):
+    """Experiment kernel: C = A . B^T from three bf16 planes per operand (six bf16 MFMA products, f32 accumulation).  The planes sum to the
+    f32 input to 24 bits; the product matches an fp64 product at the level of the f32-MFMA GEMM (rel-L2 < 1e-6) on ragged shapes, a K tail shorter than
+    the 32-element stage, and with a bias."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+
+    def planes(x):
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().gg_split3_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), L.stream()), "gg_split3_bf16")
+        return out
+    Ap, Bp = planes(A), planes(B)
+    resid = (A.double() - Ap.double().sum(0)).abs().max() / A.abs().max()
+    assert float(resid) < 2 ** -22, float(resid)                      # x1 + x2 + x3 reproduces x to (at least) 23 bits
+    out = torch.empty(M, N, device="cuda")
+    L.check(L.lib().gg_gemm_nt_split3(Ap.data_ptr(), K, Bp.data_ptr(), K, out.data_ptr(), N, M, N, K, bias.data_ptr(), L.stream()), "gg_gemm_nt_split3")
+    ref = A.double() @ B.double().T + bias.double()
+    e = float((out.double() - ref).norm() / ref.norm())
+    e32 = float((ops.gemm_nt(A, B, bias=bias).double() - ref).norm() / ref.norm())
+    print(f"\n[split3 {M}x{N}x{K}] rel-L2 vs fp64: split3 {e:.2e}, f32-MFMA {e32:.2e}")
+    assert e < 1e-6 and e < 2.5 * e32 + 1e-7
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os

@@ -7,8 +7,23 @@ split is done with torch glue and is not timed; a production form would split in
 Shapes: the stage-2 / stage-3 transformer GEMMs of the 1024-image TinyViT-21M step."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
 import torch
-from geoguessr_ai_amd import ops
+from geoguessr_ai_amd import ops, _lib as L
+
+
+def planes(x):
+    """gg_split3_bf16: f32 [rows][cols] -> bf16 [3][rows][cols]"""
+    out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device=x.device)
+    L.check(L.lib().gg_split3_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), L.stream()), "gg_split3_bf16")
+    return out
+
+
+def gemm_split3(Ap, Bp, out):
+    M, K = Ap.shape[1], Ap.shape[2]
+    N = Bp.shape[1]
+    L.check(L.lib().gg_gemm_nt_split3(Ap.data_ptr(), K, Bp.data_ptr(), K, out.data_ptr(), out.stride(0), M, N, K, None, L.stream()), "gg_gemm_nt_split3")
+    return out
 
 
 def timed(fn, n=5):
@@ -31,7 +46,7 @@ def main():
     dev = "cuda"
     shapes = [("s2.qkv", 200704, 1152, 384), ("s2.fc1", 200704, 1536, 384), ("s2.fc2", 200704, 384, 1536), ("s2.proj", 200704, 384, 384),
               ("s3.fc1", 50176, 2304, 576), ("s3.fc2", 50176, 576, 2304)]
-    print(f"{'shape':8s} {'M':>7s} {'N':>5s} {'K':>5s} | f32-MFMA us  TF/s | bf16x3 (6K) us  TF/s-eq | plain bf16 us | rel-L2 err vs fp64: f32-MFMA  bf16x3   bf16 | max|err|/max|ref|: f32-MFMA  bf16x3")
+    print(f"{'shape':8s} {'M':>7s} {'N':>5s} {'K':>5s} | f32-MFMA us  TF/s | bf16x3 (6K) us  TF/s-eq | split3 kernel us  TF/s-eq  (+A split us) | plain bf16 us | rel-L2 err vs fp64: f32-MFMA  bf16x3(6K)  split3   bf16 | max|err|/max|ref|: f32-MFMA  split3")
     for name, M, N, K in shapes:
         g = torch.Generator(device=dev).manual_seed(1)
         A = torch.randn(M, K, device=dev, generator=g)
@@ -43,16 +58,21 @@ def main():
         t32 = timed(lambda: ops.gemm_nt(A, B, out=out32))
         t6 = timed(lambda: ops.gemm_nt(A6, B6, out_f32=True, out=out6))
         t16 = timed(lambda: ops.gemm_nt(a1, b1, out_f32=True, out=out16))
+        Ap, Bp = planes(A), planes(B)
+        assert torch.equal(Ap[0], a1) and torch.equal(Ap[1], a2) and torch.equal(Ap[2], a3)            # the split kernel = the torch expression
+        outs = torch.empty(M, N, device=dev)
+        ts = timed(lambda: gemm_split3(Ap, Bp, outs))
+        tsp = timed(lambda: planes(A))
         rows = 4096
         ref = A[:rows].double() @ B.double().T
         def err(o):
             d = o[:rows].double() - ref
             return float(d.norm() / ref.norm()), float(d.abs().max() / ref.abs().max())
-        e32, e6, e16 = err(out32), err(out6), err(out16)
+        e32, e6, e16, es = err(out32), err(out6), err(out16), err(outs)
         fl = 2.0 * M * N * K
-        print(f"{name:8s} {M:7d} {N:5d} {K:5d} | {t32*1e3:9.1f} {fl/t32/1e9:6.1f} | {t6*1e3:12.1f} {fl/t6/1e9:8.1f} | {t16*1e3:10.1f} | "
-              f"{e32[0]:.2e} {e6[0]:.2e} {e16[0]:.2e} | {e32[1]:.2e} {e6[1]:.2e}", flush=True)
-        del A, B, A6, B6, out32, out6, out16, a1, a2, a3, b1, b2, b3
+        print(f"{name:8s} {M:7d} {N:5d} {K:5d} | {t32*1e3:9.1f} {fl/t32/1e9:6.1f} | {t6*1e3:12.1f} {fl/t6/1e9:8.1f} | {ts*1e3:13.1f} {fl/ts/1e9:8.1f}  ({tsp*1e3:8.1f}) | {t16*1e3:10.1f} | "
+              f"{e32[0]:.2e} {e6[0]:.2e} {es[0]:.2e} {e16[0]:.2e} | {e32[1]:.2e} {es[1]:.2e}", flush=True)
+        del A, B, A6, B6, out32, out6, out16, outs, Ap, Bp, a1, a2, a3, b1, b2, b3
         torch.cuda.empty_cache()
 
 
