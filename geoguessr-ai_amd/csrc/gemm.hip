@@ -6,7 +6,7 @@
 //
 // Tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves in 2x2, each wave 64x64 = 4x4 tiles of
 // v_mfma_f32_16x16x32_bf16.  The MFMA is issued as D = Wfrag x Xfrag, i.e. D[i=n][j=m], so one
-// lane ends up with 4 consecutive n of a single row m -> 8-byte bf16x4 / 16-byte f32x4 stores
+// lane ends up with 4 consecutive n of a single row m -> 8-byte ge4_t / 16-byte f32x4 stores
 // along the contiguous dimension of C and vectorised bias / residual / pre-activation access.
 #include "common.h"
 #include <stdlib.h>
@@ -14,24 +14,41 @@
 
 #define BK 64
 
+// Element type of this build.  The file is compiled twice: as is (bf16: the bf16 mode's GEMM, gg_gemm_nt) and once more from gemm_f16.hip with
+// GG_GEMM_ELEM_F16 inside namespace gg_f16 (fp16: the CLIP tower's fp16 inference mode, gg_gemm_nt_f16).  Tiling, LDS swizzle, buffer-load staging and the
+// epilogue classes only see 16-bit elements in 16-byte chunks; what differs is named here: the element / vector types and the MFMA instruction.
+#ifdef GG_GEMM_ELEM_F16
+typedef f16 ge_t;
+typedef f16x8 ge8_t;
+typedef f16x4 ge4_t;
+typedef f16 ge2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 ge_mfma(ge8_t a, ge8_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#else
+typedef bf16 ge_t;
+typedef bf16x8 ge8_t;
+typedef bf16x4 ge4_t;
+typedef bf16x2 ge2_t;
+__device__ __forceinline__ f32x4 ge_mfma(ge8_t a, ge8_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
+
 struct GemmParams {
-    const bf16* A; int64_t lda;
-    const bf16* B; int64_t ldb;
+    const ge_t* A; int64_t lda;
+    const ge_t* B; int64_t ldb;
     void* C; int64_t ldc;
     int M, N, K;
     const float* bias;
     int act;
-    bf16* preact;                 // optional copy of (acc+bias) before the activation
+    ge_t* preact;                 // optional copy of (acc+bias) before the activation
     const float* rowscale; int rows_per_scale;
-    const bf16* residual; int64_t ldr;
-    const bf16* dact_preact; int dact;   // out = v * act'(dact_preact[m][n]) (backward through fc1's activation)
+    const ge_t* residual; int64_t ldr;
+    const ge_t* dact_preact; int dact;   // out = v * act'(dact_preact[m][n]) (backward through fc1's activation)
     float* colstats;              // [tilesM][2][N]: per M-tile column sum / sum of squares of (acc)
     int out_f32;
     int split_k, k_per_split;     // split_k > 1: C is f32 [split][M][N] partials
     int tilesM, tilesN;
     int debug;                    // timing experiments only: 1 = no operand loads, 2 = no result stores
-    const bf16* A2; int k_split;  // optional second A source for contraction columns k >= k_split (same lda)
-    const bf16* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;   // EPI_BNBWD
+    const ge_t* A2; int k_split;  // optional second A source for contraction columns k >= k_split (same lda)
+    const ge_t* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;   // EPI_BNBWD
     const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;   // PRO: A := act(BN(A)) while staging
 };
 
@@ -60,11 +77,11 @@ enum { EPI_PLAIN = 0,    // raw accumulators (+ optional BatchNorm column statis
 // The second tensor of the row phase (residual / saved pre-activation / saved BatchNorm input) for this thread's row-phase
 // slots: range-checked 16-byte buffer loads, all passes in flight at once; rows beyond M and chunks beyond N read as zeros.
 template <int BM, int BN, int EPI>
-__device__ __forceinline__ void gemm_ext_load(const GemmParams& p, int m0, int n0, bf16x8 (&ex)[BM / (256 / (BN / 8))]) {
+__device__ __forceinline__ void gemm_ext_load(const GemmParams& p, int m0, int n0, ge8_t (&ex)[BM / (256 / (BN / 8))]) {
     constexpr int CPR = BN / 8, RPP = 256 / CPR, NP = BM / RPP;
     const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
     const int n = n0 + chunk * 8;
-    const bf16* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : (EPI == EPI_BNBWD ? p.bn_y : nullptr));
+    const ge_t* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : (EPI == EPI_BNBWD ? p.bn_y : nullptr));
     const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
     if ((EPI == EPI_DGELU || EPI == EPI_LINEAR || EPI == EPI_BNBWD) && ext) {
         if (((lde & 7) == 0) && ((p.N & 7) == 0) && (((uintptr_t)ext & 15) == 0)) {
@@ -77,13 +94,13 @@ __device__ __forceinline__ void gemm_ext_load(const GemmParams& p, int m0, int n
             for (int pass = 0; pass < NP; ++pass) {
                 const unsigned vo = ((unsigned)(pass * RPP + rr) * (unsigned)lde + (unsigned)n) * 2u;
                 const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)(n < p.N ? vo : 0xFFFFFFF0u), 0, 0);
-                ex[pass] = __builtin_bit_cast(bf16x8, raw);
+                ex[pass] = __builtin_bit_cast(ge8_t, raw);
             }
         } else {
 #pragma unroll
             for (int pass = 0; pass < NP; ++pass) {
                 const int m = m0 + pass * RPP + rr;
-                bf16x8 d = {0, 0, 0, 0, 0, 0, 0, 0};
+                ge8_t d = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (m < p.M) { for (int j = 0; j < 8; ++j) if (n + j < p.N) d[j] = ext[(int64_t)m * lde + n + j]; }
                 ex[pass] = d;
             }
@@ -92,8 +109,8 @@ __device__ __forceinline__ void gemm_ext_load(const GemmParams& p, int m0, int n
 }
 
 template <int BM, int BN, int WM, int WN, int EPI, bool PRELOADED>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
-                                              int tm, int z, int wm, int wn, int lr, int lg, bf16x8 (&ex)[BM / (256 / (BN / 8))], const float* btab) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, ge_t* smem, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], int m0, int n0,
+                                              int tm, int z, int wm, int wn, int lr, int lg, ge8_t (&ex)[BM / (256 / (BN / 8))], const float* btab) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     // ---------------- lane holds C[m = .. + mt*16 + lr][n = .. + nt*16 + lg*4 + r] ----------------
@@ -153,7 +170,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
     constexpr int CPR = BN / 8;                     // 16-byte chunks per staged row
     constexpr int RPP = 256 / CPR;                  // rows per cooperative pass
     constexpr int NP = BM / RPP;
-    bf16* Cs = smem;
+    ge_t* Cs = smem;
     float rsv[TM];
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
@@ -177,8 +194,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] *= rsv[mt];
             }
-            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *reinterpret_cast<bf16x4*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
+            ge4_t o = {(ge_t)v[0], (ge_t)v[1], (ge_t)v[2], (ge_t)v[3]};
+            *reinterpret_cast<ge4_t*>(Cs + (wm * WROWS + mt * 16 + lr) * CS + wn * WCOLS + nt * 16 + lg * 4) = o;
         }
     // ---------------- row phase: thread = (row rr + pass*RPP, 16-byte column chunk) ----------------
     const int chunk = threadIdx.x % CPR, rr = threadIdx.x / CPR;
@@ -205,25 +222,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
 #pragma unroll
     for (int j = 0; j < 4; ++j) cs2[j] = cq2[j] = (f32x2)(0.f);
     const bool bn_gelu = p.bn_act == GG_ACT_GELU;
-    auto store8 = [&](bf16* base, int m, const bf16x8& v, bool stream_out = false) {
-        bf16* g = base + (int64_t)m * p.ldc + n;
+    auto store8 = [&](ge_t* base, int m, const ge8_t& v, bool stream_out = false) {
+        ge_t* g = base + (int64_t)m * p.ldc + n;
         if (wide) {
-            if (stream_out) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(g));    // read back only in the backward pass
-            else *reinterpret_cast<bf16x8*>(g) = v;
+            if (stream_out) __builtin_nontemporal_store(v, reinterpret_cast<ge8_t*>(g));    // read back only in the backward pass
+            else *reinterpret_cast<ge8_t*>(g) = v;
         } else { for (int j = 0; j < 8; ++j) if (n + j < p.N) g[j] = v[j]; }
     };
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass) {
         const int row = pass * RPP + rr, m = m0 + row;
         if (m >= p.M || n >= p.N) continue;
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(Cs + row * CS + chunk * 8);
+        ge8_t v = *reinterpret_cast<const ge8_t*>(Cs + row * CS + chunk * 8);
         if (EPI == EPI_BNBWD && !(p.debug & 8)) {
             // dz = da * act'(gamma*xhat + beta); column sums of dz and dz*xhat (of the stored, bf16-rounded dz)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x2 y = {(float)ex[pass][2 * j], (float)ex[pass][2 * j + 1]};
                 const f32x2 d = (f32x2){(float)v[2 * j], (float)v[2 * j + 1]} * gg_act_grad_v2(y * bsc[j] + bsh[j], bn_gelu);
-                const bf16 d0 = (bf16)d.x, d1 = (bf16)d.y;
+                const ge_t d0 = (ge_t)d.x, d1 = (ge_t)d.y;
                 v[2 * j] = d0; v[2 * j + 1] = d1;
                 const f32x2 dr = {(float)d0, (float)d1};
                 cs2[j] += dr; cq2[j] += dr * (y * brs[j] + bnm[j]);
@@ -238,32 +255,32 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, bf16* smem, f
             if (p.preact) store8(p.preact, m, v, true);
             if (p.act == GG_ACT_QUICK_GELU) {       // CLIP fc1 in training (uniform branch: the pre-activation copy lives in this epilogue class)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (bf16)gg_quick_gelu((float)v[j]);
+                for (int j = 0; j < 8; ++j) v[j] = (ge_t)gg_quick_gelu((float)v[j]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     const f32x2 r = gg_gelu_v2((f32x2){(float)v[j], (float)v[j + 1]});
-                    v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+                    v[j] = (ge_t)r.x; v[j + 1] = (ge_t)r.y;
                 }
             }
         }
         if (EPI == EPI_DGELU) {
             if (p.dact == GG_ACT_QUICK_GELU) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] * gg_quick_gelu_grad((float)ex[pass][j]));
+                for (int j = 0; j < 8; ++j) v[j] = (ge_t)((float)v[j] * gg_quick_gelu_grad((float)ex[pass][j]));
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
                     const f32x2 r = (f32x2){(float)v[j], (float)v[j + 1]} * gg_gelu_grad_v2((f32x2){(float)ex[pass][j], (float)ex[pass][j + 1]});
-                    v[j] = (bf16)r.x; v[j + 1] = (bf16)r.y;
+                    v[j] = (ge_t)r.x; v[j + 1] = (ge_t)r.y;
                 }
             }
         }
         if (EPI == EPI_LINEAR && p.residual) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (bf16)((float)v[j] + (float)ex[pass][j]);
+            for (int j = 0; j < 8; ++j) v[j] = (ge_t)((float)v[j] + (float)ex[pass][j]);
         }
-        store8(reinterpret_cast<bf16*>(p.C), m, v);
+        store8(reinterpret_cast<ge_t*>(p.C), m, v);
     }
     if (stats && !(p.debug & 16)) {
         __syncthreads();
@@ -305,10 +322,10 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;     // 16-byte chunks per thread per k-tile
     constexpr int OPER = (BM + BN) * BK, STAGE = BM * (BN + 8);
-    __shared__ __attribute__((aligned(16))) bf16 smem[OPER > STAGE ? OPER : STAGE];
+    __shared__ __attribute__((aligned(16))) ge_t smem[OPER > STAGE ? OPER : STAGE];
     __shared__ __attribute__((aligned(16))) float ptab[PRO ? 2048 : 4];      // PRO: [scale[K] | shift[K]], K <= 1024
-    bf16* As = smem;
-    bf16* Bs = smem + BM * BK;
+    ge_t* As = smem;
+    ge_t* Bs = smem + BM * BK;
     if (PRO) {
         for (int k = threadIdx.x; k < p.K; k += 256) {
             const float sc = p.a_gamma[k] * p.a_stat[p.K + k];
@@ -366,7 +383,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     constexpr bool EARLY = false;          // fetching the epilogue's second tensor before the k-loop: measured no gain, +24 VGPRs
-    bf16x8 ex[BM / (256 / (BN / 8))];
+    ge8_t ex[BM / (256 / (BN / 8))];
     __shared__ __attribute__((aligned(16))) float btab[EPI == EPI_BNBWD ? 4 * BN : 4];
     if (EPI == EPI_BNBWD && threadIdx.x < BN) {
         const int c = min(n0 + (int)threadIdx.x, p.N - 1);
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
         btab[2 * BN + threadIdx.x] = rstd; btab[3 * BN + threadIdx.x] = -mu * rstd;
     }
     if (EARLY && !(p.debug & 4)) gemm_ext_load<BM, BN, EPI>(p, m0, n0, ex);
-    if (EARLY && (p.debug & 4)) { for (auto& e : ex) e = (bf16x8){1, 1, 1, 1, 1, 1, 1, 1}; }
+    if (EARLY && (p.debug & 4)) { for (auto& e : ex) e = (ge8_t){1, 1, 1, 1, 1, 1, 1, 1}; }
     u32x4 ra[LA], rb[LB];
     const int nk = (kend - kbeg + BK - 1) / BK;
     auto load_tile = [&](int kt) {
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
                 for (int q = 0; q < 4; ++q) {
                     const f32x2 v = {__uint_as_float(ra[i][q] << 16), __uint_as_float(ra[i][q] & 0xffff0000u)};
                     const f32x2 r = gg_act_v2(v * sc[q] + sh[q], pro_gelu);
-                    const bf16 lo = (bf16)r.x, hi = (bf16)r.y;
+                    const ge_t lo = (ge_t)r.x, hi = (ge_t)r.y;
                     const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, lo) | ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
                     ra[i][q] = rok ? pk : 0u;
                 }
@@ -426,16 +443,16 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
         for (int ks = 0; ks < 2; ++ks) {
             if (ks < ksteps) {
                 const int kc = ks ? kc1 : kc0;
-                bf16x8 xf[TM], wf[TN];
+                ge8_t xf[TM], wf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(As + a_base + i * 16 * BK + kc);
+                for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const ge8_t*>(As + a_base + i * 16 * BK + kc);
 #pragma unroll
-                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(Bs + b_base + i * 16 * BK + kc);
+                for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const ge8_t*>(Bs + b_base + i * 16 * BK + kc);
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < TM; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                        acc[nt][mt] = ge_mfma(wf[nt], xf[mt], acc[nt][mt]);
             }
         }
         __syncthreads();
@@ -449,23 +466,23 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
 // no transposed copies of dY and X in HBM.  Output tile 128(n) x 128(k), 2x2 waves; the m range is split over
 // blockIdx.y and each split writes an fp32 slab part[split][N][K] (deterministic; reduced by splitk_reduce_kernel).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tn_frag(const bf16* T, int RS, int col, int lr, int lg) {
+__device__ __forceinline__ ge8_t tn_frag(const ge_t* T, int RS, int col, int lr, int lg) {
     // lane (lr, lg) <- T[4lg + q][col + lr], T[16 + 4lg + q][col + lr]  (q = 0..3); lane 4q+p of a 16-lane group supplies the
     // address of row q, columns 4p..4p+3
-    const bf16* p0 = T + (4 * lg + (lr >> 2)) * RS + col + 4 * (lr & 3);
+    const ge_t* p0 = T + (4 * lg + (lr >> 2)) * RS + col + 4 * (lr & 3);
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 16 * RS));
-    union { s16x4 s[2]; bf16x8 v; } u;
+    union { s16x4 s[2]; ge8_t v; } u;
     u.s[0] = a; u.s[1] = b;
     return u.v;
 }
 struct TnParams {
-    const bf16* dY; int64_t ldy; const bf16* X; int64_t ldx;
+    const ge_t* dY; int64_t ldy; const ge_t* X; int64_t ldx;
     int M, N, K;
     const float* rowscale; int rows_per_scale;
     float* part;          // [splits][N][K]
     int tilesN, tilesK, m_per_split;
-    const bf16* Y2; const float* coef;    // optional: the dY operand is  coef0*dY + coef1*Y2 + coef2  per column (BatchNorm backward's
+    const ge_t* Y2; const float* coef;    // optional: the dY operand is  coef0*dY + coef1*Y2 + coef2  per column (BatchNorm backward's
                                           // apply step of a ConvNorm whose dy only feeds this weight gradient), bf16-rounded like the stored dy
 };
 template <bool BN>        // BN: dY := coef0*dY + coef1*Y2 + coef2 while loading (its 44 extra registers stay out of the plain kernel: 3 vs 2 waves/SIMD)
@@ -474,8 +491,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
     // read touches then fall on 16 disjoint groups of 8 banks (a 272-byte stride overlaps neighbouring rows: 2-way conflicts)
     constexpr int TB = 128, MS = 64, RS = TB + 16;
     constexpr int LS = MS / 16;                            // 16-byte chunks per thread per operand per step
-    __shared__ __attribute__((aligned(16))) bf16 Ys[MS * RS];
-    __shared__ __attribute__((aligned(16))) bf16 Xs[MS * RS];
+    __shared__ __attribute__((aligned(16))) ge_t Ys[MS * RS];
+    __shared__ __attribute__((aligned(16))) ge_t Xs[MS * RS];
     // flattened (split, tile) order laid out XCD by XCD: the tiles of one split re-read the same row range of dY (tilesK times) and
     // X (tilesN times); dispatched round-robin they would pull it into all eight L2s
     const int ntile = p.tilesN * p.tilesK;
@@ -513,16 +530,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
             ca[j] = p.coef[c]; cb[j] = p.coef[p.N + c]; cc[j] = p.coef[2 * p.N + c];
         }
     }
-    bf16x8 ry[LS], rx[LS], ry2[LS];
+    ge8_t ry[LS], rx[LS], ry2[LS];
     float rsc[LS];
     auto load_step = [&](int m0) {
         const unsigned st = (unsigned)(m0 - mbeg) / MS;
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
             // a pushed-out chunk stays out of range: its offset is only advanced when valid
-            ry[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
-            rx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(xok ? vox[i] + st * stepX : 0xFFFFFFF0u), 0, 0));
-            if (BN) ry2[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsY2, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
+            ry[i] = __builtin_bit_cast(ge8_t, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
+            rx[i] = __builtin_bit_cast(ge8_t, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(xok ? vox[i] + st * stepX : 0xFFFFFFF0u), 0, 0));
+            if (BN) ry2[i] = __builtin_bit_cast(ge8_t, __builtin_amdgcn_raw_buffer_load_b128(rsY2, (int)(yok ? voy[i] + st * stepY : 0xFFFFFFF0u), 0, 0));
         }
         if (p.rowscale) {
 #pragma unroll
@@ -542,14 +559,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
             for (int i = 0; i < LS; ++i) {
                 const bool ok = yok && (m0 + srow + 16 * i) < mend;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ry[i][j] = ok ? (bf16)fmaf(ca[j], (float)ry[i][j], fmaf(cb[j], (float)ry2[i][j], cc[j])) : (bf16)0.f;
+                for (int j = 0; j < 8; ++j) ry[i][j] = ok ? (ge_t)fmaf(ca[j], (float)ry[i][j], fmaf(cb[j], (float)ry2[i][j], cc[j])) : (ge_t)0.f;
             }
         }
         if (p.rowscale) {
 #pragma unroll
             for (int i = 0; i < LS; ++i) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ry[i][j] = (bf16)((float)ry[i][j] * rsc[i]);
+                for (int j = 0; j < 8; ++j) ry[i][j] = (ge_t)((float)ry[i][j] * rsc[i]);
             }
         }
     };
@@ -563,15 +580,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
         finish_step(m0);
 #pragma unroll
         for (int i = 0; i < LS; ++i) {
-            *reinterpret_cast<bf16x8*>(Ys + (srow + 16 * i) * RS + sch * 8) = ry[i];
-            *reinterpret_cast<bf16x8*>(Xs + (srow + 16 * i) * RS + sch * 8) = rx[i];
+            *reinterpret_cast<ge8_t*>(Ys + (srow + 16 * i) * RS + sch * 8) = ry[i];
+            *reinterpret_cast<ge8_t*>(Xs + (srow + 16 * i) * RS + sch * 8) = rx[i];
         }
         __syncthreads();
         if (m0 + MS < mend) load_step(m0 + MS);
 #pragma unroll
         for (int ms = 0; ms < MS / 32; ++ms) {
             if (m0 + ms * 32 >= mend) break;         // uniform: the tail step may hold only one k-step of rows
-            bf16x8 yf[4], xf[4];
+            ge8_t yf[4], xf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 yf[i] = tn_frag(Ys + ms * 32 * RS, RS, wn * 64 + i * 16, lr, lg);
@@ -581,7 +598,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnParams p) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
+                    acc[kt][nt] = ge_mfma(yf[nt], xf[kt], acc[kt][nt]);   // rows n, cols k
         }
         __syncthreads();
     }
@@ -630,10 +647,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_v4_kernel(const float* __re
 
 // bf16 [R, C] (row stride ld) -> bf16 [C, R] (row stride ldo), optional per-row scale (drop-path) applied while
 // transposing.  Columns/rows beyond the source are not written: the caller zero-pads ldo.
-__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restrict__ in, int64_t ld, bf16* __restrict__ out,
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const ge_t* __restrict__ in, int64_t ld, ge_t* __restrict__ out,
                                                              int64_t ldo, int R, int C, const float* rowscale,
                                                              int rows_per_scale) {
-    __shared__ bf16 tile[64][64 + 2];
+    __shared__ ge_t tile[64][64 + 2];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
     for (int i = ty; i < 64; i += 4) {
@@ -643,7 +660,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
             v = (float)in[(int64_t)r * ld + c];
             if (rowscale) v *= rowscale[r / rows_per_scale];
         }
-        tile[i][tx] = (bf16)v;
+        tile[i][tx] = (ge_t)v;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
@@ -653,8 +670,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16* __restr
 }
 
 // f32 [R, C] -> bf16 [R, ldo] (cast) and/or bf16 [C, ldt] (cast + transpose): weight-cache refresh.
-__global__ __launch_bounds__(256) void cast_transpose_f32_kernel(const float* __restrict__ in, int R, int C, bf16* __restrict__ out,
-                                                                 int64_t ldo, bf16* __restrict__ outT, int64_t ldt) {
+__global__ __launch_bounds__(256) void cast_transpose_f32_kernel(const float* __restrict__ in, int R, int C, ge_t* __restrict__ out,
+                                                                 int64_t ldo, ge_t* __restrict__ outT, int64_t ldt) {
     __shared__ float tile[64][65];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -663,7 +680,7 @@ __global__ __launch_bounds__(256) void cast_transpose_f32_kernel(const float* __
         float v = 0.f;
         if (r < R && c < C) {
             v = in[(int64_t)r * C + c];
-            if (out) out[(int64_t)r * ldo + c] = (bf16)v;
+            if (out) out[(int64_t)r * ldo + c] = (ge_t)v;
         }
         tile[i][tx] = v;
     }
@@ -671,22 +688,22 @@ __global__ __launch_bounds__(256) void cast_transpose_f32_kernel(const float* __
     if (outT) {
         for (int i = ty; i < 64; i += 4) {
             const int c = c0 + i, r = r0 + tx;
-            if (c < C && r < R) outT[(int64_t)c * ldt + r] = (bf16)tile[tx][i];
+            if (c < C && r < R) outT[(int64_t)c * ldt + r] = (ge_t)tile[tx][i];
         }
     }
 }
 
-__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, int64_t n) {
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, ge_t* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (bf16)in[i];
+        out[i] = (ge_t)in[i];
 }
-__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ in, float* __restrict__ out, int64_t n) {
+__global__ void cast_bf16_f32_kernel(const ge_t* __restrict__ in, float* __restrict__ out, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = (float)in[i];
 }
 
 // column sums of a bf16 [M, C] matrix (bias gradients): partials [gridDim.y][C] then a finalize pass.
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restrict__ x, int64_t ld, int M, int C,
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const ge_t* __restrict__ x, int64_t ld, int M, int C,
                                                              const float* rowscale, int rows_per_scale,
                                                              float* __restrict__ part, int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -701,7 +718,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16* __restr
     part[(int64_t)blockIdx.y * C + c] = s;
 }
 // 16-byte version: thread = (8-column group of 32, row lane of 8); a block covers 256 columns x rows_per_block rows
-__global__ __launch_bounds__(256) void colsum_partial_v8_kernel(const bf16* __restrict__ x, int64_t ld, int M, int C,
+__global__ __launch_bounds__(256) void colsum_partial_v8_kernel(const ge_t* __restrict__ x, int64_t ld, int M, int C,
                                                                 const float* rowscale, int rows_per_scale,
                                                                 float* __restrict__ part, int rows_per_block) {
     __shared__ float red[8][256];
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(256) void colsum_partial_v8_kernel(const bf16* __re
     if (c0 < C) {
 #pragma unroll 4
         for (int r = r0 + pp; r < r1; r += 8) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (int64_t)r * ld + c0);
+            const ge8_t v = *reinterpret_cast<const ge8_t*>(x + (int64_t)r * ld + c0);
             const float rs = rowscale ? rowscale[r / rows_per_scale] : 1.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s[j] = fmaf((float)v[j], rs, s[j]);
@@ -748,7 +765,7 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, 
 extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     GG_CHECK(a && a->A && a->B && a->C, "gg_gemm_nt: null operand");
 #ifdef GG_GEMM_SECOND_TYPE
-    GG_CHECK(!a->a_bn_stat && !a->A2 && !a->bn_y && !a->colstats && a->split_k <= 1, "gg_gemm_nt_f16: the BatchNorm-fused / two-source / split-K forms exist in the bf16 build only");
+    GG_CHECK(!a->a_bn_stat && !a->A2 && !a->bn_y && !a->colstats && a->split_k <= 1, "gg_gemm_nt_f16: the BatchNorm-fused / two-source / split-K forms exist in the ge_t build only");
 #endif
     GG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
     GG_CHECK((a->K & 7) == 0 && (a->lda & 7) == 0 && (a->ldb & 7) == 0,
@@ -771,7 +788,7 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     GG_CHECK(!(a->act && (a->rowscale || a->residual)), "gg_gemm_nt: an activation epilogue excludes rowscale/residual");
     GG_CHECK(!a->preact || a->act == GG_ACT_GELU || a->act == GG_ACT_QUICK_GELU, "gg_gemm_nt: preact is only available with an activation epilogue");
     GG_CHECK(!a->colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->out_f32),
-             "gg_gemm_nt: colstats is only available on the plain and BatchNorm-backward bf16 epilogues");
+             "gg_gemm_nt: colstats is only available on the plain and BatchNorm-backward ge_t epilogues");
     GG_CHECK(!a->out_f32 || !(a->act || a->rowscale || a->residual || a->dact_preact || a->preact), "gg_gemm_nt: f32 output supports bias only");
     if (a->A2)
         GG_CHECK(a->k_split > 0 && a->k_split < a->K && (a->k_split % BK) == 0 && split == 1 && ((uintptr_t)a->A2 & 15) == 0,
@@ -790,14 +807,14 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     }
     GemmParams p;
     p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
-    p.A2 = (const bf16*)a->A2; p.k_split = a->k_split;
-    p.bn_y = (const bf16*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
-    p.A = (const bf16*)a->A; p.lda = a->lda; p.B = (const bf16*)a->B; p.ldb = a->ldb;
+    p.A2 = (const ge_t*)a->A2; p.k_split = a->k_split;
+    p.bn_y = (const ge_t*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
+    p.A = (const ge_t*)a->A; p.lda = a->lda; p.B = (const ge_t*)a->B; p.ldb = a->ldb;
     p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.K = a->K;
-    p.bias = a->bias; p.act = a->act; p.preact = (bf16*)a->preact;
+    p.bias = a->bias; p.act = a->act; p.preact = (ge_t*)a->preact;
     p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale;
-    p.residual = (const bf16*)a->residual; p.ldr = a->ldr;
-    p.dact_preact = (const bf16*)a->dact_preact; p.dact = a->dact_preact ? a->dact : 0;
+    p.residual = (const ge_t*)a->residual; p.ldr = a->ldr;
+    p.dact_preact = (const ge_t*)a->dact_preact; p.dact = a->dact_preact ? a->dact : 0;
     p.colstats = a->colstats; p.out_f32 = a->out_f32;
     p.split_k = split;
     int kps = (int)gg_cdiv(a->K, split);
@@ -905,7 +922,7 @@ extern "C" int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t 
         const int rr = std::min(max_rows, R - r0);
         dim3 g((unsigned)gg_cdiv(C, 64), (unsigned)gg_cdiv(rr, 64));
         hipLaunchKernelGGL(transpose_bf16_kernel, g, dim3(256), 0, (hipStream_t)stream,
-                           (const bf16*)in + (int64_t)r0 * ld, ld, (bf16*)out + r0, ldo, rr, C,
+                           (const ge_t*)in + (int64_t)r0 * ld, ld, (ge_t*)out + r0, ldo, rr, C,
                            rowscale ? rowscale + 0 : nullptr, rows_per_scale);
         // rowscale index uses the chunk-local row: only valid when r0 is a multiple of rows_per_scale
         if (rowscale) GG_CHECK(r0 == 0, "gg_transpose_bf16: rowscale with > 4.19M rows unsupported");
@@ -916,7 +933,7 @@ extern "C" int gg_transpose_bf16(const void* in, int64_t ld, void* out, int64_t 
 extern "C" int gg_cast_transpose_f32(const float* in, int R, int C, void* out, int64_t ldo, void* outT, int64_t ldt, void* stream) {
     GG_CHECK(in && R > 0 && C > 0 && (out || outT), "gg_cast_transpose_f32: bad args");
     dim3 grid((unsigned)gg_cdiv(C, 64), (unsigned)gg_cdiv(R, 64));
-    hipLaunchKernelGGL(cast_transpose_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, R, C, (bf16*)out, ldo, (bf16*)outT, ldt);
+    hipLaunchKernelGGL(cast_transpose_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, R, C, (ge_t*)out, ldo, (ge_t*)outT, ldt);
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -947,14 +964,14 @@ extern "C" int gg_transpose_f32(const float* in, int R, int C, float* outT, int6
 extern "C" int gg_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
     GG_CHECK(in && out && n > 0, "gg_cast_f32_to_bf16: bad args");
     int blocks = (int)std::min<int64_t>(gg_cdiv(n, 256), 8192);
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, n);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (ge_t*)out, n);
     GG_LAUNCH_CHECK();
     return 0;
 }
 extern "C" int gg_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream) {
     GG_CHECK(in && out && n > 0, "gg_cast_bf16_to_f32: bad args");
     int blocks = (int)std::min<int64_t>(gg_cdiv(n, 256), 8192);
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out, n);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const ge_t*)in, out, n);
     GG_LAUNCH_CHECK();
     return 0;
 }
@@ -969,10 +986,10 @@ extern "C" int gg_colsum_bf16(const void* x, int64_t ld, int M, int C, const flo
     GG_CHECK(nparts <= 65535, "gg_colsum_bf16: M too large");
     if ((C & 7) == 0 && (ld & 7) == 0 && ((uintptr_t)x & 15) == 0)
         hipLaunchKernelGGL(colsum_partial_v8_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
+                           (const ge_t*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
     else
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gg_cdiv(C, 256), nparts), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
+                           (const ge_t*)x, ld, M, C, rowscale, rows_per_scale, scratch, rpb);
     const float* rows; int nrows;
     gg_reduce_rows(scratch, nparts, C, (hipStream_t)stream, &rows, &nrows);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)gg_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, nrows, C, out, accumulate);
@@ -1007,8 +1024,8 @@ static int gemm_tn_launch(const void* dY, int64_t ldy, const void* Y2, const flo
     GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gg_gemm_tn: operands must be 16-byte aligned");
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn: rows_per_scale");
     TnParams p;
-    p.dY = (const bf16*)dY; p.ldy = ldy; p.X = (const bf16*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
-    p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials; p.Y2 = (const bf16*)Y2; p.coef = coef;
+    p.dY = (const ge_t*)dY; p.ldy = ldy; p.X = (const ge_t*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;
+    p.rowscale = rowscale; p.rows_per_scale = rows_per_scale; p.part = partials; p.Y2 = (const ge_t*)Y2; p.coef = coef;
     p.tilesN = (int)gg_cdiv(N, 128); p.tilesK = (int)gg_cdiv(K, 128);
     p.m_per_split = (int)gg_align(gg_cdiv(M, splits), 64);
     GG_CHECK((int64_t)p.m_per_split * std::max(ldy, ldx) * 2 < ((int64_t)1 << 32), "gg_gemm_tn: a split's rows must span < 4 GiB per operand (use more splits)");
