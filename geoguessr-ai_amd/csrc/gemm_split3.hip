@@ -8,11 +8,12 @@
 // over a 6 K contraction the library's 128^2 two-barrier kernel gives 133-141 (it re-reads every fragment from LDS once per product).  This kernel
 // stages the three planes of both operands together, so a fragment read from LDS feeds three (A) or up to three (B) products:
 //   * operands: pre-split bf16 planes in HBM, [3][rows][ld] (gg_split3_bf16 makes them; a production form would have the PRODUCER's epilogue write them);
-//   * tile 128 x 128, k-stage 32 (one v_mfma_f32_16x16x32_bf16 step), 512 threads = 2 x 4 waves (64 x 32 per wave: 4 x 2 MFMA tiles, 48 MFMAs per stage);
-//   * LDS-DMA (`buffer_load ... lds`, 16 B per lane, no VGPR staging) into a 3-stage ring of 6 plane tiles (48 KB per stage, two stages in flight), rows of 64 bytes with the
+//   * tile 256 x 128, k-stage 32 (one v_mfma_f32_16x16x32_bf16 step), 512 threads = 4 x 2 waves (64 x 64 per wave: 4 x 4 MFMA tiles x 6 products = 96 MFMAs per
+//     24 fragment reads and stage; the 128 x 128 / 64 x 32-per-wave form moves 1.5 x the LDS bytes per MFMA and sits at the LDS-port / MFMA balance point);
+//   * LDS-DMA (`buffer_load ... lds`, 16 B per lane, no VGPR staging) into a 2-stage ring of 6 plane tiles (72 KB per stage: 144 KB, one workgroup per CU), rows of 64 bytes with the
 //     16-byte chunk index XOR-ed with (row >> 2) & 3 on the SOURCE side of the DMA, so the fragment reads (ds_read_b128: 16 rows x one chunk) are
 //     conflict-free without padding;
-//   * one raw s_barrier per stage, the next stage's DMA in flight under the current stage's 48 MFMAs; two waves per SIMD.
+//   * one raw s_barrier per stage, the next stage's DMA in flight under the current stage's 96 MFMAs; two waves per SIMD.
 // Plain epilogue (optional bias), f32 result.  Not wired into the model runtimes: measured by tools/bench_split3.py next to the f32-MFMA GEMM.
 #include "common.h"
 #include <stdlib.h>
@@ -33,51 +34,57 @@ constexpr int S3_TILE = S3_BM * S3_SK;                         // bf16 elements 
 constexpr int S3_STAGE = 6 * S3_TILE;                          // a1 a2 a3 b1 b2 b3
 template <int N> __device__ __forceinline__ void wait_outstanding() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// WM x WN waves (each (128 / WM) x (128 / WN) of the tile); PIPE: fragments of stage s + 1 are read into a second register set under the MFMAs of stage s
-template <int WM, int WN, bool PIPE>
+// BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN)), NST ring stages; PIPE: fragments of stage s + 1 are read into a second register set under the MFMAs of stage s
+template <int BM, int BN, int WM, int WN, bool PIPE, int NST>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Params p) {
-    constexpr int NW = WM * WN, TM = S3_BM / WM / 16, TN = S3_BN / WN / 16;
-    constexpr int IPT = 8 / NW;                                  // DMA instructions per plane tile and wave (a tile is 8 wave-slices of 16 rows = 1 KB)
-    constexpr int DPS = 6 * IPT;                                 // ... per stage and wave
-    static_assert(IPT >= 1 && IPT * NW == 8, "waves must divide the 8 slices of a plane tile");
+    constexpr int NW = WM * WN, TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int SLA = BM / 16, SLB = BN / 16;                  // 16-row wave-slices (1 KB) of an A / B plane tile
+    constexpr int IA = SLA / NW, IB = SLB / NW;                  // DMA instructions per A / B plane tile and wave
+    constexpr int DPS = 3 * (IA + IB);                           // ... per stage and wave
+    constexpr int TA = BM * S3_SK, TB = BN * S3_SK, STAGE = 3 * (TA + TB);
+    static_assert(IA * NW == SLA && IB * NW == SLB && IA >= 1 && IB >= 1, "waves must divide the slices of both plane tiles");
+    static_assert(!PIPE || NST == 3, "the pipelined form walks a 3-stage ring");
     extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
     const int tiles = p.tilesM * p.tilesN;
     const int bid = gg_xcd_remap(blockIdx.x, tiles);
     const int tm = bid / p.tilesN, tn = bid % p.tilesN;
-    const int m0 = tm * S3_BM, n0 = tn * S3_BN;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
     // DMA geometry: slice sl = wave + NW j covers tile rows 16 sl .. 16 sl + 15: lane -> (row 16 sl + lane / 4, LDS chunk slot lane % 4); the slot holds SOURCE chunk
     // slot ^ ((row >> 2) & 3) = slot ^ (lane >> 4) (16 sl does not touch bits 2-3)
     const int dchunk = (lane & 3) ^ (lane >> 4);
-    const unsigned rowsA = (unsigned)min(p.M - m0, S3_BM), rowsB = (unsigned)min(p.N - n0, S3_BN);
+    const unsigned rowsA = (unsigned)min(p.M - m0, BM), rowsB = (unsigned)min(p.N - n0, BN);
     __amdgpu_buffer_rsrc_t rs[6];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         rs[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + i * p.plane_a + (int64_t)m0 * p.lda), 0, (int)(rowsA * (unsigned)p.lda * 2u), 0x00020000);
         rs[3 + i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + i * p.plane_b + (int64_t)n0 * p.ldb), 0, (int)(rowsB * (unsigned)p.ldb * 2u), 0x00020000);
     }
-    unsigned voffA[IPT], voffB[IPT];
+    unsigned voffA[IA], voffB[IB];
 #pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const unsigned row = (unsigned)((wave + NW * j) * 16 + (lane >> 2));
-        voffA[j] = row * (unsigned)p.lda * 2u + dchunk * 16u;
-        voffB[j] = row * (unsigned)p.ldb * 2u + dchunk * 16u;
-    }
+    for (int j = 0; j < IA; ++j) voffA[j] = (unsigned)((wave + NW * j) * 16 + (lane >> 2)) * (unsigned)p.lda * 2u + dchunk * 16u;
+#pragma unroll
+    for (int j = 0; j < IB; ++j) voffB[j] = (unsigned)((wave + NW * j) * 16 + (lane >> 2)) * (unsigned)p.ldb * 2u + dchunk * 16u;
     auto issue_stage = [&](int st, bf16* base) {
         const int k0 = st * S3_SK;
         const bool kin = k0 + dchunk * 8 < p.K;                 // K % 8 == 0: a chunk is entirely inside or outside (outside: range check -> zeros)
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int j = 0; j < IPT; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], (__attribute__((address_space(3))) void*)(base + i * S3_TILE + (wave + NW * j) * 512), 16,
-                                                         (int)(kin ? (i < 3 ? voffA[j] : voffB[j]) : 0xFFFFFFF0u), k0 * 2, 0, 0);
+            for (int j = 0; j < IA; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[i], (__attribute__((address_space(3))) void*)(base + i * TA + (wave + NW * j) * 512), 16,
+                                                         (int)(kin ? voffA[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
+#pragma unroll
+            for (int j = 0; j < IB; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[3 + i], (__attribute__((address_space(3))) void*)(base + 3 * TA + i * TB + (wave + NW * j) * 512), 16,
+                                                         (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
+        }
     };
     // fragment addresses: row (16 t + lr) of a plane tile, k-chunk lg -> slot lg ^ ((lr >> 2) & 3) (the tile index t does not touch bits 2-3 of the row)
     const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
-    const int a_off = (wm * (S3_BM / WM) + lr) * S3_SK + fslot, b_off = (wn * (S3_BN / WN) + lr) * S3_SK + fslot;
+    const int a_off = (wm * (BM / WM) + lr) * S3_SK + fslot, b_off = 3 * TA + (wn * (BN / WN) + lr) * S3_SK + fslot;
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -88,9 +95,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int mt = 0; mt < TM; ++mt) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * S3_TILE + a_off + mt * 16 * S3_SK);
+            for (int mt = 0; mt < TM; ++mt) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * TA + a_off + mt * 16 * S3_SK);
 #pragma unroll
-            for (int nt = 0; nt < TN; ++nt) wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + (3 + pl) * S3_TILE + b_off + nt * 16 * S3_SK);
+            for (int nt = 0; nt < TN; ++nt) wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + pl * TB + b_off + nt * 16 * S3_SK);
         }
     };
     // small terms first: (a1 b3 + a2 b2 + a3 b1), (a1 b2 + a2 b1), a1 b1.  D = Wfrag x Xfrag: lane owns 4 consecutive n of row m = lr
@@ -104,12 +111,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
 #undef S3_MFMA
     };
     issue_stage(0, s3mem);
-    if (nk > 1) issue_stage(1, s3mem + S3_STAGE);
     if constexpr (PIPE) {
         // 3-stage ring, software-pipelined: iteration s multiplies the fragments of stage s (already in registers) while the fragments of stage s + 1 are read
         // from LDS into the other register set and the DMAs of stages s + 2 / s + 3 are in flight
         bf16x8 xa[3][TM], wa[3][TN], xb[3][TM], wb[3][TN];
-        if (nk > 2) issue_stage(2, s3mem + 2 * S3_STAGE);
+        if (nk > 1) issue_stage(1, s3mem + STAGE);
+        if (nk > 2) issue_stage(2, s3mem + 2 * STAGE);
         if (nk > 2) wait_outstanding<2 * DPS>(); else if (nk > 1) wait_outstanding<DPS>(); else wait_outstanding<0>();
         __builtin_amdgcn_s_barrier();
         frag_read(s3mem, xa, wa);
@@ -118,8 +125,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
             if (more) { if (s + 2 < nk) wait_outstanding<DPS>(); else wait_outstanding<0>(); }      // stage s + 1 landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // own fragment reads of stage s are in registers ...
             __builtin_amdgcn_s_barrier();                           // ... everybody's are: slot(s) may be refilled; everybody's DMAs of stage s + 1 have landed
-            if (s + 3 < nk) issue_stage(s + 3, s3mem + slot * S3_STAGE);
-            if (more) frag_read(s3mem + (slot == 2 ? 0 : slot + 1) * S3_STAGE, xn, wn_);
+            if (s + 3 < nk) issue_stage(s + 3, s3mem + slot * STAGE);
+            if (more) frag_read(s3mem + (slot == 2 ? 0 : slot + 1) * STAGE, xn, wn_);
             mfma_stage(xc, wc);
         };
         int slot = 0;
@@ -128,25 +135,38 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
             slot = slot == 2 ? 0 : slot + 1;
             if (s + 1 < nk) { iter(s + 1, slot, xb, wb, xa, wa); slot = slot == 2 ? 0 : slot + 1; }
         }
-    } else {
+    } else if constexpr (NST == 3) {
         // 3-stage ring, two stages in flight: the DMA of stage s + 2 is issued when stage s starts
+        if (nk > 1) issue_stage(1, s3mem + STAGE);
         int cb = 0;
         for (int s = 0; s < nk; ++s) {
-            bf16* const cur = s3mem + cb * S3_STAGE;
+            bf16* const cur = s3mem + cb * STAGE;
             if (s + 1 < nk) wait_outstanding<DPS>(); else wait_outstanding<0>();      // this wave's DMAs of stage s have landed (those of stage s + 1 may be in flight) ...
             __builtin_amdgcn_s_barrier();                           // ... everybody's have, and every wave has read its fragments of stage s - 1
-            if (s + 2 < nk) issue_stage(s + 2, s3mem + (cb == 0 ? 2 : cb - 1) * S3_STAGE);      // into the slot stage s - 1 occupied
+            if (s + 2 < nk) issue_stage(s + 2, s3mem + (cb == 0 ? 2 : cb - 1) * STAGE);      // into the slot stage s - 1 occupied
             cb = cb == 2 ? 0 : cb + 1;
             bf16x8 xf[3][TM], wf[3][TN];
             frag_read(cur, xf, wf);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             mfma_stage(xf, wf);
         }
+    } else {
+        // 2-stage ring: the DMA of stage s + 1 is issued when stage s starts (into the slot stage s - 1 occupied) and has the stage's MFMAs to land
+        for (int s = 0; s < nk; ++s) {
+            bf16* const cur = s3mem + (s & 1) * STAGE;
+            wait_outstanding<0>();
+            __builtin_amdgcn_s_barrier();
+            if (s + 1 < nk) issue_stage(s + 1, s3mem + ((s + 1) & 1) * STAGE);
+            bf16x8 xf[3][TM], wf[3][TN];
+            frag_read(cur, xf, wf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mfma_stage(xf, wf);
+        }
     }
-    // epilogue: lane holds C[m = m0 + (128 / WM) wm + 16 mt + lr][n = n0 + (128 / WN) wn + 16 nt + 4 lg + r]
+    // epilogue: lane holds C[m = m0 + (BM / WM) wm + 16 mt + lr][n = n0 + (BN / WN) wn + 16 nt + 4 lg + r]
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + wn * (S3_BN / WN) + nt * 16 + lg * 4;
+        const int n = n0 + wn * (BN / WN) + nt * 16 + lg * 4;
         f32x4 b = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
 #pragma unroll
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
         }
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
-            const int m = m0 + wm * (S3_BM / WM) + mt * 16 + lr;
+            const int m = m0 + wm * (BM / WM) + mt * 16 + lr;
             if (m >= p.M) continue;
             const f32x4 v = acc[nt][mt] + b;
             float* dst = p.C + (int64_t)m * p.ldc + n;
@@ -311,20 +331,25 @@ extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* 
     GG_CHECK(a_planes && b_planes && C && M > 0 && N > 0 && K > 0, "gg_gemm_nt_split3: null pointer / bad shape");
     GG_CHECK((K & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && lda >= K && ldb >= K && ldc >= N, "gg_gemm_nt_split3: K, lda, ldb must be multiples of 8, ld >= K / N");
     GG_CHECK(((uintptr_t)a_planes & 15) == 0 && ((uintptr_t)b_planes & 15) == 0 && ((uintptr_t)C & 15) == 0, "gg_gemm_nt_split3: 16-byte alignment");
-    GG_CHECK((int64_t)128 * lda * 2 < ((int64_t)1 << 31) && (int64_t)128 * ldb * 2 < ((int64_t)1 << 31), "gg_gemm_nt_split3: row pitch too large");
+    GG_CHECK((int64_t)256 * lda * 2 < ((int64_t)1 << 31) && (int64_t)256 * ldb * 2 < ((int64_t)1 << 31), "gg_gemm_nt_split3: row pitch too large");
     Split3Params p;
     p.A = (const bf16*)a_planes; p.lda = lda; p.plane_a = (int64_t)M * lda;
     p.B = (const bf16*)b_planes; p.ldb = ldb; p.plane_b = (int64_t)N * ldb;
     p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
     p.tilesM = (int)gg_cdiv(M, S3_BM); p.tilesN = (int)gg_cdiv(N, S3_BN);
-    const size_t lds = (size_t)3 * S3_STAGE * sizeof(bf16);       // 144 KB: one workgroup (8 waves) per CU
-    // form: 0 = 2 x 4 waves, fragments read before the MFMAs (default); 1 = the same, software-pipelined; 2 = 2 x 2 waves (64 x 64 per wave), pipelined;
-    // 3 = form 0 as persistent workgroups with the next tile's first stages issued before the epilogue
+    // form: 0 = 128 x 128 tile, 2 x 4 waves, fragments read before the MFMAs, 3-stage ring (default); 1 = the same, software-pipelined; 2 = 2 x 2 waves (64 x 64 per
+    // wave), pipelined; 3 = form 0 as persistent workgroups with the next tile's first stages issued before the epilogue; 4 = 256 x 128 tile, 4 x 2 waves of
+    // 64 x 64 (96 MFMAs per 24 fragment reads, two waves per SIMD), 2-stage ring
     static const char* fenv = gg_dev_env("GG_SPLIT3_FORM");
-    const int form = fenv ? atoi(fenv) : 0;
-    void (*kern)(Split3Params) = form == 3 ? gemm_nt_split3_persistent_kernel : form == 2 ? gemm_nt_split3_kernel<2, 2, true> : form == 1 ? gemm_nt_split3_kernel<2, 4, true> : gemm_nt_split3_kernel<2, 4, false>;
-    static bool raised[4] = {false, false, false, false};
-    const int fi = form >= 0 && form <= 3 ? form : 0;
+    const int form = fenv ? atoi(fenv) : (M > 128 ? 4 : 0);      // default: the 256 x 128 tile (64 x 64 per wave), the 128 x 128 one for a single row of tiles
+    const int fi = form >= 0 && form <= 4 ? form : 0;
+    void (*kern)(Split3Params) = fi == 4 ? gemm_nt_split3_kernel<256, 128, 4, 2, false, 2> : fi == 3 ? gemm_nt_split3_persistent_kernel :
+                                 fi == 2 ? gemm_nt_split3_kernel<128, 128, 2, 2, true, 3> : fi == 1 ? gemm_nt_split3_kernel<128, 128, 2, 4, true, 3> :
+                                           gemm_nt_split3_kernel<128, 128, 2, 4, false, 3>;
+    const int bm = fi == 4 ? 256 : 128;
+    p.tilesM = (int)gg_cdiv(M, bm);
+    const size_t lds = fi == 4 ? (size_t)2 * 3 * (256 + 128) * S3_SK * sizeof(bf16) : (size_t)3 * S3_STAGE * sizeof(bf16);
+    static bool raised[5] = {false, false, false, false, false};
     if (!raised[fi]) {
         GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "gg_gemm_nt_split3: cannot raise the dynamic LDS limit");
@@ -332,7 +357,7 @@ extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* 
     }
     // algorithmic work = the fp32 product it replaces: 2 M N K flop; bytes: three bf16 planes per operand + the f32 result
     GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N, stream);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(form == 3 ? std::min(p.tilesM * p.tilesN, 256) : p.tilesM * p.tilesN)), dim3(form == 2 ? 256 : 512), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(fi == 3 ? std::min(p.tilesM * p.tilesN, 256) : p.tilesM * p.tilesN)), dim3(fi == 2 ? 256 : 512), lds, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
