@@ -307,7 +307,9 @@ __device__ __forceinline__ float gg_group16_sum(float v) {
 // (bf16-rounded exactly as the separate apply pass stores it) and the applied tensor -- the residual stream -- is written to xout, so
 // the apply pass and one read of the stream disappear.
 template <typename T> __device__ __forceinline__ float ln_round(float v) { return sizeof(T) == 2 ? (float)(bf16)v : v; }   // storage rounding of T
-template <typename T, int NCH, bool BNIN = false>
+// PL3 (experiment, DESIGN.md 5 "the bf16 x 3 split"): the result leaves as three bf16 planes [3][M][C] (o = p1 + p2 + p3 to 24 bits) for gg_gemm_nt_split3
+// instead of one f32 tensor: 6 instead of 4 bytes per element written by a kernel that reads 4
+template <typename T, int NCH, bool BNIN = false, bool PL3 = false>
 __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int64_t M, int C, float eps,
                                                                 T* __restrict__ out, float* __restrict__ mean_out,
@@ -375,6 +377,20 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const T* __restr
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = fmaf(v[k][j] * rstd, g[k][j], b[k][j]);
+                if constexpr (PL3) {
+                    bf16* pl = reinterpret_cast<bf16*>(out);
+                    bf16x8 p1, p2, p3;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bf16 a = (bf16)o[j];
+                        const float r1 = o[j] - (float)a;
+                        const bf16 c2 = (bf16)r1;
+                        p1[j] = a; p2[j] = c2; p3[j] = (bf16)(r1 - (float)c2);
+                    }
+                    *reinterpret_cast<bf16x8*>(pl + m * C + ch * 8) = p1;
+                    *reinterpret_cast<bf16x8*>(pl + M * C + m * C + ch * 8) = p2;
+                    *reinterpret_cast<bf16x8*>(pl + 2 * M * C + m * C + ch * 8) = p3;
+                } else
                 Vec8<T>::store(out + m * C + ch * 8, o);
             }
         }
@@ -797,6 +813,20 @@ extern "C" int gg_layernorm_fwd(const void* x, int x_f32, const float* gamma, co
         hipLaunchKernelGGL((layernorm_fwd_kernel<float, bf16>), grid, block, 0, s, (const float*)x, gamma, beta, M, C, eps, (bf16*)out, mean, rstd);
     else
         hipLaunchKernelGGL((layernorm_fwd_kernel<bf16, float>), grid, block, 0, s, (const bf16*)x, gamma, beta, M, C, eps, (float*)out, mean, rstd);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+// experiment: f32 LayerNorm whose result leaves as three bf16 planes [3][M][C] (the A operand of gg_gemm_nt_split3)
+extern "C" int gg_layernorm_fwd_split3(const float* x, const float* gamma, const float* beta, int64_t M, int C, float eps, void* planes, float* mean, float* rstd,
+                                       void* stream) {
+    GG_CHECK(x && gamma && beta && planes && M > 0 && (C & 7) == 0 && C <= 640, "gg_layernorm_fwd_split3: bad args (C %% 8, C <= 640)");
+    const int nchl = (C / 8 + 15) / 16;
+    GG_PROF(GG_CAT_NORM, 0, 10.0 * M * C, stream);
+    const dim3 g16((unsigned)std::min<int64_t>(gg_cdiv(M, 16), 8192)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<float, N_, false, true>), g16, block, 0, s, x, gamma, beta, M, C, eps, (float*)planes, mean, rstd)
+    switch (nchl) { case 1: GG_LN_FWD(1); break; case 2: GG_LN_FWD(2); break; case 3: GG_LN_FWD(3); break; case 4: GG_LN_FWD(4); break; default: GG_LN_FWD(5); }
+#undef GG_LN_FWD
     GG_LAUNCH_CHECK();
     return 0;
 }

@@ -216,6 +216,8 @@ int gg_attention_flash_single_pass(int tokens_per_window, int head_dim, int wind
  * gg_split3_bf16: x (f32 [rows][ldx]) -> planes bf16 [3][rows][cols] with x = p1 + p2 + p3 to 24 bits.
  * gg_gemm_nt_split3: C[M,N] (f32) = A . B^T from the planes of both operands (six bf16 MFMA products, f32 accumulation); K, lda, ldb multiples of 8. */
 int gg_split3_bf16(const float* x, int64_t rows, int cols, int64_t ldx, void* planes, void* stream);
+/* the producer-side form of the split: f32 LayerNorm (timm LayerNorm in front of qkv / fc1) whose result leaves as the three planes [3][M][C] */
+int gg_layernorm_fwd_split3(const float* x, const float* gamma, const float* beta, int64_t M, int C, float eps, void* planes, float* mean, float* rstd, void* stream);
 int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,
                       void* stream);
 

@@ -76,5 +76,40 @@ def main():
         torch.cuda.empty_cache()
 
 
+def chain():
+    """Producer-side split: LayerNorm -> Linear as the model runs it (f32 LayerNorm, f32-MFMA GEMM with bias) against LayerNorm writing the three planes ->
+    gg_gemm_nt_split3 with bias (weight planes made once).  Stage-2 shapes of the 1024-image step: norm1 -> qkv and norm2 -> fc1."""
+    dev = "cuda"
+    print("\nLayerNorm -> Linear chains (us): f32 LN + f32-MFMA GEMM | LN writing bf16 planes + split3 GEMM | rel-L2 of the chain's result against fp64")
+    for name, M, C_, N in [("s2 norm1->qkv", 200704, 384, 1152), ("s2 norm2->fc1", 200704, 384, 1536), ("s1 norm2->fc1", 802816, 192, 768), ("s3 norm1->qkv", 50176, 576, 1728)]:
+        g = torch.Generator(device=dev).manual_seed(2)
+        x = torch.randn(M, C_, device=dev, generator=g) * 1.3 + 0.2
+        gamma = 1 + 0.2 * torch.randn(C_, device=dev, generator=g); beta = 0.1 * torch.randn(C_, device=dev, generator=g)
+        W = torch.randn(N, C_, device=dev, generator=g) * C_ ** -0.5; bias = 0.1 * torch.randn(N, device=dev, generator=g)
+        Wp = planes(W)
+        a = torch.empty(M, C_, device=dev); mean = torch.empty(M, device=dev); rstd = torch.empty(M, device=dev)
+        out1 = torch.empty(M, N, device=dev); out2 = torch.empty(M, N, device=dev)
+        ap = torch.empty(3, M, C_, dtype=torch.bfloat16, device=dev)
+        lib = L.lib()
+        def ln_f32():
+            L.check(lib.gg_layernorm_fwd(x.data_ptr(), 1, gamma.data_ptr(), beta.data_ptr(), M, C_, 1e-5, a.data_ptr(), 1, mean.data_ptr(), rstd.data_ptr(), L.stream()), "ln")
+        def ln_pl():
+            L.check(lib.gg_layernorm_fwd_split3(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, C_, 1e-5, ap.data_ptr(), mean.data_ptr(), rstd.data_ptr(), L.stream()), "ln3")
+        def g_f32():
+            ops.gemm_nt(a, W, bias=bias, out=out1)
+        def g_s3():
+            L.check(lib.gg_gemm_nt_split3(ap.data_ptr(), C_, Wp.data_ptr(), C_, out2.data_ptr(), N, M, N, C_, bias.data_ptr(), L.stream()), "s3")
+        t_ln, t_lp, t_g, t_s = timed(ln_f32), timed(ln_pl), timed(g_f32), timed(g_s3)
+        rows = 2048
+        xd = x[:rows].double()
+        ref = torch.nn.functional.layer_norm(xd, (C_,), gamma.double(), beta.double(), 1e-5) @ W.double().T + bias.double()
+        e1 = float((out1[:rows].double() - ref).norm() / ref.norm()); e2 = float((out2[:rows].double() - ref).norm() / ref.norm())
+        print(f"{name:14s} M={M:7d} C={C_:4d} N={N:5d} | LN {t_ln*1e3:7.1f} + GEMM {t_g*1e3:7.1f} = {(t_ln+t_g)*1e3:7.1f} | LN {t_lp*1e3:7.1f} + GEMM {t_s*1e3:7.1f} = {(t_lp+t_s)*1e3:7.1f} "
+              f"({(t_ln+t_g)/(t_lp+t_s):.2f}x) | {e1:.2e} {e2:.2e}", flush=True)
+        del x, a, ap, out1, out2, W, Wp
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
     main()
+    chain()
