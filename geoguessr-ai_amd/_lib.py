@@ -28,6 +28,13 @@ class GemmArgs(C.Structure):
                 ("a_bn_act", C.c_int)]
 
 
+class Split3Args(C.Structure):          # GgSplit3Args (experiment: fp32-accurate GEMM from three bf16 planes per operand)
+    _fields_ = [("a_planes", C.c_void_p), ("lda", C.c_int64), ("b_planes", C.c_void_p), ("ldb", C.c_int64), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("C", C.c_void_p), ("ldc", C.c_int64), ("c_planes", C.c_void_p), ("ldp", C.c_int64), ("bias", C.c_void_p), ("act", C.c_int),
+                ("preact", C.c_void_p), ("rowscale", C.c_void_p), ("rows_per_scale", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int64),
+                ("dact_preact", C.c_void_p), ("dact", C.c_int)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("qkv", C.c_void_p), ("ld", C.c_int64), ("q_off", C.c_int), ("k_off", C.c_int), ("v_off", C.c_int),
                 ("head_stride", C.c_int), ("head_dim", C.c_int), ("num_heads", C.c_int), ("num_windows", C.c_int),
@@ -141,6 +148,7 @@ SIGNATURES = {
     "gg_split3_bf16": (_I, [_P, _L, _I, _L, _P, _P]),
     "gg_layernorm_fwd_split3": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gg_gemm_nt_split3": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P]),
+    "gg_gemm_nt_split3_ex": (_I, [C.POINTER(Split3Args), _P]),
     "gg_gemm_nt_f32": (_I, [C.POINTER(GemmArgs), _P]),
     "gg_gemm_tn_f32_splits": (_I, [_I, _I, _I]),
     "gg_gemm_tn_f32": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),

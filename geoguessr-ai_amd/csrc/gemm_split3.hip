@@ -17,6 +17,7 @@
 // Plain epilogue (optional bias), f32 result.  Not wired into the model runtimes: measured by tools/bench_split3.py next to the f32-MFMA GEMM.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 #include "../../include/gg.h"
 
 namespace {
@@ -24,10 +25,69 @@ namespace {
 struct Split3Params {
     const bf16* A; int64_t lda, plane_a;      // planes a1, a2, a3 at A + i * plane_a (elements)
     const bf16* B; int64_t ldb, plane_b;
-    float* C; int64_t ldc;
+    float* C; int64_t ldc;             // f32 result (may be null when only planes are wanted)
     const float* bias;
     int M, N, K, tilesM, tilesN;
+    // epilogue family of the model's Linears (the f32 GEMM's classes): v = acc + bias; preact copy; act; * rowscale[m / rows_per_scale]; + residual;
+    // or v = (acc) * act'(dact_preact) * rowscale (the dgrad through an activation); result as f32 and / or as three bf16 planes [3][M][ldp]
+    int act; float* preact;
+    const float* rowscale; int rows_per_scale;
+    const float* residual; int64_t ldr;
+    const float* dact_preact; int dact;
+    bf16* c_planes; int64_t ldp;
 };
+
+// one 4-column group of one row in the MFMA result layout (lane: row m, columns n .. n + 3)
+__device__ __forceinline__ void split3_epilogue4(const Split3Params& p, f32x4 v, int m, int n) {
+    if (m >= p.M || n >= p.N) return;
+    const bool full = n + 3 < p.N;
+    if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] += p.bias[n + r];
+    }
+    auto ld4 = [&](const float* base, int64_t ld) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        const float* q = base + (int64_t)m * ld + n;
+        if (full && (ld & 3) == 0) t = *reinterpret_cast<const f32x4*>(q);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) t[r] = q[r];
+        }
+        return t;
+    };
+    auto st4 = [&](float* base, int64_t ld, f32x4 t) {
+        float* q = base + (int64_t)m * ld + n;
+        if (full && (ld & 3) == 0) *reinterpret_cast<f32x4*>(q) = t;
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) q[r] = t[r];
+        }
+    };
+    if (p.preact) st4(p.preact, p.ldc, v);
+    if (p.dact_preact) v = v * gg_act_grad_f32_v4(ld4(p.dact_preact, p.ldc), p.dact);
+    else if (p.act) v = gg_act_f32_v4(v, p.act);
+    if (p.rowscale) v = v * p.rowscale[m / p.rows_per_scale];
+    if (p.residual) v = v + ld4(p.residual, p.ldr);
+    if (p.C) st4(p.C, p.ldc, v);
+    if (p.c_planes) {
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bf16 a = (bf16)v[r];
+            const float r1 = v[r] - (float)a;
+            const bf16 b2 = (bf16)r1;
+            p1[r] = a; p2[r] = b2; p3[r] = (bf16)(r1 - (float)b2);
+        }
+        bf16* q = p.c_planes + (int64_t)m * p.ldp + n;
+        const int64_t plane = (int64_t)p.M * p.ldp;
+        if (full && (p.ldp & 3) == 0) {
+            *reinterpret_cast<bf16x4*>(q) = p1; *reinterpret_cast<bf16x4*>(q + plane) = p2; *reinterpret_cast<bf16x4*>(q + 2 * plane) = p3;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) { q[r] = p1[r]; q[plane + r] = p2[r]; q[2 * plane + r] = p3[r]; }
+        }
+    }
+}
 
 constexpr int S3_BM = 128, S3_BN = 128, S3_SK = 32;          // tile, k-stage (bf16 elements): a row of a plane tile is 64 bytes
 constexpr int S3_TILE = S3_BM * S3_SK;                         // bf16 elements of one plane tile (8 KB)
@@ -165,26 +225,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
     }
     // epilogue: lane holds C[m = m0 + (BM / WM) wm + 16 mt + lr][n = n0 + (BN / WN) wn + 16 nt + 4 lg + r]
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + wn * (BN / WN) + nt * 16 + lg * 4;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
+    for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
-        }
-#pragma unroll
-        for (int mt = 0; mt < TM; ++mt) {
-            const int m = m0 + wm * (BM / WM) + mt * 16 + lr;
-            if (m >= p.M) continue;
-            const f32x4 v = acc[nt][mt] + b;
-            float* dst = p.C + (int64_t)m * p.ldc + n;
-            if (n + 3 < p.N && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
-            else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = v[r];
-            }
-        }
-    }
+        for (int mt = 0; mt < TM; ++mt)
+            split3_epilogue4(p, acc[nt][mt], m0 + wm * (BM / WM) + mt * 16 + lr, n0 + wn * (BN / WN) + nt * 16 + lg * 4);
 }
 
 // Persistent form of the 2 x 4-wave kernel: one workgroup per CU walks tiles t, t + grid, ...; the first two stages of the NEXT tile are issued before the
@@ -269,26 +313,9 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
             if (nk > 1) issue_stage(1, s3mem + S3_STAGE);
         }
 #pragma unroll
-        for (int nt = 0; nt < TN; ++nt) {
-            const int n = en0 + wn * 32 + nt * 16 + lg * 4;
-            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) {
+        for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) b[r] = p.bias[n + r];
-            }
-#pragma unroll
-            for (int mt = 0; mt < TM; ++mt) {
-                const int m = em0 + wm * 64 + mt * 16 + lr;
-                if (m >= p.M) continue;
-                const f32x4 v = acc[nt][mt] + b;
-                float* dst = p.C + (int64_t)m * p.ldc + n;
-                if (n + 3 < p.N && (p.ldc & 3) == 0) *reinterpret_cast<f32x4*>(dst) = v;
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = v[r];
-                }
-            }
-        }
+            for (int mt = 0; mt < TM; ++mt) split3_epilogue4(p, acc[nt][mt], em0 + wm * 64 + mt * 16 + lr, en0 + wn * 32 + nt * 16 + lg * 4);
     }
 }
 
@@ -326,20 +353,12 @@ extern "C" int gg_split3_bf16(const float* x, int64_t rows, int cols, int64_t ld
     return 0;
 }
 
-extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
-                                 const float* bias, void* stream) {
-    GG_CHECK(a_planes && b_planes && C && M > 0 && N > 0 && K > 0, "gg_gemm_nt_split3: null pointer / bad shape");
-    GG_CHECK((K & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && lda >= K && ldb >= K && ldc >= N, "gg_gemm_nt_split3: K, lda, ldb must be multiples of 8, ld >= K / N");
-    GG_CHECK(((uintptr_t)a_planes & 15) == 0 && ((uintptr_t)b_planes & 15) == 0 && ((uintptr_t)C & 15) == 0, "gg_gemm_nt_split3: 16-byte alignment");
-    GG_CHECK((int64_t)256 * lda * 2 < ((int64_t)1 << 31) && (int64_t)256 * ldb * 2 < ((int64_t)1 << 31), "gg_gemm_nt_split3: row pitch too large");
-    Split3Params p;
-    p.A = (const bf16*)a_planes; p.lda = lda; p.plane_a = (int64_t)M * lda;
-    p.B = (const bf16*)b_planes; p.ldb = ldb; p.plane_b = (int64_t)N * ldb;
-    p.C = C; p.ldc = ldc; p.bias = bias; p.M = M; p.N = N; p.K = K;
+static int split3_launch(Split3Params& p, void* stream) {
+    const int M = p.M, N = p.N, K = p.K;
     p.tilesM = (int)gg_cdiv(M, S3_BM); p.tilesN = (int)gg_cdiv(N, S3_BN);
-    // form: 0 = 128 x 128 tile, 2 x 4 waves, fragments read before the MFMAs, 3-stage ring (default); 1 = the same, software-pipelined; 2 = 2 x 2 waves (64 x 64 per
+    // form: 0 = 128 x 128 tile, 2 x 4 waves, fragments read before the MFMAs, 3-stage ring; 1 = the same, software-pipelined; 2 = 2 x 2 waves (64 x 64 per
     // wave), pipelined; 3 = form 0 as persistent workgroups with the next tile's first stages issued before the epilogue; 4 = 256 x 128 tile, 4 x 2 waves of
-    // 64 x 64 (96 MFMAs per 24 fragment reads, two waves per SIMD), 2-stage ring
+    // 64 x 64 (96 MFMAs per 24 fragment reads, two waves per SIMD), 2-stage ring (default)
     static const char* fenv = gg_dev_env("GG_SPLIT3_FORM");
     const int form = fenv ? atoi(fenv) : (M > 128 ? 4 : 0);      // default: the 256 x 128 tile (64 x 64 per wave), the 128 x 128 one for a single row of tiles
     const int fi = form >= 0 && form <= 4 ? form : 0;
@@ -355,9 +374,39 @@ extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* 
                  "gg_gemm_nt_split3: cannot raise the dynamic LDS limit");
         raised[fi] = true;
     }
-    // algorithmic work = the fp32 product it replaces: 2 M N K flop; bytes: three bf16 planes per operand + the f32 result
-    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 6.0 * ((double)M * K + (double)N * K) + 4.0 * (double)M * N, stream);
+    // algorithmic work = the fp32 product it replaces: 2 M N K flop; bytes: three bf16 planes per operand + the result (+ the epilogue's tensors)
+    const double mn = (double)M * N;
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K,
+            6.0 * ((double)M * K + (double)N * K) + 4.0 * mn * ((p.C != nullptr) + (p.preact != nullptr) + (p.residual != nullptr) + (p.dact_preact != nullptr)) +
+                (p.c_planes ? 6.0 * mn : 0.0), stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)(fi == 3 ? std::min(p.tilesM * p.tilesN, 256) : p.tilesM * p.tilesN)), dim3(fi == 2 ? 256 : 512), lds, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int gg_gemm_nt_split3_ex(const GgSplit3Args* a, void* stream) {
+    GG_CHECK(a && a->a_planes && a->b_planes && (a->C || a->c_planes) && a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_split3: null pointer / bad shape");
+    GG_CHECK((a->K & 7) == 0 && (a->lda & 7) == 0 && (a->ldb & 7) == 0 && a->lda >= a->K && a->ldb >= a->K, "gg_gemm_nt_split3: K, lda, ldb must be multiples of 8, ld >= K");
+    GG_CHECK(((uintptr_t)a->a_planes & 15) == 0 && ((uintptr_t)a->b_planes & 15) == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->c_planes & 7) == 0,
+             "gg_gemm_nt_split3: alignment");
+    GG_CHECK((int64_t)256 * a->lda * 2 < ((int64_t)1 << 31) && (int64_t)256 * a->ldb * 2 < ((int64_t)1 << 31), "gg_gemm_nt_split3: row pitch too large");
+    GG_CHECK((!a->C || a->ldc >= a->N) && (!a->c_planes || a->ldp >= a->N) && (!a->residual || a->ldr >= a->N), "gg_gemm_nt_split3: leading dimension too small");
+    GG_CHECK((!a->preact && !a->dact_preact) || a->ldc >= a->N, "gg_gemm_nt_split3: preact / dact_preact use ldc");
+    GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3: rowscale needs rows_per_scale");
+    GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3: act and dact_preact are exclusive");
+    Split3Params p;
+    p.A = (const bf16*)a->a_planes; p.lda = a->lda; p.plane_a = (int64_t)a->M * a->lda;
+    p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = (int64_t)a->N * a->ldb;
+    p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
+    p.act = a->act; p.preact = a->preact; p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = a->residual; p.ldr = a->ldr;
+    p.dact_preact = a->dact_preact; p.dact = a->dact; p.c_planes = (bf16*)a->c_planes; p.ldp = a->ldp;
+    return split3_launch(p, stream);
+}
+
+extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K,
+                                 const float* bias, void* stream) {
+    GgSplit3Args a;
+    memset(&a, 0, sizeof(a));
+    a.a_planes = a_planes; a.lda = lda; a.b_planes = b_planes; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.bias = bias;
+    return gg_gemm_nt_split3_ex(&a, stream);
 }

@@ -220,6 +220,23 @@ int gg_split3_bf16(const float* x, int64_t rows, int cols, int64_t ldx, void* pl
 int gg_layernorm_fwd_split3(const float* x, const float* gamma, const float* beta, int64_t M, int C, float eps, void* planes, float* mean, float* rstd, void* stream);
 int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,
                       void* stream);
+/* the same with the epilogue family of the model's Linears (what gg_gemm_nt_f32 offers for qkv / proj / fc1 / fc2 and their dgrads):
+ * v = acc + bias; preact = v (optional copy); v = act(v)  |  v = acc * act'(dact_preact); v *= rowscale[m / rows_per_scale]; v += residual;
+ * result as f32 C and / or as three bf16 planes c_planes [3][M][ldp] (the next split GEMM's A operand).  preact / dact_preact share ldc. */
+typedef struct {
+    const void* a_planes; int64_t lda;      /* bf16 [3][M][lda] */
+    const void* b_planes; int64_t ldb;      /* bf16 [3][N][ldb] */
+    int M, N, K;
+    float* C; int64_t ldc;                  /* f32 [M][ldc] or NULL */
+    void* c_planes; int64_t ldp;            /* bf16 [3][M][ldp] or NULL */
+    const float* bias;                      /* [N] or NULL */
+    int act;                                /* GG_ACT_* applied to acc + bias */
+    float* preact;                          /* f32 [M][ldc] copy of acc + bias, or NULL */
+    const float* rowscale; int rows_per_scale;
+    const float* residual; int64_t ldr;
+    const float* dact_preact; int dact;     /* v = acc * act'(dact_preact[m][n]) */
+} GgSplit3Args;
+int gg_gemm_nt_split3_ex(const GgSplit3Args* args, void* stream);
 
 /* ---------------------------------------------------------------- reference-precision (fp32) mode
  * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins

@@ -40,13 +40,13 @@ def test_header_symbols_exported_and_bound(L):
 def test_struct_layouts_match_header(L):
     """sizeof() of the ctypes mirrors == sizeof of the C structs (compiled with the host compiler)."""
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "gg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",sizeof(GgGemmArgs),sizeof(GgAttnArgs),' \
-          'sizeof(GgGeoHeadArgs),sizeof(GgProtoRefineArgs),sizeof(GgTinyVitCfg),sizeof(GgClipCfg));return 0;}'
+    src = '#include <stdio.h>\n#include "gg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",sizeof(GgGemmArgs),sizeof(GgAttnArgs),' \
+          'sizeof(GgGeoHeadArgs),sizeof(GgProtoRefineArgs),sizeof(GgTinyVitCfg),sizeof(GgClipCfg),sizeof(GgSplit3Args));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = [int(v) for v in subprocess.check_output([os.path.join(d, "t")]).split()]
-    got = [C.sizeof(x) for x in (L.GemmArgs, L.AttnArgs, L.GeoHeadArgs, L.ProtoRefineArgs, L.TinyVitCfg, L.ClipCfg)]
+    got = [C.sizeof(x) for x in (L.GemmArgs, L.AttnArgs, L.GeoHeadArgs, L.ProtoRefineArgs, L.TinyVitCfg, L.ClipCfg, L.Split3Args)]
     assert got == sizes
 
 

@@ -651,6 +651,61 @@ def test_split3_gemm_is_fp32_accurate(M, N, K):
     assert e < 1e-6 and e < 2.5 * e32 + 1e-7
 
 
+def test_split3_gemm_epilogues_match_the_f32_gemm(ops):
+    """The split GEMM with the epilogue family of the model's Linears against gg_gemm_nt_f32 with the same epilogue (both f32-accurate: agreement at 1e-5):
+    fc1 (bias + GELU + pre-activation copy), fc2 / proj (bias, DropPath row scale, residual), the dgrad through GELU (x GELU'(saved pre-activation) x row
+    scale); and the result leaving as three bf16 planes that sum to the f32 result to 23 bits and feed the next split GEMM."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    M, N, K, rps = 777, 200, 96, 49
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn(M, K, generator=g).cuda(); B = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda(); res = torch.randn(M, N, generator=g).cuda(); pre = torch.randn(M, N, generator=g).cuda()
+    scale = (torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float().cuda() / 0.7
+
+    def planes(x):
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().gg_split3_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), L.stream()), "gg_split3_bf16")
+        return out
+    Ap, Bp = planes(A), planes(B)
+
+    def run(**kw):
+        a = L.Split3Args()
+        a.a_planes, a.lda, a.b_planes, a.ldb, a.M, a.N, a.K = Ap.data_ptr(), K, Bp.data_ptr(), K, M, N, K
+        out = torch.empty(M, N, device="cuda"); a.C, a.ldc = out.data_ptr(), N
+        keep = []
+        for k, v in kw.items():
+            if torch.is_tensor(v):
+                keep.append(v); setattr(a, k, v.data_ptr())
+            else:
+                setattr(a, k, v)
+        L.check(L.lib().gg_gemm_nt_split3_ex(C.byref(a), L.stream()), "gg_gemm_nt_split3_ex")
+        return out
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    # fc1: bias + GELU, pre-activation copy
+    pre_out = torch.empty(M, N, device="cuda")
+    got = run(bias=bias, act=1, preact=pre_out)
+    ref, ref_pre = ops.gemm_nt(A, B, bias=bias, act="gelu", preact=True)
+    assert rel(got, ref) < 1e-5 and rel(pre_out, ref_pre) < 1e-5
+    # fc2 / proj: bias, row scale, residual
+    got = run(bias=bias, rowscale=scale, rows_per_scale=rps, residual=res, ldr=N)
+    ref = ops.gemm_nt(A, B, bias=bias, rowscale=scale, rows_per_scale=rps, residual=res)
+    assert rel(got, ref) < 1e-5
+    # dgrad through GELU
+    got = run(dact_preact=pre, dact=1, rowscale=scale, rows_per_scale=rps)
+    ref = ops.gemm_nt(A, B, dact_preact=pre, dact="gelu", rowscale=scale, rows_per_scale=rps)
+    assert rel(got, ref) < 1e-5
+    # plane output: sums to the f32 result, and chains into the next split GEMM
+    cp = torch.empty(3, M, N, dtype=torch.bfloat16, device="cuda")
+    got = run(bias=bias, c_planes=cp, ldp=N)
+    assert float((cp.double().sum(0) - got.double()).abs().max() / got.abs().max()) < 2 ** -22
+    W2 = (torch.randn(64, N, generator=g) * N ** -0.5).cuda()
+    W2p = planes(W2)
+    out2 = torch.empty(M, 64, device="cuda")
+    L.check(L.lib().gg_gemm_nt_split3(cp.data_ptr(), N, W2p.data_ptr(), N, out2.data_ptr(), 64, M, 64, N, None, L.stream()), "gg_gemm_nt_split3")
+    assert rel(out2, got.double() @ W2.double().T) < 1e-6
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os
