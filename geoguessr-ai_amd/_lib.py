@@ -147,6 +147,7 @@ SIGNATURES = {
     "gg_attention_flash_single_pass": (_I, [_I, _I, _I, _I]),
     "gg_split3_bf16": (_I, [_P, _L, _I, _L, _P, _P]),
     "gg_layernorm_fwd_split3": (_I, [_P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
+    "gg_layernorm_fwd_bn_split3": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P]),
     "gg_gemm_nt_split3": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P, _P]),
     "gg_gemm_nt_split3_ex": (_I, [C.POINTER(Split3Args), _P]),
     "gg_gemm_nt_f32": (_I, [C.POINTER(GemmArgs), _P]),

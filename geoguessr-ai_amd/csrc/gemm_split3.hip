@@ -89,6 +89,93 @@ __device__ __forceinline__ void split3_epilogue4(const Split3Params& p, f32x4 v,
     }
 }
 
+// Row-layout epilogue of a BM x BN tile: the accumulators cross LDS (the idle ring) so that every global access of the epilogue is a run of whole rows --
+// a lane owns 8 consecutive columns of a row, 16 lanes one 128-column row: 512-byte f32 runs and 256-byte plane runs instead of the MFMA layout's
+// 64- / 32-byte pieces of 16 different rows per instruction (the plane-writing epilogues of fc1 / the fc2 dgrad were slower than the f32 GEMM's with those)
+template <int BM, int BN, int NTHR>
+__device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, float* Ct, int m0, int n0) {
+    constexpr int LDT = BN + 4;                                   // padded row: conflict-free 16-byte column writes from the MFMA layout
+    constexpr int CPR = BN / 8;                                   // 8-column chunks per row
+    constexpr int RPP = NTHR / CPR;                               // rows per pass
+    const int chunk = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+    const int n = n0 + chunk * 8;
+    const bool nfull = n + 7 < p.N;
+    float bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (p.bias && n + j < p.N) ? p.bias[n + j] : 0.f;
+    const int64_t plane = (int64_t)p.M * p.ldp;
+    for (int rr = r0; rr < BM; rr += RPP) {
+        const int m = m0 + rr;
+        if (m >= p.M || n >= p.N) continue;
+        float v[8];
+        {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Ct + rr * LDT + chunk * 8), b = *reinterpret_cast<const f32x4*>(Ct + rr * LDT + chunk * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a[j] + bv[j]; v[4 + j] = b[j] + bv[4 + j]; }
+        }
+        auto ld8 = [&](const float* base, int64_t ld, float (&t)[8]) {
+            const float* q = base + (int64_t)m * ld + n;
+            if (nfull && (ld & 3) == 0) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(q), b = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t[j] = a[j]; t[4 + j] = b[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = n + j < p.N ? q[j] : 0.f;
+            }
+        };
+        auto st8 = [&](float* base, int64_t ld, const float (&t)[8]) {
+            float* q = base + (int64_t)m * ld + n;
+            if (nfull && (ld & 3) == 0) {
+                *reinterpret_cast<f32x4*>(q) = (f32x4){t[0], t[1], t[2], t[3]};
+                *reinterpret_cast<f32x4*>(q + 4) = (f32x4){t[4], t[5], t[6], t[7]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (n + j < p.N) q[j] = t[j];
+            }
+        };
+        if (p.preact) st8(p.preact, p.ldc, v);
+        if (p.dact_preact) {
+            float t[8];
+            ld8(p.dact_preact, p.ldc, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gg_act_grad_f32(t[j], p.dact);
+        } else if (p.act) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gg_act_f32(v[j], p.act);
+        }
+        if (p.rowscale) {
+            const float sc = p.rowscale[m / p.rows_per_scale];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= sc;
+        }
+        if (p.residual) {
+            float t[8];
+            ld8(p.residual, p.ldr, t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += t[j];
+        }
+        if (p.C) st8(p.C, p.ldc, v);
+        if (p.c_planes) {
+            bf16x8 p1, p2, p3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bf16 a = (bf16)v[j];
+                const float r1 = v[j] - (float)a;
+                const bf16 b2 = (bf16)r1;
+                p1[j] = a; p2[j] = b2; p3[j] = (bf16)(r1 - (float)b2);
+            }
+            bf16* q = p.c_planes + (int64_t)m * p.ldp + n;
+            if (nfull && (p.ldp & 7) == 0) {
+                *reinterpret_cast<bf16x8*>(q) = p1; *reinterpret_cast<bf16x8*>(q + plane) = p2; *reinterpret_cast<bf16x8*>(q + 2 * plane) = p3;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (n + j < p.N) { q[j] = p1[j]; q[plane + j] = p2[j]; q[2 * plane + j] = p3[j]; }
+            }
+        }
+    }
+}
+
 constexpr int S3_BM = 128, S3_BN = 128, S3_SK = 32;          // tile, k-stage (bf16 elements): a row of a plane tile is 64 bytes
 constexpr int S3_TILE = S3_BM * S3_SK;                         // bf16 elements of one plane tile (8 KB)
 constexpr int S3_STAGE = 6 * S3_TILE;                          // a1 a2 a3 b1 b2 b3
@@ -224,11 +311,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
         }
     }
     // epilogue: lane holds C[m = m0 + (BM / WM) wm + 16 mt + lr][n = n0 + (BN / WN) wn + 16 nt + 4 lg + r]
+    constexpr bool ROWS = (size_t)BM * (BN + 4) * 4 <= (size_t)NST * STAGE * 2;      // the idle ring holds the f32 tile: row-layout epilogue
+    if constexpr (ROWS) {
+        float* Ct = reinterpret_cast<float*>(s3mem);
+        __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments: the ring is free
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt)
+        for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < TM; ++mt)
-            split3_epilogue4(p, acc[nt][mt], m0 + wm * (BM / WM) + mt * 16 + lr, n0 + wn * (BN / WN) + nt * 16 + lg * 4);
+            for (int mt = 0; mt < TM; ++mt)
+                *reinterpret_cast<f32x4*>(Ct + (wm * (BM / WM) + mt * 16 + lr) * (BN + 4) + wn * (BN / WN) + nt * 16 + lg * 4) = acc[nt][mt];
+        __syncthreads();
+        split3_epilogue_rows<BM, BN, 64 * NW>(p, Ct, m0, n0);
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt)
+                split3_epilogue4(p, acc[nt][mt], m0 + wm * (BM / WM) + mt * 16 + lr, n0 + wn * (BN / WN) + nt * 16 + lg * 4);
+    }
 }
 
 // Persistent form of the 2 x 4-wave kernel: one workgroup per CU walks tiles t, t + grid, ...; the first two stages of the NEXT tile are issued before the

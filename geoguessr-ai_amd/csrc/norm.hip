@@ -830,6 +830,20 @@ extern "C" int gg_layernorm_fwd_split3(const float* x, const float* gamma, const
     GG_LAUNCH_CHECK();
     return 0;
 }
+// ... and the form whose input is BatchNorm(y) of a saved pre-BatchNorm conv output (xout = BN(y) f32: the residual stream; planes = LN(xout))
+extern "C" int gg_layernorm_fwd_bn_split3(const float* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, float* xout, const float* gamma,
+                                          const float* beta, int64_t M, int C, float eps, void* planes, float* mean, float* rstd, void* stream) {
+    GG_CHECK(y && bn_stat && bn_gamma && bn_beta && xout && gamma && beta && planes && M > 0 && (C & 7) == 0 && C <= 640, "gg_layernorm_fwd_bn_split3: bad args");
+    const int nchl = (C / 8 + 15) / 16;
+    GG_PROF(GG_CAT_NORM, 0, 14.0 * M * C, stream);
+    const dim3 g16((unsigned)std::min<int64_t>(gg_cdiv(M, 16), 8192)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define GG_LN_FWD(N_) hipLaunchKernelGGL((layernorm_fwd_g16_kernel<float, N_, true, true>), g16, block, 0, s, y, gamma, beta, M, C, eps, (float*)planes, mean, rstd, bn_stat, bn_gamma, bn_beta, xout)
+    switch (nchl) { case 1: GG_LN_FWD(1); break; case 2: GG_LN_FWD(2); break; case 3: GG_LN_FWD(3); break; case 4: GG_LN_FWD(4); break; default: GG_LN_FWD(5); }
+#undef GG_LN_FWD
+    GG_LAUNCH_CHECK();
+    return 0;
+}
 // LayerNorm of BatchNorm(y) for a saved pre-BatchNorm conv output y: xout = BN(y) in the storage type (the residual stream), out = LN(xout)
 template <typename T>
 static int layernorm_fwd_bn_t(const void* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, void* xout,

@@ -202,7 +202,7 @@ class SuperGuessr(nn.Module):
         self.precision = precision or bb_prec or default_precision()
         if self.precision not in PRECISIONS:
             raise ValueError(f"precision='{self.precision}' (known: bf16, fp32)")
-        self.precision = "fp32" if PRECISIONS[self.precision] == 1 else "bf16"
+        self.precision = "fp32" if PRECISIONS[self.precision] in (1, 3) else "bf16"
         if len(kwargs) > 0:
             print(f"Not using keyword arguments: {list(kwargs.keys())}")
         self.base_model = base_model

@@ -38,7 +38,7 @@ VARIANTS = {
 DEPTHS = (2, 2, 6, 2)
 
 
-PRECISIONS = {"bf16": 0, "bfloat16": 0, "fp32": 1, "f32": 1, "float32": 1}
+PRECISIONS = {"bf16": 0, "bfloat16": 0, "fp32": 1, "f32": 1, "float32": 1, "fp32_split": 3}      # fp32_split: experiment (f32 storage, split-bf16 Linears in frozen blocks)
 
 
 def default_precision() -> str:
@@ -116,7 +116,8 @@ class TinyVitBackbone(FlatStore):
         super().__init__()
         self.cfg, self.variant, self.depths = make_cfg(model_name, **overrides)
         self.model_name = model_name.split(".")[0]
-        self.precision = "fp32" if self.cfg.act_dtype == 1 else "bf16"
+        self.precision = "fp32" if self.cfg.act_dtype in (1, 3) else "bf16"          # storage / arithmetic class ("fp32_split" stores and checks like fp32)
+        self.split = self.cfg.act_dtype == 3
         self.table = _tensor_table(self.cfg)
         lib = L.lib()
         self.num_features = int(self.variant["embed_dims"][-1])

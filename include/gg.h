@@ -218,6 +218,8 @@ int gg_attention_flash_single_pass(int tokens_per_window, int head_dim, int wind
 int gg_split3_bf16(const float* x, int64_t rows, int cols, int64_t ldx, void* planes, void* stream);
 /* the producer-side form of the split: f32 LayerNorm (timm LayerNorm in front of qkv / fc1) whose result leaves as the three planes [3][M][C] */
 int gg_layernorm_fwd_split3(const float* x, const float* gamma, const float* beta, int64_t M, int C, float eps, void* planes, float* mean, float* rstd, void* stream);
+int gg_layernorm_fwd_bn_split3(const float* y, const float* bn_stat, const float* bn_gamma, const float* bn_beta, float* xout, const float* gamma, const float* beta,
+                               int64_t M, int C, float eps, void* planes, float* mean, float* rstd, void* stream);
 int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, const float* bias,
                       void* stream);
 /* the same with the epilogue family of the model's Linears (what gg_gemm_nt_f32 offers for qkv / proj / fc1 / fc2 and their dgrads):
@@ -398,7 +400,10 @@ typedef struct GgTinyVitCfg {
     float bn_eps, ln_eps, bn_momentum;
     int act_dtype;       /* 0: bf16 activations + bf16 MFMA operands (fp32 accumulate / statistics / master weights);
                             1: reference-precision mode -- f32 activations, f32 MFMA (v_mfma_f32_16x16x4_f32), erf GELU at fp32 accuracy (1.2 ulp): the
-                               arithmetic of the reference's own torch fp32 forward / backward */
+                               arithmetic of the reference's own torch fp32 forward / backward;
+                            3: "fp32_split" (EXPERIMENT): mode 1's storage and kernels, except that norm1 -> qkv, norm2 -> fc1 -> fc2 and the
+                               fc2 / fc1 dgrads of FROZEN blocks with C >= 384 run as fp32-accurate products of three bf16 planes per operand
+                               (gg_gemm_nt_split3: error below the f32 MFMA GEMM's, 1.2-1.4 x its speed) */
     int features_only;   /* 1: models/tinyvit.py:38-46,139-143 (timm features_only=True): the output is the global-average-pooled
                                last feature map, head.norm is not applied (its parameters stay in the table, unused) */
 } GgTinyVitCfg;

@@ -438,7 +438,7 @@ def _train_step_case(model_name, precision, N, centroids, unfrozen, seed=0, drop
     base = base.cuda()
     cfg = R.config_for(model_name, **kw)
     model = SuperGuessr(base, panorama=True, should_smooth_labels=True).cuda().train()
-    assert model.precision == precision
+    assert model.precision == ("fp32" if precision == "fp32_split" else precision) and base.backbone.split == (precision == "fp32_split")
     if unfrozen:
         base.unfreeze_all()
     bb = base.backbone
@@ -503,6 +503,23 @@ def test_fp32_mode_train_step_matches_fp32_oracle(centroids, model_name, N, unfr
     fp32-rounding tolerances (rtol 1e-4 on embeddings, loss 1e-5 rel)."""
     case = _train_step_case(model_name, "fp32", N, centroids, unfrozen, seed=11, drop_path_rate=0.1)
     label = f"fp32 {model_name} N={N} {'unfrozen' if unfrozen else 'ref-freeze'}"
+    _compare_taps(case["bb"], case["cfg"], case["taps"], 4 * N, F32, 2e-4, label)
+    emb = case["out"].embedding.detach().cpu()
+    e_abs = float((emb - case["emb_o"]).abs().max())
+    l_rel = abs(float(case["out"].loss) - case["loss_o"]) / case["loss_o"]
+    print(f"[{label}] embedding max|err| {e_abs:.3e}, rel-L2 {relerr(emb, case['emb_o']):.3e}, loss rel {l_rel:.3e}")
+    assert e_abs < 5e-4 and relerr(emb, case["emb_o"]) < 1e-4
+    assert l_rel < 1e-5
+    _grad_table(case, 2e-3, label)
+
+
+@pytest.mark.parametrize("model_name,N", [("tiny_vit_21m_224", 4), ("tiny_vit_21m_224", 1)])
+def test_fp32_split_mode_passes_the_fp32_gate(centroids, model_name, N):
+    """The gate of the "fp32_split" experiment (f32 storage; norm1 -> qkv, norm2 -> fc1 -> fc2 and the fc2 / fc1 dgrads of frozen C >= 384 blocks as
+    fp32-accurate products of three bf16 planes per operand): the SAME assertions at the SAME tolerances as the fp32 mode's training-step test --
+    per-stage taps <= 2e-4, embedding 1e-4, loss 1e-5, every gradient tensor 2e-3 -- under the reference freeze policy (the mode only touches frozen blocks)."""
+    case = _train_step_case(model_name, "fp32_split", N, centroids, False, seed=11, drop_path_rate=0.1)
+    label = f"fp32_split {model_name} N={N} ref-freeze"
     _compare_taps(case["bb"], case["cfg"], case["taps"], 4 * N, F32, 2e-4, label)
     emb = case["out"].embedding.detach().cpu()
     e_abs = float((emb - case["emb_o"]).abs().max())
