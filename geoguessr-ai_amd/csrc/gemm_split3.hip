@@ -298,17 +298,49 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
             mfma_stage(xf, wf);
         }
     } else {
-        // 2-stage ring: the DMA of stage s + 1 is issued when stage s starts (into the slot stage s - 1 occupied) and has the stage's MFMAs to land
+        // 2-stage ring: the DMA of stage s + 1 is issued when stage s starts (into the slot stage s - 1 occupied) and has the stage's MFMAs to land.
+        // Within a stage the fragment reads are ordered by first use (a1, b3 | a2, b2 | a3, b1) so the LDS port works under the MFMAs of the previous product
+        // group, and the last product (a1 b1) of stage s is held back behind the barrier of stage s + 1: it runs while that stage's first fragments (a1, b3)
+        // and a2, b2 are read, so the matrix pipe does not idle across the barrier
+        bf16x8 xf[3][TM], wf[3][TN], xn[TM];
+        auto rd_a = [&](const bf16* cur, int pl, bf16x8 (&d)[TM]) {
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) d[mt] = *reinterpret_cast<const bf16x8*>(cur + pl * TA + a_off + mt * 16 * S3_SK);
+        };
+        auto rd_b = [&](const bf16* cur, int pl, bf16x8 (&d)[TN]) {
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) d[nt] = *reinterpret_cast<const bf16x8*>(cur + pl * TB + b_off + nt * 16 * S3_SK);
+        };
+#define S3_MFMA(PA, PB)                                                                                              \
+    _Pragma("unroll") for (int nt = 0; nt < TN; ++nt) _Pragma("unroll") for (int mt = 0; mt < TM; ++mt)             \
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB][nt], xf[PA][mt], acc[nt][mt], 0, 0, 0)
+        wait_outstanding<0>();
+        __builtin_amdgcn_s_barrier();
+        if (nk > 1) issue_stage(1, s3mem + STAGE);
+        rd_a(s3mem, 0, xf[0]); rd_b(s3mem, 2, wf[2]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(xf[0][i]));      // the compiler waits for these reads here: nothing is pending at the loop head
+#pragma unroll
+        for (int i = 0; i < TN; ++i) asm volatile("" : "+v"(wf[2][i]));
         for (int s = 0; s < nk; ++s) {
-            bf16* const cur = s3mem + (s & 1) * STAGE;
-            wait_outstanding<0>();
-            __builtin_amdgcn_s_barrier();
-            if (s + 1 < nk) issue_stage(s + 1, s3mem + ((s + 1) & 1) * STAGE);
-            bf16x8 xf[3][TM], wf[3][TN];
-            frag_read(cur, xf, wf);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            mfma_stage(xf, wf);
+            const bf16* const cur = s3mem + (s & 1) * STAGE;
+            rd_a(cur, 1, xf[1]); rd_b(cur, 1, wf[1]); rd_a(cur, 2, xf[2]); rd_b(cur, 0, wf[0]);
+            S3_MFMA(0, 2); S3_MFMA(1, 1); S3_MFMA(2, 0);
+            S3_MFMA(0, 1); S3_MFMA(1, 0);
+            if (s + 1 < nk) {
+                wait_outstanding<0>();                              // this wave's DMAs of stage s + 1 have landed ...
+                __builtin_amdgcn_s_barrier();                       // ... everybody's have, and every wave holds all its fragments of stage s: its slot may be refilled
+                if (s + 2 < nk) issue_stage(s + 2, s3mem + (s & 1) * STAGE);
+                const bf16* const nxt = s3mem + ((s + 1) & 1) * STAGE;
+                rd_a(nxt, 0, xn); rd_b(nxt, 2, wf[2]);              // b3 of stage s is dead; a1 is still needed by the held-back product
+                S3_MFMA(0, 0);
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) xf[0][mt] = xn[mt];
+            } else {
+                S3_MFMA(0, 0);
+            }
         }
+#undef S3_MFMA
     }
     // epilogue: lane holds C[m = m0 + (BM / WM) wm + 16 mt + lr][n = n0 + (BN / WN) wn + 16 nt + 4 lg + r]
     constexpr bool ROWS = (size_t)BM * (BN + 4) * 4 <= (size_t)NST * STAGE * 2;      // the idle ring holds the f32 tile: row-layout epilogue

@@ -110,6 +110,27 @@ def chain():
         torch.cuda.empty_cache()
 
 
+def quick():
+    """only the split3 kernel next to the f32-MFMA GEMM (us), plain epilogue"""
+    dev = "cuda"
+    for name, M, N, K in [("s2.qkv", 200704, 1152, 384), ("s2.fc1", 200704, 1536, 384), ("s2.fc2", 200704, 384, 1536), ("s2.proj", 200704, 384, 384),
+                          ("s3.fc1", 50176, 2304, 576), ("s3.fc2", 50176, 576, 2304)]:
+        g = torch.Generator(device=dev).manual_seed(1)
+        A = torch.randn(M, K, device=dev, generator=g); B = torch.randn(N, K, device=dev, generator=g) * K ** -0.5
+        Ap, Bp = planes(A), planes(B)
+        o1 = torch.empty(M, N, device=dev); o2 = torch.empty(M, N, device=dev)
+        t32 = timed(lambda: ops.gemm_nt(A, B, out=o1)); ts = timed(lambda: gemm_split3(Ap, Bp, o2))
+        ref = A[:2048].double() @ B.double().T
+        e1 = float((o1[:2048].double() - ref).norm() / ref.norm()); e2 = float((o2[:2048].double() - ref).norm() / ref.norm())
+        fl = 2.0 * M * N * K
+        print(f"{name:8s} f32 {t32*1e3:8.1f} us {fl/t32/1e9:6.1f} | split3 {ts*1e3:8.1f} us {fl/ts/1e9:6.1f} TF-eq ({t32/ts:.2f}x) | rel-L2 {e1:.2e} {e2:.2e}", flush=True)
+        del A, B, Ap, Bp, o1, o2
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
-    main()
-    chain()
+    if len(sys.argv) > 1 and sys.argv[1] == "quick":
+        quick()
+    else:
+        main()
+        chain()
