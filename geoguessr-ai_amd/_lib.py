@@ -202,6 +202,9 @@ SIGNATURES = {
     "gg_prof_read": (_I, [_I, C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gg_prof_count": (_I, []),
     "gg_prof_record": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "gg_graph_set_mode": (_I, [_I]),
+    "gg_graph_stats": (_I, [C.POINTER(_L), C.POINTER(_L), C.POINTER(_L)]),
+    "gg_graph_clear": (_I, []),
     "gg_tinyvit_num_tensors": (_I, [C.POINTER(TinyVitCfg)]),
     "gg_tinyvit_tensor_info": (_I, [C.POINTER(TinyVitCfg), _I, C.c_char_p, _I, C.POINTER(_L), C.POINTER(_L), C.POINTER(_I),
                                     C.POINTER(_L), C.POINTER(_I)]),

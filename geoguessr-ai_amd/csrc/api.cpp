@@ -46,6 +46,7 @@ GgProfScope::GgProfScope(int cat, double flops, double bytes, void* stream) : id
 GgProfScope::~GgProfScope() {
     if (idx_ >= 0) hipEventRecord(g_recs[idx_].b, (hipStream_t)stream_);
 }
+bool gg_prof_is_on() { return g_on; }
 extern "C" int gg_prof_enable(int on) { g_on = on != 0; return 0; }
 extern "C" int gg_prof_reset(void) { g_recs.clear(); g_pool_next = 0; return 0; }
 extern "C" int gg_prof_count(void) { return (int)g_recs.size(); }

@@ -11,6 +11,8 @@
 // R rows x 32 floats = R x 128 bytes, the same byte image as the bf16 kernel's R x 64 tile, so it uses the same 16-byte XOR swizzle
 // (conflict-free ds_write_b128 staging and ds_read_b128 fragment reads).  One ds_read_b128 hands a lane 4 consecutive k of its row:
 // they feed 4 successive MFMA k-steps (lane (r, g) owns k = 4g + s in step s for BOTH operands, so every k is summed exactly once).
+#include <map>
+#include <mutex>
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -40,6 +42,7 @@ struct F32GemmParams {
     const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
     unsigned long long* trace;      // dev (gg_gemm_f32_set_trace): per-workgroup [hw_id, xcc_id, t_start, t_first_data, t_loop_end, t_epilogue_end, tile, 0] (100 MHz ticks)
     int quick;          // FE_GELU / FE_DGELU: the activation is QuickGELU (CLIP) instead of erf GELU
+    int splits = 1, k_per_split = 0;      // small-M form: workgroup (split s, tile t) contracts k in [s k_per_split, (s + 1) k_per_split) into slab s of C ([splits][M][ldc])
 };
 
 __device__ __forceinline__ int f32_chunk_off(int row, int kc) {      // float offset of 16-byte chunk kc (0..7) of a tile row
@@ -636,9 +639,12 @@ template <int IPW> __device__ __forceinline__ void wait_stages_outstanding(int n
 // transformed by exactly one wave.
 // REPI (SB form, 64-column wave layouts): every tile of the launch is interior and aligned (checked by the host) and leaves through the row-layout
 // epilogue; the general epilogue is not compiled in (the two together exceed the 128 registers of the 4-per-CU form)
-template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false, int PRO = 0, bool REPI = false>
+// BM_ = 64 (with BN = 64, 2 x 2 waves of 32 x 32): the small-M form -- a launch with fewer 128-row tiles than the chip has CUs (one
+// serving panorama: M = 784 / 196 rows in stages 2 / 3) is cut into four times as many workgroups; a tile is MFMA-time-bound on its own CU (128 x 128 x 1536
+// = 82 us at one CU's fp32 matrix rate), so what shortens the launch is more CUs, not a better pipeline
+template <int BN, int WM, int WN, int EPI, int NST = 4, int OCC = 2, int BNC = BN, bool SB = false, int PRO = 0, bool REPI = false, int BM_ = 128>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParams p) {
-    constexpr int BM = 128, SK = 16, PTK = 384;
+    constexpr int BM = BM_, SK = 16, PTK = 384;
     constexpr int TM = BM / WM / 16, TN = BNC / WN / 16;
     constexpr int WCOLS = BNC / WN;
     constexpr int ROWS = BM + BN + (PRO == 2 ? BM : 0), STAGE = ROWS * SK;      // floats per stage
@@ -652,7 +658,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     unsigned long long mt0 = 0;
     unsigned long long tw_dma = 0, tw_bar = 0, tw_mfma = 0;       // dev trace: cycles wave 0 spent waiting for its DMAs / at the stage barrier (SB: + fragment reads, MFMA issue)
     if (p.trace) { tr0 = wall_clock64(); mt0 = __builtin_readcyclecounter(); }
-    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    int bx = blockIdx.x;
+    if constexpr (BM_ == 64) {
+        if (p.splits > 1) {          // split-K: this workgroup's share of the contraction, its own result slab
+            const int sp = bx / tiles, ks = sp * p.k_per_split;
+            bx -= sp * tiles;
+            p.A += ks; p.B += ks; p.K = min(p.k_per_split, p.K - ks);
+            p.C += (int64_t)sp * p.M * p.ldc;
+        }
+    }
+    const int bid = gg_xcd_remap(bx, tiles);
     const int tm = bid / p.tilesN, tn = bid % p.tilesN;
     const int m0 = tm * BM, n0 = tn * BNC;
     // the wave index as a scalar: everything derived from it (LDS destinations of the DMAs, the wave's rows and columns) stays in SGPRs.  fp32 MFMA
@@ -951,22 +966,21 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_f32_kernel(F32TnParams p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     if (FE || (kt < kt_lim && nt < nt_lim))
-                        acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[nt], xf[kt], acc[kt][nt], 0, 0, 0);   // rows n, cols k
+                        acc[kt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xf[kt], yf[nt], acc[kt][nt], 0, 0, 0);   // rows k, cols n
         }
         __syncthreads();
     }
-    // lane holds D[n = .. + nt*16 + 4lg + r][k = .. + kt*16 + lr]
+    // lane holds D[k = .. + kt*16 + 4lg + r][n = .. + nt*16 + lr]: its four values are consecutive along a row of part[n][k] -- one 16-byte store per
+    // fragment (K % 4 == 0: a chunk is entirely inside or outside).  With the operands the other way round a lane held four ROWS of one column and the
+    // slab left in 4-byte stores: the head's weight gradient (N = 12647, M = 256 rows to reduce) spent 0.45 of its 0.5 ms storing
     float* out = p.part + (int64_t)(SMALL ? split_id * 4 + wave : split_id) * p.N * p.K;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            const int k = k0 + wk * 64 + kt * 16 + lr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 64 + nt * 16 + lg * 4 + r;
-                if (n < p.N && k < p.K) out[(int64_t)n * p.K + k] = acc[kt][nt][r];
-            }
+            const int k = k0 + wk * 64 + kt * 16 + lg * 4;
+            const int n = n0 + wn * 64 + nt * 16 + lr;
+            if (n < p.N && k < p.K) *reinterpret_cast<f32x4*>(out + (int64_t)n * p.K + k) = acc[kt][nt];
         }
 }
 
@@ -1007,6 +1021,41 @@ __global__ void colsum_final_f32_kernel(const float* __restrict__ part, int npar
 static unsigned long long* g_f32_trace = nullptr;
 // dev: per-workgroup timeline of the ring kernel (tools/trace_gemm_f32.py); buf = 8 x uint64 per tile or NULL to switch it off
 extern "C" int gg_gemm_f32_set_trace(void* buf) { g_f32_trace = (unsigned long long*)buf; return 0; }
+// split-K of the small-M form: C[m][n] = (sum over the slabs in slab order + bias) * rowscale + residual -- the linear epilogue's arithmetic after a
+// deterministic reduction (no atomics: a step stays repeatable bit for bit)
+__global__ __launch_bounds__(256) void splitk_nt_reduce_f32_kernel(const float* __restrict__ part, int splits, int M, int N, float* __restrict__ C, int64_t ldc,
+                                                                   const float* __restrict__ bias, const float* __restrict__ rowscale, int rows_per_scale,
+                                                                   const float* __restrict__ residual, int64_t ldr) {
+    const int n4 = N >> 2;
+    const int64_t total = (int64_t)M * n4, slab = (int64_t)M * N;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)m * N + n);
+        for (int sidx = 1; sidx < splits; ++sidx) v += *reinterpret_cast<const f32x4*>(part + sidx * slab + (int64_t)m * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (rowscale) v *= rowscale[m / rows_per_scale];
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + (int64_t)m * ldr + n);
+        *reinterpret_cast<f32x4*>(C + (int64_t)m * ldc + n) = v;
+    }
+}
+// slabs of the split-K form: one lazily allocated 16 MiB buffer per device (first use is an eager call: the graph cache never captures a first sighting).
+// The library issues its GEMMs on one compute stream per device; two streams running split-K launches of the same device concurrently would share the slabs --
+// GG_GEMM_SPLITK=0 turns the form off for such a caller
+constexpr int64_t kSplitScratchFloats = (int64_t)4 << 20;
+static float* splitk_scratch() {
+    static std::mutex mu;
+    static std::map<int, float*> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = bufs.find(dev);
+    if (it != bufs.end()) return it->second;
+    float* b = nullptr;
+    if (hipMalloc((void**)&b, kSplitScratchFloats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); b = nullptr; }
+    bufs[dev] = b;
+    return b;
+}
+
 extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     GG_CHECK(a && a->A && a->B && a->C, "gg_gemm_nt_f32: null operand");
     GG_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_f32: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -1055,6 +1104,29 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     if (wide96) narrow = false;
     const int bn = wide96 ? 96 : (narrow ? 64 : 128);
     p.tilesM = (int)gg_cdiv(a->M, 128); p.tilesN = (int)gg_cdiv(a->N, bn);
+    // small-M form (64 x 64 tiles): launches that would leave CUs idle; not for the forms that write per-128-row column statistics
+    static const char* small_env = gg_dev_env("GG_GEMM_F32_NO_SMALL");
+    static const char* small_max_env = gg_dev_env("GG_GEMM_F32_SMALL_MAX");
+    static const int small_max = small_max_env ? atoi(small_max_env) : 256;      // fewer 128-row tiles than CUs
+    const bool small = !small_env && !a->a_bn_stat && !a->colstats && !a->bn_y && (int64_t)p.tilesM * p.tilesN <= small_max;
+    if (small) { p.tilesM = (int)gg_cdiv(a->M, 64); p.tilesN = (int)gg_cdiv(a->N, 64); }
+    // split-K on top: few tiles and a long contraction (the head's data gradient: M = batch, N = 576, K = 12648 -- 36 tiles walking 790 k-stages each;
+    // fc2 of stage 3 at one panorama) -- plain / linear epilogues only, applied by the reduction
+    static const char* nosplit_env = getenv("GG_GEMM_SPLITK") && atoi(getenv("GG_GEMM_SPLITK")) == 0 ? "1" : gg_dev_env("GG_GEMM_F32_NO_SPLITK");
+    float* slabs = nullptr;
+    int nsplit = 1;
+    if (small && !nosplit_env && a->K >= 1024 && (int64_t)p.tilesM * p.tilesN <= 64 && !(a->act || a->preact || a->dact_preact) && (a->N & 3) == 0 && (a->ldc & 3) == 0 &&
+        (!a->residual || (a->ldr & 3) == 0) && (!a->bias || ((uintptr_t)a->bias & 15) == 0)) {
+        const int tiles64 = p.tilesM * p.tilesN;
+        int want = std::min<int64_t>(std::max(1, 256 / tiles64), a->K / 256);
+        want = (int)std::min<int64_t>(want, kSplitScratchFloats / ((int64_t)a->M * a->N));
+        if (want > 1) {
+            const int kps = (int)gg_align(gg_cdiv(a->K, want), 16);
+            nsplit = (int)gg_cdiv(a->K, kps);
+            if (nsplit > 1 && (slabs = splitk_scratch()) != nullptr) { p.splits = nsplit; p.k_per_split = kps; }
+            else nsplit = 1;
+        }
+    }
     static const char* dbg = gg_dev_env("GG_GEMM_F32_DEBUG");
     p.debug = dbg ? atoi(dbg) : 0;
     p.trace = g_f32_trace;
@@ -1095,7 +1167,8 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     const bool sb96 = ring && wide96 && rows_ok && a->K <= sb_k;      // N = 96, 288: the 4 x 1 wave layout of the single-buffer form with the row-layout epilogue
 #define GG_LAUNCH_F32(E)                                                                                          \
     do {                                                                                                          \
-        if (sb && narrow && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true, 0, true>), grid, dim3(256), 0, st, p); \
+        if (small) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 2, 2, E, 4, 4, 64, false, 0, false, 64>), dim3(p.tilesM * p.tilesN), dim3(256), 0, st, p); \
+        else if (sb && narrow && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true, 0, true>), grid, dim3(256), 0, st, p); \
         else if (sb && rows_epi) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true, 0, true>), grid, dim3(256), 0, st, p); \
         else if (sb && narrow) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 4, 1, E, 2, (E == FE_BNBWD ? 4 : ((E == FE_DGELU || E == FE_LINEAR) ? 5 : 6)), 64, true>), grid, dim3(256), 0, st, p); \
         else if (sb) hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<128, 2, 2, E, 2, 4, 128, true>), grid, dim3(256), 0, st, p); \
@@ -1143,6 +1216,16 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         GG_LAUNCH_CHECK();
         return 0;
     }
+    if (nsplit > 1) {        // slabs through the plain epilogue, then the reduction applies bias / rowscale / residual
+        F32GemmParams q = p;
+        q.C = slabs; q.ldc = a->N; q.bias = nullptr; q.rowscale = nullptr; q.residual = nullptr;
+        hipLaunchKernelGGL((gemm_nt_f32_ring_kernel<64, 2, 2, FE_PLAIN, 4, 4, 64, false, 0, false, 64>), dim3(p.tilesM * p.tilesN * nsplit), dim3(256), 0, st, q);
+        const int64_t n4 = (int64_t)a->M * (a->N >> 2);
+        hipLaunchKernelGGL(splitk_nt_reduce_f32_kernel, dim3((unsigned)std::min<int64_t>(gg_cdiv(n4, 256), 2048)), dim3(256), 0, st, slabs, nsplit, a->M, a->N, (float*)a->C, a->ldc,
+                           a->bias, a->rowscale, a->rows_per_scale, (const float*)a->residual, a->ldr);
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     switch (epi) {
         case FE_BNBWD: GG_LAUNCH_F32(FE_BNBWD); break;
         case FE_PLAIN: GG_LAUNCH_F32(FE_PLAIN); break;
@@ -1172,7 +1255,7 @@ static int gemm_tn_f32_launch(const void* dY, const void* Y2, const float* coef,
                               int rows_per_scale, float* partials, int splits, void* stream) {
     GG_CHECK(dY && X && partials && M > 0 && N > 0 && K > 0 && splits > 0, "gg_gemm_tn_f32: bad args");
     GG_CHECK((N & 3) == 0 && (K & 3) == 0 && (ldy & 3) == 0 && (ldx & 3) == 0, "gg_gemm_tn_f32: N, K, ldy, ldx must be multiples of 4");
-    GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0, "gg_gemm_tn_f32: operands must be 16-byte aligned");
+    GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)partials & 15) == 0, "gg_gemm_tn_f32: operands and partials must be 16-byte aligned");
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn_f32: rows_per_scale");
     F32TnParams p;
     p.dY = (const float*)dY; p.ldy = ldy; p.X = (const float*)X; p.ldx = ldx; p.M = M; p.N = N; p.K = K;

@@ -1,0 +1,112 @@
+// HIP-graph cache behind gg_tinyvit_forward / gg_tinyvit_backward / gg_clip_forward (graph.h).
+#include "graph.h"
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
+#include "../../include/gg.h"
+#include "prof.h"
+
+bool gg_prof_is_on();
+
+namespace {
+struct Slot {
+    std::string key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    bool refused = false;          // capture / instantiation failed once: this key stays eager
+    uint64_t tick = 0;
+};
+std::mutex g_mu;
+std::vector<Slot> g_slots;
+uint64_t g_tick = 0;
+hipStream_t g_capture = nullptr;
+int g_mode = -2;                   // -2: read GG_GRAPH on first use; -1 auto; 0 off; 1 on
+long g_captures = 0, g_replays = 0, g_eager = 0;
+constexpr size_t kMaxSlots = 16;
+
+void drop(Slot& s) {
+    if (s.exec) (void)hipGraphExecDestroy(s.exec);
+    if (s.graph) (void)hipGraphDestroy(s.graph);
+    s.exec = nullptr; s.graph = nullptr;
+}
+int mode() {
+    if (g_mode == -2) {
+        const char* e = getenv("GG_GRAPH");
+        g_mode = !e || !*e ? -1 : (atoi(e) != 0 ? 1 : 0);
+    }
+    return g_mode;
+}
+}  // namespace
+
+bool gg_graph_wanted(bool launch_bound) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (gg_prof_is_on()) return false;
+    const int m = mode();
+    return m == 1 || (m == -1 && launch_bound);
+}
+
+int gg_graph_run(const GgGraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& body) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Slot* s = nullptr;
+    for (auto& c : g_slots) if (c.key == key.bytes) { s = &c; break; }
+    if (!s) {
+        // first sighting: run eagerly (one-time function attributes and static tables are set on this path) and remember the key
+        if (g_slots.size() >= kMaxSlots) {
+            size_t lru = 0;
+            for (size_t i = 1; i < g_slots.size(); ++i) if (g_slots[i].tick < g_slots[lru].tick) lru = i;
+            drop(g_slots[lru]);
+            g_slots.erase(g_slots.begin() + lru);
+        }
+        g_slots.emplace_back();
+        g_slots.back().key = key.bytes;
+        g_slots.back().tick = ++g_tick;
+        ++g_eager;
+        return body(stream);
+    }
+    s->tick = ++g_tick;
+    if (s->refused) { ++g_eager; return body(stream); }
+    if (!s->exec) {
+        if (!g_capture && hipStreamCreateWithFlags(&g_capture, hipStreamNonBlocking) != hipSuccess) { s->refused = true; (void)hipGetLastError(); ++g_eager; return body(stream); }
+        if (hipStreamBeginCapture(g_capture, hipStreamCaptureModeThreadLocal) != hipSuccess) { s->refused = true; (void)hipGetLastError(); ++g_eager; return body(stream); }
+        const int rc = body(g_capture);
+        hipGraph_t g = nullptr;
+        const hipError_t ec = hipStreamEndCapture(g_capture, &g);
+        if (rc != 0) {              // nothing was enqueued; the failure may belong to the capture (an allocation, a query): this key stays eager -- a genuine
+            if (g) (void)hipGraphDestroy(g);      // argument error fails again below with its own message
+            (void)hipGetLastError();
+            s->refused = true; ++g_eager;
+            return body(stream);
+        }
+        if (ec != hipSuccess || !g) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); s->refused = true; ++g_eager; return body(stream); }
+        hipGraphExec_t x = nullptr;
+        if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || !x) { (void)hipGetLastError(); (void)hipGraphDestroy(g); s->refused = true; ++g_eager; return body(stream); }
+        s->graph = g; s->exec = x;
+        ++g_captures;
+    }
+    if (hipGraphLaunch(s->exec, stream) != hipSuccess) {
+        gg_set_error("gg_graph_run: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+        return -1;
+    }
+    ++g_replays;
+    return 0;
+}
+
+extern "C" int gg_graph_set_mode(int m) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (m < -1 || m > 1) { gg_set_error("gg_graph_set_mode: mode must be -1 (auto), 0 (off) or 1 (on)"); return -1; }
+    g_mode = m;
+    return 0;
+}
+extern "C" int gg_graph_stats(int64_t* captures, int64_t* replays, int64_t* eager) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (captures) *captures = g_captures;
+    if (replays) *replays = g_replays;
+    if (eager) *eager = g_eager;
+    return (int)g_slots.size();
+}
+extern "C" int gg_graph_clear(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& s : g_slots) drop(s);
+    g_slots.clear();
+    return 0;
+}

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "common.h"
+#include "graph.h"
 #include "../../include/gg.h"
 
 namespace {
@@ -1292,12 +1293,20 @@ extern "C" int gg_tinyvit_forward(const GgTinyVitCfg* cfg, int batch, int traini
     GG_CHECK(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)wcache & 255) == 0, "gg_tinyvit_forward: workspace/wcache must be 256-byte aligned");
     Plan p; Layout L;
     plan_make(m, batch, training != 0, p, L, trainable);
-    Exec e;
-    e.m = &m; e.L = &L; e.B = batch; e.training = training != 0; e.params = params; e.buffers = buffers; e.counters = counters;
-    e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = (hipStream_t)stream; e.drop = drop_scales; e.grads = nullptr;
-    e.trainable = trainable;       // NULL: keep every activation a weight gradient could need
-    e.exec_init();
-    return forward_impl(e, x, out);
+    auto body = [&](hipStream_t st) -> int {
+        Exec e;
+        e.m = &m; e.L = &L; e.B = batch; e.training = training != 0; e.params = params; e.buffers = buffers; e.counters = counters;
+        e.wc = (const char*)wcache; e.ws = (char*)workspace; e.st = st; e.drop = drop_scales; e.grads = nullptr;
+        e.trainable = trainable;       // NULL: keep every activation a weight gradient could need
+        e.exec_init();
+        return forward_impl(e, x, out);
+    };
+    // launch-bound sizes (a serving panorama, small training batches: a few hundred launches of microseconds each) replay a captured graph
+    if (!gg_graph_wanted((int64_t)batch * cfg->img_size * cfg->img_size <= (int64_t)64 * 224 * 224)) return body((hipStream_t)stream);
+    GgGraphKey key;
+    key.add('F').add_bytes(cfg, sizeof(*cfg)).add(batch).add(training).add(params).add(buffers).add(counters).add(wcache).add(x).add(drop_scales).add(workspace).add(out)
+       .add_bytes(trainable, trainable ? m.tensors.size() : 0);
+    return gg_graph_run(key, (hipStream_t)stream, body);
 }
 extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const float* params, const void* wcache, const float* drop_scales,
                                    void* workspace, const float* d_out, float* grads, const uint8_t* trainable, void* stream,
@@ -1326,6 +1335,18 @@ extern "C" int gg_tinyvit_backward(const GgTinyVitCfg* cfg, int batch, const flo
                      "gg_tinyvit_backward: %s and %s must be trainable or frozen together (requires_grad differs within the pair)", n.c_str(), it->first.c_str());
         }
     }
-    e.exec_init();
-    return backward_impl(e, d_out);
+    if (stage_done || !gg_graph_wanted((int64_t)batch * cfg->img_size * cfg->img_size <= (int64_t)64 * 224 * 224)) {      // a host callback per stage (N > 1): eager
+        e.exec_init();
+        return backward_impl(e, d_out);
+    }
+    auto body = [&](hipStream_t st) -> int {
+        Exec g = e;
+        g.st = st;
+        g.exec_init();
+        return backward_impl(g, d_out);
+    };
+    GgGraphKey key;
+    key.add('B').add_bytes(cfg, sizeof(*cfg)).add(batch).add(params).add(wcache).add(drop_scales).add(workspace).add(d_out).add(grads)
+       .add_bytes(trainable, trainable ? m.tensors.size() : 0);
+    return gg_graph_run(key, (hipStream_t)stream, body);
 }

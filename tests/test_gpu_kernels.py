@@ -123,6 +123,34 @@ def test_f32_gemm_tn_with_batchnorm_apply_on_load(ops, M, N, K):
     assert float((got - plain).abs().max()) < 1e-5 * scale
 
 
+@pytest.mark.parametrize("M,N,K", [(784, 384, 1536), (196, 576, 2304), (8, 320, 12648), (256, 576, 12648), (1, 12648, 576), (784, 1152, 384), (200, 100, 52),
+                                   (70, 68, 1028)])
+def test_f32_gemm_small_m_form_and_split_k(ops, M, N, K):
+    """Launches with fewer 128-row tiles than CUs run as 64 x 64 tiles; few tiles with a long contraction (the head's data gradient: K = 12648; stage-3 fc2 at one
+    panorama) additionally split K into slabs reduced in slab order: every epilogue of the form against torch fp64, ragged edges included, and repeatable bit
+    for bit (no atomics)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).cuda(); B = (torch.randn(N, K, generator=g) * 0.1).cuda()
+    bias = torch.randn(N, generator=g).cuda(); res = torch.randn(M, N, generator=g).cuda()
+    rps = max(1, M // 4)
+    rsc = (torch.rand((M + rps - 1) // rps, generator=g) + 0.5).cuda()
+    ref = A.double() @ B.double().t()
+    rs_rows = rsc.double().repeat_interleave(rps)[:M, None]
+    def rel(a, b): return float((a.double() - b).abs().max() / b.abs().max())
+    tol = 2e-5 if K > 1000 else 4e-6
+    a = ops.gemm_nt(A, B)
+    assert rel(a, ref) < tol and torch.equal(a, ops.gemm_nt(A, B))
+    assert rel(ops.gemm_nt(A, B, bias=bias), ref + bias.double()) < tol
+    assert rel(ops.gemm_nt(A, B, bias=bias, residual=res), ref + bias.double() + res.double()) < tol
+    assert rel(ops.gemm_nt(A, B, rowscale=rsc, rows_per_scale=rps), ref * rs_rows) < tol
+    assert rel(ops.gemm_nt(A, B, bias=bias, residual=res, rowscale=rsc, rows_per_scale=rps), (ref + bias.double()) * rs_rows + res.double()) < tol
+    y, pre = ops.gemm_nt(A, B, bias=bias, act="gelu", preact=True)
+    assert rel(y, F.gelu(ref + bias.double())) < tol and rel(pre, ref + bias.double()) < tol
+    h = torch.randn(M, N, generator=g).cuda()
+    hh = h.double().clone().requires_grad_(True); F.gelu(hh).sum().backward()
+    assert rel(ops.gemm_nt(A, B, dact_preact=h, dact="gelu"), ref * hh.grad) < tol
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 576, 96), (12544, 576, 2304), (12544, 2304, 576), (12544, 1728, 576), (256, 64, 48), (512, 96, 64), (25088, 96, 384),
                                    (1024, 288, 128)])
 def test_f32_gemm_row_layout_epilogue(ops, M, N, K):
