@@ -247,6 +247,25 @@ def secondary_cases(dev, budget_s=15.0):
         out["c1"] = dict(workload="tiny_vit_5m_224, batch 8 single images, fwd + hard-CE + bwd + AdamW", dtype="fp32", ms_per_step=round(dt * 1e3, 3), images_per_s=round(8 / dt, 1))
         del model, base, opt, x
         cleanup()
+        # the serving call of the reference's inference.py:162-170 on ONE panorama (4 headings through TinyViT-21M + the geocell head): latency with the GPU drained
+        # after every call -- the launch-bound end of the path (64 x 64 small-M GEMM tiles, split-K, captured HIP graph)
+        base = TinyViTAdapter("tiny_vit_21m_224", pretrained=False, precision="fp32")
+        model = SuperGuessr(base, panorama=True, serving=True).to(dev).eval()
+        xs = torch.randn(1, 4, 3, 224, 224, device=dev)
+        dummy = torch.zeros(1, dtype=torch.long, device=dev)
+        with torch.no_grad():
+            for _ in range(5):
+                model(pixel_values=xs, labels_clf=dummy)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                model(pixel_values=xs, labels_clf=dummy)
+                torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 50
+        out["serve_1_panorama"] = dict(workload="tiny_vit_21m_224 + geocell head, serving call on 1 panorama (4 images), synchronised after every call", dtype="fp32",
+                                       latency_ms=round(dt * 1e3, 3), panoramas_per_s=round(1 / dt, 1))
+        del model, base, xs
+        cleanup()
         for prec in ("fp32", "fp16"):
             tower = CLIPVisionTower("openai/clip-vit-base-patch32", precision=prec).to(dev).eval()
             for p_ in tower.parameters():

@@ -1,4 +1,4 @@
-// EXPERIMENT ("the bf16 x 3 split"): an fp32-accurate GEMM on the bf16 matrix pipe.
+// The fp32_split mode's GEMM ("the bf16 x 3 split"): an fp32-accurate GEMM on the bf16 matrix pipe.
 //
 //   C[M,N] (f32) = A[M,K] . B[N,K]^T   with   A = a1 + a2 + a3,  B = b1 + b2 + b3   (three bf16 terms each: 24 significand bits)
 //                = (a1 b3 + a2 b2 + a3 b1) + (a1 b2 + a2 b1) + a1 b1                  (six bf16 products, f32 accumulation; the dropped terms are < 2^-24)
@@ -14,7 +14,8 @@
 //     16-byte chunk index XOR-ed with (row >> 2) & 3 on the SOURCE side of the DMA, so the fragment reads (ds_read_b128: 16 rows x one chunk) are
 //     conflict-free without padding;
 //   * one raw s_barrier per stage, the next stage's DMA in flight under the current stage's 96 MFMAs; two waves per SIMD.
-// Plain epilogue (optional bias), f32 result.  Not wired into the model runtimes: measured by tools/bench_split3.py next to the f32-MFMA GEMM.
+// Epilogues: the Linear family of the model (bias, GELU with a saved pre-activation, rowscale + residual, x GELU'), results as f32 and / or as planes for the
+// next split GEMM.  Used by csrc/tinyvit.hip in the fp32_split mode (frozen C >= 384 blocks); tools/bench_split3.py times it next to the f32-MFMA GEMM.
 #include "common.h"
 #include <stdlib.h>
 #include <string.h>
