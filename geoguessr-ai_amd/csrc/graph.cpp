@@ -1,6 +1,7 @@
-// HIP-graph cache behind gg_tinyvit_forward / gg_tinyvit_backward / gg_clip_forward (graph.h).
+// HIP-graph cache behind gg_tinyvit_forward / gg_tinyvit_backward (graph.h).
 #include "graph.h"
 #include <stdlib.h>
+#include <map>
 #include <mutex>
 #include <vector>
 #include "../../include/gg.h"
@@ -19,7 +20,7 @@ struct Slot {
 std::mutex g_mu;
 std::vector<Slot> g_slots;
 uint64_t g_tick = 0;
-hipStream_t g_capture = nullptr;
+std::map<int, hipStream_t> g_capture;      // per device
 int g_mode = -2;                   // -2: read GG_GRAPH on first use; -1 auto; 0 off; 1 on
 long g_captures = 0, g_replays = 0, g_eager = 0;
 constexpr size_t kMaxSlots = 16;
@@ -45,12 +46,16 @@ bool gg_graph_wanted(bool launch_bound) {
     return m == 1 || (m == -1 && launch_bound);
 }
 
-int gg_graph_run(const GgGraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& body) {
-    std::lock_guard<std::mutex> lk(g_mu);
+int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::function<int(hipStream_t)>& body) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return body(stream); }
+    GgGraphKey key = key_in;
+    key.add(dev);                                          // a graph belongs to the device it was captured on
+    std::unique_lock<std::mutex> lk(g_mu);
     Slot* s = nullptr;
     for (auto& c : g_slots) if (c.key == key.bytes) { s = &c; break; }
     if (!s) {
-        // first sighting: run eagerly (one-time function attributes and static tables are set on this path) and remember the key
+        // first sighting: run eagerly (one-time function attributes, lazily allocated scratch and static tables are set on this path) and remember the key
         if (g_slots.size() >= kMaxSlots) {
             size_t lru = 0;
             for (size_t i = 1; i < g_slots.size(); ++i) if (g_slots[i].tick < g_slots[lru].tick) lru = i;
@@ -61,25 +66,29 @@ int gg_graph_run(const GgGraphKey& key, hipStream_t stream, const std::function<
         g_slots.back().key = key.bytes;
         g_slots.back().tick = ++g_tick;
         ++g_eager;
+        lk.unlock();
         return body(stream);
     }
     s->tick = ++g_tick;
-    if (s->refused) { ++g_eager; return body(stream); }
+    if (s->refused) { ++g_eager; lk.unlock(); return body(stream); }
     if (!s->exec) {
-        if (!g_capture && hipStreamCreateWithFlags(&g_capture, hipStreamNonBlocking) != hipSuccess) { s->refused = true; (void)hipGetLastError(); ++g_eager; return body(stream); }
-        if (hipStreamBeginCapture(g_capture, hipStreamCaptureModeThreadLocal) != hipSuccess) { s->refused = true; (void)hipGetLastError(); ++g_eager; return body(stream); }
-        const int rc = body(g_capture);
+        // second sighting: capture on this device's private stream (the caller's may be the legacy default stream, which cannot be captured); the lock is
+        // held: one capture at a time, and nobody replays a half-built slot
+        hipStream_t& cap = g_capture[dev];
+        auto refuse = [&]() { (void)hipGetLastError(); s->refused = true; ++g_eager; lk.unlock(); return body(stream); };
+        if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) { cap = nullptr; return refuse(); }
+        if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) return refuse();
+        const int rc = body(cap);
         hipGraph_t g = nullptr;
-        const hipError_t ec = hipStreamEndCapture(g_capture, &g);
-        if (rc != 0) {              // nothing was enqueued; the failure may belong to the capture (an allocation, a query): this key stays eager -- a genuine
-            if (g) (void)hipGraphDestroy(g);      // argument error fails again below with its own message
-            (void)hipGetLastError();
-            s->refused = true; ++g_eager;
-            return body(stream);
+        const hipError_t ec = hipStreamEndCapture(cap, &g);
+        if (rc != 0 || ec != hipSuccess || !g) {
+            // nothing was enqueued.  The failure may belong to the capture (an allocation, a query): this key stays eager -- a genuine argument error fails
+            // again below with its own message
+            if (g) (void)hipGraphDestroy(g);
+            return refuse();
         }
-        if (ec != hipSuccess || !g) { (void)hipGetLastError(); if (g) (void)hipGraphDestroy(g); s->refused = true; ++g_eager; return body(stream); }
         hipGraphExec_t x = nullptr;
-        if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || !x) { (void)hipGetLastError(); (void)hipGraphDestroy(g); s->refused = true; ++g_eager; return body(stream); }
+        if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || !x) { (void)hipGraphDestroy(g); return refuse(); }
         s->graph = g; s->exec = x;
         ++g_captures;
     }

@@ -390,7 +390,7 @@ int gg_prof_count(void);
 int gg_prof_record(int index, int* category /* host */, double* ms /* host */, double* flops /* host */, double* bytes /* host */);
 
 /* ---------------------------------------------------------------- captured HIP graphs for launch-bound calls
- * gg_tinyvit_forward / gg_tinyvit_backward (no stage callback) / gg_clip_forward are fixed launch sequences of their arguments: the second call with
+ * gg_tinyvit_forward / gg_tinyvit_backward (no stage callback) are fixed launch sequences of their arguments: the second call with
  * the same arguments (pointers included) is captured on a private stream, later ones replay the instantiated graph on the caller's stream.
  * mode -1 (default; env GG_GRAPH unset): only launch-bound sizes (<= 64 images of 224 x 224); 0 (GG_GRAPH=0): never; 1 (GG_GRAPH=1): always.  Off while
  * gg_prof_enable(1).  The reference has no counterpart (eager PyTorch: inference.py:162-170 issues the same few hundred launches per panorama). */
