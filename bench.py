@@ -243,7 +243,7 @@ def secondary_cases(dev, budget_s=15.0):
         def c1():
             o = model(pixel_values=x, labels=lab, labels_clf=clf)
             o.loss.backward(); opt.step(); opt.zero_grad()
-        dt = timed(c1, 20, 5)
+        dt = timed(c1, 15, 4)
         out["c1"] = dict(workload="tiny_vit_5m_224, batch 8 single images, fwd + hard-CE + bwd + AdamW", dtype="fp32", ms_per_step=round(dt * 1e3, 3), images_per_s=round(8 / dt, 1))
         del model, base, opt, x
         cleanup()
@@ -258,10 +258,10 @@ def secondary_cases(dev, budget_s=15.0):
                 model(pixel_values=xs, labels_clf=dummy)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(50):
+            for _ in range(30):
                 model(pixel_values=xs, labels_clf=dummy)
                 torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 50
+            dt = (time.perf_counter() - t0) / 30
         out["serve_1_panorama"] = dict(workload="tiny_vit_21m_224 + geocell head, serving call on 1 panorama (4 images), synchronised after every call", dtype="fp32",
                                        latency_ms=round(dt * 1e3, 3), panoramas_per_s=round(1 / dt, 1))
         del model, base, xs
@@ -272,7 +272,7 @@ def secondary_cases(dev, budget_s=15.0):
                 p_.requires_grad = False
             xc = torch.randn(1024, 3, 224, 224, device=dev)
             with torch.no_grad():
-                dt = timed(lambda: tower(pixel_values=xc, return_last_hidden=False), 5 if prec == "fp32" else 10, 2)
+                dt = timed(lambda: tower(pixel_values=xc, return_last_hidden=False), 3 if prec == "fp32" else 10, 1 if prec == "fp32" else 2)
             peak = 157.3 if prec == "fp32" else 2500.0
             tf = 1024 / dt * 8.82e9 / 1e12
             out["c4_" + prec] = dict(workload="CLIP ViT-B/32 vision tower inference (random weights), batch 1024", dtype=prec, ms_per_step=round(dt * 1e3, 3),
