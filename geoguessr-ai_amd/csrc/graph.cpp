@@ -24,6 +24,8 @@ std::map<int, hipStream_t> g_capture;      // per device
 int g_mode = -2;                   // -2: read GG_GRAPH on first use; -1 auto; 0 off; 1 on
 long g_captures = 0, g_replays = 0, g_eager = 0;
 constexpr size_t kMaxSlots = 16;
+constexpr long kMaxWasted = 8;       // evicted captured graphs after which no new graph is captured (a caller whose buffers change address every call)
+long g_wasted = 0;
 
 void drop(Slot& s) {
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
@@ -59,6 +61,7 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
         if (g_slots.size() >= kMaxSlots) {
             size_t lru = 0;
             for (size_t i = 1; i < g_slots.size(); ++i) if (g_slots[i].tick < g_slots[lru].tick) lru = i;
+            if (g_slots[lru].exec) ++g_wasted;            // a captured graph leaves the cache: the caller's addresses churn
             drop(g_slots[lru]);
             g_slots.erase(g_slots.begin() + lru);
         }
@@ -71,6 +74,7 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
     }
     s->tick = ++g_tick;
     if (s->refused) { ++g_eager; lk.unlock(); return body(stream); }
+    if (!s->exec && g_wasted >= kMaxWasted) { ++g_eager; lk.unlock(); return body(stream); }      // captures keep being evicted unused-again: stop paying for new ones
     if (!s->exec) {
         // second sighting: capture on this device's private stream (the caller's may be the legacy default stream, which cannot be captured); the lock is
         // held: one capture at a time, and nobody replays a half-built slot
@@ -117,5 +121,6 @@ extern "C" int gg_graph_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& s : g_slots) drop(s);
     g_slots.clear();
+    g_wasted = 0;
     return 0;
 }

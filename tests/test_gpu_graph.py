@@ -107,3 +107,27 @@ def test_event_timing_turns_graphs_off(graph_mode):
         assert _stats()[0] == n0 and L.lib().gg_prof_count() > 0
     finally:
         L.lib().gg_prof_enable(0); L.lib().gg_prof_reset()
+
+
+def test_address_churn_stops_capturing(graph_mode):
+    """A caller whose buffers change address all the time (30 input buffers, each used twice in a row: every second call captures, then the key is never
+    seen again) must not pay for captures forever: once 8 captured graphs have been evicted unused the cache stops capturing; results stay those of the
+    eager path throughout."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    torch.manual_seed(0)
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, precision="fp32").cuda().eval()
+    src = torch.randn(4, 3, 224, 224, device="cuda")
+    graph_mode(0)
+    with torch.no_grad():
+        ref = m(pixel_values=src).pooler_output.clone()
+    graph_mode(-1)
+    bufs = [src.clone() for _ in range(30)]
+    _, cap0, _, _ = _stats()
+    with torch.no_grad():
+        for b in bufs:
+            for _ in range(2):
+                o = m(pixel_values=b).pooler_output
+                assert torch.equal(o, ref)
+                del o
+    _, cap1, _, _ = _stats()
+    assert 16 <= cap1 - cap0 <= 16 + 8, (cap0, cap1)
