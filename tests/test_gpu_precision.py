@@ -497,7 +497,7 @@ def _grad_table(case, tol, label, median_tol=None):
     assert all(bb._params[n].grad is None for n in bb._params if n not in case["trainable"])
 
 
-@pytest.mark.parametrize("model_name,N,unfrozen", [("tiny_vit_5m_224", 2, True), ("tiny_vit_21m_224", 4, False), ("tiny_vit_21m_224", 1, True)])
+@pytest.mark.parametrize("model_name,N,unfrozen", [("tiny_vit_5m_224", 2, True), ("tiny_vit_21m_224", 4, False), ("tiny_vit_21m_224", 1, True), ("tiny_vit_11m_224", 2, False)])
 def test_fp32_mode_train_step_matches_fp32_oracle(centroids, model_name, N, unfrozen):
     """Reference-precision mode: forward, loss, every stage's activations and every parameter gradient against the fp32 oracle at
     fp32-rounding tolerances (rtol 1e-4 on embeddings, loss 1e-5 rel)."""
@@ -513,7 +513,7 @@ def test_fp32_mode_train_step_matches_fp32_oracle(centroids, model_name, N, unfr
     _grad_table(case, 2e-3, label)
 
 
-@pytest.mark.parametrize("model_name,N", [("tiny_vit_21m_224", 4), ("tiny_vit_21m_224", 1)])
+@pytest.mark.parametrize("model_name,N", [("tiny_vit_21m_224", 4), ("tiny_vit_21m_224", 1), ("tiny_vit_21m_384", 1)])
 def test_fp32_split_mode_passes_the_fp32_gate(centroids, model_name, N):
     """The gate of the "fp32_split" experiment (f32 storage; norm1 -> qkv, norm2 -> fc1 -> fc2 and the fc2 / fc1 dgrads of frozen C >= 384 blocks as
     fp32-accurate products of three bf16 planes per operand): the SAME assertions at the SAME tolerances as the fp32 mode's training-step test --
