@@ -481,7 +481,10 @@ struct Exec {
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
     // fp32_split mode: this block's qkv / fc1 / fc2 (forward) and fc2 / fc1 dgrads run as split-bf16 products -- frozen blocks only (a weight gradient would
     // need the f32 operands the split path never writes), channel counts whose planes exist
-    bool split_block(const BlockL& l) const { return m->split && l.qkv.wn3 >= 0 && training && trainable && !tr(l.qkv.t_w) && !tr(l.fc1.t_w) && !tr(l.fc2.t_w); }
+    // (inference: every such block -- nothing is kept for a backward pass)
+    bool split_block(const BlockL& l) const {
+        return m->split && l.qkv.wn3 >= 0 && (!training || (trainable && !tr(l.qkv.t_w) && !tr(l.fc1.t_w) && !tr(l.fc2.t_w)));
+    }
     void exec_init() {
         f32 = m->f32;
         // reference-precision mode: the same fusions where an f32 twin exists (MBConv / PatchMerging forward, the stride-1 data gradients, the
@@ -719,7 +722,8 @@ static int forward_impl(Exec& e, const float* x, float* out) {
                 GG_TRY(gg_layernorm_fwd(e.A(a.x2), e.f32, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), e.f32, e.F(a.mean2), e.F(a.rstd2), e.st));
             }
             if (sp) {       // fc1: GELU(h) leaves as planes only (the f32 pre-activation is kept for backward), fc2 consumes them
-                GG_TRY(split3(e, e.A(L.pl_a), C, e.wc + l.fc1.wn3, l.fc1.Kp, nullptr, hid, e.A(L.pl_h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU, (float*)e.A(a.hpre)));
+                GG_TRY(split3(e, e.A(L.pl_a), C, e.wc + l.fc1.wn3, l.fc1.Kp, nullptr, hid, e.A(L.pl_h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU,
+                              e.training ? (float*)e.A(a.hpre) : nullptr));
                 GG_TRY(split3(e, e.A(L.pl_h), hid, e.wc + l.fc2.wn3, l.fc2.Kp, (float*)e.A(a.x3), C, nullptr, 0, M, C, l.fc2.Kp, e.P(l.fc2.t_b), 0, nullptr, s2, rps,
                               (const float*)e.A(a.x2)));
             } else {

@@ -597,3 +597,30 @@ def test_headline_model_prediction_agreement(centroids, precision):
     # lat/lon are a centroid gather: identical wherever the arg-max agrees
     same = out.preds_geocell.cpu() == top_o[:, 0]
     np.testing.assert_array_equal(out.preds_LLH.cpu().numpy()[same.numpy()], centroids[top_o[:, 0].numpy()][same.numpy()])
+
+
+def test_fp32_split_inference_embeddings_match_the_fp32_mode():
+    """Inference in the fp32_split mode (every C >= 384 block's norm1 -> qkv and norm2 -> fc1 -> fc2 as split-bf16 products: the bulk-embedding job of the "next" row f2)
+    gives the fp32 mode's embeddings to fp32 rounding (rel-L2 <= 1e-5: the two product forms differ by ~3e-7 per GEMM)."""
+    import warnings
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    outs = {}
+    x = torch.randn(8, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    for prec in ("fp32", "fp32_split"):
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = TinyViTAdapter("tiny_vit_21m_224", pretrained=False, precision=prec)
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for name, p in m.backbone.named_parameters():
+                if name.endswith(("bn.weight", "norm.weight")): p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif name.endswith(".bias") and p.dim() == 1: p.copy_(0.1 * torch.randn(p.shape, generator=g))
+                elif name.endswith("attention_biases"): p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                elif name.endswith(".weight") and p.dim() == 2: p.copy_(0.05 * torch.randn(p.shape, generator=g))
+        m = m.cuda().eval()
+        with torch.no_grad():
+            outs[prec] = m(pixel_values=x).pooler_output.clone()
+        del m
+    assert torch.isfinite(outs["fp32_split"]).all() and not torch.equal(outs["fp32"], outs["fp32_split"])      # the split path did run
+    assert relerr(outs["fp32_split"].cpu(), outs["fp32"].cpu()) < 1e-5
