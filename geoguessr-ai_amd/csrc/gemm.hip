@@ -10,6 +10,7 @@
 // along the contiguous dimension of C and vectorised bias / residual / pre-activation access.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/gg.h"
 
 #define BK 64
@@ -50,6 +51,7 @@ struct GemmParams {
     const ge_t* A2; int k_split;  // optional second A source for contraction columns k >= k_split (same lda)
     const ge_t* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;   // EPI_BNBWD
     const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;   // PRO: A := act(BN(A)) while staging
+    int group_m;                  // LDS-DMA form: tile order walks groups of group_m M-tiles column by column (0: row-major)
 };
 
 // LDS image of an R x 64 operand tile: unpadded 128-byte rows, the eight 16-byte chunks of a row XOR-swizzled with
@@ -460,6 +462,142 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
     gemm_epilogue<BM, BN, WM, WN, EPI, EARLY>(p, smem, acc, m0, n0, tm, z, wm, wn, lr, lg, ex, btab);
 }
 
+// ------------------------------------------------------------------------------------------- NT, LDS-DMA form (the MFMA-bound shapes)
+// The kernel above is LDS-port bound on the transformer shapes (K >= 192): per 128 x 128 x 64 k-tile it writes 32 KB with ds_write_b128 (~79 B/clk/CU:
+// 415 cycles) and reads 64 KB of fragments (256 cycles) under 512 cycles of matrix time.  Operands delivered by LDS-DMA (`buffer_load ... lds`, 16 B per lane:
+// no staging registers, no ds_write; rows beyond M / N and chunks beyond K arrive as zeros from the buffer range check) remove the write side, and then the
+// operand stream itself is the limit (tools/dma_bw.hip: the same tile walk without any matrix work).  What that stream delivers depends on the PIECE a DMA
+// instruction fetches: 16 rows x 64 B (a 32-deep k-stage) tops out at 12-15 TB/s chip-wide whatever the tile and ring, 8 rows x 128 B (whole cache lines, a
+// 64-deep stage) reaches 19-27 TB/s given enough bytes in flight -- half-line pieces cost the texture-address path a full line's cycles.  So: 64-deep stages
+// with 128-byte LDS rows, and the largest tile whose two-stage ring still lets TWO workgroups share a CU (2 x 80 KB = the whole LDS): 192 x 128, four waves of
+// 96 x 64.  Two independent workgroups per CU (rather than one of eight waves on a 256 x 256 tile) because a K = 384 ... 768 tile is short: its prologue
+// (first operands: ~1 us) and its epilogue would leave the matrix pipe idle 25-50 % of the time with nobody else on the CU.
+// LDS image: rows of 128 bytes, the eight 16-byte chunks of a row XOR-swizzled with T(row) = 2 bit1(row) + 4 bit3(row) on the SOURCE side of the DMA (the
+// LDS side of a DMA is lane-linear), which makes every 16-lane group of the fragment ds_read_b128 hit 16 distinct 16-byte bank slots (the register-staged
+// kernel's layout).
+// Schedule of one stage (two 32-deep k-steps, ONE raw s_barrier, one stage of DMA in flight): B fragments of a k-step (4) and the first two A fragments are in
+// registers when the step starts; A fragments stream through a 4-slot register ring two m-tiles ahead of their MFMAs; the second k-step's B fragments are read
+// during the first.  After the fourth m-tile of the second k-step every fragment read of the stage has been issued: wait for them and for this wave's DMAs of
+// the next stage, barrier, refill this stage's buffer with stage s + 2, read the next stage's first fragments under the last eight MFMAs.
+template <int N> __device__ __forceinline__ void gemm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, bool PRIO = false, int ABL = 0>      // ABL (dev ablations, tools/ablate_gemm16.sh): 1 = no operand DMA, 32 = no MFMAs
+__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
+    constexpr int BM = 192, BN = 128, SK = 64, NST = 2;
+    constexpr int TA = BM * SK, TB = BN * SK, STAGE = TA + TB;            // elements per stage (40 KB)
+    constexpr int CSTG = BM * (BN + 8);                                    // the epilogue's staged result tile
+    static_assert(NST * STAGE * 2 == 81920 && CSTG <= NST * STAGE, "two workgroups share the CU's 160 KB");
+    constexpr int TM = 6, TN = 4;
+    constexpr int PA = BM / 8 / 4, PB = BN / 8 / 4, DPS = PA + PB;         // DMA pieces (8 rows x 128 B) per wave and stage: 6 A + 4 B
+    __shared__ __attribute__((aligned(16))) ge_t smem[NST * STAGE];
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    // an XCD runs 64 consecutive ids at a time: row-major order makes them one A panel x 64 B panels (wide N: every B panel is fetched by one workgroup
+    // only, the whole weight matrix streams through the L2 once per M-tile row); in groups of group_m M-tiles walked column by column they are
+    // group_m A panels x 64 / group_m B panels
+    int tm, tn;
+    if (p.group_m > 1) {
+        const int per = p.group_m * p.tilesN, g = bid / per, r = bid - g * per;
+        const int first = g * p.group_m, gsz = min(p.tilesM - first, p.group_m);
+        tn = r / gsz; tm = first + (r - tn * gsz);
+    } else { tm = bid / p.tilesN; tn = bid % p.tilesN; }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lg = lane >> 4;
+    const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 2u;
+    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 2u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
+    // DMA geometry: piece pc = wave + 4 j covers tile rows 8 pc .. 8 pc + 7; lane -> (row 8 pc + lane / 8, LDS chunk slot lane % 8) and fetches SOURCE chunk
+    // slot ^ T(row); bit 1 of the row is bit 4 of the lane, bit 3 of the row is bit 0 of the piece = bit 0 of the wave (4 j is even)
+    const int dchunk = (lane & 7) ^ (((lane >> 3) & 2) | ((wave & 1) << 2));
+    unsigned voffA[PA], voffB[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) voffA[j] = (unsigned)((wave + 4 * j) * 8 + (lane >> 3)) * (unsigned)p.lda * 2u + dchunk * 16u;
+#pragma unroll
+    for (int j = 0; j < PB; ++j) voffB[j] = (unsigned)((wave + 4 * j) * 8 + (lane >> 3)) * (unsigned)p.ldb * 2u + dchunk * 16u;
+    auto issue_stage = [&](int st, ge_t* base) {
+        if (ABL & 1) return;
+        const int k0 = st * SK;
+        const bool kin = k0 + dchunk * 8 < p.K;                  // K % 8 == 0: a chunk is entirely inside or outside K
+#pragma unroll
+        for (int j = 0; j < PA; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 512), 16,
+                                                     (int)(kin ? voffA[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + TA + (wave + 4 * j) * 512), 16,
+                                                     (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
+    };
+    // fragment addresses (elements): row 16 t + lr of an operand tile, k-step ks, k-chunk lg -> chunk slot (4 ks + lg) ^ T(lr)
+    const int sw = (lr & 2) | ((lr >> 1) & 4);
+    const int kc0 = ((0 + lg) ^ sw) << 3, kc1 = ((4 + lg) ^ sw) << 3;
+    const int a_off = (wm * 96 + lr) * SK, b_off = TA + (wn * 64 + lr) * SK;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + SK - 1) / SK;
+    issue_stage(0, smem);
+    if (nk > 1) issue_stage(1, smem + STAGE);
+    if (nk > 1) gemm_wait_vmcnt<DPS>(); else gemm_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    ge8_t ar[4], bq[2][TN];
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) bq[0][nt] = *reinterpret_cast<const ge8_t*>(smem + b_off + nt * 16 * SK + kc0);
+    ar[0] = *reinterpret_cast<const ge8_t*>(smem + a_off + kc0);
+    ar[1] = *reinterpret_cast<const ge8_t*>(smem + a_off + 16 * SK + kc0);
+    // STEADY: stage s + 2 exists (no conditions inside).  The sched_barriers pin the order [read A two m-tiles ahead; 4 MFMAs of m-tile mt]: left alone the
+    // compiler sinks each read to just above its first use and waits for it there.  The next stage's first fragments are read unconditionally (the last stage
+    // reads stale bytes it never uses): a branch around them makes the compiler's wait-count merge at the join pessimistic.
+    auto stage = [&](auto steady, int s, int slot) {
+        constexpr bool STEADY = decltype(steady)::value;
+        ge_t* const cur = smem + slot * STAGE;
+        ge_t* const nxt = smem + (slot ^ 1) * STAGE;
+#pragma unroll
+        for (int i = 0; i < 2 * TM; ++i) {                         // i = 6 ks + mt
+            const int ks = i / TM, mt = i % TM;
+            if (i + 2 < 2 * TM) {
+                const int i2 = i + 2;
+                ar[i2 & 3] = *reinterpret_cast<const ge8_t*>(cur + a_off + (i2 % TM) * 16 * SK + (i2 / TM ? kc1 : kc0));
+            }
+            if (i == 2) {                                           // the second k-step's B fragments
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) bq[1][nt] = *reinterpret_cast<const ge8_t*>(cur + b_off + nt * 16 * SK + kc1);
+            }
+            if (i == 2 * TM - 2) {
+                // every fragment read of stage s has been issued (the last A fragment one m-tile ago)
+                gemm_wait_vmcnt<0>();                               // this wave's DMAs of stage s + 1 have landed (nothing else is in flight: ring of two)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                       // everybody's have, and everybody has read its fragments of stage s
+                if (STEADY || s + 2 < nk) issue_stage(s + 2, cur);
+#pragma unroll
+                for (int nt = 0; nt < TN; ++nt) bq[0][nt] = *reinterpret_cast<const ge8_t*>(nxt + b_off + nt * 16 * SK + kc0);
+                ar[0] = *reinterpret_cast<const ge8_t*>(nxt + a_off + kc0);
+                ar[1] = *reinterpret_cast<const ge8_t*>(nxt + a_off + 16 * SK + kc0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            if (!(ABL & 32))
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) acc[nt][mt] = ge_mfma(bq[ks][nt], ar[i & 3], acc[nt][mt]);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int s = 0;
+    for (; s + 3 < nk; s += 2) {
+        stage(std::true_type{}, s, 0);
+        stage(std::true_type{}, s + 1, 1);
+    }
+    for (; s < nk; ++s) stage(std::false_type{}, s, s & 1);
+    __builtin_amdgcn_s_barrier();                                   // the ring is idle (no DMA in flight, every fragment read): the epilogue stages the result tile in it
+    ge8_t ex[BM / (256 / (BN / 8))];
+    gemm_epilogue<BM, BN, 2, 2, EPI, false>(p, smem, acc, m0, n0, tm, 0, wm, wn, lr, lg, ex, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------- TN GEMM (weight gradients)
 // dW[N,K] = sum_m dY[m,n] * X[m,k]: both operands are row-major over the REDUCTION index m, so their MFMA fragments
 // (8 consecutive m for a fixed n / k) are read from the row-major LDS tiles with the transposing ds_read_b64_tr_b16 --
@@ -806,6 +944,7 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
                  "gg_gemm_nt: the BatchNorm prologue is built for the plain (+ column statistics) epilogue only");
     }
     GemmParams p;
+    p.group_m = 0;
     p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     p.A2 = (const ge_t*)a->A2; p.k_split = a->k_split;
     p.bn_y = (const ge_t*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
@@ -847,7 +986,38 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     else if (a->bias || a->rowscale || a->residual) epi = EPI_LINEAR;
     else epi = EPI_PLAIN;
     hipStream_t st = (hipStream_t)stream;
-#define GG_LAUNCH_EPI(E)                                                                                              \
+    // the MFMA-bound shapes (the transformer Linears and their data gradients) take the LDS-DMA form: 256 x 128 tiles
+    const char* dma_sw = gg_dev_env("GG_GEMM_DMA");        // (not cached: tools/bench_gemm16.py flips it between launches of one process)
+    bool dma = !p.a_stat && !p.A2 && !p.bn_y && !p.colstats && split == 1 && a->K >= 192 && a->N >= 128 && a->M >= 1024 &&
+               (rem == 0 || rem > 64) && a->lda * 512 < 0xFFFFFF00LL && a->ldb * 256 < 0xFFFFFF00LL && a->ldc * 512 < 0xFFFFFF00LL &&
+               (!a->residual || a->ldr * 512 < 0xFFFFFF00LL);
+    const int dma_var = dma_sw ? atoi(dma_sw) : 1;
+    if (dma_sw) dma = dma && dma_var != 0;
+    if (dma) {
+        p.tilesM = (int)gg_cdiv(a->M, 192); p.tilesN = (int)gg_cdiv(a->N, 128);
+        const dim3 g2(p.tilesM * p.tilesN);
+        const char* gm_sw = gg_dev_env("GG_GEMM_GM");
+        p.group_m = gm_sw ? atoi(gm_sw) : (p.tilesN > 8 ? 8 : 0);
+        if (dma_var > 1 && epi == EPI_PLAIN) {       // dev: schedule variants / ablations (tools/bench_gemm16_var.py, tools/ablate_gemm16.sh)
+            if (dma_var == 2) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, true>), g2, dim3(256), 0, st, p);
+            else if (dma_var == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 1>), g2, dim3(256), 0, st, p);
+            else if (dma_var == 4) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 32>), g2, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 33>), g2, dim3(256), 0, st, p);
+            GG_LAUNCH_CHECK();
+            return 0;
+        }
+        switch (epi) {
+            case EPI_PLAIN: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN>), g2, dim3(256), 0, st, p); break;
+            case EPI_LINEAR: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LINEAR>), g2, dim3(256), 0, st, p); break;
+            case EPI_GELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_GELU>), g2, dim3(256), 0, st, p); break;
+            case EPI_QGELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_QGELU>), g2, dim3(256), 0, st, p); break;
+            case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_DGELU>), g2, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_F32>), g2, dim3(256), 0, st, p); break;
+        }
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
+#define GG_LAUNCH_EPI(E)                                                                                            \
     do {                                                                                                              \
         if (narrow) hipLaunchKernelGGL((gemm_nt_kernel<128, 64, 4, 1, 5, E>), grid, dim3(256), 0, st, p);             \
         else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 2, 2, 3, E>), grid, dim3(256), 0, st, p);                   \
