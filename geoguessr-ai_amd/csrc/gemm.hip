@@ -479,36 +479,170 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
 // registers when the step starts; A fragments stream through a 4-slot register ring two m-tiles ahead of their MFMAs; the second k-step's B fragments are read
 // during the first.  After the fourth m-tile of the second k-step every fragment read of the stage has been issued: wait for them and for this wave's DMAs of
 // the next stage, barrier, refill this stage's buffer with stage s + 2, read the next stage's first fragments under the last eight MFMAs.
+// Epilogue of the LDS-DMA form: the same arithmetic and rounding points as gemm_epilogue (fragment phase: + bias, quick_gelu, * rowscale on the f32 accumulators,
+// round to the 16-bit type; row phase on the rounded tile: pre-activation copy, GELU, x GELU'(saved pre-activation), + residual) -- results are bit-identical to
+// the register-staged kernel's -- but WAVE-PRIVATE and without general-shape fallbacks.  A wave turns its own 96 x 64 sub-tile from the MFMA layout (a lane: 4
+// columns of one row) into rows (8 lanes x 16 B = one 128-byte line of C; an instruction covers 8 rows) through a private LDS scratch, 32 rows at a time: no
+// workgroup barrier, and while it runs the workgroup's ring is free to receive the NEXT tile's first stage.  The host sends a launch here only when every row of
+// C / the second tensor is 16-byte aligned and N % 8 == 0, so a 16-byte column chunk is entirely inside or outside N; rows beyond M and chunks beyond N are
+// dropped by the buffer range check (loads return zeros, stores do nothing): no branches, no scalar tails (the general epilogue compiled to ~200 exec-masked
+// branches per tile).  Its memory operands (bias, row scales, second tensor) are fetched by epi_fetch BEFORE the last k-stage's MFMAs.
+typedef unsigned int gemm_u32x4_t __attribute__((ext_vector_type(4)));
+// (the operand registers are plain local arrays of the kernel, passed by reference: gathered in a struct the compiler kept part of them in scratch memory)
+// bias and row scales (MFMA layout): ordinary loads issued before the last k-stage's MFMAs, pinned in registers by gemm_dma_epi_ready before the next tile's DMA
+// is issued (a wait the compiler places behind an LDS-DMA covers the DMA too: vmcnt retires in order)
+template <int EPI>
+__device__ __forceinline__ void gemm_dma_epi_fetch(const GemmParams& p, f32x4 (&bs)[4], float (&rsv)[6], int m0, int n0, int wm, int wn, int lane) {
+    asm volatile("" : "+v"(lane));        // (opaque: what is derived from it below is recomputed per tile, not hoisted out of the tile loop and kept in registers / spilled)
+    const int lr = lane & 15, lg = lane >> 4;
+    const int mw = m0 + wm * 96, nw = n0 + wn * 64;                // the wave's sub-tile
+    if (EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU) {
+        const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bs[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsBias, (nw + nt * 16 + lg * 4) * 4, 0, 0));     // (no bias: zeros)
+    }
+    if ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) {
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) rsv[mt] = p.rowscale[min(mw + mt * 16 + lr, p.M - 1) / p.rows_per_scale];
+    }
+}
+template <int EPI>
+__device__ __forceinline__ void gemm_dma_epi_ready(const GemmParams& p, f32x4 (&bs)[4], float (&rsv)[6]) {
+    if (EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(bs[nt]));
+    }
+    if ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) {
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) asm volatile("" : "+v"(rsv[mt]));
+    }
+}
+// The second tensor of the row phase (residual / saved pre-activation), 12 x 16 B per lane: 48 registers that do not fit beside the k-loop's fragments, so it is
+// requested after the k-loop, right BEHIND the next tile's first DMA stage: vmcnt retires in order, so the row phase's wait for it also covers that stage -- the
+// two round trips overlap, and one of them (not two) is exposed per tile.  (Requested ahead of the DMA and counted by hand in inline asm, the compiler moved the
+// destination registers between the load and the wait.)
+template <int EPI, bool EXT>
+__device__ __forceinline__ void gemm_dma_ext_fetch(const GemmParams& p, gemm_u32x4_t (&ex)[12], int m0, int n0, int wm, int wn, int lane) {
+    const ge_t* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : nullptr);
+    if (!EXT) return;
+    asm volatile("" : "+v"(lane));
+    const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
+    const int mw = m0 + wm * 96, nw = n0 + wn * 64;
+    const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(max(min(p.M - mw, 96), 0));      // (readfirstlane: the compiler forms the clamp on the vector ALU and would wrap every buffer access using the descriptor in a waterfall loop)
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(ext + (int64_t)mw * lde), 0, (int)(rows * (unsigned)lde * 2u), 0x00020000);
+    const int n = nw + (lane & 7) * 8;
+    const unsigned vo0 = ((unsigned)(lane >> 3) * (unsigned)lde + (unsigned)n) * 2u;
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+        ex[i] = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)(n < p.N ? vo0 + (unsigned)i * 8u * (unsigned)lde * 2u : 0xFFFFFFF0u), 0, 0);
+}
+// scratch: this wave's two 32-row x 144-byte LDS images
+template <int EPI, bool EXT>
+__device__ __forceinline__ void gemm_dma_epilogue(const GemmParams& p, ge_t* scratch, f32x4 (&acc)[4][6], const f32x4 (&bs)[4], const float (&rsv)[6], const gemm_u32x4_t (&ex)[12],
+                                                  int m0, int n0, int wm, int wn, int lane) {
+    constexpr int CS = 72;                                          // scratch row stride (elements): 144 bytes, 16-byte aligned
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    asm volatile("" : "+v"(lane));
+    const int lr = lane & 15, lg = lane >> 4;
+    const int mw = m0 + wm * 96, nw = n0 + wn * 64;
+    const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(max(min(p.M - mw, 96), 0));      // (readfirstlane: the compiler forms the clamp on the vector ALU and would wrap every buffer access using the descriptor in a waterfall loop)
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<ge_t*>(p.C) + (int64_t)mw * p.ldc), 0, (int)(rows * (unsigned)p.ldc * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == EPI_GELU && p.preact ? p.preact : reinterpret_cast<ge_t*>(p.C)) + (int64_t)mw * p.ldc), 0,
+                                                                         (int)(rows * (unsigned)p.ldc * 2u), 0x00020000);
+    const int n = nw + (lane & 7) * 8;
+    const bool nin = n < p.N;
+    const unsigned vo0 = ((unsigned)(lane >> 3) * (unsigned)p.ldc + (unsigned)n) * 2u;
+    const unsigned vstep = 8u * (unsigned)p.ldc * 2u;
+    const bool scaled = (EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale != nullptr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                   // 32 rows = m-tiles 2 c, 2 c + 1
+        ge_t* Cs = scratch + (c & 1) * 32 * CS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int mt = 2 * c + h;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                f32x4 v = acc[nt][mt];
+                if (EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU) v += bs[nt];
+                if (EPI == EPI_QGELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gg_quick_gelu(v[r]);
+                }
+                if (scaled) v *= rsv[mt];
+                const ge4_t q = {(ge_t)v[0], (ge_t)v[1], (ge_t)v[2], (ge_t)v[3]};
+                *reinterpret_cast<ge4_t*>(Cs + (h * 16 + lr) * CS + nt * 16 + lg * 4) = q;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                               // 8 rows per instruction
+            const int pass = 4 * c + g;
+            ge8_t v = *reinterpret_cast<const ge8_t*>(Cs + (g * 8 + (lane >> 3)) * CS + (lane & 7) * 8);
+            const unsigned vo = nin ? vo0 + (unsigned)pass * vstep : 0xFFFFFFF0u;
+            const ge8_t e = __builtin_bit_cast(ge8_t, ex[EXT ? pass : 0]);
+            if (EPI == EPI_GELU) {
+                if (p.preact) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsP, (int)vo, 0, 2);      // (nt: read back only in the backward pass)
+                if (p.act == GG_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (ge_t)gg_quick_gelu((float)v[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2 r = gg_gelu_v2((f32x2){(float)v[j], (float)v[j + 1]});
+                        v[j] = (ge_t)r.x; v[j + 1] = (ge_t)r.y;
+                    }
+                }
+            }
+            if (EPI == EPI_DGELU) {
+                if (p.dact == GG_ACT_QUICK_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (ge_t)((float)v[j] * gg_quick_gelu_grad((float)e[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2 r = (f32x2){(float)v[j], (float)v[j + 1]} * gg_gelu_grad_v2((f32x2){(float)e[j], (float)e[j + 1]});
+                        v[j] = (ge_t)r.x; v[j + 1] = (ge_t)r.y;
+                    }
+                }
+            }
+            if (EPI == EPI_LINEAR && EXT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (ge_t)((float)v[j] + (float)e[j]);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)vo, 0, 0);
+        }
+    }
+}
+
 template <int N> __device__ __forceinline__ void gemm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, bool PRIO = false, int ABL = 0>      // ABL (dev ablations, tools/ablate_gemm16.sh): 1 = no operand DMA, 32 = no MFMAs
+// One workgroup per tile.  (A persistent form -- two workgroups per CU walking a per-XCD tile queue, the next tile's first stage issued under the epilogue -- was
+// built and measured: the same 12.05 ms for the CLIP tower at batch 1024 as this one.  The operand stream and the chip's clock under the load set the pace,
+// not the 1 us between a workgroup's end and its successor's start.)
+template <int EPI, bool EXT = false, bool PRIO = false, int ABL = 0>      // EXT: the row phase reads a second tensor (residual / saved pre-activation); ABL (dev, tools/ablate_gemm16.sh): 1 = no operand DMA, 32 = no MFMAs, 64 = per-tile cycle trace into p.colstats
 __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
     constexpr int BM = 192, BN = 128, SK = 64, NST = 2;
     constexpr int TA = BM * SK, TB = BN * SK, STAGE = TA + TB;            // elements per stage (40 KB)
-    constexpr int CSTG = BM * (BN + 8);                                    // the epilogue's staged result tile
-    static_assert(NST * STAGE * 2 == 81920 && CSTG <= NST * STAGE, "two workgroups share the CU's 160 KB");
+    static_assert(NST * STAGE * 2 == 81920 && 4 * 2 * 32 * 72 <= STAGE, "two workgroups share the CU's 160 KB; the epilogue's wave-private scratch reuses ring buffer 1");
     constexpr int TM = 6, TN = 4;
     constexpr int PA = BM / 8 / 4, PB = BN / 8 / 4, DPS = PA + PB;         // DMA pieces (8 rows x 128 B) per wave and stage: 6 A + 4 B
     __shared__ __attribute__((aligned(16))) ge_t smem[NST * STAGE];
     const int tiles = p.tilesM * p.tilesN;
-    const int bid = gg_xcd_remap(blockIdx.x, tiles);
-    // an XCD runs 64 consecutive ids at a time: row-major order makes them one A panel x 64 B panels (wide N: every B panel is fetched by one workgroup
-    // only, the whole weight matrix streams through the L2 once per M-tile row); in groups of group_m M-tiles walked column by column they are
-    // group_m A panels x 64 / group_m B panels
-    int tm, tn;
-    if (p.group_m > 1) {
-        const int per = p.group_m * p.tilesN, g = bid / per, r = bid - g * per;
-        const int first = g * p.group_m, gsz = min(p.tilesM - first, p.group_m);
-        tn = r / gsz; tm = first + (r - tn * gsz);
-    } else { tm = bid / p.tilesN; tn = bid % p.tilesN; }
-    const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 15, lg = lane >> 4;
-    const unsigned bytesA = (unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 2u;
-    const unsigned bytesB = (unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 2u;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)bytesA, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)bytesB, 0x00020000);
+    // an XCD runs 64 consecutive ids at a time: row-major order makes them one A panel x 64 B panels (wide N: every B panel is fetched by one workgroup
+    // only, the whole weight matrix streams through the L2 once per M-tile row); in groups of group_m M-tiles walked column by column they are
+    // group_m A panels x 64 / group_m B panels
+    auto tile_mn = [&](int t, int& m0, int& n0) {
+        const int bid = gg_xcd_remap(t, tiles);
+        int tm, tn;
+        if (p.group_m > 1) {
+            const int per = p.group_m * p.tilesN, g = bid / per, r = bid - g * per;
+            const int first = g * p.group_m, gsz = min(p.tilesM - first, p.group_m);
+            tn = r / gsz; tm = first + (r - tn * gsz);
+        } else { tm = bid / p.tilesN; tn = bid - tm * p.tilesN; }
+        m0 = tm * BM; n0 = tn * BN;
+    };
     // DMA geometry: piece pc = wave + 4 j covers tile rows 8 pc .. 8 pc + 7; lane -> (row 8 pc + lane / 8, LDS chunk slot lane % 8) and fetches SOURCE chunk
     // slot ^ T(row); bit 1 of the row is bit 4 of the lane, bit 3 of the row is bit 0 of the piece = bit 0 of the wave (4 j is even)
     const int dchunk = (lane & 7) ^ (((lane >> 3) & 2) | ((wave & 1) << 2));
@@ -517,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
     for (int j = 0; j < PA; ++j) voffA[j] = (unsigned)((wave + 4 * j) * 8 + (lane >> 3)) * (unsigned)p.lda * 2u + dchunk * 16u;
 #pragma unroll
     for (int j = 0; j < PB; ++j) voffB[j] = (unsigned)((wave + 4 * j) * 8 + (lane >> 3)) * (unsigned)p.ldb * 2u + dchunk * 16u;
-    auto issue_stage = [&](int st, ge_t* base) {
+    auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int st, ge_t* base) {
         if (ABL & 1) return;
         const int k0 = st * SK;
         const bool kin = k0 + dchunk * 8 < p.K;                  // K % 8 == 0: a chunk is entirely inside or outside K
@@ -530,49 +664,65 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + TA + (wave + 4 * j) * 512), 16,
                                                      (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
     };
+    auto make_rs = [&](int m0, int n0, __amdgpu_buffer_rsrc_t& rsA, __amdgpu_buffer_rsrc_t& rsB) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)m0 * p.lda), 0, (int)((unsigned)min(p.M - m0, BM) * (unsigned)p.lda * 2u), 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)n0 * p.ldb), 0, (int)((unsigned)min(p.N - n0, BN) * (unsigned)p.ldb * 2u), 0x00020000);
+    };
     // fragment addresses (elements): row 16 t + lr of an operand tile, k-step ks, k-chunk lg -> chunk slot (4 ks + lg) ^ T(lr)
     const int sw = (lr & 2) | ((lr >> 1) & 4);
     const int kc0 = ((0 + lg) ^ sw) << 3, kc1 = ((4 + lg) ^ sw) << 3;
     const int a_off = (wm * 96 + lr) * SK, b_off = TA + (wn * 64 + lr) * SK;
+    const int nk = (p.K + SK - 1) / SK;
+    const int t = blockIdx.x;
+    int m0, n0;
+    tile_mn(t, m0, n0);
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    make_rs(m0, n0, rsA, rsB);
+    unsigned long long tr_t0 = 0, tr_first = 0, tr_wait = 0, tr_issue = 0, tr_loop = 0, tr_c0 = 0, tr_c1 = 0, tr_rt0 = 0;
+    if (ABL & 64) { tr_t0 = __builtin_readcyclecounter(); tr_rt0 = __builtin_amdgcn_s_memrealtime(); }
+    issue_stage(rsA, rsB, 0, smem);
+    if (nk > 1) issue_stage(rsA, rsB, 1, smem + STAGE);
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int nk = (p.K + SK - 1) / SK;
-    issue_stage(0, smem);
-    if (nk > 1) issue_stage(1, smem + STAGE);
-    if (nk > 1) gemm_wait_vmcnt<DPS>(); else gemm_wait_vmcnt<0>();
+    if (nk > 1) gemm_wait_vmcnt<DPS>(); else gemm_wait_vmcnt<0>();     // stage 0 has landed (stage 1 may be in flight)
     __builtin_amdgcn_s_barrier();
+    if (ABL & 64) { tr_first = __builtin_readcyclecounter(); tr_wait = 0; tr_issue = 0; }
     ge8_t ar[4], bq[2][TN];
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) bq[0][nt] = *reinterpret_cast<const ge8_t*>(smem + b_off + nt * 16 * SK + kc0);
     ar[0] = *reinterpret_cast<const ge8_t*>(smem + a_off + kc0);
     ar[1] = *reinterpret_cast<const ge8_t*>(smem + a_off + 16 * SK + kc0);
-    // STEADY: stage s + 2 exists (no conditions inside).  The sched_barriers pin the order [read A two m-tiles ahead; 4 MFMAs of m-tile mt]: left alone the
-    // compiler sinks each read to just above its first use and waits for it there.  The next stage's first fragments are read unconditionally (the last stage
-    // reads stale bytes it never uses): a branch around them makes the compiler's wait-count merge at the join pessimistic.
+    f32x4 e_bs[4]; float e_rsv[6]; gemm_u32x4_t e_ex[12];            // the epilogue's memory operands
+    // STEADY: stage s + 2 exists (no conditions inside).  The sched_barriers pin the order [read A two m-tiles ahead; 4 MFMAs of m-tile mt]: left alone
+    // the compiler sinks each read to just above its first use and waits for it there.  The next stage's first fragments are read unconditionally (the last
+    // stage reads stale bytes it never uses): a branch around them makes the compiler's wait-count merge at the join pessimistic.
     auto stage = [&](auto steady, int s, int slot) {
         constexpr bool STEADY = decltype(steady)::value;
         ge_t* const cur = smem + slot * STAGE;
         ge_t* const nxt = smem + (slot ^ 1) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) {                         // i = 6 ks + mt
+        for (int i = 0; i < 2 * TM; ++i) {                     // i = 6 ks + mt
             const int ks = i / TM, mt = i % TM;
             if (i + 2 < 2 * TM) {
                 const int i2 = i + 2;
                 ar[i2 & 3] = *reinterpret_cast<const ge8_t*>(cur + a_off + (i2 % TM) * 16 * SK + (i2 / TM ? kc1 : kc0));
             }
-            if (i == 2) {                                           // the second k-step's B fragments
+            if (i == 2) {                                       // the second k-step's B fragments
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) bq[1][nt] = *reinterpret_cast<const ge8_t*>(cur + b_off + nt * 16 * SK + kc1);
             }
             if (i == 2 * TM - 2) {
                 // every fragment read of stage s has been issued (the last A fragment one m-tile ago)
-                gemm_wait_vmcnt<0>();                               // this wave's DMAs of stage s + 1 have landed (nothing else is in flight: ring of two)
+                if (ABL & 64) tr_c0 = __builtin_readcyclecounter();
+                if (STEADY || s + 1 < nk) gemm_wait_vmcnt<0>(); // this wave's DMAs of stage s + 1 have landed (nothing else is in flight: ring of two)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                       // everybody's have, and everybody has read its fragments of stage s
-                if (STEADY || s + 2 < nk) issue_stage(s + 2, cur);
+                __builtin_amdgcn_s_barrier();                   // everybody's have, and everybody has read its fragments of stage s
+                if (ABL & 64) { tr_c1 = __builtin_readcyclecounter(); tr_wait += tr_c1 - tr_c0; }
+                if (STEADY || s + 2 < nk) issue_stage(rsA, rsB, s + 2, cur);
+                if (ABL & 64) tr_issue += __builtin_readcyclecounter() - tr_c1;
 #pragma unroll
                 for (int nt = 0; nt < TN; ++nt) bq[0][nt] = *reinterpret_cast<const ge8_t*>(nxt + b_off + nt * 16 * SK + kc0);
                 ar[0] = *reinterpret_cast<const ge8_t*>(nxt + a_off + kc0);
@@ -592,10 +742,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
         stage(std::true_type{}, s, 0);
         stage(std::true_type{}, s + 1, 1);
     }
-    for (; s < nk; ++s) stage(std::false_type{}, s, s & 1);
-    __builtin_amdgcn_s_barrier();                                   // the ring is idle (no DMA in flight, every fragment read): the epilogue stages the result tile in it
-    ge8_t ex[BM / (256 / (BN / 8))];
-    gemm_epilogue<BM, BN, 2, 2, EPI, false>(p, smem, acc, m0, n0, tm, 0, wm, wn, lr, lg, ex, nullptr);
+    for (; s < nk; ++s) {
+        if (s == nk - 1) gemm_dma_epi_fetch<EPI>(p, e_bs, e_rsv, m0, n0, wm, wn, lane);      // nothing else is in flight now: lands under the last stage's MFMAs
+        stage(std::false_type{}, s, s & 1);
+    }
+    __builtin_amdgcn_s_barrier();                               // the ring is idle: no DMA in flight, every fragment read
+    if (ABL & 64) tr_loop = __builtin_readcyclecounter();
+    gemm_dma_epi_ready<EPI>(p, e_bs, e_rsv);
+    gemm_dma_ext_fetch<EPI, EXT>(p, e_ex, m0, n0, wm, wn, lane);
+    gemm_dma_epilogue<EPI, EXT>(p, smem + STAGE + wave * (2 * 32 * 72), acc, e_bs, e_rsv, e_ex, m0, n0, wm, wn, lane);
+    if ((ABL & 64) && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* tt = reinterpret_cast<unsigned long long*>(p.colstats) + (size_t)t * 8;
+        const unsigned long long now = __builtin_readcyclecounter();
+        tt[0] = tr_first - tr_t0; tt[1] = tr_loop - tr_first; tt[2] = tr_wait; tt[3] = tr_issue; tt[4] = now - tr_loop; tt[5] = tr_rt0;
+        tt[6] = hw | ((unsigned long long)(xcc & 0xF) << 32); tt[7] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ------------------------------------------------------------------------------------------- TN GEMM (weight gradients)
@@ -987,32 +1151,39 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     else epi = EPI_PLAIN;
     hipStream_t st = (hipStream_t)stream;
     // the MFMA-bound shapes (the transformer Linears and their data gradients) take the LDS-DMA form: 256 x 128 tiles
-    const char* dma_sw = gg_dev_env("GG_GEMM_DMA");        // (not cached: tools/bench_gemm16.py flips it between launches of one process)
-    bool dma = !p.a_stat && !p.A2 && !p.bn_y && !p.colstats && split == 1 && a->K >= 192 && a->N >= 128 && a->M >= 1024 &&
-               (rem == 0 || rem > 64) && a->lda * 512 < 0xFFFFFF00LL && a->ldb * 256 < 0xFFFFFF00LL && a->ldc * 512 < 0xFFFFFF00LL &&
-               (!a->residual || a->ldr * 512 < 0xFFFFFF00LL);
+    // (its epilogue has no general-shape fallbacks: whole 16-byte column chunks, 16-byte aligned rows of every tensor it touches)
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const char* dma_sw = gg_dev_env("GG_GEMM_DMA");        // (not cached: the dev tools flip it between launches of one process)
     const int dma_var = dma_sw ? atoi(dma_sw) : 1;
+    bool dma = !p.a_stat && !p.A2 && !p.bn_y && (!p.colstats || dma_var == 6) && split == 1 && !a->out_f32 && a->K >= 192 && a->N >= 128 && a->M >= 1024 &&
+               (rem == 0 || rem > 64) && a->lda * 512 < 0xFFFFFF00LL && a->ldb * 256 < 0xFFFFFF00LL && a->ldc * 512 < 0xFFFFFF00LL &&
+               (!a->residual || (a->ldr * 512 < 0xFFFFFF00LL && (a->ldr & 7) == 0 && al16(a->residual))) && (a->N & 7) == 0 && (a->ldc & 7) == 0 && al16(a->C) &&
+               (!a->preact || al16(a->preact)) && (!a->dact_preact || al16(a->dact_preact)) && (!a->bias || al16(a->bias));
     if (dma_sw) dma = dma && dma_var != 0;
+    if (const char* only = gg_dev_env("GG_GEMM_DMA_ONLY")) { int on = 0, ok = 0, oe = -1; sscanf(only, "%d,%d,%d", &on, &ok, &oe); dma = dma && a->N == on && a->K == ok && (oe < 0 || oe == epi); }      // (dev: bisecting)
     if (dma) {
         p.tilesM = (int)gg_cdiv(a->M, 192); p.tilesN = (int)gg_cdiv(a->N, 128);
-        const dim3 g2(p.tilesM * p.tilesN);
+        const dim3 g2((unsigned)(p.tilesM * p.tilesN));
         const char* gm_sw = gg_dev_env("GG_GEMM_GM");
         p.group_m = gm_sw ? atoi(gm_sw) : (p.tilesN > 8 ? 8 : 0);
         if (dma_var > 1 && epi == EPI_PLAIN) {       // dev: schedule variants / ablations (tools/bench_gemm16_var.py, tools/ablate_gemm16.sh)
-            if (dma_var == 2) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, true>), g2, dim3(256), 0, st, p);
-            else if (dma_var == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 1>), g2, dim3(256), 0, st, p);
-            else if (dma_var == 4) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 32>), g2, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 33>), g2, dim3(256), 0, st, p);
+            if (dma_var == 2) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, true>), g2, dim3(256), 0, st, p);
+            else if (dma_var == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 1>), g2, dim3(256), 0, st, p);
+            else if (dma_var == 4) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 32>), g2, dim3(256), 0, st, p);
+            else if (dma_var == 6) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 64>), g2, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 33>), g2, dim3(256), 0, st, p);
             GG_LAUNCH_CHECK();
             return 0;
         }
         switch (epi) {
             case EPI_PLAIN: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN>), g2, dim3(256), 0, st, p); break;
-            case EPI_LINEAR: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LINEAR>), g2, dim3(256), 0, st, p); break;
+            case EPI_LINEAR:
+                if (p.residual) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LINEAR, true>), g2, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LINEAR>), g2, dim3(256), 0, st, p);
+                break;
             case EPI_GELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_GELU>), g2, dim3(256), 0, st, p); break;
             case EPI_QGELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_QGELU>), g2, dim3(256), 0, st, p); break;
-            case EPI_DGELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_DGELU>), g2, dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_F32>), g2, dim3(256), 0, st, p); break;
+            default: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_DGELU, true>), g2, dim3(256), 0, st, p); break;
         }
         GG_LAUNCH_CHECK();
         return 0;

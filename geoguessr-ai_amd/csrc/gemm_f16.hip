@@ -5,6 +5,8 @@
 // split-K forms (TinyViT training only) are refused by this build: their staging code manipulates bf16 bit patterns.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
+#include <algorithm>
 #include "../../include/gg.h"
 
 #define GG_GEMM_ELEM_F16 1
