@@ -114,6 +114,8 @@ def load_model_state(model: torch.nn.Module, path_or_state, map_location="cpu") 
     model.load_state_dict(kept, strict=False)
     if hasattr(model, "mark_params_dirty"):
         model.mark_params_dirty()
+    if isinstance(raw, dict):
+        restore_drop_path_state(model, raw)          # (a checkpoint written by make_state: the DropPath stream continues where it stopped)
     return {"loaded": sorted(kept), "skipped": sorted(skipped), "missing": sorted(k for k in own if k not in kept)}
 
 

@@ -994,8 +994,8 @@ extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
 // QK^T and PV on v_mfma_f32_16x16x32_f16, f32 accumulation and softmax.  No relative-position bias (the CLIP tower has none); sequences beyond 256
 // tokens go to the online-softmax kernel (fp16 storage, f32 arithmetic).
 extern "C" int gg_attention_fwd_f16(const GgAttnArgs* a, void* stream) {
-    if (attn_use_flash(a)) return gg_attention_flash_fwd(a, 2, stream);
     GG_CHECK(a && !a->bias && !a->bias_table, "gg_attention_fwd_f16: the fp16 forward takes no bias");
+    if (attn_use_flash(a)) return gg_attention_flash_fwd(a, 2, stream);
     AttnParams p;
     GG_TRY(attn_fill(p, a, "gg_attention_fwd_f16"));
     GG_CHECK(a->out && (a->ldo & 3) == 0, "gg_attention_fwd_f16: bad out");

@@ -1038,21 +1038,24 @@ __global__ __launch_bounds__(256) void splitk_nt_reduce_f32_kernel(const float* 
         *reinterpret_cast<f32x4*>(C + (int64_t)m * ldc + n) = v;
     }
 }
-// slabs of the split-K form: one lazily allocated 16 MiB buffer per device (first use is an eager call: the graph cache never captures a first sighting).
-// The library issues its GEMMs on one compute stream per device; two streams running split-K launches of the same device concurrently would share the slabs --
-// GG_GEMM_SPLITK=0 turns the form off for such a caller
+// slabs of the split-K form: one lazily allocated 16 MiB buffer per (device, stream).  Launches of one stream run in order, so they can share their slabs; two
+// streams (or threads) issuing qualifying GEMMs concurrently get different buffers.  A capturing stream gets none -- a captured launch may be replayed on any
+// stream, next to anything, and an allocation is not legal inside a capture -- and its launch runs unsplit (include/gg.h, gg_gemm_nt_f32).
 constexpr int64_t kSplitScratchFloats = (int64_t)4 << 20;
-static float* splitk_scratch() {
+static float* splitk_scratch(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
     static std::mutex mu;
-    static std::map<int, float*> bufs;
+    static std::map<std::pair<int, hipStream_t>, float*> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     std::lock_guard<std::mutex> lk(mu);
-    auto it = bufs.find(dev);
+    auto it = bufs.find({dev, st});
     if (it != bufs.end()) return it->second;
     float* b = nullptr;
     if (hipMalloc((void**)&b, kSplitScratchFloats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); b = nullptr; }
-    bufs[dev] = b;
+    bufs[{dev, st}] = b;
     return b;
 }
 
@@ -1123,7 +1126,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         if (want > 1) {
             const int kps = (int)gg_align(gg_cdiv(a->K, want), 16);
             nsplit = (int)gg_cdiv(a->K, kps);
-            if (nsplit > 1 && (slabs = splitk_scratch()) != nullptr) { p.splits = nsplit; p.k_per_split = kps; }
+            if (nsplit > 1 && (slabs = splitk_scratch((hipStream_t)stream)) != nullptr) { p.splits = nsplit; p.k_per_split = kps; }
             else nsplit = 1;
         }
     }

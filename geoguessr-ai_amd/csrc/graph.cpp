@@ -14,7 +14,8 @@ struct Slot {
     std::string key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    bool refused = false;          // capture / instantiation failed once: this key stays eager
+    bool refused = false;          // capture / instantiation / a launch failed once: this key stays eager
+    bool capturing = false;        // a thread is capturing this key right now (outside the lock): everybody else runs it eagerly meanwhile
     uint64_t tick = 0;
 };
 std::mutex g_mu;
@@ -75,32 +76,58 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
     s->tick = ++g_tick;
     if (s->refused) { ++g_eager; lk.unlock(); return body(stream); }
     if (!s->exec && g_wasted >= kMaxWasted) { ++g_eager; lk.unlock(); return body(stream); }      // captures keep being evicted unused-again: stop paying for new ones
+    if (s->capturing) { ++g_eager; lk.unlock(); return body(stream); }
     if (!s->exec) {
-        // second sighting: capture on this device's private stream (the caller's may be the legacy default stream, which cannot be captured); the lock is
-        // held: one capture at a time, and nobody replays a half-built slot
-        hipStream_t& cap = g_capture[dev];
-        auto refuse = [&]() { (void)hipGetLastError(); s->refused = true; ++g_eager; lk.unlock(); return body(stream); };
-        if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) { cap = nullptr; return refuse(); }
-        if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess) return refuse();
-        const int rc = body(cap);
+        // second sighting: capture on this device's private stream (the caller's may be the legacy default stream, which cannot be captured).  The capture runs
+        // WITHOUT the cache lock -- it walks the whole network's launch code, and another thread's call on another device must not wait for it -- under a
+        // per-device capture lock (one private stream per device); the slot is marked so that nobody replays or re-captures it half-built, and is looked up
+        // again by key afterwards (the slot vector may have moved)
+        static std::mutex cap_mu[16];
+        const std::string skey = s->key;
+        s->capturing = true;
+        lk.unlock();
         hipGraph_t g = nullptr;
-        const hipError_t ec = hipStreamEndCapture(cap, &g);
-        if (rc != 0 || ec != hipSuccess || !g) {
-            // nothing was enqueued.  The failure may belong to the capture (an allocation, a query): this key stays eager -- a genuine argument error fails
-            // again below with its own message
-            if (g) (void)hipGraphDestroy(g);
-            return refuse();
-        }
         hipGraphExec_t x = nullptr;
-        if (hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess || !x) { (void)hipGraphDestroy(g); return refuse(); }
+        bool ok = false;
+        {
+            std::lock_guard<std::mutex> cl(cap_mu[dev & 15]);
+            hipStream_t cap = nullptr;
+            { std::lock_guard<std::mutex> l2(g_mu); cap = g_capture[dev]; }
+            if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess) { std::lock_guard<std::mutex> l2(g_mu); g_capture[dev] = cap; }
+            if (cap && hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = body(cap);
+                const hipError_t ec = hipStreamEndCapture(cap, &g);
+                // rc != 0: nothing was enqueued.  The failure may belong to the capture (an allocation, a query): this key stays eager -- a genuine argument
+                // error fails again below with its own message
+                if (rc == 0 && ec == hipSuccess && g && hipGraphInstantiate(&x, g, nullptr, nullptr, 0) == hipSuccess && x) ok = true;
+            }
+            if (!ok) { (void)hipGetLastError(); if (x) (void)hipGraphExecDestroy(x); if (g) (void)hipGraphDestroy(g); x = nullptr; g = nullptr; }
+        }
+        lk.lock();
+        s = nullptr;
+        for (auto& c : g_slots) if (c.key == skey) { s = &c; break; }
+        if (!s) {                                          // evicted meanwhile
+            if (x) (void)hipGraphExecDestroy(x);
+            if (g) (void)hipGraphDestroy(g);
+            ++g_eager; lk.unlock();
+            return body(stream);
+        }
+        s->capturing = false;
+        if (!ok) { s->refused = true; ++g_eager; lk.unlock(); return body(stream); }
         s->graph = g; s->exec = x;
         ++g_captures;
     }
     if (hipGraphLaunch(s->exec, stream) != hipSuccess) {
-        gg_set_error("gg_graph_run: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
-        return -1;
+        // nothing was enqueued: this key stays eager from now on (a later call must not fail the same way), and this call runs eagerly
+        (void)hipGetLastError();
+        s->refused = true;
+        drop(*s);
+        ++g_eager;
+        lk.unlock();
+        return body(stream);
     }
     ++g_replays;
+    if (g_wasted > 0 && (g_replays & 15) == 0) --g_wasted;      // the waste counter decays while graphs are being reused: a caller whose addresses churned for a while is not locked out for good
     return 0;
 }
 

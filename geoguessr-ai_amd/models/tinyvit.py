@@ -176,7 +176,8 @@ class TinyVitBackbone(FlatStore):
     def make_drop_scales(self, batch: int, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
         """timm DropPath (scale_by_keep): per-sample Bernoulli(1-p)/(1-p), one row per slot, drawn by ``gg_drop_path_scales`` (a counter-based
         generator on the device).  The seed comes from torch's RNG once per backbone (so ``torch.manual_seed`` makes runs repeatable), the counter
-        advances with every call; ``generator`` re-seeds from that generator instead."""
+        advances with every call.  With ``generator`` the rows are a function of that generator's seed and of how many times that generator object has
+        been passed here (its own state is neither read on the device nor advanced); these per-generator counts are not part of ``drop_path_state()``."""
         if max(self.drop_rates) <= 0:
             return None
         dev = self._flat.device
@@ -185,12 +186,18 @@ class TinyVitBackbone(FlatStore):
             rates = self._rates_dev = torch.tensor(self.drop_rates, dtype=torch.float32, device=dev)
         if generator is not None:
             # host-side (seed, counter) from the generator's seed + a per-generator call count: no device round trip (a CUDA generator's randint +
-            # .item() was a blocking sync per step), deterministic for a given generator seed and call order
-            counts = self.__dict__.setdefault("_drop_gen_counts", {})
+            # .item() was a blocking sync per step), deterministic for a given generator seed and call order.  The count lives with the generator OBJECT
+            # (weak reference: it dies with it, and a new generator that happens to reuse its address starts from zero) and restarts when the generator
+            # is given another seed; re-seeding it with the SAME seed continues the count (initial_seed() cannot tell) -- use a fresh generator for that
+            import weakref
+            counts = self.__dict__.setdefault("_drop_gen_counts", weakref.WeakKeyDictionary())
             seed = int(generator.initial_seed()) & (2 ** 62 - 1)
-            key = (id(generator), seed)          # per generator OBJECT: two generators seeded alike give the same rows, one generator advances
-            counter = counts.get(key, 0)
-            counts[key] = counter + 1
+            ent = counts.get(generator)
+            if ent is None or ent[0] != seed:
+                ent = [seed, 0]
+            counter = ent[1]
+            ent[1] += 1
+            counts[generator] = ent
         else:
             if getattr(self, "_drop_seed", None) is None:
                 self._drop_seed, self._drop_counter = int(torch.randint(0, 2 ** 62, (1,)).item()), 0      # (CPU RNG, once per backbone)
@@ -224,6 +231,8 @@ class TinyVitBackbone(FlatStore):
         if drop_scales is not None:
             assert drop_scales.shape == (self.num_drop_slots, B) and drop_scales.dtype == torch.float32
         self._fwd_mask = mask
+        if training:
+            self._train_mask = mask          # (an eval forward in between does not change what the training workspace was laid out for)
         L.check(L.lib().gg_tinyvit_forward(C.byref(self.cfg), B, int(training), L.ptr(self._flat), L.ptr(self._flat_buf),
                                            L.ptr(self._counters), L.ptr(self._wcache), L.ptr(x), L.ptr(drop_scales), L.ptr(ws),
                                            L.ptr(out), mask, L.stream()),
@@ -263,9 +272,9 @@ class TinyVitBackbone(FlatStore):
         fg = self.attach_grads()
         ws = self._ws[True]
         mask = self.trainable_mask()
-        if getattr(self, "_fwd_mask", None) is not None and mask != self._fwd_mask:
+        if getattr(self, "_train_mask", None) is not None and mask != self._train_mask:
             # the workspace was laid out (and activations were dropped) for the forward's mask: backward must see the same one
-            changed = [t["name"] for t, a, b in zip([t for t in self.table], mask, self._fwd_mask) if bool(a) != bool(b)]
+            changed = [t["name"] for t, a, b in zip([t for t in self.table], mask, self._train_mask) if bool(a) != bool(b)]
             raise L.GgError("requires_grad changed between forward and backward for " + ", ".join(changed[:4]) +
                             " ...: the training forward laid out its workspace for the mask it saw (activations only a frozen weight's gradient "
                             "needs are not kept); run the forward again")
@@ -296,7 +305,7 @@ class TinyVitBackbone(FlatStore):
     def activation(self, name: str, batch: int) -> torch.Tensor:
         """Raw bytes of a saved activation of the last training forward (parity tests)."""
         off, nbytes = C.c_int64(), C.c_int64()
-        L.check(L.lib().gg_tinyvit_activation_info_masked(C.byref(self.cfg), batch, name.encode(), getattr(self, "_fwd_mask", None), C.byref(off),
+        L.check(L.lib().gg_tinyvit_activation_info_masked(C.byref(self.cfg), batch, name.encode(), getattr(self, "_train_mask", None), C.byref(off),
                                                           C.byref(nbytes)), "gg_tinyvit_activation_info")
         return self._ws[True][off.value:off.value + nbytes.value]
 

@@ -23,7 +23,7 @@ def score_batch(pred_llh: torch.Tensor, true_llh: torch.Tensor):
     return ops.geoguessr_score(pred_llh, true_llh)
 
 
-def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_prob: Optional[Sequence[float]] = None) -> Dict[str, float]:
+def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_prob: Optional[Sequence[float]] = None, strict: bool = False) -> Dict[str, float]:
     """run_benchmark.py:67-117.  ``top1_prob[i] < 0`` (or ``top1_prob=None``) = the sample has no top-5 list (counts as 0.0)."""
     d = np.asarray(torch.as_tensor(distance_km).cpu() if torch.is_tensor(distance_km) else distance_km, np.float64)
     s = np.asarray(torch.as_tensor(score).cpu() if torch.is_tensor(score) else score, np.float64)
@@ -32,16 +32,30 @@ def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_p
     p = np.zeros_like(d) if top1_prob is None else np.asarray(torch.as_tensor(top1_prob).cpu() if torch.is_tensor(top1_prob) else top1_prob,
                                                               np.float64)
     n = d.size
-    # gg_geoguessr_score marks a non-finite coordinate pair with distance NaN / score -1; the reference's haversine_np would have propagated the NaN
-    # into every mean silently -- refuse instead of averaging sentinels
+    # gg_geoguessr_score marks a non-finite coordinate pair with distance NaN / score -1.  The reference's haversine_np propagates such a NaN into every
+    # mean and carries on (a validation epoch never aborts a run): do the same for the run, but keep the sentinels out of the averages -- they are
+    # counted and reported (``num_invalid``, a warning), the means are over the valid samples (``strict=True`` raises instead)
     bad = ~np.isfinite(d) | (s < 0)
-    if bad.any():
-        raise ValueError(f"compute_summary: {int(bad.sum())} of {n} samples have a non-finite distance / sentinel score (first at index {int(np.argmax(bad))})")
+    n_bad = int(bad.sum())
+    if n_bad:
+        msg = f"compute_summary: {n_bad} of {n} samples have a non-finite distance / sentinel score (first at index {int(np.argmax(bad))})"
+        if strict:
+            raise ValueError(msg)
+        import warnings
+        warnings.warn(msg + "; they are left out of the averages")
+        if n_bad == n:
+            return {"num_samples": n, "num_invalid": n_bad, "avg_distance_km": float("nan"), "median_distance_km": float("nan"), "avg_top1_prob": float("nan"),
+                    "avg_score": float("nan")}
+        d, s, p = d[~bad], s[~bad], p[~bad]
+        n = d.size
     total_distance = total_score = total_top = 0.0
     for i in range(n):                       # the reference accumulates sample by sample in Python floats: keep its summation order
         total_distance += float(d[i]); total_score += float(s[i]); total_top += float(p[i]) if p[i] >= 0 else 0.0
-    return {"num_samples": n, "avg_distance_km": total_distance / n, "median_distance_km": float(np.median(d)),
-            "avg_top1_prob": total_top / n, "avg_score": total_score / n}
+    out = {"num_samples": n, "avg_distance_km": total_distance / n, "median_distance_km": float(np.median(d)),
+           "avg_top1_prob": total_top / n, "avg_score": total_score / n}
+    if n_bad:
+        out["num_invalid"] = n_bad
+    return out
 
 
 def geocell_metrics(results) -> Dict[str, float]:

@@ -19,7 +19,7 @@ N_IMG = 1024
 
 @pytest.fixture(scope="module", params=["fp32", "bf16"])
 def big(request):
-    """Both arithmetic modes at the full 1024-image size (fp32: 157 GB of saved activations, bf16: 79 GB); the model of one mode is
+    """Both arithmetic modes at the full 1024-image size (fp32: 111 GB of saved activations under the reference freeze policy, bf16: half of that); the model of one mode is
     released before the other is built."""
     import gc
     from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter

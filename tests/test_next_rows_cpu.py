@@ -85,16 +85,22 @@ def test_load_model_state_filters_by_shape():
     assert torch.equal(m[0].weight.data, torch.ones(3, 4))
 
 
-def test_compute_summary_refuses_sentinel_scores():
-    """gg_geoguessr_score marks non-finite coordinate pairs with distance NaN / score -1: the summary must not average them."""
+def test_compute_summary_keeps_sentinel_scores_out_of_the_averages():
+    """gg_geoguessr_score marks non-finite coordinate pairs with distance NaN / score -1: the summary must not average them, and -- like the
+    reference, whose epoch carries on with NaN means -- must not abort a run either (strict=True raises)."""
     import pytest
     from geoguessr_ai_amd.scoring import compute_summary
     ok = compute_summary([10.0, 20.0], [4000, 3000])
-    assert ok["avg_score"] == 3500.0 and ok["num_samples"] == 2
+    assert ok["avg_score"] == 3500.0 and ok["num_samples"] == 2 and "num_invalid" not in ok
+    with pytest.warns(UserWarning, match="sentinel"):
+        part = compute_summary([10.0, float("nan"), 30.0], [4000, -1, 2000], [0.5, 0.9, 0.1])
+    assert part["num_samples"] == 2 and part["num_invalid"] == 1 and part["avg_score"] == 3000.0 and part["avg_distance_km"] == 20.0
+    assert abs(part["avg_top1_prob"] - 0.3) < 1e-12
+    with pytest.warns(UserWarning):
+        none = compute_summary([float("nan")], [-1])
+    assert none["num_invalid"] == 1 and none["avg_score"] != none["avg_score"]
     with pytest.raises(ValueError, match="sentinel"):
-        compute_summary([10.0, float("nan")], [4000, -1])
-    with pytest.raises(ValueError, match="sentinel"):
-        compute_summary([10.0, 5.0], [4000, -1])
+        compute_summary([10.0, 5.0], [4000, -1], strict=True)
 
 
 def test_raw_image_inputs_are_converted_to_rgb():
