@@ -220,6 +220,8 @@ SIGNATURES = {
     "gg_tinyvit_refresh_weights": (_I, [C.POINTER(TinyVitCfg), _P, _P, _P]),
     "gg_tinyvit_refresh_weights_masked": (_I, [C.POINTER(TinyVitCfg), _P, _P, C.c_char_p, _P]),
     "gg_preprocess_bilinear": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
+    "gg_preprocess_pil_workspace_bytes": (C.c_int64, [_I, _I, _I, _I, _I, _I]),
+    "gg_preprocess_pil": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P, _P, _P]),
     "gg_segment_mean": (_I, [_P, _L, _P, _P, _I, _I, _P, _P]),
     "gg_tinyvit_forward": (_I, [C.POINTER(TinyVitCfg), _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, C.c_char_p, _P]),
     "gg_tinyvit_backward": (_I, [C.POINTER(TinyVitCfg), _I, _P, _P, _P, _P, _P, _P, C.c_char_p, _P, STAGE_DONE_FN, _P]),

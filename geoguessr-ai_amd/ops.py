@@ -665,6 +665,27 @@ def preprocess_bilinear(images, size=None, mean=None, std=None):
     return out.view(*lead, 3, hd, wd)
 
 
+def preprocess_pil(img_hwc, flt, resized, crop_top_left, crop_size, mean=None, std=None, mul_rescale=False, want_u8=False):
+    """One RGB image (H, W, 3) uint8 on the GPU -> (3, Hc, Wc) float32: Pillow resize of the whole image to ``resized`` = (Hr, Wr) with filter ``flt``
+    (2 bilinear, 3 bicubic), the crop window, 1/255, (x - mean) / std (``gg_preprocess_pil``; the uint8 stage is bit-identical to PIL.Image.resize)."""
+    L.require_gpu()
+    assert img_hwc.is_cuda and img_hwc.dtype == torch.uint8 and img_hwc.dim() == 3 and img_hwc.shape[2] == 3, "preprocess_pil: CUDA uint8 (H, W, 3) image"
+    x = img_hwc.contiguous()
+    hs, ws = x.shape[:2]
+    (hr, wr), (top, left), (hc, wc) = resized, crop_top_left, crop_size
+    need = L.lib().gg_preprocess_pil_workspace_bytes(hs, ws, flt, hr, wr, wc)
+    if need < 0:
+        raise L.GgError(f"preprocess_pil: bad geometry {hs}x{ws} -> {hr}x{wr}, filter {flt}")
+    ws_buf = torch.empty(need, dtype=torch.uint8, device=x.device)
+    out = torch.empty((3, hc, wc), dtype=F32, device=x.device)
+    u8 = torch.empty((hc, wc, 3), dtype=torch.uint8, device=x.device) if want_u8 else None
+    m3 = (C.c_float * 3)(*[float(v) for v in mean]) if mean is not None else None
+    s3 = (C.c_float * 3)(*[float(v) for v in std]) if std is not None else None
+    L.check(L.lib().gg_preprocess_pil(_p(x), hs, ws, int(flt), hr, wr, top, left, hc, wc, int(mul_rescale), m3, s3, _p(out), _p(u8), _p(ws_buf), L.stream()),
+            "gg_preprocess_pil")
+    return (out, u8) if want_u8 else out
+
+
 def segment_mean(emb, ptr, member):
     """out[k] = mean of emb[member[ptr[k]:ptr[k+1]]] in list order (prototype building); zeros for empty segments."""
     L.require_gpu()

@@ -216,9 +216,10 @@ class _ClipFn(torch.autograd.Function):
 
 def clip_preprocess(images, size: int, device) -> Tensor:
     """``CLIPProcessor(images=image, return_tensors="pt")["pixel_values"]`` (pretrain/clip_embedder.py:55-57) on the device: see
-    ``training.preprocess.images_to_pixel_values`` (centre crop to a square, resize, /255, CLIP mean / std)."""
+    ``training.preprocess.images_to_pixel_values`` (Pillow bicubic resize of the shortest edge to ``size``, centre crop, * 1/255, CLIP mean / std; the uint8
+    image is bit-identical to the processor's, pinned by transformers' own output in tests/golden/preprocess_pil.npz)."""
     from ..training.preprocess import images_to_pixel_values
-    return images_to_pixel_values(images, size, CLIP_MEAN, CLIP_STD, device)
+    return images_to_pixel_values(images, size, CLIP_MEAN, CLIP_STD, device, pipeline="clip")
 
 
 class CLIPEmbedding(nn.Module):

@@ -1,7 +1,8 @@
 """Drop-in for the reference's ``pretrain/tinyvit_embedder.py`` (``TinyViTEmbedding``, :8-124): frozen TinyViT with
 ``num_classes=0`` run under ``no_grad``; panorama kwargs ``image_2..4`` stack on dim 1.  Float tensors are pixel_values (:70-72); PIL images /
-uint8 arrays or tensors go through the tensor side of timm's eval transform on the device (:56-69: centre crop at the variant's crop_pct,
-resize to the model's input size, /255, ImageNet mean / std -- ``training.preprocess.images_to_pixel_values``)."""
+uint8 arrays or tensors go through timm's eval transform on the device (:51-53,67-69: Pillow bicubic resize of the shortest edge to floor(size / crop_pct) --
+of both edges in "squash" mode --, centre crop, /255, ImageNet mean / std: ``training.preprocess.images_to_pixel_values``, bit-identical to Pillow on the
+uint8 image)."""
 from __future__ import annotations
 
 import torch
@@ -29,9 +30,11 @@ class TinyViTEmbedding(torch.nn.Module):
         else:
             from ..training.preprocess import TINYVIT_MEAN, TINYVIT_STD, images_to_pixel_values
             bb = self.tinyvit_model.backbone
-            # timm's pretrained_cfg: crop_pct 0.95 for the 224 variants, 1.0 ("squash"-free centre crop) for the 384 / 512 ones
+            # timm's published default_cfgs (timm/models/tiny_vit.py; timm itself is not in the image): crop_pct 0.95 for the 224 variants, 1.0 for the 384 one,
+            # 1.0 with crop_mode "squash" for the 512 one; bicubic everywhere
             crop = 0.95 if bb.cfg.img_size == 224 else 1.0
-            pixel_values = images_to_pixel_values(image, bb.cfg.img_size, TINYVIT_MEAN, TINYVIT_STD, bb.flat_params.device, crop_pct=crop)
+            pixel_values = images_to_pixel_values(image, bb.cfg.img_size, TINYVIT_MEAN, TINYVIT_STD, bb.flat_params.device, crop_pct=crop, pipeline="timm",
+                                                  crop_mode="squash" if bb.cfg.img_size == 512 else "center")
         with torch.no_grad():
             return self.tinyvit_model(pixel_values=pixel_values).pooler_output
 

@@ -473,6 +473,17 @@ int gg_tinyvit_activation_info_masked(const GgTinyVitCfg* cfg, int batch, const 
  * dst: NCHW f32 [N,3,Hd,Wd]; mean3/std3: HOST float[3] or both NULL (no normalisation). */
 int gg_preprocess_bilinear(const void* src, int src_u8, int N, int Hs, int Ws, float* dst, int Hd, int Wd,
                            const float* mean3 /* host */, const float* std3 /* host */, void* stream);
+/* The raw-image side of the embedders: what timm's eval transform (pretrain/tinyvit_embedder.py:51-53,67-69), transformers' CLIPProcessor
+ * (pretrain/clip_embedder.py:25,51-55) and the torchvision Compose of inference.py:74-85 do to ONE RGB image -- Pillow resize of the whole image to
+ * (Hr, Wr) (filter: 2 = PIL BILINEAR, 3 = PIL BICUBIC; support scaled with the reduction as Pillow does), crop window (crop_top, crop_left, Hc, Wc) of
+ * the resized image, 1/255 (mul_rescale 0: x / 255 as torchvision's ToTensor, 1: x * (1/255) as transformers' rescale), (x - mean) / std.  The uint8
+ * resize result is bit-identical to PIL.Image.resize (8-bit fixed-point resampling with an 8-bit intermediate image; tests/golden/preprocess_pil.npz).
+ * src: device uint8 [Hs, Ws, 3] (HWC, RGB); dst_chw: device f32 [3, Hc, Wc]; dst_u8_hwc: optional device uint8 [Hc, Wc, 3] (the crop before 1/255);
+ * mean3 / std3: HOST float[3] or both NULL; workspace: device, gg_preprocess_pil_workspace_bytes(...) bytes (-1: bad arguments).  The geometry rules of
+ * the three pipelines (shortest edge, crop rounding) are host arithmetic: geoguessr-ai_amd/training/preprocess.py. */
+int64_t gg_preprocess_pil_workspace_bytes(int Hs, int Ws, int filter, int Hr, int Wr, int Wc);
+int gg_preprocess_pil(const void* src_hwc_u8, int Hs, int Ws, int filter, int Hr, int Wr, int crop_top, int crop_left, int Hc, int Wc, int mul_rescale,
+                      const float* mean3 /* host */, const float* std3 /* host */, float* dst_chw, void* dst_u8_hwc, void* workspace, void* stream);
 /* f2: prototype building (models/proto_refiner.py:461-517): per-segment mean of embedding rows, CSR segments ptr[K+1] over the
  * member row list, summed in list order in fp32 (the reference's running sum), zeros for empty segments. */
 int gg_segment_mean(const float* emb, int64_t ld, const int64_t* ptr, const int64_t* member, int num_segments, int D, float* out,

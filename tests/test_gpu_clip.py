@@ -187,8 +187,8 @@ def test_clip_large_patch14_336_forward_and_finetune_fp32(centroids):
 
 def test_clip_embedding_wrapper_tensor_and_raw_image_inputs():
     """CLIPEmbedding (pretrain/clip_embedder.py:10-101): float tensors are pixel_values (:58-59), panorama kwargs stack on dim 1 (:94-101); raw
-    uint8 images (PIL-style HWC arrays, a list of them, or an NCHW uint8 tensor) go through the processor's tensor side on the device: centre crop to
-    a square, resize, /255, CLIP mean / std."""
+    uint8 images (PIL-style HWC arrays, a list of them, or an NCHW uint8 tensor) go through the processor's pipeline on the device: Pillow bicubic resize
+    of the shortest edge, centre crop, * 1/255, CLIP mean / std (bit-identical uint8 stage: tests/test_gpu_kernels.py::test_preprocess_pil_matches_...)."""
     from geoguessr_ai_amd.pretrain.clip_embedder import CLIPEmbedding, CLIP_MEAN, CLIP_STD
     e = CLIPEmbedding("openai/clip-vit-base-patch32", device="cuda", panorama=True, precision="bf16")
     assert not any(p.requires_grad for p in e.parameters()) and not e.training
@@ -198,13 +198,13 @@ def test_clip_embedding_wrapper_tensor_and_raw_image_inputs():
     single = e(xs[1].cuda())
     assert single.shape == (2, 768) and torch.allclose(single, pano[:, 1], atol=2e-3)
     rng = np.random.default_rng(0)
-    img = rng.integers(0, 256, (300, 448, 3), dtype=np.uint8)                     # landscape HWC image: centre 300 x 300 crop
-    crop = torch.from_numpy(img[:, 74:374]).permute(2, 0, 1).float().unsqueeze(0)
-    want = torch.nn.functional.interpolate(crop, size=(224, 224), mode="bilinear", align_corners=False) / 255.0
-    want = (want - torch.tensor(CLIP_MEAN).view(1, 3, 1, 1)) / torch.tensor(CLIP_STD).view(1, 3, 1, 1)
+    img = rng.integers(0, 256, (300, 448, 3), dtype=np.uint8)                     # landscape HWC image
+    from oracle import preprocess_ref as P                                         # (the Pillow-pinned restatement of the processor)
+    _, want = P.raw_image_pixel_values(img, "clip", 224, CLIP_MEAN, CLIP_STD)
+    want = torch.from_numpy(want).unsqueeze(0)
     from geoguessr_ai_amd.pretrain.clip_embedder import clip_preprocess
     got = clip_preprocess(img, 224, "cuda")
-    assert got.shape == (1, 3, 224, 224) and torch.allclose(got.cpu(), want, atol=1e-5)
+    assert got.shape == (1, 3, 224, 224) and torch.allclose(got.cpu(), want, atol=1e-6)
     a = e(img)
     b_ = e(want.cuda())
     assert a.shape == (1, 768) and torch.allclose(a, b_, atol=1e-3)

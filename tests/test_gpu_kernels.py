@@ -1037,3 +1037,44 @@ def test_dwconv_stride2_data_gradient_with_batchnorm_fusions_f32(ops, C, H, B):
     plain, _ = ops.dwconv3x3_s2_bwd_data_fused(dev(dy), None, None, dev(taps), H, H)
     close(plain, conv_t(dy), rtol=2e-4, atol=2e-5, what="f32 s2 plain dgrad")
     close(plain, ops.dwconv3x3_bwd_data(dev(dy), dev(taps), B, H, H, C, stride=2), rtol=1e-5, atol=1e-6, what="agrees with the unfused gather (tap order differs)")
+
+
+def test_preprocess_pil_matches_pillow_and_transformers_golden():
+    """gg_preprocess_pil through training.preprocess.images_to_pixel_values against tests/golden/preprocess_pil.npz (Pillow's Image.resize and transformers'
+    CLIPImageProcessorPil, run by tests/golden/make_golden_r5.py): the uint8 crop of every pipeline -- CLIPProcessor (pretrain/clip_embedder.py:51-55), timm's eval
+    transform at 224 / 384 / 512-squash (pretrain/tinyvit_embedder.py:51-69), inference.py:84's Resize + CenterCrop -- is BIT-IDENTICAL; pixel_values agree to
+    1e-6 (one fp32 ulp: transformers rescales in a wider type).  Images: landscape, portrait, mode L, mode RGBA, an up-scale, a no-op resize, a 2.2:1 strip."""
+    import hashlib
+    from oracle import preprocess_ref as P
+    from geoguessr_ai_amd import _lib as L, ops
+    from geoguessr_ai_amd.training.preprocess import images_to_pixel_values, TINYVIT_MEAN, TINYVIT_STD, CLIP_MEAN, CLIP_STD
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "preprocess_pil.npz"))
+    checked = 0
+    for n in sorted({k.split(".")[0] for k in g.files}):
+        img = P.to_rgb(g[n + ".img"], "".join(chr(c) for c in g[n + ".mode"]))
+        for key, pipe, size, ms, kw in (("clip", "clip", 224, (CLIP_MEAN, CLIP_STD), {}), ("timm224", "timm", 224, (TINYVIT_MEAN, TINYVIT_STD), dict(crop_pct=0.95)),
+                                        ("timm512", "timm", 512, (TINYVIT_MEAN, TINYVIT_STD), dict(crop_pct=1.0, crop_mode="squash")),
+                                        ("inf336", "torchvision", 336, (CLIP_MEAN, CLIP_STD), {}), ("timm384", "timm", 384, (TINYVIT_MEAN, TINYVIT_STD), dict(crop_pct=1.0))):
+            if not any(f"{n}.{key}_{suf}" in g.files for suf in ("u8", "sha")):
+                continue
+            pv, u8 = images_to_pixel_values(img, size, ms[0], ms[1], "cuda", pipeline=pipe, return_u8=True, **kw)
+            pv, u8 = pv[0].cpu().numpy(), u8[0].cpu().numpy()
+            if f"{n}.{key}_u8" in g.files:
+                assert np.array_equal(u8, g[f"{n}.{key}_u8"]), (n, key, int((u8 != g[f"{n}.{key}_u8"]).sum()))
+            else:
+                assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).digest() == g[f"{n}.{key}_sha"].tobytes(), (n, key)
+            if f"{n}.{key}_pv" in g.files:
+                assert np.abs(pv - g[f"{n}.{key}_pv"]).max() <= 1e-6, (n, key)
+            elif f"{n}.{key}_pv_sum" in g.files:
+                cs = np.asarray([pv.astype(np.float64).sum(), np.abs(pv.astype(np.float64)).sum()])
+                assert np.abs(cs - g[f"{n}.{key}_pv_sum"]).max() <= 1e-6 * g[f"{n}.{key}_pv_sum"][1], (n, key)
+            checked += 1
+    assert checked == 19
+    # the NCHW uint8 tensor form and a list give the same rows; an image that the upstream transforms would have to pad is refused
+    land = P.to_rgb(g["land.img"], "RGB")
+    a = images_to_pixel_values(land, 224, CLIP_MEAN, CLIP_STD, "cuda", pipeline="clip")
+    b = images_to_pixel_values(torch.from_numpy(land).permute(2, 0, 1), 224, CLIP_MEAN, CLIP_STD, "cuda", pipeline="clip")
+    c = images_to_pixel_values([land, land[:, ::-1].copy()], 224, CLIP_MEAN, CLIP_STD, "cuda", pipeline="clip")
+    assert torch.equal(a, b) and c.shape == (2, 3, 224, 224) and torch.equal(c[:1], a)
+    with pytest.raises(L.GgError, match="inside the resized image|smaller than"):
+        ops.preprocess_pil(torch.zeros((50, 60, 3), dtype=torch.uint8, device="cuda"), 3, (50, 60), (0, 0), (224, 224))

@@ -107,7 +107,7 @@ def test_raw_image_inputs_are_converted_to_rgb():
     """PIL images of any mode go through ``convert("RGB")`` like CLIPProcessor / timm's transform; arrays of another layout are refused by name."""
     import numpy as np
     import pytest
-    from geoguessr_ai_amd.training.preprocess import _rgb_chw
+    from geoguessr_ai_amd.training.preprocess import _rgb_hwc
     from geoguessr_ai_amd._lib import GgError
     class FakePIL:                      # the two attributes the path reads (Pillow is optional in this image)
         mode = "L"
@@ -116,12 +116,12 @@ def test_raw_image_inputs_are_converted_to_rgb():
             self.converted = mode
             return np.zeros((5, 7, 3), np.uint8)
     im = FakePIL()
-    t = _rgb_chw(im)
-    assert im.converted == "RGB" and tuple(t.shape) == (3, 5, 7)
+    t = _rgb_hwc(im)
+    assert im.converted == "RGB" and tuple(t.shape) == (5, 7, 3)
     with pytest.raises(GgError, match="raw image"):
-        _rgb_chw(np.zeros((5, 7), np.uint8))
+        _rgb_hwc(np.zeros((5, 7), np.uint8))
     with pytest.raises(GgError, match="raw image"):
-        _rgb_chw(np.zeros((5, 7, 4), np.uint8))
+        _rgb_hwc(np.zeros((5, 7, 4), np.uint8))
 
 
 def test_drop_path_state_travels_with_the_checkpoint():
@@ -137,3 +137,16 @@ def test_drop_path_state_travels_with_the_checkpoint():
     CK.restore_drop_path_state(m2, st)
     assert (m2.backbone._drop_seed, m2.backbone._drop_counter) == (1234567, 42)
     CK.restore_drop_path_state(m2, {"epoch": 1})            # a checkpoint without the key (the reference's own) is fine
+
+
+def test_raw_image_geometry_matches_the_oracle_rules():
+    """The host arithmetic of the three raw-image pipelines (shortest edge, long edge truncation, crop rounding) is the oracle's, which the Pillow / transformers
+    fixture pins (tests/test_oracle_geo.py::test_pil_pipelines_match_pillow_and_transformers)."""
+    from geoguessr_ai_amd.training.preprocess import raw_image_geometry
+    from oracle import preprocess_ref as P
+    for h, w in ((301, 452), (381, 233), (224, 224), (226, 230), (240, 531), (1000, 333), (225, 4000)):
+        for pipe, size, kw in (("clip", 224, {}), ("timm", 224, dict(crop_pct=0.95)), ("timm", 512, dict(crop_pct=1.0, crop_mode="squash")), ("timm", 384, dict(crop_pct=1.0)),
+                               ("torchvision", 336, {}), ("torchvision", 512, {})):
+            flt, resized, crop = raw_image_geometry(h, w, pipe, size, **kw)
+            oflt, oresized, ocrop, _ = P.raw_image_geometry(h, w, pipe, size, **kw)
+            assert (flt, resized, crop) == (oflt, oresized, ocrop), (h, w, pipe, size)
