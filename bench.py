@@ -113,13 +113,13 @@ def cpu_baseline(seconds_budget: float = 14.0):
 
     torch.set_num_threads(cores)
     med, steps, dt = timed(n, seconds_budget, 2)
-    n1 = 2
+    n1 = 1
     torch.set_num_threads(1)
-    med1, steps1, dt1 = timed(n1, 0.0, 1)
+    med1, steps1, dt1 = timed(n1, 0.0, 3)
     torch.set_num_threads(cores)
     return dict(value=round(n * 4 / med, 3), unit="images/s", cores=cores, kind="port", host_cpus=os.cpu_count(), usable_cpus=usable, cpu_model=cpu_model,
                 one_thread=dict(value=round(n1 * 4 / med1, 3), unit="images/s", cores=1,
-                                sample=f"1 warm-up + {steps1} timed step(s) of {n1} panoramas = {n1 * 4} images, {dt1:.1f} s"),
+                                sample=f"1 warm-up + {steps1} timed steps (median) of {n1} panorama = {n1 * 4} images, {dt1:.1f} s"),
                 sample=f"1 warm-up + {steps} timed oracle train steps (fwd+bwd+AdamW, torch fp32, median) of {n} panoramas = {n * 4} images, "
                        f"TinyViT-21M-224 + 12647-cell head, reference freeze policy, {cores} threads on a host with {os.cpu_count()} CPUs ({cpu_model}), {dt:.1f} s")
 
@@ -201,6 +201,47 @@ def class_rooflines(breakdown_raw, steps, precision, pmc_classes, pmc_info):
     return out
 
 
+def class_profile(fn, steps, wall_ms, peak_tf):
+    """Roofline-shaped objects for one secondary workload: `steps` instrumented calls (the library's per-launch HIP-event log: class, ms, algorithmic flops and
+    bytes; HIP graphs are off while it is on), summed per kernel class.  A class is priced against the roof that bounds it -- max(flops / MFMA peak of the
+    mode, bytes / 8 TB/s) -- and the workload as a whole reports its launches per step and the share of the un-instrumented wall time its kernels fill
+    (`gpu_busy_frac`: what is left is launch latency -- the launch-bound configs)."""
+    import torch
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    lib = L.lib()
+    lib.gg_prof_reset(); lib.gg_prof_enable(1)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    lib.gg_prof_enable(0)
+    tot = {c: [0.0, 0, 0.0, 0.0] for c in range(len(CATS))}
+    cat, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
+    for i in range(lib.gg_prof_count()):
+        L.check(lib.gg_prof_record(i, C.byref(cat), C.byref(ms), C.byref(fl), C.byref(by)), "gg_prof_record")
+        t = tot[cat.value]
+        t[0] += ms.value; t[1] += 1; t[2] += fl.value; t[3] += by.value
+    lib.gg_prof_reset()
+    classes = {}
+    for c, name in enumerate(CATS):
+        ms_, n_, fl_, by_ = tot[c]
+        if n_ == 0 or ms_ <= 0:
+            continue
+        t_mfma, t_hbm = fl_ / (peak_tf * 1e9), by_ / (HBM_PEAK_GBS * 1e6)            # ms at either roof
+        if t_mfma >= t_hbm:
+            ach = fl_ / ms_ / 1e9
+            o = dict(bound="mfma", achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach / peak_tf, 4))
+        else:
+            ach = by_ / ms_ / 1e6
+            o = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))
+        o.update(ms_per_step=round(ms_ / steps, 4), launches_per_step=n_ // steps, algorithmic_gflop_per_step=round(fl_ / steps / 1e9, 3),
+                 algorithmic_bytes_per_step=int(by_ / steps), traffic=None)
+        classes[name] = o
+    busy = sum(t[0] for t in tot.values()) / steps
+    return dict(class_rooflines=classes, launches_per_step=sum(t[1] for t in tot.values()) // steps, gpu_busy_ms_per_step=round(busy, 4),
+                gpu_busy_frac=round(min(1.0, busy / max(wall_ms, 1e-9)), 4))
+
+
 def secondary_cases(dev, budget_s=15.0):
     """BASELINE.json configs other than the headline, timed in the same process on the same device with the protocol of tools/bench_secondary.py
     (W warm-up calls, K timed calls between synchronisations), bounded to ~`budget_s` seconds in total:
@@ -244,7 +285,8 @@ def secondary_cases(dev, budget_s=15.0):
             o = model(pixel_values=x, labels=lab, labels_clf=clf)
             o.loss.backward(); opt.step(); opt.zero_grad()
         dt = timed(c1, 15, 4)
-        out["c1"] = dict(workload="tiny_vit_5m_224, batch 8 single images, fwd + hard-CE + bwd + AdamW", dtype="fp32", ms_per_step=round(dt * 1e3, 3), images_per_s=round(8 / dt, 1))
+        out["c1"] = dict(workload="tiny_vit_5m_224, batch 8 single images, fwd + hard-CE + bwd + AdamW", dtype="fp32", ms_per_step=round(dt * 1e3, 3), images_per_s=round(8 / dt, 1),
+                         **class_profile(c1, 3, dt * 1e3, 157.3))
         del model, base, opt, x
         cleanup()
         # the serving call of the reference's inference.py:162-170 on ONE panorama (4 headings through TinyViT-21M + the geocell head): latency with the GPU drained
@@ -262,8 +304,11 @@ def secondary_cases(dev, budget_s=15.0):
                 model(pixel_values=xs, labels_clf=dummy)
                 torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 30
+        def serve():
+            with torch.no_grad():
+                model(pixel_values=xs, labels_clf=dummy)
         out["serve_1_panorama"] = dict(workload="tiny_vit_21m_224 + geocell head, serving call on 1 panorama (4 images), synchronised after every call", dtype="fp32",
-                                       latency_ms=round(dt * 1e3, 3), panoramas_per_s=round(1 / dt, 1))
+                                       latency_ms=round(dt * 1e3, 3), panoramas_per_s=round(1 / dt, 1), **class_profile(serve, 3, dt * 1e3, 157.3))
         del model, base, xs
         cleanup()
         for prec in ("fp32", "fp16"):
@@ -275,8 +320,11 @@ def secondary_cases(dev, budget_s=15.0):
                 dt = timed(lambda: tower(pixel_values=xc, return_last_hidden=False), 3 if prec == "fp32" else 10, 1 if prec == "fp32" else 2)
             peak = 157.3 if prec == "fp32" else 2500.0
             tf = 1024 / dt * 8.82e9 / 1e12
+            def c4():
+                with torch.no_grad():
+                    tower(pixel_values=xc, return_last_hidden=False)
             out["c4_" + prec] = dict(workload="CLIP ViT-B/32 vision tower inference (random weights), batch 1024", dtype=prec, ms_per_step=round(dt * 1e3, 3),
-                                     images_per_s=round(1024 / dt, 1), tflops=round(tf, 1), frac_of_mfma_peak=round(tf / peak, 4))
+                                     images_per_s=round(1024 / dt, 1), tflops=round(tf, 1), frac_of_mfma_peak=round(tf / peak, 4), **class_profile(c4, 2, dt * 1e3, peak))
             del tower, xc
             cleanup()
         Bq, D = 4096, 576
@@ -295,7 +343,7 @@ def secondary_cases(dev, budget_s=15.0):
                 refiner(e, llh, topk.indices, topk.values)
         dt = timed(c5, 10, 3)
         out["c5"] = dict(workload="SuperGuessr serving head (576 -> 12647, softmax, top-5) + ProtoRefiner on precomputed embeddings, batch 4096 per GPU", dtype="fp32",
-                         prototypes=int(len(gi)), ms_per_step=round(dt * 1e3, 3), samples_per_s=round(Bq / dt, 1))
+                         prototypes=int(len(gi)), ms_per_step=round(dt * 1e3, 3), samples_per_s=round(Bq / dt, 1), **class_profile(c5, 3, dt * 1e3, 157.3))
         del head, refiner, emb
         cleanup()
     except Exception as e:           # the secondary block must never cost the headline line
@@ -456,6 +504,8 @@ def run_mode(precision, args, rank, world, dev, x, lab):
     N = x.shape[0]
 
     def step():
+        if world > 1:
+            opt.broadcast_buffers()                      # DDP(broadcast_buffers=True) before every training forward, as training/train_eval_loop.py does
         with opt.overlap_allreduce():                    # gradient buckets leave while the backward pass is still running
             out = model(pixel_values=x, labels=lab)      # nearest-centroid labels + soft targets fused in the head kernel
             out.loss.backward()
@@ -589,6 +639,10 @@ def main():
                  f"(or run `python bench.py --gpus {args.gpus}` and let it start the ranks itself)")
     L.require_gpu()
     backend = os.environ.get("GG_DIST_BACKEND", "nccl")          # "gloo" + GG_BENCH_ONE_DEVICE=1: rehearsal of the N>1 path on a one-GPU box
+    # what carries the gradient buckets: torch.distributed's backend, or -- GG_NATIVE_COMM=1 -- the C-ABI communicator gg_comm_* (RCCL through comm.cpp;
+    # torch.distributed then only carries the rendezvous, the barrier and this script's scalar reductions)
+    from geoguessr_ai_amd import comm as _gg_comm
+    comm_backend = "gg_comm (RCCL behind the C-ABI, csrc/comm.cpp)" if _gg_comm.enabled() else ("rccl (torch.distributed nccl)" if backend == "nccl" else backend)
     if os.environ.get("GG_BENCH_ONE_DEVICE"):
         local = 0
     torch.cuda.set_device(local)
@@ -614,7 +668,8 @@ def main():
 
     # fp32_split (experiment): f32 storage, the Linears of frozen C >= 384 blocks as fp32-accurate products of three bf16 planes per operand; it passes
     # the fp32 mode's parity gate (tests/test_gpu_precision.py::test_fp32_split_mode_passes_the_fp32_gate) and is reported under its own key, never as the headline
-    modes = ["fp32", "bf16", "fp32_split"] if args.precision == "both" else [args.precision]
+    # (fp32_split is closed -- DESIGN.md 5 -- and no longer part of the default run: `--precision fp32_split` still times it)
+    modes = ["fp32", "bf16"] if args.precision == "both" else [args.precision]
     results = {m: run_mode(m, args, rank, world, dev, x, lab) for m in modes}
     head = results[modes[0]]
 
@@ -634,8 +689,8 @@ def main():
                     config=dict(workload=f"{args.model} 4x224x224 panoramas, fwd+bwd+AdamW, soft-CE over 12647 geocells, "
                                          f"{'all params' if args.unfrozen else 'freeze_all_but_last_stage'}, DropPath, train-mode BN",
                                 panoramas_per_gpu=N, images_per_gpu=N * 4, global_batch_panoramas=N * world, parallelism=f"dp{world}",
-                                precision=modes[0]),
-                    rccl_ranks=rccl_ranks, comm_backend=(backend if world > 1 else None),
+                                precision=modes[0], **({"buffer_broadcast": "BatchNorm running statistics from rank 0 before every forward"} if world > 1 else {})),
+                    rccl_ranks=rccl_ranks, comm_backend=(comm_backend if world > 1 else None),
                     allreduce_ms_per_step=head.get("allreduce_ms_per_step"), allreduce_bytes_per_step=head.get("allreduce_bytes_per_step"),
                     allreduce_busbw_gbps=head.get("allreduce_busbw_gbps"), allreduce_buckets=head.get("allreduce_buckets"),
                     allreduce_bucket_bytes=head.get("allreduce_bucket_bytes"),

@@ -187,17 +187,19 @@ class TinyVitBackbone(FlatStore):
         if generator is not None:
             # host-side (seed, counter) from the generator's seed + a per-generator call count: no device round trip (a CUDA generator's randint +
             # .item() was a blocking sync per step), deterministic for a given generator seed and call order.  The count lives with the generator OBJECT
-            # (weak reference: it dies with it, and a new generator that happens to reuse its address starts from zero) and restarts when the generator
-            # is given another seed; re-seeding it with the SAME seed continues the count (initial_seed() cannot tell) -- use a fresh generator for that
-            import weakref
-            counts = self.__dict__.setdefault("_drop_gen_counts", weakref.WeakKeyDictionary())
+            # (torch generators can be neither weakly referenced nor given attributes: the entry holds a strong reference, so the object's id cannot be
+            # reused by another generator while the entry lives; the table keeps the 16 most recently used generators) and restarts when the generator is
+            # given another seed; re-seeding it with the SAME seed continues the count (initial_seed() cannot tell) -- use a fresh generator for that
+            counts = self.__dict__.setdefault("_drop_gen_counts", {})
             seed = int(generator.initial_seed()) & (2 ** 62 - 1)
-            ent = counts.get(generator)
-            if ent is None or ent[0] != seed:
-                ent = [seed, 0]
-            counter = ent[1]
-            ent[1] += 1
-            counts[generator] = ent
+            ent = counts.pop(id(generator), None)
+            if ent is None or ent[0] is not generator or ent[1] != seed:
+                ent = [generator, seed, 0]
+            counter = ent[2]
+            ent[2] += 1
+            counts[id(generator)] = ent                 # (re-inserted last: dicts keep insertion order, the oldest entry leaves first)
+            while len(counts) > 16:
+                counts.pop(next(iter(counts)))
         else:
             if getattr(self, "_drop_seed", None) is None:
                 self._drop_seed, self._drop_counter = int(torch.randint(0, 2 ** 62, (1,)).item()), 0      # (CPU RNG, once per backbone)
