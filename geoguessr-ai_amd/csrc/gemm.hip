@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_nt_kernel(GemmParams p) {
 // the next stage, barrier, refill this stage's buffer with stage s + 2, read the next stage's first fragments under the last eight MFMAs.
 // Epilogue of the LDS-DMA form: the same arithmetic and rounding points as gemm_epilogue (fragment phase: + bias, quick_gelu, * rowscale on the f32 accumulators,
 // round to the 16-bit type; row phase on the rounded tile: pre-activation copy, GELU, x GELU'(saved pre-activation), + residual) -- results are bit-identical to
-// the register-staged kernel's -- but WAVE-PRIVATE and without general-shape fallbacks.  A wave turns its own 96 x 64 sub-tile from the MFMA layout (a lane: 4
+// the register-staged kernel's -- but WAVE-PRIVATE and without general-shape fallbacks.  A wave turns its own (16 TM) x 64 sub-tile from the MFMA layout (a lane: 4
 // columns of one row) into rows (8 lanes x 16 B = one 128-byte line of C; an instruction covers 8 rows) through a private LDS scratch, 32 rows at a time: no
 // workgroup barrier, and while it runs the workgroup's ring is free to receive the NEXT tile's first stage.  The host sends a launch here only when every row of
 // C / the second tensor is 16-byte aligned and N % 8 == 0, so a 16-byte column chunk is entirely inside or outside N; rows beyond M and chunks beyond N are
@@ -491,11 +491,11 @@ typedef unsigned int gemm_u32x4_t __attribute__((ext_vector_type(4)));
 // (the operand registers are plain local arrays of the kernel, passed by reference: gathered in a struct the compiler kept part of them in scratch memory)
 // bias and row scales (MFMA layout): ordinary loads issued before the last k-stage's MFMAs, pinned in registers by gemm_dma_epi_ready before the next tile's DMA
 // is issued (a wait the compiler places behind an LDS-DMA covers the DMA too: vmcnt retires in order)
-template <int EPI>
-__device__ __forceinline__ void gemm_dma_epi_fetch(const GemmParams& p, f32x4 (&bs)[4], float (&rsv)[6], int m0, int n0, int wm, int wn, int lane) {
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_dma_epi_fetch(const GemmParams& p, f32x4 (&bs)[4], float (&rsv)[TM], int m0, int n0, int wm, int wn, int lane) {
     asm volatile("" : "+v"(lane));        // (opaque: what is derived from it below is recomputed per tile, not hoisted out of the tile loop and kept in registers / spilled)
     const int lr = lane & 15, lg = lane >> 4;
-    const int mw = m0 + wm * 96, nw = n0 + wn * 64;                // the wave's sub-tile
+    const int mw = m0 + wm * (TM * 16), nw = n0 + wn * 64;         // the wave's sub-tile
     if (EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU) {
         const __amdgpu_buffer_rsrc_t rsBias = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.bias ? p.N * 4 : 0, 0x00020000);
 #pragma unroll
@@ -503,49 +503,49 @@ __device__ __forceinline__ void gemm_dma_epi_fetch(const GemmParams& p, f32x4 (&
     }
     if ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) {
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) rsv[mt] = p.rowscale[min(mw + mt * 16 + lr, p.M - 1) / p.rows_per_scale];
+        for (int mt = 0; mt < TM; ++mt) rsv[mt] = p.rowscale[min(mw + mt * 16 + lr, p.M - 1) / p.rows_per_scale];
     }
 }
-template <int EPI>
-__device__ __forceinline__ void gemm_dma_epi_ready(const GemmParams& p, f32x4 (&bs)[4], float (&rsv)[6]) {
+template <int EPI, int TM>
+__device__ __forceinline__ void gemm_dma_epi_ready(const GemmParams& p, f32x4 (&bs)[4], float (&rsv)[TM]) {
     if (EPI == EPI_LINEAR || EPI == EPI_GELU || EPI == EPI_QGELU) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(bs[nt]));
     }
     if ((EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale) {
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) asm volatile("" : "+v"(rsv[mt]));
+        for (int mt = 0; mt < TM; ++mt) asm volatile("" : "+v"(rsv[mt]));
     }
 }
-// The second tensor of the row phase (residual / saved pre-activation), 12 x 16 B per lane: 48 registers that do not fit beside the k-loop's fragments, so it is
+// The second tensor of the row phase (residual / saved pre-activation), 2 TM x 16 B per lane: 48 - 64 registers that do not fit beside the k-loop's fragments, so it is
 // requested after the k-loop, right BEHIND the next tile's first DMA stage: vmcnt retires in order, so the row phase's wait for it also covers that stage -- the
 // two round trips overlap, and one of them (not two) is exposed per tile.  (Requested ahead of the DMA and counted by hand in inline asm, the compiler moved the
 // destination registers between the load and the wait.)
-template <int EPI, bool EXT>
-__device__ __forceinline__ void gemm_dma_ext_fetch(const GemmParams& p, gemm_u32x4_t (&ex)[12], int m0, int n0, int wm, int wn, int lane) {
+template <int EPI, bool EXT, int TM>
+__device__ __forceinline__ void gemm_dma_ext_fetch(const GemmParams& p, gemm_u32x4_t (&ex)[2 * TM], int m0, int n0, int wm, int wn, int lane) {
     const ge_t* ext = EPI == EPI_DGELU ? p.dact_preact : (EPI == EPI_LINEAR ? p.residual : nullptr);
     if (!EXT) return;
     asm volatile("" : "+v"(lane));
     const int64_t lde = EPI == EPI_LINEAR ? p.ldr : p.ldc;
-    const int mw = m0 + wm * 96, nw = n0 + wn * 64;
-    const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(max(min(p.M - mw, 96), 0));      // (readfirstlane: the compiler forms the clamp on the vector ALU and would wrap every buffer access using the descriptor in a waterfall loop)
+    const int mw = m0 + wm * (TM * 16), nw = n0 + wn * 64;
+    const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(max(min(p.M - mw, TM * 16), 0));      // (readfirstlane: the compiler forms the clamp on the vector ALU and would wrap every buffer access using the descriptor in a waterfall loop)
     const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc((void*)(ext + (int64_t)mw * lde), 0, (int)(rows * (unsigned)lde * 2u), 0x00020000);
     const int n = nw + (lane & 7) * 8;
     const unsigned vo0 = ((unsigned)(lane >> 3) * (unsigned)lde + (unsigned)n) * 2u;
 #pragma unroll
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 2 * TM; ++i)
         ex[i] = __builtin_amdgcn_raw_buffer_load_b128(rsE, (int)(n < p.N ? vo0 + (unsigned)i * 8u * (unsigned)lde * 2u : 0xFFFFFFF0u), 0, 0);
 }
 // scratch: this wave's two 32-row x 144-byte LDS images
-template <int EPI, bool EXT>
-__device__ __forceinline__ void gemm_dma_epilogue(const GemmParams& p, ge_t* scratch, f32x4 (&acc)[4][6], const f32x4 (&bs)[4], const float (&rsv)[6], const gemm_u32x4_t (&ex)[12],
+template <int EPI, bool EXT, int TM>
+__device__ __forceinline__ void gemm_dma_epilogue(const GemmParams& p, ge_t* scratch, f32x4 (&acc)[4][TM], const f32x4 (&bs)[4], const float (&rsv)[TM], const gemm_u32x4_t (&ex)[2 * TM],
                                                   int m0, int n0, int wm, int wn, int lane) {
     constexpr int CS = 72;                                          // scratch row stride (elements): 144 bytes, 16-byte aligned
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     asm volatile("" : "+v"(lane));
     const int lr = lane & 15, lg = lane >> 4;
-    const int mw = m0 + wm * 96, nw = n0 + wn * 64;
-    const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(max(min(p.M - mw, 96), 0));      // (readfirstlane: the compiler forms the clamp on the vector ALU and would wrap every buffer access using the descriptor in a waterfall loop)
+    const int mw = m0 + wm * (TM * 16), nw = n0 + wn * 64;
+    const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(max(min(p.M - mw, TM * 16), 0));      // (readfirstlane: the compiler forms the clamp on the vector ALU and would wrap every buffer access using the descriptor in a waterfall loop)
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<ge_t*>(p.C) + (int64_t)mw * p.ldc), 0, (int)(rows * (unsigned)p.ldc * 2u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI == EPI_GELU && p.preact ? p.preact : reinterpret_cast<ge_t*>(p.C)) + (int64_t)mw * p.ldc), 0,
                                                                          (int)(rows * (unsigned)p.ldc * 2u), 0x00020000);
@@ -555,7 +555,7 @@ __device__ __forceinline__ void gemm_dma_epilogue(const GemmParams& p, ge_t* scr
     const unsigned vstep = 8u * (unsigned)p.ldc * 2u;
     const bool scaled = (EPI == EPI_LINEAR || EPI == EPI_DGELU) && p.rowscale != nullptr;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {                                   // 32 rows = m-tiles 2 c, 2 c + 1
+    for (int c = 0; c < TM / 2; ++c) {                              // 32 rows = m-tiles 2 c, 2 c + 1
         ge_t* Cs = scratch + (c & 1) * 32 * CS;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -618,17 +618,23 @@ template <int N> __device__ __forceinline__ void gemm_wait_vmcnt() { asm volatil
 // One workgroup per tile.  (A persistent form -- two workgroups per CU walking a per-XCD tile queue, the next tile's first stage issued under the epilogue -- was
 // built and measured: the same 12.05 ms for the CLIP tower at batch 1024 as this one.  The operand stream and the chip's clock under the load set the pace,
 // not the 1 us between a workgroup's end and its successor's start.)
-template <int EPI, bool EXT = false, bool PRIO = false, int ABL = 0>      // EXT: the row phase reads a second tensor (residual / saved pre-activation); ABL (dev, tools/ablate_gemm16.sh): 1 = no operand DMA, 32 = no MFMAs, 64 = per-tile cycle trace into p.colstats
-__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
-    constexpr int BM = 192, BN = 128, SK = 64, NST = 2;
-    constexpr int TA = BM * SK, TB = BN * SK, STAGE = TA + TB;            // elements per stage (40 KB)
-    static_assert(NST * STAGE * 2 == 81920 && 4 * 2 * 32 * 72 <= STAGE, "two workgroups share the CU's 160 KB; the epilogue's wave-private scratch reuses ring buffer 1");
-    constexpr int TM = 6, TN = 4;
-    constexpr int PA = BM / 8 / 4, PB = BN / 8 / 4, DPS = PA + PB;         // DMA pieces (8 rows x 128 B) per wave and stage: 6 A + 4 B
+// Two geometries of the same code (TM m-tiles of 16 rows per wave, NWN waves along N; two wave rows):
+//   TM = 6, NWN = 2: 192 x 128 tile, four waves, 2 x 80 KB of LDS = two workgroups per CU (above);
+//   TM = 8, NWN = 4: 256 x 256 tile, eight waves of 128 x 64, 128 KB = ONE workgroup per CU: 128 instead of 77 flop per operand byte and 8 instead of 10 DMA
+//     pieces per 64 / 48 MFMAs of a wave -- the long-K, wide-N shapes whose k-loop outweighs the exposed prologue / epilogue of a lone workgroup.
+template <int EPI, bool EXT = false, int TM = 6, int NWN = 2, int ABL = 0>      // EXT: the row phase reads a second tensor (residual / saved pre-activation); ABL (dev, tools/ablate_gemm16.sh): 1 = no operand DMA, 32 = no MFMAs, 64 = per-tile cycle trace into p.colstats
+__global__ __launch_bounds__(128 * NWN, 2) void gemm_nt_dma_kernel(GemmParams p) {
+    constexpr int NW = 2 * NWN, NTHR = 64 * NW;
+    constexpr int BM = 2 * TM * 16, BN = NWN * 64, SK = 64, NST = 2;
+    constexpr int TA = BM * SK, TB = BN * SK, STAGE = TA + TB;            // elements per stage (40 KB / 64 KB)
+    static_assert(NST * STAGE * 2 <= 163840 / (NWN == 2 ? 2 : 1) && NW * 2 * 32 * 72 <= NST * STAGE, "LDS: two workgroups of the 192 x 128 form share a CU; the epilogue's wave-private scratch reuses the ring");
+    constexpr int TN = 4;
+    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW, DPS = PA + PB;       // DMA pieces (8 rows x 128 B) per wave and stage: 6 A + 4 B / 4 A + 4 B
+    static_assert(PA * NW * 8 == BM && PB * NW * 8 == BN, "the waves must divide the pieces of both operand tiles");
     __shared__ __attribute__((aligned(16))) ge_t smem[NST * STAGE];
     const int tiles = p.tilesM * p.tilesN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int lr = lane & 15, lg = lane >> 4;
     // an XCD runs 64 consecutive ids at a time: row-major order makes them one A panel x 64 B panels (wide N: every B panel is fetched by one workgroup
     // only, the whole weight matrix streams through the L2 once per M-tile row); in groups of group_m M-tiles walked column by column they are
@@ -643,25 +649,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
         } else { tm = bid / p.tilesN; tn = bid - tm * p.tilesN; }
         m0 = tm * BM; n0 = tn * BN;
     };
-    // DMA geometry: piece pc = wave + 4 j covers tile rows 8 pc .. 8 pc + 7; lane -> (row 8 pc + lane / 8, LDS chunk slot lane % 8) and fetches SOURCE chunk
-    // slot ^ T(row); bit 1 of the row is bit 4 of the lane, bit 3 of the row is bit 0 of the piece = bit 0 of the wave (4 j is even)
+    // DMA geometry: piece pc = wave + NW j covers tile rows 8 pc .. 8 pc + 7; lane -> (row 8 pc + lane / 8, LDS chunk slot lane % 8) and fetches SOURCE chunk
+    // slot ^ T(row); bit 1 of the row is bit 4 of the lane, bit 3 of the row is bit 0 of the piece = bit 0 of the wave (NW j is even)
     const int dchunk = (lane & 7) ^ (((lane >> 3) & 2) | ((wave & 1) << 2));
     unsigned voffA[PA], voffB[PB];
 #pragma unroll
-    for (int j = 0; j < PA; ++j) voffA[j] = (unsigned)((wave + 4 * j) * 8 + (lane >> 3)) * (unsigned)p.lda * 2u + dchunk * 16u;
+    for (int j = 0; j < PA; ++j) voffA[j] = (unsigned)((wave + NW * j) * 8 + (lane >> 3)) * (unsigned)p.lda * 2u + dchunk * 16u;
 #pragma unroll
-    for (int j = 0; j < PB; ++j) voffB[j] = (unsigned)((wave + 4 * j) * 8 + (lane >> 3)) * (unsigned)p.ldb * 2u + dchunk * 16u;
+    for (int j = 0; j < PB; ++j) voffB[j] = (unsigned)((wave + NW * j) * 8 + (lane >> 3)) * (unsigned)p.ldb * 2u + dchunk * 16u;
     auto issue_stage = [&](const __amdgpu_buffer_rsrc_t& rsA, const __amdgpu_buffer_rsrc_t& rsB, int st, ge_t* base) {
         if (ABL & 1) return;
         const int k0 = st * SK;
         const bool kin = k0 + dchunk * 8 < p.K;                  // K % 8 == 0: a chunk is entirely inside or outside K
 #pragma unroll
         for (int j = 0; j < PA; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + (wave + 4 * j) * 512), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + (wave + NW * j) * 512), 16,
                                                      (int)(kin ? voffA[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + TA + (wave + 4 * j) * 512), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(base + TA + (wave + NW * j) * 512), 16,
                                                      (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
     };
     auto make_rs = [&](int m0, int n0, __amdgpu_buffer_rsrc_t& rsA, __amdgpu_buffer_rsrc_t& rsB) {
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
     // fragment addresses (elements): row 16 t + lr of an operand tile, k-step ks, k-chunk lg -> chunk slot (4 ks + lg) ^ T(lr)
     const int sw = (lr & 2) | ((lr >> 1) & 4);
     const int kc0 = ((0 + lg) ^ sw) << 3, kc1 = ((4 + lg) ^ sw) << 3;
-    const int a_off = (wm * 96 + lr) * SK, b_off = TA + (wn * 64 + lr) * SK;
+    const int a_off = (wm * (TM * 16) + lr) * SK, b_off = TA + (wn * 64 + lr) * SK;
     const int nk = (p.K + SK - 1) / SK;
     const int t = blockIdx.x;
     int m0, n0;
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
     for (int nt = 0; nt < TN; ++nt) bq[0][nt] = *reinterpret_cast<const ge8_t*>(smem + b_off + nt * 16 * SK + kc0);
     ar[0] = *reinterpret_cast<const ge8_t*>(smem + a_off + kc0);
     ar[1] = *reinterpret_cast<const ge8_t*>(smem + a_off + 16 * SK + kc0);
-    f32x4 e_bs[4]; float e_rsv[6]; gemm_u32x4_t e_ex[12];            // the epilogue's memory operands
+    f32x4 e_bs[4]; float e_rsv[TM]; gemm_u32x4_t e_ex[2 * TM];            // the epilogue's memory operands
     // STEADY: stage s + 2 exists (no conditions inside).  The sched_barriers pin the order [read A two m-tiles ahead; 4 MFMAs of m-tile mt]: left alone
     // the compiler sinks each read to just above its first use and waits for it there.  The next stage's first fragments are read unconditionally (the last
     // stage reads stale bytes it never uses): a branch around them makes the compiler's wait-count merge at the join pessimistic.
@@ -704,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
         ge_t* const cur = smem + slot * STAGE;
         ge_t* const nxt = smem + (slot ^ 1) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2 * TM; ++i) {                     // i = 6 ks + mt
+        for (int i = 0; i < 2 * TM; ++i) {                     // i = TM ks + mt
             const int ks = i / TM, mt = i % TM;
             if (i + 2 < 2 * TM) {
                 const int i2 = i + 2;
@@ -729,11 +735,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
                 ar[1] = *reinterpret_cast<const ge8_t*>(nxt + a_off + 16 * SK + kc0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (PRIO) __builtin_amdgcn_s_setprio(1);
             if (!(ABL & 32))
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) acc[nt][mt] = ge_mfma(bq[ks][nt], ar[i & 3], acc[nt][mt]);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -743,14 +747,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(GemmParams p) {
         stage(std::true_type{}, s + 1, 1);
     }
     for (; s < nk; ++s) {
-        if (s == nk - 1) gemm_dma_epi_fetch<EPI>(p, e_bs, e_rsv, m0, n0, wm, wn, lane);      // nothing else is in flight now: lands under the last stage's MFMAs
+        if (s == nk - 1) gemm_dma_epi_fetch<EPI, TM>(p, e_bs, e_rsv, m0, n0, wm, wn, lane);      // nothing else is in flight now: lands under the last stage's MFMAs
         stage(std::false_type{}, s, s & 1);
     }
     __builtin_amdgcn_s_barrier();                               // the ring is idle: no DMA in flight, every fragment read
     if (ABL & 64) tr_loop = __builtin_readcyclecounter();
-    gemm_dma_epi_ready<EPI>(p, e_bs, e_rsv);
-    gemm_dma_ext_fetch<EPI, EXT>(p, e_ex, m0, n0, wm, wn, lane);
-    gemm_dma_epilogue<EPI, EXT>(p, smem + STAGE + wave * (2 * 32 * 72), acc, e_bs, e_rsv, e_ex, m0, n0, wm, wn, lane);
+    gemm_dma_epi_ready<EPI, TM>(p, e_bs, e_rsv);
+    gemm_dma_ext_fetch<EPI, EXT, TM>(p, e_ex, m0, n0, wm, wn, lane);
+    gemm_dma_epilogue<EPI, EXT, TM>(p, smem + wave * (2 * 32 * 72), acc, e_bs, e_rsv, e_ex, m0, n0, wm, wn, lane);
     if ((ABL & 64) && threadIdx.x == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1162,29 +1166,42 @@ extern "C" int GG_GEMM_NT_NAME(const GgGemmArgs* a, void* stream) {
     if (dma_sw) dma = dma && dma_var != 0;
     if (const char* only = gg_dev_env("GG_GEMM_DMA_ONLY")) { int on = 0, ok = 0, oe = -1; sscanf(only, "%d,%d,%d", &on, &ok, &oe); dma = dma && a->N == on && a->K == ok && (oe < 0 || oe == epi); }      // (dev: bisecting)
     if (dma) {
-        p.tilesM = (int)gg_cdiv(a->M, 192); p.tilesN = (int)gg_cdiv(a->N, 128);
-        const dim3 g2((unsigned)(p.tilesM * p.tilesN));
+        // the 256 x 256 geometry (one workgroup per CU) where its k-loop outweighs a lone workgroup's exposed prologue / epilogue: measured (tools/bench_gemm16.py,
+        // profiles/r05_gemm16_forms.txt) 1.37-1.41 PFLOP/s against 1.13-1.15 at K = 4096 / 8192, a tie at K = 3072 (CLIP fc2), 5-12 % slower at K = 384 ... 768
+        // -- except under the heaviest epilogue (GELU + pre-activation copy: two output tensors), where its eight waves finish the tile 3-5 % sooner
+        const char* tile_sw = gg_dev_env("GG_GEMM_DMA_TILE");
+        bool big = (a->K >= 4096 || (epi == EPI_GELU && a->preact && a->N >= 1536)) && a->N % 256 == 0 && (int64_t)gg_cdiv(a->M, 256) * gg_cdiv(a->N, 256) >= 512 &&
+                   a->ldb * 512 < 0xFFFFFF00LL;
+        if (tile_sw) big = atoi(tile_sw) == 256 && a->ldb * 512 < 0xFFFFFF00LL;
+        const int bm = big ? 256 : 192, bn = big ? 256 : 128;
+        p.tilesM = (int)gg_cdiv(a->M, bm); p.tilesN = (int)gg_cdiv(a->N, bn);
+        const dim3 g2((unsigned)(p.tilesM * p.tilesN)), blk(big ? 512 : 256);
         const char* gm_sw = gg_dev_env("GG_GEMM_GM");
-        p.group_m = gm_sw ? atoi(gm_sw) : (p.tilesN > 8 ? 8 : 0);
-        if (dma_var > 1 && epi == EPI_PLAIN) {       // dev: schedule variants / ablations (tools/bench_gemm16_var.py, tools/ablate_gemm16.sh)
-            if (dma_var == 2) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, true>), g2, dim3(256), 0, st, p);
-            else if (dma_var == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 1>), g2, dim3(256), 0, st, p);
-            else if (dma_var == 4) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 32>), g2, dim3(256), 0, st, p);
-            else if (dma_var == 6) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 64>), g2, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, false, 33>), g2, dim3(256), 0, st, p);
+        p.group_m = gm_sw ? atoi(gm_sw) : (p.tilesN > (big ? 4 : 8) ? (big ? 4 : 8) : 0);
+        if (dma_var > 1 && epi == EPI_PLAIN && !big) {       // dev: ablations / trace (tools/ablate_gemm16.sh, tools/trace_gemm16.py)
+            if (dma_var == 3) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 6, 2, 1>), g2, blk, 0, st, p);
+            else if (dma_var == 4) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 6, 2, 32>), g2, blk, 0, st, p);
+            else if (dma_var == 6) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 6, 2, 64>), g2, blk, 0, st, p);
+            else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN, false, 6, 2, 33>), g2, blk, 0, st, p);
             GG_LAUNCH_CHECK();
             return 0;
         }
+#define GG_DMA_LAUNCH(E, X)                                                                                             \
+    do {                                                                                                                \
+        if (big) hipLaunchKernelGGL((gemm_nt_dma_kernel<E, X, 8, 4>), g2, blk, 0, st, p);                               \
+        else hipLaunchKernelGGL((gemm_nt_dma_kernel<E, X, 6, 2>), g2, blk, 0, st, p);                                   \
+    } while (0)
         switch (epi) {
-            case EPI_PLAIN: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_PLAIN>), g2, dim3(256), 0, st, p); break;
+            case EPI_PLAIN: GG_DMA_LAUNCH(EPI_PLAIN, false); break;
             case EPI_LINEAR:
-                if (p.residual) hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LINEAR, true>), g2, dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_LINEAR>), g2, dim3(256), 0, st, p);
+                if (p.residual) GG_DMA_LAUNCH(EPI_LINEAR, true);
+                else GG_DMA_LAUNCH(EPI_LINEAR, false);
                 break;
-            case EPI_GELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_GELU>), g2, dim3(256), 0, st, p); break;
-            case EPI_QGELU: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_QGELU>), g2, dim3(256), 0, st, p); break;
-            default: hipLaunchKernelGGL((gemm_nt_dma_kernel<EPI_DGELU, true>), g2, dim3(256), 0, st, p); break;
+            case EPI_GELU: GG_DMA_LAUNCH(EPI_GELU, false); break;
+            case EPI_QGELU: GG_DMA_LAUNCH(EPI_QGELU, false); break;
+            default: GG_DMA_LAUNCH(EPI_DGELU, true); break;
         }
+#undef GG_DMA_LAUNCH
         GG_LAUNCH_CHECK();
         return 0;
     }

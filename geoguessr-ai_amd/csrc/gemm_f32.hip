@@ -1039,18 +1039,31 @@ __global__ __launch_bounds__(256) void splitk_nt_reduce_f32_kernel(const float* 
     }
 }
 // slabs of the split-K form: one lazily allocated 16 MiB buffer per (device, stream).  Launches of one stream run in order, so they can share their slabs; two
-// streams (or threads) issuing qualifying GEMMs concurrently get different buffers.  A capturing stream gets none -- a captured launch may be replayed on any
-// stream, next to anything, and an allocation is not legal inside a capture -- and its launch runs unsplit (include/gg.h, gg_gemm_nt_f32).
+// streams (or threads) issuing qualifying GEMMs concurrently get different buffers.  Under stream capture nothing can be allocated and the launch may be replayed
+// on any stream next to anything: the graph cache (graph.cpp) hands every captured graph slabs of its OWN (gg_gemm_f32_capture_scratch, allocated before the
+// capture starts when the key's eager run used the split form, freed with the graph), so a replay computes exactly what the eager call did; a capture that
+// was given none runs unsplit.
 constexpr int64_t kSplitScratchFloats = (int64_t)4 << 20;
+static std::mutex g_split_mu;
+static std::map<hipStream_t, float*> g_capture_slabs;
+static thread_local long tl_splitk_uses = 0;
+long gg_gemm_f32_splitk_uses() { return tl_splitk_uses; }                       // (graph.h) split-form launches issued by this thread so far
+size_t gg_gemm_f32_splitk_bytes() { return (size_t)kSplitScratchFloats * sizeof(float); }
+void gg_gemm_f32_capture_scratch(hipStream_t cap, float* buf) {                 // buf == nullptr: forget the stream
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    if (buf) g_capture_slabs[cap] = buf; else g_capture_slabs.erase(cap);
+}
 static float* splitk_scratch(hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (cs != hipStreamCaptureStatusNone) return nullptr;
-    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    if (cs != hipStreamCaptureStatusNone) {
+        auto it = g_capture_slabs.find(st);
+        return it == g_capture_slabs.end() ? nullptr : it->second;
+    }
     static std::map<std::pair<int, hipStream_t>, float*> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    std::lock_guard<std::mutex> lk(mu);
     auto it = bufs.find({dev, st});
     if (it != bufs.end()) return it->second;
     float* b = nullptr;
@@ -1126,7 +1139,7 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
         if (want > 1) {
             const int kps = (int)gg_align(gg_cdiv(a->K, want), 16);
             nsplit = (int)gg_cdiv(a->K, kps);
-            if (nsplit > 1 && (slabs = splitk_scratch((hipStream_t)stream)) != nullptr) { p.splits = nsplit; p.k_per_split = kps; }
+            if (nsplit > 1 && (slabs = splitk_scratch((hipStream_t)stream)) != nullptr) { p.splits = nsplit; p.k_per_split = kps; ++tl_splitk_uses; }
             else nsplit = 1;
         }
     }

@@ -16,6 +16,8 @@ struct Slot {
     hipGraphExec_t exec = nullptr;
     bool refused = false;          // capture / instantiation / a launch failed once: this key stays eager
     bool capturing = false;        // a thread is capturing this key right now (outside the lock): everybody else runs it eagerly meanwhile
+    bool wants_slabs = false;      // the key's eager run issued split-K GEMMs: its graph gets split-K slabs of its own
+    float* slabs = nullptr;
     uint64_t tick = 0;
 };
 std::mutex g_mu;
@@ -31,7 +33,8 @@ long g_wasted = 0;
 void drop(Slot& s) {
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
     if (s.graph) (void)hipGraphDestroy(s.graph);
-    s.exec = nullptr; s.graph = nullptr;
+    if (s.slabs) (void)hipFree(s.slabs);
+    s.exec = nullptr; s.graph = nullptr; s.slabs = nullptr;
 }
 int mode() {
     if (g_mode == -2) {
@@ -71,7 +74,13 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
         g_slots.back().tick = ++g_tick;
         ++g_eager;
         lk.unlock();
-        return body(stream);
+        const long uses0 = gg_gemm_f32_splitk_uses();
+        const int rc = body(stream);
+        if (gg_gemm_f32_splitk_uses() != uses0) {
+            lk.lock();
+            for (auto& c : g_slots) if (c.key == key.bytes) { c.wants_slabs = true; break; }
+        }
+        return rc;
     }
     s->tick = ++g_tick;
     if (s->refused) { ++g_eager; lk.unlock(); return body(stream); }
@@ -84,16 +93,20 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
         // again by key afterwards (the slot vector may have moved)
         static std::mutex cap_mu[16];
         const std::string skey = s->key;
+        const bool wants_slabs = s->wants_slabs;
         s->capturing = true;
         lk.unlock();
         hipGraph_t g = nullptr;
         hipGraphExec_t x = nullptr;
+        float* slabs = nullptr;
         bool ok = false;
+        if (wants_slabs && hipMalloc((void**)&slabs, gg_gemm_f32_splitk_bytes()) != hipSuccess) { (void)hipGetLastError(); slabs = nullptr; }
         {
             std::lock_guard<std::mutex> cl(cap_mu[dev & 15]);
             hipStream_t cap = nullptr;
             { std::lock_guard<std::mutex> l2(g_mu); cap = g_capture[dev]; }
             if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess) { std::lock_guard<std::mutex> l2(g_mu); g_capture[dev] = cap; }
+            if (cap && slabs) gg_gemm_f32_capture_scratch(cap, slabs);
             if (cap && hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int rc = body(cap);
                 const hipError_t ec = hipStreamEndCapture(cap, &g);
@@ -101,20 +114,23 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
                 // error fails again below with its own message
                 if (rc == 0 && ec == hipSuccess && g && hipGraphInstantiate(&x, g, nullptr, nullptr, 0) == hipSuccess && x) ok = true;
             }
+            if (cap) gg_gemm_f32_capture_scratch(cap, nullptr);
             if (!ok) { (void)hipGetLastError(); if (x) (void)hipGraphExecDestroy(x); if (g) (void)hipGraphDestroy(g); x = nullptr; g = nullptr; }
         }
+        if (!ok && slabs) { (void)hipFree(slabs); slabs = nullptr; }
         lk.lock();
         s = nullptr;
         for (auto& c : g_slots) if (c.key == skey) { s = &c; break; }
         if (!s) {                                          // evicted meanwhile
             if (x) (void)hipGraphExecDestroy(x);
             if (g) (void)hipGraphDestroy(g);
+            if (slabs) (void)hipFree(slabs);
             ++g_eager; lk.unlock();
             return body(stream);
         }
         s->capturing = false;
         if (!ok) { s->refused = true; ++g_eager; lk.unlock(); return body(stream); }
-        s->graph = g; s->exec = x;
+        s->graph = g; s->exec = x; s->slabs = slabs;
         ++g_captures;
     }
     if (hipGraphLaunch(s->exec, stream) != hipSuccess) {

@@ -18,3 +18,10 @@ bool gg_graph_wanted(bool launch_bound);
 // Runs `body(stream)` eagerly the first time a key is seen, captures it the second time and replays it afterwards.  `body` must only enqueue work on the
 // stream it is given (no synchronisation, no allocation, no host-side dependence on device results).
 int gg_graph_run(const GgGraphKey& key, hipStream_t stream, const std::function<int(hipStream_t)>& body);
+
+// gemm_f32.hip: the split-K form of gg_gemm_nt_f32 reduces through library-owned slabs.  A captured graph gets slabs of its own (so that a replay computes what
+// the eager call computed, and two graphs replayed on two streams share nothing): the cache watches whether a key's eager run used the form, allocates before
+// the capture, registers the buffer for the capture stream and frees it with the graph.
+long gg_gemm_f32_splitk_uses();
+size_t gg_gemm_f32_splitk_bytes();
+void gg_gemm_f32_capture_scratch(hipStream_t capture_stream, float* slabs);

@@ -8,7 +8,7 @@
  *     freed by the library.  Process-global state it does keep, all of it internal and none of it part of a result: the HIP-graph cache of
  *     gg_tinyvit_forward / _backward (captured graphs, one private capture stream per device, hit counters: gg_graph_stats reads them,
  *     gg_graph_clear() is the teardown and must run before the buffers a captured graph refers to are freed), the launch log of the profiling
- *     hooks (gg_prof_*: off unless enabled), and one lazily allocated 16 MiB split-K slab buffer per (device, stream) of gg_gemm_nt_f32;
+ *     hooks (gg_prof_*: off unless enabled), and one lazily allocated 16 MiB split-K slab buffer per (device, stream) of gg_gemm_nt_f32 (plus one per captured graph whose launches use the form);
  *   - `stream` is a hipStream_t; work is only enqueued, nothing here synchronises;
  *   - bf16 tensors are passed as void*; matrices are row-major with an explicit leading dimension
  *     in ELEMENTS; activations are NHWC / [tokens, channels].
@@ -248,7 +248,7 @@ int gg_gemm_nt_split3_ex(const GgSplit3Args* args, void* stream);
  * of the kernels above: f32 activations [tokens, channels], f32 MFMA (v_mfma_f32_16x16x4_f32 -- exact f32 products, f32
  * accumulation), erf GELU through an fp32-accurate Phi (gg_phi_f32: 1.2 ulp of 1).  GgTinyVitCfg.act_dtype = 1 runs the whole encoder on them. */
 int gg_gemm_nt_f32(const GgGemmArgs* args, void* stream);   /* all matrices f32; K, lda, ldb multiples of 4; args->split_k is ignored (the library splits a long contraction of a small launch itself, into slabs
-                                                               * it owns per (device, stream) -- never under stream capture, where the launch runs unsplit); the A2 (two-source) and BatchNorm-fused forms of GgGemmArgs are honoured (see below) */
+                                                               * it owns per (device, stream); under a caller's own stream capture the launch runs unsplit, the library's graph cache gives every captured graph slabs of its own); the A2 (two-source) and BatchNorm-fused forms of GgGemmArgs are honoured (see below) */
 int gg_gemm_tn_f32_splits(int M, int N, int K);
 int gg_gemm_tn_f32(const void* dY, int64_t ldy, const void* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale,
                    float* partials, int splits, void* stream);
