@@ -40,6 +40,7 @@ struct FlashParams {
     uint32_t rcp_ws, rcp_w2;          // ceil(2^20 / ws), ceil(2^20 / (2 ws - 1)): t / ws == (t * rcp_ws) >> 20 for every index these kernels form (checked on the host)
     uint32_t rcp_img, rcp_nwx;        // ceil(2^32 / windows per image), ceil(2^32 / windows per row) (0: divisor 1): window -> (image, row, column) in scalar arithmetic
     float neg_inv_scale;              // -1 / scale
+    int debug;                        // dev ablations (GG_ATTN_ABL under GG_DEV_SWITCHES): 1 = skip the main loop of the split kernels
 };
 // integer division by a launch constant without the ~30-instruction software divide (fp32 MFMA and VALU share the SIMD's issue: the divides of the
 // staging loops were most of the vector instructions of a 7 x 7 window's workgroup)
@@ -1109,6 +1110,8 @@ __global__ __launch_bounds__(NT ? (NT < 4 ? 256 : 64 * NT) : 1024) void flash_bw
     }
 }
 
+#include "attention_split.h"
+
 __global__ void flash_dbias_final_kernel(const float* __restrict__ rows, int nrows, int W, float* __restrict__ dbias) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W) return;
@@ -1147,6 +1150,7 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.nbpad = (int)gg_align(std::max(4, (2 * a->window_size - 1) * (2 * a->window_size - 1)), 4);      // expanded (signed-offset) bias table
     p.rcp_ws = p.rcp_w2 = p.rcp_img = p.rcp_nwx = 0;
     p.neg_inv_scale = -1.0f / p.scale;
+    { static const char* abl = gg_dev_env("GG_ATTN_ABL"); p.debug = abl ? atoi(abl) : 0; }
     {
         auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); };      // exact for numerators < 2^32 / d
         p.rcp_img = magic(p.nWx * p.nWy); p.rcp_nwx = magic(p.nWx);
@@ -1197,6 +1201,26 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
     FlashParams p;
     GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_fwd"));
     GG_CHECK(a->out && (a->ldo & 3) == 0 && ((uintptr_t)a->out & 15) == 0, "gg_attention_flash_fwd: bad out");
+    // fp32 storage, head dim 32, windows of 4 / 9 / 13 tiles (7 x 7, 12 x 12, 14 x 14): the products run as split-bf16 MFMAs (attention_split.h)
+    static const bool nosplit = gg_dev_env("GG_ATTN_NO_SPLIT") != nullptr;
+    const int nt16 = p.npad / 16;
+    if (dtype == 1 && a->head_dim == 32 && !nosplit && (nt16 == 4 || nt16 == 9 || nt16 == 13)) {
+        const size_t lds = sp_lds_fwd(p);
+        GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 16.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
+        void (*kern)(FlashParams) = nt16 == 13 ? flash_fwd_split_kernel<13> : nt16 == 9 ? flash_fwd_split_kernel<9> : flash_fwd_split_kernel<4>;
+        if (lds > 64 * 1024) {
+            static bool raised[3] = {false, false, false};
+            const int ri = nt16 == 13 ? 0 : nt16 == 9 ? 1 : 2;
+            if (!raised[ri]) {
+                GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                         "gg_attention_flash_fwd: cannot raise the dynamic LDS limit of the split kernel");
+                raised[ri] = true;
+            }
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a->num_windows * a->num_heads)), dim3(64 * nt16), lds, (hipStream_t)stream, p);
+        GG_LAUNCH_CHECK();
+        return 0;
+    }
     const bool res = flash_resident(p, a->head_dim, false);
     const bool ftail = res && flash_fwd_tail(p);
     const dim3 grid((unsigned)(a->num_windows * a->num_heads * (res ? 1 : p.ntile))), block(res ? 64 * (ftail ? p.npad / 16 - 1 : std::min(16, p.npad / 16)) : 256);
@@ -1252,6 +1276,40 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     const size_t lds_q = flash_lds_fwd(p, a->head_dim, R), lds_kv = flash_lds_dkv(p, a->head_dim, R, p.dbias != nullptr);
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype ? 4.0 : 2.0;
+    {
+        // fp32 storage, head dim 32: the single-pass backward on split-bf16 MFMAs (attention_split.h)
+        static const bool nosplit = gg_dev_env("GG_ATTN_NO_SPLIT") != nullptr;
+        static const char* only = gg_dev_env("GG_ATTN_SPLIT_BWD_NT");            // dev: "4,13" -- tile counts that take the split backward
+        const int nt16 = p.npad / 16;
+        bool take = true;
+        if (only) { take = false; for (const char* c = only; *c; ++c) if (atoi(c) == nt16 && (c == only || c[-1] == ',')) take = true; }
+        if (dtype == 1 && a->head_dim == 32 && !nosplit && take && (nt16 == 4 || nt16 == 9 || nt16 == 13) && sp_lds_bwd(p, p.dbias != nullptr) <= 160 * 1024) {
+            GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
+                    8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
+            const size_t lds = sp_lds_bwd(p, p.dbias != nullptr);
+            void (*kern)(FlashParams);
+            if (p.dbias) kern = nt16 == 13 ? flash_bwd_split_kernel<true, 13> : nt16 == 9 ? flash_bwd_split_kernel<true, 9> : flash_bwd_split_kernel<true, 4>;
+            else kern = nt16 == 13 ? flash_bwd_split_kernel<false, 13> : nt16 == 9 ? flash_bwd_split_kernel<false, 9> : flash_bwd_split_kernel<false, 4>;
+            if (lds > 64 * 1024) {
+                static bool raised[6] = {false, false, false, false, false, false};
+                const int ri = (p.dbias != nullptr) * 3 + (nt16 == 13 ? 0 : nt16 == 9 ? 1 : 2);
+                if (!raised[ri]) {
+                    GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                             "gg_attention_flash_bwd: cannot raise the dynamic LDS limit of the split kernel");
+                    raised[ri] = true;
+                }
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)(a->num_windows * a->num_heads)), dim3(64 * ((nt16 + 1) / 2)), lds, s, p);
+            if (p.dbias && p.dbias_part) {
+                const int Wd = p.nh * p.ws * p.ws;
+                const float* rows; int nrows;
+                gg_reduce_rows(p.dbias_part, a->num_windows, Wd, s, &rows, &nrows);
+                hipLaunchKernelGGL(flash_dbias_final_kernel, dim3((unsigned)gg_cdiv(Wd, 256)), dim3(256), 0, s, rows, nrows, Wd, p.dbias);
+            }
+            GG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (flash_fused_ok(p, a->head_dim, p.dbias != nullptr)) {
         // windows of at most 256 tokens: the single-pass kernel (no dS scratch, no second phase)
         GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
