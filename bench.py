@@ -157,7 +157,7 @@ def pmc_traffic(precision):
     from geoguessr_ai_amd import _lib as L
     if precision not in ("fp32", "bf16"):
         return None, None, None                  # (the fp32_split experiment has no PMC passes)
-    names = [f"r{r:02d}_hbm_traffic_pmc_{precision}.json" for r in (4, 3, 2)] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
+    names = [f"r{r:02d}_hbm_traffic_pmc_{precision}.json" for r in (5, 4, 3, 2)] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:

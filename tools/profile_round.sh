@@ -3,7 +3,7 @@
 # (the box has no .git: pass the commit in; the JSON also records the sha256 of the kernel sources, which bench.py checks)
 set -x
 P=${1:-fp32}
-TAG=${2:-r04_$P}
+TAG=${2:-r05_$P}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 cd $R
