@@ -960,9 +960,19 @@ extern "C" int gg_attention_expand_bias(const float* table, int num_heads, int w
 // beyond 256 tokens per window (tiny_vit_21m_384 / _512 stage 2, CLIP ViT-L/14-336) a score row no longer fits a wave's registers:
 // those shapes run on the online-softmax kernels of attention_flash.hip (bias from the compact f32 table)
 static bool attn_use_flash(const GgAttnArgs* a) { return a && (a->tokens_per_window > 256 || a->window_size > 16); }
+// The BACKWARD of 12 x 12 / 14 x 14 windows of head dim 32 also leaves this file: attention_split.h's single-pass kernel (bf16 storage, one plane) reads q, k, v,
+// dO, O once and forms five products instead of the seven of attn_bwd_kernel's two phases, and gathers the bias from the compact f32 table in LDS instead of
+// reading the expanded [heads][Np][Np] table from memory twice per workgroup (590 against 756 us per 14 x 14 layer; the expanded table's re-reads were the
+// 1.49x HBM traffic of round 4's bf16 attention class).  7 x 7 windows stay on the grouped kernels below, every forward stays here.
+static bool attn_use_split_bwd(const GgAttnArgs* a) {
+    static const bool nosplit = gg_dev_env("GG_ATTN_NO_SPLIT") != nullptr;
+    if (!a || nosplit || a->head_dim != 32 || a->window_size <= 0) return false;
+    const int nt16 = (a->tokens_per_window + 15) / 16;
+    return (nt16 == 13 || nt16 == 9) && (!a->bias || a->bias_table);
+}
 extern "C" int gg_attention_fwd(const GgAttnArgs* a, void* stream) {
     if (attn_use_flash(a)) {
-        GG_CHECK(!a->bias || a->bias_table, "gg_attention_fwd: windows of more than 256 tokens take the bias as bias_table (compact f32)");
+        GG_CHECK(!a->bias || a->bias_table, "gg_attention_fwd: this window shape takes the bias as bias_table (compact f32)");
         return gg_attention_flash_fwd(a, 0, stream);
     }
     AttnParams p;
@@ -1014,8 +1024,8 @@ extern "C" int gg_attention_fwd_f16(const GgAttnArgs* a, void* stream) {
     return 0;
 }
 extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
-    if (attn_use_flash(a)) {
-        GG_CHECK(!a->bias || a->bias_table, "gg_attention_bwd: windows of more than 256 tokens take the bias as bias_table (compact f32)");
+    if (attn_use_flash(a) || attn_use_split_bwd(a)) {
+        GG_CHECK(!a->bias || a->bias_table, "gg_attention_bwd: this window shape takes the bias as bias_table (compact f32)");
         return gg_attention_flash_bwd(a, 0, stream);
     }
     AttnParams p;

@@ -1201,13 +1201,15 @@ extern "C" int gg_attention_flash_fwd(const GgAttnArgs* a, int dtype, void* stre
     FlashParams p;
     GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_fwd"));
     GG_CHECK(a->out && (a->ldo & 3) == 0 && ((uintptr_t)a->out & 15) == 0, "gg_attention_flash_fwd: bad out");
-    // fp32 storage, head dim 32, windows of 4 / 9 / 13 tiles (7 x 7, 12 x 12, 14 x 14): the products run as split-bf16 MFMAs (attention_split.h)
+    // fp32 storage, head dim 32, windows of 4 / 9 / 13 tiles (7 x 7, 12 x 12, 14 x 14): the products run as split-bf16 MFMAs (attention_split.h).  (The same
+    // kernel instantiated for bf16 storage -- one plane -- measured 403 us per 14 x 14 layer with a wave per strip and 497 us with two strips per wave, against
+    // 301 us of attention.hip's attn_fwd_kernel: the bf16 forward stays there.)
     static const bool nosplit = gg_dev_env("GG_ATTN_NO_SPLIT") != nullptr;
     const int nt16 = p.npad / 16;
     if (dtype == 1 && a->head_dim == 32 && !nosplit && (nt16 == 4 || nt16 == 9 || nt16 == 13)) {
-        const size_t lds = sp_lds_fwd(p);
+        const size_t lds = sp_lds_fwd(p, 3);
         GG_PROF(GG_CAT_ATTN, 4.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim, 16.0 * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
-        void (*kern)(FlashParams) = nt16 == 13 ? flash_fwd_split_kernel<13> : nt16 == 9 ? flash_fwd_split_kernel<9> : flash_fwd_split_kernel<4>;
+        void (*kern)(FlashParams) = nt16 == 13 ? flash_fwd_split_kernel<float, 3, 13> : nt16 == 9 ? flash_fwd_split_kernel<float, 3, 9> : flash_fwd_split_kernel<float, 3, 4>;
         if (lds > 64 * 1024) {
             static bool raised[3] = {false, false, false};
             const int ri = nt16 == 13 ? 0 : nt16 == 9 ? 1 : 2;
@@ -1277,22 +1279,30 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     hipStream_t s = (hipStream_t)stream;
     const double es = dtype ? 4.0 : 2.0;
     {
-        // fp32 storage, head dim 32: the single-pass backward on split-bf16 MFMAs (attention_split.h)
+        // head dim 32: the single-pass backward of attention_split.h (fp32 storage: split-bf16 products; bf16 storage: plain bf16 products)
         static const bool nosplit = gg_dev_env("GG_ATTN_NO_SPLIT") != nullptr;
         static const char* only = gg_dev_env("GG_ATTN_SPLIT_BWD_NT");            // dev: "4,13" -- tile counts that take the split backward
         const int nt16 = p.npad / 16;
+        const int npl = dtype == 1 ? 3 : 1;
         bool take = true;
         if (only) { take = false; for (const char* c = only; *c; ++c) if (atoi(c) == nt16 && (c == only || c[-1] == ',')) take = true; }
-        if (dtype == 1 && a->head_dim == 32 && !nosplit && take && (nt16 == 4 || nt16 == 9 || nt16 == 13) && sp_lds_bwd(p, p.dbias != nullptr) <= 160 * 1024) {
+        if ((dtype == 1 || dtype == 0) && a->head_dim == 32 && !nosplit && take && (nt16 == 4 || nt16 == 9 || nt16 == 13) && sp_lds_bwd(p, p.dbias != nullptr, npl) <= 160 * 1024) {
+            GG_CHECK(dtype == 1 || ((a->ld & 7) == 0 && (a->ldo & 7) == 0 && (a->lddo & 7) == 0 && ((a->q_off | a->k_off | a->v_off | a->head_stride) & 7) == 0),
+                     "gg_attention_flash_bwd: bf16 rows must be 16-byte aligned");
             GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,
                     8.0 * es * a->num_windows * a->num_heads * (double)p.N * a->head_dim, stream);
-            const size_t lds = sp_lds_bwd(p, p.dbias != nullptr);
+            const size_t lds = sp_lds_bwd(p, p.dbias != nullptr, npl);
             void (*kern)(FlashParams);
-            if (p.dbias) kern = nt16 == 13 ? flash_bwd_split_kernel<true, 13> : nt16 == 9 ? flash_bwd_split_kernel<true, 9> : flash_bwd_split_kernel<true, 4>;
-            else kern = nt16 == 13 ? flash_bwd_split_kernel<false, 13> : nt16 == 9 ? flash_bwd_split_kernel<false, 9> : flash_bwd_split_kernel<false, 4>;
+#define GG_SP_BWD(T_, N_)                                                                                                                     \
+    do {                                                                                                                                      \
+        if (p.dbias) kern = nt16 == 13 ? flash_bwd_split_kernel<T_, N_, true, 13> : nt16 == 9 ? flash_bwd_split_kernel<T_, N_, true, 9> : flash_bwd_split_kernel<T_, N_, true, 4>;      \
+        else kern = nt16 == 13 ? flash_bwd_split_kernel<T_, N_, false, 13> : nt16 == 9 ? flash_bwd_split_kernel<T_, N_, false, 9> : flash_bwd_split_kernel<T_, N_, false, 4>;        \
+    } while (0)
+            if (dtype == 1) GG_SP_BWD(float, 3); else GG_SP_BWD(bf16, 1);
+#undef GG_SP_BWD
             if (lds > 64 * 1024) {
-                static bool raised[6] = {false, false, false, false, false, false};
-                const int ri = (p.dbias != nullptr) * 3 + (nt16 == 13 ? 0 : nt16 == 9 ? 1 : 2);
+                static bool raised[12] = {};
+                const int ri = (dtype == 1 ? 0 : 6) + (p.dbias != nullptr) * 3 + (nt16 == 13 ? 0 : nt16 == 9 ? 1 : 2);
                 if (!raised[ri]) {
                     GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                              "gg_attention_flash_bwd: cannot raise the dynamic LDS limit of the split kernel");

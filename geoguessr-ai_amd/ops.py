@@ -566,6 +566,8 @@ def attention(qkv, *, num_windows, tokens_per_window, num_heads, head_dim, q_off
         L.check(L.lib().gg_attention_expand_bias(_p(bias, F32, "bias"), num_heads, window_size, a.scale, _p(full),
                                                  L.stream()), "gg_attention_expand_bias")
     a.bias = _p(full)
+    if bias is not None:
+        a.bias_table = _p(bias, F32, "bias")          # compact table: the resident-window kernels of 12 x 12 / 14 x 14 windows gather from it in LDS
     tokens = qkv.shape[0]
     if dout is None:
         out = torch.empty((tokens, num_heads * head_dim), dtype=qkv.dtype, device=qkv.device)

@@ -7,6 +7,12 @@ import ctypes as C
 import torch
 from geoguessr_ai_amd import _lib as L
 B = int(os.environ.get("B", "1024"))
+DT = torch.bfloat16 if os.environ.get("DT") == "bf16" else torch.float32
+CODE = 0 if DT == torch.bfloat16 else 1
+def FWD(a):
+    return L.lib().gg_attention_flash_fwd(C.byref(a), 1, L.stream()) if CODE else L.lib().gg_attention_fwd(C.byref(a), L.stream())
+def BWD(a):
+    return L.lib().gg_attention_flash_bwd(C.byref(a), 1, L.stream()) if CODE else L.lib().gg_attention_bwd(C.byref(a), L.stream())
 def timed(fn, n=5):
     for _ in range(2): fn()
     torch.cuda.synchronize()
@@ -23,7 +29,7 @@ def bias_full(table, ws):
 for name, res, ws, Cc, nh in [("s1", 28, 7, 192, 6), ("s2", 14, 14, 384, 12), ("s3", 7, 7, 576, 18)]:
     M, N = B * res * res, ws * ws
     g = torch.Generator(device="cuda").manual_seed(1)
-    qkv = torch.randn(M, 3 * Cc, device="cuda", generator=g); out = torch.empty(M, Cc, device="cuda"); dout = torch.randn(M, Cc, device="cuda", generator=g)
+    qkv = torch.randn(M, 3 * Cc, device="cuda", generator=g).to(DT); out = torch.empty(M, Cc, device="cuda", dtype=DT); dout = torch.randn(M, Cc, device="cuda", generator=g).to(DT)
     dqkv = torch.zeros_like(qkv); lse = torch.empty(M, nh, device="cuda"); table = torch.randn(nh, N, device="cuda", generator=g) * 0.3
     dbias = torch.zeros_like(table)
     a = L.AttnArgs()
@@ -31,10 +37,15 @@ for name, res, ws, Cc, nh in [("s1", 28, 7, 192, 6), ("s2", 14, 14, 384, 12), ("
     a.num_heads, a.num_windows, a.tokens_per_window = nh, B * (res // ws) ** 2, N
     a.window_size, a.map_h, a.map_w = ws, res, res
     a.bias_table = table.data_ptr(); a.scale = 32 ** -0.5
+    if not CODE:
+        Np = L.lib().gg_attention_padded_tokens(N)
+        full = torch.empty((nh, Np, Np), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().gg_attention_expand_bias(table.data_ptr(), nh, ws, C.c_float(a.scale), full.data_ptr(), L.stream()))
+        a.bias = full.data_ptr()
     a.out, a.ldo, a.lse = out.data_ptr(), Cc, lse.data_ptr()
-    L.check(L.lib().gg_attention_flash_fwd(C.byref(a), 1, L.stream()))
+    L.check(FWD(a))
     a.dout, a.lddo, a.dqkv = dout.data_ptr(), Cc, dqkv.data_ptr()
-    L.check(L.lib().gg_attention_flash_bwd(C.byref(a), 1, L.stream()))
+    L.check(BWD(a))
     torch.cuda.synchronize()
     # fp64 reference on the first and last image
     nW = res // ws
@@ -64,7 +75,7 @@ for name, res, ws, Cc, nh in [("s1", 28, 7, 192, 6), ("s2", 14, 14, 384, 12), ("
         for nm, lo in (("dq", 0), ("dk", 32), ("dv", 64)):
             gg_, rr_ = dgot.view(-1, nh, 96)[..., lo:lo + 32], dref.view(-1, nh, 96)[..., lo:lo + 32]
             errs.setdefault(nm, []).append(float((gg_ - rr_).norm() / rr_.norm()))
-    tf = timed(lambda: L.check(L.lib().gg_attention_flash_fwd(C.byref(a), 1, L.stream())))
-    tb = timed(lambda: L.check(L.lib().gg_attention_flash_bwd(C.byref(a), 1, L.stream())))
+    tf = timed(lambda: L.check(FWD(a)))
+    tb = timed(lambda: L.check(BWD(a)))
     fl = 4.0 * M * N * Cc
     print(f"{name} ws={ws}  fwd {tf*1e3:8.1f} us ({fl/tf/1e9:6.1f} TF/s)   bwd {tb*1e3:8.1f} us ({2.5*fl/tb/1e9:6.1f} TF/s)   rel-L2 vs fp64: out {max(errs['out']):.2e}  dqkv {max(errs['dqkv']):.2e} (dq {max(errs['dq']):.1e} dk {max(errs['dk']):.1e} dv {max(errs['dv']):.1e})", flush=True)
