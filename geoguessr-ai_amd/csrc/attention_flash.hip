@@ -40,6 +40,7 @@ struct FlashParams {
     uint32_t rcp_ws, rcp_w2;          // ceil(2^20 / ws), ceil(2^20 / (2 ws - 1)): t / ws == (t * rcp_ws) >> 20 for every index these kernels form (checked on the host)
     uint32_t rcp_img, rcp_nwx;        // ceil(2^32 / windows per image), ceil(2^32 / windows per row) (0: divisor 1): window -> (image, row, column) in scalar arithmetic
     float neg_inv_scale;              // -1 / scale
+    int round_bias;                   // bf16 storage, expanded bias table also given: the forward was attention.hip's (bias added as bf16(bias / scale)); the backward recomputes P with the same value
     int debug;                        // dev ablations (GG_ATTN_ABL under GG_DEV_SWITCHES): 1 = skip the main loop of the split kernels
 };
 // integer division by a launch constant without the ~30-instruction software divide (fp32 MFMA and VALU share the SIMD's issue: the divides of the
@@ -1151,6 +1152,7 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.rcp_ws = p.rcp_w2 = p.rcp_img = p.rcp_nwx = 0;
     p.neg_inv_scale = -1.0f / p.scale;
     { static const char* abl = gg_dev_env("GG_ATTN_ABL"); p.debug = abl ? atoi(abl) : 0; }
+    p.round_bias = (dtype == 0 && a->bias != nullptr) ? 1 : 0;
     {
         auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); };      // exact for numerators < 2^32 / d
         p.rcp_img = magic(p.nWx * p.nWy); p.rcp_nwx = magic(p.nWx);

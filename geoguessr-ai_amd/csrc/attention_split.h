@@ -281,8 +281,8 @@ __global__ __launch_bounds__(64 * ((NT + 1) / 2)) void flash_bwd_split_kernel(Fl
     // run the vector work of one product under the matrix work of another)
     if (has_bias) {
         fl_stage_bias(p, h, btab);
-        if constexpr (NPL == 1) {
-            // bf16 storage: the forward (attention.hip, expanded table) adds the bias as bf16(bias / scale) in the score accumulator; P is recomputed from the
+        if (NPL == 1 && p.round_bias) {
+            // bf16 storage, forward by attention.hip (expanded table: the bias enters the score accumulator as bf16(bias / scale)); P is recomputed from that
             // forward's lse, so the same rounded value goes here
             __syncthreads();
             for (int i = threadIdx.x; i < w2 * w2; i += blockDim.x) {

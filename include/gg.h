@@ -186,8 +186,11 @@ typedef struct GgAttnArgs {
     float* lse;                           /* f32 [tokens][num_heads] row log-sum-exp: forward writes (may be NULL), backward reads;
                                              backward also reads `out` (the forward result) */
     const float* bias_table;              /* COMPACT attention_biases f32 [num_heads][ws*ws] (index |dy|*ws+|dx|, timm's first-seen order)
-                                             or NULL: what the online-softmax kernels read (gg_attention_flash_*, and gg_attention_fwd/bwd
-                                             beyond 256 tokens per window, where `bias` is ignored) */
+                                             or NULL: what the online-softmax and resident-window kernels read (gg_attention_flash_*;
+                                             gg_attention_fwd/bwd beyond 256 tokens per window, where `bias` is ignored; gg_attention_bwd of
+                                             12 x 12 / 14 x 14 windows, which runs the single-pass backward).  A biased gg_attention_fwd/bwd call
+                                             therefore passes BOTH forms.  With both given and bf16 storage the backward recomputes P with the
+                                             value the expanded table holds, bf16(bias / scale), i.e. with the forward's */
     float* ds_scratch;                    /* optional (gg_attention_flash_bwd, windows beyond 256 tokens only -- see gg_attention_flash_single_pass): f32
                                              [gg_attention_flash_ds_scratch_floats(...)] = 4 * windows * heads * roundup16(tokens)^2 bytes (22 MB per image at
                                              CLIP ViT-L/14-336).  With it the dK/dV pass runs first and hands dS to the dQ pass, which then is ONE product
@@ -204,7 +207,9 @@ int gg_attention_bwd(const GgAttnArgs* args, void* stream);
 int gg_attention_fwd_f16(const GgAttnArgs* args, void* stream);
 /* Online-softmax (flash) form for ANY tokens_per_window (1024-token windows of the reference's default tiny_vit_21m_512, config.py:9;
  * 577 tokens of CLIP ViT-L/14-336, config.py:6) and for the reference-precision mode: dtype 0 = bf16, 1 = f32, 2 = fp16 (forward only) storage of
- * qkv / out / dout / dqkv; arithmetic is f32 MFMA either way.  window_size <= 32.  dbias_scratch (optional): f32
+ * qkv / out / dout / dqkv; arithmetic is f32-accurate either way: f32 MFMA, or -- fp32 storage, head dim 32, 7 x 7 / 12 x 12 / 14 x 14 windows --
+ * split products on the bf16 MFMA (x = x1 + x2 + x3 in bf16, six products per f32 product: DESIGN.md 5 has the error table); bf16 storage of those
+ * window shapes runs the same single-pass backward with plain bf16 products.  window_size <= 32.  dbias_scratch (optional): f32
  * [gg_attention_flash_dbias_rows(num_windows, tokens_per_window)][num_heads][ws*ws]. */
 int gg_attention_flash_fwd(const GgAttnArgs* args, int dtype, void* stream);
 int gg_attention_flash_bwd(const GgAttnArgs* args, int dtype, void* stream);
