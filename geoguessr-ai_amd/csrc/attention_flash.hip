@@ -41,7 +41,6 @@ struct FlashParams {
     uint32_t rcp_img, rcp_nwx;        // ceil(2^32 / windows per image), ceil(2^32 / windows per row) (0: divisor 1): window -> (image, row, column) in scalar arithmetic
     float neg_inv_scale;              // -1 / scale
     int round_bias;                   // bf16 storage, expanded bias table also given: the forward was attention.hip's (bias added as bf16(bias / scale)); the backward recomputes P with the same value
-    int debug;                        // dev ablations (GG_ATTN_ABL under GG_DEV_SWITCHES): 1 = skip the main loop of the split kernels
 };
 // integer division by a launch constant without the ~30-instruction software divide (fp32 MFMA and VALU share the SIMD's issue: the divides of the
 // staging loops were most of the vector instructions of a 7 x 7 window's workgroup)
@@ -1151,7 +1150,6 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.nbpad = (int)gg_align(std::max(4, (2 * a->window_size - 1) * (2 * a->window_size - 1)), 4);      // expanded (signed-offset) bias table
     p.rcp_ws = p.rcp_w2 = p.rcp_img = p.rcp_nwx = 0;
     p.neg_inv_scale = -1.0f / p.scale;
-    { static const char* abl = gg_dev_env("GG_ATTN_ABL"); p.debug = abl ? atoi(abl) : 0; }
     p.round_bias = (dtype == 0 && a->bias != nullptr) ? 1 : 0;
     {
         auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); };      // exact for numerators < 2^32 / d
@@ -1283,12 +1281,9 @@ extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stre
     {
         // head dim 32: the single-pass backward of attention_split.h (fp32 storage: split-bf16 products; bf16 storage: plain bf16 products)
         static const bool nosplit = gg_dev_env("GG_ATTN_NO_SPLIT") != nullptr;
-        static const char* only = gg_dev_env("GG_ATTN_SPLIT_BWD_NT");            // dev: "4,13" -- tile counts that take the split backward
         const int nt16 = p.npad / 16;
         const int npl = dtype == 1 ? 3 : 1;
-        bool take = true;
-        if (only) { take = false; for (const char* c = only; *c; ++c) if (atoi(c) == nt16 && (c == only || c[-1] == ',')) take = true; }
-        if ((dtype == 1 || dtype == 0) && a->head_dim == 32 && !nosplit && take && (nt16 == 4 || nt16 == 9 || nt16 == 13) && sp_lds_bwd(p, p.dbias != nullptr, npl) <= 160 * 1024) {
+        if ((dtype == 1 || dtype == 0) && a->head_dim == 32 && !nosplit && (nt16 == 4 || nt16 == 9 || nt16 == 13) && sp_lds_bwd(p, p.dbias != nullptr, npl) <= 160 * 1024) {
             GG_CHECK(dtype == 1 || ((a->ld & 7) == 0 && (a->ldo & 7) == 0 && (a->lddo & 7) == 0 && ((a->q_off | a->k_off | a->v_off | a->head_stride) & 7) == 0),
                      "gg_attention_flash_bwd: bf16 rows must be 16-byte aligned");
             GG_PROF(GG_CAT_ATTN, 10.0 * a->num_windows * a->num_heads * (double)p.N * p.N * a->head_dim,

@@ -140,23 +140,35 @@ __global__ __launch_bounds__(64 * NT) void flash_fwd_split_kernel(FlashParams p)
     const __amdgpu_buffer_rsrc_t rsQKV = fl_rsrc(reinterpret_cast<const T*>(p.qkv) + origin * p.ld, span * ldb);
     const __amdgpu_buffer_rsrc_t rsOUT = fl_rsrc(reinterpret_cast<T*>(p.out) + origin * p.ldo, span * ldob);
     const __amdgpu_buffer_rsrc_t rsLSE = fl_rsrc(p.lse ? p.lse + origin * p.nh : nullptr, p.lse ? span * p.nh * 4 : 0);
-    if (has_bias) fl_stage_bias(p, h, btab);
-    sp_stage<T, NPL>(p, rsQKV, ldb, (p.k_off + hc) * ES, Kp, R);
-    sp_stage<T, NPL>(p, rsQKV, ldb, (p.v_off + hc) * ES, Vp, R);
-    if (has_bias) fl_stage_coords(p, 0, klin, R);
-    const float sc2 = p.scale * 1.4426950408889634f;
-    __syncthreads();
+    // every global load of the workgroup is issued before anything waits: the K / V rows (R * 4 eight-column chunks over 64 NT threads: one each) and the
+    // wave's query strip; the bias table and the coordinates are staged under their latency
+    const int srow = threadIdx.x >> 2, sch = threadIdx.x & 3;                     // (R * 4 == 64 * NT: one chunk per thread)
+    const int soff = srow < p.N ? fl_tokrel(p, srow) * ldb + (hc + sch * 8) * ES : FL_OOB;
+    f32x4 klo, khi, vlo, vhi, qlo, qhi;
+    SpLd8<T>::load(rsQKV, soff == FL_OOB ? FL_OOB : soff + p.k_off * ES, klo, khi);
+    SpLd8<T>::load(rsQKV, soff == FL_OOB ? FL_OOB : soff + p.v_off * ES, vlo, vhi);
     const int strip = wave;
-    if (strip * 16 >= p.N) return;                                  // (a strip of padding only: nothing to do; no barrier follows)
     // this wave's query strip: 8 contraction slots d = 8 lg .. of query row lr, split once
     const int qi = strip * 16 + lr;
     const bool qok = qi < p.N;
     const int qrel = qok ? fl_tokrel(p, qi) : 0;
-    const int qo = qok ? qrel * ldb + (p.q_off + hc + 8 * lg) * ES : FL_OOB;
-    f32x4 qlo, qhi;
-    SpLd8<T>::load(rsQKV, qo, qlo, qhi);
+    SpLd8<T>::load(rsQKV, qok ? qrel * ldb + (p.q_off + hc + 8 * lg) * ES : FL_OOB, qlo, qhi);
+    if (has_bias) fl_stage_bias(p, h, btab);
+    if (has_bias) fl_stage_coords(p, 0, klin, R);
+    {
+        const Sp8 k3 = sp_split8<NPL>(klo, khi), v3 = sp_split8<NPL>(vlo, vhi);
+        const int o = sp_off(srow, sch);
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+            *reinterpret_cast<bf16x8*>(Kp + pl * PL + o) = k3.p[pl];
+            *reinterpret_cast<bf16x8*>(Vp + pl * PL + o) = v3.p[pl];
+        }
+    }
     const Sp8 q3 = sp_split8<NPL>(qlo, qhi);
     const int qlin = has_bias ? fl_lin4(p, min(qi, p.N - 1)) + 4 * (p.ws - 1) * 2 * p.ws : 0;
+    const float sc2 = p.scale * 1.4426950408889634f;
+    __syncthreads();
+    if (strip * 16 >= p.N) return;                                  // (a strip of padding only: nothing to do; no barrier follows)
     // S^T[key][q] tiles: lane holds keys 16 kt + 4 lg + r of query lr
     f32x4 st[NT];
     float mx = -INFINITY;
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(64 * ((NT + 1) / 2)) void flash_bwd_split_kernel(Fl
     __syncthreads();
 
     int pair = wave;
-    for (int t = 0; t < ((p.debug & 1) ? 0 : NP); ++t) {
+    for (int t = 0; t < NP; ++t) {
         f32x4 pr[2][2], ds[2][2];                                  // [query tile of the pair][strip]; lane holds [q = 16 tile + 4 lg + r][key = lr]
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
