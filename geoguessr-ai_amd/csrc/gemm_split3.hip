@@ -17,6 +17,7 @@
 // Epilogues: the Linear family of the model (bias, GELU with a saved pre-activation, rowscale + residual, x GELU'), results as f32 and / or as planes for the
 // next split GEMM.  Used by csrc/tinyvit.hip in the fp32_split mode (frozen C >= 384 blocks); tools/bench_split3.py times it next to the f32-MFMA GEMM.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 #include "../../include/gg.h"
@@ -25,6 +26,7 @@ namespace {
 
 struct Split3Params {
     const bf16* A; int64_t lda, plane_a;      // planes a1, a2, a3 at A + i * plane_a (elements)
+    const float* Af; int64_t ldaf;            // ... or the f32 operand itself (gemm_nt_split3a_kernel splits it while it is staged)
     const bf16* B; int64_t ldb, plane_b;
     float* C; int64_t ldc;             // f32 result (may be null when only planes are wanted)
     const float* bias;
@@ -452,6 +454,169 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
     }
 }
 
+// ------------------------------------------------------------------------------------------- A as f32, split while it is staged
+// The form every Linear of the model can take: the activation operand stays the f32 tensor its producer wrote (no plane copy in HBM: 6 instead of 4 bytes per
+// element, and a producer epilogue that has to write it), only the WEIGHT comes as cached planes.  Tile 256 x 128, 4 x 2 waves of 64 x 64, k-stage 32, 2-stage
+// LDS ring of 72 KB as above.  B planes by LDS-DMA.  A: a thread loads one f32x4 of four rows per stage (8 lanes cover the 128 bytes = one cache line of a
+// row), TWO stages ahead of its use, and -- one stage ahead -- splits it into three bf16x4 (20 vector instructions, which ride under the 96 MFMAs of the
+// running stage: the bf16 MFMA does not share its issue with the vector ALU the way the f32 MFMA does) and writes them into the ring with the fragment
+// reads' chunk swizzle.  In-order VMEM completion makes one counted wait per stage enough: at the top of stage s the queue holds A(s+1), B(s), A(s+2);
+// vmcnt(4) leaves only A(s+2) in flight.
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
+    constexpr int BM = 256, BN = 128, WN = 2, NW = 8, TM = 4, TN = 4;
+    constexpr int TA = BM * S3_SK, TB = BN * S3_SK, STAGE = 3 * (TA + TB);
+    extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    const int tm = bid / p.tilesN, tn = bid % p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+    const unsigned rowsA = (unsigned)min(p.M - m0, BM), rowsB = (unsigned)min(p.N - n0, BN);
+    // B planes: 16-row slices by LDS-DMA (one per plane and wave: 8 slices = 128 rows), source chunk = slot ^ ((row >> 2) & 3)
+    const int dchunk = (lane & 3) ^ (lane >> 4);
+    __amdgpu_buffer_rsrc_t rsB[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        rsB[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + i * p.plane_b + (int64_t)n0 * p.ldb), 0, (int)(rowsB * (unsigned)p.ldb * 2u), 0x00020000);
+    const unsigned voffB = (unsigned)(wave * 16 + (lane >> 2)) * (unsigned)p.ldb * 2u + dchunk * 16u;
+    // A: thread -> f32x4 number kq of rows (tid >> 3) + 64 j; its bf16x4 goes to chunk (kq >> 1) ^ ((row >> 2) & 3), half kq & 1 of the plane row
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Af + (int64_t)m0 * p.ldaf), 0, (int)(rowsA * (unsigned)p.ldaf * 4u), 0x00020000);
+    const int kq = threadIdx.x & 7, arow = threadIdx.x >> 3;
+    unsigned voffA[4];
+    int ldsA[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = arow + 64 * j;
+        voffA[j] = (unsigned)row * (unsigned)p.ldaf * 4u + kq * 16u;
+        ldsA[j] = row * S3_SK + (((kq >> 1) ^ ((row >> 2) & 3)) << 3) + ((kq & 1) << 2);
+    }
+    auto issue_b = [&](int st, bf16* base) {
+        const int k0 = st * S3_SK;
+        const bool kin = k0 + dchunk * 8 < p.K;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[i], (__attribute__((address_space(3))) void*)(base + 3 * TA + i * TB + wave * 512), 16,
+                                                     (int)(kin ? voffB : 0xFFFFFFF0u), k0 * 2, 0, 0);
+    };
+    auto load_a = [&](int st, f32x4 (&r)[4]) {
+        const int k0 = st * S3_SK;
+        const bool kin = k0 + kq * 4 < p.K;                     // K % 4 == 0: an f32x4 is entirely inside or outside
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voffA[j] : 0xFFFFFFF0u), k0 * 4, 0));
+    };
+    auto split_store = [&](const f32x4 (&r)[4], bf16* base) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 p1, p2, p3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bf16 a = (bf16)r[j][e];
+                const float r1 = r[j][e] - (float)a;
+                const bf16 b2 = (bf16)r1;
+                p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+            }
+            *reinterpret_cast<bf16x4*>(base + ldsA[j]) = p1;
+            *reinterpret_cast<bf16x4*>(base + TA + ldsA[j]) = p2;
+            *reinterpret_cast<bf16x4*>(base + 2 * TA + ldsA[j]) = p3;
+        }
+    };
+    const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
+    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = 3 * TA + (wn * 64 + lr) * S3_SK + fslot;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + S3_SK - 1) / S3_SK;
+    f32x4 ra[2][4];
+    issue_b(0, s3mem);
+    load_a(0, ra[0]);
+    load_a(1, ra[1]);
+    wait_vm<4>();                                                   // B(0) and A(0)
+    split_store(ra[0], s3mem);
+    load_a(2, ra[0]);
+    // Every stage runs the same branch-free code, written in the order it should issue: 24 quads of MFMAs (one n-tile x four m-tiles of one plane product), and
+    // between them, in 12 slices, the split of A(s + 1) (two elements per slice), its plane writes and the reload of the freed registers with A(s + 3); the
+    // fragment reads of the second and third product group ride under the first.  A scheduling barrier after every quad keeps that order (left to itself the
+    // compiler puts all vector work in front of one solid run of 96 MFMAs: ~700 cycles per stage with the matrix pipe idle; sched_group_barrier patterns of
+    // this size were honoured for one build and dropped by the next).  Stages beyond K are harmless: their loads / DMAs fail the k-mask (no memory access,
+    // zeros), their plane writes go to a slot nobody reads; so the per-stage VMEM count is constant and one counted wait serves all.
+    auto stage = [&](int s, f32x4 (&rnext)[4]) {
+        // rnext holds A(s + 1) (loaded two stages ago); after its split it is reloaded with A(s + 3)
+        bf16* const cur = s3mem + (s & 1) * STAGE;
+        bf16* const nxt = s3mem + ((s + 1) & 1) * STAGE;
+        wait_vm<4>();                                               // B(s) and A(s + 1) have landed; A(s + 2) may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own plane writes of A(s) are done ...
+        __builtin_amdgcn_s_barrier();                               // ... everybody's are, and every wave has read its fragments of stage s - 1: that slot is free
+        issue_b(s + 1, nxt);
+        bf16x8 xf[3][TM], wf[3][TN];
+        auto rd_a1 = [&](int pl, int mt) { xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * TA + a_off + mt * 16 * S3_SK); };
+        auto rd_b1 = [&](int pl, int nt) { wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + pl * TB + b_off + nt * 16 * S3_SK); };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { rd_a1(0, t); rd_b1(2, t); }
+        const int k3 = (s + 3) * S3_SK;
+        const bool kin3 = k3 + kq * 4 < p.K;
+        bf16x4 p1, p2, p3;
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // small terms first: (a1 b3 + a2 b2 + a3 b1), (a1 b2 + a2 b1), a1 b1
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB[g]][nt], xf[PA[g]][mt], acc[nt][mt], 0, 0, 0);
+                const int qi = g * 4 + nt;
+                if (g == 0 && nt < 3) {                             // a2, b2 under the first product group
+                    if (nt == 0) { rd_a1(1, 0); rd_a1(1, 1); rd_a1(1, 2); }
+                    if (nt == 1) { rd_a1(1, 3); rd_b1(1, 0); rd_b1(1, 1); }
+                    if (nt == 2) { rd_b1(1, 2); rd_b1(1, 3); }
+                }
+                if (g == 1 && nt < 3) {                             // a3, b1 under the second
+                    if (nt == 0) { rd_a1(2, 0); rd_a1(2, 1); rd_a1(2, 2); }
+                    if (nt == 1) { rd_a1(2, 3); rd_b1(0, 0); rd_b1(0, 1); }
+                    if (nt == 2) { rd_b1(0, 2); rd_b1(0, 3); }
+                }
+                if (qi & 1) {
+                    const int ms = qi >> 1, jj = ms / 3, part = ms % 3;
+                    if (part < 2) {
+#pragma unroll
+                        for (int e = 2 * part; e < 2 * part + 2; ++e) {
+                            const bf16 a = (bf16)rnext[jj][e];
+                            const float r1 = rnext[jj][e] - (float)a;
+                            const bf16 b2 = (bf16)r1;
+                            p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+                        }
+                    } else {
+                        *reinterpret_cast<bf16x4*>(nxt + ldsA[jj]) = p1;
+                        *reinterpret_cast<bf16x4*>(nxt + TA + ldsA[jj]) = p2;
+                        *reinterpret_cast<bf16x4*>(nxt + 2 * TA + ldsA[jj]) = p3;
+                        rnext[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin3 ? voffA[jj] : 0xFFFFFFF0u), k3 * 4, 0));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int s = 0; s < nk; s += 2) {
+        stage(s, ra[1]);
+        if (s + 1 < nk) stage(s + 1, ra[0]);
+    }
+    wait_vm<0>();                                                   // (the masked loads / DMAs of the stages beyond K: nothing may land in the ring after this)
+    // epilogue: the accumulators cross the idle ring to whole rows
+    float* Ct = reinterpret_cast<float*>(s3mem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+            *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 64 + nt * 16 + lg * 4) = acc[nt][mt];
+    __syncthreads();
+    split3_epilogue_rows<BM, BN, 512>(p, Ct, m0, n0);
+}
+
 // x (f32, [rows][ldx]) -> planes [3][rows][cols] bf16: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx, bf16* __restrict__ out) {
     const int64_t n4 = rows * (cols / 4);
@@ -528,7 +693,7 @@ extern "C" int gg_gemm_nt_split3_ex(const GgSplit3Args* a, void* stream) {
     GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3: rowscale needs rows_per_scale");
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3: act and dact_preact are exclusive");
     Split3Params p;
-    p.A = (const bf16*)a->a_planes; p.lda = a->lda; p.plane_a = (int64_t)a->M * a->lda;
+    p.A = (const bf16*)a->a_planes; p.lda = a->lda; p.plane_a = (int64_t)a->M * a->lda; p.Af = nullptr; p.ldaf = 0;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
     p.act = a->act; p.preact = a->preact; p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = a->residual; p.ldr = a->ldr;
@@ -542,4 +707,36 @@ extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* 
     memset(&a, 0, sizeof(a));
     a.a_planes = a_planes; a.lda = lda; a.b_planes = b_planes; a.ldb = ldb; a.C = C; a.ldc = ldc; a.M = M; a.N = N; a.K = K; a.bias = bias;
     return gg_gemm_nt_split3_ex(&a, stream);
+}
+
+// A as f32 [M][lda] (split in the kernel's loader), B as planes b_plane_stride elements apart (0: N * ldb): args->a_planes / lda are ignored
+extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, void* stream) {
+    GG_CHECK(a && A && a->b_planes && (a->C || a->c_planes) && a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_split3_af32: null pointer / bad shape");
+    GG_CHECK((a->K & 7) == 0 && (lda & 3) == 0 && (a->ldb & 7) == 0 && lda >= a->K && a->ldb >= a->K, "gg_gemm_nt_split3_af32: K %% 8, lda %% 4, ldb %% 8, ld >= K");
+    GG_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)a->b_planes & 15) == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->c_planes & 7) == 0, "gg_gemm_nt_split3_af32: alignment");
+    GG_CHECK((int64_t)256 * lda * 4 < ((int64_t)1 << 31) && (int64_t)256 * a->ldb * 2 < ((int64_t)1 << 31), "gg_gemm_nt_split3_af32: row pitch too large");
+    GG_CHECK((!a->C || a->ldc >= a->N) && (!a->c_planes || a->ldp >= a->N) && (!a->residual || a->ldr >= a->N), "gg_gemm_nt_split3_af32: leading dimension too small");
+    GG_CHECK((!a->preact && !a->dact_preact) || a->ldc >= a->N, "gg_gemm_nt_split3_af32: preact / dact_preact use ldc");
+    GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3_af32: rowscale needs rows_per_scale");
+    GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3_af32: act and dact_preact are exclusive");
+    Split3Params p;
+    p.A = nullptr; p.lda = 0; p.plane_a = 0; p.Af = A; p.ldaf = lda;
+    p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = b_plane_stride > 0 ? b_plane_stride : (int64_t)a->N * a->ldb;
+    p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
+    p.act = a->act; p.preact = a->preact; p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = a->residual; p.ldr = a->ldr;
+    p.dact_preact = a->dact_preact; p.dact = a->dact; p.c_planes = (bf16*)a->c_planes; p.ldp = a->ldp;
+    p.tilesM = (int)gg_cdiv(p.M, 256); p.tilesN = (int)gg_cdiv(p.N, 128);
+    static bool raised = false;
+    if (!raised) {
+        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_split3a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                 "gg_gemm_nt_split3_af32: cannot raise the dynamic LDS limit");
+        raised = true;
+    }
+    const double mn = (double)p.M * p.N;
+    GG_PROF(GG_CAT_GEMM, 2.0 * p.M * (double)p.N * p.K,
+            4.0 * (double)p.M * p.K + 6.0 * (double)p.N * p.K + 4.0 * mn * ((p.C != nullptr) + (p.preact != nullptr) + (p.residual != nullptr) + (p.dact_preact != nullptr)) +
+                (p.c_planes ? 6.0 * mn : 0.0), stream);
+    hipLaunchKernelGGL(gemm_nt_split3a_kernel, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(512), (size_t)2 * 3 * (256 + 128) * S3_SK * sizeof(bf16), (hipStream_t)stream, p);
+    GG_LAUNCH_CHECK();
+    return 0;
 }

@@ -34,7 +34,10 @@ struct Model {
     GgTinyVitCfg cfg;
     int es = 2;             // bytes per activation / cached-weight element: 2 (bf16) or 4 (f32, reference-precision mode)
     bool f32 = false;
-    bool split = false;     // act_dtype 3 ("fp32_split", experiment): f32 storage; the Linears of frozen C >= 384 blocks run as fp32-accurate products of three bf16 planes per operand
+    bool split = false;     // act_dtype 3 ("fp32_split"): f32 storage and arithmetic; the Linears of the transformer blocks (forward and data gradients) run as fp32-accurate
+                            // split products on the bf16 MFMA -- the activation operand split while the kernel stages it, the weight as cached planes
+    struct PlaneOf { int64_t w, planes; int rows, ld; };      // cached f32 matrix at wcache offset w ([rows][ld]) -> its bf16 planes [3][rows][ld]
+    std::vector<PlaneOf> plane_of;
     std::vector<TensorInfo> tensors;
     int64_t param_floats = 0, buffer_floats = 0, wcache_bytes = 0;
     int num_counters = 0;
@@ -152,12 +155,13 @@ static int build_model(const GgTinyVitCfg* cfg, Model& m) {
             bn = p + ".mlp.fc2.bias";
             make_dense(m, b.fc2, p + ".mlp.fc2.weight", C, hid, 1, &bn, false);
             make_convbn_dw(m, b.local, p + ".local_conv", C);
-            if (m.split && C >= 384) {      // weight planes of the Linears the split mode runs (K = 192 shapes gain 7 %: not worth the plane traffic)
-                b.qkv.wn3 = wc_alloc(m, (int64_t)3 * b.qkv.N * b.qkv.Kp * 2);
-                b.fc1.wn3 = wc_alloc(m, (int64_t)3 * b.fc1.N * b.fc1.Kp * 2);
-                b.fc1.wt3 = wc_alloc(m, (int64_t)3 * b.fc1.Kp * b.fc1.Np * 2);
-                b.fc2.wn3 = wc_alloc(m, (int64_t)3 * b.fc2.N * b.fc2.Kp * 2);
-                b.fc2.wt3 = wc_alloc(m, (int64_t)3 * b.fc2.Kp * b.fc2.Np * 2);
+            if (m.split) {      // bf16 planes of W and W^T of the block's four Linears (B operand of gg_gemm_nt_split3_af32: forward and data gradients)
+                for (DenseW* w : {&b.qkv, &b.proj, &b.fc1, &b.fc2}) {
+                    w->wn3 = wc_alloc(m, (int64_t)3 * w->N * w->Kp * 2);
+                    w->wt3 = wc_alloc(m, (int64_t)3 * w->Kp * w->Np * 2);
+                    m.plane_of.push_back({w->wn, w->wn3, w->N, w->Kp});
+                    m.plane_of.push_back({w->wt, w->wt3, w->Kp, w->Np});
+                }
             }
         }
     }
@@ -244,7 +248,6 @@ struct Layout {
     // scratch
     int64_t statpart, bnscratch, lnscratch, colsum, splitk, attn_ds = -1, G[5];
     int64_t foldw, foldb;        // BatchNorm-backward-folded dgrad weights bf16 [Cin][2*Cout] and bias f32 [Cin]
-    int64_t pl_a = -1, pl_h = -1;   // fp32_split mode: bf16 planes [3][M][C] (LayerNorm output / gradient stream) and [3][M][4C] (GELU(fc1) / its gradient) of the current block
     int64_t gbytes;
 };
 
@@ -344,17 +347,6 @@ static void plan_build(const Model& m, int B, Plan& p, Layout& L) {
         }
         res = st.res;
         Mprev = M;
-    }
-    if (m.split) {
-        int64_t pa = 0, ph = 0;
-        for (int s2 = 0; s2 < 3; ++s2) {
-            const StageL& st2 = m.stages[s2];
-            if (st2.C < 384) continue;
-            const int64_t M2 = (int64_t)B * st2.res * st2.res;
-            pa = std::max(pa, 3 * M2 * st2.C * 2);
-            ph = std::max(ph, 3 * M2 * (int64_t)(st2.C * c.mlp_ratio) * 2);
-        }
-        if (pa > 0) { L.pl_a = p.alloc("scratch.planes_a", pa, false); L.pl_h = p.alloc("scratch.planes_h", ph, false); }
     }
     L.pooled = p.alloc("head.pooled", (int64_t)B * d[3] * 4, false);
     L.mean_h = p.alloc("head.mean", (int64_t)B * 4, false);
@@ -479,12 +471,6 @@ struct Exec {
     const float* P(int t) const { return params + m->tensors[t].offset; }
     float* Gd(int t) const { return grads + m->tensors[t].offset; }
     bool tr(int t) const { return trainable == nullptr || trainable[t] != 0; }
-    // fp32_split mode: this block's qkv / fc1 / fc2 (forward) and fc2 / fc1 dgrads run as split-bf16 products -- frozen blocks only (a weight gradient would
-    // need the f32 operands the split path never writes), channel counts whose planes exist
-    // (inference: every such block -- nothing is kept for a backward pass)
-    bool split_block(const BlockL& l) const {
-        return m->split && l.qkv.wn3 >= 0 && (!training || (trainable && !tr(l.qkv.t_w) && !tr(l.fc1.t_w) && !tr(l.fc2.t_w)));
-    }
     void exec_init() {
         f32 = m->f32;
         // reference-precision mode: the same fusions where an f32 twin exists (MBConv / PatchMerging forward, the stride-1 data gradients, the
@@ -534,23 +520,26 @@ static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const act_t* dz, co
 static int gemm(const Exec& e, const act_t* A, int64_t lda, const act_t* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
                 const float* bias = nullptr, int act = 0, void* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
                 const act_t* residual = nullptr, float* colstats = nullptr, const act_t* dact_pre = nullptr, int dact = 0) {
+    if (e.m->split && !colstats && M >= 256 && (K & 7) == 0 && (lda & 3) == 0) {
+        // fp32_split mode: a Linear whose weight operand has cached planes runs as a split product (A = the f32 activation itself, split in the kernel's loader)
+        const int64_t off = reinterpret_cast<const char*>(Bm) - e.wc;
+        for (const Model::PlaneOf& po : e.m->plane_of) {
+            if (po.w != off) continue;
+            if (po.ld != ldb || po.rows < N) break;
+            GgSplit3Args g;
+            memset(&g, 0, sizeof(g));
+            g.b_planes = e.wc + po.planes; g.ldb = ldb; g.M = (int)M; g.N = N; g.K = K; g.C = (float*)C; g.ldc = ldc;
+            g.bias = bias; g.act = act; g.preact = (float*)preact; g.rowscale = rowscale; g.rows_per_scale = rps; g.residual = (const float*)residual; g.ldr = ldc;
+            g.dact_preact = (const float*)dact_pre; g.dact = dact;
+            return gg_gemm_nt_split3_af32(&g, (const float*)A, lda, (int64_t)po.rows * po.ld, e.st);
+        }
+    }
     GgGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.B = Bm; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = (int)M; g.N = N; g.K = K;
     g.bias = bias; g.act = act; g.preact = preact; g.rowscale = rowscale; g.rows_per_scale = rps;
     g.residual = residual; g.ldr = ldc; g.colstats = colstats; g.dact_preact = dact_pre; g.dact = dact;
     return e.f32 ? gg_gemm_nt_f32(&g, e.st) : gg_gemm_nt(&g, e.st);
-}
-
-// fp32_split mode: C (f32, optional) / c_planes (optional) = epilogue(A planes . B planes^T)
-static int split3(const Exec& e, const void* a_planes, int64_t lda, const void* b_planes, int64_t ldb, float* C, int64_t ldc, void* c_planes, int64_t ldp, int64_t M, int N,
-                  int K, const float* bias = nullptr, int act = 0, float* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
-                  const float* residual = nullptr, const float* dact_pre = nullptr, int dact = 0) {
-    GgSplit3Args g;
-    memset(&g, 0, sizeof(g));
-    g.a_planes = a_planes; g.lda = lda; g.b_planes = b_planes; g.ldb = ldb; g.M = (int)M; g.N = N; g.K = K; g.C = C; g.ldc = ldc; g.c_planes = c_planes; g.ldp = ldp;
-    g.bias = bias; g.act = act; g.preact = preact; g.rowscale = rowscale; g.rows_per_scale = rps; g.residual = residual; g.ldr = ldc; g.dact_preact = dact_pre; g.dact = dact;
-    return gg_gemm_nt_split3_ex(&g, e.st);
 }
 
 // BatchNorm statistics for a ConvNorm whose producer wrote `nparts` partial rows into statpart
@@ -695,23 +684,14 @@ static int forward_impl(Exec& e, const float* x, float* out) {
             const float* s1 = e.training ? e.dropv(slot) : nullptr;
             const float* s2 = e.training ? e.dropv(slot + 1) : nullptr;
             slot += 2;
-            const bool sp = e.split_block(l);
-            if (sp) {       // norm1 leaves as three bf16 planes, qkv = their fp32-accurate product with the weight planes
-                GG_TRY(gg_layernorm_fwd_split3((const float*)e.A(a.x0), e.P(l.ln1.t_g), e.P(l.ln1.t_b), M, C, c.ln_eps, e.A(L.pl_a), e.F(a.mean1), e.F(a.rstd1), e.st));
-                GG_TRY(split3(e, e.A(L.pl_a), C, e.wc + l.qkv.wn3, l.qkv.Kp, (float*)e.A(a.qkv), 3 * C, nullptr, 0, M, 3 * C, l.qkv.Kp, e.P(l.qkv.t_b)));
-            } else {
             GG_TRY(gg_layernorm_fwd(e.A(a.x0), e.f32, e.P(l.ln1.t_g), e.P(l.ln1.t_b), M, C, c.ln_eps, e.A(a.a), e.f32, e.F(a.mean1), e.F(a.rstd1), e.st));
             GG_TRY(gemm(e, e.A(a.a), C, e.Wn(l.qkv), l.qkv.Kp, e.A(a.qkv), 3 * C, M, 3 * C, l.qkv.Kp, e.P(l.qkv.t_b)));
-            }
             GgAttnArgs at;
             attn_args(e, st, l, a, B, at);
             GG_TRY(e.f32 ? gg_attention_flash_fwd(&at, 1, e.st) : gg_attention_fwd(&at, e.st));
             GG_TRY(gemm(e, e.A(a.o), C, e.Wn(l.proj), l.proj.Kp, e.A(a.x1), C, M, C, l.proj.Kp, e.P(l.proj.t_b), 0, nullptr, s1, rps, e.A(a.x0)));
             GG_TRY(conv_dw_fwd(e, l.local, a.local, e.A(a.x1), B, st.res, st.res, 1));
-            if (sp) {                                   // norm2 (with local_conv's BatchNorm apply on its load) leaves as planes
-                GG_TRY(gg_layernorm_fwd_bn_split3((const float*)e.A(a.local.y), e.F(a.local.stat), e.P(l.local.bn.t_g), e.P(l.local.bn.t_b), (float*)e.A(a.x2),
-                                                  e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(L.pl_a), e.F(a.mean2), e.F(a.rstd2), e.st));
-            } else if (C <= 640 && e.f32 && e.fuse_lnbn) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
+            if (C <= 640 && e.f32 && e.fuse_lnbn) {      // BatchNorm apply of local_conv rides on norm2's load (x2 = the residual stream is written there)
                 GG_TRY(gg_layernorm_fwd_bn_f32((const float*)e.A(a.local.y), e.F(a.local.stat), e.P(l.local.bn.t_g), e.P(l.local.bn.t_b), (float*)e.A(a.x2),
                                                e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, (float*)e.A(a.b), e.F(a.mean2), e.F(a.rstd2), e.st));
             } else if (C <= 640 && !e.f32) {
@@ -721,16 +701,9 @@ static int forward_impl(Exec& e, const float* x, float* out) {
                 GG_TRY(bn_apply(e, l.local.bn, a.local, M, GG_ACT_NONE, e.A(a.x2)));
                 GG_TRY(gg_layernorm_fwd(e.A(a.x2), e.f32, e.P(l.ln2.t_g), e.P(l.ln2.t_b), M, C, c.ln_eps, e.A(a.b), e.f32, e.F(a.mean2), e.F(a.rstd2), e.st));
             }
-            if (sp) {       // fc1: GELU(h) leaves as planes only (the f32 pre-activation is kept for backward), fc2 consumes them
-                GG_TRY(split3(e, e.A(L.pl_a), C, e.wc + l.fc1.wn3, l.fc1.Kp, nullptr, hid, e.A(L.pl_h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU,
-                              e.training ? (float*)e.A(a.hpre) : nullptr));
-                GG_TRY(split3(e, e.A(L.pl_h), hid, e.wc + l.fc2.wn3, l.fc2.Kp, (float*)e.A(a.x3), C, nullptr, 0, M, C, l.fc2.Kp, e.P(l.fc2.t_b), 0, nullptr, s2, rps,
-                              (const float*)e.A(a.x2)));
-            } else {
             GG_TRY(gemm(e, e.A(a.b), C, e.Wn(l.fc1), l.fc1.Kp, e.A(a.h), hid, M, hid, l.fc1.Kp, e.P(l.fc1.t_b), GG_ACT_GELU,
                         e.training ? (void*)e.A(a.hpre) : nullptr));
             GG_TRY(gemm(e, e.A(a.h), hid, e.Wn(l.fc2), l.fc2.Kp, e.A(a.x3), C, M, C, l.fc2.Kp, e.P(l.fc2.t_b), 0, nullptr, s2, rps, e.A(a.x2)));
-            }
             prev = a.x3;
         }
         if (st.blocks.empty()) prev = ma.out;
@@ -907,14 +880,6 @@ static int backward_impl(Exec& e, const float* d_out) {
             act_t* t_a = (dx == G0) ? G1 : G0;    // scratch distinct from dx
             act_t* t_b = G2; act_t* t_c = G3; act_t* t_d = G4;
             // dh = (s2*dx) . W2  * gelu'(hpre)                      [M, hid]
-            const bool sp = e.split_block(l);
-            if (sp) {
-                // fp32_split: the gradient stream is split into planes (one pass), dh leaves the first product as planes only and feeds the second
-                GG_TRY(gg_split3_bf16((const float*)dx, M, C, C, e.A(L.pl_a), e.st));
-                GG_TRY(split3(e, e.A(L.pl_a), C, e.wc + l.fc2.wt3, l.fc2.Np, nullptr, hid, e.A(L.pl_h), hid, M, hid, C, nullptr, 0, nullptr, s2, rps, nullptr,
-                              (const float*)e.A(a.hpre), GG_ACT_GELU));
-                GG_TRY(split3(e, e.A(L.pl_h), hid, e.wc + l.fc1.wt3, l.fc1.Np, (float*)t_a, C, nullptr, 0, M, C, hid));
-            } else {
             GG_TRY(gemm(e, dx, C, e.Wt(l.fc2), l.fc2.Np, t_b, hid, M, hid, C, nullptr, 0, nullptr, s2, rps, nullptr, nullptr, e.A(a.hpre), GG_ACT_GELU));
             if (e.tr(l.fc2.t_w)) {
                 GG_TRY(dense_wgrad(e, l.fc2, e.A(a.h), hid, dx, C, M, s2, rps, t_c, t_d, false));
@@ -922,7 +887,6 @@ static int backward_impl(Exec& e, const float* d_out) {
             }
             // db = dh . W1                                           [M, C]
             GG_TRY(gemm(e, t_b, hid, e.Wt(l.fc1), l.fc1.Np, t_a, C, M, C, hid));
-            }
             if (e.tr(l.fc1.t_w)) {
                 GG_TRY(dense_wgrad(e, l.fc1, e.A(a.b), C, t_b, hid, M, nullptr, 0, t_c, t_d, false));
                 GG_TRY(bias_grad(e, l.fc1.t_b, t_b, hid, M, hid, nullptr, 0));

@@ -247,6 +247,9 @@ typedef struct {
     const float* dact_preact; int dact;     /* v = acc * act'(dact_preact[m][n]) */
 } GgSplit3Args;
 int gg_gemm_nt_split3_ex(const GgSplit3Args* args, void* stream);
+/* the same with the A operand as the f32 tensor itself ([M][lda], split into its three bf16 terms while the kernel stages it: no plane copy of an
+ * activation in HBM; args->a_planes / lda are ignored) and the weight as cached planes: the form every Linear of the fp32 model can take. */
+int gg_gemm_nt_split3_af32(const GgSplit3Args* args, const float* A, int64_t lda, int64_t b_plane_stride /* elements between the weight's planes; 0: N * ldb */, void* stream);
 
 /* ---------------------------------------------------------------- reference-precision (fp32) mode
  * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins
