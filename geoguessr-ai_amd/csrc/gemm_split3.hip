@@ -617,6 +617,151 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     split3_epilogue_rows<BM, BN, 512>(p, Ct, m0, n0);
 }
 
+// The same product on a 128 x 128 tile with FOUR waves (2 x 2 of 64 x 64) and 72 KB of LDS, so that TWO workgroups share a CU: with one 144 KB workgroup per CU
+// nothing hides a tile's prologue and -- worse -- its epilogue (the GELU / GELU' epilogues of fc1 / the fc2 data gradient are 8 us of vector work per 256 x 128
+// tile next to 11 us of MFMAs at K = 384: in the model those launches ran 20-45 % slower than the bias-only shape).  LDS: the A planes single-buffered (24 KB:
+// a wave reads ALL its A fragments of a stage, a second barrier frees the buffer, and the split of A(s + 1) is written into it under the stage's MFMAs), the B
+// planes double-buffered by LDS-DMA (2 x 24 KB).  Everything else as above.
+__global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
+    constexpr int BM = 128, BN = 128, WN = 2, TM = 4, TN = 4;
+    constexpr int TA = BM * S3_SK, TB = BN * S3_SK;
+    extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
+    bf16* const Abuf = s3mem;                                      // [3][TA]
+    bf16* const Bbuf = s3mem + 3 * TA;                             // [2][3][TB]
+    const int tiles = p.tilesM * p.tilesN;
+    const int bid = gg_xcd_remap(blockIdx.x, tiles);
+    const int tm = bid / p.tilesN, tn = bid % p.tilesN;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+    const unsigned rowsA = (unsigned)min(p.M - m0, BM), rowsB = (unsigned)min(p.N - n0, BN);
+    const int dchunk = (lane & 3) ^ (lane >> 4);
+    __amdgpu_buffer_rsrc_t rsB[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        rsB[i] = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + i * p.plane_b + (int64_t)n0 * p.ldb), 0, (int)(rowsB * (unsigned)p.ldb * 2u), 0x00020000);
+    unsigned voffB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) voffB[j] = (unsigned)((wave + 4 * j) * 16 + (lane >> 2)) * (unsigned)p.ldb * 2u + dchunk * 16u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Af + (int64_t)m0 * p.ldaf), 0, (int)(rowsA * (unsigned)p.ldaf * 4u), 0x00020000);
+    const int kq = threadIdx.x & 7, arow = threadIdx.x >> 3;
+    unsigned voffA[4];
+    int ldsA[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = arow + 32 * j;
+        voffA[j] = (unsigned)row * (unsigned)p.ldaf * 4u + kq * 16u;
+        ldsA[j] = row * S3_SK + (((kq >> 1) ^ ((row >> 2) & 3)) << 3) + ((kq & 1) << 2);
+    }
+    auto issue_b = [&](int st) {
+        bf16* const base = Bbuf + (st & 1) * 3 * TB;
+        const int k0 = st * S3_SK;
+        const bool kin = k0 + dchunk * 8 < p.K;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[i], (__attribute__((address_space(3))) void*)(base + i * TB + (wave + 4 * j) * 512), 16,
+                                                         (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
+    };
+    auto load_a = [&](int st, f32x4 (&r)[4]) {
+        const int k0 = st * S3_SK;
+        const bool kin = k0 + kq * 4 < p.K;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin ? voffA[j] : 0xFFFFFFF0u), k0 * 4, 0));
+    };
+    auto split2 = [&](const f32x4& v, int e0, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+#pragma unroll
+        for (int e = e0; e < e0 + 2; ++e) {
+            const bf16 a = (bf16)v[e];
+            const float r1 = v[e] - (float)a;
+            const bf16 b2 = (bf16)r1;
+            p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+        }
+    };
+    const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
+    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = (wn * 64 + lr) * S3_SK + fslot;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = (p.K + S3_SK - 1) / S3_SK;
+    f32x4 ra[2][4];
+    issue_b(0);
+    load_a(0, ra[0]);
+    load_a(1, ra[1]);
+    wait_vm<4>();                                                   // B(0) and A(0)
+    {
+        bf16x4 p1, p2, p3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            split2(ra[0][j], 0, p1, p2, p3); split2(ra[0][j], 2, p1, p2, p3);
+            *reinterpret_cast<bf16x4*>(Abuf + ldsA[j]) = p1; *reinterpret_cast<bf16x4*>(Abuf + TA + ldsA[j]) = p2; *reinterpret_cast<bf16x4*>(Abuf + 2 * TA + ldsA[j]) = p3;
+        }
+    }
+    load_a(2, ra[0]);
+    auto stage = [&](int s, f32x4 (&rnext)[4]) {
+        const bf16* const curB = Bbuf + (s & 1) * 3 * TB;
+        wait_vm<4>();                                               // B(s) and A(s + 1) have landed; A(s + 2) may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own plane writes of A(s) are done ...
+        __builtin_amdgcn_s_barrier();                               // ... everybody's are; everybody's B(s) is there; every wave is past its B reads of stage s - 1
+        issue_b(s + 1);
+        bf16x8 xf[3][TM], wf[3][TN];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int mt = 0; mt < TM; ++mt) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(Abuf + pl * TA + a_off + mt * 16 * S3_SK);
+        auto rd_b1 = [&](int pl, int nt) { wf[pl][nt] = *reinterpret_cast<const bf16x8*>(curB + pl * TB + b_off + nt * 16 * S3_SK); };
+#pragma unroll
+        for (int t = 0; t < 4; ++t) rd_b1(2, t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the twelve A fragments (and b3) are in registers ...
+        __builtin_amdgcn_s_barrier();                               // ... everybody's are: the A buffer is free for the planes of A(s + 1)
+        const int k3 = (s + 3) * S3_SK;
+        const bool kin3 = k3 + kq * 4 < p.K;
+        bf16x4 p1, p2, p3;
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < TN; ++nt) {
+#pragma unroll
+                for (int mt = 0; mt < TM; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB[g]][nt], xf[PA[g]][mt], acc[nt][mt], 0, 0, 0);
+                const int qi = g * 4 + nt;
+                if (g == 0 && nt < 2) { rd_b1(1, 2 * nt); rd_b1(1, 2 * nt + 1); }      // b2 under the first product group
+                if (g == 1 && nt < 2) { rd_b1(0, 2 * nt); rd_b1(0, 2 * nt + 1); }      // b1 under the second
+                if (qi & 1) {
+                    const int ms = qi >> 1, jj = ms / 3, part = ms % 3;
+                    if (part < 2) split2(rnext[jj], 2 * part, p1, p2, p3);
+                    else {
+                        *reinterpret_cast<bf16x4*>(Abuf + ldsA[jj]) = p1;
+                        *reinterpret_cast<bf16x4*>(Abuf + TA + ldsA[jj]) = p2;
+                        *reinterpret_cast<bf16x4*>(Abuf + 2 * TA + ldsA[jj]) = p3;
+                        rnext[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)(kin3 ? voffA[jj] : 0xFFFFFFF0u), k3 * 4, 0));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int s = 0; s < nk; s += 2) {
+        stage(s, ra[1]);
+        if (s + 1 < nk) stage(s + 1, ra[0]);
+    }
+    wait_vm<0>();
+    float* Ct = reinterpret_cast<float*>(s3mem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+            *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 64 + nt * 16 + lg * 4) = acc[nt][mt];
+    __syncthreads();
+    split3_epilogue_rows<BM, BN, 256>(p, Ct, m0, n0);
+}
+
 // x (f32, [rows][ldx]) -> planes [3][rows][cols] bf16: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx, bf16* __restrict__ out) {
     const int64_t n4 = rows * (cols / 4);
@@ -725,18 +870,24 @@ extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
     p.act = a->act; p.preact = a->preact; p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = a->residual; p.ldr = a->ldr;
     p.dact_preact = a->dact_preact; p.dact = a->dact; p.c_planes = (bf16*)a->c_planes; p.ldp = a->ldp;
-    p.tilesM = (int)gg_cdiv(p.M, 256); p.tilesN = (int)gg_cdiv(p.N, 128);
-    static bool raised = false;
-    if (!raised) {
-        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_split3a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+    // 256 x 128 (one 144 KB workgroup per CU) from K = 384 on; 128 x 128 (two per CU) for the short contractions of stage 1, where a tile lives only 6 stages and
+    // the second workgroup hides its prologue / epilogue (K = 192: 1.30 x against 1.22 x the f32-MFMA GEMM; at K >= 384 the big tile wins by 1-2 %)
+    static const char* tenv = gg_dev_env("GG_SPLIT3A_TILE");      // dev: 256 / 128 forces one form
+    const bool big = tenv ? atoi(tenv) == 256 : p.K >= 384;
+    p.tilesM = (int)gg_cdiv(p.M, big ? 256 : 128); p.tilesN = (int)gg_cdiv(p.N, 128);
+    void (*kern)(Split3Params) = big ? gemm_nt_split3a_kernel : gemm_nt_split3b_kernel;
+    const size_t lds = big ? (size_t)2 * 3 * (256 + 128) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * 128) * S3_SK * sizeof(bf16);
+    static bool raised[2] = {false, false};
+    if (!raised[big]) {
+        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "gg_gemm_nt_split3_af32: cannot raise the dynamic LDS limit");
-        raised = true;
+        raised[big] = true;
     }
     const double mn = (double)p.M * p.N;
     GG_PROF(GG_CAT_GEMM, 2.0 * p.M * (double)p.N * p.K,
             4.0 * (double)p.M * p.K + 6.0 * (double)p.N * p.K + 4.0 * mn * ((p.C != nullptr) + (p.preact != nullptr) + (p.residual != nullptr) + (p.dact_preact != nullptr)) +
                 (p.c_planes ? 6.0 * mn : 0.0), stream);
-    hipLaunchKernelGGL(gemm_nt_split3a_kernel, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(512), (size_t)2 * 3 * (256 + 128) * S3_SK * sizeof(bf16), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(big ? 512 : 256), lds, (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
