@@ -423,9 +423,10 @@ typedef struct GgTinyVitCfg {
     int act_dtype;       /* 0: bf16 activations + bf16 MFMA operands (fp32 accumulate / statistics / master weights);
                             1: reference-precision mode -- f32 activations, f32 MFMA (v_mfma_f32_16x16x4_f32), erf GELU at fp32 accuracy (1.2 ulp): the
                                arithmetic of the reference's own torch fp32 forward / backward;
-                            3: "fp32_split" (EXPERIMENT): mode 1's storage and kernels, except that norm1 -> qkv, norm2 -> fc1 -> fc2 and the
-                               fc2 / fc1 dgrads of FROZEN blocks with C >= 384 run as fp32-accurate products of three bf16 planes per operand
-                               (gg_gemm_nt_split3: error below the f32 MFMA GEMM's, 1.2-1.4 x its speed) */
+                            3: "fp32_split" (DESIGN.md 5): mode 1's storage and kernels, except that the four Linears of every transformer block (qkv, proj,
+                               fc1, fc2: forward and data gradients) run as fp32-accurate SPLIT products on the bf16 MFMA -- the f32 activation operand is
+                               split into three bf16 terms while the GEMM stages it (gg_gemm_nt_split3_af32), the weight's terms are cached planes; error
+                               against fp64 below the f32 MFMA GEMM's, 1.15-1.5 x its speed.  Weight gradients, the conv stages and everything else as mode 1 */
     int features_only;   /* 1: models/tinyvit.py:38-46,139-143 (timm features_only=True): the output is the global-average-pooled
                                last feature map, head.norm is not applied (its parameters stay in the table, unused) */
 } GgTinyVitCfg;

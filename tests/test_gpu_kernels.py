@@ -734,6 +734,61 @@ def test_split3_gemm_epilogues_match_the_f32_gemm(ops):
     assert rel(out2, got.double() @ W2.double().T) < 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,lda", [(300, 200, 96, 96), (4099, 384, 384, 400), (1000, 136, 712, 712), (257, 1153, 1536, 1536), (256, 128, 8, 8)])
+def test_split3_gemm_with_f32_activation_operand(ops, M, N, K, lda):
+    """gg_gemm_nt_split3_af32 (the fp32_split mode's Linear): A is the f32 activation itself, split into its three bf16 terms while the kernel stages it; the
+    weight comes as cached planes.  Both tile forms (K < 384: 128 x 128, two workgroups per CU; else 256 x 128) on ragged shapes, a K that is not a multiple
+    of the 32-element stage, a strided A: the result is BIT-IDENTICAL to the plane-fed kernel on pre-split planes of the same A (same products, same order),
+    f32-accurate against fp64, and the epilogue family (bias + GELU + pre-activation copy; row scale + residual; x GELU') matches gg_gemm_nt_f32."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    Afull = torch.randn(M, lda, generator=g).cuda()
+    A = Afull[:, :K]
+    B = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda(); res = torch.randn(M, N, generator=g).cuda(); pre = torch.randn(M, N, generator=g).cuda()
+    rps = 49
+    scale = (torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float().cuda() / 0.7
+
+    def planes(x):
+        x = x.contiguous()
+        out = torch.empty((3,) + tuple(x.shape), dtype=torch.bfloat16, device="cuda")
+        L.check(L.lib().gg_split3_bf16(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), out.data_ptr(), L.stream()), "gg_split3_bf16")
+        return out
+    Ap, Bp = planes(A), planes(B)
+
+    def run(**kw):
+        a = L.Split3Args()
+        a.b_planes, a.ldb, a.M, a.N, a.K = Bp.data_ptr(), K, M, N, K
+        out = torch.empty(M, N, device="cuda"); a.C, a.ldc = out.data_ptr(), N
+        keep = []
+        for k, v in kw.items():
+            if torch.is_tensor(v):
+                keep.append(v); setattr(a, k, v.data_ptr())
+            else:
+                setattr(a, k, v)
+        L.check(L.lib().gg_gemm_nt_split3_af32(C.byref(a), Afull.data_ptr(), lda, 0, L.stream()), "gg_gemm_nt_split3_af32")
+        return out
+    got = run(bias=bias)
+    fed = torch.empty(M, N, device="cuda")
+    L.check(L.lib().gg_gemm_nt_split3(Ap.data_ptr(), K, Bp.data_ptr(), K, fed.data_ptr(), N, M, N, K, bias.data_ptr(), L.stream()), "gg_gemm_nt_split3")
+    assert torch.equal(got, fed)
+    ref = A.double() @ B.double().T + bias.double()
+    e = float((got.double() - ref).norm() / ref.norm())
+    e32 = float((ops.gemm_nt(A.contiguous(), B, bias=bias).double() - ref).norm() / ref.norm())
+    assert e < 1e-6 and e < 1.5 * e32 + 1e-7, (e, e32)
+    rel = lambda x, y: float((x.double() - y.double()).norm() / y.double().norm())
+    Ac = A.contiguous()
+    pre_out = torch.empty(M, N, device="cuda")
+    got = run(bias=bias, act=1, preact=pre_out)
+    r, r_pre = ops.gemm_nt(Ac, B, bias=bias, act="gelu", preact=True)
+    assert rel(got, r) < 1e-5 and rel(pre_out, r_pre) < 1e-5
+    got = run(bias=bias, rowscale=scale, rows_per_scale=rps, residual=res, ldr=N)
+    assert rel(got, ops.gemm_nt(Ac, B, bias=bias, rowscale=scale, rows_per_scale=rps, residual=res)) < 1e-5
+    got = run(dact_preact=pre, dact=1, rowscale=scale, rows_per_scale=rps)
+    assert rel(got, ops.gemm_nt(Ac, B, dact_preact=pre, dact="gelu", rowscale=scale, rows_per_scale=rps)) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os
