@@ -463,6 +463,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
 // reads' chunk swizzle.  In-order VMEM completion makes one counted wait per stage enough: at the top of stage s the queue holds A(s+1), B(s), A(s+2);
 // vmcnt(4) leaves only A(s+2) in flight.
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int ABL>
 __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     constexpr int BM = 256, BN = 128, WN = 2, NW = 8, TM = 4, TN = 4;
     constexpr int TA = BM * S3_SK, TB = BN * S3_SK, STAGE = 3 * (TA + TB);
@@ -551,10 +552,16 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
         wait_vm<4>();                                               // B(s) and A(s + 1) have landed; A(s + 2) may be in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own plane writes of A(s) are done ...
         __builtin_amdgcn_s_barrier();                               // ... everybody's are, and every wave has read its fragments of stage s - 1: that slot is free
-        issue_b(s + 1, nxt);
+        if (!(ABL & 8)) issue_b(s + 1, nxt);
         bf16x8 xf[3][TM], wf[3][TN];
-        auto rd_a1 = [&](int pl, int mt) { xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * TA + a_off + mt * 16 * S3_SK); };
-        auto rd_b1 = [&](int pl, int nt) { wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + pl * TB + b_off + nt * 16 * S3_SK); };
+        if (ABL & 2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { xf[pl][t] = __builtin_bit_cast(bf16x8, acc[0][t]); wf[pl][t] = __builtin_bit_cast(bf16x8, acc[1][t]); }
+        }
+        auto rd_a1 = [&](int pl, int mt) { if (!(ABL & 2)) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * TA + a_off + mt * 16 * S3_SK); };
+        auto rd_b1 = [&](int pl, int nt) { if (!(ABL & 2)) wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + pl * TB + b_off + nt * 16 * S3_SK); };
 #pragma unroll
         for (int t = 0; t < 4; ++t) { rd_a1(0, t); rd_b1(2, t); }
         const int k3 = (s + 3) * S3_SK;
@@ -566,7 +573,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
 #pragma unroll
             for (int nt = 0; nt < TN; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < TM; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB[g]][nt], xf[PA[g]][mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < TM; ++mt) {
+                    if (!(ABL & 1)) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB[g]][nt], xf[PA[g]][mt], acc[nt][mt], 0, 0, 0);
+                    else { acc[nt][mt][0] += (float)wf[PB[g]][nt][0]; acc[nt][mt][1] += (float)xf[PA[g]][mt][0]; }
+                }
                 const int qi = g * 4 + nt;
                 if (g == 0 && nt < 3) {                             // a2, b2 under the first product group
                     if (nt == 0) { rd_a1(1, 0); rd_a1(1, 1); rd_a1(1, 2); }
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
                     if (nt == 1) { rd_a1(2, 3); rd_b1(0, 0); rd_b1(0, 1); }
                     if (nt == 2) { rd_b1(0, 2); rd_b1(0, 3); }
                 }
-                if (qi & 1) {
+                if ((qi & 1) && !(ABL & 4)) {
                     const int ms = qi >> 1, jj = ms / 3, part = ms % 3;
                     if (part < 2) {
 #pragma unroll
@@ -875,10 +885,13 @@ extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int
     static const char* tenv = gg_dev_env("GG_SPLIT3A_TILE");      // dev: 256 / 128 forces one form
     const bool big = tenv ? atoi(tenv) == 256 : p.K >= 384;
     p.tilesM = (int)gg_cdiv(p.M, big ? 256 : 128); p.tilesN = (int)gg_cdiv(p.N, 128);
-    void (*kern)(Split3Params) = big ? gemm_nt_split3a_kernel : gemm_nt_split3b_kernel;
+    static const char* aenv = gg_dev_env("GG_SPLIT3A_ABL");      // dev ablations of the 256 x 128 form (results are garbage): 1 no MFMA, 2 no fragment reads, 4 no A path, 8 no B DMA
+    const int abl = aenv ? atoi(aenv) : 0;
+    void (*kern)(Split3Params) = !big ? gemm_nt_split3b_kernel : abl == 1 ? gemm_nt_split3a_kernel<1> : abl == 2 ? gemm_nt_split3a_kernel<2> : abl == 4 ? gemm_nt_split3a_kernel<4> :
+                                 abl == 8 ? gemm_nt_split3a_kernel<8> : abl == 6 ? gemm_nt_split3a_kernel<6> : gemm_nt_split3a_kernel<0>;
     const size_t lds = big ? (size_t)2 * 3 * (256 + 128) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * 128) * S3_SK * sizeof(bf16);
     static bool raised[2] = {false, false};
-    if (!raised[big]) {
+    if (!raised[big] || abl) {
         GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "gg_gemm_nt_split3_af32: cannot raise the dynamic LDS limit");
         raised[big] = true;

@@ -513,13 +513,15 @@ def test_fp32_mode_train_step_matches_fp32_oracle(centroids, model_name, N, unfr
     _grad_table(case, 2e-3, label)
 
 
-@pytest.mark.parametrize("model_name,N", [("tiny_vit_21m_224", 4), ("tiny_vit_21m_224", 1), ("tiny_vit_21m_384", 1)])
-def test_fp32_split_mode_passes_the_fp32_gate(centroids, model_name, N):
-    """The gate of the "fp32_split" experiment (f32 storage; norm1 -> qkv, norm2 -> fc1 -> fc2 and the fc2 / fc1 dgrads of frozen C >= 384 blocks as
-    fp32-accurate products of three bf16 planes per operand): the SAME assertions at the SAME tolerances as the fp32 mode's training-step test --
-    per-stage taps <= 2e-4, embedding 1e-4, loss 1e-5, every gradient tensor 2e-3 -- under the reference freeze policy (the mode only touches frozen blocks)."""
-    case = _train_step_case(model_name, "fp32_split", N, centroids, False, seed=11, drop_path_rate=0.1)
-    label = f"fp32_split {model_name} N={N} ref-freeze"
+@pytest.mark.parametrize("model_name,N,unfrozen", [("tiny_vit_21m_224", 4, False), ("tiny_vit_21m_224", 1, False), ("tiny_vit_21m_384", 1, False), ("tiny_vit_5m_224", 3, True),
+                                                   ("tiny_vit_11m_224", 2, True)])
+def test_fp32_split_mode_passes_the_fp32_gate(centroids, model_name, N, unfrozen):
+    """The gate of the "fp32_split" mode (f32 storage; the four Linears of every transformer block -- forward and data gradients, frozen or trainable -- as
+    fp32-accurate split products on the bf16 MFMA, the f32 activation split inside the GEMM's loader): the SAME assertions at the SAME tolerances as the
+    fp32 mode's training-step test -- per-stage taps <= 2e-4, embedding 1e-4, loss 1e-5, every gradient tensor 2e-3 -- under the reference freeze policy
+    (stage 3 trainable: its weight gradients stay f32 TN GEMMs fed by split-product data gradients) and with every parameter trainable."""
+    case = _train_step_case(model_name, "fp32_split", N, centroids, unfrozen, seed=11, drop_path_rate=0.1)
+    label = f"fp32_split {model_name} N={N} {'unfrozen' if unfrozen else 'ref-freeze'}"
     _compare_taps(case["bb"], case["cfg"], case["taps"], 4 * N, F32, 2e-4, label)
     emb = case["out"].embedding.detach().cpu()
     e_abs = float((emb - case["emb_o"]).abs().max())
