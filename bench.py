@@ -155,8 +155,6 @@ def pmc_traffic(precision):
     measurement of the same workload.  The file records the sha256 of the kernel sources it was measured on: when the running tree differs the
     figure is still reported but marked ``stale``.  -> (bytes or None, info dict, per-class table or None)."""
     from geoguessr_ai_amd import _lib as L
-    if precision not in ("fp32", "bf16"):
-        return None, None, None                  # (the fp32_split experiment has no PMC passes)
     names = [f"r{r:02d}_hbm_traffic_pmc_{precision}.json" for r in (5, 4, 3, 2)] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
     for name in names:
         try:
