@@ -138,14 +138,17 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
             }
         };
         if (p.preact) st8(p.preact, p.ldc, v);
+        // (the packed forms: GELU / GELU' on two lanes of a v_pk_* instruction -- the scalar forms were a third of these launches' time at K = 192)
         if (p.dact_preact) {
             float t[8];
             ld8(p.dact_preact, p.ldc, t);
+            const f32x4 g0 = gg_act_grad_f32_v4((f32x4){t[0], t[1], t[2], t[3]}, p.dact), g1 = gg_act_grad_f32_v4((f32x4){t[4], t[5], t[6], t[7]}, p.dact);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] *= gg_act_grad_f32(t[j], p.dact);
+            for (int j = 0; j < 4; ++j) { v[j] *= g0[j]; v[4 + j] *= g1[j]; }
         } else if (p.act) {
+            const f32x4 a0 = gg_act_f32_v4((f32x4){v[0], v[1], v[2], v[3]}, p.act), a1 = gg_act_f32_v4((f32x4){v[4], v[5], v[6], v[7]}, p.act);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gg_act_f32(v[j], p.act);
+            for (int j = 0; j < 4; ++j) { v[j] = a0[j]; v[4 + j] = a1[j]; }
         }
         if (p.rowscale) {
             const float sc = p.rowscale[m / p.rows_per_scale];

@@ -532,6 +532,45 @@ def test_fp32_split_mode_passes_the_fp32_gate(centroids, model_name, N, unfrozen
     _grad_table(case, 2e-3, label)
 
 
+def test_fp32_split_mode_tracks_fp32_over_optimizer_steps(centroids):
+    """The split mode reads the weights of its Linears from CACHED bf16 planes: after an optimizer step the planes of the trainable tensors must be re-split
+    (gg_tinyvit_refresh_weights_masked).  Four AdamW steps at a large learning rate from the same initial state in both modes: losses and the trained
+    parameters agree at fp32 rounding level -- with stale planes the second forward would already differ at the size of the first update."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    from geoguessr_ai_amd.optim import AdamW
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 4, 3, 224, 224, generator=g).cuda()
+    lab = torch.stack([torch.rand(3, generator=g) * 360 - 180, torch.rand(3, generator=g) * 180 - 90], 1).cuda()
+    runs = {}
+    for precision in ("fp32", "fp32_split"):
+        torch.manual_seed(21)
+        base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, precision=precision, drop_path_rate=0.0)
+        _randomize(base.backbone, 22)
+        model = SuperGuessr(base.cuda(), panorama=True, should_smooth_labels=True).cuda().train()
+        for p_ in model.parameters():
+            p_.requires_grad_(True)
+        opt = AdamW(model, lr=3e-3, betas=(0.9, 0.999), weight_decay=0.01)
+        losses = []
+        for _ in range(4):
+            out = model(pixel_values=x, labels=lab)
+            out.loss.backward()
+            opt.step(); opt.zero_grad()
+            losses.append(float(out.loss))
+        runs[precision] = (losses, {n: p_.detach().float().cpu().clone() for n, p_ in model.named_parameters()})
+    la, lb = runs["fp32"][0], runs["fp32_split"][0]
+    print("[fp32 vs fp32_split, 4 steps] losses", la, lb)
+    assert abs(la[0] - la[-1]) > 1e-3 * abs(la[0])                     # the steps are large enough to matter
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-4 * abs(a), (la, lb)
+    # (matrices; bias / norm vectors that start at zero take Adam's sign-like first updates from gradients near zero: percent-level differences, no signal)
+    errs = sorted(((relerr(runs["fp32_split"][1][n], t), n) for n, t in runs["fp32"][1].items() if t.dim() >= 2), reverse=True)
+    print("[fp32 vs fp32_split, 4 steps] worst matrix rel-L2", errs[:4])
+    assert errs[0][0] < 2e-3
+    vec = max(relerr(runs["fp32_split"][1][n], t) for n, t in runs["fp32"][1].items() if t.dim() == 1 and t.numel() > 1)
+    assert vec < 5e-2
+
+
 def test_a_half_frozen_parameter_pair_is_refused_by_name(centroids):
     """The TinyViT schedule forms the gradients of a (weight, bias) / (gamma, beta) pair together; a mask that trains ``mlp.norm.bias`` while
     ``mlp.norm.weight`` stays frozen has no schedule and must fail loudly in backward (it used to leave the bias gradient at zero in the fused
