@@ -15,7 +15,8 @@
 //     conflict-free without padding;
 //   * one raw s_barrier per stage, the next stage's DMA in flight under the current stage's 96 MFMAs; two waves per SIMD.
 // Epilogues: the Linear family of the model (bias, GELU with a saved pre-activation, rowscale + residual, x GELU'), results as f32 and / or as planes for the
-// next split GEMM.  Used by csrc/tinyvit.hip in the fp32_split mode (frozen C >= 384 blocks); tools/bench_split3.py times it next to the f32-MFMA GEMM.
+// next split GEMM.  The fp32_split mode of csrc/tinyvit.hip runs on the forms further down (gemm_nt_split3a / b_kernel: A as f32, split in the loader); this
+// plane-fed form is what they are checked against bit for bit (tests/test_gpu_kernels.py) and what tools/bench_split3.py times next to the f32-MFMA GEMM.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>

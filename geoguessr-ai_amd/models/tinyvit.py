@@ -38,7 +38,7 @@ VARIANTS = {
 DEPTHS = (2, 2, 6, 2)
 
 
-PRECISIONS = {"bf16": 0, "bfloat16": 0, "fp32": 1, "f32": 1, "float32": 1, "fp32_split": 3}      # fp32_split: experiment (f32 storage, split-bf16 Linears in frozen blocks)
+PRECISIONS = {"bf16": 0, "bfloat16": 0, "fp32": 1, "f32": 1, "float32": 1, "fp32_split": 3}      # fp32_split: f32 storage, the transformer blocks' Linears as f32-accurate split-bf16 products
 
 
 def default_precision() -> str:

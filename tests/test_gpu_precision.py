@@ -641,7 +641,7 @@ def test_headline_model_prediction_agreement(centroids, precision):
 
 
 def test_fp32_split_inference_embeddings_match_the_fp32_mode():
-    """Inference in the fp32_split mode (every C >= 384 block's norm1 -> qkv and norm2 -> fc1 -> fc2 as split-bf16 products: the bulk-embedding job of the "next" row f2)
+    """Inference in the fp32_split mode (every transformer block's qkv / proj / fc1 / fc2 as split-bf16 products from 64 tokens per call on: the bulk-embedding job of the "next" row f2)
     gives the fp32 mode's embeddings to fp32 rounding (rel-L2 <= 1e-5: the two product forms differ by ~3e-7 per GEMM)."""
     import warnings
     from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
