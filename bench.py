@@ -125,28 +125,36 @@ def cpu_baseline(seconds_budget: float = 14.0):
 
 
 def clock_under_gemm_load(dev):
-    """Shader clock while the fp32 GEMM runs: a traced launch of the model's qkv shape (gg_gemm_f32_set_trace: every workgroup records
-    s_memtime, which ticks at the shader clock, and the constant 100 MHz wall clock over its life).  MI355X lowers its clock under sustained
-    fp32 MFMA load, so the matrix peak that can be reached is 157.3 TFLOP/s x (this clock / 2.4 GHz)."""
+    """Shader clock while the fp32 GEMMs run: traced launches of the five heaviest GEMM forms of the fp32 step (gg_gemm_f32_set_trace: every workgroup
+    records s_memtime, which ticks at the shader clock, and the constant 100 MHz wall clock over its life).  MI355X lowers its clock under sustained fp32
+    MFMA load, so the matrix peak that can be reached is 157.3 TFLOP/s x (clock / 2.4 GHz).  -> (flop-weighted mean MHz, {form: MHz})."""
     import numpy as np
     import torch
     from geoguessr_ai_amd import ops, _lib as L
-    M, N, K = 200704, 1152, 384
-    A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev) * 0.05; out = torch.empty(M, N, device=dev)
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    buf = torch.zeros(tiles, 8, dtype=torch.int64, device=dev)
-    for _ in range(3):
-        ops.gemm_nt(A, B, out=out)
-    L.lib().gg_gemm_f32_set_trace(buf.data_ptr())
-    try:
-        ops.gemm_nt(A, B, out=out)
-        torch.cuda.synchronize(dev)
-    finally:
-        L.lib().gg_gemm_f32_set_trace(None)
-    t = buf.cpu().numpy().astype("float64")
-    life_us = (t[:, 5] - t[:, 2]) * 0.01
-    ok = life_us > 1.0
-    return float(np.median(t[ok, 1] / life_us[ok])) if ok.any() else None
+    forms = [("stage2.qkv 200704x1152x384", 200704, 1152, 384), ("stage2.fc1 200704x1536x384", 200704, 1536, 384), ("stage2.fc2 200704x384x1536", 200704, 384, 1536),
+             ("stage1.fc1 802816x768x192", 802816, 768, 192), ("stage0.conv3 3211264x96x384", 3211264, 96, 384)]
+    per, wsum, w = {}, 0.0, 0.0
+    for name, M, N, K in forms:
+        A = torch.randn(M, K, device=dev); B = torch.randn(N, K, device=dev) * 0.05; out = torch.empty(M, N, device=dev)
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)                  # (at least as many records as any tile form launches workgroups)
+        buf = torch.zeros(tiles, 8, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            ops.gemm_nt(A, B, out=out)
+        L.lib().gg_gemm_f32_set_trace(buf.data_ptr())
+        try:
+            ops.gemm_nt(A, B, out=out)
+            torch.cuda.synchronize(dev)
+        finally:
+            L.lib().gg_gemm_f32_set_trace(None)
+        t = buf.cpu().numpy().astype("float64")
+        life_us = (t[:, 5] - t[:, 2]) * 0.01
+        ok = life_us > 1.0
+        if ok.any():
+            mhz = float(np.median(t[ok, 1] / life_us[ok]))
+            per[name] = round(mhz, 0)
+            wsum += mhz * M * N * K; w += float(M) * N * K
+        del A, B, out, buf
+    return (wsum / w if w else None), per
 
 
 def pmc_traffic(precision):
@@ -584,10 +592,11 @@ def run_mode(precision, args, rank, world, dev, x, lab):
         else:
             roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach_tf / peak_tf, 4), **common)
         if precision == "fp32" and roof["bound"] == "mfma":
-            mhz = clock_under_gemm_load(dev)
+            mhz, per_form = clock_under_gemm_load(dev)
             if mhz:
                 pk = peak_tf * mhz / 2400.0
-                roof.update(shader_clock_mhz_under_load=round(mhz, 0), peak_at_measured_clock=round(pk, 1), frac_at_measured_clock=round(ach_tf / pk, 4))
+                roof.update(shader_clock_mhz_under_load=round(mhz, 0), shader_clock_mhz_per_form=per_form, peak_at_measured_clock=round(pk, 1),
+                            frac_at_measured_clock=round(ach_tf / pk, 4))
         lib.gg_prof_reset()
         if args.dump_launches and rank == 0:
             # one step's launches in issue order (category, ms, algorithmic flops, algorithmic bytes): tools/pmc_traffic.py joins them with the PMC
