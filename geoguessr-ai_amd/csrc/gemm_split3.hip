@@ -101,6 +101,7 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
     constexpr int LDT = BN + 4;                                   // padded row: conflict-free 16-byte column writes from the MFMA layout
     constexpr int CPR = BN / 8;                                   // 8-column chunks per row
     constexpr int RPP = NTHR / CPR;                               // rows per pass
+    if ((int)threadIdx.x >= RPP * CPR) return;                     // (BN = 96: 12 chunks per row do not divide the block; no barrier follows)
     const int chunk = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
     const int n = n0 + chunk * 8;
     const bool nfull = n + 7 < p.N;
@@ -467,9 +468,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
 // reads' chunk swizzle.  In-order VMEM completion makes one counted wait per stage enough: at the top of stage s the queue holds A(s+1), B(s), A(s+2);
 // vmcnt(4) leaves only A(s+2) in flight.
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-template <int ABL>
+// TN_: 16-column MFMA tiles per wave (4: 128-column tile; 3: 96 -- for N = 192, which 128-wide tiles cover with a quarter of the work wasted)
+template <int ABL, int TN_ = 4>
 __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
-    constexpr int BM = 256, BN = 128, WN = 2, NW = 8, TM = 4, TN = 4;
+    constexpr int TN = TN_, BM = 256, BN = 32 * TN, WN = 2, NW = 8, TM = 4;
     constexpr int TA = BM * S3_SK, TB = BN * S3_SK, STAGE = 3 * (TA + TB);
     extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
     const int tiles = p.tilesM * p.tilesN;
@@ -501,10 +503,12 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     auto issue_b = [&](int st, bf16* base) {
         const int k0 = st * S3_SK;
         const bool kin = k0 + dchunk * 8 < p.K;
+        if (wave < BN / 16) {                                   // (wave-uniform: BN / 16 slices of 16 rows per plane)
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[i], (__attribute__((address_space(3))) void*)(base + 3 * TA + i * TB + wave * 512), 16,
-                                                     (int)(kin ? voffB : 0xFFFFFFF0u), k0 * 2, 0, 0);
+            for (int i = 0; i < 3; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[i], (__attribute__((address_space(3))) void*)(base + 3 * TA + i * TB + wave * 512), 16,
+                                                         (int)(kin ? voffB : 0xFFFFFFF0u), k0 * 2, 0, 0);
+        }
     };
     auto load_a = [&](int st, f32x4 (&r)[4]) {
         const int k0 = st * S3_SK;
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
         }
     };
     const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
-    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = 3 * TA + (wn * 64 + lr) * S3_SK + fslot;
+    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = 3 * TA + (wn * 16 * TN + lr) * S3_SK + fslot;
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -562,12 +566,12 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { xf[pl][t] = __builtin_bit_cast(bf16x8, acc[0][t]); wf[pl][t] = __builtin_bit_cast(bf16x8, acc[1][t]); }
+                for (int t = 0; t < 4; ++t) { xf[pl][t] = __builtin_bit_cast(bf16x8, acc[0][t]); if (t < TN) wf[pl][t] = __builtin_bit_cast(bf16x8, acc[1][t]); }
         }
         auto rd_a1 = [&](int pl, int mt) { if (!(ABL & 2)) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(cur + pl * TA + a_off + mt * 16 * S3_SK); };
         auto rd_b1 = [&](int pl, int nt) { if (!(ABL & 2)) wf[pl][nt] = *reinterpret_cast<const bf16x8*>(cur + pl * TB + b_off + nt * 16 * S3_SK); };
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { rd_a1(0, t); rd_b1(2, t); }
+        for (int t = 0; t < 4; ++t) { rd_a1(0, t); if (t < TN) rd_b1(2, t); }
         const int k3 = (s + 3) * S3_SK;
         const bool kin3 = k3 + kq * 4 < p.K;
         bf16x4 p1, p2, p3;
@@ -581,19 +585,17 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
                     if (!(ABL & 1)) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB[g]][nt], xf[PA[g]][mt], acc[nt][mt], 0, 0, 0);
                     else { acc[nt][mt][0] += (float)wf[PB[g]][nt][0]; acc[nt][mt][1] += (float)xf[PA[g]][mt][0]; }
                 }
-                const int qi = g * 4 + nt;
-                if (g == 0 && nt < 3) {                             // a2, b2 under the first product group
-                    if (nt == 0) { rd_a1(1, 0); rd_a1(1, 1); rd_a1(1, 2); }
-                    if (nt == 1) { rd_a1(1, 3); rd_b1(1, 0); rd_b1(1, 1); }
-                    if (nt == 2) { rd_b1(1, 2); rd_b1(1, 3); }
+                constexpr int Q = 6 * TN;                           // quads per stage; the split's 12 slices go to the quads with (12 qi) mod Q < 12
+                const int qi = g * TN + nt;
+                if (g < 2) {                                        // a2, b2 under the first product group; a3, b1 under the second: three reads per quad
+#pragma unroll
+                    for (int idx = 3 * nt; idx < 3 * nt + 3; ++idx) {
+                        if (idx < 4) rd_a1(g + 1, idx);
+                        else if (idx - 4 < TN) rd_b1(1 - g, idx - 4);
+                    }
                 }
-                if (g == 1 && nt < 3) {                             // a3, b1 under the second
-                    if (nt == 0) { rd_a1(2, 0); rd_a1(2, 1); rd_a1(2, 2); }
-                    if (nt == 1) { rd_a1(2, 3); rd_b1(0, 0); rd_b1(0, 1); }
-                    if (nt == 2) { rd_b1(0, 2); rd_b1(0, 3); }
-                }
-                if ((qi & 1) && !(ABL & 4)) {
-                    const int ms = qi >> 1, jj = ms / 3, part = ms % 3;
+                if ((qi * 12) % Q < 12 && !(ABL & 4)) {
+                    const int ms = (qi * 12) / Q, jj = ms / 3, part = ms % 3;
                     if (part < 2) {
 #pragma unroll
                         for (int e = 2 * part; e < 2 * part + 2; ++e) {
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
-            *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 64 + nt * 16 + lg * 4) = acc[nt][mt];
+            *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 16 * TN + nt * 16 + lg * 4) = acc[nt][mt];
     __syncthreads();
     split3_epilogue_rows<BM, BN, 512>(p, Ct, m0, n0);
 }
@@ -636,8 +638,9 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
 // tile next to 11 us of MFMAs at K = 384: in the model those launches ran 20-45 % slower than the bias-only shape).  LDS: the A planes single-buffered (24 KB:
 // a wave reads ALL its A fragments of a stage, a second barrier frees the buffer, and the split of A(s + 1) is written into it under the stage's MFMAs), the B
 // planes double-buffered by LDS-DMA (2 x 24 KB).  Everything else as above.
+template <int TN_ = 4>
 __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
-    constexpr int BM = 128, BN = 128, WN = 2, TM = 4, TN = 4;
+    constexpr int TN = TN_, BM = 128, BN = 32 * TN, WN = 2, TM = 4;
     constexpr int TA = BM * S3_SK, TB = BN * S3_SK;
     extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
     bf16* const Abuf = s3mem;                                      // [3][TA]
@@ -676,8 +679,9 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[i], (__attribute__((address_space(3))) void*)(base + i * TB + (wave + 4 * j) * 512), 16,
-                                                         (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
+                if (wave + 4 * j < BN / 16)                       // (wave-uniform)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB[i], (__attribute__((address_space(3))) void*)(base + i * TB + (wave + 4 * j) * 512), 16,
+                                                             (int)(kin ? voffB[j] : 0xFFFFFFF0u), k0 * 2, 0, 0);
     };
     auto load_a = [&](int st, f32x4 (&r)[4]) {
         const int k0 = st * S3_SK;
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
         }
     };
     const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
-    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = (wn * 64 + lr) * S3_SK + fslot;
+    const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = (wn * 16 * TN + lr) * S3_SK + fslot;
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
@@ -729,7 +733,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
             for (int mt = 0; mt < TM; ++mt) xf[pl][mt] = *reinterpret_cast<const bf16x8*>(Abuf + pl * TA + a_off + mt * 16 * S3_SK);
         auto rd_b1 = [&](int pl, int nt) { wf[pl][nt] = *reinterpret_cast<const bf16x8*>(curB + pl * TB + b_off + nt * 16 * S3_SK); };
 #pragma unroll
-        for (int t = 0; t < 4; ++t) rd_b1(2, t);
+        for (int t = 0; t < TN; ++t) rd_b1(2, t);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the twelve A fragments (and b3) are in registers ...
         __builtin_amdgcn_s_barrier();                               // ... everybody's are: the A buffer is free for the planes of A(s + 1)
         const int k3 = (s + 3) * S3_SK;
@@ -742,11 +746,11 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
             for (int nt = 0; nt < TN; ++nt) {
 #pragma unroll
                 for (int mt = 0; mt < TM; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PB[g]][nt], xf[PA[g]][mt], acc[nt][mt], 0, 0, 0);
-                const int qi = g * 4 + nt;
-                if (g == 0 && nt < 2) { rd_b1(1, 2 * nt); rd_b1(1, 2 * nt + 1); }      // b2 under the first product group
-                if (g == 1 && nt < 2) { rd_b1(0, 2 * nt); rd_b1(0, 2 * nt + 1); }      // b1 under the second
-                if (qi & 1) {
-                    const int ms = qi >> 1, jj = ms / 3, part = ms % 3;
+                constexpr int Q = 6 * TN;
+                const int qi = g * TN + nt;
+                if (g < 2 && 2 * nt < TN) { rd_b1(1 - g, 2 * nt); if (2 * nt + 1 < TN) rd_b1(1 - g, 2 * nt + 1); }      // b2 under the first product group, b1 under the second
+                if ((qi * 12) % Q < 12) {
+                    const int ms = (qi * 12) / Q, jj = ms / 3, part = ms % 3;
                     if (part < 2) split2(rnext[jj], 2 * part, p1, p2, p3);
                     else {
                         *reinterpret_cast<bf16x4*>(Abuf + ldsA[jj]) = p1;
@@ -771,7 +775,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
     for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt)
-            *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 64 + nt * 16 + lg * 4) = acc[nt][mt];
+            *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 16 * TN + nt * 16 + lg * 4) = acc[nt][mt];
     __syncthreads();
     split3_epilogue_rows<BM, BN, 256>(p, Ct, m0, n0);
 }
@@ -888,17 +892,24 @@ extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int
     // the second workgroup hides its prologue / epilogue (K = 192: 1.30 x against 1.22 x the f32-MFMA GEMM; at K >= 384 the big tile wins by 1-2 %)
     static const char* tenv = gg_dev_env("GG_SPLIT3A_TILE");      // dev: 256 / 128 forces one form
     const bool big = tenv ? atoi(tenv) == 256 : p.K >= 384;
-    p.tilesM = (int)gg_cdiv(p.M, big ? 256 : 128); p.tilesN = (int)gg_cdiv(p.N, 128);
+    // 96-column tiles where 128-column ones would waste a fifth or more of their work on columns beyond N that 96-column ones do not (N = 192: 25 % -> -8...-11 %
+    // in time; N = 576, 10 %: the narrower tile's higher LDS traffic per MFMA costs more than the waste)
+    static const char* nenv = gg_dev_env("GG_SPLIT3A_BN");          // dev: 96 / 128 forces one width
+    const double w128 = 1.0 - (double)p.N / ((double)gg_cdiv(p.N, 128) * 128), w96 = 1.0 - (double)p.N / ((double)gg_cdiv(p.N, 96) * 96);
+    const bool n96 = nenv ? atoi(nenv) == 96 : (w128 - w96 >= 0.2);
+    const int bn = n96 ? 96 : 128;
+    p.tilesM = (int)gg_cdiv(p.M, big ? 256 : 128); p.tilesN = (int)gg_cdiv(p.N, bn);
     static const char* aenv = gg_dev_env("GG_SPLIT3A_ABL");      // dev ablations of the 256 x 128 form (results are garbage): 1 no MFMA, 2 no fragment reads, 4 no A path, 8 no B DMA
     const int abl = aenv ? atoi(aenv) : 0;
-    void (*kern)(Split3Params) = !big ? gemm_nt_split3b_kernel : abl == 1 ? gemm_nt_split3a_kernel<1> : abl == 2 ? gemm_nt_split3a_kernel<2> : abl == 4 ? gemm_nt_split3a_kernel<4> :
+    void (*kern)(Split3Params) = !big ? (n96 ? gemm_nt_split3b_kernel<3> : gemm_nt_split3b_kernel<4>) : n96 ? gemm_nt_split3a_kernel<0, 3> :
+                                 abl == 1 ? gemm_nt_split3a_kernel<1> : abl == 2 ? gemm_nt_split3a_kernel<2> : abl == 4 ? gemm_nt_split3a_kernel<4> :
                                  abl == 8 ? gemm_nt_split3a_kernel<8> : abl == 6 ? gemm_nt_split3a_kernel<6> : gemm_nt_split3a_kernel<0>;
-    const size_t lds = big ? (size_t)2 * 3 * (256 + 128) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * 128) * S3_SK * sizeof(bf16);
-    static bool raised[2] = {false, false};
-    if (!raised[big] || abl) {
+    const size_t lds = big ? (size_t)2 * 3 * (256 + bn) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * bn) * S3_SK * sizeof(bf16);
+    static bool raised[4] = {false, false, false, false};
+    if (!raised[big * 2 + n96] || abl) {
         GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "gg_gemm_nt_split3_af32: cannot raise the dynamic LDS limit");
-        raised[big] = true;
+        raised[big * 2 + n96] = true;
     }
     const double mn = (double)p.M * p.N;
     GG_PROF(GG_CAT_GEMM, 2.0 * p.M * (double)p.N * p.K,

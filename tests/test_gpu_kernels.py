@@ -734,10 +734,11 @@ def test_split3_gemm_epilogues_match_the_f32_gemm(ops):
     assert rel(out2, got.double() @ W2.double().T) < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K,lda", [(300, 200, 96, 96), (4099, 384, 384, 400), (1000, 136, 712, 712), (257, 1153, 1536, 1536), (256, 128, 8, 8)])
+@pytest.mark.parametrize("M,N,K,lda", [(300, 200, 96, 96), (4099, 384, 384, 400), (1000, 136, 712, 712), (257, 1153, 1536, 1536), (256, 128, 8, 8), (600, 192, 96, 96), (700, 192, 768, 776),
+                                       (513, 90, 416, 416)])
 def test_split3_gemm_with_f32_activation_operand(ops, M, N, K, lda):
     """gg_gemm_nt_split3_af32 (the fp32_split mode's Linear): A is the f32 activation itself, split into its three bf16 terms while the kernel stages it; the
-    weight comes as cached planes.  Both tile forms (K < 384: 128 x 128, two workgroups per CU; else 256 x 128) on ragged shapes, a K that is not a multiple
+    weight comes as cached planes.  Both tile forms (K < 384: 128 x 128, two workgroups per CU; else 256 x 128), each with 128- and 96-column tiles (N = 192, 90), on ragged shapes, a K that is not a multiple
     of the 32-element stage, a strided A: the result is BIT-IDENTICAL to the plane-fed kernel on pre-split planes of the same A (same products, same order),
     f32-accurate against fp64, and the epilogue family (bias + GELU + pre-activation copy; row scale + residual; x GELU') matches gg_gemm_nt_f32."""
     import ctypes as C

@@ -35,7 +35,7 @@ def af32(A, Bp, out, bias=None):
 
 
 shapes = [("s1.qkv", 802816, 576, 192), ("s1.fc1", 802816, 768, 192), ("s1.fc2", 802816, 192, 768),
-          ("s2.qkv", 200704, 1152, 384), ("s2.fc1", 200704, 1536, 384), ("s2.fc2", 200704, 384, 1536), ("s2.proj", 200704, 384, 384),
+          ("s1.fc2b", 802816, 192, 768), ("s1.proj", 802816, 192, 192), ("s3.proj", 50176, 576, 576), ("s2.qkv", 200704, 1152, 384), ("s2.fc1", 200704, 1536, 384), ("s2.fc2", 200704, 384, 1536), ("s2.proj", 200704, 384, 384),
           ("s3.qkv", 50176, 1728, 576), ("s3.fc1", 50176, 2304, 576), ("s3.fc2", 50176, 576, 2304), ("edge", 5000, 1000, 712)]
 only = sys.argv[1:]
 for name, M, N, K in shapes:
