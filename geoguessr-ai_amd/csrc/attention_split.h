@@ -4,9 +4,11 @@
 // SIMD's vector issue with the softmax arithmetic: a 16 x 16 x 32 tile product is 8 instructions = 256 matrix-pipe cycles.  Here every f32 operand is carried as
 // THREE bf16 planes (x = x1 + x2 + x3: 24 significand bits, the same split as gg_gemm_nt_split3 / gg_split3_bf16) and a product is six bf16 MFMAs
 //     (a1 b3 + a2 b2 + a3 b1) + (a1 b2 + a2 b1) + a1 b1        (small terms first; f32 accumulation; the dropped terms are < 2^-24 of the product)
-// = 96 cycles for the same tile (v_mfma_f32_16x16x32_bf16; v_mfma_f32_16x16x16_bf16 where the contraction runs over the 16 tokens of a tile), which leave
-// the vector ALU free half the time.  Error against an fp64 product: that of the f32 MFMA (2.9e-7 vs 3.5e-7 relative on the GEMM shapes); the
-// kernels pass the fp32 mode's own gates (tests/test_gpu_kernels.py::test_flash_attention_forward_backward, tests/test_gpu_precision.py).
+// = 96 cycles for the same tile on v_mfma_f32_16x16x32_bf16 (every contraction is 32 deep: the 16-deep bf16 MFMA costs the same 16 cycles, so products over
+// tokens pair two 16-token tiles per instruction), and the bf16 MFMA does not share its issue with the vector ALU the way the f32 MFMA does.  Error against an
+// fp64 reference (tools/check_attn_split.py): below the f32-MFMA kernels' on five of the six forward / backward shapes of TinyViT-21M-224, 15 %
+// above on the 14 x 14 backward; the kernels pass the fp32 mode's own gates at unchanged tolerances (tests/test_gpu_kernels.py::
+// test_flash_attention_forward_backward, tests/test_gpu_precision.py).
 // Operands that are reused -- K / V (forward), Q / dO (backward) of the whole window -- are split ONCE while they are staged into LDS (three bf16 images
 // of 64-byte rows, 16-byte chunks XOR-swizzled with (-(row >> 2)) & 3: conflict-free fragment ds_read_b128); per-wave strips are split once in registers;
 // probabilities / dS tiles are split where they are formed (5 vector instructions per score).
