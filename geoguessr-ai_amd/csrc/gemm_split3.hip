@@ -780,6 +780,178 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
     split3_epilogue_rows<BM, BN, 256>(p, Ct, m0, n0);
 }
 
+// ------------------------------------------------------------------------------------------- weight gradient (TN), both operands f32
+// dW[N][K] = sum_m s_m dY[m][n] X[m][k]  (s = the DropPath row scale or 1): the contraction runs over the ROWS of both operands, so both are split in the loader
+// and staged as plane images [32 m][columns] (sub-images of 32 columns: 64-byte rows, chunk swizzle (-(row >> 2)) & 3 as in attention_split.h), and the
+// fragments -- 8 consecutive m of one column per lane -- come out of LDS through the transposing read ds_read_tr16_b64 (two per fragment).  Tile 256 (n) x 128
+// (k), 4 x 2 waves of 64 x 64, 32 rows per stage, 2-stage ring of 72 KB; D = X^T-fragment x dY^T-fragment, so a lane owns 4 consecutive k of one n (16-byte
+// stores).  The rows are cut into `splits` slabs (one workgroup per tile and slab), partial tiles go to the slab scratch and gg_splitk_reduce adds them in slab
+// order -- the protocol of gg_gemm_tn_f32, whose place this kernel takes in the fp32_split mode.
+typedef short s3_s4 __attribute__((ext_vector_type(4)));
+struct Split3TnParams {
+    const float* dY; int64_t ldy; const float* X; int64_t ldx;
+    int M, N, K; const float* rowscale; int rps;
+    float* part; int rows_per_split, tilesN, tilesK;
+};
+__device__ __forceinline__ int s3_img_off(int row, int ch) { return row * 32 + ((ch ^ ((-(row >> 2)) & 3)) << 3); }
+__global__ __launch_bounds__(512) void gemm_tn_split3_kernel(Split3TnParams p) {
+    constexpr int BN = 256, BK = 128, WK = 2;
+    constexpr int PY = 32 * BN, PX = 32 * BK, STAGE = 3 * (PY + PX);     // plane images of one stage (bf16 elements): dY then X
+    extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
+    const int tiles = p.tilesN * p.tilesK;
+    const int t = blockIdx.x % tiles, slab = blockIdx.x / tiles;
+    const int tn = t / p.tilesK, tk = t % p.tilesK;
+    const int n0 = tn * BN, k0 = tk * BK;
+    const int m_begin = slab * p.rows_per_split, rows = min(p.M - m_begin, p.rows_per_split);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WK, wk = wave % WK;                       // wave: n range 64 wm, k range 64 wk
+    const int lr = lane & 15, lg = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dY + (int64_t)m_begin * p.ldy), 0, (int)((unsigned)rows * (unsigned)p.ldy * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(p.X + (int64_t)m_begin * p.ldx), 0, (int)((unsigned)rows * (unsigned)p.ldx * 4u), 0x00020000);
+    // loader: dY f32x4 number c4 of rows (tid >> 6) + 8 j (j < 4); X f32x4 number c4 of rows (tid >> 5) + 16 j (j < 2); columns beyond N / K are masked
+    unsigned voff[6];
+    int ldso[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (threadIdx.x >> 6) + 8 * j, col = (threadIdx.x & 63) * 4;
+        voff[j] = (n0 + col < p.N) ? (unsigned)row * (unsigned)p.ldy * 4u + (unsigned)(n0 + col) * 4u : 0xFFFFFFF0u;
+        ldso[j] = (col >> 5) * 1024 + s3_img_off(row, (col & 31) >> 3) + (col & 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (threadIdx.x >> 5) + 16 * j, col = (threadIdx.x & 31) * 4;
+        voff[4 + j] = (k0 + col < p.K) ? (unsigned)row * (unsigned)p.ldx * 4u + (unsigned)(k0 + col) * 4u : 0xFFFFFFF0u;
+        ldso[4 + j] = 3 * PY + (col >> 5) * 1024 + s3_img_off(row, (col & 31) >> 3) + (col & 4);
+    }
+    // DropPath row scale of the four dY rows of this thread: index (m / rps) kept as a quotient / remainder pair that advances by 32 rows per stage
+    int sq[4], sr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m_begin + (int)(threadIdx.x >> 6) + 8 * j;
+        sq[j] = p.rowscale ? m / p.rps : 0; sr[j] = p.rowscale ? m % p.rps : 0;
+    }
+    const int nk = (rows + 31) >> 5;
+    auto load = [&](int st, f32x4 (&r)[6]) {
+        // (rows beyond the slab fail the descriptor's range check: zeros)
+        const unsigned sy = (unsigned)st * 32u * (unsigned)p.ldy * 4u, sx = (unsigned)st * 32u * (unsigned)p.ldx * 4u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(st < nk ? voff[j] : 0xFFFFFFF0u), (int)sy, 0));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) r[4 + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(st < nk ? voff[4 + j] : 0xFFFFFFF0u), (int)sx, 0));
+    };
+    auto split2 = [&](const f32x4& v, int e0, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
+#pragma unroll
+        for (int e = e0; e < e0 + 2; ++e) {
+            const bf16 a = (bf16)v[e];
+            const float r1 = v[e] - (float)a;
+            const bf16 b2 = (bf16)r1;
+            p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+        }
+    };
+    auto scale_rows = [&](f32x4 (&r)[6]) {                          // the scales of the rows just loaded; then the counters move on to the rows two stages later
+        if (!p.rowscale) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] *= p.rowscale[sq[j]];
+    };
+    auto advance_rows = [&]() {
+        if (!p.rowscale) return;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sr[j] += 32; while (sr[j] >= p.rps) { sr[j] -= p.rps; ++sq[j]; } }
+    };
+    auto store_planes = [&](const f32x4 (&r)[6], bf16* base) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            bf16x4 p1, p2, p3;
+            split2(r[j], 0, p1, p2, p3); split2(r[j], 2, p1, p2, p3);
+            const int pl = j < 4 ? PY : PX;
+            *reinterpret_cast<bf16x4*>(base + ldso[j]) = p1; *reinterpret_cast<bf16x4*>(base + pl + ldso[j]) = p2; *reinterpret_cast<bf16x4*>(base + 2 * pl + ldso[j]) = p3;
+        }
+    };
+    // fragment addresses (element offsets within a plane; + 16 rows = + 512): lane (lr, lg) supplies row 4 lg + (lr >> 2), columns 4 (lr & 3) .. of the 16-column block
+    int yoff[4], xoff[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int row = 4 * lg + (lr >> 2);
+        const int cy = 64 * wm + 16 * tt + 4 * (lr & 3), cx = 64 * wk + 16 * tt + 4 * (lr & 3);
+        yoff[tt] = (cy >> 5) * 1024 + s3_img_off(row, (cy & 31) >> 3) + (cy & 7);
+        xoff[tt] = 3 * PY + (cx >> 5) * 1024 + s3_img_off(row, (cx & 31) >> 3) + (cx & 7);
+    }
+    f32x4 acc[4][4];                                                // [n-tile][k-tile]; lane: n = lr, k = 4 lg + r
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[2][6];
+    load(0, ra[0]);
+    load(1, ra[1]);
+    wait_vm<6>();
+    scale_rows(ra[0]); advance_rows();
+    store_planes(ra[0], s3mem);
+    load(2, ra[0]);
+    auto stage = [&](int s, f32x4 (&rnext)[6]) {
+        // rnext holds the rows of stage s + 1 (loaded two stages ago); after their split it is reloaded with stage s + 3
+        const bf16* const cur = s3mem + (s & 1) * STAGE;
+        bf16* const nxt = s3mem + ((s + 1) & 1) * STAGE;
+        wait_vm<6>();                                               // the rows of stage s + 1 have landed; those of stage s + 2 may be in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // everybody's planes of stage s are written, everybody's fragments of stage s - 1 are read
+        union Fr { s3_s4 h[2]; bf16x8 v; };
+        Fr xf[3][4], yf[3][4];                                      // X^T fragments per k-tile (A operand: i = k), dY^T fragments per n-tile (B operand: j = n)
+        auto rd = [&](bool isx, int pl, int tt, int half) {
+            const bf16* a = cur + (isx ? pl * PX + xoff[tt] : pl * PY + yoff[tt]) + half * 512;
+            (isx ? xf[pl][tt] : yf[pl][tt]).h[half] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s3_s4*)a);
+        };
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) { rd(true, 0, tt, 0); rd(true, 0, tt, 1); rd(false, 2, tt, 0); rd(false, 2, tt, 1); }
+        scale_rows(rnext); advance_rows();
+        bf16x4 p1, p2, p3;
+        constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // small terms first
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[PA[g]][kt].v, yf[PB[g]][nt].v, acc[nt][kt], 0, 0, 0);
+                const int qi = g * 4 + nt;
+                if (g < 2) {                                        // x2, dy2 under the first product group; x3, dy1 under the second: four reads per quad
+#pragma unroll
+                    for (int idx = 4 * nt; idx < 4 * nt + 4; ++idx) {
+                        if (idx < 8) rd(true, g + 1, idx >> 1, idx & 1);
+                        else rd(false, 1 - g, (idx - 8) >> 1, idx & 1);
+                    }
+                }
+                if ((qi * 18) % 24 < 18) {                          // the split's 18 slices on 18 of the 24 quads
+                    const int ms = (qi * 18) / 24, jj = ms / 3, part = ms % 3;
+                    if (part < 2) split2(rnext[jj], 2 * part, p1, p2, p3);
+                    else {
+                        const int pl = jj < 4 ? PY : PX;
+                        *reinterpret_cast<bf16x4*>(nxt + ldso[jj]) = p1; *reinterpret_cast<bf16x4*>(nxt + pl + ldso[jj]) = p2; *reinterpret_cast<bf16x4*>(nxt + 2 * pl + ldso[jj]) = p3;
+                        const int st3 = s + 3;
+                        if (jj < 4) rnext[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(st3 < nk ? voff[jj] : 0xFFFFFFF0u), (int)((unsigned)st3 * 32u * (unsigned)p.ldy * 4u), 0));
+                        else rnext[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(st3 < nk ? voff[jj] : 0xFFFFFFF0u), (int)((unsigned)st3 * 32u * (unsigned)p.ldx * 4u), 0));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int s = 0; s < nk; s += 2) {
+        stage(s, ra[1]);
+        if (s + 1 < nk) stage(s + 1, ra[0]);
+    }
+    wait_vm<0>();
+    float* out = p.part + (int64_t)slab * p.N * p.K;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 64 * wm + 16 * nt + lr;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int k = k0 + 64 * wk + 16 * kt + 4 * lg;
+            if (n < p.N && k < p.K) *reinterpret_cast<f32x4*>(out + (int64_t)n * p.K + k) = acc[nt][kt];
+        }
+    }
+}
+
 // x (f32, [rows][ldx]) -> planes [3][rows][cols] bf16: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t rows, int cols, int64_t ldx, bf16* __restrict__ out) {
     const int64_t n4 = rows * (cols / 4);
@@ -916,6 +1088,43 @@ extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int
             4.0 * (double)p.M * p.K + 6.0 * (double)p.N * p.K + 4.0 * mn * ((p.C != nullptr) + (p.preact != nullptr) + (p.residual != nullptr) + (p.dact_preact != nullptr)) +
                 (p.c_planes ? 6.0 * mn : 0.0), stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(big ? 512 : 256), lds, (hipStream_t)stream, p);
+    GG_LAUNCH_CHECK();
+    return 0;
+}
+
+// weight gradient of a Linear in the fp32_split mode: partial dW[N][K] slabs like gg_gemm_tn_f32 (same arguments; reduce with gg_splitk_reduce)
+extern "C" int gg_gemm_tn_split3_splits(int M, int N, int K) {
+    const int64_t tiles = gg_cdiv(N, 256) * gg_cdiv(K, 128);
+    const int64_t cap = std::max<int64_t>(1, ((int64_t)128 << 20) / ((int64_t)N * K * 4));        // 128 MiB of slabs at most (scratch.splitk)
+    const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(cap, gg_cdiv(M, 1024)));             // at least 32 stages per slab
+    int64_t s = 1;
+    double best = 0.0;
+    for (int64_t c = 1; c <= smax && c * tiles <= 4 * 256; ++c) {                                     // one 144 KB workgroup per CU: whole rounds of 256
+        const double eff = (double)(c * tiles) / (256.0 * (double)gg_cdiv(c * tiles, 256));
+        if (eff > best + 0.02) { best = eff; s = c; }
+    }
+    return (int)s;
+}
+extern "C" int gg_gemm_tn_split3(const float* dY, int64_t ldy, const float* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale, float* partials,
+                                 int splits, void* stream) {
+    GG_CHECK(dY && X && partials && M > 0 && N > 0 && K > 0 && splits > 0, "gg_gemm_tn_split3: bad args");
+    GG_CHECK((N & 3) == 0 && (K & 3) == 0 && (ldy & 3) == 0 && (ldx & 3) == 0 && ldy >= N && ldx >= K, "gg_gemm_tn_split3: N, K, ldy, ldx must be multiples of 4, ld >= columns");
+    GG_CHECK(((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)partials & 15) == 0, "gg_gemm_tn_split3: operands and partials must be 16-byte aligned");
+    GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn_split3: rows_per_scale");
+    Split3TnParams p;
+    p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.M = M; p.N = N; p.K = K; p.rowscale = rowscale; p.rps = rows_per_scale > 0 ? rows_per_scale : 1; p.part = partials;
+    p.rows_per_split = (int)(gg_cdiv(gg_cdiv(M, splits), 32) * 32);
+    GG_CHECK((int64_t)p.rows_per_split * (splits - 1) < M, "gg_gemm_tn_split3: more splits than 32-row stages");
+    GG_CHECK((int64_t)p.rows_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 31), "gg_gemm_tn_split3: a slab exceeds the 2 GiB descriptor range");
+    p.tilesN = (int)gg_cdiv(N, 256); p.tilesK = (int)gg_cdiv(K, 128);
+    static bool raised = false;
+    if (!raised) {
+        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_split3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+                 "gg_gemm_tn_split3: cannot raise the dynamic LDS limit");
+        raised = true;
+    }
+    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K) + 8.0 * splits * (double)N * K, stream);
+    hipLaunchKernelGGL(gemm_tn_split3_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(512), (size_t)2 * 3 * (256 + 128) * 32 * sizeof(bf16), (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }

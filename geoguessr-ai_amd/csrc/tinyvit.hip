@@ -759,8 +759,11 @@ static int dense_wgrad(const Exec& e, const DenseW& w, const act_t* X, int64_t l
                        const float* rowscale, int rps, act_t* T0, act_t* T1, bool conv_reorder) {
     (void)T0; (void)T1;
     const int K = conv_reorder ? w.Kp : w.K;   // im2col'd operand has Kp columns
-    const int split = e.f32 ? gg_gemm_tn_f32_splits((int)M, w.N, K) : gg_gemm_tn_splits((int)M, w.N, K);
-    if (e.f32) GG_TRY(gg_gemm_tn_f32(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
+    // fp32_split mode: the weight gradient of a block Linear (the tensors that have planes) as split products too, same slab protocol
+    const bool sp = e.m->split && w.wn3 >= 0 && !conv_reorder && M >= 1024;
+    const int split = sp ? gg_gemm_tn_split3_splits((int)M, w.N, K) : e.f32 ? gg_gemm_tn_f32_splits((int)M, w.N, K) : gg_gemm_tn_splits((int)M, w.N, K);
+    if (sp) GG_TRY(gg_gemm_tn_split3((const float*)dY, ldy, (const float*)X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
+    else if (e.f32) GG_TRY(gg_gemm_tn_f32(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
     else GG_TRY(gg_gemm_tn(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
     float* gw = e.Gd(w.t_w);
     if (!conv_reorder) {

@@ -249,7 +249,13 @@ typedef struct {
 int gg_gemm_nt_split3_ex(const GgSplit3Args* args, void* stream);
 /* the same with the A operand as the f32 tensor itself ([M][lda], split into its three bf16 terms while the kernel stages it: no plane copy of an
  * activation in HBM; args->a_planes / lda are ignored) and the weight as cached planes: the form every Linear of the fp32 model can take. */
-int gg_gemm_nt_split3_af32(const GgSplit3Args* args, const float* A, int64_t lda, int64_t b_plane_stride /* elements between the weight's planes; 0: N * ldb */, void* stream);
+int gg_gemm_nt_split3_af32(const GgSplit3Args* args, const float* A, int64_t lda, int64_t b_plane_stride /* elements between the weight's planes (0: N * ldb) */,
+                           void* stream);
+/* weight gradient dW[N][K] = sum_m s_m dY[m][n] X[m][k] as split products (both f32 operands split in the kernel's loader): the arguments and the slab protocol
+ * of gg_gemm_tn_f32 (partials [splits][N][K], reduced by gg_splitk_reduce); splits from gg_gemm_tn_split3_splits. */
+int gg_gemm_tn_split3_splits(int M, int N, int K);
+int gg_gemm_tn_split3(const float* dY, int64_t ldy, const float* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale, float* partials,
+                      int splits, void* stream);
 
 /* ---------------------------------------------------------------- reference-precision (fp32) mode
  * The reference computes this whole path in fp32 (torch defaults).  These entry points are the f32-storage twins
