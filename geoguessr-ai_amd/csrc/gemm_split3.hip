@@ -39,6 +39,7 @@ struct Split3Params {
     const float* residual; int64_t ldr;
     const float* dact_preact; int dact;
     bf16* c_planes; int64_t ldp;
+    float* colstats;                   // BatchNorm partials [ceil(M / 128)][2][N] (column sums of the result and of its square per 128-row block; plain epilogue only) or null
 };
 
 // one 4-column group of one row in the MFMA result layout (lane: row m, columns n .. n + 3)
@@ -101,7 +102,8 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
     constexpr int LDT = BN + 4;                                   // padded row: conflict-free 16-byte column writes from the MFMA layout
     constexpr int CPR = BN / 8;                                   // 8-column chunks per row
     constexpr int RPP = NTHR / CPR;                               // rows per pass
-    if ((int)threadIdx.x >= RPP * CPR) return;                     // (BN = 96: 12 chunks per row do not divide the block; no barrier follows)
+    const bool live = (int)threadIdx.x < RPP * CPR;                // (BN = 96: 12 chunks per row do not divide the block)
+    if (!live && !p.colstats) return;                              // (no barrier follows without column statistics)
     const int chunk = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
     const int n = n0 + chunk * 8;
     const bool nfull = n + 7 < p.N;
@@ -109,7 +111,10 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = (p.bias && n + j < p.N) ? p.bias[n + j] : 0.f;
     const int64_t plane = (int64_t)p.M * p.ldp;
-    for (int rr = r0; rr < BM; rr += RPP) {
+    float cs[2][8], cq[2][8];                                        // column sums of this thread's rows, per 128-row block (p.colstats)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[0][j] = cs[1][j] = cq[0][j] = cq[1][j] = 0.f;
+    for (int rr = r0; rr < BM && live; rr += RPP) {
         const int m = m0 + rr;
         if (m >= p.M || n >= p.N) continue;
         float v[8];
@@ -164,6 +169,11 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
             for (int j = 0; j < 8; ++j) v[j] += t[j];
         }
         if (p.C) st8(p.C, p.ldc, v);
+        if (p.colstats) {
+            const float hi = rr >= 128 ? 1.f : 0.f, lo = 1.f - hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { cs[0][j] += lo * v[j]; cq[0][j] += lo * v[j] * v[j]; cs[1][j] += hi * v[j]; cq[1][j] += hi * v[j] * v[j]; }
+        }
         if (p.c_planes) {
             bf16x8 p1, p2, p3;
 #pragma unroll
@@ -180,6 +190,29 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (n + j < p.N) { q[j] = p1[j]; q[plane + j] = p2[j]; q[2 * plane + j] = p3[j]; }
             }
+        }
+    }
+    if (p.colstats) {
+        // thread partials -> LDS [block][which][r0][BN] (the tile image is dead after the barrier) -> one thread per (block, which, column) adds the RPP rows in order
+        constexpr int PARTS = BM / 128;
+        __syncthreads();
+        if (live) {
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    Ct[((part * 2 + 0) * RPP + r0) * BN + chunk * 8 + j] = cs[part][j];
+                    Ct[((part * 2 + 1) * RPP + r0) * BN + chunk * 8 + j] = cq[part][j];
+                }
+        }
+        __syncthreads();
+        const int nparts = (p.M + 127) / 128;
+        for (int t = threadIdx.x; t < PARTS * 2 * BN; t += NTHR) {
+            const int part = t / (2 * BN), which = (t / BN) & 1, col = t % BN;
+            float sum = 0.f;
+            for (int q = 0; q < RPP; ++q) sum += Ct[((part * 2 + which) * RPP + q) * BN + col];
+            const int prow = m0 / 128 + part;
+            if (prow < nparts && n0 + col < p.N) p.colstats[((int64_t)prow * 2 + which) * p.N + n0 + col] = sum;
         }
     }
 }
@@ -1032,7 +1065,7 @@ extern "C" int gg_gemm_nt_split3_ex(const GgSplit3Args* a, void* stream) {
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
     p.act = a->act; p.preact = a->preact; p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = a->residual; p.ldr = a->ldr;
-    p.dact_preact = a->dact_preact; p.dact = a->dact; p.c_planes = (bf16*)a->c_planes; p.ldp = a->ldp;
+    p.dact_preact = a->dact_preact; p.dact = a->dact; p.c_planes = (bf16*)a->c_planes; p.ldp = a->ldp; p.colstats = nullptr;
     return split3_launch(p, stream);
 }
 
@@ -1045,7 +1078,12 @@ extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* 
 }
 
 // A as f32 [M][lda] (split in the kernel's loader), B as planes b_plane_stride elements apart (0: N * ldb): args->a_planes / lda are ignored
+// colstats (optional; plain epilogue only): BatchNorm partials [ceil(M / 128)][2][N] as gg_gemm_nt_f32 writes them (GgGemmArgs.colstats)
+extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, void* stream);
 extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, void* stream) {
+    return gg_gemm_nt_split3_af32_stats(a, A, lda, b_plane_stride, nullptr, stream);
+}
+extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, void* stream) {
     GG_CHECK(a && A && a->b_planes && (a->C || a->c_planes) && a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_split3_af32: null pointer / bad shape");
     GG_CHECK((a->K & 7) == 0 && (lda & 3) == 0 && (a->ldb & 7) == 0 && lda >= a->K && a->ldb >= a->K, "gg_gemm_nt_split3_af32: K %% 8, lda %% 4, ldb %% 8, ld >= K");
     GG_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)a->b_planes & 15) == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->c_planes & 7) == 0, "gg_gemm_nt_split3_af32: alignment");
@@ -1054,7 +1092,9 @@ extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int
     GG_CHECK((!a->preact && !a->dact_preact) || a->ldc >= a->N, "gg_gemm_nt_split3_af32: preact / dact_preact use ldc");
     GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3_af32: rowscale needs rows_per_scale");
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3_af32: act and dact_preact are exclusive");
+    GG_CHECK(!colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->c_planes), "gg_gemm_nt_split3_af32: colstats needs the plain epilogue");
     Split3Params p;
+    p.colstats = colstats;
     p.A = nullptr; p.lda = 0; p.plane_a = 0; p.Af = A; p.ldaf = lda;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = b_plane_stride > 0 ? b_plane_stride : (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;

@@ -84,6 +84,10 @@ static void make_bn(Model& m, BNP& bn, const std::string& prefix, int C) {
 static void make_convbn_dense(Model& m, ConvBNDense& c, const std::string& prefix, int cin, int cout, int taps) {
     make_dense(m, c.w, prefix + ".conv.weight", cout, cin, taps, nullptr, true);
     make_bn(m, c.bn, prefix, cout);
+    if (m.split) {      // planes of W: the forward of a ConvNorm's dense convolution (plain epilogue + BatchNorm partials) runs as a split product
+        c.w.wn3 = wc_alloc(m, (int64_t)3 * c.w.N * c.w.Kp * 2);
+        m.plane_of.push_back({c.w.wn, c.w.wn3, c.w.N, c.w.Kp});
+    }
 }
 static void make_convbn_dw(Model& m, ConvBNDw& c, const std::string& prefix, int C) {
     c.w.C = C;
@@ -520,7 +524,7 @@ static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const act_t* dz, co
 static int gemm(const Exec& e, const act_t* A, int64_t lda, const act_t* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
                 const float* bias = nullptr, int act = 0, void* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
                 const act_t* residual = nullptr, float* colstats = nullptr, const act_t* dact_pre = nullptr, int dact = 0) {
-    if (e.m->split && !colstats && M >= 256 && (K & 7) == 0 && (lda & 3) == 0) {
+    if (e.m->split && M >= 256 && (K & 7) == 0 && (lda & 3) == 0 && (!colstats || !(bias || act || preact || rowscale || residual || dact_pre))) {
         // fp32_split mode: a Linear whose weight operand has cached planes runs as a split product (A = the f32 activation itself, split in the kernel's loader)
         const int64_t off = reinterpret_cast<const char*>(Bm) - e.wc;
         for (const Model::PlaneOf& po : e.m->plane_of) {
@@ -531,7 +535,7 @@ static int gemm(const Exec& e, const act_t* A, int64_t lda, const act_t* Bm, int
             g.b_planes = e.wc + po.planes; g.ldb = ldb; g.M = (int)M; g.N = N; g.K = K; g.C = (float*)C; g.ldc = ldc;
             g.bias = bias; g.act = act; g.preact = (float*)preact; g.rowscale = rowscale; g.rows_per_scale = rps; g.residual = (const float*)residual; g.ldr = ldc;
             g.dact_preact = (const float*)dact_pre; g.dact = dact;
-            return gg_gemm_nt_split3_af32(&g, (const float*)A, lda, (int64_t)po.rows * po.ld, e.st);
+            return gg_gemm_nt_split3_af32_stats(&g, (const float*)A, lda, (int64_t)po.rows * po.ld, colstats, e.st);
         }
     }
     GgGemmArgs g;

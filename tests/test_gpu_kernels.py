@@ -790,6 +790,34 @@ def test_split3_gemm_with_f32_activation_operand(ops, M, N, K, lda):
     assert rel(got, ops.gemm_nt(Ac, B, dact_preact=pre, dact="gelu", rowscale=scale, rows_per_scale=rps)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 200, 96), (700, 192, 416), (5000, 384, 96), (300, 48, 32)])
+def test_split3_gemm_batchnorm_partials(M, N, K):
+    """gg_gemm_nt_split3_af32_stats: the plain-epilogue split product of a ConvNorm's dense convolution also leaves the BatchNorm partials GgGemmArgs.colstats
+    defines -- per 128-row block the column sums of the result and of its square, [ceil(M / 128)][2][N] -- in both tile heights and both tile widths."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).cuda(); B = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    Bp = torch.empty(3, N, K, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().gg_split3_bf16(B.data_ptr(), N, K, K, Bp.data_ptr(), L.stream()), "gg_split3_bf16")
+    parts = (M + 127) // 128
+    out = torch.empty(M, N, device="cuda"); stats = torch.full((parts, 2, N), float("nan"), device="cuda")
+    a = L.Split3Args()
+    a.b_planes, a.ldb, a.M, a.N, a.K, a.C, a.ldc = Bp.data_ptr(), K, M, N, K, out.data_ptr(), N
+    L.check(L.lib().gg_gemm_nt_split3_af32_stats(C.byref(a), A.data_ptr(), K, 0, stats.data_ptr(), L.stream()), "gg_gemm_nt_split3_af32_stats")
+    ref = A.double() @ B.double().T
+    assert float((out.double() - ref).norm() / ref.norm()) < 1e-6
+    pad = torch.zeros(parts * 128, N, dtype=torch.float64, device="cuda"); pad[:M] = out.double()
+    blk = pad.view(parts, 128, N)
+    want = torch.stack([blk.sum(1), (blk * blk).sum(1)], 1)
+    assert torch.isfinite(stats).all()
+    assert float((stats.double() - want).abs().max() / want.abs().max()) < 1e-5
+    out2 = torch.empty(M, N, device="cuda"); stats2 = torch.empty_like(stats)
+    a.C = out2.data_ptr()
+    L.check(L.lib().gg_gemm_nt_split3_af32_stats(C.byref(a), A.data_ptr(), K, 0, stats2.data_ptr(), L.stream()), "gg_gemm_nt_split3_af32_stats")
+    assert torch.equal(stats, stats2) and torch.equal(out, out2)            # no atomics: repeatable
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os
