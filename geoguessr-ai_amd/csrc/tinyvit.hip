@@ -87,6 +87,8 @@ static void make_convbn_dense(Model& m, ConvBNDense& c, const std::string& prefi
     if (m.split) {      // planes of W: the forward of a ConvNorm's dense convolution (plain epilogue + BatchNorm partials) runs as a split product
         c.w.wn3 = wc_alloc(m, (int64_t)3 * c.w.N * c.w.Kp * 2);
         m.plane_of.push_back({c.w.wn, c.w.wn3, c.w.N, c.w.Kp});
+        c.w.wt3 = wc_alloc(m, (int64_t)3 * c.w.Kp * c.w.Np * 2);      // ... and of W^T: the data gradients that go through the plain / Linear epilogues
+        m.plane_of.push_back({c.w.wt, c.w.wt3, c.w.Kp, c.w.Np});
     }
 }
 static void make_convbn_dw(Model& m, ConvBNDw& c, const std::string& prefix, int C) {
