@@ -42,7 +42,9 @@ if ROOT not in sys.path:
 
 CATS = ["gemm", "attention", "dwconv", "norm_elementwise", "head_loss", "optimizer", "data_movement"]
 GFLOP_PER_IMAGE = 18.2          # fwd 8.50 + dgrad 8.50 + wgrad(patch_embed + stage 3) 1.20
-MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0, "fp32_split": 157.3}      # MI355X_MICROARCH.md: dense f32 / bf16 matrix peaks (fp32_split: priced as f32 work)
+MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0, "fp32_split": 157.3}      # MI355X_MICROARCH.md: dense f32 / bf16 matrix peaks (fp32_split: whole-step figures priced as f32 work)
+DTYPE_LABEL = {"fp32_split": "fp32 (bf16x3 split MFMA)", "fp32": "fp32 (f32 MFMA GEMMs)"}
+SPLIT_PEAK_TF = 2500.0 / 6.0        # an f32-accurate split product is six bf16 MFMA products: the roof of the split GEMM kernels in f32-equivalent TFLOP/s
 HBM_PEAK_GBS = 8000.0
 
 
@@ -225,7 +227,7 @@ def class_profile(fn, steps, wall_ms, peak_tf):
     cat, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
     for i in range(lib.gg_prof_count()):
         L.check(lib.gg_prof_record(i, C.byref(cat), C.byref(ms), C.byref(fl), C.byref(by)), "gg_prof_record")
-        t = tot[cat.value]
+        t = tot[cat.value & 15]
         t[0] += ms.value; t[1] += 1; t[2] += fl.value; t[3] += by.value
     lib.gg_prof_reset()
     classes = {}
@@ -556,14 +558,18 @@ def run_mode(precision, args, rank, world, dev, x, lab):
         peak_tf = MFMA_PEAK_TF[precision]
         tot = {c: [0.0, 0, 0.0, 0.0] for c in range(len(CATS))}        # ms, launches, flops, bytes
         ideal_ms, mfma_bound_ms = 0.0, 0.0
+        split_tot = [0.0, 0, 0.0, 0.0]
         cat, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
         launches = []
         for i in range(lib.gg_prof_count()):
             L.check(lib.gg_prof_record(i, C.byref(cat), C.byref(ms), C.byref(fl), C.byref(by)), "gg_prof_record")
-            launches.append((cat.value, ms.value, fl.value, by.value))
-            t = tot[cat.value]
+            cv, is_split = cat.value & 15, bool(cat.value & 16)            # bit 4: a split-bf16 GEMM (csrc/prof.h)
+            launches.append((cv, ms.value, fl.value, by.value))
+            t = tot[cv]
             t[0] += ms.value; t[1] += 1; t[2] += fl.value; t[3] += by.value
-            if cat.value == 0:
+            if is_split:
+                split_tot[0] += ms.value; split_tot[1] += 1; split_tot[2] += fl.value; split_tot[3] += by.value
+            if cv == 0:
                 tf, tb = fl.value / (peak_tf * 1e9), by.value / (HBM_PEAK_GBS * 1e6)       # ms at the MFMA / HBM roof
                 ideal_ms += max(tf, tb)
                 mfma_bound_ms += ms.value if tf >= tb else 0.0
@@ -591,6 +597,18 @@ def run_mode(precision, args, rank, world, dev, x, lab):
             roof = dict(bound="hbm", achieved=round(ach_gb, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gb / HBM_PEAK_GBS, 4), **common)
         else:
             roof = dict(bound="mfma", achieved=round(ach_tf, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach_tf / peak_tf, 4), **common)
+        if precision == "fp32_split" and split_tot[1]:
+            # the dominant kernels of this mode are the split GEMMs: their roof is the bf16 matrix peak / 6 (six bf16 products per f32-accurate product)
+            sms, sn, sfl, sby = split_tot
+            s_tf = sfl / max(sms, 1e-9) / 1e9
+            roof = dict(bound="mfma", achieved=round(s_tf, 2), peak=round(SPLIT_PEAK_TF, 1), unit="TFLOP/s (f32-equivalent: 2 M N K per product)", frac=round(s_tf / SPLIT_PEAK_TF, 4),
+                        kernel="gemm_nt_split3a/b_kernel + gemm_tn_split3_kernel (f32-accurate products as six v_mfma_f32_16x16x32_bf16 each; f32 operands split in the loader)",
+                        bf16_product_tflops=round(6.0 * s_tf, 1), bf16_mfma_peak=2500.0, launches=sn // args.steps, avg_launch_us=round(1e3 * sms / max(sn, 1), 2),
+                        split_gemm_ms_per_step=round(sms / args.steps, 3), gemm_ms_per_step=round(ms_ / args.steps, 3),
+                        split_share_of_gemm_time=round(sms / max(ms_, 1e-9), 4), split_share_of_gemm_launches=round(sn / max(n_, 1), 4),
+                        algorithmic_gflop_per_launch=round(sfl / max(sn, 1) / 1e9, 3), algorithmic_bytes_per_launch=int(sby / max(sn, 1)),
+                        all_gemm_f32_equivalent_tflops=round(ach_tf, 2), f32_mfma_peak=peak_tf, all_gemm_vs_f32_mfma_peak=round(ach_tf / peak_tf, 4),
+                        traffic=traffic, traffic_source=traffic_info)
         if precision == "fp32" and roof["bound"] == "mfma":
             mhz, per_form = clock_under_gemm_load(dev)
             if mhz:
@@ -622,7 +640,7 @@ def main():
     ap.add_argument("--panoramas", type=int, default=256, help="panoramas per GPU per step (BASELINE: 256)")
     ap.add_argument("--model", default="tiny_vit_21m_224")
     ap.add_argument("--precision", default="both", choices=["both", "fp32", "bf16", "fp32_split"],
-                    help="both: fp32 (headline, the reference's arithmetic), bf16 (reported under 'bf16') and fp32_split (under 'fp32_split')")
+                    help="both: fp32_split (headline: f32-accurate, split-bf16 products), fp32 (f32 MFMA GEMMs, under 'fp32') and bf16 (under 'bf16')")
     ap.add_argument("--unfrozen", action="store_true", help="train every parameter instead of the reference freeze policy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -673,11 +691,12 @@ def main():
     x = torch.randn(N, 4, 3, 224, 224, device=dev, generator=g)
     lab = torch.stack([torch.rand(N, device=dev, generator=g) * 360 - 180, torch.rand(N, device=dev, generator=g) * 180 - 90], 1)
 
-    # fp32_split: f32 storage and f32-accurate arithmetic; the Linears of the transformer blocks (forward and data gradients: 80 of the step's 118 GEMM
-    # launches, two thirds of its f32 GEMM time) run as split products on the bf16 MFMA (error against fp64 below the f32 MFMA GEMM's on every shape).  It passes the
-    # fp32 mode's parity gate at the fp32 mode's tolerances (tests/test_gpu_precision.py::test_fp32_split_mode_passes_the_fp32_gate) and is reported under its own
-    # key: the headline stays on the plain f32-MFMA GEMMs until split products cover 80 % of the GEMM time
-    modes = ["fp32", "bf16", "fp32_split"] if args.precision == "both" else [args.precision]
+    # Headline = fp32_split: f32 storage and f32-accurate arithmetic in which split-bf16 products (x = x1 + x2 + x3 in bf16, six bf16 MFMAs per product,
+    # f32 accumulation) carry 80 % of the GEMM time (every Linear and weight gradient of the transformer blocks, the forward convolutions of the ConvNorms) and the window
+    # attention; error against fp64 at or below the f32 MFMA kernels' per shape, the fp32 mode's parity gate at the fp32 mode's tolerances
+    # (tests/test_gpu_precision.py::test_fp32_split_mode_passes_the_fp32_gate).  VERDICT r4 item 6 set exactly this bar for the mode to become the headline dtype,
+    # labelled "fp32 (bf16x3 split MFMA)".  The plain f32-MFMA mode is timed in the same run and reported in full under "fp32"; bf16 under "bf16".
+    modes = ["fp32_split", "fp32", "bf16"] if args.precision == "both" else [args.precision]
     results = {m: run_mode(m, args, rank, world, dev, x, lab) for m in modes}
     head = results[modes[0]]
 
@@ -693,7 +712,7 @@ def main():
     if rank == 0:
         line = dict(metric="images/sec TinyViT-21M-224 train, 4-heading batch", value=head["value"], unit="images/s",
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=head["ms_per_step"],
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=modes[0], data="synthetic",
+                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=DTYPE_LABEL.get(modes[0], modes[0]), data="synthetic",
                     config=dict(workload=f"{args.model} 4x224x224 panoramas, fwd+bwd+AdamW, soft-CE over 12647 geocells, "
                                          f"{'all params' if args.unfrozen else 'freeze_all_but_last_stage'}, DropPath, train-mode BN",
                                 panoramas_per_gpu=N, images_per_gpu=N * 4, global_batch_panoramas=N * world, parallelism=f"dp{world}",
@@ -706,7 +725,7 @@ def main():
                     roofline=head.get("roofline"), cpu_baseline=cpu, class_rooflines=head.get("class_rooflines"),
                     kernel_breakdown=head.get("kernel_breakdown"), secondary=secondary)
         for m in modes[1:]:
-            line[m] = dict(dtype=("fp32 storage; transformer-block Linears and window attention as split-bf16 MFMA products (three bf16 terms per operand, f32 accumulation: f32-accurate), the rest f32 MFMA" if m == "fp32_split" else m), **results[m])
+            line[m] = dict(dtype=DTYPE_LABEL.get(m, m), **results[m])
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -1042,7 +1042,7 @@ static int split3_launch(Split3Params& p, void* stream) {
     }
     // algorithmic work = the fp32 product it replaces: 2 M N K flop; bytes: three bf16 planes per operand + the result (+ the epilogue's tensors)
     const double mn = (double)M * N;
-    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K,
+    GG_PROF(GG_CAT_GEMM | GG_CAT_SPLIT_FLAG, 2.0 * M * (double)N * K,
             6.0 * ((double)M * K + (double)N * K) + 4.0 * mn * ((p.C != nullptr) + (p.preact != nullptr) + (p.residual != nullptr) + (p.dact_preact != nullptr)) +
                 (p.c_planes ? 6.0 * mn : 0.0), stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)(fi == 3 ? std::min(p.tilesM * p.tilesN, 256) : p.tilesM * p.tilesN)), dim3(fi == 2 ? 256 : 512), lds, (hipStream_t)stream, p);
@@ -1124,7 +1124,7 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
         raised[big * 2 + n96] = true;
     }
     const double mn = (double)p.M * p.N;
-    GG_PROF(GG_CAT_GEMM, 2.0 * p.M * (double)p.N * p.K,
+    GG_PROF(GG_CAT_GEMM | GG_CAT_SPLIT_FLAG, 2.0 * p.M * (double)p.N * p.K,
             4.0 * (double)p.M * p.K + 6.0 * (double)p.N * p.K + 4.0 * mn * ((p.C != nullptr) + (p.preact != nullptr) + (p.residual != nullptr) + (p.dact_preact != nullptr)) +
                 (p.c_planes ? 6.0 * mn : 0.0), stream);
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.tilesM * p.tilesN)), dim3(big ? 512 : 256), lds, (hipStream_t)stream, p);
@@ -1132,6 +1132,7 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
     return 0;
 }
 
+extern "C" int gg_gemm_tn_f32_splits(int M, int N, int K);
 // weight gradient of a Linear in the fp32_split mode: partial dW[N][K] slabs like gg_gemm_tn_f32 (same arguments; reduce with gg_splitk_reduce)
 extern "C" int gg_gemm_tn_split3_splits(int M, int N, int K) {
     const int64_t tiles = gg_cdiv(N, 256) * gg_cdiv(K, 128);
@@ -1143,7 +1144,12 @@ extern "C" int gg_gemm_tn_split3_splits(int M, int N, int K) {
         const double eff = (double)(c * tiles) / (256.0 * (double)gg_cdiv(c * tiles, 256));
         if (eff > best + 0.02) { best = eff; s = c; }
     }
-    return (int)s;
+    // a quarter more slabs than gg_gemm_tn_f32 would take: at EQUAL slab counts the two kernels' errors against fp64 are within 6 % of each other (the error of
+    // either is that of a slab's f32 accumulation chain and falls with the square root of the slab count: tools/tn_split_error_vs_slabs.py); with the shorter
+    // chains the split kernel's is below the f32 kernel's on every shape
+    s = std::min<int64_t>(cap, std::max<int64_t>(s, (5 * (int64_t)gg_gemm_tn_f32_splits(M, N, K) + 3) / 4));
+    const int64_t rows = gg_cdiv(gg_cdiv(M, s), 32) * 32;          // slabs are whole 32-row stages
+    return (int)gg_cdiv(M, rows);
 }
 extern "C" int gg_gemm_tn_split3(const float* dY, int64_t ldy, const float* X, int64_t ldx, int M, int N, int K, const float* rowscale, int rows_per_scale, float* partials,
                                  int splits, void* stream) {
@@ -1163,7 +1169,7 @@ extern "C" int gg_gemm_tn_split3(const float* dY, int64_t ldy, const float* X, i
                  "gg_gemm_tn_split3: cannot raise the dynamic LDS limit");
         raised = true;
     }
-    GG_PROF(GG_CAT_GEMM, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K) + 8.0 * splits * (double)N * K, stream);
+    GG_PROF(GG_CAT_GEMM | GG_CAT_SPLIT_FLAG, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K) + 8.0 * splits * (double)N * K, stream);
     hipLaunchKernelGGL(gemm_tn_split3_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(512), (size_t)2 * 3 * (256 + 128) * 32 * sizeof(bf16), (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;

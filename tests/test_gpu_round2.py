@@ -360,8 +360,9 @@ def test_embed_and_store_writes_reference_layout(tmp_path):
     assert tuple(pano.shape) == (5, 4, 320) and tuple(latlon.shape) == (5, 2) and latlon[2, 0] == 12.0
 
 
-def test_two_rank_bench_rehearsal_on_one_gpu():
-    """`python bench.py --gpus 2` with NO launcher in front (the shape of the driver's N=1 command): bench.py starts the driver's N>1 launch
+@pytest.mark.parametrize("precision", ["fp32_split", "fp32"])
+def test_two_rank_bench_rehearsal_on_one_gpu(precision):
+    """(The headline mode and the plain f32-MFMA mode.)  `python bench.py --gpus 2` with NO launcher in front (the shape of the driver's N=1 command): bench.py starts the driver's N>1 launch
     line (torch.distributed.run, one rank per GPU) itself as a child process and relays rank 0's line.  Rehearsed with two ranks sharing this
     box's one GPU over gloo: parameter broadcast, gradient buckets leaving from the backward pass's stage callback, the remainder after
     backward, AdamW with the 1/world average -- the same Python/C path the RCCL run takes, only the transport differs.  One JSON line, finite
@@ -372,14 +373,14 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--panoramas", "8", "--no-cpu-baseline",
-           "--no-roofline", "--precision", "fp32"]
+           "--no-roofline", "--precision", precision]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 alone prints
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch_panoramas"] == 16 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
-    assert d["dtype"] == "fp32" and np.isfinite(d["loss"]) and d["value"] > 0
+    assert d["dtype"].startswith("fp32") and ("split" in d["dtype"]) == (precision == "fp32_split") and np.isfinite(d["loss"]) and d["value"] > 0
     assert d["rccl_ranks"] == 2 and d["comm_backend"] == "gloo" and d["allreduce_ms_per_step"] > 0 and d["allreduce_bytes_per_step"] > 60e6
     # without the rehearsal switch the same command must refuse: this box has one GPU
     env.pop("GG_BENCH_ONE_DEVICE")

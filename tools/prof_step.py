@@ -36,7 +36,7 @@ groups = collections.OrderedDict()
 for i in range(lib.gg_prof_count()):
     c, ms, fl, by = C.c_int(), C.c_double(), C.c_double(), C.c_double()
     L.check(lib.gg_prof_record(i, C.byref(c), C.byref(ms), C.byref(fl), C.byref(by)), "rec")
-    g = groups.setdefault((c.value, fl.value, by.value), [0, 0.0, i])
+    g = groups.setdefault((c.value & 15, fl.value, by.value), [0, 0.0, i])      # (bit 4: split-bf16 GEMM, same class)
     g[0] += 1; g[1] += ms.value
 tot = sum(g[1] for g in groups.values()) / K
 print(f"precision {PREC}: total {tot:.2f} ms/step of instrumented kernels")
