@@ -818,6 +818,35 @@ def test_split3_gemm_batchnorm_partials(M, N, K):
     assert torch.equal(stats, stats2) and torch.equal(out, out2)            # no atomics: repeatable
 
 
+@pytest.mark.parametrize("M,N,K,rps", [(5003, 200, 136, 7), (40, 8, 12, 0), (9000, 576, 320, 49), (4096, 260, 132, 0), (1100, 96, 432, 64)])
+def test_split3_weight_gradient_gemm(M, N, K, rps):
+    """gg_gemm_tn_split3 (the fp32_split mode's weight gradient): dW[N][K] = sum_m s_m dY[m][n] X[m][k] with both f32 operands split in the kernel's loader, row slabs
+    reduced by gg_splitk_reduce -- against an fp64 product (ragged row counts, N / K that are not multiples of the 256 x 128 tile, a DropPath row scale with zeros,
+    strided operands), at the accuracy of gg_gemm_tn_f32 and repeatable bit for bit."""
+    from geoguessr_ai_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    dYf = torch.randn(M, N + 4, generator=g).cuda(); Xf = torch.randn(M, K + 8, generator=g).cuda()
+    dY, X = dYf[:, :N], Xf[:, :K]
+    scale = ((torch.rand((M + rps - 1) // rps, generator=g) > 0.3).float() / 0.7).cuda() if rps else None
+    scratch = torch.empty(8 << 20, device="cuda")
+
+    def run(kind, out):
+        fn_s, fn = (lib.gg_gemm_tn_split3_splits, lib.gg_gemm_tn_split3) if kind == "split" else (lib.gg_gemm_tn_f32_splits, lib.gg_gemm_tn_f32)
+        s = fn_s(M, N, K)
+        assert s >= 1 and s * N * K <= scratch.numel()
+        L.check(fn(dYf.data_ptr(), dYf.stride(0), Xf.data_ptr(), Xf.stride(0), M, N, K, scale.data_ptr() if rps else None, rps, scratch.data_ptr(), s, L.stream()), kind)
+        L.check(lib.gg_splitk_reduce(scratch.data_ptr(), out.data_ptr(), N * K, s, 0, 1.0, L.stream()), "gg_splitk_reduce")
+    o3, o3b, o32 = (torch.empty(N, K, device="cuda") for _ in range(3))
+    run("split", o3); run("f32", o32); run("split", o3b)
+    w = scale.double().repeat_interleave(rps)[:M, None] if rps else 1.0
+    ref = (dY.double() * w).T @ X.double()
+    e3 = float((o3.double() - ref).norm() / ref.norm()); e32 = float((o32.double() - ref).norm() / ref.norm())
+    print(f"\n[tn split {M}x{N}x{K}] rel-L2 vs fp64: split {e3:.2e}, f32-MFMA {e32:.2e}")
+    assert e3 < 2e-6 and e3 < 1.5 * e32 + 2e-7
+    assert torch.equal(o3, o3b)
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os
