@@ -526,7 +526,10 @@ static int gemm_folded_dgrad(const Exec& e, const DenseW& w, const act_t* dz, co
 static int gemm(const Exec& e, const act_t* A, int64_t lda, const act_t* Bm, int64_t ldb, void* C, int64_t ldc, int64_t M, int N, int K,
                 const float* bias = nullptr, int act = 0, void* preact = nullptr, const float* rowscale = nullptr, int rps = 0,
                 const act_t* residual = nullptr, float* colstats = nullptr, const act_t* dact_pre = nullptr, int dact = 0) {
-    if (e.m->split && M >= 256 && (K & 7) == 0 && (lda & 3) == 0 && (!colstats || !(bias || act || preact || rowscale || residual || dact_pre))) {
+    // (launch-bound sizes stay on the f32 GEMM, whose 64 x 64 tiles and split-K fill the chip where a 256- / 128-row split tile would leave most CUs idle:
+    // the split form needs at least half the CUs' worth of tiles)
+    const int64_t split_tiles = ((M + (K >= 384 ? 255 : 127)) / (K >= 384 ? 256 : 128)) * ((N + 127) / 128);
+    if (e.m->split && split_tiles >= 128 && (K & 7) == 0 && (lda & 3) == 0 && (!colstats || !(bias || act || preact || rowscale || residual || dact_pre))) {
         // fp32_split mode: a Linear whose weight operand has cached planes runs as a split product (A = the f32 activation itself, split in the kernel's loader)
         const int64_t off = reinterpret_cast<const char*>(Bm) - e.wc;
         for (const Model::PlaneOf& po : e.m->plane_of) {
