@@ -40,8 +40,6 @@ struct Split3Params {
     const float* dact_preact; int dact;
     bf16* c_planes; int64_t ldp;
     float* colstats;                   // BatchNorm partials [ceil(M / 128)][2][N] (column sums of the result and of its square per 128-row block; plain epilogue only) or null
-    // BatchNorm-backward epilogue (with colstats): C = dz = acc * act'(BN(bn_y)), partials = column sums of (dz, dz * xhat)   [gg_gemm_nt_f32's FE_BNBWD]
-    const float* bn_y; const float* bn_stat; const float* bn_gamma; const float* bn_beta; int bn_act;
 };
 
 // one 4-column group of one row in the MFMA result layout (lane: row m, columns n .. n + 3)
@@ -114,16 +112,6 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
     for (int j = 0; j < 8; ++j) bv[j] = (p.bias && n + j < p.N) ? p.bias[n + j] : 0.f;
     const int64_t plane = (int64_t)p.M * p.ldp;
     float cs[2][8], cq[2][8];                                        // column sums of this thread's rows, per 128-row block (p.colstats)
-    float bsc[8], bsh[8], brs[8], bnm[8];                            // BatchNorm-backward epilogue: act'(y * bsc + bsh), xhat = y * brs + bnm of this thread's 8 columns
-    if (p.bn_y) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const bool ok = n + j < p.N;
-            const float mu = ok ? p.bn_stat[n + j] : 0.f, rsd = ok ? p.bn_stat[p.N + n + j] : 0.f;
-            bsc[j] = rsd * (ok ? p.bn_gamma[n + j] : 0.f); bsh[j] = (ok ? p.bn_beta[n + j] : 0.f) - mu * bsc[j];
-            brs[j] = rsd; bnm[j] = -mu * rsd;
-        }
-    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[0][j] = cs[1][j] = cq[0][j] = cq[1][j] = 0.f;
     for (int rr = r0; rr < BM && live; rr += RPP) {
@@ -156,17 +144,6 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
                 for (int j = 0; j < 8; ++j) if (n + j < p.N) q[j] = t[j];
             }
         };
-        float xh[8];
-        if (p.bn_y) {
-            float yv[8];
-            ld8(p.bn_y, p.ldc, yv);
-            float z[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { z[j] = fmaf(yv[j], bsc[j], bsh[j]); xh[j] = fmaf(yv[j], brs[j], bnm[j]); }
-            const f32x4 g0 = gg_act_grad_f32_v4((f32x4){z[0], z[1], z[2], z[3]}, p.bn_act), g1 = gg_act_grad_f32_v4((f32x4){z[4], z[5], z[6], z[7]}, p.bn_act);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] *= g0[j]; v[4 + j] *= g1[j]; }
-        }
         if (p.preact) st8(p.preact, p.ldc, v);
         // (the packed forms: GELU / GELU' on two lanes of a v_pk_* instruction -- the scalar forms were a third of these launches' time at K = 192)
         if (p.dact_preact) {
@@ -195,10 +172,7 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
         if (p.colstats) {
             const float hi = rr >= 128 ? 1.f : 0.f, lo = 1.f - hi;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float w2 = v[j] * (p.bn_y ? xh[j] : v[j]);      // sum of squares (forward statistics) or of dz * xhat (BatchNorm backward)
-                cs[0][j] += lo * v[j]; cq[0][j] += lo * w2; cs[1][j] += hi * v[j]; cq[1][j] += hi * w2;
-            }
+            for (int j = 0; j < 8; ++j) { cs[0][j] += lo * v[j]; cq[0][j] += lo * v[j] * v[j]; cs[1][j] += hi * v[j]; cq[1][j] += hi * v[j] * v[j]; }
         }
         if (p.c_planes) {
             bf16x8 p1, p2, p3;
@@ -1092,7 +1066,6 @@ extern "C" int gg_gemm_nt_split3_ex(const GgSplit3Args* a, void* stream) {
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
     p.act = a->act; p.preact = a->preact; p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = a->residual; p.ldr = a->ldr;
     p.dact_preact = a->dact_preact; p.dact = a->dact; p.c_planes = (bf16*)a->c_planes; p.ldp = a->ldp; p.colstats = nullptr;
-    p.bn_y = nullptr; p.bn_stat = nullptr; p.bn_gamma = nullptr; p.bn_beta = nullptr; p.bn_act = 0;
     return split3_launch(p, stream);
 }
 
@@ -1106,18 +1079,11 @@ extern "C" int gg_gemm_nt_split3(const void* a_planes, int64_t lda, const void* 
 
 // A as f32 [M][lda] (split in the kernel's loader), B as planes b_plane_stride elements apart (0: N * ldb): args->a_planes / lda are ignored
 // colstats (optional; plain epilogue only): BatchNorm partials [ceil(M / 128)][2][N] as gg_gemm_nt_f32 writes them (GgGemmArgs.colstats)
-extern "C" int gg_gemm_nt_split3_af32_bnbwd(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, const float* bn_y, const float* bn_stat,
-                                            const float* bn_gamma, const float* bn_beta, int bn_act, void* stream);
+extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, void* stream);
 extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, void* stream) {
-    return gg_gemm_nt_split3_af32_bnbwd(a, A, lda, b_plane_stride, nullptr, nullptr, nullptr, nullptr, nullptr, 0, stream);
+    return gg_gemm_nt_split3_af32_stats(a, A, lda, b_plane_stride, nullptr, stream);
 }
 extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, void* stream) {
-    return gg_gemm_nt_split3_af32_bnbwd(a, A, lda, b_plane_stride, colstats, nullptr, nullptr, nullptr, nullptr, 0, stream);
-}
-// ... and the BatchNorm-backward epilogue of a ConvNorm's data gradient (gg_gemm_nt_f32 with bn_y): C = dz = (A . W^T) * act'(BN(bn_y)) with bn_y [M][ldc],
-// bn_stat = [mean | rstd][N]; colstats (required) <- column sums of (dz, dz * xhat) per 128-row block
-extern "C" int gg_gemm_nt_split3_af32_bnbwd(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, const float* bn_y, const float* bn_stat,
-                                            const float* bn_gamma, const float* bn_beta, int bn_act, void* stream) {
     GG_CHECK(a && A && a->b_planes && (a->C || a->c_planes) && a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_split3_af32: null pointer / bad shape");
     GG_CHECK((a->K & 7) == 0 && (lda & 3) == 0 && (a->ldb & 7) == 0 && lda >= a->K && a->ldb >= a->K, "gg_gemm_nt_split3_af32: K %% 8, lda %% 4, ldb %% 8, ld >= K");
     GG_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)a->b_planes & 15) == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->c_planes & 7) == 0, "gg_gemm_nt_split3_af32: alignment");
@@ -1127,9 +1093,8 @@ extern "C" int gg_gemm_nt_split3_af32_bnbwd(const GgSplit3Args* a, const float* 
     GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3_af32: rowscale needs rows_per_scale");
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3_af32: act and dact_preact are exclusive");
     GG_CHECK(!colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->c_planes), "gg_gemm_nt_split3_af32: colstats needs the plain epilogue");
-    GG_CHECK(!bn_y || (colstats && bn_stat && bn_gamma && bn_beta && a->C && ((uintptr_t)bn_y & 15) == 0), "gg_gemm_nt_split3_af32: the BatchNorm-backward epilogue needs colstats, stat, gamma, beta");
     Split3Params p;
-    p.colstats = colstats; p.bn_y = bn_y; p.bn_stat = bn_stat; p.bn_gamma = bn_gamma; p.bn_beta = bn_beta; p.bn_act = bn_act;
+    p.colstats = colstats;
     p.A = nullptr; p.lda = 0; p.plane_a = 0; p.Af = A; p.ldaf = lda;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = b_plane_stride > 0 ? b_plane_stride : (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;

@@ -496,8 +496,6 @@ struct Exec {
 // column sums -> statpart
 static int gemm_bnbwd(const Exec& e, const act_t* dY, int64_t ldy, const act_t* Wt, int64_t ldw, act_t* dz, int64_t M, int N, int K,
                       const BNP& bn, const Act& a, int act) {
-    // (fp32_split mode: stays on the f32 GEMM.  gg_gemm_nt_split3_af32_bnbwd has this epilogue, but the launches that use it contract over K = 96 -- three k-stages:
-    // they are all epilogue, 10 GB of traffic each, and the f32 GEMM's epilogue streams that faster: 5.8 against 7.5 ms per step for the three of them)
     GgGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = dY; g.lda = ldy; g.B = Wt; g.ldb = ldw; g.C = dz; g.ldc = N; g.M = (int)M; g.N = N; g.K = K;

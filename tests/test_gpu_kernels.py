@@ -818,38 +818,6 @@ def test_split3_gemm_batchnorm_partials(M, N, K):
     assert torch.equal(stats, stats2) and torch.equal(out, out2)            # no atomics: repeatable
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 200, 96), (700, 192, 416), (5000, 96, 384)])
-def test_split3_gemm_batchnorm_backward_epilogue(M, N, K):
-    """gg_gemm_nt_split3_af32_bnbwd: a ConvNorm's data gradient with BatchNorm backward's first half in the epilogue, as gg_gemm_nt_f32 does it with GgGemmArgs.bn_y --
-    dz = (dY . W) * GELU'(gamma * xhat + beta), and per 128-row block the column sums of dz and of dz * xhat -- against the torch expressions."""
-    import ctypes as C
-    from geoguessr_ai_amd import _lib as L
-    g = torch.Generator().manual_seed(M + K)
-    A = torch.randn(M, K, generator=g).cuda(); B = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
-    y = (torch.randn(M, N, generator=g) * 1.5 + 0.3).cuda()
-    mean, var = y.mean(0), y.var(0, unbiased=False)
-    stat = torch.stack([mean, torch.rsqrt(var + 1e-5)]).contiguous()
-    gamma = (torch.rand(N, generator=g) + 0.5).cuda(); beta = (torch.randn(N, generator=g) * 0.2).cuda()
-    Bp = torch.empty(3, N, K, dtype=torch.bfloat16, device="cuda")
-    L.check(L.lib().gg_split3_bf16(B.data_ptr(), N, K, K, Bp.data_ptr(), L.stream()), "gg_split3_bf16")
-    parts = (M + 127) // 128
-    dz = torch.empty(M, N, device="cuda"); stats = torch.full((parts, 2, N), float("nan"), device="cuda")
-    a = L.Split3Args()
-    a.b_planes, a.ldb, a.M, a.N, a.K, a.C, a.ldc = Bp.data_ptr(), K, M, N, K, dz.data_ptr(), N
-    L.check(L.lib().gg_gemm_nt_split3_af32_bnbwd(C.byref(a), A.data_ptr(), K, 0, stats.data_ptr(), y.data_ptr(), stat.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1, L.stream()),
-            "gg_gemm_nt_split3_af32_bnbwd")
-    xhat = (y.double() - mean.double()) * stat[1].double()
-    z = (xhat * gamma.double() + beta.double()).requires_grad_(True)
-    torch.nn.functional.gelu(z).sum().backward()
-    ref = (A.double() @ B.double().T) * z.grad
-    assert float((dz.double() - ref).norm() / ref.norm()) < 2e-6
-    pad = torch.zeros(parts * 128, N, dtype=torch.float64, device="cuda"); pad[:M] = ref
-    padx = torch.zeros_like(pad); padx[:M] = ref * xhat
-    want = torch.stack([pad.view(parts, 128, N).sum(1), padx.view(parts, 128, N).sum(1)], 1)
-    assert torch.isfinite(stats).all()
-    assert float((stats.double() - want).abs().max() / want.abs().max()) < 2e-5
-
-
 @pytest.mark.parametrize("M,N,K,rps", [(5003, 200, 136, 7), (40, 8, 12, 0), (9000, 576, 320, 49), (4096, 260, 132, 0), (1100, 96, 432, 64)])
 def test_split3_weight_gradient_gemm(M, N, K, rps):
     """gg_gemm_tn_split3 (the fp32_split mode's weight gradient): dW[N][K] = sum_m s_m dY[m][n] X[m][k] with both f32 operands split in the kernel's loader, row slabs
