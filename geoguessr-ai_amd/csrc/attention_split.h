@@ -6,9 +6,9 @@
 //     (a1 b3 + a2 b2 + a3 b1) + (a1 b2 + a2 b1) + a1 b1        (small terms first; f32 accumulation; the dropped terms are < 2^-24 of the product)
 // = 96 cycles for the same tile on v_mfma_f32_16x16x32_bf16 (every contraction is 32 deep: the 16-deep bf16 MFMA costs the same 16 cycles, so products over
 // tokens pair two 16-token tiles per instruction), and the bf16 MFMA does not share its issue with the vector ALU the way the f32 MFMA does.  Error against an
-// fp64 reference (tools/check_attn_split.py): below the f32-MFMA kernels' on five of the six forward / backward shapes of TinyViT-21M-224, 15 %
-// above on the 14 x 14 backward; the kernels pass the fp32 mode's own gates at unchanged tolerances (tests/test_gpu_kernels.py::
-// test_flash_attention_forward_backward, tests/test_gpu_precision.py).
+// fp64 reference (tools/check_attn_split.py): below the f32-MFMA kernels' on all six forward / backward shapes of TinyViT-21M-224 (about half
+// of it in the backward, where -lse joins the exponent after the product instead of seeding the score accumulator); the kernels pass the fp32 mode's own
+// gates at unchanged tolerances (tests/test_gpu_kernels.py::test_flash_attention_forward_backward, tests/test_gpu_precision.py).
 // Operands that are reused -- K / V (forward), Q / dO (backward) of the whole window -- are split ONCE while they are staged into LDS (three bf16 images
 // of 64-byte rows, 16-byte chunks XOR-swizzled with (-(row >> 2)) & 3: conflict-free fragment ds_read_b128); per-wave strips are split once in registers;
 // probabilities / dS tiles are split where they are formed (5 vector instructions per score).
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64 * ((NT + 1) / 2)) void flash_bwd_split_kernel(Fl
         dsum += __shfl_xor(dsum, 2, 64);
         if (ch == 0) {
             del_s[row] = -dsum;
-            lse_s[row] = row < p.N ? lsev[i] * p.neg_inv_scale : -INFINITY;
+            lse_s[row] = row < p.N ? -1.4426950408889634f * lsev[i] : -INFINITY;      // -lse in the exp2 domain: joins the bias AFTER the product (below)
         }
     }
     __syncthreads();
@@ -366,7 +366,9 @@ __global__ __launch_bounds__(64 * ((NT + 1) / 2)) void flash_bwd_split_kernel(Fl
         for (int a = 0; a < 2; ++a) {
             const int tile = 2 * pair + a, q4 = tile * 16 + 4 * lg;
             const Sp8 qf = sp_frag<NPL>(Qp, PL, tile * 16 + lr, lg), of = sp_frag<NPL>(Op, PL, tile * 16 + lr, lg);
-            const f32x4 st0 = *reinterpret_cast<const f32x4*>(lse_s + q4), dp0 = *reinterpret_cast<const f32x4*>(del_s + q4);      // S - lse / scale, dP - delta
+            // S starts from zero and -lse is added with the bias: an accumulator that starts at -lse / scale (magnitude ~170 against scores of ~30) rounds every one
+            // of the six partial products to the ulp of 170 -- that was the 15 % by which this kernel's gradients missed the f32-MFMA kernel's error
+            const f32x4 st0 = {0.f, 0.f, 0.f, 0.f}, nl4 = *reinterpret_cast<const f32x4*>(lse_s + q4), dp0 = *reinterpret_cast<const f32x4*>(del_s + q4);      // dP - delta
             const i32x4 ql4 = *reinterpret_cast<const i32x4*>(qlin + q4);
             f32x4 dT[2];
 #pragma unroll
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(64 * ((NT + 1) / 2)) void flash_bwd_split_kernel(Fl
                 for (int r = 0; r < 4; ++r) bia[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(btab) + boff4[r]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r]));     // -inf for padded queries -> 0
+                    const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r] + nl4[r]));     // -inf for padded queries -> 0
                     const float g = e * dp[r];
                     pr[a][s][r] = e;
                     ds[a][s][r] = g;                                                    // the softmax scale is applied once, to dK and dQ

@@ -561,12 +561,15 @@ def test_fp32_split_mode_tracks_fp32_over_optimizer_steps(centroids):
     la, lb = runs["fp32"][0], runs["fp32_split"][0]
     print("[fp32 vs fp32_split, 4 steps] losses", la, lb)
     assert abs(la[0] - la[-1]) > 1e-3 * abs(la[0])                     # the steps are large enough to matter
+    # (a forward on stale planes would repeat the previous step's loss: 9.3 instead of 6.0.  Four steps that take the loss from 9.3 to 3.8 amplify rounding-level
+    # differences between the two product forms: 2e-5 after the first update, a few 1e-4 after the third)
+    assert abs(la[1] - lb[1]) <= 1e-4 * abs(la[1]), (la, lb)
     for a, b in zip(la, lb):
-        assert abs(a - b) <= 2e-4 * abs(a), (la, lb)
+        assert abs(a - b) <= 2e-3 * abs(a), (la, lb)
     # (matrices; bias / norm vectors that start at zero take Adam's sign-like first updates from gradients near zero: percent-level differences, no signal)
     errs = sorted(((relerr(runs["fp32_split"][1][n], t), n) for n, t in runs["fp32"][1].items() if t.dim() >= 2), reverse=True)
     print("[fp32 vs fp32_split, 4 steps] worst matrix rel-L2", errs[:4])
-    assert errs[0][0] < 2e-3
+    assert errs[0][0] < 5e-3
     vec = max(relerr(runs["fp32_split"][1][n], t) for n, t in runs["fp32"][1].items() if t.dim() == 1 and t.numel() > 1)
     assert vec < 5e-2
 
