@@ -159,7 +159,8 @@ __device__ __forceinline__ void fl_stage_rowstats_b(const FlashParams& p, __amdg
         if (part == 0 && row < R) {
             const float l = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rslse, ok ? (rel * p.nh + h) * 4 : FL_OOB, 0, 0));
             del_s[row] = -dsum;
-            lse_s[row] = ok ? l * p.neg_inv_scale : -INFINITY;
+            lse_s[row] = ok ? -1.4426950408889634f * l : -INFINITY;      // -lse in the exp2 domain: added to the exponent with the bias (a score accumulator seeded
+                                                                         // with -lse / scale, magnitude ~170, rounds every partial product to the ulp of 170: twice the error)
         }
     }
 }
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
         d += __shfl_xor(d, 16, 64);
         d += __shfl_xor(d, 32, 64);
         delta[u] = d;
-        lse2[u] = -(qok[u] ? p.lse[qtok[u] * p.nh + h] : 0.f) / p.scale;          // initial value of the S accumulators (see fl_stage_rowstats)
+        lse2[u] = -1.4426950408889634f * (qok[u] ? p.lse[qtok[u] * p.nh + h] : 0.f);          // -lse in the exp2 domain: joins the bias in the exponent (see fl_stage_rowstats_b)
         qlin[u] = has_bias ? fl_lin4(p, min(qi, p.N - 1)) + 4 * (p.ws - 1) * 2 * p.ws : 0;       // + the table's centre (dy = dx = 0)
     }
     const bool wave_on = strip0 * 16 < p.N;
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             if (kt >= nsub) continue;
             f32x4 st[QS], dp[QS];
 #pragma unroll
-            for (int u = 0; u < QS; ++u) { st[u] = (f32x4){lse2[u], lse2[u], lse2[u], lse2[u]}; dp[u] = (f32x4){-delta[u], -delta[u], -delta[u], -delta[u]}; }
+            for (int u = 0; u < QS; ++u) { st[u] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[u] = (f32x4){-delta[u], -delta[u], -delta[u], -delta[u]}; }
             if (t0 + 16 * kt + 15 >= p.N) {          // wave-uniform: only the window's last sub-tile holds padded keys; -inf there -> P = 0
 #pragma unroll
                 for (int u = 0; u < QS; ++u)
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dq_kernel(FlashPar
             for (int u = 0; u < QS; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(st[u][r], sc2, bia[u][r]));      // rows beyond N are never stored: no query mask needed in this pass
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(st[u][r], sc2, bia[u][r] + lse2[u]));      // rows beyond N are never stored: no query mask needed in this pass
                     st[u][r] = pr * dp[u][r];                            // dS^T; the softmax scale is applied once, to dQ
                 }
 #pragma unroll
@@ -743,7 +744,7 @@ __device__ __forceinline__ void fl_stage_rowstats(const FlashParams& p, const T*
         dsum += __shfl_xor(dsum, 2, 64);
         // stored negated and in the units of the raw products: they become the INITIAL VALUES of the S / dP accumulators, so that "- lse" and
         // "- delta" cost no VALU instruction per score (fp32 MFMA and VALU share the SIMD's issue: tools/mfma_shadow.hip).  -inf for padded queries: P = 0
-        if (part == 0 && row < n) { del_s[row] = -dsum; lse_s[row] = ok ? -p.lse[tok * p.nh + h] / p.scale : -INFINITY; }
+        if (part == 0 && row < n) { del_s[row] = -dsum; lse_s[row] = ok ? -1.4426950408889634f * p.lse[tok * p.nh + h] : -INFINITY; }      // (-lse, exp2 domain: see fl_stage_rowstats_b)
     }
 }
 template <typename T, int D, bool DBIAS, bool RES, bool STORE_DS = false>
@@ -821,7 +822,8 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
         for (int qs = 0; qs < 4; ++qs) {
             if (qs >= nsub) continue;
             const int q4 = ro + 16 * qs + 4 * lg;                              // this lane's 4 consecutive queries: one 16-byte read per array
-            f32x4 st = *reinterpret_cast<const f32x4*>(lse_s + q4), dp = *reinterpret_cast<const f32x4*>(del_s + q4);      // S - lse / scale, dP - delta
+            const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + q4);      // -lse (exp2 domain; -inf for padded queries)
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = *reinterpret_cast<const f32x4*>(del_s + q4);      // S, dP - delta
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
                 const f32x4 qa = *reinterpret_cast<const f32x4*>(Qt + (16 * qs + lr) * RS + 16 * c + 4 * lg);
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(RES ? 1024 : 256) void flash_bwd_dkv_kernel(FlashPa
             for (int r = 0; r < 4; ++r) {
                 const int ql = 16 * qs + 4 * lg + r;
                 const int boff = boff4[r];
-                const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r]));     // -inf for padded queries -> 0; a padded key's column is never stored
+                const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r] + nl4[r]));     // -inf for padded queries -> 0; a padded key's column is never stored
                 const float g = e * dp[r];
                 pr[r] = e;
                 ds[r] = g;                                                     // the softmax scale is applied once, to dK
@@ -991,7 +993,8 @@ __global__ __launch_bounds__(NT ? (NT < 4 ? 256 : 64 * NT) : 1024) void flash_bw
         const float* Qt = Qs + tile * 16 * RS;
         const float* Ot = Os + tile * 16 * RS;
         const int q4 = tile * 16 + 4 * lg;
-        f32x4 st = *reinterpret_cast<const f32x4*>(lse_s + q4), dp = *reinterpret_cast<const f32x4*>(del_s + q4);      // S - lse / scale, dP - delta
+        const f32x4 nl4 = *reinterpret_cast<const f32x4*>(lse_s + q4);      // -lse (exp2 domain; -inf for padded queries)
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = *reinterpret_cast<const f32x4*>(del_s + q4);      // S, dP - delta
 #pragma unroll
         for (int c = 0; c < DC; ++c) {
             const f32x4 qa = *reinterpret_cast<const f32x4*>(Qt + lr * RS + 16 * c + 4 * lg);
@@ -1011,7 +1014,7 @@ __global__ __launch_bounds__(NT ? (NT < 4 ? 256 : 64 * NT) : 1024) void flash_bw
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r]));     // -inf for padded queries -> 0
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[r], sc2, bia[r] + nl4[r]));     // -inf for padded queries -> 0
             const float g = e * dp[r];
             pr[r] = e;
             ds[r] = g;                                                         // the softmax scale is applied once, to dK and dQ
