@@ -57,7 +57,15 @@ class _HeadFn(torch.autograd.Function):
             L.check(L.lib().gg_view_mean_fwd(L.ptr(emb), L.ptr(xm), Cc, N, V, Cc, L.stream()), "gg_view_mean_fwd")
             wn, wt = model._weight_cache()
         logits = torch.empty((N, Kp), dtype=torch.float32, device=dev)
-        ops.gemm_nt(xm, wn, bias=bias.detach(), out_f32=True, out=logits, N=K, ldc=Kp)
+        if f32 and getattr(model, "split", False) and N >= 1024 and Cc % 8 == 0:
+            # "fp32_split": logits = xm . W^T + b as a split product (the f32 view mean split in the GEMM's loader, the weight as cached planes)
+            import ctypes as C
+            a = L.Split3Args()
+            a.b_planes, a.ldb, a.M, a.N, a.K = L.ptr(model._weight_planes()), Cc, N, K, Cc
+            a.C, a.ldc, a.bias = L.ptr(logits), Kp, L.ptr(bias.detach(), torch.float32, "cell_layer.bias")
+            L.check(L.lib().gg_gemm_nt_split3_af32(C.byref(a), L.ptr(xm, torch.float32, "view mean"), Cc, 0, L.stream()), "gg_gemm_nt_split3_af32")
+        else:
+            ops.gemm_nt(xm, wn, bias=bias.detach(), out_f32=True, out=logits, N=K, ldc=Kp)
         need_grad = mode != 0 and any(ctx.needs_input_grad)      # grad mode is off inside Function.forward
         r = ops.geo_head(logits, model.geocell_centroid_coords.data, labels=labels, labels_clf=labels_clf, mode=mode,
                          smoothing_km=float(LABEL_SMOOTHING_CONSTANT), want_dlogits=need_grad,
@@ -202,6 +210,8 @@ class SuperGuessr(nn.Module):
         self.precision = precision or bb_prec or default_precision()
         if self.precision not in PRECISIONS:
             raise ValueError(f"precision='{self.precision}' (known: bf16, fp32)")
+        # "fp32_split" (asked for, or the base model's mode): the geocell Linear's forward as an f32-accurate split-bf16 product from 1024 rows on
+        self.split = PRECISIONS[self.precision] == 3 or (precision is None and bool(getattr(getattr(base_model, "backbone", None), "split", False)))
         self.precision = "fp32" if PRECISIONS[self.precision] in (1, 3) else "bf16"
         if len(kwargs) > 0:
             print(f"Not using keyword arguments: {list(kwargs.keys())}")
@@ -298,6 +308,18 @@ class SuperGuessr(nn.Module):
             self._wc_version, self._wc_dirty = ver, False
         return self._wc
 
+    def _weight_planes(self):
+        """bf16 planes [3][K][C] of the head weight (w = w1 + w2 + w3 to 24 bits): the cached operand of the split forward GEMM of the "fp32_split" mode."""
+        w = self.cell_layer.weight
+        ver = (w._version, w.data_ptr())
+        if getattr(self, "_wpl", None) is None or self._wpl_version != ver or getattr(self, "_wpl_dirty", False) or self._wpl.device != w.device:
+            K, Cc = w.shape
+            if getattr(self, "_wpl", None) is None or self._wpl.device != w.device:
+                self._wpl = torch.empty((3, K, Cc), dtype=torch.bfloat16, device=w.device)
+            L.check(L.lib().gg_split3_bf16(L.ptr(w.detach(), torch.float32, "cell_layer.weight"), K, Cc, Cc, L.ptr(self._wpl), L.stream()), "gg_split3_bf16")
+            self._wpl_version, self._wpl_dirty = ver, False
+        return self._wpl
+
     def _weight_t_f32(self):
         """(C, Kpad) f32 transpose of the head weight for the f32 dgrad (dlogits . W as an NT GEMM)."""
         w = self.cell_layer.weight
@@ -314,6 +336,7 @@ class SuperGuessr(nn.Module):
 
     def mark_params_dirty(self, backbone: bool = True):
         self._wc_dirty = True
+        self._wpl_dirty = True
         bb = getattr(self.base_model, "backbone", None) if backbone else None
         if bb is not None and hasattr(bb, "mark_params_dirty"):
             bb.mark_params_dirty()

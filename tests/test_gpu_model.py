@@ -310,3 +310,31 @@ def test_checkpoint_round_trip_in_reference_format(adapter5m, centroids, tmp_pat
     step(m1, o1); step(m2, o2)
     for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
         assert torch.allclose(p1, p2, rtol=1e-4, atol=1e-6), n1
+
+
+def test_split_serving_head_matches_the_fp32_head(centroids):
+    """SuperGuessr(precision="fp32_split") serving head on precomputed embeddings (BASELINE c5's shape: 4096 x 4 x 576 -> 12647 cells): the geocell Linear runs as a
+    split-bf16 product (weight planes cached per parameter version); the top-5 probabilities agree with the f32-MFMA head to 1e-4 relative, the top cell and its
+    coordinates are identical wherever the two leading probabilities differ by more than 0.1 %, and an in-place weight update is picked up."""
+    from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+    torch.manual_seed(3)
+    emb = torch.randn(4096, 4, 576, device="cuda")
+    heads = {}
+    for prec in ("fp32", "fp32_split"):
+        torch.manual_seed(5)
+        heads[prec] = SuperGuessr(None, panorama=True, serving=True, embed_dim=576, precision=prec).cuda().eval()
+    heads["fp32_split"].load_state_dict(heads["fp32"].state_dict())
+    assert heads["fp32_split"].split and not heads["fp32"].split
+    for it in range(2):
+        with torch.no_grad():
+            ref = heads["fp32"](embedding=emb); got = heads["fp32_split"](embedding=emb)
+        llh_r, top_r = ref[0].float(), ref[1]                  # predicted (lon, lat) of the top cell; top-5 probabilities and cells
+        llh_g, top_g = got[0].float(), got[1]
+        assert float(((top_g.values - top_r.values).abs() / top_r.values).max()) < 1e-4
+        clear = (top_r.values[:, 0] - top_r.values[:, 1]) > 1e-3 * top_r.values[:, 0]
+        assert float(clear.float().mean()) > 0.9
+        assert bool((top_g.indices[clear, 0] == top_r.indices[clear, 0]).all()) and torch.equal(llh_g[clear], llh_r[clear])
+        with torch.no_grad():                                   # an optimizer-style in-place update: both caches must follow
+            for h in heads.values():
+                h.cell_layer.weight.mul_(1.5)
+
