@@ -825,6 +825,7 @@ struct Split3TnParams {
     const float* dY; int64_t ldy; const float* X; int64_t ldx;
     int M, N, K; const float* rowscale; int rps;
     float* part; int rows_per_split, tilesN, tilesK;
+    int last_scale;                     // (M - 1) / rps: the row-scale index is clamped to it (rows beyond M -- zeros -- in a slab's last stages must not read past the array)
 };
 __device__ __forceinline__ int s3_img_off(int row, int ch) { return row * 32 + ((ch ^ ((-(row >> 2)) & 3)) << 3); }
 __global__ __launch_bounds__(512) void gemm_tn_split3_kernel(Split3TnParams p) {
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(512) void gemm_tn_split3_kernel(Split3TnParams p) {
     auto scale_rows = [&](f32x4 (&r)[6]) {                          // the scales of the rows just loaded; then the counters move on to the rows two stages later
         if (!p.rowscale) return;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] *= p.rowscale[sq[j]];
+        for (int j = 0; j < 4; ++j) r[j] *= p.rowscale[min(sq[j], p.last_scale)];
     };
     auto advance_rows = [&]() {
         if (!p.rowscale) return;
@@ -1159,6 +1160,7 @@ extern "C" int gg_gemm_tn_split3(const float* dY, int64_t ldy, const float* X, i
     GG_CHECK(!rowscale || rows_per_scale > 0, "gg_gemm_tn_split3: rows_per_scale");
     Split3TnParams p;
     p.dY = dY; p.ldy = ldy; p.X = X; p.ldx = ldx; p.M = M; p.N = N; p.K = K; p.rowscale = rowscale; p.rps = rows_per_scale > 0 ? rows_per_scale : 1; p.part = partials;
+    p.last_scale = (M - 1) / p.rps;
     p.rows_per_split = (int)(gg_cdiv(gg_cdiv(M, splits), 32) * 32);
     GG_CHECK((int64_t)p.rows_per_split * (splits - 1) < M, "gg_gemm_tn_split3: more splits than 32-row stages");
     GG_CHECK((int64_t)p.rows_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 31), "gg_gemm_tn_split3: a slab exceeds the 2 GiB descriptor range");
