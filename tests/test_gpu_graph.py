@@ -53,6 +53,36 @@ def test_serving_forward_replays_bit_identically(graph_mode):
         assert torch.equal(o, ref[i % 3]), i
 
 
+def test_split_mode_forward_replays_bit_identically(graph_mode):
+    """The fp32_split mode at a size where its Linears run on the split-bf16 GEMMs (96 images: thousands of tiles per launch), forced into graphs: the captured
+    call and its replays return the eager call's bits (the split kernels hold no state that a capture would freeze: weight planes live in the weight cache)."""
+    from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+    torch.manual_seed(0)
+    m = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, precision="fp32_split").cuda().eval()
+    xs = [torch.randn(96, 3, 224, 224, device="cuda", generator=torch.Generator(device="cuda").manual_seed(s)) for s in range(2)]
+    x = torch.empty_like(xs[0])
+    graph_mode(0)
+    ref = []
+    with torch.no_grad():
+        for v in xs:
+            x.copy_(v)
+            ref.append(m(pixel_values=x).pooler_output.clone())
+    graph_mode(1)
+    _, cap0, rep0, _ = _stats()
+    got = []
+    with torch.no_grad():
+        for rnd in range(3):
+            for v in xs:
+                x.copy_(v)
+                o = m(pixel_values=x).pooler_output
+                got.append(o.clone())
+                del o
+    _, cap1, rep1, _ = _stats()
+    assert cap1 - cap0 >= 1 and rep1 - rep0 >= 4, (cap0, cap1, rep0, rep1)
+    for i, o in enumerate(got):
+        assert torch.equal(o, ref[i % 2]), i
+
+
 def test_training_step_replays_bit_identically(graph_mode, centroids):
     """forward + backward of the encoder as two graphs (the head, the loss and AdamW are single launches): losses and every parameter after three steps
     equal the eager run's bit for bit (BatchNorm running statistics and the batch counter included; the attention-bias tables are frozen, their gradient
