@@ -56,6 +56,16 @@ static inline const char* gg_dev_env(const char* name) {
     static const bool on = getenv("GG_DEV_SWITCHES") != nullptr;
     return on ? getenv(name) : nullptr;
 }
+// x = a + b + c with three bf16 terms (RNE; exact for every finite f32 whose low terms stay normal: 3 x 8 significand bits).  The first term is formed from x clamped
+// to the largest finite bf16 (3.39e38): bf16(x) alone rounds the top half-ulp of the f32 range (|x| >= 3.3961e38) to inf, which would turn a finite operand into
+// (inf, -inf, NaN).  +-inf / NaN operands give non-finite planes (NaN in the product where an f32 GEMM may keep +-inf: inf - inf in the residual).
+#define GG_BF16_MAX_F 3.3895313892515355e38f
+__device__ __forceinline__ void gg_split3_rne(float x, __bf16& a, __bf16& b, __bf16& c) {
+    a = (__bf16)__builtin_amdgcn_fmed3f(x, -GG_BF16_MAX_F, GG_BF16_MAX_F);
+    const float r1 = x - (float)a;
+    b = (__bf16)r1;
+    c = (__bf16)(r1 - (float)b);
+}
 static inline int64_t gg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t gg_align(int64_t a, int64_t b) { return gg_cdiv(a, b) * b; }
 

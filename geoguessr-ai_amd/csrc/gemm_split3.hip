@@ -78,10 +78,9 @@ __device__ __forceinline__ void split3_epilogue4(const Split3Params& p, f32x4 v,
         bf16x4 p1, p2, p3;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bf16 a = (bf16)v[r];
-            const float r1 = v[r] - (float)a;
-            const bf16 b2 = (bf16)r1;
-            p1[r] = a; p2[r] = b2; p3[r] = (bf16)(r1 - (float)b2);
+            bf16 s1_, s2_, s3_;
+            gg_split3_rne(v[r], s1_, s2_, s3_);
+            p1[r] = s1_; p2[r] = s2_; p3[r] = s3_;
         }
         bf16* q = p.c_planes + (int64_t)m * p.ldp + n;
         const int64_t plane = (int64_t)p.M * p.ldp;
@@ -178,10 +177,9 @@ __device__ __forceinline__ void split3_epilogue_rows(const Split3Params& p, floa
             bf16x8 p1, p2, p3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const bf16 a = (bf16)v[j];
-                const float r1 = v[j] - (float)a;
-                const bf16 b2 = (bf16)r1;
-                p1[j] = a; p2[j] = b2; p3[j] = (bf16)(r1 - (float)b2);
+                bf16 s1_, s2_, s3_;
+                gg_split3_rne(v[j], s1_, s2_, s3_);
+                p1[j] = s1_; p2[j] = s2_; p3[j] = s3_;
             }
             bf16* q = p.c_planes + (int64_t)m * p.ldp + n;
             if (nfull && (p.ldp & 7) == 0) {
@@ -555,10 +553,9 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
             bf16x4 p1, p2, p3;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const bf16 a = (bf16)r[j][e];
-                const float r1 = r[j][e] - (float)a;
-                const bf16 b2 = (bf16)r1;
-                p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+                bf16 s1_, s2_, s3_;
+                gg_split3_rne(r[j][e], s1_, s2_, s3_);
+                p1[e] = s1_; p2[e] = s2_; p3[e] = s3_;
             }
             *reinterpret_cast<bf16x4*>(base + ldsA[j]) = p1;
             *reinterpret_cast<bf16x4*>(base + TA + ldsA[j]) = p2;
@@ -632,10 +629,9 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
                     if (part < 2) {
 #pragma unroll
                         for (int e = 2 * part; e < 2 * part + 2; ++e) {
-                            const bf16 a = (bf16)rnext[jj][e];
-                            const float r1 = rnext[jj][e] - (float)a;
-                            const bf16 b2 = (bf16)r1;
-                            p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+                            bf16 s1_, s2_, s3_;
+                            gg_split3_rne(rnext[jj][e], s1_, s2_, s3_);
+                            p1[e] = s1_; p2[e] = s2_; p3[e] = s3_;
                         }
                     } else {
                         *reinterpret_cast<bf16x4*>(nxt + ldsA[jj]) = p1;
@@ -725,10 +721,9 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
     auto split2 = [&](const f32x4& v, int e0, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
 #pragma unroll
         for (int e = e0; e < e0 + 2; ++e) {
-            const bf16 a = (bf16)v[e];
-            const float r1 = v[e] - (float)a;
-            const bf16 b2 = (bf16)r1;
-            p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+            bf16 s1_, s2_, s3_;
+            gg_split3_rne(v[e], s1_, s2_, s3_);
+            p1[e] = s1_; p2[e] = s2_; p3[e] = s3_;
         }
     };
     const int fslot = (lg ^ ((lr >> 2) & 3)) * 8;
@@ -876,10 +871,9 @@ __global__ __launch_bounds__(512) void gemm_tn_split3_kernel(Split3TnParams p) {
     auto split2 = [&](const f32x4& v, int e0, bf16x4& p1, bf16x4& p2, bf16x4& p3) {
 #pragma unroll
         for (int e = e0; e < e0 + 2; ++e) {
-            const bf16 a = (bf16)v[e];
-            const float r1 = v[e] - (float)a;
-            const bf16 b2 = (bf16)r1;
-            p1[e] = a; p2[e] = b2; p3[e] = (bf16)(r1 - (float)b2);
+            bf16 s1_, s2_, s3_;
+            gg_split3_rne(v[e], s1_, s2_, s3_);
+            p1[e] = s1_; p2[e] = s2_; p3[e] = s3_;
         }
     };
     auto scale_rows = [&](f32x4 (&r)[6]) {                          // the scales of the rows just loaded; then the counters move on to the rows two stages later
@@ -997,10 +991,9 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
         bf16x4 p1, p2, p3;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const bf16 a = (bf16)v[j];
-            const float r1 = v[j] - (float)a;
-            const bf16 b = (bf16)r1;
-            p1[j] = a; p2[j] = b; p3[j] = (bf16)(r1 - (float)b);
+            bf16 s1_, s2_, s3_;
+            gg_split3_rne(v[j], s1_, s2_, s3_);
+            p1[j] = s1_; p2[j] = s2_; p3[j] = s3_;
         }
         *reinterpret_cast<bf16x4*>(out + r * cols + c) = p1;
         *reinterpret_cast<bf16x4*>(out + plane + r * cols + c) = p2;

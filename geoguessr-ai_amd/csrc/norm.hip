@@ -410,10 +410,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_g16_kernel(const T* __restr
                     bf16x8 p1, p2, p3;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const bf16 a = (bf16)o[j];
-                        const float r1 = o[j] - (float)a;
-                        const bf16 c2 = (bf16)r1;
-                        p1[j] = a; p2[j] = c2; p3[j] = (bf16)(r1 - (float)c2);
+                        bf16 s1_, s2_, s3_;
+                        gg_split3_rne(o[j], s1_, s2_, s3_);
+                        p1[j] = s1_; p2[j] = s2_; p3[j] = s3_;
                     }
                     *reinterpret_cast<bf16x8*>(pl + m * C + ch * 8) = p1;
                     *reinterpret_cast<bf16x8*>(pl + M * C + m * C + ch * 8) = p2;

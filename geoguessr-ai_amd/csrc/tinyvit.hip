@@ -529,7 +529,10 @@ static int gemm(const Exec& e, const act_t* A, int64_t lda, const act_t* Bm, int
     // (launch-bound sizes stay on the f32 GEMM, whose 64 x 64 tiles and split-K fill the chip where a 256- / 128-row split tile would leave most CUs idle:
     // the split form needs at least half the CUs' worth of tiles)
     const int64_t split_tiles = ((M + (K >= 384 ? 255 : 127)) / (K >= 384 ? 256 : 128)) * ((N + 127) / 128);
-    if (e.m->split && split_tiles >= 128 && (K & 7) == 0 && (lda & 3) == 0 && (!colstats || !(bias || act || preact || rowscale || residual || dact_pre))) {
+    // (dev: GG_SPLIT_MIN_TILES lowers the threshold so that the oracle gate can take every split route at a batch the CPU oracle finishes in seconds)
+    static const char* min_tiles_env = gg_dev_env("GG_SPLIT_MIN_TILES");
+    static const int64_t min_tiles = min_tiles_env ? atoll(min_tiles_env) : 128;
+    if (e.m->split && split_tiles >= min_tiles && (K & 7) == 0 && (lda & 3) == 0 && (!colstats || !(bias || act || preact || rowscale || residual || dact_pre))) {
         // fp32_split mode: a Linear whose weight operand has cached planes runs as a split product (A = the f32 activation itself, split in the kernel's loader)
         const int64_t off = reinterpret_cast<const char*>(Bm) - e.wc;
         for (const Model::PlaneOf& po : e.m->plane_of) {
@@ -769,7 +772,9 @@ static int dense_wgrad(const Exec& e, const DenseW& w, const act_t* X, int64_t l
     (void)T0; (void)T1;
     const int K = conv_reorder ? w.Kp : w.K;   // im2col'd operand has Kp columns
     // fp32_split mode: the weight gradient of a block Linear (the tensors that have planes) as split products too, same slab protocol
-    const bool sp = e.m->split && w.wn3 >= 0 && !conv_reorder && M >= 1024;
+    static const char* tn_min_env = gg_dev_env("GG_SPLIT_TN_MIN_M");      // (dev: the same for the weight gradients' row threshold)
+    static const int64_t tn_min_m = tn_min_env ? atoll(tn_min_env) : 1024;
+    const bool sp = e.m->split && w.wn3 >= 0 && !conv_reorder && M >= tn_min_m;
     const int split = sp ? gg_gemm_tn_split3_splits((int)M, w.N, K) : e.f32 ? gg_gemm_tn_f32_splits((int)M, w.N, K) : gg_gemm_tn_splits((int)M, w.N, K);
     if (sp) GG_TRY(gg_gemm_tn_split3((const float*)dY, ldy, (const float*)X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));
     else if (e.f32) GG_TRY(gg_gemm_tn_f32(dY, ldy, X, ldx, (int)M, w.N, K, rowscale, rps, e.F(e.L->splitk), split, e.st));

@@ -847,6 +847,101 @@ def test_split3_weight_gradient_gemm(M, N, K, rps):
     assert torch.equal(o3, o3b)
 
 
+def _range_rows(M, K, g):
+    """Operand rows for the range tests of the split GEMMs: row blocks of (0) N(0,1); (1) one power of ten per ROW from 1e-20 ... 1e20; (2) one power of ten per
+    ELEMENT from 1e-6 ... 1e6; (3) f32 denormals (|x| ~ 1e-40); (4) the top of the f32 range, 3.39e38 ... 3.4028e38 -- where bf16(x) alone rounds to inf;
+    (5) rows holding one +inf, one -inf or one NaN.  Returns (A, block index per row)."""
+    A = torch.randn(M, K, generator=g)
+    blk = torch.arange(M) % 6
+    A[blk == 1] *= 10.0 ** torch.randint(-20, 21, (int((blk == 1).sum()), 1), generator=g).float()
+    A[blk == 2] *= 10.0 ** torch.randint(-6, 7, (int((blk == 2).sum()), K), generator=g).float()
+    A[blk == 3] *= 1e-40
+    top = torch.rand(int((blk == 4).sum()), K, generator=g) * (3.4028e38 - 3.39e38) + 3.39e38
+    A[blk == 4] = top * torch.sign(torch.randn(top.shape, generator=g))
+    A[blk == 4, 0] = 3.4028234e38                                # FLT_MAX itself
+    rows5 = torch.nonzero(blk == 5).flatten()
+    for i, r in enumerate(rows5.tolist()):
+        A[r, (7 * i) % K] = (float("inf"), float("-inf"), float("nan"))[i % 3]
+    return A, blk
+
+
+@pytest.mark.parametrize("M,N,K", [(516, 192, 416), (300, 130, 96), (1030, 90, 1536)])
+def test_split3_gemm_operand_range(ops, M, N, K):
+    """gg_gemm_nt_split3_af32 outside N(0, 1): mixed magnitudes per row and per element, f32 denormals, the top of the f32 range, +-inf / NaN (both tile
+    heights and widths).  Stated bounds, per element c = sum_k a_k b_k:
+      * finite operands: the result is FINITE wherever gg_gemm_nt_f32's is (the first bf16 term is clamped to the largest finite bf16: without the clamp
+        |a| >= 3.3961e38 became (inf, -inf, NaN)), and |c - c_fp64| <= 1e-5 sum_k |a_k b_k| + K 2^-126 (max_k |a_k| + max_k |b_k| + 1) -- the f32 accumulation bound
+        plus flush-to-zero of sub-normal operand terms and products (what lies below 2^-126 may be dropped; the f32 kernel gets the same allowance);
+      * an operand row holding +-inf or NaN gives a NON-FINITE result in every column, as the f32 GEMM does (the split product gives NaN where the f32
+        GEMM may keep +-inf: inf - inf in the residual of the split)."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    A, blk = _range_rows(M, K, g)
+    B = torch.randn(N, K, generator=g) * (0.1 * K ** -0.5)         # |c| stays below FLT_MAX on the top-of-range rows
+    Ad, Bd = A.cuda(), B.cuda()
+    Bp = torch.empty(3, N, K, dtype=torch.bfloat16, device="cuda")
+    L.check(L.lib().gg_split3_bf16(Bd.data_ptr(), N, K, K, Bp.data_ptr(), L.stream()), "gg_split3_bf16")
+    a = L.Split3Args()
+    got = torch.empty(M, N, device="cuda")
+    a.b_planes, a.ldb, a.M, a.N, a.K, a.C, a.ldc = Bp.data_ptr(), K, M, N, K, got.data_ptr(), N
+    L.check(L.lib().gg_gemm_nt_split3_af32(C.byref(a), Ad.data_ptr(), K, 0, L.stream()), "gg_gemm_nt_split3_af32")
+    f32 = ops.gemm_nt(Ad, Bd).cpu()
+    got = got.cpu()
+    fin = blk != 5
+    assert torch.isfinite(f32[fin]).all() and torch.isfinite(got[fin]).all(), "finite operands must give finite results (near-FLT_MAX clamp)"
+    assert not torch.isfinite(got[~fin]).any() and not torch.isfinite(f32[~fin]).any(), "an inf / NaN operand row must give non-finite results"
+    ref = A[fin].double() @ B.double().T
+    bound = 1e-5 * (A[fin].double().abs() @ B.double().abs().T) + K * 2.0 ** -126 * (A[fin].double().abs().amax(1, keepdim=True) + B.double().abs().amax(1)[None, :] + 1.0)
+    err, err32 = (got[fin].double() - ref).abs(), (f32[fin].double() - ref).abs()
+    worst = float((err / bound).max())
+    print(f"\n[split3 range {M}x{N}x{K}] worst |err| / bound: split {worst:.3f}, f32-MFMA {float((err32 / bound).max()):.3f}")
+    assert worst <= 1.0 and float((err32 / bound).max()) <= 1.0
+    for b in range(5):                                              # per regime, in the norm the other split tests use (denormal rows: covered by the bound above)
+        if b == 3: continue
+        sel = blk[fin] == b
+        e = float((got[fin][sel].double() - ref[sel]).norm() / ref[sel].norm())
+        assert e < 2e-6, (b, e)
+
+
+def test_split3_weight_gradient_operand_range():
+    """gg_gemm_tn_split3 outside N(0, 1): the contraction runs over rows, so the regimes are per COLUMN of dY / X -- powers of ten from 1e-15 ... 1e15, a denormal
+    column, a column holding the top of the f32 range (finite result: its partner operand is small), and columns holding +inf / NaN.  Result class per element equal to
+    gg_gemm_tn_f32's (finite where it is finite, non-finite where it is not), error of the finite part <= 1e-5 sum_m |dy x| + M 2^-126 (max_m |dy| + max_m |x| + 1) (sub-normal terms may be flushed)."""
+    from geoguessr_ai_amd import _lib as L
+    lib = L.lib()
+    M, N, K = 2100, 264, 136
+    g = torch.Generator().manual_seed(77)
+    dY, X = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g) * 0.01
+    dY[:, 8:200] *= 10.0 ** torch.randint(-15, 16, (1, 192), generator=g).float()
+    X[:, 4:100] *= 10.0 ** torch.randint(-15, 16, (1, 96), generator=g).float()
+    dY[:, 200] *= 1e-40; X[:, 100] *= 1e-38                           # denormal columns
+    dY[:, 201] = 0.0; dY[5, 201] = 3.4028234e38; dY[900, 201] = -3.395e38      # top of the range (x stays <= ~0.05: the products are finite)
+    dY[17, 202] = float("inf"); dY[1800, 203] = float("nan"); X[33, 101] = float("-inf")
+    bad_n, bad_k = torch.tensor([202, 203]), torch.tensor([101])
+    dYd, Xd = dY.cuda(), X.cuda()
+    scratch = torch.empty(8 << 20, device="cuda")
+
+    def run(kind):
+        out = torch.empty(N, K, device="cuda")
+        fn_s, fn = (lib.gg_gemm_tn_split3_splits, lib.gg_gemm_tn_split3) if kind == "split" else (lib.gg_gemm_tn_f32_splits, lib.gg_gemm_tn_f32)
+        s_ = fn_s(M, N, K)
+        L.check(fn(dYd.data_ptr(), N, Xd.data_ptr(), K, M, N, K, None, 0, scratch.data_ptr(), s_, L.stream()), kind)
+        L.check(lib.gg_splitk_reduce(scratch.data_ptr(), out.data_ptr(), N * K, s_, 0, 1.0, L.stream()), "gg_splitk_reduce")
+        return out.cpu()
+    got, f32 = run("split"), run("f32")
+    nonfin = torch.zeros(N, K, dtype=torch.bool); nonfin[bad_n] = True; nonfin[:, bad_k] = True
+    assert torch.isfinite(got[~nonfin]).all() and torch.isfinite(f32[~nonfin]).all()
+    assert not torch.isfinite(got[nonfin]).any() and not torch.isfinite(f32[nonfin]).any()
+    dYc, Xc = dY.double().clone(), X.double().clone()
+    dYc[:, bad_n] = 0; Xc[:, bad_k] = 0
+    ref = dYc.T @ Xc
+    bound = 1e-5 * (dYc.abs().T @ Xc.abs()) + M * 2.0 ** -126 * (dYc.abs().amax(0)[:, None] + Xc.abs().amax(0)[None, :] + 1.0)
+    w3 = float(((got.double() - ref).abs() / bound)[~nonfin].max()); w32 = float(((f32.double() - ref).abs() / bound)[~nonfin].max())
+    print(f"\n[tn split range] worst |err| / bound: split {w3:.3f}, f32-MFMA {w32:.3f}")
+    assert w3 <= 1.0 and w32 <= 1.0
+
+
 # ------------------------------------------------------------------------------------------- head / loss / geo
 def test_geo_head_matches_oracle_and_reference_golden(ops, golden_dir, centroids):
     import os
