@@ -14,6 +14,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include "../../include/gg.h"
+int gg_attention_flash_bwd_impl(const GgAttnArgs* a, int dtype, int forward_rounded_bias, void* stream);      // attention_flash.hip
 
 struct AttnParams {
     const bf16* qkv; int64_t ld;
@@ -1026,7 +1027,7 @@ extern "C" int gg_attention_fwd_f16(const GgAttnArgs* a, void* stream) {
 extern "C" int gg_attention_bwd(const GgAttnArgs* a, void* stream) {
     if (attn_use_flash(a) || attn_use_split_bwd(a)) {
         GG_CHECK(!a->bias || a->bias_table, "gg_attention_bwd: this window shape takes the bias as bias_table (compact f32)");
-        return gg_attention_flash_bwd(a, 0, stream);
+        return gg_attention_flash_bwd_impl(a, 0, 1, stream);      // (this forward added the bias as bf16(bias / scale): the backward recomputes P with that value)
     }
     AttnParams p;
     GG_TRY(attn_fill(p, a, "gg_attention_bwd"));

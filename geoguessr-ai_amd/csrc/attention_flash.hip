@@ -1153,7 +1153,7 @@ int flash_fill(FlashParams& p, const GgAttnArgs* a, int dtype, const char* who) 
     p.nbpad = (int)gg_align(std::max(4, (2 * a->window_size - 1) * (2 * a->window_size - 1)), 4);      // expanded (signed-offset) bias table
     p.rcp_ws = p.rcp_w2 = p.rcp_img = p.rcp_nwx = 0;
     p.neg_inv_scale = -1.0f / p.scale;
-    p.round_bias = (dtype == 0 && a->bias != nullptr) ? 1 : 0;
+    p.round_bias = 0;                                     // (set by gg_attention_flash_bwd_impl when the forward was attention.hip's)
     {
         auto magic = [](int d) { return d <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + d - 1) / d); };      // exact for numerators < 2^32 / d
         p.rcp_img = magic(p.nWx * p.nWy); p.rcp_nwx = magic(p.nWx);
@@ -1267,10 +1267,16 @@ extern "C" int64_t gg_attention_flash_ds_scratch_floats(int num_windows, int num
 extern "C" int64_t gg_attention_flash_dbias_rows(int num_windows, int tokens_per_window) {
     return (int64_t)num_windows * gg_cdiv(tokens_per_window, 64) + GG_REDUCE_SLICES;
 }
-extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stream) {
+// forward_rounded_bias: the forward that produced `lse` was gg_attention_fwd's bf16 kernel, which adds the bias as bf16(bias / scale) from the expanded table: P is
+// recomputed with that value.  Only gg_attention_bwd passes 1 (attention.hip); the public entry point pairs with gg_attention_flash_fwd, which reads the compact
+// f32 table -- a caller who fills both `bias` and `bias_table` and calls the flash pair directly gets the same bias in both passes
+int gg_attention_flash_bwd_impl(const GgAttnArgs* a, int dtype, int forward_rounded_bias, void* stream);
+extern "C" int gg_attention_flash_bwd(const GgAttnArgs* a, int dtype, void* stream) { return gg_attention_flash_bwd_impl(a, dtype, 0, stream); }
+int gg_attention_flash_bwd_impl(const GgAttnArgs* a, int dtype, int forward_rounded_bias, void* stream) {
     FlashParams p;
     GG_CHECK(dtype != 2, "gg_attention_flash_bwd: fp16 storage is inference-only");
     GG_TRY(flash_fill(p, a, dtype, "gg_attention_flash_bwd"));
+    p.round_bias = (forward_rounded_bias && dtype == 0 && a->bias != nullptr) ? 1 : 0;
     GG_CHECK(a->dout && a->dqkv && (a->lddo & 3) == 0 && ((uintptr_t)a->dout & 15) == 0 && ((uintptr_t)a->dqkv & 15) == 0,
              "gg_attention_flash_bwd: bad dout/dqkv");
     GG_CHECK(a->lse && a->out && (a->ldo & 3) == 0, "gg_attention_flash_bwd: needs the forward's lse and out");

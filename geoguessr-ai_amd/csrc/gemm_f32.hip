@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void splitk_nt_reduce_f32_kernel(const float* 
         *reinterpret_cast<f32x4*>(C + (int64_t)m * ldc + n) = v;
     }
 }
-// slabs of the split-K form: one lazily allocated 16 MiB buffer per (device, stream).  Launches of one stream run in order, so they can share their slabs; two
+// slabs of the split-K form: one lazily allocated 16 MiB buffer per (device, stream), at most 8 of them (least recently used released), all released by gg_graph_clear.  Launches of one stream run in order, so they can share their slabs; two
 // streams (or threads) issuing qualifying GEMMs concurrently get different buffers.  Under stream capture nothing can be allocated and the launch may be replayed
 // on any stream next to anything: the graph cache (graph.cpp) hands every captured graph slabs of its OWN (gg_gemm_f32_capture_scratch, allocated before the
 // capture starts when the key's eager run used the split form, freed with the graph), so a replay computes exactly what the eager call did; a capture that
@@ -1046,6 +1046,10 @@ __global__ __launch_bounds__(256) void splitk_nt_reduce_f32_kernel(const float* 
 constexpr int64_t kSplitScratchFloats = (int64_t)4 << 20;
 static std::mutex g_split_mu;
 static std::map<hipStream_t, float*> g_capture_slabs;
+struct StreamSlab { float* buf; uint64_t tick; };
+static std::map<std::pair<int, hipStream_t>, StreamSlab> g_stream_slabs;
+static uint64_t g_slab_tick = 0;
+constexpr size_t kMaxStreamSlabs = 8;
 static thread_local long tl_splitk_uses = 0;
 long gg_gemm_f32_splitk_uses() { return tl_splitk_uses; }                       // (graph.h) split-form launches issued by this thread so far
 size_t gg_gemm_f32_splitk_bytes() { return (size_t)kSplitScratchFloats * sizeof(float); }
@@ -1061,15 +1065,38 @@ static float* splitk_scratch(hipStream_t st) {
         auto it = g_capture_slabs.find(st);
         return it == g_capture_slabs.end() ? nullptr : it->second;
     }
-    static std::map<std::pair<int, hipStream_t>, float*> bufs;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    auto it = bufs.find({dev, st});
-    if (it != bufs.end()) return it->second;
+    auto it = g_stream_slabs.find({dev, st});
+    if (it != g_stream_slabs.end()) { it->second.tick = ++g_slab_tick; return it->second.buf; }
+    // bounded: at most kMaxStreamSlabs (device, stream) entries; the least recently used one is released (hipFree waits for the device, so work that still reads the
+    // slab has finished) -- a process that creates a stream per request does not grow by 16 MiB per stream handle
+    if (g_stream_slabs.size() >= kMaxStreamSlabs) {
+        auto lru = g_stream_slabs.begin();
+        for (auto j = g_stream_slabs.begin(); j != g_stream_slabs.end(); ++j) if (j->second.tick < lru->second.tick) lru = j;
+        int cur = dev;
+        if (lru->first.first != cur) (void)hipSetDevice(lru->first.first);
+        if (lru->second.buf) (void)hipFree(lru->second.buf);
+        if (lru->first.first != cur) (void)hipSetDevice(cur);
+        g_stream_slabs.erase(lru);
+    }
     float* b = nullptr;
     if (hipMalloc((void**)&b, kSplitScratchFloats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); b = nullptr; }
-    bufs[{dev, st}] = b;
+    g_stream_slabs[{dev, st}] = StreamSlab{b, ++g_slab_tick};
     return b;
+}
+// teardown (gg_graph_clear): every per-stream slab is released; the next qualifying GEMM allocates again
+void gg_gemm_f32_release_scratch() {
+    std::lock_guard<std::mutex> lk(g_split_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& kv : g_stream_slabs) {
+        if (!kv.second.buf) continue;
+        (void)hipSetDevice(kv.first.first);
+        (void)hipFree(kv.second.buf);
+    }
+    (void)hipSetDevice(cur);
+    g_stream_slabs.clear();
 }
 
 extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {

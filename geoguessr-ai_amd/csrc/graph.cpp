@@ -16,6 +16,7 @@ struct Slot {
     hipGraphExec_t exec = nullptr;
     bool refused = false;          // capture / instantiation / a launch failed once: this key stays eager
     bool capturing = false;        // a thread is capturing this key right now (outside the lock): everybody else runs it eagerly meanwhile
+    bool first_run = false;        // the key's first (eager) run is still in flight on some thread: wants_slabs is not known yet, nobody captures it meanwhile
     bool wants_slabs = false;      // the key's eager run issued split-K GEMMs: its graph gets split-K slabs of its own
     float* slabs = nullptr;
     uint64_t tick = 0;
@@ -72,18 +73,18 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
         g_slots.emplace_back();
         g_slots.back().key = key.bytes;
         g_slots.back().tick = ++g_tick;
+        g_slots.back().first_run = true;               // (another thread that meets the key before this run has finished must not capture: wants_slabs is decided below)
         ++g_eager;
         lk.unlock();
         const long uses0 = gg_gemm_f32_splitk_uses();
         const int rc = body(stream);
-        if (gg_gemm_f32_splitk_uses() != uses0) {
-            lk.lock();
-            for (auto& c : g_slots) if (c.key == key.bytes) { c.wants_slabs = true; break; }
-        }
+        const bool used = gg_gemm_f32_splitk_uses() != uses0;
+        lk.lock();
+        for (auto& c : g_slots) if (c.key == key.bytes) { c.wants_slabs = used; c.first_run = false; break; }
         return rc;
     }
     s->tick = ++g_tick;
-    if (s->refused) { ++g_eager; lk.unlock(); return body(stream); }
+    if (s->refused || s->first_run) { ++g_eager; lk.unlock(); return body(stream); }
     if (!s->exec && g_wasted >= kMaxWasted) { ++g_eager; lk.unlock(); return body(stream); }      // captures keep being evicted unused-again: stop paying for new ones
     if (s->capturing) { ++g_eager; lk.unlock(); return body(stream); }
     if (!s->exec) {
@@ -100,8 +101,11 @@ int gg_graph_run(const GgGraphKey& key_in, hipStream_t stream, const std::functi
         hipGraphExec_t x = nullptr;
         float* slabs = nullptr;
         bool ok = false;
-        if (wants_slabs && hipMalloc((void**)&slabs, gg_gemm_f32_splitk_bytes()) != hipSuccess) { (void)hipGetLastError(); slabs = nullptr; }
-        {
+        // no slabs for a key whose eager run used the split-K form: a graph captured without them would run those GEMMs unsplit and its replays would differ
+        // from the eager call in rounding -- the key stays eager instead (replays return the eager call's bits, or there are no replays)
+        const bool no_slabs = wants_slabs && hipMalloc((void**)&slabs, gg_gemm_f32_splitk_bytes()) != hipSuccess;
+        if (no_slabs) { (void)hipGetLastError(); slabs = nullptr; }
+        if (!no_slabs) {
             std::lock_guard<std::mutex> cl(cap_mu[dev & 15]);
             hipStream_t cap = nullptr;
             { std::lock_guard<std::mutex> l2(g_mu); cap = g_capture[dev]; }
@@ -165,5 +169,6 @@ extern "C" int gg_graph_clear(void) {
     for (auto& s : g_slots) drop(s);
     g_slots.clear();
     g_wasted = 0;
+    gg_gemm_f32_release_scratch();
     return 0;
 }

@@ -25,3 +25,4 @@ int gg_graph_run(const GgGraphKey& key, hipStream_t stream, const std::function<
 long gg_gemm_f32_splitk_uses();
 size_t gg_gemm_f32_splitk_bytes();
 void gg_gemm_f32_capture_scratch(hipStream_t capture_stream, float* slabs);
+void gg_gemm_f32_release_scratch();     // frees the per-(device, stream) slabs of eager launches (gg_graph_clear)

@@ -31,10 +31,11 @@ def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_p
         raise ValueError("Expected a non-empty list of samples for summary computation")
     p = np.zeros_like(d) if top1_prob is None else np.asarray(torch.as_tensor(top1_prob).cpu() if torch.is_tensor(top1_prob) else top1_prob,
                                                               np.float64)
-    n = d.size
+    n = n_total = d.size
     # gg_geoguessr_score marks a non-finite coordinate pair with distance NaN / score -1.  The reference's haversine_np propagates such a NaN into every
     # mean and carries on (a validation epoch never aborts a run): do the same for the run, but keep the sentinels out of the averages -- they are
-    # counted and reported (``num_invalid``, a warning), the means are over the valid samples (``strict=True`` raises instead)
+    # counted and reported (a warning), the means are over the valid samples (``strict=True`` raises instead).  ``num_samples`` is always the TOTAL, as in the
+    # reference; ``num_valid`` / ``num_invalid`` say how many the averages are over
     bad = ~np.isfinite(d) | (s < 0)
     n_bad = int(bad.sum())
     if n_bad:
@@ -44,17 +45,17 @@ def compute_summary(distance_km: Sequence[float], score: Sequence[float], top1_p
         import warnings
         warnings.warn(msg + "; they are left out of the averages")
         if n_bad == n:
-            return {"num_samples": n, "num_invalid": n_bad, "avg_distance_km": float("nan"), "median_distance_km": float("nan"), "avg_top1_prob": float("nan"),
+            return {"num_samples": n_total, "num_valid": 0, "num_invalid": n_bad, "avg_distance_km": float("nan"), "median_distance_km": float("nan"), "avg_top1_prob": float("nan"),
                     "avg_score": float("nan")}
         d, s, p = d[~bad], s[~bad], p[~bad]
         n = d.size
     total_distance = total_score = total_top = 0.0
     for i in range(n):                       # the reference accumulates sample by sample in Python floats: keep its summation order
         total_distance += float(d[i]); total_score += float(s[i]); total_top += float(p[i]) if p[i] >= 0 else 0.0
-    out = {"num_samples": n, "avg_distance_km": total_distance / n, "median_distance_km": float(np.median(d)),
+    out = {"num_samples": n_total, "avg_distance_km": total_distance / n, "median_distance_km": float(np.median(d)),
            "avg_top1_prob": total_top / n, "avg_score": total_score / n}
     if n_bad:
-        out["num_invalid"] = n_bad
+        out["num_valid"], out["num_invalid"] = n, n_bad
     return out
 
 

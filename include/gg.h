@@ -8,7 +8,9 @@
  *     freed by the library.  Process-global state it does keep, all of it internal and none of it part of a result: the HIP-graph cache of
  *     gg_tinyvit_forward / _backward (captured graphs, one private capture stream per device, hit counters: gg_graph_stats reads them,
  *     gg_graph_clear() is the teardown and must run before the buffers a captured graph refers to are freed), the launch log of the profiling
- *     hooks (gg_prof_*: off unless enabled), and one lazily allocated 16 MiB split-K slab buffer per (device, stream) of gg_gemm_nt_f32 (plus one per captured graph whose launches use the form);
+ *     hooks (gg_prof_*: off unless enabled), and lazily allocated 16 MiB split-K slab buffers of gg_gemm_nt_f32: one per (device, stream) that issued the form, at
+ *     most 8 (least recently used released), plus one per captured graph whose launches use the form; gg_graph_clear() releases them all.  Under a CALLER's own
+ *     stream capture no slab can be handed out and the form runs unsplit (same product, different rounding than the eager call);
  *   - `stream` is a hipStream_t; work is only enqueued, nothing here synchronises;
  *   - bf16 tensors are passed as void*; matrices are row-major with an explicit leading dimension
  *     in ELEMENTS; activations are NHWC / [tokens, channels].
@@ -189,8 +191,9 @@ typedef struct GgAttnArgs {
                                              or NULL: what the online-softmax and resident-window kernels read (gg_attention_flash_*;
                                              gg_attention_fwd/bwd beyond 256 tokens per window, where `bias` is ignored; gg_attention_bwd of
                                              12 x 12 / 14 x 14 windows, which runs the single-pass backward).  A biased gg_attention_fwd/bwd call
-                                             therefore passes BOTH forms.  With both given and bf16 storage the backward recomputes P with the
-                                             value the expanded table holds, bf16(bias / scale), i.e. with the forward's */
+                                             therefore passes BOTH forms.  gg_attention_bwd (bf16 storage, both given) recomputes P with the value the
+                                             expanded table holds, bf16(bias / scale), i.e. with its own forward's; the gg_attention_flash_fwd / _bwd pair
+                                             reads only this compact table in both passes (`bias` is ignored there) */
     float* ds_scratch;                    /* optional (gg_attention_flash_bwd, windows beyond 256 tokens only -- see gg_attention_flash_single_pass): f32
                                              [gg_attention_flash_ds_scratch_floats(...)] = 4 * windows * heads * roundup16(tokens)^2 bytes (22 MB per image at
                                              CLIP ViT-L/14-336).  With it the dK/dV pass runs first and hands dS to the dQ pass, which then is ONE product
@@ -431,10 +434,14 @@ typedef struct GgTinyVitCfg {
     int act_dtype;       /* 0: bf16 activations + bf16 MFMA operands (fp32 accumulate / statistics / master weights);
                             1: reference-precision mode -- f32 activations, f32 MFMA (v_mfma_f32_16x16x4_f32), erf GELU at fp32 accuracy (1.2 ulp): the
                                arithmetic of the reference's own torch fp32 forward / backward;
-                            3: "fp32_split" (DESIGN.md 5): mode 1's storage and kernels, except that the four Linears of every transformer block (qkv, proj,
-                               fc1, fc2: forward and data gradients) run as fp32-accurate SPLIT products on the bf16 MFMA -- the f32 activation operand is
-                               split into three bf16 terms while the GEMM stages it (gg_gemm_nt_split3_af32), the weight's terms are cached planes; error
-                               against fp64 below the f32 MFMA GEMM's, 1.15-1.5 x its speed.  Weight gradients, the conv stages and everything else as mode 1 */
+                            3: "fp32_split" (DESIGN.md 5): mode 1's storage, with the GEMMs whose weight operand has cached bf16 planes run as fp32-accurate
+                               SPLIT products on the bf16 MFMA -- the f32 activation operand is split into three bf16 terms while the GEMM stages it
+                               (gg_gemm_nt_split3_af32), the weight's terms are cached planes: the four Linears of every transformer block (qkv, proj, fc1,
+                               fc2: forward and data gradients), the dense 1 x 1 / im2col convolutions of the ConvNorms (forward, with the BatchNorm
+                               partials in the epilogue, and their plain data gradients); the block Linears' WEIGHT gradients run as gg_gemm_tn_split3
+                               (both operands split in the loader).  Routing is by size: a Linear needs 128 output tiles, a weight gradient 1024 rows
+                               (smaller calls stay on mode 1's f32-MFMA kernels, which fill the chip with 64 x 64 tiles / split-K).  The BatchNorm-fused
+                               conv forms of stage 0 and the conv weight gradients as mode 1.  Error against fp64 at or below the f32 MFMA GEMM's */
     int features_only;   /* 1: models/tinyvit.py:38-46,139-143 (timm features_only=True): the output is the global-average-pooled
                                last feature map, head.norm is not applied (its parameters stay in the table, unused) */
 } GgTinyVitCfg;

@@ -931,13 +931,15 @@ def test_split3_weight_gradient_operand_range():
         return out.cpu()
     got, f32 = run("split"), run("f32")
     nonfin = torch.zeros(N, K, dtype=torch.bool); nonfin[bad_n] = True; nonfin[:, bad_k] = True
-    assert torch.isfinite(got[~nonfin]).all() and torch.isfinite(f32[~nonfin]).all()
-    assert not torch.isfinite(got[nonfin]).any() and not torch.isfinite(f32[nonfin]).any()
     dYc, Xc = dY.double().clone(), X.double().clone()
     dYc[:, bad_n] = 0; Xc[:, bad_k] = 0
-    ref = dYc.T @ Xc
-    bound = 1e-5 * (dYc.abs().T @ Xc.abs()) + M * 2.0 ** -126 * (dYc.abs().amax(0)[:, None] + Xc.abs().amax(0)[None, :] + 1.0)
-    w3 = float(((got.double() - ref).abs() / bound)[~nonfin].max()); w32 = float(((f32.double() - ref).abs() / bound)[~nonfin].max())
+    ref, mag = dYc.T @ Xc, dYc.abs().T @ Xc.abs()
+    fin = ~nonfin & (mag < 1e37)                                      # (the top-of-range column against an X column scaled up by 1e15 overflows f32 legitimately: excluded)
+    assert int((mag[201] < 1e37).sum()) >= 30                         # ... but most of its row is in range
+    assert torch.isfinite(got[fin]).all() and torch.isfinite(f32[fin]).all()
+    assert not torch.isfinite(got[nonfin]).any() and not torch.isfinite(f32[nonfin]).any()
+    bound = 1e-5 * mag + M * 2.0 ** -126 * (dYc.abs().amax(0)[:, None] + Xc.abs().amax(0)[None, :] + 1.0)
+    w3 = float(((got.double() - ref).abs() / bound)[fin].max()); w32 = float(((f32.double() - ref).abs() / bound)[fin].max())
     print(f"\n[tn split range] worst |err| / bound: split {w3:.3f}, f32-MFMA {w32:.3f}")
     assert w3 <= 1.0 and w32 <= 1.0
 

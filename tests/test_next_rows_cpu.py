@@ -94,11 +94,12 @@ def test_compute_summary_keeps_sentinel_scores_out_of_the_averages():
     assert ok["avg_score"] == 3500.0 and ok["num_samples"] == 2 and "num_invalid" not in ok
     with pytest.warns(UserWarning, match="sentinel"):
         part = compute_summary([10.0, float("nan"), 30.0], [4000, -1, 2000], [0.5, 0.9, 0.1])
-    assert part["num_samples"] == 2 and part["num_invalid"] == 1 and part["avg_score"] == 3000.0 and part["avg_distance_km"] == 20.0
+    # num_samples is the TOTAL, as in the reference (run_benchmark.py:67-117); the averages are over num_valid
+    assert part["num_samples"] == 3 and part["num_valid"] == 2 and part["num_invalid"] == 1 and part["avg_score"] == 3000.0 and part["avg_distance_km"] == 20.0
     assert abs(part["avg_top1_prob"] - 0.3) < 1e-12
     with pytest.warns(UserWarning):
         none = compute_summary([float("nan")], [-1])
-    assert none["num_invalid"] == 1 and none["avg_score"] != none["avg_score"]
+    assert none["num_samples"] == 1 and none["num_valid"] == 0 and none["num_invalid"] == 1 and none["avg_score"] != none["avg_score"]
     with pytest.raises(ValueError, match="sentinel"):
         compute_summary([10.0, 5.0], [4000, -1], strict=True)
 
