@@ -165,7 +165,7 @@ def pmc_traffic(precision):
     measurement of the same workload.  The file records the sha256 of the kernel sources it was measured on: when the running tree differs the
     figure is still reported but marked ``stale``.  -> (bytes or None, info dict, per-class table or None)."""
     from geoguessr_ai_amd import _lib as L
-    names = [f"r{r:02d}_hbm_traffic_pmc_{precision}.json" for r in (5, 4, 3, 2)] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
+    names = [f"r{r:02d}_hbm_traffic_pmc_{precision}.json" for r in (6, 5, 4, 3, 2)] + (["r01_hbm_traffic_pmc.json"] if precision == "bf16" else [])
     for name in names:
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -196,9 +196,17 @@ def class_rooflines(breakdown_raw, steps, precision, pmc_classes, pmc_info):
             traffic = sum((pmc_classes.get(k, {}).get("fetch_GB_per_step", 0.0) + pmc_classes.get(k, {}).get("write_GB_per_step", 0.0)) for k in PMC_CLASSES[name]) * 1e9
         alg_bytes_step = by_ / steps
         if name == "attention":
-            ach = fl_ / ms_ / 1e9
-            o = dict(bound="mfma", achieved=round(ach, 2), peak=MFMA_PEAK_TF[precision], unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TF[precision], 4),
-                     algorithmic_gflop_per_step=round(fl_ / steps / 1e9, 1))
+            # the window attention of both f32-storage modes runs on split products (csrc/attention_split.h: six bf16 MFMAs per f32 product), so its matrix roof is the
+            # bf16 peak / 6, as for the split GEMMs -- not the f32 MFMA peak, a pipe these kernels do not use.  The class is priced against whichever roof bounds it:
+            # max(flops / matrix roof, algorithmic bytes / 8 TB/s); the other fraction is reported beside it
+            peak = SPLIT_PEAK_TF if precision in ("fp32", "fp32_split") else MFMA_PEAK_TF[precision]
+            ach, ach_gb = fl_ / ms_ / 1e9, by_ / ms_ / 1e6
+            t_mfma, t_hbm = fl_ / (peak * 1e9), by_ / (HBM_PEAK_GBS * 1e6)
+            if t_mfma >= t_hbm:
+                o = dict(bound="mfma", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4), hbm_frac=round(ach_gb / HBM_PEAK_GBS, 4))
+            else:
+                o = dict(bound="hbm", achieved=round(ach_gb, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach_gb / HBM_PEAK_GBS, 4), mfma_frac=round(ach / peak, 4))
+            o["algorithmic_gflop_per_step"] = round(fl_ / steps / 1e9, 1)
         else:
             ach = by_ / ms_ / 1e6
             o = dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4))

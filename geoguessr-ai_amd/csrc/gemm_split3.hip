@@ -96,6 +96,62 @@ __device__ __forceinline__ void split3_epilogue4(const Split3Params& p, f32x4 v,
     }
 }
 
+// Epilogue classes known at compile time (EC; the host picks one when the shape allows the vector path: N % 8 == 0, row pitches % 4 == 0): the generic row epilogue
+// below decides bias / activation / row scale / residual / planes / statistics per row behind ~40 runtime branches, and the compiler cannot move a row's global loads across
+// them.  Here the aux rows a thread needs (the saved pre-activation of the GELU' data gradient, the residual) are ALL requested before the first tile row is touched (8 rows
+// x 32 bytes per thread in flight), and the loop body is branch-free.  Arithmetic, operation order and rounding are the generic path's: results are bit-identical.
+//   1: C = acc + bias                                    (qkv, plain data gradients)
+//   2: pre = acc + bias;  C = GELU(pre)                  (fc1 forward; pre-activation saved)
+//   3: C = acc * GELU'(saved pre-activation) [* scale]   (fc2 data gradient)
+//   4: C = (acc + bias) [* scale] + residual             (proj / fc2 forward)
+template <int BM, int BN, int NTHR, int HINT, int EC>
+__device__ __forceinline__ void split3_epilogue_rows_ec(const Split3Params& p, const float* Ct, int m0, int n0) {
+    constexpr int LDT = BN + 4, CPR = BN / 8, RPP = NTHR / CPR, NR = (BM + RPP - 1) / RPP;
+    if ((int)threadIdx.x >= RPP * CPR) return;
+    const int chunk = threadIdx.x % CPR, r0 = threadIdx.x / CPR;
+    const int n = n0 + chunk * 8;
+    if (n >= p.N) return;                                           // (N % 8 == 0: a chunk is entirely inside or outside)
+    auto ldg = [&](const float* q) -> f32x4 {
+        if constexpr (HINT & 4) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
+        else return *reinterpret_cast<const f32x4*>(q);
+    };
+    auto stg = [&](float* q, f32x4 t) {
+        if constexpr (HINT & 1) __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(q));
+        else *reinterpret_cast<f32x4*>(q) = t;
+    };
+    f32x4 aux[(EC == 3 || EC == 4) ? NR : 1][2];
+    if constexpr (EC == 3 || EC == 4) {
+        const float* base = EC == 3 ? p.dact_preact : p.residual;
+        const int64_t ld = EC == 3 ? p.ldc : p.ldr;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int rr = r0 + i * RPP, m = m0 + rr;
+            if (rr < BM && m < p.M) { aux[i][0] = ldg(base + (int64_t)m * ld + n); aux[i][1] = ldg(base + (int64_t)m * ld + n + 4); }
+            else aux[i][0] = aux[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (EC != 3 && p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int rr = r0 + i * RPP, m = m0 + rr;
+        if (rr >= BM || m >= p.M) break;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(Ct + rr * LDT + chunk * 8) + b0, v1 = *reinterpret_cast<const f32x4*>(Ct + rr * LDT + chunk * 8 + 4) + b1;
+        float* const c = p.C + (int64_t)m * p.ldc + n;
+        if constexpr (EC == 2) {
+            float* const pre = p.preact + (int64_t)m * p.ldc + n;
+            stg(pre, v0); stg(pre + 4, v1);
+            v0 = gg_act_f32_v4(v0, 1); v1 = gg_act_f32_v4(v1, 1);
+        }
+        if constexpr (EC == 3) { v0 = v0 * gg_act_grad_f32_v4(aux[i][0], 1); v1 = v1 * gg_act_grad_f32_v4(aux[i][1], 1); }
+        if constexpr (EC == 3 || EC == 4) {
+            if (p.rowscale) { const float sc = p.rowscale[m / p.rows_per_scale]; v0 = v0 * sc; v1 = v1 * sc; }
+        }
+        if constexpr (EC == 4) { v0 = v0 + aux[i][0]; v1 = v1 + aux[i][1]; }
+        stg(c, v0); stg(c + 4, v1);
+    }
+}
+
 // Row-layout epilogue of a BM x BN tile: the accumulators cross LDS (the idle ring) so that every global access of the epilogue is a run of whole rows --
 // a lane owns 8 consecutive columns of a row, 16 lanes one 128-column row: 512-byte f32 runs and 256-byte plane runs instead of the MFMA layout's
 // 64- / 32-byte pieces of 16 different rows per instruction (the plane-writing epilogues of fc1 / the fc2 dgrad were slower than the f32 GEMM's with those)
@@ -519,7 +575,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
 // vmcnt(4) leaves only A(s+2) in flight.
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // TN_: 16-column MFMA tiles per wave (4: 128-column tile; 3: 96 -- for N = 192, which 128-wide tiles cover with a quarter of the work wasted)
-template <int ABL, int TN_ = 4>
+template <int ABL, int TN_ = 4, int EC = 0>
 __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     constexpr int TN = TN_, BM = 256, BN = 32 * TN, WN = 2, NW = 8, TM = 4;
     constexpr int TA = BM * S3_SK, TB = BN * S3_SK, STAGE = 3 * (TA + TB);
@@ -679,7 +735,8 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
         for (int mt = 0; mt < TM; ++mt)
             *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 16 * TN + nt * 16 + lg * 4) = acc[nt][mt];
     __syncthreads();
-    split3_epilogue_rows<BM, BN, 512, ((ABL & 16) ? 1 : 0) | ((ABL & 64) ? 4 : 0)>(p, Ct, m0, n0);
+    if constexpr (EC == 0) split3_epilogue_rows<BM, BN, 512, ((ABL & 16) ? 1 : 0) | ((ABL & 64) ? 4 : 0)>(p, Ct, m0, n0);
+    else split3_epilogue_rows_ec<BM, BN, 512, ((ABL & 16) ? 1 : 0) | ((ABL & 64) ? 4 : 0), EC>(p, Ct, m0, n0);
 }
 
 // The 256 x 128 form on v_mfma_f32_32x32x16_bf16 (the default for 128-column tiles).  Same tile, ring, loader, split and epilogue as gemm_nt_split3a_kernel; a wave's
@@ -853,7 +910,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3w_kernel(Split3Params p) {
 // tile next to 11 us of MFMAs at K = 384: in the model those launches ran 20-45 % slower than the bias-only shape).  LDS: the A planes single-buffered (24 KB:
 // a wave reads ALL its A fragments of a stage, a second barrier frees the buffer, and the split of A(s + 1) is written into it under the stage's MFMAs), the B
 // planes double-buffered by LDS-DMA (2 x 24 KB).  Everything else as above.
-template <int TN_ = 4>
+template <int TN_ = 4, int EC = 0>
 __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
     constexpr int TN = TN_, BM = 128, BN = 32 * TN, WN = 2, TM = 4;
     constexpr int TA = BM * S3_SK, TB = BN * S3_SK;
@@ -991,7 +1048,8 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
         for (int mt = 0; mt < TM; ++mt)
             *reinterpret_cast<f32x4*>(Ct + (wm * 64 + mt * 16 + lr) * (BN + 4) + wn * 16 * TN + nt * 16 + lg * 4) = acc[nt][mt];
     __syncthreads();
-    split3_epilogue_rows<BM, BN, 256, 1>(p, Ct, m0, n0);      // (non-temporal result stores, as the 256 x 128 form)
+    if constexpr (EC == 0) split3_epilogue_rows<BM, BN, 256, 1>(p, Ct, m0, n0);      // (non-temporal result stores, as the 256 x 128 form)
+    else split3_epilogue_rows_ec<BM, BN, 256, 1, EC>(p, Ct, m0, n0);
 }
 
 // ------------------------------------------------------------------------------------------- weight gradient (TN), both operands f32
@@ -1306,12 +1364,24 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
     // dev: 32 = the 256 x 128 form on v_mfma_f32_32x32x16_bf16 (gemm_nt_split3w_kernel: 10 % fewer wave cycles, the same wall time at the clock the chip then holds)
     static const char* menv = gg_dev_env("GG_SPLIT3A_MFMA");
     const bool wide = menv && atoi(menv) == 32;
-    void (*kern)(Split3Params) = !big ? (n96 ? gemm_nt_split3b_kernel<3> : gemm_nt_split3b_kernel<4>) : n96 ? gemm_nt_split3a_kernel<16, 3> :
+    // epilogue class (split3_epilogue_rows_ec) when the shape takes the vector path and the options are one of the model's four combinations; 0 = the generic epilogue
+    static const char* eenv = gg_dev_env("GG_SPLIT3_NO_EC");       // dev: the generic epilogue everywhere
+    int ec = 0;
+    if (!eenv && p.C && !p.c_planes && !p.colstats && (p.N & 7) == 0 && (p.ldc & 3) == 0 && (!p.residual || (p.ldr & 3) == 0) && (!p.bias || ((uintptr_t)p.bias & 15) == 0)) {
+        if (p.act == 1 && p.preact && !p.rowscale && !p.residual && !p.dact_preact) ec = 2;
+        else if (p.dact_preact && p.dact == 1 && !p.bias && !p.act && !p.preact && !p.residual) ec = 3;
+        else if (p.residual && !p.act && !p.preact && !p.dact_preact) ec = 4;
+        else if (!p.act && !p.preact && !p.rowscale && !p.residual && !p.dact_preact) ec = 1;
+    }
+#define S3_EC(K, ...) (ec == 1 ? K<__VA_ARGS__, 1> : ec == 2 ? K<__VA_ARGS__, 2> : ec == 3 ? K<__VA_ARGS__, 3> : ec == 4 ? K<__VA_ARGS__, 4> : K<__VA_ARGS__, 0>)
+    void (*kern)(Split3Params) = !big ? (n96 ? S3_EC(gemm_nt_split3b_kernel, 3) : S3_EC(gemm_nt_split3b_kernel, 4)) : n96 ? S3_EC(gemm_nt_split3a_kernel, 16, 3) :
+                                 (!wide && abl == 16) ? S3_EC(gemm_nt_split3a_kernel, 16, 4) :
                                  wide ? (abl == 256 ? gemm_nt_split3w_kernel<0> : abl == 48 ? gemm_nt_split3w_kernel<48> : gemm_nt_split3w_kernel<16>) :
                                  abl == 1 ? gemm_nt_split3a_kernel<1> : abl == 2 ? gemm_nt_split3a_kernel<2> : abl == 4 ? gemm_nt_split3a_kernel<4> :
                                  abl == 8 ? gemm_nt_split3a_kernel<8> : abl == 6 ? gemm_nt_split3a_kernel<6> : abl == 256 ? gemm_nt_split3a_kernel<0> :
                                  abl == 32 ? gemm_nt_split3a_kernel<32> : abl == 48 ? gemm_nt_split3a_kernel<48> : abl == 80 ? gemm_nt_split3a_kernel<80> :
                                  abl == 112 ? gemm_nt_split3a_kernel<112> : gemm_nt_split3a_kernel<16>;
+#undef S3_EC
     const size_t lds = big ? (size_t)2 * 3 * (256 + bn) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * bn) * S3_SK * sizeof(bf16);
     {
         static std::mutex raised_mu;

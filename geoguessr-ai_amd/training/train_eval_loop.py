@@ -148,9 +148,10 @@ def evaluate_model(model, dataset, metrics: Callable, train_args, refiner=None, 
 
 
 def train_model(loaded_model: Any, dataset, on_embeddings: bool, train_args, metrics: Callable, patience: int = None,
-                should_profile: bool = False, refiner=None, log_fn: Optional[Callable] = None, save_path: str = CURRENT_SAVE_PATH,
+                should_profile: bool = True, refiner=None, log_fn: Optional[Callable] = None, save_path: str = CURRENT_SAVE_PATH,
                 broadcast_buffers: bool = True):
-    """Reference contract (:158-274).  DDP start-up semantics of ``accelerator.prepare`` (:200-202) are kept: parameters and
+    """Reference contract (:158-274; ``should_profile`` defaults to True as there, :165: the torch.profiler schedule of ``generate_profiler`` writes its
+    traces under ``runs/profile``).  DDP start-up semantics of ``accelerator.prepare`` (:200-202) are kept: parameters and
     buffers are broadcast from rank 0 once, BatchNorm running statistics are re-broadcast from rank 0 before every training
     forward (``DistributedDataParallel(broadcast_buffers=True)``, the default), gradients are summed over ranks before each
     optimizer step (overlapped with the encoder's backward pass) and averaged inside the AdamW kernel."""

@@ -191,7 +191,7 @@ def _train_worker(rank, world, port, out):
                                  gradient_accumulation_steps=2, logging_steps=1, seed=1)
     logs = []
     save = f"/tmp/gg_test_train_model_{port}.pt"
-    best = T.train_model(model, data, True, args, metrics, patience=2, refiner=None, log_fn=lambda *a: logs.append(a), save_path=save)
+    best = T.train_model(model, data, True, args, metrics, patience=2, should_profile=False, refiner=None, log_fn=lambda *a: logs.append(a), save_path=save)
     saved = torch.load(save) if rank == 0 else None
     out.put((rank, [p.detach().numpy().copy() for p in model.parameters()], calls, len(logs), best is model,
              None if saved is None else {k: v.numpy().copy() for k, v in saved.items()}))

@@ -784,10 +784,19 @@ def test_split3_gemm_with_f32_activation_operand(ops, M, N, K, lda):
     got = run(bias=bias, act=1, preact=pre_out)
     r, r_pre = ops.gemm_nt(Ac, B, bias=bias, act="gelu", preact=True)
     assert rel(got, r) < 1e-5 and rel(pre_out, r_pre) < 1e-5
+    # the compile-time epilogue classes (split3_epilogue_rows_ec: taken when N % 8 == 0 and the pitches allow the vector path) against the generic row epilogue, which a
+    # plane output forces: same arithmetic in the same order, bit for bit
+    cp = torch.empty(3, M, N, dtype=torch.bfloat16, device="cuda")
+    pre_gen = torch.empty(M, N, device="cuda")
+    assert torch.equal(got, run(bias=bias, act=1, preact=pre_gen, c_planes=cp, ldp=N)) and torch.equal(pre_out, pre_gen)
     got = run(bias=bias, rowscale=scale, rows_per_scale=rps, residual=res, ldr=N)
     assert rel(got, ops.gemm_nt(Ac, B, bias=bias, rowscale=scale, rows_per_scale=rps, residual=res)) < 1e-5
+    assert torch.equal(got, run(bias=bias, rowscale=scale, rows_per_scale=rps, residual=res, ldr=N, c_planes=cp, ldp=N))
+    assert torch.equal(run(bias=bias, residual=res, ldr=N), run(bias=bias, residual=res, ldr=N, c_planes=cp, ldp=N))
     got = run(dact_preact=pre, dact=1, rowscale=scale, rows_per_scale=rps)
     assert rel(got, ops.gemm_nt(Ac, B, dact_preact=pre, dact="gelu", rowscale=scale, rows_per_scale=rps)) < 1e-5
+    assert torch.equal(got, run(dact_preact=pre, dact=1, rowscale=scale, rows_per_scale=rps, c_planes=cp, ldp=N))
+    assert torch.equal(run(dact_preact=pre, dact=1), run(dact_preact=pre, dact=1, c_planes=cp, ldp=N))
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 200, 96), (700, 192, 416), (5000, 384, 96), (300, 48, 32)])

@@ -72,7 +72,7 @@ def test_train_model_and_evaluate_model_c1(centroids, tmp_path):
     logs = []
     save = str(tmp_path / "best.model")
     w_before = model.cell_layer.weight.detach().clone()
-    best = train_model(model, data, False, args, metrics, patience=2, refiner=refiner, log_fn=lambda tag, v, step: logs.append((tag, float(v), step)),
+    best = train_model(model, data, False, args, metrics, patience=2, should_profile=False, refiner=refiner, log_fn=lambda tag, v, step: logs.append((tag, float(v), step)),
                        save_path=save)
     assert best is model
     train_losses = [v for t, v, _ in logs if t == "Loss/train"]

@@ -57,6 +57,9 @@ for name, M, N, K in shapes:
     A = torch.randn(M, K, device="cuda", generator=g)
     B = torch.randn(N, K, device="cuda", generator=g) * K ** -0.5
     bias = torch.randn(N, device="cuda", generator=g)
+    if os.environ.get("ZERO") == "1": A.zero_(); B.zero_()          # (clock experiment: all-zero operands toggle no matrix-pipe inputs)
+    if os.environ.get("ZERO") == "A": A.zero_()
+    if os.environ.get("ZERO") == "small": A.mul_(2.0 ** -8).round_().mul_(2.0 ** 8)      # (operands exactly representable in bf16: planes 2 and 3 are zero)
     Ap, Bp = planes(A), planes(B)
     o32, o3, o3a = (torch.empty(M, N, device="cuda") for _ in range(3))
     t32 = timed(lambda: ops.gemm_nt(A, B, bias=bias, out=o32))
