@@ -11,7 +11,7 @@
 //   * tile 256 x 128, k-stage 32 (one v_mfma_f32_16x16x32_bf16 step), 512 threads = 4 x 2 waves (64 x 64 per wave: 4 x 4 MFMA tiles x 6 products = 96 MFMAs per
 //     24 fragment reads and stage; the 128 x 128 / 64 x 32-per-wave form moves 1.5 x the LDS bytes per MFMA and sits at the LDS-port / MFMA balance point);
 //   * LDS-DMA (`buffer_load ... lds`, 16 B per lane, no VGPR staging) into a 2-stage ring of 6 plane tiles (72 KB per stage: 144 KB, one workgroup per CU), rows of 64 bytes with the
-//     16-byte chunk index XOR-ed with s3_swz((row >> 2) & 3) on the SOURCE side of the DMA, so the fragment reads (ds_read_b128: 16 rows x one chunk) are
+//     16-byte chunk index XOR-ed with s3_swz((row >> 2) & 3, p.swz_plain) on the SOURCE side of the DMA, so the fragment reads (ds_read_b128: 16 rows x one chunk) are
 //     conflict-free without padding (s3_swz: the permutation the instruction's 16-lane service groups need);
 //   * one raw s_barrier per stage, the next stage's DMA in flight under the current stage's 96 MFMAs; two waves per SIMD.
 // Epilogues: the Linear family of the model (bias, GELU with a saved pre-activation, rowscale + residual, x GELU'), results as f32 and / or as planes for the
@@ -42,6 +42,7 @@ struct Split3Params {
     const float* residual; int64_t ldr;
     const float* dact_preact; int dact;
     bf16* c_planes; int64_t ldp;
+    int swz_plain;                     // dev A/B: 1 = the round-5 chunk swizzle (plain XOR with the row quad: 2-way bank conflicts on every fragment read)
     float* colstats;                   // BatchNorm partials [ceil(M / 128)][2][N] (column sums of the result and of its square per 128-row block; plain epilogue only) or null
 };
 
@@ -292,7 +293,7 @@ constexpr int S3_STAGE = 6 * S3_TILE;                          // a1 a2 a3 b1 b2
 // different positions.  The plain XOR (position = c ^ q) maps (q 0, lg 0) and (q 1, lg 1) to the same position: a 2-way conflict in every group, every
 // fragment read took 8 instead of 4 LDS cycles (SQ_LDS_BANK_CONFLICT = 4 cycles per ds_read_b128, 39 % of the LDS-active cycles:
 // profiles/r06_split_sq_counters.txt).  The permutation q -> {0, 2, 3, 1} makes every group a permutation of the 16 slots.
-__device__ __forceinline__ int s3_swz(int q) { return (0x78 >> (2 * q)) & 3; }
+__device__ __forceinline__ int s3_swz(int q, int plain = 0) { return plain ? q : (0x78 >> (2 * q)) & 3; }
 template <int N> __device__ __forceinline__ void wait_outstanding() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // BM x BN tile, WM x WN waves (each (BM / WM) x (BN / WN)), NST ring stages; PIPE: fragments of stage s + 1 are read into a second register set under the MFMAs of stage s
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
     const int lr = lane & 15, lg = lane >> 4;
     // DMA geometry: slice sl = wave + NW j covers tile rows 16 sl .. 16 sl + 15: lane -> (row 16 sl + lane / 4, LDS chunk slot lane % 4); the slot holds SOURCE chunk
     // slot ^ ((row >> 2) & 3) = slot ^ (lane >> 4) (16 sl does not touch bits 2-3)
-    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4);
+    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4, p.swz_plain);
     const unsigned rowsA = (unsigned)min(p.M - m0, BM), rowsB = (unsigned)min(p.N - n0, BN);
     __amdgpu_buffer_rsrc_t rs[6];
 #pragma unroll
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_split3_kernel(Split3Para
         }
     };
     // fragment addresses: row (16 t + lr) of a plane tile, k-chunk lg -> slot lg ^ ((lr >> 2) & 3) (the tile index t does not touch bits 2-3 of the row)
-    const int fslot = (lg ^ s3_swz((lr >> 2) & 3)) * 8;
+    const int fslot = (lg ^ s3_swz((lr >> 2) & 3, p.swz_plain)) * 8;
     const int a_off = (wm * (BM / WM) + lr) * S3_SK + fslot, b_off = 3 * TA + (wn * (BN / WN) + lr) * S3_SK + fslot;
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -487,10 +488,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
-    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4);
+    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4, p.swz_plain);
     const unsigned row = (unsigned)(wave * 16 + (lane >> 2));
     const unsigned voffA = row * (unsigned)p.lda * 2u + dchunk * 16u, voffB = row * (unsigned)p.ldb * 2u + dchunk * 16u;
-    const int fslot = (lg ^ s3_swz((lr >> 2) & 3)) * 8;
+    const int fslot = (lg ^ s3_swz((lr >> 2) & 3, p.swz_plain)) * 8;
     const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = (wn * 32 + lr) * S3_SK + fslot;
     const int nk = (p.K + S3_SK - 1) / S3_SK;
     __amdgpu_buffer_rsrc_t rs[6];
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     const int lr = lane & 15, lg = lane >> 4;
     const unsigned rowsA = (unsigned)min(p.M - m0, BM), rowsB = (unsigned)min(p.N - n0, BN);
     // B planes: 16-row slices by LDS-DMA (one per plane and wave: 8 slices = 128 rows), source chunk = slot ^ ((row >> 2) & 3)
-    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4);
+    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4, p.swz_plain);
     __amdgpu_buffer_rsrc_t rsB[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     for (int j = 0; j < 4; ++j) {
         const int row = arow + 64 * j;
         voffA[j] = (unsigned)row * (unsigned)p.ldaf * 4u + kq * 16u;
-        ldsA[j] = row * S3_SK + (((kq >> 1) ^ s3_swz((row >> 2) & 3)) << 3) + ((kq & 1) << 2);
+        ldsA[j] = row * S3_SK + (((kq >> 1) ^ s3_swz((row >> 2) & 3, p.swz_plain)) << 3) + ((kq & 1) << 2);
     }
     auto issue_b = [&](int st, bf16* base) {
         const int k0 = st * S3_SK;
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
             *reinterpret_cast<bf16x4*>(base + 2 * TA + ldsA[j]) = p3;
         }
     };
-    const int fslot = (lg ^ s3_swz((lr >> 2) & 3)) * 8;
+    const int fslot = (lg ^ s3_swz((lr >> 2) & 3, p.swz_plain)) * 8;
     const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = 3 * TA + (wn * 16 * TN + lr) * S3_SK + fslot;
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
     const unsigned rowsA = (unsigned)min(p.M - m0, BM), rowsB = (unsigned)min(p.N - n0, BN);
-    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4);
+    const int dchunk = (lane & 3) ^ s3_swz(lane >> 4, p.swz_plain);
     __amdgpu_buffer_rsrc_t rsB[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
     for (int j = 0; j < 4; ++j) {
         const int row = arow + 32 * j;
         voffA[j] = (unsigned)row * (unsigned)p.ldaf * 4u + kq * 16u;
-        ldsA[j] = row * S3_SK + (((kq >> 1) ^ s3_swz((row >> 2) & 3)) << 3) + ((kq & 1) << 2);
+        ldsA[j] = row * S3_SK + (((kq >> 1) ^ s3_swz((row >> 2) & 3, p.swz_plain)) << 3) + ((kq & 1) << 2);
     }
     auto issue_b = [&](int st) {
         bf16* const base = Bbuf + (st & 1) * 3 * TB;
@@ -969,7 +970,7 @@ __global__ __launch_bounds__(256) void gemm_nt_split3b_kernel(Split3Params p) {
             p1[e] = s1_; p2[e] = s2_; p3[e] = s3_;
         }
     };
-    const int fslot = (lg ^ s3_swz((lr >> 2) & 3)) * 8;
+    const int fslot = (lg ^ s3_swz((lr >> 2) & 3, p.swz_plain)) * 8;
     const int a_off = (wm * 64 + lr) * S3_SK + fslot, b_off = (wn * 16 * TN + lr) * S3_SK + fslot;
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -1068,18 +1069,19 @@ struct Split3TnParams {
 };
 constexpr int TN3_SUB = 1024 + 32;                                 // elements of one 32-column sub-image of the TN kernel's plane images (skewed: see the kernel)
 __device__ __forceinline__ int s3_img_off(int row, int ch) { return row * 32 + ((ch ^ ((-(row >> 2)) & 3)) << 3); }
+template <int SUB_, bool REMAP>
 __global__ __launch_bounds__(512) void gemm_tn_split3_kernel(Split3TnParams p) {
     constexpr int BN = 256, BK = 128, WK = 2;
-    // plane images of one stage (bf16 elements): dY then X, as sub-images of 32 columns x 32 rows.  A sub-image is 1024 + 32 elements: the 64-byte skew puts the
-    // two sub-images a 16-lane group of a plane write (ds_write_b64: 4 x 16 lanes over 32 banks) touches on different halves of the 128-byte bank window -- at a
-    // pitch of exactly 2 KB every plane write was a 2-way conflict (576 LDS cycles per stage: profiles/r06_split_sq_counters.txt)
-    constexpr int SUB = TN3_SUB;
+    // plane images of one stage (bf16 elements): dY then X, as sub-images of 32 columns x 32 rows (SUB elements each: 1024, or 1024 + 32 -- the 64-byte skew that puts the
+    // two sub-images a 16-lane group of a plane write touches on different halves of the 128-byte bank window; at a pitch of exactly 2 KB every plane write is a 2-way
+    // conflict, 576 LDS cycles per stage, and yet the unskewed image is the faster one: see gg_gemm_tn_split3)
+    constexpr int SUB = SUB_;
     constexpr int PY = (BN / 32) * SUB, PX = (BK / 32) * SUB, STAGE = 3 * (PY + PX);
     extern __shared__ __attribute__((aligned(16))) bf16 s3mem[];
     // XCD-contiguous walk: the tiles of one row slab are consecutive logical ids, so they run on ONE XCD at about the same time and its L2 serves the slab's dY / X rows to
     // all of them (in dispatch order the K-tiles of a slab sat on different XCDs: dY was fetched once per K-tile and X once per N-tile from HBM, 3-4 x the algorithmic bytes)
     const int tiles = p.tilesN * p.tilesK;
-    const int lid = gg_xcd_remap(blockIdx.x, gridDim.x);
+    const int lid = REMAP ? gg_xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int t = lid % tiles, slab = lid / tiles;
     const int tn = t / p.tilesK, tk = t % p.tilesK;
     const int n0 = tn * BN, k0 = tk * BK;
@@ -1307,6 +1309,7 @@ extern "C" int gg_gemm_nt_split3_ex(const GgSplit3Args* a, void* stream) {
     GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3: rowscale needs rows_per_scale");
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3: act and dact_preact are exclusive");
     Split3Params p;
+    p.swz_plain = 0;
     p.A = (const bf16*)a->a_planes; p.lda = a->lda; p.plane_a = (int64_t)a->M * a->lda; p.Af = nullptr; p.ldaf = 0;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
@@ -1340,6 +1343,8 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3_af32: act and dact_preact are exclusive");
     GG_CHECK(!colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->c_planes), "gg_gemm_nt_split3_af32: colstats needs the plain epilogue");
     Split3Params p;
+    static const char* senv = gg_dev_env("GG_SPLIT3_SWZ");      // dev A/B: 0 = the plain-XOR chunk swizzle of round 5
+    p.swz_plain = senv && atoi(senv) == 0;
     p.colstats = colstats;
     p.A = nullptr; p.lda = 0; p.plane_a = 0; p.Af = A; p.ldaf = lda;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = b_plane_stride > 0 ? b_plane_stride : (int64_t)a->N * a->ldb;
@@ -1434,14 +1439,22 @@ extern "C" int gg_gemm_tn_split3(const float* dY, int64_t ldy, const float* X, i
     GG_CHECK((int64_t)p.rows_per_split * (splits - 1) < M, "gg_gemm_tn_split3: more splits than 32-row stages");
     GG_CHECK((int64_t)p.rows_per_split * std::max(ldy, ldx) * 4 < ((int64_t)1 << 31), "gg_gemm_tn_split3: a slab exceeds the 2 GiB descriptor range");
     p.tilesN = (int)gg_cdiv(N, 256); p.tilesK = (int)gg_cdiv(K, 128);
-    static bool raised = false;
-    if (!raised) {
-        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_split3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+    // dev A/B (same box, tools/bench_split3_tn.py, profiles/r06_tn_split_ab.txt): bit 0 = dispatch-order walk (no XCD-contiguous remap), bit 1 = sub-images skewed by 64 bytes.
+    // Default: remap, no skew -- the remap is worth 3-5 % (and cuts the HBM fetch 4 x); the skew removes every LDS bank conflict of the plane writes (SQ_LDS_BANK_CONFLICT
+    // 41 M -> 0 per launch) and still LOSES 5-9 %: those conflict cycles were hidden under the MFMAs, the 152 KB ring's larger offsets are not free
+    static const char* tenv = gg_dev_env("GG_SPLIT3_TN");
+    const int tv = tenv ? atoi(tenv) : 0;
+    void (*kern)(Split3TnParams) = tv == 1 ? gemm_tn_split3_kernel<1024, false> : tv == 2 ? gemm_tn_split3_kernel<TN3_SUB, true> : tv == 3 ? gemm_tn_split3_kernel<TN3_SUB, false> :
+                                   gemm_tn_split3_kernel<1024, true>;
+    const int sub = (tv & 2) ? TN3_SUB : 1024;
+    static bool raised[4] = {false, false, false, false};
+    if (!raised[tv & 3]) {
+        GG_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
                  "gg_gemm_tn_split3: cannot raise the dynamic LDS limit");
-        raised = true;
+        raised[tv & 3] = true;
     }
     GG_PROF(GG_CAT_GEMM | GG_CAT_SPLIT_FLAG, 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K) + 8.0 * splits * (double)N * K, stream);
-    hipLaunchKernelGGL(gemm_tn_split3_kernel, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(512), (size_t)2 * 3 * (256 / 32 + 128 / 32) * TN3_SUB * sizeof(bf16), (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.tilesN * p.tilesK * splits)), dim3(512), (size_t)2 * 3 * (256 / 32 + 128 / 32) * sub * sizeof(bf16), (hipStream_t)stream, p);
     GG_LAUNCH_CHECK();
     return 0;
 }
