@@ -608,7 +608,10 @@ __device__ __forceinline__ void gemm_dma_epilogue(const GemmParams& p, ge_t* scr
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (ge_t)((float)v[j] + (float)e[j]);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)vo, 0, 0);
+            // result stores non-temporal: the tile's rows are not read again by this launch, and kept out of the L2's way they do not evict the weight panel and the A rows
+            // the concurrent tiles share (c4 fp16 12.1 -> 11.9 ms, bf16 11.8 -> 11.55: same-box A/B, profiles/r06_c4_nt_stores.txt; dev: GG_GEMM_DEBUG=32 restores the default policy)
+            if (p.debug & 32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)vo, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)vo, 0, 2);
         }
     }
 }
