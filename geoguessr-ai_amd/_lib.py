@@ -152,6 +152,7 @@ SIGNATURES = {
     "gg_gemm_nt_split3_ex": (_I, [C.POINTER(Split3Args), _P]),
     "gg_gemm_nt_split3_af32": (_I, [C.POINTER(Split3Args), _P, _L, _L, _P]),
     "gg_gemm_nt_split3_af32_stats": (_I, [C.POINTER(Split3Args), _P, _L, _L, _P, _P]),
+    "gg_gemm_nt_split3_af32_pro": (_I, [C.POINTER(Split3Args), _P, _L, _L, _P, _P, _P, _I, _P, _P]),
     "gg_gemm_tn_split3_splits": (_I, [_I, _I, _I]),
     "gg_gemm_tn_split3": (_I, [_P, _L, _P, _L, _I, _I, _I, _P, _I, _P, _I, _P]),
     "gg_gemm_nt_f32": (_I, [C.POINTER(GemmArgs), _P]),

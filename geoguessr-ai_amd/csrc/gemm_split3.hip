@@ -42,6 +42,7 @@ struct Split3Params {
     const float* residual; int64_t ldr;
     const float* dact_preact; int dact;
     bf16* c_planes; int64_t ldp;
+    const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;      // A prologue (gemm_nt_split3a_kernel<..., PRO>): A := a_act(BatchNorm(A)), a_stat = [mean | rstd][K]
     int swz_plain;                     // dev A/B: 1 = the round-5 chunk swizzle (plain XOR with the row quad: 2-way bank conflicts on every fragment read)
     float* colstats;                   // BatchNorm partials [ceil(M / 128)][2][N] (column sums of the result and of its square per 128-row block; plain epilogue only) or null
 };
@@ -576,7 +577,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split3_persistent_kernel(Split3Pa
 // vmcnt(4) leaves only A(s+2) in flight.
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // TN_: 16-column MFMA tiles per wave (4: 128-column tile; 3: 96 -- for N = 192, which 128-wide tiles cover with a quarter of the work wasted)
-template <int ABL, int TN_ = 4, int EC = 0>
+// PRO: the A operand is a saved pre-BatchNorm convolution output and the product wants act(BatchNorm(A)) (MBConv conv3 reading BN2 + GELU of the depthwise conv): the
+// transform rides on the loader, in front of the split -- per element one FMA with the column's (scale, shift) from an LDS table + the f32-accurate GELU; with one N-tile
+// (N = 96) every element is transformed exactly once and the activation tensor is never written (the f32-MFMA form of this fusion applied it to the fragments of every wave)
+template <int ABL, int TN_ = 4, int EC = 0, int PRO = 0>      // PRO: 0 off; 1 + activation code of the prologue (1 BatchNorm only, 2 + GELU, 3 + QuickGELU): compile-time, so a stage carries one activation's code
 __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     constexpr int TN = TN_, BM = 256, BN = 32 * TN, WN = 2, NW = 8, TM = 4;
     constexpr int TA = BM * S3_SK, TB = BN * S3_SK, STAGE = 3 * (TA + TB);
@@ -608,6 +612,23 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
         voffA[j] = (unsigned)row * (unsigned)p.ldaf * 4u + kq * 16u;
         ldsA[j] = row * S3_SK + (((kq >> 1) ^ s3_swz((row >> 2) & 3, p.swz_plain)) << 3) + ((kq & 1) << 2);
     }
+    // PRO: (scale, shift) per contraction column behind the ring: [2][KT] floats, zero beyond K (the masked stages then transform zeros into act(0) = 0)
+    float* const ptab = reinterpret_cast<float*>(s3mem + 2 * STAGE);
+    const int KT = PRO ? ((p.K + 31) & ~31) + 3 * S3_SK : 0;
+    if constexpr (PRO) {
+        for (int k = threadIdx.x; k < KT; k += 512) {
+            float sc = 0.f, sh = 0.f;
+            if (k < p.K) { sc = p.a_gamma[k] * p.a_stat[p.K + k]; sh = p.a_beta[k] - p.a_stat[k] * sc; }
+            ptab[k] = sc; ptab[KT + k] = sh;
+        }
+        __syncthreads();
+    }
+    auto pro4 = [&](f32x4 v, int st) -> f32x4 {                     // act(v * scale + shift) for this thread's four columns of stage st
+        if constexpr (PRO) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(ptab + st * S3_SK + kq * 4), sh = *reinterpret_cast<const f32x4*>(ptab + KT + st * S3_SK + kq * 4);
+            return gg_act_f32_v4(v * sc + sh, PRO - 1);
+        } else return v;
+    };
     auto issue_b = [&](int st, bf16* base) {
         const int k0 = st * S3_SK;
         const bool kin = k0 + dchunk * 8 < p.K;
@@ -652,6 +673,10 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
     load_a(0, ra[0]);
     load_a(1, ra[1]);
     wait_vm<4>();                                                   // B(0) and A(0)
+    if constexpr (PRO) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ra[0][j] = pro4(ra[0][j], 0);
+    }
     split_store(ra[0], s3mem);
     load_a(2, ra[0]);
     // Every stage runs the same branch-free code, written in the order it should issue: 24 quads of MFMAs (one n-tile x four m-tiles of one plane product), and
@@ -704,6 +729,7 @@ __global__ __launch_bounds__(512) void gemm_nt_split3a_kernel(Split3Params p) {
                 if ((qi * 12) % Q < 12 && !(ABL & 4)) {
                     const int ms = (qi * 12) / Q, jj = ms / 3, part = ms % 3;
                     if (part < 2) {
+                        if (PRO && part == 0) rnext[jj] = pro4(rnext[jj], s + 1);      // (the row's four columns at once: two packed GELU evaluations)
 #pragma unroll
                         for (int e = 2 * part; e < 2 * part + 2; ++e) {
                             bf16 s1_, s2_, s3_;
@@ -1310,6 +1336,7 @@ extern "C" int gg_gemm_nt_split3_ex(const GgSplit3Args* a, void* stream) {
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3: act and dact_preact are exclusive");
     Split3Params p;
     p.swz_plain = 0;
+    p.a_stat = p.a_gamma = p.a_beta = nullptr; p.a_act = 0;
     p.A = (const bf16*)a->a_planes; p.lda = a->lda; p.plane_a = (int64_t)a->M * a->lda; p.Af = nullptr; p.ldaf = 0;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
@@ -1332,7 +1359,23 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
 extern "C" int gg_gemm_nt_split3_af32(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, void* stream) {
     return gg_gemm_nt_split3_af32_stats(a, A, lda, b_plane_stride, nullptr, stream);
 }
+static int split3_af32_launch(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, const float* bn_stat, const float* bn_gamma,
+                              const float* bn_beta, int bn_act, void* stream);
 extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, void* stream) {
+    return split3_af32_launch(a, A, lda, b_plane_stride, colstats, nullptr, nullptr, nullptr, 0, stream);
+}
+// A := act(BatchNorm(A)) formed in the loader (bn_stat = [mean | rstd][K] as gg_bn_finalize leaves it; act GG_ACT_NONE / GELU / QUICK_GELU): the split twin of
+// GgGemmArgs.a_bn_* (gg_gemm_nt_f32's BatchNorm prologue).  K >= 384 (the 256 x 128 form), K <= 1024, plain epilogue (optionally with colstats)
+extern "C" int gg_gemm_nt_split3_af32_pro(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, const float* bn_stat, const float* bn_gamma,
+                                          const float* bn_beta, int bn_act, float* colstats, void* stream) {
+    GG_CHECK(bn_stat && bn_gamma && bn_beta, "gg_gemm_nt_split3_af32_pro: the BatchNorm prologue needs stat, gamma, beta");
+    GG_CHECK(a && a->K >= 384 && a->K <= 1024, "gg_gemm_nt_split3_af32_pro: K must be 384 ... 1024");
+    GG_CHECK(bn_act >= 0 && bn_act <= 2, "gg_gemm_nt_split3_af32_pro: act must be GG_ACT_NONE, GG_ACT_GELU or GG_ACT_QUICK_GELU");
+    GG_CHECK(!(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->c_planes), "gg_gemm_nt_split3_af32_pro: plain epilogue only");
+    return split3_af32_launch(a, A, lda, b_plane_stride, colstats, bn_stat, bn_gamma, bn_beta, bn_act, stream);
+}
+static int split3_af32_launch(const GgSplit3Args* a, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, const float* bn_stat, const float* bn_gamma,
+                              const float* bn_beta, int bn_act, void* stream) {
     GG_CHECK(a && A && a->b_planes && (a->C || a->c_planes) && a->M > 0 && a->N > 0 && a->K > 0, "gg_gemm_nt_split3_af32: null pointer / bad shape");
     GG_CHECK((a->K & 7) == 0 && (lda & 3) == 0 && (a->ldb & 7) == 0 && lda >= a->K && a->ldb >= a->K, "gg_gemm_nt_split3_af32: K %% 8, lda %% 4, ldb %% 8, ld >= K");
     GG_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)a->b_planes & 15) == 0 && ((uintptr_t)a->C & 15) == 0 && ((uintptr_t)a->c_planes & 7) == 0, "gg_gemm_nt_split3_af32: alignment");
@@ -1346,6 +1389,8 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
     static const char* senv = gg_dev_env("GG_SPLIT3_SWZ");      // dev A/B: 0 = the plain-XOR chunk swizzle of round 5
     p.swz_plain = senv && atoi(senv) == 0;
     p.colstats = colstats;
+    p.a_stat = bn_stat; p.a_gamma = bn_gamma; p.a_beta = bn_beta; p.a_act = bn_act;
+    const bool pro = bn_stat != nullptr;
     p.A = nullptr; p.lda = 0; p.plane_a = 0; p.Af = A; p.ldaf = lda;
     p.B = (const bf16*)a->b_planes; p.ldb = a->ldb; p.plane_b = b_plane_stride > 0 ? b_plane_stride : (int64_t)a->N * a->ldb;
     p.C = a->C; p.ldc = a->ldc ? a->ldc : a->N; p.bias = a->bias; p.M = a->M; p.N = a->N; p.K = a->K;
@@ -1354,7 +1399,7 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
     // 256 x 128 (one 144 KB workgroup per CU) from K = 384 on; 128 x 128 (two per CU) for the short contractions of stage 1, where a tile lives only 6 stages and
     // the second workgroup hides its prologue / epilogue (K = 192: 1.30 x against 1.22 x the f32-MFMA GEMM; at K >= 384 the big tile wins by 1-2 %)
     static const char* tenv = gg_dev_env("GG_SPLIT3A_TILE");      // dev: 256 / 128 forces one form
-    const bool big = tenv ? atoi(tenv) == 256 : p.K >= 384;
+    const bool big = pro || (tenv ? atoi(tenv) == 256 : p.K >= 384);
     // 96-column tiles where 128-column ones would waste a fifth or more of their work on columns beyond N that 96-column ones do not (N = 192: 25 % -> -8...-11 %
     // in time; N = 576, 10 %: the narrower tile's higher LDS traffic per MFMA costs more than the waste)
     static const char* nenv = gg_dev_env("GG_SPLIT3A_BN");          // dev: 96 / 128 forces one width
@@ -1379,7 +1424,9 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
         else if (!p.act && !p.preact && !p.rowscale && !p.residual && !p.dact_preact) ec = 1;
     }
 #define S3_EC(K, ...) (ec == 1 ? K<__VA_ARGS__, 1> : ec == 2 ? K<__VA_ARGS__, 2> : ec == 3 ? K<__VA_ARGS__, 3> : ec == 4 ? K<__VA_ARGS__, 4> : K<__VA_ARGS__, 0>)
-    void (*kern)(Split3Params) = !big ? (n96 ? S3_EC(gemm_nt_split3b_kernel, 3) : S3_EC(gemm_nt_split3b_kernel, 4)) : n96 ? S3_EC(gemm_nt_split3a_kernel, 16, 3) :
+    void (*kern)(Split3Params) = pro ? (n96 ? (bn_act == 1 ? gemm_nt_split3a_kernel<16, 3, 0, 2> : bn_act == 2 ? gemm_nt_split3a_kernel<16, 3, 0, 3> : gemm_nt_split3a_kernel<16, 3, 0, 1>)
+                                            : (bn_act == 1 ? gemm_nt_split3a_kernel<16, 4, 0, 2> : bn_act == 2 ? gemm_nt_split3a_kernel<16, 4, 0, 3> : gemm_nt_split3a_kernel<16, 4, 0, 1>)) :
+                                 !big ? (n96 ? S3_EC(gemm_nt_split3b_kernel, 3) : S3_EC(gemm_nt_split3b_kernel, 4)) : n96 ? S3_EC(gemm_nt_split3a_kernel, 16, 3) :
                                  (!wide && abl == 16) ? S3_EC(gemm_nt_split3a_kernel, 16, 4) :
                                  wide ? (abl == 256 ? gemm_nt_split3w_kernel<0> : abl == 48 ? gemm_nt_split3w_kernel<48> : gemm_nt_split3w_kernel<16>) :
                                  abl == 1 ? gemm_nt_split3a_kernel<1> : abl == 2 ? gemm_nt_split3a_kernel<2> : abl == 4 ? gemm_nt_split3a_kernel<4> :
@@ -1387,7 +1434,9 @@ extern "C" int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* a, const float* 
                                  abl == 32 ? gemm_nt_split3a_kernel<32> : abl == 48 ? gemm_nt_split3a_kernel<48> : abl == 80 ? gemm_nt_split3a_kernel<80> :
                                  abl == 112 ? gemm_nt_split3a_kernel<112> : gemm_nt_split3a_kernel<16>;
 #undef S3_EC
-    const size_t lds = big ? (size_t)2 * 3 * (256 + bn) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * bn) * S3_SK * sizeof(bf16);
+    const size_t lds = (big ? (size_t)2 * 3 * (256 + bn) * S3_SK * sizeof(bf16) : (size_t)3 * (128 + 2 * bn) * S3_SK * sizeof(bf16)) +
+                       (pro ? (size_t)2 * (((p.K + 31) & ~31) + 3 * S3_SK) * sizeof(float) : 0);
+    GG_CHECK(lds <= 160 * 1024, "gg_gemm_nt_split3_af32: the ring plus the prologue table exceed the LDS");
     {
         static std::mutex raised_mu;
         static std::vector<const void*> raised;                    // kernels whose dynamic LDS limit has been raised (per kernel function, once)

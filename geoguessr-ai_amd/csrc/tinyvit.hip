@@ -572,6 +572,23 @@ static int conv_dense_fwd(const Exec& e, const ConvBNDense& c, const Act& a, con
 }
 // dense ConvNorm whose input is act(BN(prev.y)) of the preceding ConvNorm, formed while the GEMM stages its A tile
 static int conv_dense_fwd_pro(const Exec& e, const ConvBNDense& c, const Act& a, const BNP& prev_bn, const Act& prev, int in_act, int64_t M) {
+    // fp32_split mode: the same fusion on the split kernels (the transform rides on the loader, in front of the split; 256-row tiles: K >= 384)
+    static const char* min_tiles_env = gg_dev_env("GG_SPLIT_MIN_TILES");
+    const int64_t min_tiles = min_tiles_env ? atoll(min_tiles_env) : 128;
+    static const char* nopro_env = gg_dev_env("GG_SPLIT3_NO_PRO");          // dev: the f32-MFMA prologue GEMM in the split mode too
+    if (e.m->split && !nopro_env && c.w.Kp >= 384 && c.w.Kp <= 1024 && (c.w.Kp & 7) == 0 && ((M + 255) / 256) * ((c.w.N + 127) / 128) >= min_tiles) {
+        const int64_t off = reinterpret_cast<const char*>(e.Wn(c.w)) - e.wc;
+        for (const Model::PlaneOf& po : e.m->plane_of) {
+            if (po.w != off) continue;
+            if (po.ld != c.w.Kp || po.rows < c.w.N) break;
+            GgSplit3Args g;
+            memset(&g, 0, sizeof(g));
+            g.b_planes = e.wc + po.planes; g.ldb = c.w.Kp; g.M = (int)M; g.N = c.w.N; g.K = c.w.Kp; g.C = (float*)e.A(a.y); g.ldc = c.w.N;
+            GG_TRY(gg_gemm_nt_split3_af32_pro(&g, (const float*)e.A(prev.y), c.w.Kp, (int64_t)po.rows * po.ld, e.F(prev.stat), e.P(prev_bn.t_g), e.P(prev_bn.t_b), in_act,
+                                              e.training ? e.F(e.L->statpart) : nullptr, e.st));
+            return bn_stats(e, c.bn, a, gg_gemm_colstats_rows((int)M), M);
+        }
+    }
     GgGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = e.A(prev.y); g.lda = c.w.Kp; g.B = e.Wn(c.w); g.ldb = c.w.Kp; g.C = e.A(a.y); g.ldc = c.w.N;

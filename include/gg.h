@@ -256,6 +256,11 @@ int gg_gemm_nt_split3_af32(const GgSplit3Args* args, const float* A, int64_t lda
                            void* stream);
 /* ... with BatchNorm partials of the result (plain epilogue only): colstats [gg_gemm_colstats_rows(M)][2][N] as GgGemmArgs.colstats -- a ConvNorm's 1 x 1 convolution */
 int gg_gemm_nt_split3_af32_stats(const GgSplit3Args* args, const float* A, int64_t lda, int64_t b_plane_stride, float* colstats, void* stream);
+/* ... with A := act(BatchNorm(A)) formed in the loader, in front of the split (bn_stat = [mean | rstd][K] as gg_bn_finalize leaves it; act GG_ACT_NONE / GELU /
+ * QUICK_GELU): the split twin of GgGemmArgs.a_bn_* -- MBConv.conv3 reading BatchNorm2 + GELU of the depthwise convolution's saved output without the activation
+ * tensor ever being written (timm MBConv.forward, reached from models/tinyvit.py:135).  384 <= K <= 1024, plain epilogue, colstats optional. */
+int gg_gemm_nt_split3_af32_pro(const GgSplit3Args* args, const float* A, int64_t lda, int64_t b_plane_stride, const float* bn_stat, const float* bn_gamma,
+                               const float* bn_beta, int bn_act, float* colstats, void* stream);
 /* weight gradient dW[N][K] = sum_m s_m dY[m][n] X[m][k] as split products (both f32 operands split in the kernel's loader): the arguments and the slab protocol
  * of gg_gemm_tn_f32 (partials [splits][N][K], reduced by gg_splitk_reduce); splits from gg_gemm_tn_split3_splits. */
 int gg_gemm_tn_split3_splits(int M, int N, int K);

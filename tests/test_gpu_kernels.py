@@ -827,6 +827,52 @@ def test_split3_gemm_batchnorm_partials(M, N, K):
     assert torch.equal(stats, stats2) and torch.equal(out, out2)            # no atomics: repeatable
 
 
+@pytest.mark.parametrize("M,N,K,act", [(1000, 96, 384, 1), (700, 200, 416, 1), (513, 96, 1024, 0), (300, 128, 384, 2)])
+def test_split3_gemm_batchnorm_act_prologue(M, N, K, act):
+    """gg_gemm_nt_split3_af32_pro (the fp32_split mode's MBConv.conv3): C = act(BatchNorm(A)) . W^T with the transform formed in the loader, in front of the split --
+    against an fp64 product of the fp64-transformed operand (exact erf GELU / QuickGELU), against gg_gemm_nt_f32's own BatchNorm prologue (GgGemmArgs.a_bn_*), and
+    the BatchNorm partials of the result; 96- and 128-column tiles, a K that is not a multiple of the stage, a ragged M."""
+    import ctypes as C
+    from geoguessr_ai_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(M + N + K + act)
+    A = (torch.randn(M, K, generator=g) * 1.5 + 0.3).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    mean, rstd = torch.randn(K, generator=g) * 0.3, torch.rand(K, generator=g) + 0.5
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g) * 0.2
+    stat = torch.stack([mean, rstd]).contiguous().cuda(); gd, bd = gamma.cuda(), beta.cuda()
+    Wp = torch.empty(3, N, K, dtype=torch.bfloat16, device="cuda")
+    L.check(lib.gg_split3_bf16(W.data_ptr(), N, K, K, Wp.data_ptr(), L.stream()), "gg_split3_bf16")
+    parts = (M + 127) // 128
+    out = torch.empty(M, N, device="cuda"); stats = torch.full((parts, 2, N), float("nan"), device="cuda")
+    a = L.Split3Args()
+    a.b_planes, a.ldb, a.M, a.N, a.K, a.C, a.ldc = Wp.data_ptr(), K, M, N, K, out.data_ptr(), N
+    L.check(lib.gg_gemm_nt_split3_af32_pro(C.byref(a), A.data_ptr(), K, 0, stat.data_ptr(), gd.data_ptr(), bd.data_ptr(), act, stats.data_ptr(), L.stream()), "gg_gemm_nt_split3_af32_pro")
+    z = (A.double().cpu() - mean.double()) * (rstd.double() * gamma.double()) + beta.double()
+    t = z if act == 0 else 0.5 * z * (1 + torch.erf(z / 2 ** 0.5)) if act == 1 else z * torch.sigmoid(1.702 * z)
+    ref = t @ W.double().cpu().T
+    e = float((out.double().cpu() - ref).norm() / ref.norm())
+    # the f32-MFMA kernel's prologue on the same operands
+    ga = L.GemmArgs()
+    o32 = torch.empty(M, N, device="cuda")
+    ga.A, ga.lda, ga.B, ga.ldb, ga.C, ga.ldc, ga.M, ga.N, ga.K = A.data_ptr(), K, W.data_ptr(), K, o32.data_ptr(), N, M, N, K
+    ga.a_bn_stat, ga.a_bn_gamma, ga.a_bn_beta, ga.a_bn_act = stat.data_ptr(), gd.data_ptr(), bd.data_ptr(), act
+    L.check(lib.gg_gemm_nt_f32(C.byref(ga), L.stream()), "gg_gemm_nt_f32")
+    e32 = float((o32.double().cpu() - ref).norm() / ref.norm())
+    print(f"\n[split3 BN prologue {M}x{N}x{K} act {act}] rel-L2 vs fp64: split {e:.2e}, f32-MFMA {e32:.2e}")
+    assert e < 2e-6 and e < 1.5 * e32 + 2e-7
+    pad = torch.zeros(parts * 128, N, dtype=torch.float64); pad[:M] = out.double().cpu()
+    blk = pad.view(parts, 128, N)
+    want = torch.stack([blk.sum(1), (blk * blk).sum(1)], 1)
+    assert torch.isfinite(stats).all() and float((stats.double().cpu() - want).abs().max() / want.abs().max()) < 1e-5
+    # without statistics, and refused outside its domain
+    out2 = torch.empty(M, N, device="cuda"); a.C = out2.data_ptr()
+    L.check(lib.gg_gemm_nt_split3_af32_pro(C.byref(a), A.data_ptr(), K, 0, stat.data_ptr(), gd.data_ptr(), bd.data_ptr(), act, None, L.stream()), "gg_gemm_nt_split3_af32_pro")
+    assert torch.equal(out, out2)
+    a.K = 192
+    assert lib.gg_gemm_nt_split3_af32_pro(C.byref(a), A.data_ptr(), K, 0, stat.data_ptr(), gd.data_ptr(), bd.data_ptr(), act, None, L.stream()) != 0
+
+
 @pytest.mark.parametrize("M,N,K,rps", [(5003, 200, 136, 7), (40, 8, 12, 0), (9000, 576, 320, 49), (4096, 260, 132, 0), (1100, 96, 432, 64)])
 def test_split3_weight_gradient_gemm(M, N, K, rps):
     """gg_gemm_tn_split3 (the fp32_split mode's weight gradient): dW[N][K] = sum_m s_m dY[m][n] X[m][k] with both f32 operands split in the kernel's loader, row slabs
