@@ -261,10 +261,20 @@ def _patch_merging(c: _Ctx, x, p):
 
 def _attention(c: _Ctx, x, p, nh, ws):
     """x: (B', N, C) windows.  Per-head interleaved [q|k|v] split."""
-    Bw, N, C = x.shape
+    C = x.shape[-1]
+    st = c.st
+    xn = c.q(F.layer_norm(x, (C,), st[f"{p}.attn.norm.weight"], st[f"{p}.attn.norm.bias"], c.cfg.ln_eps))
+    return _attention_core(c, xn, p, nh, ws)
+
+
+def _attention_core(c: _Ctx, xn, p, nh, ws):
+    """Everything of timm's TinyViT ``Attention`` behind its LayerNorm: qkv Linear, per-head [q|k|v] split, scaled scores + relative-position bias gathered through
+    the first-seen offset table, softmax, P.V, head merge (tap ``attn.out``), proj.  timm's class is LeViT's attention (Graham et al. 2021) with a LayerNorm in front
+    and plain Linears; the part up to the head merge is PINNED against the LeViT implementation that ships with ``transformers``
+    (``transformers.models.levit.modeling_levit.LevitAttention``: tests/test_oracle_models.py::test_tinyvit_attention_core_matches_transformers_levit)."""
+    Bw, N, C = xn.shape
     st = c.st
     hd = C // nh
-    xn = c.q(F.layer_norm(x, (C,), st[f"{p}.attn.norm.weight"], st[f"{p}.attn.norm.bias"], c.cfg.ln_eps))
     qkv = c.q(F.linear(xn, c.w(f"{p}.attn.qkv.weight"), st[f"{p}.attn.qkv.bias"]))
     q, k, v = qkv.view(Bw, N, nh, 3 * hd).split([hd, hd, hd], dim=3)
     q, k, v = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)

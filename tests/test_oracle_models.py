@@ -1,3 +1,4 @@
+import pytest
 """Oracle self-checks: CLIP restatement pinned to transformers; TinyViT restatement (parity
 UNPINNED, timm absent) checked by invariants from SURVEY.md App. A.  CPU only."""
 import os
@@ -92,6 +93,50 @@ def test_tinyvit_window_partition_equals_blockwise_attention():
     np.testing.assert_allclose(torch.roll(taps_a["stages.1.blocks.0.x1"], (7, 14), (1, 2)).numpy(),
                                taps_b["stages.1.blocks.0.x1"].numpy(), rtol=1e-4, atol=1e-5)
     assert y.shape == ys.shape
+
+
+@pytest.mark.parametrize("C,nh,ws", [(192, 6, 7), (384, 12, 14), (64, 2, 3)])
+def test_tinyvit_attention_core_matches_transformers_levit(C, nh, ws):
+    """A component pin for the otherwise unpinned TinyViT oracle (timm is not installed): timm's TinyViT ``Attention`` is LeViT's attention -- the same
+    per-head [q|k|v] split of one fused projection, ``q k^T * key_dim^-0.5 + attention_biases[:, attention_bias_idxs]`` with the offsets numbered in first-seen
+    order, softmax, P.V, head merge -- and ``transformers`` ships LeViT (``LevitAttention``), an implementation this repository did not write.  Its qkv projection is
+    Linear + BatchNorm1d: in eval mode with running_mean 0, gamma = sqrt(running_var + eps), beta = b that is exactly Linear with bias b.  The tensor it hands to its
+    output projection (captured in front of its Hardswish) must equal the oracle's ``attn.out`` tap for the same weights and the same (already normalised) input."""
+    from transformers.models.levit.modeling_levit import LevitAttention
+    from oracle import tinyvit_ref as R
+    g = torch.Generator().manual_seed(C + ws)
+    hd = C // nh
+    assert hd == 32
+    ref = LevitAttention(C, hd, nh, 1, ws)
+    ref.eval()                                      # (its train() override returns None)
+    W = torch.randn(3 * C, C, generator=g) * C ** -0.5
+    b = torch.randn(3 * C, generator=g) * 0.1
+    bias_tab = torch.randn(nh, ws * ws, generator=g) * 0.5
+    with torch.no_grad():
+        ref.queries_keys_values.linear.weight.copy_(W)
+        bn = ref.queries_keys_values.batch_norm
+        bn.running_mean.zero_(); bn.running_var.copy_(torch.rand(3 * C, generator=g) + 0.5)
+        bn.weight.copy_(torch.sqrt(bn.running_var + bn.eps)); bn.bias.copy_(b)
+        assert ref.attention_biases.shape == bias_tab.shape            # one entry per (|dy|, |dx|) offset: ws * ws
+        ref.attention_biases.copy_(bias_tab)
+    seen = {}
+    ref.activation.register_forward_pre_hook(lambda m, inp: seen.__setitem__("o", inp[0].detach().clone()))
+    xn = torch.randn(5, ws * ws, C, generator=g)
+    with torch.no_grad():
+        ref(xn)
+    # the oracle's block on the same weights (its proj is irrelevant here: identity)
+    cfg = R.config_for("tiny_vit_21m_224")
+    p = "blk"
+    st = {f"{p}.attn.qkv.weight": W, f"{p}.attn.qkv.bias": b, f"{p}.attn.attention_biases": bias_tab,
+          f"{p}.attn.proj.weight": torch.eye(C), f"{p}.attn.proj.bias": torch.zeros(C)}
+    taps = {}
+    c = R._Ctx(cfg, st, False, False, False, taps)
+    with torch.no_grad():
+        R._attention_core(c, xn, p, nh, ws)
+    got = taps[f"{p}.attn.out"]
+    assert got.shape == seen["o"].shape
+    assert torch.equal(ref.attention_bias_idxs, R.attention_bias_idxs(ws))
+    assert torch.allclose(got, seen["o"], rtol=1e-5, atol=2e-6), float((got - seen["o"]).abs().max())
 
 
 def test_clip_training_step_matches_reference_golden(golden_dir, centroids):
