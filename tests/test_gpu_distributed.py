@@ -1,0 +1,97 @@
+"""The data-parallel step on REAL kernels with two ranks (what DDP does for the reference: training/train_eval_loop.py:184-202,234).
+
+There is one GPU on the test box and RCCL refuses two ranks on one device, so the two processes share cuda:0 and exchange over gloo (torch.distributed stages CUDA
+tensors through the host).  Everything else is the N > 1 path as it runs under RCCL: parameter / buffer broadcast from rank 0, each rank's own shard through the HIP
+forward and backward, the stage-3 bucket's all-reduce launched by ``gg_tinyvit_backward``'s stage callback WHILE the earlier stages are still being differentiated, the
+remainder after the backward, 1 / world folded into the AdamW kernel.  Checked: the reduced gradients equal the sum of the two shards' gradients computed one after the
+other in one process (a bucket that left before its gradients were final, or a kernel that wrote into a range after its bucket had gone, would show here), the frozen
+ranges are never exchanged, and after the optimizer step both ranks hold bit-identical parameters."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from geoguessr_ai_amd.models.tinyvit import TinyViTAdapter
+        from geoguessr_ai_amd.models.super_guessr import SuperGuessr
+        from geoguessr_ai_amd.optim import AdamW
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(100 + rank)                      # ranks start from DIFFERENT weights: the broadcast must fix that
+        base = TinyViTAdapter("tiny_vit_5m_224", pretrained=False, drop_path_rate=0.0, precision="fp32")
+        cent = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "centroids_12647x2_f32.npy"))[:256]
+        model = SuperGuessr(base, panorama=True, should_smooth_labels=True, centroids=cent).to(dev).train()
+        bb = base.backbone
+        opt = AdamW(model, lr=1e-3)
+        opt.broadcast_params()
+        p_start = bb.flat_params.clone()
+        shards = []
+        for r in range(world):                               # every rank can form every shard (the expected values need both)
+            g = torch.Generator().manual_seed(7 + r)
+            shards.append((torch.randn(2, 4, 3, 224, 224, generator=g).to(dev),
+                           torch.stack([torch.rand(2, generator=g) * 360 - 180, torch.rand(2, generator=g) * 180 - 90], 1).to(dev)))
+
+        def grads_of(x, lab):
+            opt.zero_grad()
+            o = model(pixel_values=x, labels=lab)
+            o.loss.backward()
+            torch.cuda.synchronize()
+            return bb.flat_grads().clone(), model.cell_layer.weight.grad.clone(), float(o.loss)
+
+        # expected: the two shards one after the other, no exchange (weights are not stepped in between)
+        g0, w0, _ = grads_of(*shards[0])
+        g1, w1, _ = grads_of(*shards[1])
+        want_flat, want_w = g0 + g1, w0 + w1
+        # the data-parallel step: this rank's shard, buckets leaving from the backward pass
+        opt.zero_grad()
+        x, lab = shards[rank]
+        with opt.overlap_allreduce(enabled=True):
+            o = model(pixel_values=x, labels=lab)
+            o.loss.backward()
+            launched = len(opt._inflight)
+        opt.allreduce_grads()
+        torch.cuda.synchronize()
+        got_flat, got_w = bb.flat_grads().clone(), model.cell_layer.weight.grad.clone()
+        ranges = bb.trainable_ranges()
+        ok_ranges = all(torch.allclose(got_flat[s:e], want_flat[s:e], rtol=1e-5, atol=1e-7) for s, e in ranges)
+        worst = max(float((got_flat[s:e] - want_flat[s:e]).abs().max()) for s, e in ranges)
+        frozen_lo = ranges[0][1]
+        frozen_equal_local = bool(torch.equal(got_flat[frozen_lo:ranges[1][0]], (g0 if rank == 0 else g1)[frozen_lo:ranges[1][0]]))
+        ok_w = bool(torch.allclose(got_w, want_w, rtol=1e-5, atol=1e-8))
+        opt.step()
+        torch.cuda.synchronize()
+        moved = float((bb.flat_params - p_start).abs().max())
+        digest = bb.flat_params.double().sum().item(), model.cell_layer.weight.double().sum().item()
+        params = bb.flat_params.detach().cpu().numpy().copy()
+        out.put((rank, ok_ranges, worst, frozen_equal_local, ok_w, launched, moved, digest, params))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_on_the_gpu():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, ok0, worst0, fr0, w0, l0, moved0, d0, p0), (_, ok1, worst1, fr1, w1, l1, moved1, d1, p1) = res
+    print(f"\n[2-rank DP on cuda:0 over gloo] worst |reduced - (g0 + g1)| {max(worst0, worst1):.2e}; buckets launched from inside the backward: {l0}, {l1}")
+    assert ok0 and ok1 and w0 and w1
+    assert fr0 and fr1                                      # frozen stages' gradient floats were not exchanged
+    assert l0 >= 1 and l1 >= 1                              # the stage-3 bucket (and the head's) left before the backward pass returned
+    assert moved0 > 0 and np.array_equal(p0, p1) and d0 == d1          # one optimizer step on the averaged gradient: the replicas stay bit-identical
