@@ -17,6 +17,9 @@
 // Epilogues: the Linear family of the model (bias, GELU with a saved pre-activation, rowscale + residual, x GELU'), results as f32 and / or as planes for the
 // next split GEMM.  The fp32_split mode of csrc/tinyvit.hip runs on the forms further down (gemm_nt_split3a / b_kernel: A as f32, split in the loader); this
 // plane-fed form is what they are checked against bit for bit (tests/test_gpu_kernels.py) and what tools/bench_split3.py times next to the f32-MFMA GEMM.
+// What the A-as-f32 forms add (round 6): compile-time epilogue classes (split3_epilogue_rows_ec), non-temporal result stores, an optional act(BatchNorm(A)) prologue in
+// the loader (gg_gemm_nt_split3_af32_pro), the conflict-free chunk permutation s3_swz, a 32 x 32 x 16 MFMA variant kept as a measured alternative (gemm_nt_split3w_kernel);
+// what bounds them -- the chip's power limit on random data, not a pipe -- is in DESIGN.md 5.
 #include "common.h"
 #include <type_traits>
 #include <algorithm>
@@ -1390,6 +1393,8 @@ static int split3_af32_launch(const GgSplit3Args* a, const float* A, int64_t lda
     GG_CHECK(!a->rowscale || a->rows_per_scale > 0, "gg_gemm_nt_split3_af32: rowscale needs rows_per_scale");
     GG_CHECK(!(a->dact_preact && a->act), "gg_gemm_nt_split3_af32: act and dact_preact are exclusive");
     GG_CHECK(!colstats || !(a->bias || a->act || a->rowscale || a->residual || a->dact_preact || a->preact || a->c_planes), "gg_gemm_nt_split3_af32: colstats needs the plain epilogue");
+    GG_CHECK(((uintptr_t)a->preact & 15) == 0 && ((uintptr_t)a->residual & 15) == 0 && ((uintptr_t)a->dact_preact & 15) == 0,
+             "gg_gemm_nt_split3_af32: preact, residual and dact_preact must be 16-byte aligned (the row epilogue moves them 16 bytes at a time)");
     Split3Params p;
     static const char* senv = gg_dev_env("GG_SPLIT3_SWZ");      // dev A/B: 0 = the plain-XOR chunk swizzle of round 5
     p.swz_plain = senv && atoi(senv) == 0;
