@@ -78,7 +78,9 @@ def _worker(rank, world, port, out):
 
 
 def test_two_rank_data_parallel_step_on_the_gpu():
+    import gc
     import torch.multiprocessing as mp
+    gc.collect(); torch.cuda.empty_cache()                  # the two child processes share this card with whatever this process still caches
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
