@@ -87,10 +87,15 @@ def test_two_rank_data_parallel_step_on_the_gpu():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                                     # a rank that died before reporting must not leave its peer waiting on the card
+            if p.is_alive():
+                p.kill()
     (_, ok0, worst0, fr0, w0, l0, moved0, d0, p0), (_, ok1, worst1, fr1, w1, l1, moved1, d1, p1) = res
     print(f"\n[2-rank DP on cuda:0 over gloo] worst |reduced - (g0 + g1)| {max(worst0, worst1):.2e}; buckets launched from inside the backward: {l0}, {l1}")
     assert ok0 and ok1 and w0 and w1
