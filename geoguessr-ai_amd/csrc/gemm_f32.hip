@@ -42,6 +42,7 @@ struct F32GemmParams {
     const float* A2; const float* a_stat; const float* a_gamma; const float* a_beta; int a_act;
     unsigned long long* trace;      // dev (gg_gemm_f32_set_trace): per-workgroup [hw_id, xcc_id, t_start, t_first_data, t_loop_end, t_epilogue_end, tile, 0] (100 MHz ticks)
     int quick;          // FE_GELU / FE_DGELU: the activation is QuickGELU (CLIP) instead of erf GELU
+    int swz_plain = 0;  // dev A/B (GG_GEMM_F32_SWZ=0): the ring kernel's tile rows unpermuted (rounds 2-5: 2-way bank conflicts on the fragment reads)
     int splits = 1, k_per_split = 0;      // small-M form: workgroup (split s, tile t) contracts k in [s k_per_split, (s + 1) k_per_split) into slab s of C ([splits][M][ldc])
 };
 
@@ -693,7 +694,10 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
     }
     if (PRO) __syncthreads();
     // DMA geometry: block blk = wave + 4 j covers tile rows 16 blk .. 16 blk + 15 (A rows first, then B rows, then A2 rows) x 16 k: lane -> (row lane/4, 16-byte chunk lane%4)
-    const int drow = lane >> 2, dch = lane & 3;
+    // 64-byte tile rows (16 floats): the LDS side of a DMA is lane-linear, so the bank permutation is applied on the SOURCE side -- LDS slot (lane & 3) of row lane / 4
+    // receives global chunk slot ^ perm(row quad) -- and undone in the fragment reads below.  perm = {0, 2, 3, 1} is what ds_read_b128's 16-lane service groups
+    // ({0-3, 12-15, 20-27}, ...) need for 16 rows x one k-chunk; read straight (as rounds 2-5 did) every fragment read was a 2-way bank conflict
+    const int drow = lane >> 2, dch = (lane & 3) ^ (p.swz_plain ? 0 : ((0x78 >> (2 * (lane >> 4))) & 3));
     unsigned voff[IPW];
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
@@ -717,7 +721,8 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_ring_kernel(F32GemmParam
         }
     };
     auto issue_stage = [&](int st) { issue_stage_at(st, smem + (st % NST) * STAGE); };
-    const int a_off = (wm * (BM / WM) + lr) * SK + lg * 4, b_off = BM * SK + (wn * WCOLS + lr) * SK + lg * 4;
+    const int fch = lg ^ (p.swz_plain ? 0 : ((0x78 >> (2 * ((lr >> 2) & 3))) & 3));      // position of this lane's k-chunk lg in its row
+    const int a_off = (wm * (BM / WM) + lr) * SK + fch * 4, b_off = BM * SK + (wn * WCOLS + lr) * SK + fch * 4;
     auto frag_read_at = [&](const float* base, f32x4 (&xf)[TM], f32x4 (&wf)[TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const f32x4*>(base + a_off + i * 16 * SK);
@@ -1135,6 +1140,8 @@ extern "C" int gg_gemm_nt_f32(const GgGemmArgs* a, void* stream) {
     p.rowscale = a->rowscale; p.rows_per_scale = a->rows_per_scale; p.residual = (const float*)a->residual; p.ldr = a->ldr;
     p.dact_preact = (const float*)a->dact_preact; p.colstats = a->colstats;
     p.quick = (a->dact_preact ? a->dact : a->act) == GG_ACT_QUICK_GELU;
+    static const char* swz_env = gg_dev_env("GG_GEMM_F32_SWZ");
+    p.swz_plain = swz_env && atoi(swz_env) == 0;
     p.bn_y = (const float*)a->bn_y; p.bn_stat = a->bn_stat; p.bn_gamma = a->bn_gamma; p.bn_beta = a->bn_beta; p.bn_act = a->bn_act;
     p.A2 = (const float*)a->A2; p.a_stat = a->a_bn_stat; p.a_gamma = a->a_bn_gamma; p.a_beta = a->a_bn_beta; p.a_act = a->a_bn_act;
     const int rem = a->N % 128;
